@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference (oracle/_ref, built by oracle/build_ref.sh from
+/root/reference) at num_thr=1 -- the only setting at which the reference is deterministic
+(reorder.cpp:545-552 races otherwise).  Runs only in the build container; the GPU box sees only the
+committed fixtures tests/golden/<case>.tar.xz, each holding
+
+    reads.txt              the FASTQ sequence lines fed to preprocess.out (inputs)
+    stage1/<file>          output/ after reorder.out   (reorder.cpp:722-830 file family)
+    stage2/<file>          output/ after encoder.out   (encoder.cpp:457-505, packbits :512-616)
+    packed/<file>          read_order.bin(+.tail) after pack_order.out (pack_order.cpp:20-77)
+    decoded.txt            output.dna of the reference decoder.out run on stage2 (decoder.cpp:65-172)
+    meta.json              L, counts, stdout counters of the reference run
+
+This file is test infrastructure (oracle side); nothing in the product imports it.
+"""
+import json, os, shutil, subprocess, sys, tarfile, tempfile, io
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.path.join(HERE, "_ref")
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def revcomp(s):
+    return "".join(COMP[c] for c in reversed(s))
+
+
+def gen_reads(seed, n, L, genome_len, err=0.0, rc=True, repeat=0, dup=0, n_frac=0.25):
+    """i.i.d. genome (optionally with one `repeat`-bp segment copied elsewhere), uniform read starts,
+    per-base substitution probability `err` of which n_frac become 'N' (gen_fastq_noRC.cpp:67-71 spirit),
+    odd reads reverse-complemented, `dup` extra identical copies of read 0."""
+    rs = np.random.RandomState(seed)
+    g = rs.randint(0, 4, size=genome_len)
+    if repeat:
+        g[genome_len // 2: genome_len // 2 + repeat] = g[100:100 + repeat]
+    genome = "".join("ACGT"[x] for x in g)
+    reads = []
+    for i in range(n):
+        p = rs.randint(0, genome_len - L)
+        r = list(genome[p:p + L])
+        if err > 0:
+            for j in range(L):
+                if rs.random_sample() < err:
+                    if rs.random_sample() < n_frac:
+                        r[j] = "N"
+                    else:
+                        r[j] = "ACGT"[(("ACGT".index(r[j]) if r[j] != "N" else 0) + rs.randint(1, 4)) % 4]
+        r = "".join(r)
+        if rc and (i & 1):
+            r = revcomp(r)
+        reads.append(r)
+    for _ in range(dup):
+        reads.insert(rs.randint(0, len(reads)), reads[0])
+    return reads
+
+
+CASES = {
+    # name: dict(kwargs for gen_reads)
+    "L100_clean_5k": dict(seed=1, n=5000, L=100, genome_len=25000),
+    "L100_err_5k": dict(seed=2, n=5000, L=100, genome_len=25000, err=0.01),
+    "L100_lowcov_4k": dict(seed=3, n=4000, L=100, genome_len=130000, err=0.005),
+    "L150_err_3k": dict(seed=4, n=3000, L=150, genome_len=20000, err=0.01),
+    "L101_err_3k": dict(seed=5, n=3000, L=101, genome_len=15000, err=0.01),
+    "L63_err_3k": dict(seed=6, n=3000, L=63, genome_len=10000, err=0.01),
+    "L40_err_3k": dict(seed=7, n=3000, L=40, genome_len=6000, err=0.01),
+    "L255_err_1k": dict(seed=8, n=1000, L=255, genome_len=12000, err=0.01),
+    "L100_repeat_dup_4k": dict(seed=9, n=2500, L=100, genome_len=12000, err=0.005, repeat=2000, dup=1500),
+    "L100_one": dict(seed=10, n=1, L=100, genome_len=1000),
+    "L100_allN_20": dict(seed=11, n=20, L=100, genome_len=1000, err=0.2, n_frac=1.0),
+    "L100_three": dict(seed=12, n=3, L=100, genome_len=120),
+}
+
+
+def run(cmd, cwd):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode not in (0,):
+        raise RuntimeError(f"{cmd} failed rc={r.returncode}:\n{r.stdout}")
+    return r.stdout
+
+
+def snapshot(outdir):
+    d = {}
+    for f in sorted(os.listdir(outdir)):
+        p = os.path.join(outdir, f)
+        if os.path.isfile(p):
+            with open(p, "rb") as fh:
+                d[f] = fh.read()
+    return d
+
+
+def make_case(name, kw):
+    L = kw["L"]
+    subprocess.check_call([os.path.join(HERE, "build_ref.sh")])
+    subprocess.check_call([os.path.join(HERE, "build_ref.sh"), str(L), "1"])
+    reads = gen_reads(**kw)
+    wd = tempfile.mkdtemp(prefix="harc_gold_")
+    try:
+        os.makedirs(os.path.join(wd, "output"))
+        fq = os.path.join(wd, "in.fastq")
+        with open(fq, "w") as f:
+            for i, r in enumerate(reads):
+                f.write(f"@T.{i}\n{r}\n+\n{'H' * L}\n")
+        log = run([os.path.join(REF, "preprocess.out"), fq, wd, "False", "False", str(L)], wd)
+        log += run([os.path.join(REF, f"reorder_L{L}_t1.out"), wd], wd)   # cwd=wd: BBHash temp files land in CWD
+        stage1 = snapshot(os.path.join(wd, "output"))
+        log += run([os.path.join(REF, f"encoder_L{L}_t1.out"), wd], wd)
+        stage2 = snapshot(os.path.join(wd, "output"))
+        # -p path: pack_order on a copy of read_order.bin (harc:112)
+        pd = tempfile.mkdtemp(prefix="harc_gold_p_")
+        os.makedirs(os.path.join(pd, "output"))
+        shutil.copy(os.path.join(wd, "output", "read_order.bin"), os.path.join(pd, "output", "read_order.bin"))
+        packed = {}
+        if len(stage2["read_order.bin"]) > 0:      # pack_order.cpp:36 log2(0) is UB on empty input
+            run([os.path.join(REF, "pack_order.out"), pd], pd)
+            packed = snapshot(os.path.join(pd, "output"))
+        shutil.rmtree(pd)
+        # decode with the reference decoder (harc:188): decoder.out <dir> <num_thr> <num_thr_e>
+        log += run([os.path.join(REF, "decoder.out"), wd, "1", "1"], wd)
+        with open(os.path.join(wd, "output", "output.dna"), "rb") as fh:
+            decoded = fh.read()
+        assert sorted(decoded.decode().split()) == sorted(reads), "reference round trip failed?!"
+        meta = dict(name=name, L=L, n_reads=len(reads), gen=kw, log=log.splitlines())
+        os.makedirs(GOLD, exist_ok=True)
+        tarpath = os.path.join(GOLD, name + ".tar.xz")
+        with tarfile.open(tarpath, "w:xz", preset=9) as tf:
+            def add(arc, data):
+                ti = tarfile.TarInfo(arc)
+                ti.size = len(data)
+                ti.mtime = 0
+                tf.addfile(ti, io.BytesIO(data))
+            add("reads.txt", ("\n".join(reads) + "\n").encode())
+            for k, v in stage1.items():
+                add("stage1/" + k, v)
+            for k, v in stage2.items():
+                add("stage2/" + k, v)
+            for k, v in packed.items():
+                add("packed/" + k, v)
+            add("decoded.txt", decoded)
+            add("meta.json", json.dumps(meta, indent=1).encode())
+        print(name, os.path.getsize(tarpath), "bytes;", [l for l in meta["log"] if "unmatched" in l or "aligned" in l])
+    finally:
+        shutil.rmtree(wd)
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        make_case(n, CASES[n])
