@@ -1,0 +1,68 @@
+"""P0 of the parity ladder: the CPU oracle at K=1, E=1 is byte-identical to the REAL reference
+(golden vectors made by oracle/make_goldens.py from /root/reference at num_thr=1)."""
+import ctypes as C
+import os
+
+import pytest
+
+from tests import oracle_lib as ol
+
+CASES = ol.golden_cases()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_preprocess_matches_reference(case, oracle, tmp_path):
+    g = ol.load_golden(case)
+    L = len(g["reads.txt"].split(b"\n")[0])
+    base = ol.stage_dir(tmp_path, {})
+    assert oracle.harc_oracle_preprocess(g["reads.txt"], len(g["reads.txt"]), L, base.encode()) == 0
+    got = ol.read_dir(base)
+    for f in ["input_clean.dna", "input_N.dna", "numreads.bin", "read_order_N.bin"]:
+        assert got[f] == g["stage1/" + f], f
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_stage1_K1_bit_exact(case, oracle, tmp_path):
+    g = ol.load_golden(case)
+    L = len(g["reads.txt"].split(b"\n")[0])
+    base = ol.stage_dir(tmp_path, {k: g["stage1/" + k] for k in ["input_clean.dna", "numreads.bin"]})
+    unmatched = C.c_uint32(0)
+    assert oracle.harc_oracle_reorder(base.encode(), L, 1, C.byref(unmatched), None) == 0
+    got = ol.read_dir(base)
+    for f in ol.STAGE1_FILES:
+        assert got[f] == g["stage1/" + f], f"{case}: {f} differs from reference"
+    import json
+    log = json.loads(g["meta.json"])["log"]
+    ref_unmatched = [int(l.split()[2]) for l in log if l.startswith("Reordering done")][0]
+    assert unmatched.value == ref_unmatched
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_stage2_E1_bit_exact(case, oracle, tmp_path):
+    g = ol.load_golden(case)
+    L = len(g["reads.txt"].split(b"\n")[0])
+    base = ol.stage_dir(tmp_path, {k[len("stage1/"):]: v for k, v in g.items() if k.startswith("stage1/")})
+    ms, mn = C.c_uint32(0), C.c_uint32(0)
+    assert oracle.harc_oracle_encoder(base.encode(), L, 1, C.byref(ms), C.byref(mn)) == 0
+    got = ol.read_dir(base)
+    for f in ol.stage2_files(1):
+        assert got[f] == g["stage2/" + f], f"{case}: {f} differs from reference"
+    import json
+    log = json.loads(g["meta.json"])["log"]
+    assert ms.value == [int(l.split()[0]) for l in log if "singleton reads were aligned" in l][0]
+    assert mn.value == [int(l.split()[0]) for l in log if "reads with N were aligned" in l][0]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_pack_order_and_decoder(case, oracle, tmp_path):
+    g = ol.load_golden(case)
+    base = ol.stage_dir(tmp_path, {k[len("stage2/"):]: v for k, v in g.items() if k.startswith("stage2/")})
+    assert oracle.harc_oracle_decoder(base.encode(), 1) == 0
+    assert ol.read_dir(base)["output.dna"] == g["decoded.txt"]
+    if "packed/read_order.bin" in g:
+        assert oracle.harc_oracle_pack_order(base.encode()) == 0
+        got = ol.read_dir(base)
+        assert got["read_order.bin"] == g["packed/read_order.bin"]
+        assert got["read_order.bin.tail"] == g["packed/read_order.bin.tail"]
+    else:
+        assert oracle.harc_oracle_pack_order(base.encode()) == -3
