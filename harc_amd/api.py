@@ -1,0 +1,174 @@
+"""ctypes binding of include/harc_amd.h."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class HarcAmdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"harc_amd error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """harc_amd_params == src/config.h macros (harc:52-63)"""
+    _fields_ = [("readlen", C.c_int32), ("num_thr", C.c_int32), ("num_chains", C.c_int32), ("maxmatch", C.c_int32),
+                ("thresh", C.c_int32), ("thresh_s", C.c_int32), ("maxsearch", C.c_int32), ("dict_start", C.c_int32 * 2),
+                ("dict_end", C.c_int32 * 2), ("device", C.c_int32), ("profile", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_clean", C.c_uint64), ("n_N", C.c_uint64), ("n_main", C.c_uint64), ("n_singleton", C.c_uint64),
+                ("unmatched", C.c_uint64), ("aligned_singletons", C.c_uint64), ("aligned_N", C.c_uint64),
+                ("chains", C.c_uint64), ("rounds", C.c_uint64), ("probes", C.c_uint64), ("candidates", C.c_uint64),
+                ("conflicts", C.c_uint64), ("propose_launches", C.c_uint64), ("propose_ms", C.c_double),
+                ("index_ms", C.c_double), ("chain_ms", C.c_double), ("encode_ms", C.c_double), ("total_ms", C.c_double),
+                ("contigs", C.c_uint64), ("seq_bases", C.c_uint64), ("bins_over_maxsearch", C.c_uint64),
+                ("device_bytes_peak", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+STREAMS = dict(S1_ORDER=0, S1_FLAG=1, S1_POS=2, S1_RC=3, S1_ORDER_SINGLETON=4, S1_DNA=5, S1_DNA_SINGLETON=6,
+               S2_SEQ=10, S2_SEQ_TAIL=11, S2_POS=12, S2_NOISE=13, S2_NOISEPOS=14, S2_REV=15, S2_REV_TAIL=16,
+               S2_ORDER=20, S2_ORDER_N_PE=21, S2_SINGLETON=22, S2_SINGLETON_TAIL=23, S2_INPUT_N=24, S2_META=25,
+               P_ORDER=30, P_ORDER_TAIL=31)
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(HERE, "libharc_amd.so")
+
+
+def lib():
+    """Load libharc_amd.so; fails loudly when the HIP extension has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise HarcAmdError(-2, f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C harc_amd/csrc`; harc_amd has no CPU path")
+    l = C.CDLL(p)
+    PP = C.POINTER(Params)
+    ctx = C.c_void_p
+    l.harc_amd_default_params.argtypes = [C.c_int32, PP]
+    l.harc_amd_create.argtypes = [PP, C.POINTER(ctx)]
+    l.harc_amd_destroy.argtypes = [ctx]
+    l.harc_amd_destroy.restype = None
+    l.harc_amd_last_error.restype = C.c_char_p
+    l.harc_amd_set_reads_ascii.argtypes = [ctx, C.c_char_p, C.c_uint32, C.c_uint32]
+    l.harc_amd_set_reads_ascii_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32]
+    l.harc_amd_set_reads_packed_device.argtypes = [ctx, C.c_void_p, C.c_uint32]
+    l.harc_amd_set_nreads_ascii.argtypes = [ctx, C.c_char_p, C.c_uint32, C.c_uint32]
+    l.harc_amd_set_nreads_ascii_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32]
+    l.harc_amd_set_stage1_streams.argtypes = [ctx, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32,
+                                              C.c_char_p, C.c_char_p, C.c_uint32]
+    for f in ("harc_amd_reorder", "harc_amd_encode", "harc_amd_pack_order"):
+        getattr(l, f).argtypes = [ctx]
+    l.harc_amd_get_stream.argtypes = [ctx, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    l.harc_amd_get_counters.argtypes = [ctx, C.POINTER(Counters)]
+    for f in ("harc_amd_reorder_files", "harc_amd_encoder_files", "harc_amd_compress_files", "harc_amd_pack_order_files"):
+        getattr(l, f).argtypes = [PP, C.c_char_p]
+    _lib = l
+    return l
+
+
+def _check(rc):
+    if rc != 0:
+        raise HarcAmdError(rc, lib().harc_amd_last_error().decode(errors="replace"))
+
+
+def default_params(readlen, num_thr=8, num_chains=0, device=0, profile=0):
+    p = Params()
+    _check(lib().harc_amd_default_params(readlen, C.byref(p)))
+    p.num_thr, p.num_chains, p.device, p.profile = num_thr, num_chains, device, profile
+    return p
+
+
+# ---- the reference's stage programs (file contract)
+def reorder(basedir, readlen, num_chains=1, **kw):
+    """== `reorder.out <basedir>` (src/reorder.cpp:100-131)"""
+    p = default_params(readlen, num_chains=num_chains, **kw)
+    _check(lib().harc_amd_reorder_files(C.byref(p), os.fsencode(basedir)))
+
+
+def encoder(basedir, readlen, num_thr=1, **kw):
+    """== `encoder.out <basedir>` (src/encoder.cpp:108-152)"""
+    p = default_params(readlen, num_thr=num_thr, **kw)
+    _check(lib().harc_amd_encoder_files(C.byref(p), os.fsencode(basedir)))
+
+
+def compress(basedir, readlen, num_thr=1, num_chains=1, **kw):
+    """harc:65-69 fused: stage I -> stage II in HBM"""
+    p = default_params(readlen, num_thr=num_thr, num_chains=num_chains, **kw)
+    _check(lib().harc_amd_compress_files(C.byref(p), os.fsencode(basedir)))
+
+
+def pack_order(basedir, readlen=100, **kw):
+    """== `pack_order.out <basedir>` (src/pack_order.cpp:11-77)"""
+    p = default_params(readlen, **kw)
+    _check(lib().harc_amd_pack_order_files(C.byref(p), os.fsencode(basedir)))
+
+
+class HarcAmd:
+    """In-memory API: one context = one HIP device + stream."""
+
+    def __init__(self, params):
+        self.params = params
+        self._ctx = C.c_void_p()
+        _check(lib().harc_amd_create(C.byref(params), C.byref(self._ctx)))
+
+    def close(self):
+        if self._ctx:
+            lib().harc_amd_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_reads_ascii(self, buf, n, stride):
+        _check(lib().harc_amd_set_reads_ascii(self._ctx, buf, n, stride))
+
+    def set_reads_ascii_device(self, dptr, n, stride):
+        _check(lib().harc_amd_set_reads_ascii_device(self._ctx, C.c_void_p(dptr), n, stride))
+
+    def set_reads_packed_device(self, dptr, n):
+        _check(lib().harc_amd_set_reads_packed_device(self._ctx, C.c_void_p(dptr), n))
+
+    def set_nreads_ascii(self, buf, n, stride):
+        _check(lib().harc_amd_set_nreads_ascii(self._ctx, buf, n, stride))
+
+    def set_nreads_ascii_device(self, dptr, n, stride):
+        _check(lib().harc_amd_set_nreads_ascii_device(self._ctx, C.c_void_p(dptr), n, stride))
+
+    def reorder(self):
+        _check(lib().harc_amd_reorder(self._ctx))
+
+    def encode(self):
+        _check(lib().harc_amd_encode(self._ctx))
+
+    def pack_order(self):
+        _check(lib().harc_amd_pack_order(self._ctx))
+
+    def stream(self, name, shard=0):
+        ptr, ln = C.c_void_p(), C.c_size_t()
+        _check(lib().harc_amd_get_stream(self._ctx, STREAMS[name], shard, C.byref(ptr), C.byref(ln)))
+        return C.string_at(ptr, ln.value) if ln.value else b""
+
+    def counters(self):
+        c = Counters()
+        _check(lib().harc_amd_get_counters(self._ctx, C.byref(c)))
+        return c

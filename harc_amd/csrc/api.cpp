@@ -1,0 +1,294 @@
+// api.cpp -- the C-ABI of include/harc_amd.h: context, inputs, outputs.  Compiled with hipcc (host code only).
+#include "internal.h"
+#include <stdarg.h>
+#include <chrono>
+
+static thread_local char g_err[512] = "";
+void harc_set_error(const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+}
+extern "C" const char *harc_amd_last_error(void) { return g_err; }
+
+int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes)
+{
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { harc_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return HARC_AMD_ENOMEM; }
+    c->owned.push_back(*p);
+    c->sizes[*p] = bytes;
+    c->dev_bytes += bytes;
+    if (c->dev_bytes > c->dev_peak) c->dev_peak = c->dev_bytes;
+    return HARC_AMD_OK;
+}
+void harc_dev_free(harc_amd_ctx *c, void *p)
+{
+    if (!p) return;
+    for (size_t i = 0; i < c->owned.size(); i++)
+        if (c->owned[i] == p) { c->owned[i] = c->owned.back(); c->owned.pop_back(); break; }
+    auto it = c->sizes.find(p);
+    if (it != c->sizes.end()) { c->dev_bytes -= it->second; c->sizes.erase(it); }
+    (void)hipFree(p);
+}
+int harc_d2h(harc_amd_ctx *c, std::vector<uint8_t> &dst, const void *d_src, size_t bytes)
+{
+    dst.resize(bytes);
+    if (bytes) HIP_TRY(hipMemcpyAsync(dst.data(), d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_default_params(int32_t L, harc_amd_params *p)
+{
+    if (!p || L < 1 || L > 255) { harc_set_error("readlen %d out of range 1..255 (harc:46-49; 256 breaks the pos byte, decoder.cpp:93)", L); return HARC_AMD_EINVAL; }
+    memset(p, 0, sizeof *p);
+    p->readlen = L; p->num_thr = 8; p->num_chains = 0;
+    p->maxmatch = L / 2; p->thresh = 4; p->thresh_s = 24; p->maxsearch = 1000;          // harc:52-56
+    const int h = L / 2;
+    if (L > 100) { p->dict_start[0] = h - 32; p->dict_end[0] = h - 1; p->dict_start[1] = h; p->dict_end[1] = h - 1 + 32; }   // harc:57-60
+    else { p->dict_start[0] = h - L * 32 / 100; p->dict_end[0] = h - 1; p->dict_start[1] = h; p->dict_end[1] = h - 1 + L * 32 / 100; }
+    return HARC_AMD_OK;
+}
+
+static int check_params(const harc_amd_params *p)
+{
+    if (!p) return HARC_AMD_EINVAL;
+    const int L = p->readlen;
+    if (L < 1 || L > 255) { harc_set_error("readlen %d out of range 1..255", L); return HARC_AMD_EINVAL; }
+    if (p->num_thr < 1 || p->num_thr > 4096) { harc_set_error("num_thr %d out of range", p->num_thr); return HARC_AMD_EINVAL; }
+    if (p->num_chains < 0) { harc_set_error("num_chains < 0"); return HARC_AMD_EINVAL; }
+    if (p->maxmatch < 0 || p->maxmatch > 128 || p->maxmatch > L) { harc_set_error("maxmatch out of range"); return HARC_AMD_EINVAL; }
+    if (p->maxsearch < 1 || p->thresh < 0 || p->thresh_s < 0) { harc_set_error("thresholds out of range"); return HARC_AMD_EINVAL; }
+    for (int l = 0; l < 2; l++) {
+        const int n = p->dict_end[l] - p->dict_start[l] + 1;
+        if (p->dict_start[l] < 0 || p->dict_end[l] >= L || n < 0 || n > 32) { harc_set_error("dictionary window %d out of range", l); return HARC_AMD_EINVAL; }
+    }
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_create(const harc_amd_params *params, harc_amd_ctx **out)
+{
+    if (!out) return HARC_AMD_EINVAL;
+    *out = nullptr;
+    RC_TRY(check_params(params));
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { harc_set_error("no HIP device (%s); libharc_amd has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e)); return HARC_AMD_ENODEVICE; }
+    if (params->device < 0 || params->device >= ndev) { harc_set_error("device %d not in [0,%d)", params->device, ndev); return HARC_AMD_EINVAL; }
+    HIP_TRY(hipSetDevice(params->device));
+    harc_amd_ctx *c = new harc_amd_ctx();
+    c->P = *params;
+    c->W = (2 * params->readlen + 63) / 64;
+    c->W3 = (3 * params->readlen + 63) / 64;
+    memset(&c->C, 0, sizeof c->C);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; harc_set_error("hipStreamCreate failed"); return HARC_AMD_ENODEVICE; }
+    *out = c;
+    return HARC_AMD_OK;
+}
+
+extern "C" void harc_amd_destroy(harc_amd_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->P.device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    for (void *p : c->owned) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static void drop_results(harc_amd_ctx *c)
+{
+    void *ps[] = { c->d_order, c->d_flag, c->d_pos, c->d_rc, c->d_order_s, c->d_oreads, c->d_sreads };
+    for (void *p : ps) if (p) harc_dev_free(c, p);
+    c->d_order = nullptr; c->d_flag = c->d_pos = c->d_rc = nullptr; c->d_order_s = nullptr; c->d_oreads = nullptr; c->d_sreads = nullptr;
+    c->have_s1 = c->have_s2 = c->s1_from_files = false; c->M = c->S = 0;
+    c->out.clear();
+}
+
+static int upload(harc_amd_ctx *c, const void *host, size_t bytes, char **d)
+{
+    RC_TRY(harc_dev_alloc(c, (void **)d, bytes + 16));
+    if (bytes) HIP_TRY(hipMemcpyAsync(*d, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_set_reads_ascii_device(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride)
+{
+    if (!c || (n && !d_ascii) || stride < (uint32_t)c->P.readlen) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    drop_results(c);
+    if (c->d_reads) { harc_dev_free(c, c->d_reads); c->d_reads = nullptr; }
+    c->N = n;
+    RC_TRY(dalloc(c, &c->d_reads, (size_t)n * c->W + 1));
+    RC_TRY(s1_pack_ascii(c, d_ascii, n, stride, c->d_reads));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->C.n_clean = n;
+    return HARC_AMD_OK;
+}
+extern "C" int harc_amd_set_reads_ascii(harc_amd_ctx *c, const char *ascii, uint32_t n, uint32_t stride)
+{
+    if (!c || (n && !ascii) || stride < (uint32_t)c->P.readlen) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    char *d = nullptr;
+    const size_t bytes = n ? (size_t)(n - 1) * stride + c->P.readlen : 0;
+    RC_TRY(upload(c, ascii, bytes, &d));
+    int r = harc_amd_set_reads_ascii_device(c, d, n, stride);
+    harc_dev_free(c, d);
+    return r;
+}
+extern "C" int harc_amd_set_reads_packed_device(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n)
+{
+    if (!c || (n && !d_packed)) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    drop_results(c);
+    if (c->d_reads) { harc_dev_free(c, c->d_reads); c->d_reads = nullptr; }
+    c->N = n;
+    RC_TRY(dalloc(c, &c->d_reads, (size_t)n * c->W + 1));
+    if (n) HIP_TRY(hipMemcpyAsync(c->d_reads, d_packed, (size_t)n * c->W * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->C.n_clean = n;
+    return HARC_AMD_OK;
+}
+extern "C" int harc_amd_set_nreads_ascii_device(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride)
+{
+    if (!c || (n && !d_ascii) || stride < (uint32_t)c->P.readlen) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    if (c->d_nreads3) { harc_dev_free(c, c->d_nreads3); c->d_nreads3 = nullptr; }
+    c->NN = n; c->have_s2 = false;
+    RC_TRY(dalloc(c, &c->d_nreads3, (size_t)n * c->W3 + 1));
+    RC_TRY(s1_pack3_ascii(c, d_ascii, n, stride, c->d_nreads3));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->C.n_N = n;
+    return HARC_AMD_OK;
+}
+extern "C" int harc_amd_set_nreads_ascii(harc_amd_ctx *c, const char *ascii, uint32_t n, uint32_t stride)
+{
+    if (!c || (n && !ascii) || stride < (uint32_t)c->P.readlen) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    char *d = nullptr;
+    const size_t bytes = n ? (size_t)(n - 1) * stride + c->P.readlen : 0;
+    RC_TRY(upload(c, ascii, bytes, &d));
+    int r = harc_amd_set_nreads_ascii_device(c, d, n, stride);
+    harc_dev_free(c, d);
+    return r;
+}
+
+extern "C" int harc_amd_set_stage1_streams(harc_amd_ctx *c, const char *temp_dna, const uint8_t *flag, const uint8_t *pos,
+                                           const uint32_t *order, const uint8_t *rc, uint32_t M,
+                                           const char *temp_dna_s, const uint32_t *order_s, uint32_t S)
+{
+    if (!c || (M && (!temp_dna || !flag || !pos || !order || !rc)) || (S && (!temp_dna_s || !order_s))) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    drop_results(c);
+    const int L = c->P.readlen;
+    c->M = M; c->S = S;
+    RC_TRY(dalloc(c, &c->d_order, (size_t)M + 1)); RC_TRY(dalloc(c, &c->d_flag, (size_t)M + 1)); RC_TRY(dalloc(c, &c->d_pos, (size_t)M + 1));
+    RC_TRY(dalloc(c, &c->d_rc, (size_t)M + 1)); RC_TRY(dalloc(c, &c->d_order_s, (size_t)S + 1));
+    RC_TRY(dalloc(c, &c->d_oreads, (size_t)M * c->W + 1)); RC_TRY(dalloc(c, &c->d_sreads, (size_t)S * c->W + 1));
+    if (M) {
+        HIP_TRY(hipMemcpyAsync(c->d_order, order, (size_t)M * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_flag, flag, M, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_pos, pos, M, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_rc, rc, M, hipMemcpyHostToDevice, c->stream));
+        char *d = nullptr; RC_TRY(upload(c, temp_dna, (size_t)(M - 1) * (L + 1) + L, &d));
+        RC_TRY(s1_pack_ascii(c, d, M, (uint32_t)L + 1, c->d_oreads));
+        HIP_TRY(hipStreamSynchronize(c->stream)); harc_dev_free(c, d);
+    }
+    if (S) {
+        HIP_TRY(hipMemcpyAsync(c->d_order_s, order_s, (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
+        char *d = nullptr; RC_TRY(upload(c, temp_dna_s, (size_t)(S - 1) * (L + 1) + L, &d));
+        RC_TRY(s1_pack_ascii(c, d, S, (uint32_t)L + 1, c->d_sreads));
+        HIP_TRY(hipStreamSynchronize(c->stream)); harc_dev_free(c, d);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_s1 = true; c->s1_from_files = true;
+    c->C.n_main = M; c->C.n_singleton = S;
+    return HARC_AMD_OK;
+}
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+extern "C" int harc_amd_reorder(harc_amd_ctx *c)
+{
+    if (!c) return HARC_AMD_EINVAL;
+    if (!c->d_reads) { harc_set_error("harc_amd_reorder: no reads set"); return HARC_AMD_ESTATE; }
+    HIP_TRY(hipSetDevice(c->P.device));
+    drop_results(c);
+    const double t0 = now_ms();
+    RC_TRY(stage1_run(c));
+    c->C.total_ms = now_ms() - t0;
+    c->C.device_bytes_peak = c->dev_peak;
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_encode(harc_amd_ctx *c)
+{
+    if (!c) return HARC_AMD_EINVAL;
+    if (!c->have_s1) { harc_set_error("harc_amd_encode: no stage-I result (call harc_amd_reorder or harc_amd_set_stage1_streams)"); return HARC_AMD_ESTATE; }
+    HIP_TRY(hipSetDevice(c->P.device));
+    const double t0 = now_ms();
+    if (!c->s1_from_files) RC_TRY(stage1_make_oriented(c));
+    RC_TRY(stage2_run(c));
+    c->C.encode_ms = now_ms() - t0;
+    c->C.total_ms += c->C.encode_ms;
+    c->C.device_bytes_peak = c->dev_peak;
+    c->have_s2 = true;
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_pack_order(harc_amd_ctx *c)
+{
+    if (!c) return HARC_AMD_EINVAL;
+    if (!c->have_s2) { harc_set_error("harc_amd_pack_order: encode first"); return HARC_AMD_ESTATE; }
+    HIP_TRY(hipSetDevice(c->P.device));
+    return pack_order_run(c);
+}
+
+extern "C" int harc_amd_get_stream(harc_amd_ctx *c, int32_t id, int32_t shard, const void **ptr, size_t *len)
+{
+    if (!c || !ptr || !len) return HARC_AMD_EINVAL;
+    *ptr = nullptr; *len = 0;
+    HIP_TRY(hipSetDevice(c->P.device));
+    auto key = std::make_pair((int)id, (int)shard);
+    auto it = c->out.find(key);
+    if (it == c->out.end()) {
+        if (id >= HARC_AMD_S1_ORDER && id <= HARC_AMD_S1_DNA_SINGLETON) {
+            if (!c->have_s1 || shard != 0) { harc_set_error("stream %d not available", id); return HARC_AMD_ESTATE; }
+            std::vector<uint8_t> &b = c->out[key];
+            const int L = c->P.readlen;
+            switch (id) {
+            case HARC_AMD_S1_ORDER: RC_TRY(harc_d2h(c, b, c->d_order, (size_t)c->M * 4)); break;
+            case HARC_AMD_S1_FLAG: RC_TRY(harc_d2h(c, b, c->d_flag, c->M)); break;
+            case HARC_AMD_S1_POS: RC_TRY(harc_d2h(c, b, c->d_pos, c->M)); break;
+            case HARC_AMD_S1_RC: RC_TRY(harc_d2h(c, b, c->d_rc, c->M)); break;
+            case HARC_AMD_S1_ORDER_SINGLETON: RC_TRY(harc_d2h(c, b, c->d_order_s, (size_t)c->S * 4)); break;
+            case HARC_AMD_S1_DNA: {
+                if (!c->d_oreads) RC_TRY(stage1_make_oriented(c));
+                char *d = nullptr; RC_TRY(dalloc(c, &d, (size_t)c->M * (L + 1) + 1));
+                RC_TRY(s1_unpack_to_ascii(c, c->d_oreads, c->M, d));
+                RC_TRY(harc_d2h(c, b, d, (size_t)c->M * (L + 1)));
+                HIP_TRY(hipStreamSynchronize(c->stream)); harc_dev_free(c, d);
+                break; }
+            case HARC_AMD_S1_DNA_SINGLETON: {
+                uint64_t *sr = c->d_sreads; bool tmp = false;
+                if (!sr) { RC_TRY(dalloc(c, &sr, (size_t)c->S * c->W + 1)); tmp = true; RC_TRY(s1_orient(c, c->d_reads, c->d_order_s, nullptr, c->S, sr)); }
+                char *d = nullptr; RC_TRY(dalloc(c, &d, (size_t)c->S * (L + 1) + 1));
+                RC_TRY(s1_unpack_to_ascii(c, sr, c->S, d));
+                RC_TRY(harc_d2h(c, b, d, (size_t)c->S * (L + 1)));
+                HIP_TRY(hipStreamSynchronize(c->stream)); harc_dev_free(c, d); if (tmp) harc_dev_free(c, sr);
+                break; }
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            it = c->out.find(key);
+        } else { harc_set_error("stream %d shard %d not available", id, shard); return HARC_AMD_ESTATE; }
+    }
+    *ptr = it->second.data(); *len = it->second.size();
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_get_counters(harc_amd_ctx *c, harc_amd_counters *out)
+{
+    if (!c || !out) return HARC_AMD_EINVAL;
+    *out = c->C;
+    return HARC_AMD_OK;
+}

@@ -1,0 +1,132 @@
+// devutil.h -- device-side helpers shared by stage1.hip and stage2.hip (wave = 64 lanes on gfx950)
+#pragma once
+#include "internal.h"
+
+// ------------------------------------------------------------------------------------------------ device helpers
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+
+// a[idx] for a small register array and a lane-varying idx; out-of-range -> 0
+template <int W> __device__ __forceinline__ uint64_t sel0(const uint64_t (&a)[W], int idx)
+{
+    uint64_t r = 0;
+#pragma unroll
+    for (int k = 0; k < W; k++) r = (idx == k) ? a[k] : r;
+    return r;
+}
+
+// nbits (<=64) starting at bit `off` of the W-word little-endian number a
+template <int W> __device__ __forceinline__ uint64_t extract_bits(const uint64_t (&a)[W], int off, int nbits)
+{
+    const int wi = off >> 6, sh = off & 63;
+    uint64_t lo = sel0<W>(a, wi), hi = sel0<W>(a, wi + 1);
+    uint64_t v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    if (nbits < 64) v &= ((uint64_t)1 << nbits) - 1;
+    return v;
+}
+
+template <int W> __device__ __forceinline__ void shr_words(const uint64_t (&a)[W], int s, uint64_t (&o)[W])
+{
+    const int ws = s >> 6, bs = s & 63;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        uint64_t lo = sel0<W>(a, w + ws), hi = sel0<W>(a, w + ws + 1);
+        o[w] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+    }
+}
+template <int W> __device__ __forceinline__ void shl_words(const uint64_t (&a)[W], int s, uint64_t (&o)[W])
+{
+    const int ws = s >> 6, bs = s & 63;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        uint64_t hi = sel0<W>(a, w - ws), lo = sel0<W>(a, w - ws - 1);     // negative index -> 0
+        o[w] = bs ? ((hi << bs) | (lo >> (64 - bs))) : hi;
+    }
+}
+// word w of the mask with the low nb bits set
+__device__ __forceinline__ uint64_t lowmask_word(int nb, int w)
+{
+    const int r = nb - 64 * w;
+    return r >= 64 ? ~(uint64_t)0 : (r <= 0 ? 0 : (((uint64_t)1 << r) - 1));
+}
+// reverse the order of the 32 two-bit fields of x
+__device__ __forceinline__ uint64_t rev2(uint64_t x)
+{
+    x = __brevll(x);
+    return ((x & 0xAAAAAAAAAAAAAAAAULL) >> 1) | ((x & 0x5555555555555555ULL) << 1);
+}
+// reverse complement of a packed read of L bases (complement of the 2-bit code is bitwise NOT: A0<->T3, G1<->C2)
+template <int W> __device__ __forceinline__ void rc_words(const uint64_t (&a)[W], int L, uint64_t (&o)[W])
+{
+    uint64_t r[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) r[w] = rev2(a[W - 1 - w]);
+    const int s = 64 * W - 2 * L;                  // wave-uniform shift
+    const int ws = s >> 6, bs = s & 63;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        uint64_t lo = sel0<W>(r, w + ws), hi = sel0<W>(r, w + ws + 1);
+        uint64_t v = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+        o[w] = (~v) & lowmask_word(2 * L, w);
+    }
+}
+// spread the low 32 bits of a to the even bit positions
+__device__ __forceinline__ uint64_t spread32(uint64_t a)
+{
+    a &= 0xFFFFFFFFULL;
+    a = (a | (a << 16)) & 0x0000FFFF0000FFFFULL;
+    a = (a | (a << 8)) & 0x00FF00FF00FF00FFULL;
+    a = (a | (a << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    a = (a | (a << 2)) & 0x3333333333333333ULL;
+    a = (a | (a << 1)) & 0x5555555555555555ULL;
+    return a;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// exclusive prefix sum over the 64 lanes; *total = wave sum
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+// block-wide exclusive scan for blockDim.x = NT (multiple of 64, <= 1024). sm must hold NT/64+1 words.
+template <int NT> __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *sm, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t wtot;
+    uint32_t ex = wave_excl_scan_u32(v, &wtot);
+    __syncthreads();
+    if (lane == 0) sm[wv] = wtot;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; k++) { uint32_t x = sm[k]; if (k < wv) base += x; tot += x; }
+    *total = tot;
+    return base + ex;
+}
+
+
+// exact key -> (start,count) lookup in the open-addressing table built by harc_dict_build; count 0 = absent
+__device__ __forceinline__ bool dict_lookup(const HashSlot *tab, uint64_t cap, uint64_t key, uint32_t *start, uint32_t *count, uint32_t *nprobe)
+{
+    if (!cap) return false;
+    uint64_t sl = __umul64hi(mix64(key), cap);
+    for (;;) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(&tab[sl]);
+        (*nprobe)++;
+        if (raw.w == 0) return false;
+        if (((uint64_t)raw.x | ((uint64_t)raw.y << 32)) == key) { *start = raw.z; *count = raw.w; return true; }
+        if (++sl == cap) sl = 0;
+    }
+}

@@ -1,0 +1,127 @@
+// internal.h -- shared between the translation units of libharc_amd.so (not installed; the public ABI is include/harc_amd.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../../include/harc_amd.h"
+
+#define HARC_NONE 0xFFFFFFFFu
+#define HARC_MAXW 8      // ceil(2*255/64) words of a 2-bit read
+#define HARC_MAXW3 12    // ceil(3*255/64) words of a 3-bit read
+#define HARC_MAXK (1u << 20)
+
+void harc_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t _e = (expr);                                                                                \
+        if (_e != hipSuccess) {                                                                                \
+            harc_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));               \
+            return HARC_AMD_ENODEVICE;                                                                         \
+        }                                                                                                      \
+    } while (0)
+#define RC_TRY(expr)                 \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != HARC_AMD_OK) return _r; \
+    } while (0)
+
+// Stage-I chain header, one per chain (32 B; AoS: a chain's wave reads it with one 32-B access)
+struct ChainHdr {
+    uint32_t cur;       // read the chain currently sits on
+    uint32_t prev;      // pending seed (reorder.cpp `prev`)
+    uint32_t flags;     // bit0 active, bit1 prev_unmatched, bit2 count-buffer parity
+    uint32_t upd;       // consensus update owed to the next propose launch: kind<<16 | dir<<8 | shift ; kind 0 none, 1 match, 2 reset
+    uint32_t n_main;    // records emitted to the main stream so far
+    uint32_t n_sing;    // records emitted to the singleton stream so far
+    uint32_t nprobe;    // statistics
+    uint32_t ncand;
+};
+#define CH_ACTIVE 1u
+#define CH_PREVUNM 2u
+#define CH_PARITY 4u
+
+// One emitted record of stage I (16 B); scattered into stream order by k_s1_scatter
+struct LogRec {
+    uint32_t chain;
+    uint32_t seq;       // index inside the chain's stream (main or singleton)
+    uint32_t rid;
+    uint32_t meta;      // pos | flag<<8 | rc<<9 | type<<10 (type 1 = singleton stream)
+};
+
+struct HashSlot {       // 16 B, one global_load_dwordx4
+    uint64_t key;
+    uint32_t start;     // first index into ids[]
+    uint32_t count;     // 0 = empty slot
+};
+
+struct DictDev {
+    HashSlot *slots = nullptr;
+    uint64_t cap = 0;          // number of slots
+    uint32_t *ids = nullptr;   // read ids sorted by (key, id)
+    uint32_t *d_nbins = nullptr;
+    uint32_t nbins = 0;
+};
+
+struct harc_amd_ctx {
+    harc_amd_params P;
+    int W = 0, W3 = 0;
+    hipStream_t stream = nullptr;
+    size_t dev_bytes = 0, dev_peak = 0;
+    std::vector<void *> owned;             // every live device allocation (freed in destroy)
+    std::map<void *, size_t> sizes;
+
+    // inputs
+    uint32_t N = 0;  uint64_t *d_reads = nullptr;      // N x W, 2-bit
+    uint32_t NN = 0; uint64_t *d_nreads3 = nullptr;    // NN x W3, 3-bit (reads with N)
+    // stage-I result, device
+    bool have_s1 = false;
+    uint32_t M = 0, S = 0;
+    uint32_t *d_order = nullptr; uint8_t *d_flag = nullptr, *d_pos = nullptr, *d_rc = nullptr; uint32_t *d_order_s = nullptr;
+    // stage-II inputs, device
+    uint64_t *d_oreads = nullptr;          // M x W oriented reads (= temp.dna)
+    uint64_t *d_sreads = nullptr;          // S x W singleton reads (= temp.dna.singleton), only when set from files
+    bool s1_from_files = false;
+    bool have_s2 = false;
+
+    std::map<std::pair<int, int>, std::vector<uint8_t>> out;   // (stream id, shard) -> bytes
+    harc_amd_counters C;
+
+    // scratch for rocPRIM
+    void *d_tmp = nullptr; size_t tmp_bytes = 0;
+};
+
+// ---- device memory helpers (api.cpp)
+int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes);
+void harc_dev_free(harc_amd_ctx *c, void *p);
+template <class T> static inline int dalloc(harc_amd_ctx *c, T **p, size_t n) { return harc_dev_alloc(c, (void **)p, n * sizeof(T) + 16); }
+int harc_tmp_reserve(harc_amd_ctx *c, size_t bytes);
+
+// ---- primitives (prims.hip): thin wrappers over rocPRIM device-wide sort / scan
+int prim_sort_pairs_u64_u32(harc_amd_ctx *c, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit);
+int prim_excl_scan_u32(harc_amd_ctx *c, const uint32_t *in, uint32_t *out, size_t n);
+int prim_excl_scan_u32_to_u64(harc_amd_ctx *c, const uint32_t *in, uint64_t *out, size_t n);
+int prim_excl_scan_u8_to_u64(harc_amd_ctx *c, const uint8_t *in, uint64_t *out, size_t n);
+int prim_incl_scan_u64(harc_amd_ctx *c, const uint64_t *in, uint64_t *out, size_t n);
+int prim_incl_max_u32(harc_amd_ctx *c, const uint32_t *in, uint32_t *out, size_t n);
+
+// ---- stages
+int s1_pack_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride, uint64_t *d_out);               // 2-bit
+int s1_pack3_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride, uint64_t *d_out);              // 3-bit
+int s1_unpack_to_ascii(harc_amd_ctx *c, const uint64_t *d_reads, uint32_t n, char *d_out);                           // n x (L+1) text
+int stage1_run(harc_amd_ctx *c);
+int stage1_make_oriented(harc_amd_ctx *c);      // d_oreads from d_reads/d_order/d_rc
+int s1_orient(harc_amd_ctx *c, const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, uint64_t *out);
+// exact key->bin table over n keys (ids must hold 0..n-1 on entry); allocates d->slots / d->ids / d->d_nbins
+int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, uint32_t n, unsigned kbits);
+void harc_dict_free(harc_amd_ctx *c, DictDev *d);
+int stage2_run(harc_amd_ctx *c);
+int pack_order_run(harc_amd_ctx *c);
+
+static inline std::vector<uint8_t> &out_buf(harc_amd_ctx *c, int id, int shard) { return c->out[std::make_pair(id, shard)]; }
+int harc_d2h(harc_amd_ctx *c, std::vector<uint8_t> &dst, const void *d_src, size_t bytes);

@@ -1,0 +1,27 @@
+// main.cpp -- harc_amd_stage: command-line twin of the reference's stage executables.
+//   harc_amd_stage reorder  <basedir> <readlen> [num_thr] [num_chains]     == src/reorder.out  <basedir>   (harc:67)
+//   harc_amd_stage encoder  <basedir> <readlen> [num_thr] [num_chains]     == src/encoder.out  <basedir>   (harc:69)
+//   harc_amd_stage compress <basedir> <readlen> [num_thr] [num_chains]     == both, stage I -> II handed over in HBM
+//   harc_amd_stage pack_order <basedir> <readlen>                          == src/pack_order.out <basedir> (harc:112)
+// readlen / num_thr arrive as arguments instead of the compile-time macros of src/config.h (harc:52-63).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/harc_amd.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) { fprintf(stderr, "usage: %s reorder|encoder|compress|pack_order <basedir> <readlen> [num_thr] [num_chains]\n", argv[0]); return 2; }
+    harc_amd_params P;
+    if (harc_amd_default_params(atoi(argv[3]), &P) != 0) { fprintf(stderr, "%s\n", harc_amd_last_error()); return 1; }
+    if (argc > 4) P.num_thr = atoi(argv[4]);
+    if (argc > 5) P.num_chains = atoi(argv[5]);
+    int rc;
+    if (!strcmp(argv[1], "reorder")) rc = harc_amd_reorder_files(&P, argv[2]);
+    else if (!strcmp(argv[1], "encoder")) rc = harc_amd_encoder_files(&P, argv[2]);
+    else if (!strcmp(argv[1], "compress")) rc = harc_amd_compress_files(&P, argv[2]);
+    else if (!strcmp(argv[1], "pack_order")) rc = harc_amd_pack_order_files(&P, argv[2]);
+    else { fprintf(stderr, "unknown stage %s\n", argv[1]); return 2; }
+    if (rc != 0) { fprintf(stderr, "harc_amd_stage %s failed (%d): %s\n", argv[1], rc, harc_amd_last_error()); return 1; }   // non-zero aborts `set -e` (harc:2)
+    return 0;
+}

@@ -1,0 +1,72 @@
+// prims.hip -- device-wide sort / scan building blocks (rocPRIM).  Everything algorithm-specific is hand-written in
+// stage1.hip / stage2.hip; these are the "plain library" pieces (the role std::sort plays at reorder.cpp:305).
+#include "internal.h"
+#include <rocprim/rocprim.hpp>
+
+int harc_tmp_reserve(harc_amd_ctx *c, size_t bytes)
+{
+    if (bytes <= c->tmp_bytes) return HARC_AMD_OK;
+    if (c->d_tmp) harc_dev_free(c, c->d_tmp);
+    c->d_tmp = nullptr; c->tmp_bytes = 0;
+    size_t want = bytes + (bytes >> 3) + 4096;
+    RC_TRY(harc_dev_alloc(c, &c->d_tmp, want));
+    c->tmp_bytes = want;
+    return HARC_AMD_OK;
+}
+
+#define PRIM_CALL(call_with_tmp)                                \
+    do {                                                        \
+        size_t bytes = 0; void *tmp = nullptr;                  \
+        HIP_TRY(call_with_tmp);                                 \
+        RC_TRY(harc_tmp_reserve(c, bytes));                     \
+        tmp = c->d_tmp; bytes = c->tmp_bytes;                   \
+        HIP_TRY(call_with_tmp);                                 \
+    } while (0)
+
+int prim_sort_pairs_u64_u32(harc_amd_ctx *c, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit)
+{
+    if (n == 0) return HARC_AMD_OK;
+    if (end_bit > 64) end_bit = 64;
+    PRIM_CALL(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0u, end_bit, c->stream));
+    return HARC_AMD_OK;
+}
+
+int prim_excl_scan_u32(harc_amd_ctx *c, const uint32_t *in, uint32_t *out, size_t n)
+{
+    if (n == 0) return HARC_AMD_OK;
+    PRIM_CALL(rocprim::exclusive_scan(tmp, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), c->stream));
+    return HARC_AMD_OK;
+}
+
+struct u32_to_u64 { __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; } };
+struct u8_to_u64 { __host__ __device__ uint64_t operator()(uint8_t x) const { return (uint64_t)x; } };
+
+int prim_excl_scan_u32_to_u64(harc_amd_ctx *c, const uint32_t *in, uint64_t *out, size_t n)
+{
+    if (n == 0) return HARC_AMD_OK;
+    auto it = rocprim::make_transform_iterator(in, u32_to_u64());
+    PRIM_CALL(rocprim::exclusive_scan(tmp, bytes, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c->stream));
+    return HARC_AMD_OK;
+}
+
+int prim_excl_scan_u8_to_u64(harc_amd_ctx *c, const uint8_t *in, uint64_t *out, size_t n)
+{
+    if (n == 0) return HARC_AMD_OK;
+    auto it = rocprim::make_transform_iterator(in, u8_to_u64());
+    PRIM_CALL(rocprim::exclusive_scan(tmp, bytes, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c->stream));
+    return HARC_AMD_OK;
+}
+
+int prim_incl_scan_u64(harc_amd_ctx *c, const uint64_t *in, uint64_t *out, size_t n)
+{
+    if (n == 0) return HARC_AMD_OK;
+    PRIM_CALL(rocprim::inclusive_scan(tmp, bytes, in, out, n, rocprim::plus<uint64_t>(), c->stream));
+    return HARC_AMD_OK;
+}
+
+int prim_incl_max_u32(harc_amd_ctx *c, const uint32_t *in, uint32_t *out, size_t n)
+{
+    if (n == 0) return HARC_AMD_OK;
+    PRIM_CALL(rocprim::inclusive_scan(tmp, bytes, in, out, n, rocprim::maximum<uint32_t>(), c->stream));
+    return HARC_AMD_OK;
+}

@@ -1,0 +1,686 @@
+// stage1.hip -- HARC stage I (hash-based read reordering) for gfx950.
+//
+// Reference: src/reorder.cpp.  constructdictionary :277-394 -> k_keygen + radix sort + k_table_insert (an exact
+// open-addressing key->bin table replaces BBHash: the MPHF value never reaches an output byte).  reorder() :434-703 ->
+// the round-synchronous K-chain schedule of DESIGN.md: k_propose (one 64-lane wave per chain, the (shift, direction,
+// dictionary) probes of one chain step spread over the lanes, priority = lane order), k_resolve (lowest chain id wins a
+// read), k_reseed (one global descending cursor, reorder.cpp:652-668).  updaterefcount :863-915 -> the consensus update
+// at the top of k_propose.  writetofile :722-830 -> k_s1_scatter (+ k_orient for the in-HBM hand-over to stage II).
+//
+// Integer / HBM-latency bound; no MFMA.  Wave = 64 everywhere.
+#include "devutil.h"
+
+// ------------------------------------------------------------------------------------------------ kernel argument block
+struct S1Args {
+    int L, maxmatch, thresh, maxsearch, Lp;
+    int ds[2], de[2], kbits[2];
+    uint32_t N, K;
+    const uint64_t *reads;
+    const HashSlot *slots[2];
+    uint64_t cap[2];
+    const uint32_t *ids[2];
+    unsigned long long *claimed;     // bitmap, bit rid&63 of word rid>>6
+    uint32_t *bid;                   // per read: lowest chain id proposing it this round
+    ChainHdr *hdr;
+    uint4 *cnt;                      // [2][K][Lp] column counts (A,C,G,T) -- reorder.cpp:467 `count`
+    uint64_t *ref;                   // [K][W] packed consensus
+    uint2 *prop;                     // per chain: {rid | NONE, shift | dir<<8}
+    LogRec *log;
+    unsigned long long *logcount;
+    uint32_t *blockcnt;              // per k_resolve block: chains that need a new seed
+    uint32_t *needseg;               // [blocks][256] those chains, in chain order
+    long long *cursor;               // reorder.cpp `remainingpos`, one for all chains
+    unsigned long long *stats;       // [0] unmatched [1] conflicts [2] active chains [3] probes [4] candidates
+    const uint16_t *probe_tab;       // the probes of one chain step in priority order: shift | dir<<8 | dict<<9
+    int nprobe;
+};
+enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_N = 8 };
+
+// ------------------------------------------------------------------------------------------------ packing kernels
+// ASCII -> std::bitset<2L> words (reorder.cpp:184-209). One thread per (read, word).
+__global__ void k_pack2(const char *ascii, uint32_t n, uint32_t stride, int L, int W, uint64_t *out)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * W) return;
+    const uint32_t i = (uint32_t)(gid / W); const int w = (int)(gid % W);
+    const char *s = ascii + (size_t)i * stride;
+    uint64_t v = 0;
+    for (int k = 0; k < 32; k++) {
+        const int b = 32 * w + k;
+        if (b < L) {
+            const char ch = s[b];
+            const uint64_t pc = ch == 'A' ? 0 : ch == 'G' ? 1 : ch == 'C' ? 2 : 3;
+            v |= pc << (2 * k);
+        }
+    }
+    out[gid] = v;
+}
+// ASCII -> std::bitset<3L> words (encoder.cpp:729-749): A=0 N=1 G=2 C=4 T=6 at bits 3i.. One thread per (read, word).
+__global__ void k_pack3(const char *ascii, uint32_t n, uint32_t stride, int L, int W3, uint64_t *out)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * W3) return;
+    const uint32_t i = (uint32_t)(gid / W3); const int w = (int)(gid % W3);
+    const char *s = ascii + (size_t)i * stride;
+    uint64_t v = 0;
+    const int b0 = (64 * w) / 3, b1 = (64 * w + 63) / 3;
+    for (int b = b0; b <= b1 && b < L; b++) {
+        const char ch = s[b];
+        const uint64_t c3 = ch == 'A' ? 0 : ch == 'N' ? 1 : ch == 'G' ? 2 : ch == 'C' ? 4 : 6;
+        const int sh = 3 * b - 64 * w;
+        v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
+    }
+    out[gid] = v;
+}
+// 2-bit words -> text lines of L+1 bytes (reorder.cpp:832-846 bitsettostring). One thread per (read, word).
+__global__ void k_unpack2(const uint64_t *reads, uint32_t n, int L, int W, char *out)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * W) return;
+    const uint32_t i = (uint32_t)(gid / W); const int w = (int)(gid % W);
+    uint64_t v = reads[gid];
+    char *s = out + (size_t)i * (L + 1);
+    for (int k = 0; k < 32; k++) {
+        const int b = 32 * w + k;
+        if (b < L) { const int pc = (int)(v & 3); s[b] = pc == 0 ? 'A' : pc == 1 ? 'G' : pc == 2 ? 'C' : 'T'; v >>= 2; }
+    }
+    if (w == W - 1) s[L] = '\n';
+}
+
+int s1_pack_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride, uint64_t *d_out)
+{
+    if (!n) return HARC_AMD_OK;
+    const size_t tot = (size_t)n * c->W;
+    hipLaunchKernelGGL(k_pack2, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, d_ascii, n, stride, c->P.readlen, c->W, d_out);
+    HIP_TRY(hipGetLastError());
+    return HARC_AMD_OK;
+}
+int s1_pack3_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride, uint64_t *d_out)
+{
+    if (!n) return HARC_AMD_OK;
+    const size_t tot = (size_t)n * c->W3;
+    hipLaunchKernelGGL(k_pack3, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, d_ascii, n, stride, c->P.readlen, c->W3, d_out);
+    HIP_TRY(hipGetLastError());
+    return HARC_AMD_OK;
+}
+int s1_unpack_to_ascii(harc_amd_ctx *c, const uint64_t *d_reads, uint32_t n, char *d_out)
+{
+    if (!n) return HARC_AMD_OK;
+    const size_t tot = (size_t)n * c->W;
+    hipLaunchKernelGGL(k_unpack2, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, d_reads, n, c->P.readlen, c->W, d_out);
+    HIP_TRY(hipGetLastError());
+    return HARC_AMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ index build
+// key_l(read) = bases [ds_l, de_l] of the read (reorder.cpp:295-299)
+template <int W> __global__ void k_keygen(const uint64_t *reads, uint32_t n, int off, int nbits, uint64_t *keys, uint32_t *ids)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t r[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) r[w] = reads[(size_t)i * W + w];
+    const int wi = off >> 6, sh = off & 63;                     // uniform
+    uint64_t lo = sel0<W>(r, wi), hi = sel0<W>(r, wi + 1);
+    uint64_t v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    if (nbits < 64) v &= ((uint64_t)1 << nbits) - 1;
+    keys[i] = v; ids[i] = i;
+}
+__global__ void k_mark_heads(const uint64_t *skeys, uint32_t n, uint32_t *head)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    head[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1u : 0u;
+}
+__global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint32_t n, uint32_t *binstart, uint32_t *nbins)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (head[i]) binstart[binidx[i]] = i;
+    if (i == n - 1) *nbins = binidx[i] + head[i];
+}
+// one thread per bin: claim an empty slot by CAS on the (start,count) word; keys are unique so no key compare is needed
+__global__ void k_table_insert(const uint64_t *skeys, const uint32_t *binstart, const uint32_t *nbins_p, uint32_t n,
+                               HashSlot *slots, uint64_t cap)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nbins = *nbins_p;
+    if (b >= nbins) return;
+    const uint32_t st = binstart[b];
+    const uint32_t en = (b + 1 < nbins) ? binstart[b + 1] : n;
+    const uint64_t key = skeys[st];
+    const unsigned long long meta = (unsigned long long)st | ((unsigned long long)(en - st) << 32);
+    uint64_t sl = __umul64hi(mix64(key), cap);
+    for (;;) {
+        unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
+        if (atomicCAS(mp, 0ULL, meta) == 0ULL) { slots[sl].key = key; return; }
+        if (++sl == cap) sl = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ chain kernels
+__global__ void k_init_chains(S1Args s)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= s.K) return;
+    ChainHdr h; memset(&h, 0, sizeof h);
+    const uint32_t step = s.N / s.K;                             // reorder.cpp:490
+    const bool act = s.N > 0 && (c == 0 || step > 0);            // a seed that is already taken makes the chain give up (:484)
+    if (act) {
+        const uint32_t seed = c * step;
+        atomicOr(&s.claimed[seed >> 6], 1ULL << (seed & 63));
+        h.cur = seed; h.prev = seed; h.flags = CH_ACTIVE | CH_PREVUNM; h.upd = 2u << 16;
+        atomicAdd(&s.stats[ST_UNMATCHED], 1ULL);
+        atomicAdd(&s.stats[ST_ACTIVE], 1ULL);
+    }
+    s.hdr[c] = h;
+    s.prop[c] = make_uint2(HARC_NONE, 0);
+}
+
+// The dominant kernel.  One wave per chain, 4 chains per 256-thread workgroup.
+//  (1) apply the consensus update owed from the previous round (reorder.cpp:863-915), lanes = consensus columns;
+//  (2) the probes of this chain step (reorder.cpp:517-649) are dealt to the lanes in priority order, 64 at a time:
+//      key -> open-addressing slot -> bin scan from the highest unclaimed id (<= maxsearch of them) ->
+//      XOR+popcount Hamming on the packed words; the lowest lane with a hit is the step's candidate;
+//  (3) lane 0 bids for the candidate with atomicMin(chain id).
+template <int W> __global__ __launch_bounds__(256) void k_propose(S1Args s)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= s.K) return;
+    ChainHdr h = s.hdr[c];
+    if (!(h.flags & CH_ACTIVE)) return;
+    const int L = s.L;
+    uint64_t ref[W];
+    const uint32_t kind = h.upd >> 16;
+    if (kind) {
+        const int shift = (int)(h.upd & 0xFF), rev = (int)((h.upd >> 8) & 1);
+        const uint32_t par = (h.flags & CH_PARITY) ? 1u : 0u;
+        const uint4 *src = s.cnt + ((size_t)par * s.K + c) * s.Lp;
+        uint4 *dst = s.cnt + ((size_t)(par ^ 1u) * s.K + c) * s.Lp;
+        uint64_t rw[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) rw[w] = s.reads[(size_t)h.cur * W + w];
+#pragma unroll
+        for (int t = 0; t < (W + 1) / 2; t++) {
+            const int col = lane + 64 * t;
+            const bool valid = col < L;
+            int v = 0;
+            if (valid) {
+                const int sc = rev ? (L - 1 - col) : col;
+                const int pc = (int)((sel0<W>(rw, sc >> 5) >> (2 * (sc & 31))) & 3);
+                v = ((pc & 1) << 1) | (pc >> 1);                 // packed code A0 G1 C2 T3 -> count row A0 C1 G2 T3
+                if (rev) v = 3 - v;
+                uint4 q = make_uint4(0, 0, 0, 0);
+                if (kind == 1 && col < L - shift) {
+                    q = src[col + shift];
+                    q.x += (v == 0); q.y += (v == 1); q.z += (v == 2); q.w += (v == 3);
+                    uint32_t mx = 0; int ind = 0;                // first strict maximum: ties A<C<G<T (reorder.cpp:893-899)
+                    if (q.x > mx) { mx = q.x; ind = 0; }
+                    if (q.y > mx) { mx = q.y; ind = 1; }
+                    if (q.z > mx) { mx = q.z; ind = 2; }
+                    if (q.w > mx) { mx = q.w; ind = 3; }
+                    v = ind;
+                } else {
+                    q.x = (v == 0); q.y = (v == 1); q.z = (v == 2); q.w = (v == 3);
+                }
+                dst[col] = q;
+            }
+            // consensus -> packed words by ballot: code bit0 = row>>1, bit1 = row&1
+            const unsigned long long b0 = __ballot(valid && (v >> 1)), b1 = __ballot(valid && (v & 1));
+            ref[2 * t] = spread32(b0) | (spread32(b1) << 1);
+            if (2 * t + 1 < W) ref[2 * t + 1] = spread32(b0 >> 32) | (spread32(b1 >> 32) << 1);
+        }
+        if (lane < W) s.ref[(size_t)c * W + lane] = sel0<W>(ref, lane);
+        h.flags ^= CH_PARITY;
+        h.upd = 0;
+    } else {
+#pragma unroll
+        for (int w = 0; w < W; w++) ref[w] = s.ref[(size_t)c * W + w];
+    }
+    uint64_t rref[W];
+    rc_words<W>(ref, L, rref);
+
+    uint32_t found = HARC_NONE; int fj = 0, fdir = 0;
+    uint32_t np = 0, nc = 0;
+    for (int base = 0; base < s.nprobe; base += 64) {
+        const int p = base + lane;
+        uint32_t mine = HARC_NONE; int j = 0, dir = 0;
+        if (p < s.nprobe) {
+            const uint32_t e = s.probe_tab[p];
+            j = (int)(e & 0xFF); dir = (int)((e >> 8) & 1);
+            const int l = (int)((e >> 9) & 1);
+            const int off = dir ? 2 * (s.ds[l] - j) : 2 * (s.ds[l] + j);
+            uint64_t src[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) src[w] = dir ? rref[w] : ref[w];
+            const uint64_t key = extract_bits<W>(src, off, s.kbits[l]);
+            const uint64_t cap = s.cap[l];
+            const HashSlot *tab = s.slots[l];
+            const uint32_t *ids = s.ids[l];
+            if (cap) {
+                uint64_t sl = __umul64hi(mix64(key), cap);
+                for (;;) {
+                    const uint4 raw = *reinterpret_cast<const uint4 *>(&tab[sl]);
+                    np++;
+                    const uint64_t k2 = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+                    const uint32_t st = raw.z, cntb = raw.w;
+                    if (cntb == 0) break;
+                    if (k2 == key) {
+                        // shifted consensus for this (shift, direction): reorder.cpp:647-648
+                        uint64_t sh[W];
+                        if (dir) shl_words<W>(rref, 2 * j, sh); else shr_words<W>(ref, 2 * j, sh);
+                        const int nb = 2 * (L - j);
+                        int seen = 0;
+                        for (uint32_t i = st + cntb; i > st && seen < s.maxsearch; i--) {
+                            const uint32_t rid = ids[i - 1];
+                            if ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) continue;
+                            seen++; nc++;
+                            int hd = 0;
+#pragma unroll
+                            for (int w = 0; w < W; w++) {
+                                const uint64_t rd = s.reads[(size_t)rid * W + w];
+                                // forward: low 2(L-j) bits (mask[j], reorder.cpp:712-713); reverse: bits >= 2j below 2L (revmask[j], :714-715)
+                                const uint64_t m = dir ? (lowmask_word(2 * L, w) & ~lowmask_word(2 * j, w)) : lowmask_word(nb, w);
+                                hd += __popcll((sh[w] ^ rd) & m);
+                            }
+                            if (hd <= s.thresh) { mine = rid; break; }
+                        }
+                        break;
+                    }
+                    if (++sl == cap) sl = 0;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(mine != HARC_NONE);
+        if (m) {
+            const int srcl = __ffsll((long long)m) - 1;
+            found = __shfl(mine, srcl, 64); fj = __shfl(j, srcl, 64); fdir = __shfl(dir, srcl, 64);
+            break;
+        }
+    }
+    np = wave_sum_u32(np); nc = wave_sum_u32(nc);
+    if (lane == 0) {
+        h.nprobe += np; h.ncand += nc;
+        s.hdr[c] = h;
+        s.prop[c] = make_uint2(found, (uint32_t)fj | ((uint32_t)fdir << 8));
+        if (found != HARC_NONE) atomicMin(&s.bid[found], c);
+    }
+}
+
+// pass 1 (one thread per chain): the lowest chain id bidding for a read claims it (reorder.cpp:545-578 made deterministic);
+// chains without a candidate are listed, in chain order, for k_reseed.
+__global__ __launch_bounds__(256) void k_resolve(S1Args s)
+{
+    __shared__ uint32_t sm[8];
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    uint32_t need = 0, nrec = 0, conflict = 0;
+    ChainHdr h; uint2 p = make_uint2(HARC_NONE, 0);
+    bool act = false, won = false;
+    if (c < s.K) {
+        h = s.hdr[c];
+        act = (h.flags & CH_ACTIVE) != 0;
+        if (act) {
+            p = s.prop[c];
+            if (p.x == HARC_NONE) need = 1;
+            else if (s.bid[p.x] == c) { won = true; nrec = (h.flags & CH_PREVUNM) ? 2u : 1u; }
+            else conflict = 1;
+        }
+    }
+    // log slots: one atomic per wave
+    uint32_t wtot; const uint32_t wex = wave_excl_scan_u32(nrec, &wtot);
+    unsigned long long wbase = 0;
+    if (wtot) {
+        if ((threadIdx.x & 63) == 0) wbase = atomicAdd(s.logcount, (unsigned long long)wtot);
+        wbase = __shfl(wbase, 0, 64);
+    }
+    if (won) {
+        const uint32_t rid = p.x;
+        s.bid[rid] = HARC_NONE;
+        atomicOr(&s.claimed[rid >> 6], 1ULL << (rid & 63));
+        unsigned long long at = wbase + wex;
+        if (h.flags & CH_PREVUNM) {                              // the pending seed opens a contig (reorder.cpp:564-570)
+            LogRec r; r.chain = c; r.seq = h.n_main++; r.rid = h.prev; r.meta = (uint32_t)(s.L & 0xFF);
+            s.log[at++] = r;
+        }
+        LogRec r; r.chain = c; r.seq = h.n_main++; r.rid = rid;
+        r.meta = (p.y & 0xFF) | (1u << 8) | (((p.y >> 8) & 1u) << 9);
+        s.log[at] = r;
+        h.cur = rid; h.flags &= ~CH_PREVUNM; h.upd = (1u << 16) | (p.y & 0x1FF);
+        s.hdr[c] = h;
+    }
+    uint32_t ntot; const uint32_t lrank = block_excl_scan_u32<256>(need, sm, &ntot);
+    if (need) s.needseg[(size_t)blockIdx.x * 256 + lrank] = c;
+    if (threadIdx.x == 0) s.blockcnt[blockIdx.x] = ntot;
+    const uint32_t cw = wave_sum_u32(conflict);
+    if ((threadIdx.x & 63) == 0 && cw) atomicAdd(&s.stats[ST_CONFLICTS], (unsigned long long)cw);
+}
+
+// pass 2 (one workgroup): chains without a candidate take new seeds, in chain order, from the single descending cursor over
+// unclaimed reads (reorder.cpp:650-688); when the cursor runs out they finish.
+__global__ __launch_bounds__(1024) void k_reseed(S1Args s)
+{
+    __shared__ uint32_t sbase[4096 + 1];
+    __shared__ uint32_t sm[20];
+    __shared__ long long scursor;
+    const int t = threadIdx.x;
+    const uint32_t nb = (s.K + 255) / 256;                        // <= 4096 (K <= 2^20)
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t idx = (uint32_t)t * 4 + k; v[k] = idx < nb ? s.blockcnt[idx] : 0; sum += v[k]; }
+    uint32_t R; uint32_t tb = block_excl_scan_u32<1024>(sum, sm, &R);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { sbase[t * 4 + k] = tb; tb += v[k]; }
+    if (t == 1023) sbase[4096] = tb;
+    __syncthreads();
+    if (R == 0) return;
+
+    auto chain_of_rank = [&](uint32_t r) -> uint32_t {            // largest b with sbase[b] <= r
+        uint32_t lo = 0, hi = nb;                                 // invariant sbase[lo] <= r < sbase[hi]
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sbase[mid] <= r) lo = mid; else hi = mid; }
+        return s.needseg[(size_t)lo * 256 + (r - sbase[lo])];
+    };
+
+    long long cursor = *s.cursor;
+    uint32_t assigned = 0;
+    while (assigned < R && cursor >= 0) {
+        const long long cwd = cursor >> 6, wi = cwd - t;
+        unsigned long long bits = 0;
+        if (wi >= 0) {
+            bits = ~s.claimed[wi];
+            if (wi == cwd) { const int top = (int)(cursor & 63); if (top < 63) bits &= (2ULL << top) - 1ULL; }
+        }
+        uint32_t total; const uint32_t off = block_excl_scan_u32<1024>((uint32_t)__popcll(bits), sm, &total);
+        unsigned long long newclaim = 0; uint32_t k = 0;
+        while (bits && assigned + off + k < R) {
+            const int b = 63 - __clzll((long long)bits);
+            bits &= ~(1ULL << b);
+            const uint32_t id = (uint32_t)(wi * 64 + b), r = assigned + off + k;
+            k++; newclaim |= 1ULL << b;
+            const uint32_t c = chain_of_rank(r);
+            ChainHdr h = s.hdr[c];
+            if (h.flags & CH_PREVUNM) {                           // previous seed found nothing: singleton (reorder.cpp:681-684)
+                const unsigned long long at = atomicAdd(s.logcount, 1ULL);
+                LogRec rec; rec.chain = c; rec.seq = h.n_sing++; rec.rid = h.prev; rec.meta = 1u << 10;
+                s.log[at] = rec;
+            }
+            h.cur = id; h.prev = id; h.flags |= CH_PREVUNM; h.upd = 2u << 16;
+            s.hdr[c] = h;
+            atomicAdd(&s.stats[ST_UNMATCHED], 1ULL);
+            if (r == R - 1) scursor = (long long)id - 1;
+        }
+        if (newclaim) s.claimed[wi] |= newclaim;                  // this workgroup is the only writer of the bitmap in this launch
+        __syncthreads();
+        if (assigned + total >= R) { assigned = R; cursor = scursor; }
+        else { assigned += total; cursor = (cwd - 1023) * 64 - 1; }
+        __syncthreads();
+    }
+    // cursor exhausted: the remaining chains are done (reorder.cpp:670-677)
+    for (uint32_t r = assigned + (uint32_t)t; r < R; r += 1024) {
+        const uint32_t c = chain_of_rank(r);
+        ChainHdr h = s.hdr[c];
+        if (h.flags & CH_PREVUNM) {
+            const unsigned long long at = atomicAdd(s.logcount, 1ULL);
+            LogRec rec; rec.chain = c; rec.seq = h.n_sing++; rec.rid = h.prev; rec.meta = 1u << 10;
+            s.log[at] = rec;
+        }
+        h.flags &= ~(CH_ACTIVE | CH_PREVUNM);
+        s.hdr[c] = h;
+        atomicAdd(&s.stats[ST_ACTIVE], ~0ULL);                    // -1
+    }
+    if (t == 0) *s.cursor = cursor < -1 ? -1 : cursor;
+}
+
+// ------------------------------------------------------------------------------------------------ finalisation
+__global__ void k_chain_counts(const ChainHdr *hdr, uint32_t K, uint32_t *nmain, uint32_t *nsing, unsigned long long *stats)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t np = 0, nc = 0;
+    if (c < K) { nmain[c] = hdr[c].n_main; nsing[c] = hdr[c].n_sing; np = hdr[c].nprobe; nc = hdr[c].ncand; }
+    np = wave_sum_u32(np); nc = wave_sum_u32(nc);
+    if ((threadIdx.x & 63) == 0) { if (np) atomicAdd(&stats[ST_PROBES], (unsigned long long)np); if (nc) atomicAdd(&stats[ST_CANDS], (unsigned long long)nc); }
+}
+// per-chain streams concatenated in chain order (reorder.cpp:778-821)
+__global__ void k_s1_scatter(const LogRec *log, unsigned long long nlog, const uint32_t *base_main, const uint32_t *base_sing,
+                             uint32_t *order, uint8_t *flag, uint8_t *pos, uint8_t *rc, uint32_t *order_s)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlog) return;
+    const LogRec r = log[i];
+    if (r.meta & (1u << 10)) order_s[base_sing[r.chain] + r.seq] = r.rid;
+    else {
+        const uint32_t at = base_main[r.chain] + r.seq;
+        order[at] = r.rid; pos[at] = (uint8_t)(r.meta & 0xFF);
+        flag[at] = (r.meta >> 8) & 1 ? '1' : '0'; rc[at] = (r.meta >> 9) & 1 ? 'r' : 'd';
+    }
+}
+// temp.dna in HBM: read `order[i]`, reverse-complemented where rc[i]=='r' (reorder.cpp:743-752)
+template <int W> __global__ void k_orient(const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, int L, uint64_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t rid = order[i];
+    uint64_t r[W], o[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) r[w] = reads[(size_t)rid * W + w];
+    if (rc == nullptr || rc[i] != 'r') {
+#pragma unroll
+        for (int w = 0; w < W; w++) o[w] = r[w];
+    } else rc_words<W>(r, L, o);
+#pragma unroll
+    for (int w = 0; w < W; w++) out[(size_t)i * W + w] = o[w];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, uint32_t n, unsigned kbits)
+{
+    d->cap = 0; d->slots = nullptr; d->ids = nullptr; d->d_nbins = nullptr;
+    if (n == 0) return HARC_AMD_OK;
+    uint64_t *k1 = nullptr; uint32_t *h0 = nullptr, *b0 = nullptr, *bs = nullptr;
+    RC_TRY(dalloc(c, &k1, n)); RC_TRY(dalloc(c, &h0, n)); RC_TRY(dalloc(c, &b0, n)); RC_TRY(dalloc(c, &bs, n));
+    d->cap = 2ull * n + 2;
+    RC_TRY(dalloc(c, &d->slots, d->cap)); RC_TRY(dalloc(c, &d->ids, n)); RC_TRY(dalloc(c, &d->d_nbins, 1));
+    const unsigned g = (n + 255) / 256;
+    RC_TRY(prim_sort_pairs_u64_u32(c, keys, k1, ids, d->ids, n, kbits));        // stable: ids ascending inside a bin (reorder.cpp:372-384)
+    hipLaunchKernelGGL(k_mark_heads, dim3(g), dim3(256), 0, c->stream, k1, n, h0);
+    RC_TRY(prim_excl_scan_u32(c, h0, b0, n));
+    hipLaunchKernelGGL(k_bin_starts, dim3(g), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins);
+    HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
+    hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, bs, d->d_nbins, n, d->slots, d->cap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&d->nbins, d->d_nbins, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    harc_dev_free(c, k1); harc_dev_free(c, h0); harc_dev_free(c, b0); harc_dev_free(c, bs);
+    return HARC_AMD_OK;
+}
+void harc_dict_free(harc_amd_ctx *c, DictDev *d)
+{
+    if (d->slots) harc_dev_free(c, d->slots);
+    if (d->ids) harc_dev_free(c, d->ids);
+    if (d->d_nbins) harc_dev_free(c, d->d_nbins);
+    d->slots = nullptr; d->ids = nullptr; d->d_nbins = nullptr; d->cap = 0;
+}
+
+static std::vector<uint16_t> make_probe_table(const harc_amd_params &P)
+{
+    // reorder.cpp:517-649: for j: forward l=0,1 (skip if dict_end[l]+j >= readlen), reverse l=0,1 (skip if dict_start[l] <= j)
+    std::vector<uint16_t> t;
+    for (int j = 0; j < P.maxmatch; j++) {
+        for (int l = 0; l < 2; l++) if (P.dict_end[l] + j < P.readlen) t.push_back((uint16_t)(j | (0 << 8) | (l << 9)));
+        for (int l = 0; l < 2; l++) if (P.dict_start[l] > j) t.push_back((uint16_t)(j | (1 << 8) | (l << 9)));
+    }
+    return t;
+}
+
+static uint32_t auto_chains(uint32_t N)
+{
+    // one chain per ~1024 reads keeps chains sparse on the genome (conflicts <0.5 % below ~1 chain / kb);
+    // 65536 waves is several full waves of occupancy on 256 CUs
+    uint32_t k = N / 1024;
+    if (k > 65536) k = 65536;
+    if (k < 1) k = 1;
+    return k;
+}
+
+template <int W> static int stage1_run_w(harc_amd_ctx *c)
+{
+    const harc_amd_params &P = c->P;
+    const uint32_t N = c->N;
+    uint32_t K = P.num_chains > 0 ? (uint32_t)P.num_chains : auto_chains(N);
+    if (K > HARC_MAXK) K = HARC_MAXK;
+    if (N == 0 || K > N) K = 1;                                  // floor(N/K)=0: only chain 0 ever runs (reorder.cpp:484-490)
+    c->C.chains = K;
+    hipEvent_t e0, e1, e2;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+    HIP_TRY(hipEventRecord(e0, c->stream));
+
+    // ---- dictionaries (constructdictionary, reorder.cpp:277-394)
+    DictDev dict[2];
+    if (N) {
+        uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
+        RC_TRY(dalloc(c, &k0, N)); RC_TRY(dalloc(c, &i0, N));
+        for (int l = 0; l < 2; l++) {
+            const int kbits = 2 * (P.dict_end[l] - P.dict_start[l] + 1);
+            hipLaunchKernelGGL((k_keygen<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[l], kbits, k0, i0);
+            RC_TRY(harc_dict_build(c, &dict[l], k0, i0, N, (unsigned)kbits));
+        }
+        harc_dev_free(c, k0); harc_dev_free(c, i0);
+    }
+    HIP_TRY(hipEventRecord(e1, c->stream));
+
+    // ---- chain state
+    S1Args a; memset(&a, 0, sizeof a);
+    a.L = P.readlen; a.maxmatch = P.maxmatch; a.thresh = P.thresh; a.maxsearch = P.maxsearch;
+    a.Lp = ((W + 1) / 2) * 64;
+    for (int l = 0; l < 2; l++) { a.ds[l] = P.dict_start[l]; a.de[l] = P.dict_end[l]; a.kbits[l] = 2 * (P.dict_end[l] - P.dict_start[l] + 1); }
+    a.N = N; a.K = K; a.reads = c->d_reads;
+    for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
+    const size_t nwords = (size_t)N / 64 + 2;
+    const uint32_t nblk = (K + 255) / 256;
+    RC_TRY(dalloc(c, &a.claimed, nwords)); RC_TRY(dalloc(c, &a.bid, (size_t)N + 1)); RC_TRY(dalloc(c, &a.hdr, K));
+    RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.ref, (size_t)K * W)); RC_TRY(dalloc(c, &a.prop, K));
+    RC_TRY(dalloc(c, &a.log, (size_t)N + 1)); RC_TRY(dalloc(c, &a.logcount, 1)); RC_TRY(dalloc(c, &a.blockcnt, nblk));
+    RC_TRY(dalloc(c, &a.needseg, (size_t)nblk * 256)); RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N));
+    std::vector<uint16_t> tab = make_probe_table(P);
+    uint16_t *d_tab = nullptr; RC_TRY(dalloc(c, &d_tab, tab.size() + 1));
+    HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream));
+    a.probe_tab = d_tab; a.nprobe = (int)tab.size();
+    HIP_TRY(hipMemsetAsync(a.claimed, 0, nwords * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(a.bid, 0xFF, ((size_t)N + 1) * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(a.logcount, 0, 8, c->stream));
+    HIP_TRY(hipMemsetAsync(a.stats, 0, ST_N * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(a.blockcnt, 0, nblk * 4, c->stream));
+    const long long cur0 = (long long)N - 1;
+    HIP_TRY(hipMemcpyAsync(a.cursor, &cur0, 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_init_chains, dim3(nblk), dim3(256), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+
+    // ---- rounds
+    unsigned long long *h_stats = nullptr;
+    HIP_TRY(hipHostMalloc((void **)&h_stats, ST_N * 8));
+    std::vector<hipEvent_t> ev;
+    const bool prof = P.profile != 0;
+    uint64_t rounds = 0, launches = 0;
+    const int batch = 32;
+    for (;;) {
+        for (int r = 0; r < batch; r++) {
+            if (prof) { hipEvent_t a0, a1; HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1)); ev.push_back(a0); ev.push_back(a1); HIP_TRY(hipEventRecord(a0, c->stream)); }
+            hipLaunchKernelGGL((k_propose<W>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
+            if (prof) HIP_TRY(hipEventRecord(ev.back(), c->stream));
+            hipLaunchKernelGGL(k_resolve, dim3(nblk), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL(k_reseed, dim3(1), dim3(1024), 0, c->stream, a);
+            launches++;
+        }
+        rounds += batch;
+        HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipGetLastError());
+        if (h_stats[ST_ACTIVE] == 0) break;
+        if (rounds > (uint64_t)N * 2 + 1024) { harc_set_error("stage I did not converge after %llu rounds", (unsigned long long)rounds); return HARC_AMD_ENODEVICE; }
+    }
+    HIP_TRY(hipEventRecord(e2, c->stream));
+
+    // ---- per-chain streams -> chain-major output
+    uint32_t *nmain = nullptr, *nsing = nullptr, *bmain = nullptr, *bsing = nullptr;
+    RC_TRY(dalloc(c, &nmain, (size_t)K + 1)); RC_TRY(dalloc(c, &nsing, (size_t)K + 1)); RC_TRY(dalloc(c, &bmain, (size_t)K + 1)); RC_TRY(dalloc(c, &bsing, (size_t)K + 1));
+    HIP_TRY(hipMemsetAsync(nmain, 0, ((size_t)K + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(nsing, 0, ((size_t)K + 1) * 4, c->stream));
+    hipLaunchKernelGGL(k_chain_counts, dim3(nblk), dim3(256), 0, c->stream, a.hdr, K, nmain, nsing, a.stats);
+    RC_TRY(prim_excl_scan_u32(c, nmain, bmain, (size_t)K + 1));
+    RC_TRY(prim_excl_scan_u32(c, nsing, bsing, (size_t)K + 1));
+    uint32_t M = 0, S = 0; unsigned long long nlog = 0;
+    HIP_TRY(hipMemcpyAsync(&M, bmain + K, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&S, bsing + K, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&nlog, a.logcount, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((unsigned long long)M + S != nlog || nlog != N) { harc_set_error("stage I bookkeeping: M=%u S=%u log=%llu N=%u", M, S, nlog, N); return HARC_AMD_ENODEVICE; }
+    c->M = M; c->S = S;
+    RC_TRY(dalloc(c, &c->d_order, (size_t)M + 1)); RC_TRY(dalloc(c, &c->d_flag, (size_t)M + 1)); RC_TRY(dalloc(c, &c->d_pos, (size_t)M + 1));
+    RC_TRY(dalloc(c, &c->d_rc, (size_t)M + 1)); RC_TRY(dalloc(c, &c->d_order_s, (size_t)S + 1));
+    if (nlog) hipLaunchKernelGGL(k_s1_scatter, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, c->stream, a.log, nlog, bmain, bsing,
+                                 c->d_order, c->d_flag, c->d_pos, c->d_rc, c->d_order_s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    c->C.n_main = M; c->C.n_singleton = S; c->C.unmatched = h_stats[ST_UNMATCHED]; c->C.conflicts = h_stats[ST_CONFLICTS];
+    c->C.probes = h_stats[ST_PROBES]; c->C.candidates = h_stats[ST_CANDS]; c->C.rounds = rounds; c->C.propose_launches = launches;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1)); c->C.index_ms = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, e1, e2)); c->C.chain_ms = ms;
+    double pms = 0;
+    for (size_t i = 0; i + 1 < ev.size(); i += 2) { float x = 0; HIP_TRY(hipEventElapsedTime(&x, ev[i], ev[i + 1])); pms += x; }
+    c->C.propose_ms = pms;
+    for (hipEvent_t e : ev) hipEventDestroy(e);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    hipHostFree(h_stats);
+
+    // free everything stage II does not need
+    void *tofree[] = { a.claimed, a.bid, a.hdr, a.cnt, a.ref, a.prop, a.log, a.logcount, a.blockcnt, a.needseg, a.cursor, a.stats, d_tab,
+                       nmain, nsing, bmain, bsing, dict[0].slots, dict[0].ids, dict[0].d_nbins, dict[1].slots, dict[1].ids, dict[1].d_nbins };
+    for (void *p : tofree) if (p) harc_dev_free(c, p);
+    c->have_s1 = true;
+    return HARC_AMD_OK;
+}
+
+template <int W> static int orient_w(harc_amd_ctx *c, const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, uint64_t *out)
+{
+    if (!m) return HARC_AMD_OK;
+    hipLaunchKernelGGL((k_orient<W>), dim3((m + 255) / 256), dim3(256), 0, c->stream, reads, order, rc, m, c->P.readlen, out);
+    HIP_TRY(hipGetLastError());
+    return HARC_AMD_OK;
+}
+int s1_orient(harc_amd_ctx *c, const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, uint64_t *out)
+{
+    switch (c->W) {
+    case 1: return orient_w<1>(c, reads, order, rc, m, out);
+    case 2: return orient_w<2>(c, reads, order, rc, m, out);
+    case 3: return orient_w<3>(c, reads, order, rc, m, out);
+    case 4: return orient_w<4>(c, reads, order, rc, m, out);
+    case 5: return orient_w<5>(c, reads, order, rc, m, out);
+    case 6: return orient_w<6>(c, reads, order, rc, m, out);
+    case 7: return orient_w<7>(c, reads, order, rc, m, out);
+    default: return orient_w<8>(c, reads, order, rc, m, out);
+    }
+}
+
+int stage1_run(harc_amd_ctx *c)
+{
+    switch (c->W) {
+    case 1: return stage1_run_w<1>(c);
+    case 2: return stage1_run_w<2>(c);
+    case 3: return stage1_run_w<3>(c);
+    case 4: return stage1_run_w<4>(c);
+    case 5: return stage1_run_w<5>(c);
+    case 6: return stage1_run_w<6>(c);
+    case 7: return stage1_run_w<7>(c);
+    default: return stage1_run_w<8>(c);
+    }
+}
+
+int stage1_make_oriented(harc_amd_ctx *c)
+{
+    if (c->d_oreads) { harc_dev_free(c, c->d_oreads); c->d_oreads = nullptr; }
+    RC_TRY(dalloc(c, &c->d_oreads, (size_t)c->M * c->W + 1));
+    return s1_orient(c, c->d_reads, c->d_order, c->d_rc, c->M, c->d_oreads);
+}

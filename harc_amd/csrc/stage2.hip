@@ -1,0 +1,575 @@
+// stage2.hip -- HARC stage II (reference-delta encoding) for gfx950.
+//
+// Reference: src/encoder.cpp.  The per-thread sequential contig loop (:219-441) becomes a fully data-parallel pipeline over
+// ONE global column coordinate: every reordered read i gets gstart[i] = the column of its first base in the concatenation
+// of all contig consensi (a prefix sum of the shift bytes, a contig head advancing by readlen).  Then
+//   buildcontig  :619-652  -> k_consensus   (one thread per column, majority over the reads covering it, ties A<C<G<T)
+//   realignment  :231-418  -> k_realign_propose (one thread per window start, 4 dictionary probes, 3-bit XOR+popcount) +
+//                             atomicMin of the (column, direction, dictionary) tuple per candidate read: the sequential
+//                             first-come claim of the reference at num_thr=1 is exactly the minimum tuple
+//   list.insert  :310-313  -> a merge by rank (two binary searches) of the reads with the accepted candidates
+//   writecontig  :654-717  -> k_count_noise / k_emit (noise, noisepos, pos, order routing, rc)
+//   packbits     :512-616  -> k_pack2_bytes / k_pack1_bytes
+// Shard e of num_thr owns reordered reads [e*q, (e+1)*q) (:171-180); its streams are slices of the global arrays.
+#include "devutil.h"
+#include <algorithm>
+
+#define TUPLE_NONE 0xFFFFFFFFFFFFFFFFULL
+
+struct S2Args {
+    int L, W, W3, thresh_s, maxsearch;
+    int ds[2], de[2], kbits[2];
+    uint32_t M, S, T, q, nC;
+    uint64_t total;                    // total consensus columns
+    const uint64_t *oreads;            // M x W oriented reads
+    const uint8_t *flag, *pos, *rc;
+    const uint32_t *order;
+    const uint64_t *cand3;             // T x W3 : singletons then N reads, 3-bit
+    const uint32_t *cand_order;        // T
+    uint8_t *head;                     // M
+    uint64_t *gstart;                  // M
+    uint8_t *cons;                     // total bytes, A0 C1 G2 T3
+    const uint32_t *chead;             // nC: read index of each contig head
+    const HashSlot *slots[2]; uint64_t cap[2]; const uint32_t *ids[2];
+    unsigned long long *best;          // T
+};
+
+// ---------------------------------------------------------------------------------------------- small device helpers
+__device__ __forceinline__ int base2_at(const uint64_t *r, int j) { return (int)((r[j >> 5] >> (2 * (j & 31))) & 3); }     // packed code A0 G1 C2 T3
+__device__ __forceinline__ int pc_to_idx(int pc) { return ((pc & 1) << 1) | (pc >> 1); }                                   // -> A0 C1 G2 T3
+__device__ __forceinline__ int c3_at(const uint64_t *r, int W3, int j)
+{
+    const int off = 3 * j, wi = off >> 6, sh = off & 63;
+    uint64_t v = r[wi] >> sh;
+    if (sh > 61 && wi + 1 < W3) v |= r[wi + 1] << (64 - sh);
+    return (int)(v & 7);
+}
+__device__ __forceinline__ int c3_to_idx5(int c3) { return c3 == 0 ? 0 : c3 == 4 ? 1 : c3 == 2 ? 2 : c3 == 6 ? 3 : 4; }   // A C G T N
+__device__ __forceinline__ int idx_to_c3(int idx) { return idx == 0 ? 0 : idx == 1 ? 4 : idx == 2 ? 2 : 6; }
+__device__ __forceinline__ int comp5(int b) { return b == 4 ? 4 : 3 - b; }
+// enc_noise (encoder.cpp:751-771), rows = consensus base A C G T, columns = read base A C G T N
+__device__ __forceinline__ char enc_noise(int ref, int rd)
+{
+    const unsigned tabA = 0x32100, tabC = 0x32100, tabG = 0x30021, tabT = 0x30012;   // nibble rd -> code
+    const unsigned t = ref == 0 ? tabA : ref == 1 ? tabC : ref == 2 ? tabG : tabT;
+    return (char)('0' + ((t >> (4 * rd)) & 0xF));
+}
+// largest i in [0,n) with a[i] <= x, or -1
+__device__ __forceinline__ long long ub_le(const uint64_t *a, long long n, uint64_t x)
+{
+    long long lo = -1, hi = n;                                   // a[lo] <= x < a[hi]
+    while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if (a[mid] <= x) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------- candidates (3-bit store)
+// singleton r: 2-bit read -> std::bitset<3L> words (encoder.cpp:815-821). One thread per (read, word).
+__global__ void k_cand3_from2(const uint64_t *reads2, const uint32_t *gather, uint32_t n, int L, int W, int W3, uint64_t *out)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * W3) return;
+    const uint32_t i = (uint32_t)(gid / W3); const int w = (int)(gid % W3);
+    const uint64_t *r = reads2 + (size_t)(gather ? gather[i] : i) * W;
+    uint64_t v = 0;
+    const int b0 = (64 * w) / 3, b1 = (64 * w + 63) / 3;
+    for (int b = b0; b <= b1 && b < L; b++) {
+        const uint64_t c3 = (uint64_t)(2 * base2_at(r, b));      // A0 G1 C2 T3 -> A0 G2 C4 T6
+        const int sh = 3 * b - 64 * w;
+        v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
+    }
+    out[gid] = v;
+}
+__global__ void k_cand_order(const uint32_t *order_s, uint32_t S, uint32_t T, uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    out[i] = i < S ? order_s[i] : i - S;                          // encoder.cpp:865-870
+}
+__global__ void k_key3(const uint64_t *cand3, uint32_t T, int W3, int off, int nbits, uint64_t *keys, uint32_t *ids)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const uint64_t *r = cand3 + (size_t)i * W3;
+    const int wi = off >> 6, sh = off & 63;
+    uint64_t v = r[wi] >> sh;
+    if (sh && wi + 1 < W3) v |= r[wi + 1] << (64 - sh);
+    if (nbits < 64) v &= ((uint64_t)1 << nbits) - 1;
+    keys[i] = v; ids[i] = i;
+}
+__global__ void k_count_big_bins(const HashSlot *slots, uint64_t cap, uint32_t maxsearch, unsigned long long *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    if (slots[i].count > maxsearch) atomicAdd(out, 1ULL);
+}
+
+// ---------------------------------------------------------------------------------------------- contig structure
+// contig heads: flag '0', shard starts (encoder.cpp:171-180) -- step 1
+__global__ void k_heads1(const uint8_t *flag, uint32_t M, uint32_t q, uint8_t *head, uint32_t *hidx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const uint8_t h = (flag[i] == '0' || (i % q) == 0) ? 1 : 0;
+    head[i] = h; hidx[i] = h ? i : 0;
+}
+// step 2: a contig is cut once it holds 10,000,001 reads (encoder.cpp:226 `list_size>10000000`)
+__global__ void k_heads2(uint32_t M, uint8_t *head, const uint32_t *hmax, uint32_t *hidx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const uint32_t r = i - hmax[i];
+    if (r > 0 && (r % 10000001u) == 0) head[i] = 1;
+    hidx[i] = head[i] ? 1u : 0u;                                  // reused as the flag array for the contig-id scan
+}
+__global__ void k_steps(const uint8_t *head, const uint8_t *pos, uint32_t M, int L, uint64_t *d)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    d[i] = head[i] ? (i == 0 ? 0 : (uint64_t)L) : (uint64_t)pos[i];
+}
+__global__ void k_contig_heads(const uint8_t *head, const uint32_t *cid, uint32_t M, uint32_t *chead)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    if (head[i]) chead[cid[i]] = i;
+}
+
+// buildcontig (encoder.cpp:619-652): column x <- first strict maximum over A,C,G,T of the reads covering it
+__global__ __launch_bounds__(256) void k_consensus(S2Args s)
+{
+    const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= s.total) return;
+    long long i = ub_le(s.gstart, (long long)s.M, x);
+    uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
+    for (; i >= 0; i--) {
+        const uint64_t g = s.gstart[i];
+        if (g + (uint64_t)s.L <= x) break;                        // reads are sorted by gstart; nothing further left can cover x
+        const int v = pc_to_idx(base2_at(s.oreads + (size_t)i * s.W, (int)(x - g)));
+        cA += (v == 0); cC += (v == 1); cG += (v == 2); cT += (v == 3);
+    }
+    uint32_t mx = 0; int ind = 0;
+    if (cA > mx) { mx = cA; ind = 0; }
+    if (cC > mx) { mx = cC; ind = 1; }
+    if (cG > mx) { mx = cG; ind = 2; }
+    if (cT > mx) { mx = cT; ind = 3; }
+    s.cons[x] = (uint8_t)ind;
+}
+
+// singleton / N-read realignment, phase 1 (encoder.cpp:252-410): one thread per window start x.
+__global__ __launch_bounds__(256) void k_realign_propose(S2Args s)
+{
+    const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= s.total) return;
+    // which contig? largest k with gstart[chead[k]] <= x  (binary search over contig heads)
+    long long lo = 0, hi = s.nC;
+    while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if (s.gstart[s.chead[mid]] <= x) lo = mid; else hi = mid; }
+    const uint32_t k = (uint32_t)lo;
+    const bool lastc = (k + 1 == s.nC) || (s.chead[k + 1] % s.q) == 0;      // last contig of a shard: no realignment (:438-441)
+    if (lastc) return;
+    const uint64_t cend = s.gstart[s.chead[k + 1]];
+    if (x + (uint64_t)s.L > cend) return;                                   // window must fit in the contig (:252)
+    const uint8_t *win = s.cons + x;
+    const int L = s.L, W3 = s.W3;
+    for (int dir = 0; dir < 2; dir++) {
+        for (int l = 0; l < 2; l++) {
+            uint64_t key = 0;
+            for (int b = s.ds[l]; b <= s.de[l]; b++) {
+                const int idx = dir ? 3 - (int)win[L - 1 - b] : (int)win[b];
+                key |= (uint64_t)idx_to_c3(idx) << (3 * (b - s.ds[l]));
+            }
+            uint32_t st = 0, cnt = 0, np = 0;
+            if (!dict_lookup(s.slots[l], s.cap[l], key, &st, &cnt, &np)) continue;
+            const uint32_t lim = cnt > (uint32_t)s.maxsearch ? (uint32_t)s.maxsearch : cnt;   // static window: top maxsearch ids of the bin
+            for (uint32_t t = 0; t < lim; t++) {
+                const uint32_t rid = s.ids[l][st + cnt - 1 - t];
+                const uint64_t *r = s.cand3 + (size_t)rid * W3;
+                int hd = 0;
+                for (int w = 0; w < W3; w++) {                                // 3-bit window word w, built on the fly
+                    uint64_t v = 0;
+                    const int b0 = (64 * w) / 3, b1 = (64 * w + 63) / 3;
+                    for (int b = b0; b <= b1 && b < L; b++) {
+                        const int idx = dir ? 3 - (int)win[L - 1 - b] : (int)win[b];
+                        const uint64_t c3 = (uint64_t)idx_to_c3(idx);
+                        const int sh = 3 * b - 64 * w;
+                        v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
+                    }
+                    hd += __popcll(v ^ r[w]);
+                    if (hd > s.thresh_s) break;
+                }
+                if (hd <= s.thresh_s) atomicMin(&s.best[rid], (unsigned long long)((x << 2) | ((uint64_t)dir << 1) | (uint64_t)l));
+            }
+        }
+    }
+}
+
+__global__ void k_acc_flags(const unsigned long long *best, uint32_t T, uint32_t *flag)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    flag[i] = best[i] != TUPLE_NONE ? 1u : 0u;
+}
+// accepted candidates, in DESCENDING rid order (so that the stable sort by tuple leaves equal tuples rid-descending,
+// the order in which one bin scan inserts them, encoder.cpp:293-317)
+__global__ void k_acc_compact(const unsigned long long *best, const uint32_t *rank, uint32_t T, uint32_t A, uint64_t *tup, uint32_t *rid)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    if (best[i] != TUPLE_NONE) { const uint32_t at = A - 1 - rank[i]; tup[at] = best[i]; rid[at] = i; }
+}
+
+// merge by rank: final index of read i = i + #accepted with column < gstart[i]; of accepted k = k + #reads with gstart <= column
+struct FinalArrays { uint32_t *ref; uint8_t *kind; uint64_t *g; };   // kind 0 original, 1 candidate forward, 2 candidate reverse
+__global__ void k_merge_orig(const uint64_t *gstart, uint32_t M, const uint64_t *tup, uint32_t A, FinalArrays f, uint32_t *fidx_orig)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const uint64_t g = gstart[i];
+    long long lo = -1, hi = A;                                    // #accepted with (tuple>>2) < g
+    while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if ((tup[mid] >> 2) < g) lo = mid; else hi = mid; }
+    const uint32_t at = i + (uint32_t)(lo + 1);
+    f.ref[at] = i; f.kind[at] = 0; f.g[at] = g;
+    fidx_orig[i] = at;
+}
+__global__ void k_merge_acc(const uint64_t *gstart, uint32_t M, const uint64_t *tup, const uint32_t *rid, uint32_t A, FinalArrays f)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A) return;
+    const uint64_t x = tup[k] >> 2;
+    const long long n = ub_le(gstart, (long long)M, x) + 1;       // originals with cumulative pos <= j come first (encoder.cpp:254-268)
+    const uint32_t at = k + (uint32_t)n;
+    f.ref[at] = rid[k]; f.kind[at] = (tup[k] & 2) ? 2 : 1; f.g[at] = x;
+}
+
+// base j (A C G T N = 0..4) of final element f as it is written to the contig (candidates reverse-complemented when kind 2)
+__device__ __forceinline__ int final_base(const S2Args &s, uint32_t ref, int kind, int j)
+{
+    if (kind == 0) return pc_to_idx(base2_at(s.oreads + (size_t)ref * s.W, j));
+    const uint64_t *r = s.cand3 + (size_t)ref * s.W3;
+    if (kind == 1) return c3_to_idx5(c3_at(r, s.W3, j));
+    return comp5(c3_to_idx5(c3_at(r, s.W3, s.L - 1 - j)));
+}
+__global__ void k_count_noise(S2Args s, FinalArrays f, uint32_t F, uint32_t *nm, uint32_t *nonN)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    const uint32_t ref = f.ref[i]; const int kind = f.kind[i]; const uint64_t g = f.g[i];
+    uint32_t n = 0;
+    for (int j = 0; j < s.L; j++) n += (final_base(s, ref, kind, j) != (int)s.cons[g + j]);
+    nm[i] = n;
+    nonN[i] = (kind != 0 && ref >= s.S) ? 0u : 1u;                // N reads are exactly the candidates with index >= S
+}
+// writecontig (encoder.cpp:654-717)
+__global__ void k_emit(S2Args s, FinalArrays f, uint32_t F, const uint64_t *nmoff, const uint32_t *nonNrank,
+                       uint8_t *noise, uint8_t *noisepos, uint8_t *posb, uint8_t *rcb, uint32_t *order_out, uint32_t *orderN_out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    const uint32_t ref = f.ref[i]; const int kind = f.kind[i]; const uint64_t g = f.g[i];
+    uint64_t np = nmoff[i], nz = nmoff[i] + i;                    // one '\n' per earlier read
+    int prevj = 0;
+    for (int j = 0; j < s.L; j++) {
+        const int b = final_base(s, ref, kind, j), cb = (int)s.cons[g + j];
+        if (b != cb) { noise[nz++] = (uint8_t)enc_noise(cb, b); noisepos[np++] = (uint8_t)(j - prevj); prevj = j; }
+    }
+    noise[nz] = '\n';
+    const bool is_head = (kind == 0) && s.head[ref];
+    posb[i] = is_head ? (uint8_t)s.L : (uint8_t)(g - f.g[i - 1]);
+    rcb[i] = kind == 0 ? s.rc[ref] : (kind == 1 ? 'd' : 'r');
+    const uint32_t ov = kind == 0 ? s.order[ref] : s.cand_order[ref];
+    const bool isN = (kind != 0 && ref >= s.S);
+    if (isN) orderN_out[i - nonNrank[i]] = ov; else order_out[nonNrank[i]] = ov;
+}
+
+// unaligned candidates (encoder.cpp:484-499): singletons -> order + bases; N reads -> order_N + text
+__global__ void k_left_flags(const unsigned long long *best, uint32_t T, uint32_t S, uint32_t *fs, uint32_t *fn)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const bool un = best[i] == TUPLE_NONE;
+    fs[i] = (un && i < S) ? 1u : 0u; fn[i] = (un && i >= S) ? 1u : 0u;
+}
+__global__ void k_left_emit(S2Args s, const uint32_t *rs, const uint32_t *rn, uint32_t *order_out, uint32_t order_base,
+                            uint32_t *orderN_out, uint32_t orderN_base, uint8_t *sing_bases, char *ntext)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.T) return;
+    if (s.best[i] != TUPLE_NONE) return;
+    const uint64_t *r = s.cand3 + (size_t)i * s.W3;
+    if (i < s.S) {
+        const uint32_t k = rs[i];
+        order_out[order_base + k] = s.cand_order[i];
+        for (int j = 0; j < s.L; j++) sing_bases[(size_t)k * s.L + j] = (uint8_t)c3_to_idx5(c3_at(r, s.W3, j));
+    } else {
+        const uint32_t k = rn[i];
+        orderN_out[orderN_base + k] = s.cand_order[i];
+        char *o = ntext + (size_t)k * (s.L + 1);
+        for (int j = 0; j < s.L; j++) o[j] = "ACGTN"[c3_to_idx5(c3_at(r, s.W3, j))];
+        o[s.L] = '\n';
+    }
+}
+
+// packbits (encoder.cpp:527-548, :560-578)
+__global__ void k_pack2_bytes(const uint8_t *bases, uint64_t nbytes_out, uint8_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbytes_out) return;
+    const uint8_t *b = bases + 4 * i;
+    out[i] = (uint8_t)(b[0] | (b[1] << 2) | (b[2] << 4) | (b[3] << 6));
+}
+__global__ void k_pack1_bytes(const uint8_t *rc, uint64_t nbytes_out, uint8_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbytes_out) return;
+    const uint8_t *b = rc + 8 * i;
+    uint8_t v = 0;
+    for (int k = 0; k < 8; k++) v |= (uint8_t)((b[k] == 'r') << k);
+    out[i] = v;
+}
+__global__ void k_bases_to_ascii(const uint8_t *bases, uint64_t n, uint8_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (uint8_t)"ACGT"[bases[i] & 3];
+}
+
+// pack_order.cpp:36-65: every 32 values -> numbits u32 words, LSB-first bit stream. One thread per output word.
+__global__ void k_pack_order(const uint32_t *order, uint32_t ngroups, int numbits, uint32_t *out)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)ngroups * numbits) return;
+    const uint32_t g = (uint32_t)(gid / numbits); const int w = (int)(gid % numbits);
+    const int k0 = (32 * w) / numbits, k1 = (32 * w + 31) / numbits;
+    uint32_t v = 0;
+    for (int k = k0; k <= k1 && k < 32; k++) {
+        const uint32_t o = order[(size_t)g * 32 + k];
+        const int sh = k * numbits - 32 * w;
+        v |= sh >= 0 ? (o << sh) : (o >> (-sh));
+    }
+    out[gid] = v;
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+#define G256(n) dim3((unsigned)((((uint64_t)(n)) + 255) / 256)), dim3(256), 0, c->stream
+
+static void put(harc_amd_ctx *c, int id, int shard, const uint8_t *p, size_t n) { std::vector<uint8_t> &b = out_buf(c, id, shard); b.assign(p, p + n); }
+
+int stage2_run(harc_amd_ctx *c)
+{
+    const harc_amd_params &P = c->P;
+    const int L = P.readlen, W = c->W, W3 = c->W3;
+    const uint32_t M = c->M, S = c->S, NN = c->NN, T = S + NN, E = (uint32_t)P.num_thr;
+    // drop earlier stage-II outputs
+    for (auto it = c->out.begin(); it != c->out.end();) { if (it->first.first >= HARC_AMD_S2_SEQ) it = c->out.erase(it); else ++it; }
+
+    S2Args a; memset(&a, 0, sizeof a);
+    a.L = L; a.W = W; a.W3 = W3; a.thresh_s = P.thresh_s; a.maxsearch = P.maxsearch;
+    if (L > 50) { a.ds[0] = 0; a.de[0] = 20; a.ds[1] = 21; a.de[1] = 41; }                     // encoder.cpp:132-145
+    else { a.ds[0] = 0; a.de[0] = 20 * L / 50; a.ds[1] = 20 * L / 50 + 1; a.de[1] = 41 * L / 50; }
+    for (int l = 0; l < 2; l++) a.kbits[l] = 3 * (a.de[l] - a.ds[l] + 1);
+    a.M = M; a.S = S; a.T = T;
+    a.q = 1u + (uint32_t)((M - 1u) / E);                          // uint32 arithmetic as encoder.cpp:171
+    if (a.q == 0) a.q = 1;
+    a.oreads = c->d_oreads; a.flag = c->d_flag; a.pos = c->d_pos; a.rc = c->d_rc; a.order = c->d_order;
+
+    // ---- candidates: singletons then N reads, 3-bit (readsingletons, encoder.cpp:823-872)
+    uint64_t *cand3 = nullptr; uint32_t *cand_order = nullptr; unsigned long long *best = nullptr;
+    RC_TRY(dalloc(c, &cand3, (size_t)T * W3 + 1)); RC_TRY(dalloc(c, &cand_order, (size_t)T + 1)); RC_TRY(dalloc(c, &best, (size_t)T + 1));
+    if (S) {
+        if (c->d_sreads) hipLaunchKernelGGL(k_cand3_from2, G256((size_t)S * W3), c->d_sreads, (const uint32_t *)nullptr, S, L, W, W3, cand3);
+        else hipLaunchKernelGGL(k_cand3_from2, G256((size_t)S * W3), c->d_reads, c->d_order_s, S, L, W, W3, cand3);
+    }
+    if (NN) HIP_TRY(hipMemcpyAsync(cand3 + (size_t)S * W3, c->d_nreads3, (size_t)NN * W3 * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (T) hipLaunchKernelGGL(k_cand_order, G256(T), c->d_order_s, S, T, cand_order);
+    HIP_TRY(hipMemsetAsync(best, 0xFF, ((size_t)T + 1) * 8, c->stream));
+    a.cand3 = cand3; a.cand_order = cand_order; a.best = best;
+
+    // ---- dictionaries over the candidates (encoder.cpp:886-992)
+    DictDev dict[2];
+    unsigned long long *d_big = nullptr; RC_TRY(dalloc(c, &d_big, 1));
+    HIP_TRY(hipMemsetAsync(d_big, 0, 8, c->stream));
+    if (T) {
+        uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
+        RC_TRY(dalloc(c, &k0, T)); RC_TRY(dalloc(c, &i0, T));
+        for (int l = 0; l < 2; l++) {
+            hipLaunchKernelGGL(k_key3, G256(T), cand3, T, W3, 3 * a.ds[l], a.kbits[l], k0, i0);
+            RC_TRY(harc_dict_build(c, &dict[l], k0, i0, T, (unsigned)a.kbits[l]));
+            hipLaunchKernelGGL(k_count_big_bins, G256(dict[l].cap), dict[l].slots, dict[l].cap, (uint32_t)P.maxsearch, d_big);
+        }
+        harc_dev_free(c, k0); harc_dev_free(c, i0);
+    }
+    for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
+
+    // ---- contig structure on the global column axis
+    uint8_t *head = nullptr; uint32_t *u0 = nullptr, *u1 = nullptr; uint64_t *d64 = nullptr, *gstart = nullptr; uint32_t *chead = nullptr;
+    RC_TRY(dalloc(c, &head, (size_t)M + 1)); RC_TRY(dalloc(c, &u0, (size_t)M + 1)); RC_TRY(dalloc(c, &u1, (size_t)M + 1));
+    RC_TRY(dalloc(c, &d64, (size_t)M + 1)); RC_TRY(dalloc(c, &gstart, (size_t)M + 1));
+    uint32_t nC = 0; uint64_t total = 0;
+    if (M) {
+        hipLaunchKernelGGL(k_heads1, G256(M), c->d_flag, M, a.q, head, u0);
+        RC_TRY(prim_incl_max_u32(c, u0, u1, M));
+        hipLaunchKernelGGL(k_heads2, G256(M), M, head, u1, u0);                  // u0 := head flags as u32
+        RC_TRY(prim_excl_scan_u32(c, u0, u1, M));                                // u1 := contig id
+        hipLaunchKernelGGL(k_steps, G256(M), head, c->d_pos, M, L, d64);
+        RC_TRY(prim_incl_scan_u64(c, d64, gstart, M));
+        uint32_t lastcid = 0, lasthead = 0; uint64_t lastg = 0;
+        HIP_TRY(hipMemcpyAsync(&lastcid, u1 + (M - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&lasthead, u0 + (M - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&lastg, gstart + (M - 1), 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        nC = lastcid + lasthead; total = lastg + (uint64_t)L;
+        RC_TRY(dalloc(c, &chead, (size_t)nC + 1));
+        hipLaunchKernelGGL(k_contig_heads, G256(M), head, u1, M, chead);
+    }
+    a.head = head; a.gstart = gstart; a.chead = chead; a.nC = nC; a.total = total;
+    c->C.contigs = nC; c->C.seq_bases = total;
+
+    // ---- consensus + realignment proposals
+    uint8_t *cons = nullptr; RC_TRY(dalloc(c, &cons, (size_t)total + 8));
+    a.cons = cons;
+    if (total) {
+        hipLaunchKernelGGL(k_consensus, G256(total), a);
+        if (T) hipLaunchKernelGGL(k_realign_propose, G256(total), a);
+    }
+    HIP_TRY(hipGetLastError());
+
+    // ---- accepted candidates sorted by (tuple, rid descending)
+    uint32_t A = 0;
+    uint32_t *t0 = nullptr, *t1 = nullptr; uint64_t *tup0 = nullptr, *tup = nullptr; uint32_t *rid0 = nullptr, *rid = nullptr;
+    RC_TRY(dalloc(c, &t0, (size_t)T + 1)); RC_TRY(dalloc(c, &t1, (size_t)T + 1));
+    if (T) {
+        HIP_TRY(hipMemsetAsync(t0, 0, ((size_t)T + 1) * 4, c->stream));
+        hipLaunchKernelGGL(k_acc_flags, G256(T), best, T, t0);
+        RC_TRY(prim_excl_scan_u32(c, t0, t1, (size_t)T + 1));
+        HIP_TRY(hipMemcpyAsync(&A, t1 + T, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    RC_TRY(dalloc(c, &tup0, (size_t)A + 1)); RC_TRY(dalloc(c, &tup, (size_t)A + 1)); RC_TRY(dalloc(c, &rid0, (size_t)A + 1)); RC_TRY(dalloc(c, &rid, (size_t)A + 1));
+    if (A) {
+        hipLaunchKernelGGL(k_acc_compact, G256(T), best, t1, T, A, tup0, rid0);
+        unsigned bits = 2; while (bits < 64 && (total >> (bits - 2)) != 0) bits++;
+        RC_TRY(prim_sort_pairs_u64_u32(c, tup0, tup, rid0, rid, A, bits));
+    }
+
+    // ---- merge into the final read list
+    const uint32_t F = M + A;
+    FinalArrays f; uint32_t *fidx_orig = nullptr;
+    RC_TRY(dalloc(c, &f.ref, (size_t)F + 1)); RC_TRY(dalloc(c, &f.kind, (size_t)F + 1)); RC_TRY(dalloc(c, &f.g, (size_t)F + 1)); RC_TRY(dalloc(c, &fidx_orig, (size_t)M + 1));
+    if (M) hipLaunchKernelGGL(k_merge_orig, G256(M), gstart, M, tup, A, f, fidx_orig);
+    if (A) hipLaunchKernelGGL(k_merge_acc, G256(A), gstart, M, tup, rid, A, f);
+
+    // ---- noise / pos / order / rc streams
+    uint32_t *nm = nullptr, *nonN = nullptr, *nonNrank = nullptr; uint64_t *nmoff = nullptr;
+    RC_TRY(dalloc(c, &nm, (size_t)F + 1)); RC_TRY(dalloc(c, &nonN, (size_t)F + 1)); RC_TRY(dalloc(c, &nonNrank, (size_t)F + 1)); RC_TRY(dalloc(c, &nmoff, (size_t)F + 1));
+    HIP_TRY(hipMemsetAsync(nm, 0, ((size_t)F + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(nonN, 0, ((size_t)F + 1) * 4, c->stream));
+    if (F) hipLaunchKernelGGL(k_count_noise, G256(F), a, f, F, nm, nonN);
+    RC_TRY(prim_excl_scan_u32_to_u64(c, nm, nmoff, (size_t)F + 1));
+    RC_TRY(prim_excl_scan_u32(c, nonN, nonNrank, (size_t)F + 1));
+    uint64_t nmtot = 0; uint32_t n_nonN = 0;
+    HIP_TRY(hipMemcpyAsync(&nmtot, nmoff + F, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&n_nonN, nonNrank + F, 4, hipMemcpyDeviceToHost, c->stream));
+    // leftovers
+    uint32_t *ls = nullptr, *ln = nullptr, *rs = nullptr, *rn = nullptr;
+    RC_TRY(dalloc(c, &ls, (size_t)T + 1)); RC_TRY(dalloc(c, &ln, (size_t)T + 1)); RC_TRY(dalloc(c, &rs, (size_t)T + 1)); RC_TRY(dalloc(c, &rn, (size_t)T + 1));
+    HIP_TRY(hipMemsetAsync(ls, 0, ((size_t)T + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(ln, 0, ((size_t)T + 1) * 4, c->stream));
+    if (T) hipLaunchKernelGGL(k_left_flags, G256(T), best, T, S, ls, ln);
+    RC_TRY(prim_excl_scan_u32(c, ls, rs, (size_t)T + 1)); RC_TRY(prim_excl_scan_u32(c, ln, rn, (size_t)T + 1));
+    uint32_t US = 0, UN = 0;
+    HIP_TRY(hipMemcpyAsync(&US, rs + T, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&UN, rn + T, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t n_N_aligned = F - n_nonN;
+
+    uint8_t *noise = nullptr, *noisepos = nullptr, *posb = nullptr, *rcb = nullptr; uint32_t *order_out = nullptr, *orderN_out = nullptr;
+    uint8_t *sing_bases = nullptr; char *ntext = nullptr;
+    RC_TRY(dalloc(c, &noise, (size_t)nmtot + F + 1)); RC_TRY(dalloc(c, &noisepos, (size_t)nmtot + 1)); RC_TRY(dalloc(c, &posb, (size_t)F + 1)); RC_TRY(dalloc(c, &rcb, (size_t)F + 8));
+    RC_TRY(dalloc(c, &order_out, (size_t)n_nonN + US + 1)); RC_TRY(dalloc(c, &orderN_out, (size_t)n_N_aligned + UN + 1));
+    RC_TRY(dalloc(c, &sing_bases, (size_t)US * L + 8)); RC_TRY(dalloc(c, &ntext, (size_t)UN * (L + 1) + 1));
+    if (F) hipLaunchKernelGGL(k_emit, G256(F), a, f, F, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out);
+    if (T) hipLaunchKernelGGL(k_left_emit, G256(T), a, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned, sing_bases, ntext);
+    HIP_TRY(hipGetLastError());
+
+    // ---- shard boundaries in final-list / column / noise coordinates
+    std::vector<uint32_t> sh_i(E + 1), sh_f(E + 1); std::vector<uint64_t> sh_col(E + 1), sh_nm(E + 1);
+    for (uint32_t e = 0; e <= E; e++) { uint64_t st = (uint64_t)e * a.q; sh_i[e] = (uint32_t)(st > M ? M : st); }
+    sh_i[E] = M;
+    for (uint32_t e = 0; e <= E; e++) {
+        if (sh_i[e] >= M) { sh_f[e] = F; sh_col[e] = total; sh_nm[e] = nmtot; continue; }
+        HIP_TRY(hipMemcpyAsync(&sh_f[e], fidx_orig + sh_i[e], 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&sh_col[e], gstart + sh_i[e], 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t e = 0; e <= E; e++) if (sh_i[e] < M) HIP_TRY(hipMemcpyAsync(&sh_nm[e], nmoff + sh_f[e], 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    // ---- packbits per shard + device -> host
+    uint8_t *packed = nullptr; RC_TRY(dalloc(c, &packed, (size_t)total / 4 + (size_t)F / 8 + (size_t)US * L / 4 + 64));
+    std::vector<uint8_t> h_noise, h_noisepos, h_pos, h_rc, h_cons_tail;
+    RC_TRY(harc_d2h(c, h_noise, noise, (size_t)nmtot + F)); RC_TRY(harc_d2h(c, h_noisepos, noisepos, (size_t)nmtot)); RC_TRY(harc_d2h(c, h_pos, posb, F));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t e = 0; e < E; e++) {
+        const uint64_t c0 = sh_col[e], c1 = sh_col[e + 1], nb = (c1 - c0) / 4, tl = (c1 - c0) % 4;
+        std::vector<uint8_t> seq, tail(tl), rev, rtail;
+        if (nb) { hipLaunchKernelGGL(k_pack2_bytes, G256(nb), cons + c0, nb, packed); RC_TRY(harc_d2h(c, seq, packed, nb)); }
+        if (tl) { hipLaunchKernelGGL(k_bases_to_ascii, G256(tl), cons + c0 + 4 * nb, tl, packed + nb); RC_TRY(harc_d2h(c, tail, packed + nb, tl)); }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint32_t f0 = sh_f[e], f1 = sh_f[e + 1]; const uint64_t rb = (f1 - f0) / 8, rt = (f1 - f0) % 8;
+        if (rb) { hipLaunchKernelGGL(k_pack1_bytes, G256(rb), rcb + f0, rb, packed); RC_TRY(harc_d2h(c, rev, packed, rb)); }
+        if (rt) RC_TRY(harc_d2h(c, rtail, rcb + f0 + 8 * rb, rt));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        out_buf(c, HARC_AMD_S2_SEQ, e) = seq; out_buf(c, HARC_AMD_S2_SEQ_TAIL, e) = tail;
+        out_buf(c, HARC_AMD_S2_REV, e) = rev; out_buf(c, HARC_AMD_S2_REV_TAIL, e) = rtail;
+        put(c, HARC_AMD_S2_POS, e, h_pos.data() + f0, f1 - f0);
+        put(c, HARC_AMD_S2_NOISE, e, h_noise.data() + sh_nm[e] + f0, (sh_nm[e + 1] + f1) - (sh_nm[e] + f0));
+        put(c, HARC_AMD_S2_NOISEPOS, e, h_noisepos.data() + sh_nm[e], sh_nm[e + 1] - sh_nm[e]);
+    }
+    {   // whole-job streams
+        const uint64_t sb = (uint64_t)US * L / 4, st = (uint64_t)US * L % 4;
+        std::vector<uint8_t> sing, stail(st);
+        if (sb) { hipLaunchKernelGGL(k_pack2_bytes, G256(sb), sing_bases, sb, packed); RC_TRY(harc_d2h(c, sing, packed, sb)); }
+        if (st) { hipLaunchKernelGGL(k_bases_to_ascii, G256(st), sing_bases + 4 * sb, st, packed + sb); RC_TRY(harc_d2h(c, stail, packed + sb, st)); }
+        RC_TRY(harc_d2h(c, out_buf(c, HARC_AMD_S2_ORDER, 0), order_out, ((size_t)n_nonN + US) * 4));
+        RC_TRY(harc_d2h(c, out_buf(c, HARC_AMD_S2_ORDER_N_PE, 0), orderN_out, ((size_t)n_N_aligned + UN) * 4));
+        RC_TRY(harc_d2h(c, out_buf(c, HARC_AMD_S2_INPUT_N, 0), ntext, (size_t)UN * (L + 1)));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        out_buf(c, HARC_AMD_S2_SINGLETON, 0) = sing; out_buf(c, HARC_AMD_S2_SINGLETON_TAIL, 0) = stail;
+        char meta[32]; const int ml = snprintf(meta, sizeof meta, "%d\n", L);
+        put(c, HARC_AMD_S2_META, 0, (const uint8_t *)meta, (size_t)ml);
+    }
+    unsigned long long big = 0;
+    HIP_TRY(hipMemcpyAsync(&big, d_big, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->C.bins_over_maxsearch = big;
+    c->C.aligned_singletons = (uint64_t)S - US;                   // encoder.cpp:506-508
+    c->C.aligned_N = (uint64_t)NN - UN;
+
+    void *tofree[] = { cand3, cand_order, best, d_big, head, u0, u1, d64, gstart, chead, cons, t0, t1, tup0, tup, rid0, rid, f.ref, f.kind, f.g, fidx_orig,
+                       nm, nonN, nonNrank, nmoff, ls, ln, rs, rn, noise, noisepos, posb, rcb, order_out, orderN_out, sing_bases, ntext, packed };
+    for (void *p : tofree) if (p) harc_dev_free(c, p);
+    harc_dict_free(c, &dict[0]); harc_dict_free(c, &dict[1]);
+    return HARC_AMD_OK;
+}
+
+int pack_order_run(harc_amd_ctx *c)
+{
+    auto it = c->out.find(std::make_pair((int)HARC_AMD_S2_ORDER, 0));
+    if (it == c->out.end()) { harc_set_error("pack_order: no read_order.bin"); return HARC_AMD_ESTATE; }
+    const std::vector<uint8_t> &in = it->second;
+    const uint32_t n = (uint32_t)(in.size() / 4);
+    if (n == 0) { harc_set_error("pack_order: empty read_order.bin (the reference evaluates log2(0), pack_order.cpp:36)"); return HARC_AMD_EINVAL; }
+    int numbits = 0; { uint32_t x = n; while (x) { numbits++; x >>= 1; } }        // (int)(log2(n)+1)
+    const uint32_t ng = n / 32;
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    RC_TRY(dalloc(c, &d_in, (size_t)n + 1)); RC_TRY(dalloc(c, &d_out, (size_t)ng * numbits + 1));
+    HIP_TRY(hipMemcpyAsync(d_in, in.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (ng) hipLaunchKernelGGL(k_pack_order, G256((uint64_t)ng * numbits), d_in, ng, numbits, d_out);
+    std::vector<uint8_t> body;
+    RC_TRY(harc_d2h(c, body, d_out, (size_t)ng * numbits * 4));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<uint8_t> &o = out_buf(c, HARC_AMD_P_ORDER, 0);
+    o.resize(8 + body.size());
+    memcpy(o.data(), &numbits, 4); memcpy(o.data() + 4, &n, 4);                   // pack_order.cpp:37-38
+    if (!body.empty()) memcpy(o.data() + 8, body.data(), body.size());
+    put(c, HARC_AMD_P_ORDER_TAIL, 0, in.data() + (size_t)ng * 32 * 4, (size_t)(n % 32) * 4);
+    harc_dev_free(c, d_in); harc_dev_free(c, d_out);
+    return HARC_AMD_OK;
+}

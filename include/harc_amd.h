@@ -1,0 +1,154 @@
+/*
+ * harc_amd.h -- C-ABI of libharc_amd.so: the MI355X (gfx950) implementation of HARC's hash-based read reordering
+ * + reference-delta encoding hot path.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * What each entry point replaces in the reference (file:line into shubhamchandak94/HARC):
+ *
+ *   harc_amd_reorder_files     == `reorder.out <basedir>`      src/reorder.cpp:100-131, invoked at harc:67
+ *   harc_amd_encoder_files     == `encoder.out <basedir>`      src/encoder.cpp:108-152, invoked at harc:69
+ *   harc_amd_pack_order_files  == `pack_order.out <basedir>`   src/pack_order.cpp:11-18, invoked at harc:112
+ *   harc_amd_compress_files    == harc:65-69 fused (stage I -> stage II handed over in HBM, no temp.dna round trip)
+ *   harc_amd_params            == the compile-time macros the bash driver writes to src/config.h (harc:52-63)
+ *
+ *   In-memory API (what a cgo/JNI/ctypes binding of the same path would bind; used by bench.py and the tests):
+ *   harc_amd_create/destroy, harc_amd_set_* (inputs = what reorder.cpp:240-263 readDnaFile / encoder.cpp:823-872
+ *   readsingletons parse), harc_amd_reorder (reorder.cpp:277-703), harc_amd_encode (encoder.cpp:154-616),
+ *   harc_amd_pack_order (pack_order.cpp:20-77), harc_amd_get_stream (the files of reorder.cpp:722-830 and
+ *   encoder.cpp:190-196,457-503 as byte ranges).
+ *
+ * Conventions: every function returns 0 on success, a negative HARC_AMD_E* code otherwise (the reference's
+ * programs return 0 / print a message; the bash driver runs under `set -e`, harc:2).  No exceptions cross the ABI.
+ * Input buffers are caller-owned and may be released after the call returns.  Output buffers returned by
+ * harc_amd_get_stream are library-owned host memory, valid until the next harc_amd_reorder/encode/pack_order on
+ * the same context or harc_amd_destroy.  One context per host thread; one HIP device per context.
+ *
+ * There is NO CPU fallback: every compute entry point fails with HARC_AMD_ENODEVICE when no gfx950 device is usable.
+ */
+#ifndef HARC_AMD_H
+#define HARC_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HARC_AMD_OK 0
+#define HARC_AMD_EINVAL (-1)      /* bad argument / parameter out of range (readlen > 255: harc:46-49, preprocess.cpp:122) */
+#define HARC_AMD_ENODEVICE (-2)   /* no usable HIP device, or a HIP call failed (message via harc_amd_last_error) */
+#define HARC_AMD_EIO (-3)         /* file contract violated (missing / short file) */
+#define HARC_AMD_ESTATE (-4)      /* call order violated (e.g. encode before reorder and without stage-I inputs) */
+#define HARC_AMD_ENOMEM (-5)
+
+/* Runtime equivalent of src/config.h (harc:52-63).  Fill with harc_amd_default_params, then override. */
+typedef struct harc_amd_params {
+    int32_t readlen;          /* `readlen`; 1..255 */
+    int32_t num_thr;          /* `num_thr`: E, the number of encoder shards; visible in the output file suffixes (encoder.cpp:190-196) */
+    int32_t num_chains;       /* K concurrent chains of stage I.  1 reproduces the reference at num_thr=1 byte for byte.
+                                 0 = auto (throughput mode).  The reference's own num_thr>1 is a race (reorder.cpp:545-552);
+                                 K>1 here is the deterministic round-synchronous schedule documented in DESIGN.md. */
+    int32_t maxmatch;         /* `maxmatch` = readlen/2 */
+    int32_t thresh;           /* `thresh` = 4 */
+    int32_t thresh_s;         /* `thresh_s` = 24 */
+    int32_t maxsearch;        /* `maxsearch` = 1000 */
+    int32_t dict_start[2];    /* `dict1_start`,`dict2_start` */
+    int32_t dict_end[2];      /* `dict1_end`,`dict2_end` */
+    int32_t device;           /* HIP device ordinal */
+    int32_t profile;          /* 1: time every launch of the dominant kernel with HIP events on the context's stream */
+    int32_t reserved[4];
+} harc_amd_params;
+
+/* Counters: the three numbers the reference prints (reorder.cpp:701, encoder.cpp:506-508) + kernel-side statistics. */
+typedef struct harc_amd_counters {
+    uint64_t n_clean, n_N;            /* inputs */
+    uint64_t n_main, n_singleton;     /* stage I: reads in temp.dna / temp.dna.singleton */
+    uint64_t unmatched;               /* "Reordering done, X were unmatched" */
+    uint64_t aligned_singletons;      /* "X singleton reads were aligned" */
+    uint64_t aligned_N;               /* "X reads with N were aligned" */
+    uint64_t chains, rounds;          /* stage I schedule */
+    uint64_t probes;                  /* hash-table slots inspected by the chain kernel */
+    uint64_t candidates;              /* candidate reads fetched + Hamming-tested by the chain kernel */
+    uint64_t conflicts;               /* proposals that lost arbitration */
+    uint64_t propose_launches;        /* launches of the dominant kernel (k_propose) */
+    double propose_ms;                /* sum of their HIP-event durations (params.profile=1), else 0 */
+    double index_ms, chain_ms, encode_ms, total_ms;   /* host wall-clock of the phases, stream-synchronised */
+    uint64_t contigs, seq_bases;      /* stage II */
+    uint64_t bins_over_maxsearch;     /* stage-II dictionary bins larger than maxsearch (static window) */
+    uint64_t device_bytes_peak;
+} harc_amd_counters;
+
+/* stream ids for harc_amd_get_stream; names are the reference's file names */
+enum {
+    /* stage I (reorder.cpp:722-830); shard must be 0 */
+    HARC_AMD_S1_ORDER = 0,          /* read_order.bin            u32 per main read */
+    HARC_AMD_S1_FLAG = 1,           /* tempflag.txt              '0'/'1' */
+    HARC_AMD_S1_POS = 2,            /* temppos.txt               u8 */
+    HARC_AMD_S1_RC = 3,             /* read_rev.txt              'd'/'r' */
+    HARC_AMD_S1_ORDER_SINGLETON = 4,/* read_order.bin.singleton  u32 */
+    HARC_AMD_S1_DNA = 5,            /* temp.dna                  text, produced on demand */
+    HARC_AMD_S1_DNA_SINGLETON = 6,  /* temp.dna.singleton        text, produced on demand */
+    /* stage II (encoder.cpp); per shard e in [0,num_thr) */
+    HARC_AMD_S2_SEQ = 10,           /* read_seq.txt.<e>      2-bit packed */
+    HARC_AMD_S2_SEQ_TAIL = 11,      /* read_seq.txt.<e>.tail */
+    HARC_AMD_S2_POS = 12,           /* read_pos.txt.<e> */
+    HARC_AMD_S2_NOISE = 13,         /* read_noise.txt.<e> */
+    HARC_AMD_S2_NOISEPOS = 14,      /* read_noisepos.txt.<e> */
+    HARC_AMD_S2_REV = 15,           /* read_rev.txt.<e>      1-bit packed */
+    HARC_AMD_S2_REV_TAIL = 16,      /* read_rev.txt.<e>.tail */
+    /* stage II, whole job; shard must be 0 */
+    HARC_AMD_S2_ORDER = 20,         /* read_order.bin (post-encode; encoder.cpp:458-500) */
+    HARC_AMD_S2_ORDER_N_PE = 21,    /* read_order_N_pe.bin */
+    HARC_AMD_S2_SINGLETON = 22,     /* read_singleton.txt    2-bit packed */
+    HARC_AMD_S2_SINGLETON_TAIL = 23,/* read_singleton.txt.tail */
+    HARC_AMD_S2_INPUT_N = 24,       /* input_N.dna rewritten: unaligned N reads (encoder.cpp:493-499) */
+    HARC_AMD_S2_META = 25,          /* read_meta.txt */
+    /* -p (pack_order.cpp) */
+    HARC_AMD_P_ORDER = 30,          /* read_order.bin packed */
+    HARC_AMD_P_ORDER_TAIL = 31      /* read_order.bin.tail */
+};
+
+typedef struct harc_amd_ctx harc_amd_ctx;
+
+/* harc:52-60 formulae.  num_thr=8 (harc:195), num_chains=0 (auto). */
+int harc_amd_default_params(int32_t readlen, harc_amd_params *out);
+
+int harc_amd_create(const harc_amd_params *params, harc_amd_ctx **out);
+void harc_amd_destroy(harc_amd_ctx *ctx);
+const char *harc_amd_last_error(void);
+
+/* ---- inputs.  Clean reads = the lines of input_clean.dna (alphabet ACGT, preprocess.cpp:104-108). */
+/* host ASCII; read i starts at ascii + i*stride (stride = readlen+1 for the file layout, reorder.cpp:252) */
+int harc_amd_set_reads_ascii(harc_amd_ctx *ctx, const char *ascii, uint32_t n_reads, uint32_t stride);
+/* same, buffer already in device memory of params.device */
+int harc_amd_set_reads_ascii_device(harc_amd_ctx *ctx, const char *d_ascii, uint32_t n_reads, uint32_t stride);
+/* device buffer of n_reads * ceil(2*readlen/64) little-endian u64 words in std::bitset<2*readlen> layout
+   (reorder.cpp:184-198: base i at bits 2i,2i+1, A=0 G=1 C=2 T=3); the buffer is copied */
+int harc_amd_set_reads_packed_device(harc_amd_ctx *ctx, const uint64_t *d_packed, uint32_t n_reads);
+/* reads containing N = the lines of input_N.dna (preprocess.cpp:98-103); host ASCII */
+int harc_amd_set_nreads_ascii(harc_amd_ctx *ctx, const char *ascii, uint32_t n_reads, uint32_t stride);
+int harc_amd_set_nreads_ascii_device(harc_amd_ctx *ctx, const char *d_ascii, uint32_t n_reads, uint32_t stride);
+/* stage-II inputs when stage I ran elsewhere (the file family of reorder.cpp:722-830): host buffers.
+   dna/dna_s are text with stride readlen+1 */
+int harc_amd_set_stage1_streams(harc_amd_ctx *ctx, const char *temp_dna, const uint8_t *flag, const uint8_t *pos,
+                                const uint32_t *order, const uint8_t *rc, uint32_t n_main,
+                                const char *temp_dna_singleton, const uint32_t *order_singleton, uint32_t n_singleton);
+
+/* ---- compute (all on params.device, asynchronous internally, synchronised before return) */
+int harc_amd_reorder(harc_amd_ctx *ctx);      /* index build + chaining: reorder.cpp:277-703 */
+int harc_amd_encode(harc_amd_ctx *ctx);       /* encoder.cpp:154-616 on the stage-I result held in HBM (or set_stage1_streams) */
+int harc_amd_pack_order(harc_amd_ctx *ctx);   /* pack_order.cpp:20-77 on HARC_AMD_S2_ORDER */
+
+/* ---- outputs */
+int harc_amd_get_stream(harc_amd_ctx *ctx, int32_t stream_id, int32_t shard, const void **ptr, size_t *len);
+int harc_amd_get_counters(harc_amd_ctx *ctx, harc_amd_counters *out);
+
+/* ---- file contract: drop-ins for the reference's stage programs.  basedir as argv[1] of those programs. */
+int harc_amd_reorder_files(const harc_amd_params *params, const char *basedir);
+int harc_amd_encoder_files(const harc_amd_params *params, const char *basedir);
+int harc_amd_compress_files(const harc_amd_params *params, const char *basedir);
+int harc_amd_pack_order_files(const harc_amd_params *params, const char *basedir);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HARC_AMD_H */

@@ -1,0 +1,39 @@
+"""Seeded synthetic read generator for the tests (numpy RandomState is stable across numpy versions).
+Same spirit as the reference's util/gen_fastq_noRC (uniform read starts on an i.i.d. genome; -e: 1 % substitutions of which
+a quarter become N, gen_fastq_noRC.cpp:67-71,119-130) plus reverse-complemented odd reads as util/gen_fastq."""
+import numpy as np
+
+_COMP = np.zeros(256, dtype=np.uint8)
+for a, b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[a] = b
+
+
+def reads_array(seed, n, L, genome_len, err=0.0, rc=True, n_frac=0.25):
+    """-> uint8 array [n, L] of ASCII bases"""
+    rs = np.random.RandomState(seed)
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rs.randint(0, 4, size=genome_len)]
+    starts = rs.randint(0, genome_len - L, size=n)
+    idx = starts[:, None] + np.arange(L)[None, :]
+    r = genome[idx].copy()
+    if err > 0:
+        e = rs.random_sample((n, L)) < err
+        isN = e & (rs.random_sample((n, L)) < n_frac)
+        sub = e & ~isN
+        code = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), r)
+        newcode = (code + rs.randint(1, 4, size=(n, L))) % 4
+        r[sub] = np.frombuffer(b"ACGT", dtype=np.uint8)[newcode[sub]]
+        r[isN] = ord("N")
+    if rc:
+        odd = np.arange(n) % 2 == 1
+        r[odd] = _COMP[r[odd][:, ::-1]]
+    return r
+
+
+def reads_text(*a, **kw):
+    """-> bytes: one read per line"""
+    r = reads_array(*a, **kw)
+    n, L = r.shape
+    out = np.empty((n, L + 1), dtype=np.uint8)
+    out[:, :L] = r
+    out[:, L] = 10
+    return out.tobytes()

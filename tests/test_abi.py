@@ -1,0 +1,45 @@
+"""CPU-side checks of the drop-in boundary: libharc_amd.so loads, exports every symbol include/harc_amd.h declares,
+fills the reference's parameter formulae (harc:52-60), and refuses to compute without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import harc_amd
+    hdr = open(os.path.join(ROOT, "include", "harc_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(harc_amd_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 18
+    l = harc_amd.lib()
+    for name in declared:
+        assert hasattr(l, name), f"{name} declared in include/harc_amd.h but not exported"
+
+
+@pytest.mark.parametrize("L,d1,d2", [(100, (18, 49), (50, 81)), (150, (43, 74), (75, 106)), (40, (8, 19), (20, 31)), (101, (18, 49), (50, 81)),
+                                      (63, (11, 30), (31, 50)), (255, (95, 126), (127, 158))])
+def test_default_params_follow_harc_driver(L, d1, d2):
+    import harc_amd
+    p = harc_amd.default_params(L)
+    assert (p.dict_start[0], p.dict_end[0]) == d1 and (p.dict_start[1], p.dict_end[1]) == d2
+    assert p.maxmatch == L // 2 and p.thresh == 4 and p.thresh_s == 24 and p.maxsearch == 1000 and p.num_thr == 8
+
+
+def test_readlen_limits():
+    import harc_amd
+    for bad in (0, 256, 1000, -3):
+        with pytest.raises(harc_amd.HarcAmdError):
+            harc_amd.default_params(bad)
+
+
+def test_no_cpu_fallback():
+    import torch
+    import harc_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(harc_amd.HarcAmdError) as e:
+        harc_amd.HarcAmd(harc_amd.default_params(100))
+    assert e.value.code == -2

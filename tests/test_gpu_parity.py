@@ -1,0 +1,143 @@
+"""GPU parity tests proper (run with -m gpu on an MI355X): libharc_amd.so through its C-ABI file contract vs
+ (P1) the golden vectors of the REAL reference at num_thr=1 (K=1, E=1), byte for byte;
+ (P4) the reference's own stage-I files fed to the HIP encoder;
+ (P2) the CPU oracle for K>1 chains / E>1 shards on the same seeded inputs, byte for byte;
+ (P3) decode round trips at larger sizes."""
+import ctypes as C
+import os
+
+import pytest
+
+from tests import gen
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+CASES = ol.golden_cases()
+
+
+def _L(g):
+    return len(g["reads.txt"].split(b"\n")[0])
+
+
+def _diff(name, a, b):
+    if a == b:
+        return None
+    n = min(len(a), len(b))
+    first = next((i for i in range(n) if a[i] != b[i]), n)
+    return f"{name}: len {len(a)} vs {len(b)}, first difference at byte {first}: {a[first:first+16]!r} vs {b[first:first+16]!r}"
+
+
+def assert_same(got, want, files, what):
+    errs = [d for d in (_diff(f, got.get(f, b"<missing>"), want[f]) for f in files) if d]
+    assert not errs, what + "\n" + "\n".join(errs)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_stage1_K1_matches_reference(case, tmp_path):
+    import harc_amd
+    g = ol.load_golden(case)
+    base = ol.stage_dir(tmp_path, {k: g["stage1/" + k] for k in ["input_clean.dna", "numreads.bin"]})
+    harc_amd.reorder(base, _L(g), num_chains=1)
+    assert_same(ol.read_dir(base), {f: g["stage1/" + f] for f in ol.STAGE1_FILES}, ol.STAGE1_FILES, f"{case}: stage I vs reference -t 1")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_stage2_E1_on_reference_stage1_files(case, tmp_path):
+    import harc_amd
+    g = ol.load_golden(case)
+    base = ol.stage_dir(tmp_path, {k[len("stage1/"):]: v for k, v in g.items() if k.startswith("stage1/")})
+    harc_amd.encoder(base, _L(g), num_thr=1)
+    fs = ol.stage2_files(1)
+    assert_same(ol.read_dir(base), {f: g["stage2/" + f] for f in fs}, fs, f"{case}: stage II vs reference -t 1")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fused_compress_and_pack_order_match_reference(case, tmp_path):
+    import harc_amd
+    g = ol.load_golden(case)
+    base = ol.stage_dir(tmp_path, {k: g["stage1/" + k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.compress(base, _L(g), num_thr=1, num_chains=1)
+    fs = ol.stage2_files(1)
+    got = ol.read_dir(base)
+    assert_same(got, {f: g["stage2/" + f] for f in fs}, fs, f"{case}: fused compress vs reference -t 1")
+    if "packed/read_order.bin" in g:
+        harc_amd.pack_order(base, _L(g))
+        got = ol.read_dir(base)
+        assert got["read_order.bin"] == g["packed/read_order.bin"]
+        assert got["read_order.bin.tail"] == g["packed/read_order.bin.tail"]
+    else:
+        with pytest.raises(harc_amd.HarcAmdError):
+            harc_amd.pack_order(base, _L(g))
+
+
+def _oracle_pipeline(oracle, reads_txt, L, K, E, d):
+    base = ol.stage_dir(d, {})
+    assert oracle.harc_oracle_preprocess(reads_txt, len(reads_txt), L, base.encode()) == 0
+    inputs = ol.read_dir(base)
+    assert oracle.harc_oracle_reorder(base.encode(), L, K, None, None) == 0
+    s1 = ol.read_dir(base)
+    assert oracle.harc_oracle_encoder(base.encode(), L, E, None, None) == 0
+    return inputs, s1, ol.read_dir(base), base
+
+
+@pytest.mark.parametrize("case,K,E", [("L100_err_5k", 4, 3), ("L100_err_5k", 64, 8), ("L150_err_3k", 16, 2), ("L63_err_3k", 7, 5),
+                                        ("L100_repeat_dup_4k", 32, 4), ("L100_three", 8, 8), ("L100_allN_20", 2, 2),
+                                        ("L255_err_1k", 5, 3), ("L100_lowcov_4k", 128, 1), ("L40_err_3k", 300, 2), ("L101_err_3k", 9, 4)])
+def test_K_chains_E_shards_match_oracle(case, K, E, oracle, tmp_path):
+    import harc_amd
+    g = ol.load_golden(case)
+    L = _L(g)
+    (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, g["reads.txt"], L, K, E, tmp_path / "o")
+    base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.reorder(base, L, num_chains=K)
+    assert_same(ol.read_dir(base), s1, ol.STAGE1_FILES, f"{case} K={K}: stage I vs oracle")
+    harc_amd.encoder(base, L, num_thr=E)
+    fs = ol.stage2_files(E)
+    assert_same(ol.read_dir(base), s2, fs, f"{case} K={K} E={E}: stage II vs oracle")
+
+
+@pytest.mark.parametrize("n,L,glen,err,K,E", [(60000, 100, 300000, 0.01, 64, 8), (40000, 100, 2000000, 0.0, 40, 3), (30000, 150, 200000, 0.01, 0, 8)])
+def test_medium_vs_oracle_and_roundtrip(n, L, glen, err, K, E, oracle, tmp_path):
+    import harc_amd
+    txt = gen.reads_text(1234 + n, n, L, glen, err=err)
+    (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
+    Ko = K if K else max(1, (txt.count(b"\n") - sum(1 for l in txt.split(b"\n") if b"N" in l)) // 1024)
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, L, Ko, E, tmp_path / "o")
+    base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.compress(base, L, num_thr=E, num_chains=K)
+    fs = ol.stage2_files(E)
+    assert_same(ol.read_dir(base), s2, fs, "fused compress vs oracle")
+    assert oracle.harc_oracle_decoder(base.encode(), E) == 0
+    assert sorted(ol.read_dir(base)["output.dna"].split()) == sorted(txt.split())
+
+
+def test_in_memory_api_and_counters(oracle, tmp_path):
+    import harc_amd
+    g = ol.load_golden("L100_err_5k")
+    clean, withN = g["stage1/input_clean.dna"], g["stage1/input_N.dna"]
+    p = harc_amd.default_params(100, num_thr=1, num_chains=1, profile=1)
+    with harc_amd.HarcAmd(p) as h:
+        h.set_reads_ascii(clean, len(clean) // 101, 101)
+        h.set_nreads_ascii(withN, len(withN) // 101, 101)
+        h.reorder()
+        assert h.stream("S1_ORDER") == g["stage1/read_order.bin"]
+        assert h.stream("S1_DNA") == g["stage1/temp.dna"]
+        h.encode()
+        assert h.stream("S2_SEQ", 0) == g["stage2/read_seq.txt.0"]
+        assert h.stream("S2_NOISE", 0) == g["stage2/read_noise.txt.0"]
+        h.pack_order()
+        assert h.stream("P_ORDER") == g["packed/read_order.bin"]
+        c = h.counters()
+        assert c.unmatched == 346 and c.aligned_singletons == 239 and c.aligned_N == 979      # the reference's printed counters
+        assert c.propose_launches > 0 and c.propose_ms > 0 and c.probes > 0
+
+
+def test_bad_arguments_fail_loudly():
+    import harc_amd
+    with pytest.raises(harc_amd.HarcAmdError):
+        harc_amd.default_params(256)          # harc:46-49 / decoder.cpp:93: readlen 256 is not representable
+    p = harc_amd.default_params(100)
+    with harc_amd.HarcAmd(p) as h:
+        with pytest.raises(harc_amd.HarcAmdError):
+            h.encode()                        # no stage-I result yet
