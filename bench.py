@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- Mreads/s of HARC reorder+encode (100 bp) on 1/2/4/8 MI355X, with the roofline of the dominant kernel and
+the reference's CPU path timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c1|mini] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over the synthetic batch: index build + chaining (reorder.cpp:277-703) + encoding
+(encoder.cpp:154-616), from 2-bit packed reads resident in HBM to every stage-II stream resident in host memory.
+N>1: every rank owns a batch of the same size drawn from a genome N times larger (weak scaling); reads are sharded
+by a canonical-minimizer bucket with ONE all-to-all over xGMI (RCCL), then each GPU chains and encodes its shard
+independently (BASELINE.json north_star; DESIGN.md "Multi-GPU").  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (device memory, streams and torch.distributed only)
+
+WORKLOADS = {
+    # name: (reads per GPU, read length, genome bp per GPU, error rate, description == BASELINE.json config)
+    "c2": (3_300_000, 100, 6_300_000, 0.005, "configs[1] stand-in: 3.3M x 100bp, 6.3 Mbp i.i.d. genome (~52x), 0.5% substitutions (1/4 N), odd reads RC"),
+    "c3": (350_000_000, 100, 3_100_000_000, 0.0, "configs[2] stand-in: 350M x 100bp error-free, 3.1 Gbp i.i.d. genome (11.3x), odd reads RC"),
+    "c3s": (50_000_000, 100, 443_000_000, 0.0, "configs[2] at 1/7 scale: 50M x 100bp error-free, 443 Mbp i.i.d. genome (11.3x)"),
+    "c1": (1_000_000, 100, 35_000_000, 0.0, "configs[0] stand-in: 1M x 100bp error-free, 35 Mbp i.i.d. genome (2.9x)"),
+    "mini": (200_000, 100, 400_000, 0.005, "smoke-sized: 200k x 100bp, 0.4 Mbp genome"),
+}
+
+
+def synth_reads(n, L, G, err, seed, dev):
+    """[n, L] uint8 ASCII reads: uniform starts on an i.i.d. genome, substitutions (a quarter become N, as
+    gen_fastq_noRC.cpp:67-71), odd reads reverse-complemented (gen_fastq.cpp:105-113)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242 + G)                                      # the genome is the same on every rank
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    genome = torch.empty(G, dtype=torch.uint8, device=dev)
+    for s in range(0, G, 1 << 28):
+        m = min(1 << 28, G - s)
+        genome[s:s + m] = lut[torch.randint(0, 4, (m,), generator=g, device=dev)]
+    g.manual_seed(seed)                                          # the reads differ per rank
+    out = torch.empty((n, L), dtype=torch.uint8, device=dev)
+    ar = torch.arange(L, device=dev)
+    CH = 4_000_000
+    for s in range(0, n, CH):
+        m = min(CH, n - s)
+        st = torch.randint(0, G - L, (m,), generator=g, device=dev)
+        r = genome[st[:, None] + ar[None, :]]
+        if err > 0:
+            e = torch.rand((m, L), generator=g, device=dev) < err
+            isN = e & (torch.rand((m, L), generator=g, device=dev) < 0.25)
+            code = torch.searchsorted(lut, r)
+            nc = (code + torch.randint(1, 4, (m, L), generator=g, device=dev)) % 4
+            r = torch.where(e & ~isN, lut[nc], r)
+            r = torch.where(isN, torch.full_like(r, ord("N")), r)
+        odd = (torch.arange(s, s + m, device=dev) % 2) == 1
+        r = torch.where(odd[:, None], comp[r.flip(1).long()], r)
+        out[s:s + m] = r
+    del genome
+    return out
+
+
+def cpu_baseline(n_sample, L, G_sample, err, seed, dev):
+    """The reference itself (oracle/_ref, built from /root/reference by oracle/build_ref.sh) timed on this box's host cores on
+    a bounded sample of the workload; falls back to the C port (oracle/liboracle.so) when the prebuilt reference is absent."""
+    ncpu = os.cpu_count() or 1
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    reads = synth_reads(n_sample, L, G_sample, err, seed, dev).cpu().numpy()
+    hasN = (reads == ord("N")).any(1)
+    import numpy as np
+    nl = np.full((reads.shape[0], 1), 10, dtype=np.uint8)
+    lines = np.concatenate([reads, nl], axis=1)
+    clean, withN = lines[~hasN], lines[hasN]
+    thr = max([t for t in (1, 8, 16, 32, 64) if t <= ncpu and os.path.exists(os.path.join(refdir, f"reorder_L{L}_t{t}.out"))], default=0)
+    tmp = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmp, prefix="harc_cpu_") as d:
+        od = os.path.join(d, "output")
+        os.makedirs(od)
+        clean.tofile(os.path.join(od, "input_clean.dna"))
+        withN.tofile(os.path.join(od, "input_N.dna"))
+        np.array([clean.shape[0]], dtype=np.uint32).tofile(os.path.join(od, "numreads.bin"))
+        if thr:
+            t0 = time.time()
+            subprocess.check_call([os.path.join(refdir, f"reorder_L{L}_t{thr}.out"), d], cwd=d, stdout=subprocess.DEVNULL)
+            subprocess.check_call([os.path.join(refdir, f"encoder_L{L}_t{thr}.out"), d], cwd=d, stdout=subprocess.DEVNULL)
+            dt = time.time() - t0
+            kind, cores = "reference", thr
+        else:
+            from tests import oracle_lib as ol
+            o = ol.load()
+            t0 = time.time()
+            assert o.harc_oracle_reorder(d.encode(), L, 1, None, None) == 0
+            assert o.harc_oracle_encoder(d.encode(), L, 1, None, None) == 0
+            dt = time.time() - t0
+            kind, cores = "port", 1
+    return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": kind,
+            "sample": f"{n_sample} reads of the same generator on a {G_sample} bp genome (same coverage and error rate), "
+                      f"reorder+encode wall {dt:.1f}s" + (f", ./harc -t {thr} stage programs" if thr else ", scalar C port")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("HARC_BENCH_WORKLOAD", "c2"))
+    ap.add_argument("--chains", type=int, default=0)
+    ap.add_argument("--shards", type=int, default=8, help="num_thr of the reference = encoder shards per GPU (harc:195 default 8)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libharc_amd has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)        # nccl == RCCL on ROCm
+
+    import harc_amd
+    n, L, G, err, desc = WORKLOADS[args.workload]
+    # weak scaling: same reads per GPU, genome (and so coverage) per GPU constant; every rank samples the WHOLE genome
+    reads = synth_reads(n, L, G * world, err, 1000 + rank, dev)
+    hasN = (reads == ord("N")).any(1)
+    clean = reads[~hasN].contiguous()
+    withN = reads[hasN].contiguous()
+    del reads, hasN
+    p = harc_amd.default_params(L, num_thr=args.shards, num_chains=args.chains, device=local, profile=1)
+    h = harc_amd.HarcAmd(p)
+    sharder = None
+    if world > 1:
+        from harc_amd import multigpu
+        sharder = multigpu.BucketSharder(h, dist, dev, L)
+        packed = sharder.pack(clean)                              # local 2-bit reads, resident in HBM before the clock starts
+        del clean
+    else:
+        h.set_reads_ascii_device(clean.data_ptr(), clean.shape[0], L)
+        del clean
+    h.set_nreads_ascii_device(withN.data_ptr(), withN.shape[0], L)
+    torch.cuda.synchronize()
+
+    def step():
+        if sharder is not None:
+            sharder.exchange_and_set(packed)                      # bucket -> one all-to-all(v) over xGMI -> this GPU's shard
+        h.reorder()
+        h.encode()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    agg = dict(propose_ms=0.0, launches=0, steps_alg=0, useful=0, cands=0, probes=0, rounds=0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        c = h.counters()
+        agg["propose_ms"] += c.propose_ms
+        agg["launches"] += c.propose_launches
+        agg["cands"] += c.candidates
+        agg["probes"] += c.probes
+        agg["useful"] += c.useful_probes
+        agg["rounds"] += c.rounds
+        agg["steps_alg"] += c.n_clean
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    c = h.counters()
+    total_reads = n * world * args.steps
+    value = total_reads / dt / 1e6
+
+    # roofline of the dominant kernel k_propose (DESIGN.md "Kernels"): algorithmic bytes of SURVEY.md 8(d)'s chain step
+    #   49 B/read (removals 40 + claim 2 + outputs 7) + 16 B per dictionary lookup of a strictly sequential scan (L-bar, counted by
+    #   the kernel as `useful_probes`; the speculative lookups of the 64-lane batches are NOT counted) + 36 B per candidate (id + 32 B read)
+    alg_bytes = 49.0 * agg["steps_alg"] + 16.0 * agg["useful"] + 36.0 * agg["cands"]
+    launches = max(1, agg["launches"])
+    avg_ms = agg["propose_ms"] / launches
+    achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"kernel": "k_propose", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 5), "traffic": None,
+                "avg_launch_us": round(avg_ms * 1e3, 2), "launches": launches,
+                "alg_bytes_per_launch": round(alg_bytes / launches, 1),
+                "Lbar_sequential_lookups_per_read": round(agg["useful"] / max(1, agg["steps_alg"]), 2),
+                "slots_inspected_per_read": round(agg["probes"] / max(1, agg["steps_alg"]), 2),
+                "candidates_per_read": round(agg["cands"] / max(1, agg["steps_alg"]), 3),
+                "Gslots_per_s": round(agg["probes"] / (agg["propose_ms"] * 1e-3) / 1e9, 2) if agg["propose_ms"] > 0 else None,
+                "note": "random-access regime: 16-B slots and 32-B reads fetched as >=64-B sectors; see DESIGN.md"}
+    out = {
+        "metric": "Mreads/s reorder+encode, 100 bp", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64 (2-bit packed bases, XOR+popcount)", "data": "synthetic",
+        "config": {"workload": args.workload, "description": desc, "reads_per_gpu": n, "readlen": L, "genome_bp": G * world,
+                   "error_rate": err, "chains_per_gpu": int(c.chains), "encoder_shards_per_gpu": args.shards,
+                   "parallelism": "single GPU" if world == 1 else f"minimizer-bucket shard x{world}, one RCCL all-to-all"},
+        "roofline": roofline,
+        "phases_ms_last_step": {"index": round(c.index_ms, 2), "chain": round(c.chain_ms, 2), "encode": round(c.encode_ms, 2)},
+        "counters_last_step": {"unmatched": int(c.unmatched), "singletons_aligned": int(c.aligned_singletons), "N_aligned": int(c.aligned_N),
+                               "rounds": int(c.rounds), "conflicts": int(c.conflicts), "contigs": int(c.contigs),
+                               "seq_bases": int(c.seq_bases), "device_bytes_peak": int(c.device_bytes_peak)},
+    }
+    if rank == 0 and not args.no_cpu:
+        ns = args.cpu_sample or min(n, 3_300_000 if err > 0 or G // max(1, n) < 10 else 1_000_000)
+        Gs = max(L * 4, int(G * (ns / n)))
+        out["cpu_baseline"] = cpu_baseline(ns, L, Gs, err, 999, dev)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,7 @@ class Counters(C.Structure):
                 ("conflicts", C.c_uint64), ("propose_launches", C.c_uint64), ("propose_ms", C.c_double),
                 ("index_ms", C.c_double), ("chain_ms", C.c_double), ("encode_ms", C.c_double), ("total_ms", C.c_double),
                 ("contigs", C.c_uint64), ("seq_bases", C.c_uint64), ("bins_over_maxsearch", C.c_uint64),
-                ("device_bytes_peak", C.c_uint64)]
+                ("device_bytes_peak", C.c_uint64), ("useful_probes", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -67,6 +67,8 @@ def lib():
     l.harc_amd_set_nreads_ascii_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32]
     l.harc_amd_set_stage1_streams.argtypes = [ctx, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32,
                                               C.c_char_p, C.c_char_p, C.c_uint32]
+    l.harc_amd_pack_reads_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    l.harc_amd_bucket_reads_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     for f in ("harc_amd_reorder", "harc_amd_encode", "harc_amd_pack_order"):
         getattr(l, f).argtypes = [ctx]
     l.harc_amd_get_stream.argtypes = [ctx, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -153,6 +155,12 @@ class HarcAmd:
 
     def set_nreads_ascii_device(self, dptr, n, stride):
         _check(lib().harc_amd_set_nreads_ascii_device(self._ctx, C.c_void_p(dptr), n, stride))
+
+    def pack_reads_device(self, d_ascii, n, stride, d_out):
+        _check(lib().harc_amd_pack_reads_device(self._ctx, C.c_void_p(d_ascii), n, stride, C.c_void_p(d_out)))
+
+    def bucket_reads_device(self, d_packed, n, n_buckets, d_out):
+        _check(lib().harc_amd_bucket_reads_device(self._ctx, C.c_void_p(d_packed), n, n_buckets, C.c_void_p(d_out)))
 
     def reorder(self):
         _check(lib().harc_amd_reorder(self._ctx))

@@ -206,6 +206,23 @@ extern "C" int harc_amd_set_stage1_streams(harc_amd_ctx *c, const char *temp_dna
     return HARC_AMD_OK;
 }
 
+extern "C" int harc_amd_pack_reads_device(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride, uint64_t *d_out)
+{
+    if (!c || (n && (!d_ascii || !d_out)) || stride < (uint32_t)c->P.readlen) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    RC_TRY(s1_pack_ascii(c, d_ascii, n, stride, d_out));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HARC_AMD_OK;
+}
+extern "C" int harc_amd_bucket_reads_device(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint32_t *d_out)
+{
+    if (!c || nb == 0 || (n && (!d_packed || !d_out))) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    RC_TRY(s1_bucket_reads(c, d_packed, n, nb, d_out));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HARC_AMD_OK;
+}
+
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 extern "C" int harc_amd_reorder(harc_amd_ctx *c)

@@ -39,8 +39,7 @@ struct ChainHdr {
     uint32_t upd;       // consensus update owed to the next propose launch: kind<<16 | dir<<8 | shift ; kind 0 none, 1 match, 2 reset
     uint32_t n_main;    // records emitted to the main stream so far
     uint32_t n_sing;    // records emitted to the singleton stream so far
-    uint32_t nprobe;    // statistics
-    uint32_t ncand;
+    uint32_t pad0, pad1;
 };
 #define CH_ACTIVE 1u
 #define CH_PREVUNM 2u
@@ -114,6 +113,7 @@ int prim_incl_max_u32(harc_amd_ctx *c, const uint32_t *in, uint32_t *out, size_t
 int s1_pack_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride, uint64_t *d_out);               // 2-bit
 int s1_pack3_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride, uint64_t *d_out);              // 3-bit
 int s1_unpack_to_ascii(harc_amd_ctx *c, const uint64_t *d_reads, uint32_t n, char *d_out);                           // n x (L+1) text
+int s1_bucket_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint32_t *d_out);
 int stage1_run(harc_amd_ctx *c);
 int stage1_make_oriented(harc_amd_ctx *c);      // d_oreads from d_reads/d_order/d_rc
 int s1_orient(harc_amd_ctx *c, const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, uint64_t *out);

@@ -33,8 +33,9 @@ struct S1Args {
     unsigned long long *stats;       // [0] unmatched [1] conflicts [2] active chains [3] probes [4] candidates
     const uint16_t *probe_tab;       // the probes of one chain step in priority order: shift | dir<<8 | dict<<9
     int nprobe;
+    uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups
 };
-enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_N = 8 };
+enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_USEFUL = 5, ST_N = 8 };
 
 // ------------------------------------------------------------------------------------------------ packing kernels
 // ASCII -> std::bitset<2L> words (reorder.cpp:184-209). One thread per (read, word).
@@ -108,6 +109,31 @@ int s1_unpack_to_ascii(harc_amd_ctx *c, const uint64_t *d_reads, uint32_t n, cha
     if (!n) return HARC_AMD_OK;
     const size_t tot = (size_t)n * c->W;
     hipLaunchKernelGGL(k_unpack2, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, d_reads, n, c->P.readlen, c->W, d_out);
+    HIP_TRY(hipGetLastError());
+    return HARC_AMD_OK;
+}
+
+// multi-GPU shard key: hash of the canonical minimizer (k=15) of the whole read, modulo the number of GPUs.  One thread per read.
+__global__ void k_bucket(const uint64_t *reads, uint32_t n, int L, int W, uint32_t nb, uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t *r = reads + (size_t)i * W;
+    const int K = L < 15 ? L : 15;
+    const uint64_t kmask = (K < 32) ? (((uint64_t)1 << (2 * K)) - 1) : ~(uint64_t)0;
+    uint64_t fw = 0, rv = 0, best = ~(uint64_t)0;
+    for (int b = 0; b < L; b++) {
+        const uint64_t pc = (r[b >> 5] >> (2 * (b & 31))) & 3;
+        fw = ((fw << 2) | pc) & kmask;
+        rv = (rv >> 2) | ((3 - pc) << (2 * (K - 1)));
+        if (b >= K - 1) { const uint64_t h = mix64(fw < rv ? fw : rv); best = h < best ? h : best; }
+    }
+    out[i] = (uint32_t)(best % nb);
+}
+int s1_bucket_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint32_t *d_out)
+{
+    if (!n) return HARC_AMD_OK;
+    hipLaunchKernelGGL(k_bucket, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_packed, n, c->P.readlen, c->W, nb, d_out);
     HIP_TRY(hipGetLastError());
     return HARC_AMD_OK;
 }
@@ -243,7 +269,7 @@ template <int W> __global__ __launch_bounds__(256) void k_propose(S1Args s)
     rc_words<W>(ref, L, rref);
 
     uint32_t found = HARC_NONE; int fj = 0, fdir = 0;
-    uint32_t np = 0, nc = 0;
+    uint32_t np = 0, nc = 0, nuse = (uint32_t)s.nprobe;
     for (int base = 0; base < s.nprobe; base += 64) {
         const int p = base + lane;
         uint32_t mine = HARC_NONE; int j = 0, dir = 0;
@@ -297,12 +323,13 @@ template <int W> __global__ __launch_bounds__(256) void k_propose(S1Args s)
         if (m) {
             const int srcl = __ffsll((long long)m) - 1;
             found = __shfl(mine, srcl, 64); fj = __shfl(j, srcl, 64); fdir = __shfl(dir, srcl, 64);
+            nuse = (uint32_t)(base + srcl + 1);
             break;
         }
     }
     np = wave_sum_u32(np); nc = wave_sum_u32(nc);
     if (lane == 0) {
-        h.nprobe += np; h.ncand += nc;
+        uint4 st = s.cstat[c]; st.x += np; st.y += nc; st.z += nuse; s.cstat[c] = st;
         s.hdr[c] = h;
         s.prop[c] = make_uint2(found, (uint32_t)fj | ((uint32_t)fdir << 8));
         if (found != HARC_NONE) atomicMin(&s.bid[found], c);
@@ -433,13 +460,17 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
 }
 
 // ------------------------------------------------------------------------------------------------ finalisation
-__global__ void k_chain_counts(const ChainHdr *hdr, uint32_t K, uint32_t *nmain, uint32_t *nsing, unsigned long long *stats)
+__global__ void k_chain_counts(const ChainHdr *hdr, const uint4 *cstat, uint32_t K, uint32_t *nmain, uint32_t *nsing, unsigned long long *stats)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t np = 0, nc = 0;
-    if (c < K) { nmain[c] = hdr[c].n_main; nsing[c] = hdr[c].n_sing; np = hdr[c].nprobe; nc = hdr[c].ncand; }
-    np = wave_sum_u32(np); nc = wave_sum_u32(nc);
-    if ((threadIdx.x & 63) == 0) { if (np) atomicAdd(&stats[ST_PROBES], (unsigned long long)np); if (nc) atomicAdd(&stats[ST_CANDS], (unsigned long long)nc); }
+    uint32_t np = 0, nc = 0, nu = 0;
+    if (c < K) { nmain[c] = hdr[c].n_main; nsing[c] = hdr[c].n_sing; const uint4 st = cstat[c]; np = st.x; nc = st.y; nu = st.z; }
+    np = wave_sum_u32(np); nc = wave_sum_u32(nc); nu = wave_sum_u32(nu);
+    if ((threadIdx.x & 63) == 0) {
+        if (np) atomicAdd(&stats[ST_PROBES], (unsigned long long)np);
+        if (nc) atomicAdd(&stats[ST_CANDS], (unsigned long long)nc);
+        if (nu) atomicAdd(&stats[ST_USEFUL], (unsigned long long)nu);
+    }
 }
 // per-chain streams concatenated in chain order (reorder.cpp:778-821)
 __global__ void k_s1_scatter(const LogRec *log, unsigned long long nlog, const uint32_t *base_main, const uint32_t *base_sing,
@@ -562,6 +593,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.ref, (size_t)K * W)); RC_TRY(dalloc(c, &a.prop, K));
     RC_TRY(dalloc(c, &a.log, (size_t)N + 1)); RC_TRY(dalloc(c, &a.logcount, 1)); RC_TRY(dalloc(c, &a.blockcnt, nblk));
     RC_TRY(dalloc(c, &a.needseg, (size_t)nblk * 256)); RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N));
+    RC_TRY(dalloc(c, &a.cstat, K)); HIP_TRY(hipMemsetAsync(a.cstat, 0, (size_t)K * 16, c->stream));
     std::vector<uint16_t> tab = make_probe_table(P);
     uint16_t *d_tab = nullptr; RC_TRY(dalloc(c, &d_tab, tab.size() + 1));
     HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream));
@@ -605,7 +637,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     uint32_t *nmain = nullptr, *nsing = nullptr, *bmain = nullptr, *bsing = nullptr;
     RC_TRY(dalloc(c, &nmain, (size_t)K + 1)); RC_TRY(dalloc(c, &nsing, (size_t)K + 1)); RC_TRY(dalloc(c, &bmain, (size_t)K + 1)); RC_TRY(dalloc(c, &bsing, (size_t)K + 1));
     HIP_TRY(hipMemsetAsync(nmain, 0, ((size_t)K + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(nsing, 0, ((size_t)K + 1) * 4, c->stream));
-    hipLaunchKernelGGL(k_chain_counts, dim3(nblk), dim3(256), 0, c->stream, a.hdr, K, nmain, nsing, a.stats);
+    hipLaunchKernelGGL(k_chain_counts, dim3(nblk), dim3(256), 0, c->stream, a.hdr, a.cstat, K, nmain, nsing, a.stats);
     RC_TRY(prim_excl_scan_u32(c, nmain, bmain, (size_t)K + 1));
     RC_TRY(prim_excl_scan_u32(c, nsing, bsing, (size_t)K + 1));
     uint32_t M = 0, S = 0; unsigned long long nlog = 0;
@@ -624,7 +656,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
 
     c->C.n_main = M; c->C.n_singleton = S; c->C.unmatched = h_stats[ST_UNMATCHED]; c->C.conflicts = h_stats[ST_CONFLICTS];
-    c->C.probes = h_stats[ST_PROBES]; c->C.candidates = h_stats[ST_CANDS]; c->C.rounds = rounds; c->C.propose_launches = launches;
+    c->C.probes = h_stats[ST_PROBES]; c->C.candidates = h_stats[ST_CANDS]; c->C.useful_probes = h_stats[ST_USEFUL]; c->C.rounds = rounds; c->C.propose_launches = launches;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1)); c->C.index_ms = ms;
     HIP_TRY(hipEventElapsedTime(&ms, e1, e2)); c->C.chain_ms = ms;
@@ -636,7 +668,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     hipHostFree(h_stats);
 
     // free everything stage II does not need
-    void *tofree[] = { a.claimed, a.bid, a.hdr, a.cnt, a.ref, a.prop, a.log, a.logcount, a.blockcnt, a.needseg, a.cursor, a.stats, d_tab,
+    void *tofree[] = { a.claimed, a.bid, a.hdr, a.cnt, a.ref, a.prop, a.log, a.logcount, a.blockcnt, a.needseg, a.cursor, a.stats, a.cstat, d_tab,
                        nmain, nsing, bmain, bsing, dict[0].slots, dict[0].ids, dict[0].d_nbins, dict[1].slots, dict[1].ids, dict[1].d_nbins };
     for (void *p : tofree) if (p) harc_dev_free(c, p);
     c->have_s1 = true;

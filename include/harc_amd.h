@@ -75,6 +75,8 @@ typedef struct harc_amd_counters {
     uint64_t contigs, seq_bases;      /* stage II */
     uint64_t bins_over_maxsearch;     /* stage-II dictionary bins larger than maxsearch (static window) */
     uint64_t device_bytes_peak;
+    uint64_t useful_probes;           /* dictionary keys a strictly sequential scan (reorder.cpp:517-649) would have looked up:
+                                         priority index of the winning probe + 1, or all probes of the step on a miss */
 } harc_amd_counters;
 
 /* stream ids for harc_amd_get_stream; names are the reference's file names */
@@ -132,6 +134,14 @@ int harc_amd_set_nreads_ascii_device(harc_amd_ctx *ctx, const char *d_ascii, uin
 int harc_amd_set_stage1_streams(harc_amd_ctx *ctx, const char *temp_dna, const uint8_t *flag, const uint8_t *pos,
                                 const uint32_t *order, const uint8_t *rc, uint32_t n_main,
                                 const char *temp_dna_singleton, const uint32_t *order_singleton, uint32_t n_singleton);
+
+/* ---- multi-GPU sharding helpers (BASELINE.json north_star: reads shard by k-mer bucket, one all-to-all, then every GPU
+   runs the whole path on its shard).  Device buffers of params.device. */
+/* 2-bit pack n ASCII reads into the caller's buffer of n*ceil(2*readlen/64) u64 (layout of harc_amd_set_reads_packed_device) */
+int harc_amd_pack_reads_device(harc_amd_ctx *ctx, const char *d_ascii, uint32_t n_reads, uint32_t stride, uint64_t *d_packed_out);
+/* bucket[i] = hash(canonical minimizer, k=15, of the whole read i) % n_buckets: reads that overlap by >= ~half a read
+   share a minimizer with high probability and land on the same GPU */
+int harc_amd_bucket_reads_device(harc_amd_ctx *ctx, const uint64_t *d_packed, uint32_t n_reads, uint32_t n_buckets, uint32_t *d_bucket_out);
 
 /* ---- compute (all on params.device, asynchronous internally, synchronised before return) */
 int harc_amd_reorder(harc_amd_ctx *ctx);      /* index build + chaining: reorder.cpp:277-703 */

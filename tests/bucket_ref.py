@@ -1,0 +1,41 @@
+"""numpy restatement of the multi-GPU shard key (harc_amd/csrc/stage1.hip k_bucket) -- test infrastructure."""
+import numpy as np
+
+_PC = np.zeros(256, dtype=np.uint64)
+for ch, v in zip(b"AGCT", range(4)):
+    _PC[ch] = v
+M1, M2 = np.uint64(0xff51afd7ed558ccd), np.uint64(0xc4ceb9fe1a85ec53)
+
+
+def pack2(reads):
+    """[n, L] ASCII -> [n, W] int64 in std::bitset<2L> layout (A0 G1 C2 T3 at bits 2i)"""
+    n, L = reads.shape
+    W = (2 * L + 63) // 64
+    out = np.zeros((n, W), dtype=np.uint64)
+    code = _PC[reads]
+    for i in range(L):
+        out[:, i // 32] |= code[:, i] << np.uint64(2 * (i % 32))
+    return out.view(np.int64)
+
+
+def _mix64(x):
+    with np.errstate(over="ignore"):
+        x = x ^ (x >> np.uint64(33)); x = x * M1; x = x ^ (x >> np.uint64(33)); x = x * M2; x = x ^ (x >> np.uint64(33))
+    return x
+
+
+def bucket_ref(packed, L, nb):
+    p = packed.view(np.uint64)
+    n = p.shape[0]
+    K = min(L, 15)
+    kmask = np.uint64((1 << (2 * K)) - 1)
+    fw = np.zeros(n, dtype=np.uint64); rv = np.zeros(n, dtype=np.uint64)
+    best = np.full(n, np.uint64(0xFFFFFFFFFFFFFFFF))
+    for b in range(L):
+        pc = (p[:, b // 32] >> np.uint64(2 * (b % 32))) & np.uint64(3)
+        fw = ((fw << np.uint64(2)) | pc) & kmask
+        rv = (rv >> np.uint64(2)) | ((np.uint64(3) - pc) << np.uint64(2 * (K - 1)))
+        if b >= K - 1:
+            h = _mix64(np.minimum(fw, rv))
+            best = np.minimum(best, h)
+    return (best % np.uint64(nb)).astype(np.int64)

@@ -141,3 +141,20 @@ def test_bad_arguments_fail_loudly():
     with harc_amd.HarcAmd(p) as h:
         with pytest.raises(harc_amd.HarcAmdError):
             h.encode()                        # no stage-I result yet
+
+
+def test_bucket_kernel_matches_numpy_restatement():
+    import numpy as np
+    import torch
+    import harc_amd
+    from tests.bucket_ref import pack2, bucket_ref
+    reads = gen.reads_array(3, 20000, 100, 100000, err=0.0)
+    p = harc_amd.default_params(100)
+    with harc_amd.HarcAmd(p) as h:
+        d = torch.from_numpy(reads).cuda()
+        packed = torch.empty((reads.shape[0], 4), dtype=torch.int64, device="cuda")
+        h.pack_reads_device(d.data_ptr(), reads.shape[0], 100, packed.data_ptr())
+        assert (packed.cpu().numpy() == pack2(reads)).all()
+        b = torch.empty((reads.shape[0],), dtype=torch.int32, device="cuda")
+        h.bucket_reads_device(packed.data_ptr(), reads.shape[0], 8, b.data_ptr())
+        assert (b.cpu().numpy() == bucket_ref(pack2(reads), 100, 8)).all()
