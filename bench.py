@@ -98,7 +98,7 @@ def cpu_baseline(n_sample, L, G_sample, err, seed, dev):
             from tests import oracle_lib as ol
             o = ol.load()
             t0 = time.time()
-            assert o.harc_oracle_reorder(d.encode(), L, 1, None, None) == 0
+            assert o.harc_oracle_reorder(d.encode(), L, 1, 1, None, None) == 0
             assert o.harc_oracle_encoder(d.encode(), L, 1, None, None) == 0
             dt = time.time() - t0
             kind, cores = "port", 1

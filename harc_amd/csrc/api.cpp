@@ -57,6 +57,7 @@ static int check_params(const harc_amd_params *p)
     if (L < 1 || L > 255) { harc_set_error("readlen %d out of range 1..255", L); return HARC_AMD_EINVAL; }
     if (p->num_thr < 1 || p->num_thr > 4096) { harc_set_error("num_thr %d out of range", p->num_thr); return HARC_AMD_EINVAL; }
     if (p->num_chains < 0) { harc_set_error("num_chains < 0"); return HARC_AMD_EINVAL; }
+    if (p->num_steps < 0 || p->num_steps > 64) { harc_set_error("num_steps %d out of range 0..64", p->num_steps); return HARC_AMD_EINVAL; }
     if (p->maxmatch < 0 || p->maxmatch > 128 || p->maxmatch > L) { harc_set_error("maxmatch out of range"); return HARC_AMD_EINVAL; }
     if (p->maxsearch < 1 || p->thresh < 0 || p->thresh_s < 0) { harc_set_error("thresholds out of range"); return HARC_AMD_EINVAL; }
     for (int l = 0; l < 2; l++) {

@@ -35,15 +35,18 @@ void harc_set_error(const char *fmt, ...);
 struct ChainHdr {
     uint32_t cur;       // read the chain currently sits on
     uint32_t prev;      // pending seed (reorder.cpp `prev`)
-    uint32_t flags;     // bit0 active, bit1 prev_unmatched, bit2 count-buffer parity
-    uint32_t upd;       // consensus update owed to the next propose launch: kind<<16 | dir<<8 | shift ; kind 0 none, 1 match, 2 reset
+    uint32_t flags;     // CH_* bits
+    uint32_t mode;      // where the consensus of the next super-round comes from: 0 = cnt[parity], 1 = cnt[parity] + replay of the
+                        // `nsteps>>8` kept steps (after a lost bid), 2 = reset from reads[cur] (fresh seed)
     uint32_t n_main;    // records emitted to the main stream so far
     uint32_t n_sing;    // records emitted to the singleton stream so far
-    uint32_t pad0, pad1;
+    uint32_t nsteps;    // low byte: steps walked in the last k_steps launch; next byte: steps to replay
+    uint32_t pad0;
 };
 #define CH_ACTIVE 1u
 #define CH_PREVUNM 2u
-#define CH_PARITY 4u
+#define CH_PARITY 4u     // which half of cnt[2][K][Lp] holds the state at the start of the super-round
+#define CH_NEEDSEED 8u   // the last walk stopped because a step found no candidate
 
 // One emitted record of stage I (16 B); scattered into stream order by k_s1_scatter
 struct LogRec {
@@ -55,9 +58,12 @@ struct LogRec {
 
 struct HashSlot {       // 16 B, one global_load_dwordx4
     uint64_t key;
-    uint32_t start;     // first index into ids[]
-    uint32_t count;     // 0 = empty slot
+    uint32_t start;     // first index into ids[]; the read id itself when SLOT_EMB is set
+    uint32_t count;     // 0 = empty slot; low 30 bits = live entries [start, start+count); flags below
 };
+#define SLOT_DEAD 0x80000000u      // hint: every read of the bin is claimed
+#define SLOT_EMB 0x40000000u       // bin holds exactly one read and `start` is its id
+#define SLOT_CNT_MASK 0x3FFFFFFFu
 
 struct DictDev {
     HashSlot *slots = nullptr;

@@ -2,10 +2,10 @@
 //
 // Reference: src/reorder.cpp.  constructdictionary :277-394 -> k_keygen + radix sort + k_table_insert (an exact
 // open-addressing key->bin table replaces BBHash: the MPHF value never reaches an output byte).  reorder() :434-703 ->
-// the round-synchronous K-chain schedule of DESIGN.md: k_propose (one 64-lane wave per chain, the (shift, direction,
-// dictionary) probes of one chain step spread over the lanes, priority = lane order), k_resolve (lowest chain id wins a
-// read), k_reseed (one global descending cursor, reorder.cpp:652-668).  updaterefcount :863-915 -> the consensus update
-// at the top of k_propose.  writetofile :722-830 -> k_s1_scatter (+ k_orient for the in-HBM hand-over to stage II).
+// the super-round-synchronous K-chain x S-step schedule of DESIGN.md: k_steps (one 64-lane wave per chain, the (shift,
+// direction, dictionary) probes of a chain step spread over the lanes, priority = lane order, up to S steps per launch with
+// the consensus counts in registers), k_resolve (smallest (step, chain) bid wins a read), k_reseed (one global descending
+// cursor, reorder.cpp:652-668).  updaterefcount :863-915 -> cons_update inside k_steps.  writetofile :722-830 -> k_s1_scatter (+ k_orient for the in-HBM hand-over to stage II).
 //
 // Integer / HBM-latency bound; no MFMA.  Wave = 64 everywhere.
 #include "devutil.h"
@@ -16,23 +16,24 @@ struct S1Args {
     int ds[2], de[2], kbits[2];
     uint32_t N, K;
     const uint64_t *reads;
-    const HashSlot *slots[2];
+    HashSlot *slots[2];
     uint64_t cap[2];
     const uint32_t *ids[2];
     unsigned long long *claimed;     // bitmap, bit rid&63 of word rid>>6
-    uint32_t *bid;                   // per read: lowest chain id proposing it this round
+    uint32_t *bid;                   // per read: smallest (step<<20 | chain) bidding for it this super-round
     ChainHdr *hdr;
     uint4 *cnt;                      // [2][K][Lp] column counts (A,C,G,T) -- reorder.cpp:467 `count`
-    uint64_t *ref;                   // [K][W] packed consensus
-    uint2 *prop;                     // per chain: {rid | NONE, shift | dir<<8}
+    uint2 *steps;                    // [K][64] steps of the current super-round: {rid, shift | dir<<8}
+    uint8_t *need;                   // per chain: wants a new seed (set by k_resolve, consumed by k_reseed)
+    uint32_t *seedbuf;               // [K] seeds found by k_reseed, by rank
+    int S;                           // speculative steps per super-round (1..64)
     LogRec *log;
     unsigned long long *logcount;
-    uint32_t *blockcnt;              // per k_resolve block: chains that need a new seed
-    uint32_t *needseg;               // [blocks][256] those chains, in chain order
     long long *cursor;               // reorder.cpp `remainingpos`, one for all chains
     unsigned long long *stats;       // [0] unmatched [1] conflicts [2] active chains [3] probes [4] candidates
     const uint16_t *probe_tab;       // the probes of one chain step in priority order: shift | dir<<8 | dict<<9
     int nprobe;
+    int nbatch, batch_end[12];       // probe batches: [0,batch_end[0]), [batch_end[0],batch_end[1]) ... each at most 64 wide
     uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups
 };
 enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_USEFUL = 5, ST_N = 8 };
@@ -167,7 +168,7 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
     if (i == n - 1) *nbins = binidx[i] + head[i];
 }
 // one thread per bin: claim an empty slot by CAS on the (start,count) word; keys are unique so no key compare is needed
-__global__ void k_table_insert(const uint64_t *skeys, const uint32_t *binstart, const uint32_t *nbins_p, uint32_t n,
+__global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, const uint32_t *nbins_p, uint32_t n,
                                HashSlot *slots, uint64_t cap)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,7 +177,10 @@ __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *binstart, 
     const uint32_t st = binstart[b];
     const uint32_t en = (b + 1 < nbins) ? binstart[b + 1] : n;
     const uint64_t key = skeys[st];
-    const unsigned long long meta = (unsigned long long)st | ((unsigned long long)(en - st) << 32);
+    // single-read bins (the common case) carry the read id in `start`: one dependent load less on every hit
+    const uint32_t cnt = en - st;
+    const unsigned long long meta = cnt == 1 ? ((unsigned long long)sids[st] | ((unsigned long long)(1u | SLOT_EMB) << 32))
+                                             : ((unsigned long long)st | ((unsigned long long)(cnt & SLOT_CNT_MASK) << 32));
     uint64_t sl = __umul64hi(mix64(key), cap);
     for (;;) {
         unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
@@ -186,6 +190,11 @@ __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *binstart, 
 }
 
 // ------------------------------------------------------------------------------------------------ chain kernels
+// Schedule (the oracle's stage1_run restates it on the CPU): K chains, super-rounds of S speculative steps.
+//   k_steps   (A) every live chain -- one 64-lane wave -- walks up to S steps against the FROZEN claim bitmap with its
+//                 consensus counts held in registers, bidding (step<<20 | chain) for every read it takes;
+//   k_resolve (B) a read goes to the smallest bid; a chain keeps the steps before its first lost bid and is rolled back to there;
+//   k_reseed  (C) chains that ran out of candidates take new seeds, in chain order, from ONE descending cursor (reorder.cpp:652-668).
 __global__ void k_init_chains(S1Args s)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -196,218 +205,351 @@ __global__ void k_init_chains(S1Args s)
     if (act) {
         const uint32_t seed = c * step;
         atomicOr(&s.claimed[seed >> 6], 1ULL << (seed & 63));
-        h.cur = seed; h.prev = seed; h.flags = CH_ACTIVE | CH_PREVUNM; h.upd = 2u << 16;
+        h.cur = seed; h.prev = seed; h.flags = CH_ACTIVE | CH_PREVUNM; h.mode = 2;
         atomicAdd(&s.stats[ST_UNMATCHED], 1ULL);
         atomicAdd(&s.stats[ST_ACTIVE], 1ULL);
     }
     s.hdr[c] = h;
-    s.prop[c] = make_uint2(HARC_NONE, 0);
+    s.need[c] = 0;
 }
 
-// The dominant kernel.  One wave per chain, 4 chains per 256-thread workgroup.
-//  (1) apply the consensus update owed from the previous round (reorder.cpp:863-915), lanes = consensus columns;
-//  (2) the probes of this chain step (reorder.cpp:517-649) are dealt to the lanes in priority order, 64 at a time:
-//      key -> open-addressing slot -> bin scan from the highest unclaimed id (<= maxsearch of them) ->
-//      XOR+popcount Hamming on the packed words; the lowest lane with a hit is the step's candidate;
-//  (3) lane 0 bids for the candidate with atomicMin(chain id).
-template <int W> __global__ __launch_bounds__(256) void k_propose(S1Args s)
+// consensus state of one chain, spread over the wave: lane owns ring slots p = lane + 64 t (t < CT); the slot holding
+// consensus column i is p = (i + base) mod LP, so a shift of the chain only moves `base` (reorder.cpp:887-908 without data movement)
+template <int W> struct ConsState {
+    static constexpr int CT = (W + 1) / 2;
+    static constexpr int LP = 64 * CT;
+    uint4 q[CT];      // counts A,C,G,T of the slot (reorder.cpp:467 `count`)
+    int v[CT];        // consensus base of the slot (first strict maximum)
+    int base;
+};
+__device__ __forceinline__ int argmax4(const uint4 &q)
+{
+    uint32_t mx = 0; int ind = 0;                                // first strict maximum: ties A<C<G<T (reorder.cpp:893-899)
+    if (q.x > mx) { mx = q.x; ind = 0; }
+    if (q.y > mx) { mx = q.y; ind = 1; }
+    if (q.z > mx) { mx = q.z; ind = 2; }
+    if (q.w > mx) { mx = q.w; ind = 3; }
+    return ind;
+}
+// base (count row A0 C1 G2 T3) of the oriented read at column i
+template <int W> __device__ __forceinline__ int oriented_base(const uint64_t (&rw)[W], int L, int rev, int i)
+{
+    const int sc = rev ? (L - 1 - i) : i;
+    const int pc = (int)((sel0<W>(rw, sc >> 5) >> (2 * (sc & 31))) & 3);
+    const int b = ((pc & 1) << 1) | (pc >> 1);                   // packed code A0 G1 C2 T3 -> A0 C1 G2 T3
+    return rev ? 3 - b : b;
+}
+template <int W> __device__ __forceinline__ void cons_reset(ConsState<W> &st, const uint64_t (&rw)[W], int L, int lane)
+{
+    st.base = 0;
+#pragma unroll
+    for (int t = 0; t < ConsState<W>::CT; t++) {
+        const int i = lane + 64 * t;
+        int b = 0; uint4 q = make_uint4(0, 0, 0, 0);
+        if (i < L) { b = oriented_base<W>(rw, L, 0, i); q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3); }
+        st.q[t] = q; st.v[t] = b;
+    }
+}
+// updaterefcount for a match at `shift` with the read oriented by `rev` (reorder.cpp:884-909)
+template <int W> __device__ __forceinline__ void cons_update(ConsState<W> &st, const uint64_t (&rw)[W], int L, int rev, int shift, int lane)
+{
+    constexpr int LP = ConsState<W>::LP;
+    int nb = st.base + shift; if (nb >= LP) nb -= LP;
+#pragma unroll
+    for (int t = 0; t < ConsState<W>::CT; t++) {
+        const int p = lane + 64 * t;
+        int oldl = p - st.base; if (oldl < 0) oldl += LP;
+        int newl = p - nb; if (newl < 0) newl += LP;
+        uint4 q = st.q[t]; int v = 0;
+        if (newl < L) {
+            const int b = oriented_base<W>(rw, L, rev, newl);
+            if (oldl < L && oldl >= shift) { q.x += (b == 0); q.y += (b == 1); q.z += (b == 2); q.w += (b == 3); v = argmax4(q); }
+            else { q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3); v = b; }
+        } else q = make_uint4(0, 0, 0, 0);
+        st.q[t] = q; st.v[t] = v;
+    }
+    st.base = nb;
+}
+template <int W> __device__ __forceinline__ void cons_load(ConsState<W> &st, const uint4 *src, int L, int lane)
+{
+    st.base = 0;
+#pragma unroll
+    for (int t = 0; t < ConsState<W>::CT; t++) {
+        const int i = lane + 64 * t;
+        uint4 q = make_uint4(0, 0, 0, 0); int v = 0;
+        if (i < L) { q = src[i]; v = argmax4(q); }
+        st.q[t] = q; st.v[t] = v;
+    }
+}
+template <int W> __device__ __forceinline__ void cons_store(const ConsState<W> &st, uint4 *dst, int L, int lane)
+{
+    constexpr int LP = ConsState<W>::LP;
+#pragma unroll
+    for (int t = 0; t < ConsState<W>::CT; t++) {
+        int l = lane + 64 * t - st.base; if (l < 0) l += LP;
+        if (l < L) dst[l] = st.q[t];
+    }
+}
+// consensus -> packed 2-bit words in column order: ballot the two code bits per ring slot, then rotate the ring by `base`
+template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &st, int L, int lane, uint64_t (&ref)[W])
+{
+    constexpr int CT = ConsState<W>::CT, LP = ConsState<W>::LP, RW = 2 * CT;
+    uint64_t ring[RW];
+#pragma unroll
+    for (int t = 0; t < CT; t++) {
+        int l = lane + 64 * t - st.base; if (l < 0) l += LP;
+        const bool valid = l < L;
+        const int v = st.v[t];
+        const unsigned long long b0 = __ballot(valid && (v >> 1)), b1 = __ballot(valid && (v & 1));   // code bit0 = row>>1, bit1 = row&1
+        ring[2 * t] = spread32(b0) | (spread32(b1) << 1);
+        ring[2 * t + 1] = spread32(b0 >> 32) | (spread32(b1 >> 32) << 1);
+    }
+    const int sb = 2 * st.base, ws = sb >> 6, bs = sb & 63;      // wave-uniform
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        int i0 = w + ws; if (i0 >= RW) i0 -= RW;
+        int i1 = i0 + 1; if (i1 >= RW) i1 -= RW;
+        const uint64_t lo = sel0<RW>(ring, i0), hi = sel0<RW>(ring, i1);
+        ref[w] = (bs ? ((lo >> bs) | (hi << (64 - bs))) : lo) & lowmask_word(2 * L, w);
+    }
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t x, int src)
+{
+    const uint32_t lo = __shfl((uint32_t)x, src, 64), hi = __shfl((uint32_t)(x >> 32), src, 64);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// The dominant kernel.  One wave per chain, 4 chains per 256-thread workgroup.  Per step:
+//  (1) consensus -> packed words (ballots), reverse complement;
+//  (2) the probes of the step (reorder.cpp:517-649) are dealt to the lanes in priority order, in batches: key -> open-addressing
+//      slot -> bin scan from the highest unclaimed id (<= maxsearch of them) -> XOR+popcount Hamming on the packed words;
+//      the lowest lane with a hit is the step's read;
+//  (3) lane 0 records the step and bids for the read with atomicMin(step<<20 | chain); the counts are updated in registers.
+template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
+{
+    __shared__ uint32_t s_own[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x * 4 + wv;
+    if (c >= s.K) return;
+    ChainHdr h = s.hdr[c];
+    uint4 cst = s.cstat[c];
+    if (!(h.flags & CH_ACTIVE)) return;
+    const int L = s.L;
+    constexpr int LP = ConsState<W>::LP;
+    const uint32_t par = (h.flags & CH_PARITY) ? 1u : 0u;
+    uint4 *B0 = s.cnt + ((size_t)par * s.K + c) * LP;            // state at the start of this super-round (rollback point)
+    uint4 *B1 = s.cnt + ((size_t)(par ^ 1u) * s.K + c) * LP;     // state at its end
+    ConsState<W> st;
+    if (h.mode == 2) {                                           // fresh seed (reorder.cpp:875-883)
+        uint64_t rw[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) rw[w] = s.reads[(size_t)h.cur * W + w];
+        cons_reset<W>(st, rw, L, lane);
+    } else {
+        cons_load<W>(st, B0, L, lane);
+        if (h.mode == 1) {                                       // rolled back last time: replay the steps that were kept
+            const int nrep = (int)((h.nsteps >> 8) & 0xFF);
+            uint2 sp = make_uint2(0, 0);
+            uint64_t mrw[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) mrw[w] = 0;
+            if (lane < nrep) {
+                sp = s.steps[(size_t)c * 64 + lane];
+#pragma unroll
+                for (int w = 0; w < W; w++) mrw[w] = s.reads[(size_t)sp.x * W + w];
+            }
+            for (int t = 0; t < nrep; t++) {
+                uint64_t rw[W];
+#pragma unroll
+                for (int w = 0; w < W; w++) rw[w] = shfl_u64(mrw[w], t);
+                const uint32_t y = __shfl(sp.y, t, 64);
+                cons_update<W>(st, rw, L, (int)((y >> 8) & 1), (int)(y & 0xFF), lane);
+            }
+        }
+    }
+    if (h.mode != 0) cons_store<W>(st, B0, L, lane);             // B0 now holds the rollback point of this super-round
+
+    uint32_t np = 0, nc = 0, nuse = 0;
+    int nst = 0; bool needseed = false;
+    for (int t = 0; t < s.S; t++) {
+        uint64_t ref[W], rref[W];
+        cons_pack<W>(st, L, lane, ref);
+        rc_words<W>(ref, L, rref);
+        uint32_t found = HARC_NONE; int fj = 0, fdir = 0;
+        uint64_t frd[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) frd[w] = 0;
+        // Probes are issued in priority order in batches: every probe behind the first hit of a batch is speculative traffic,
+        // every extra batch is a serial round trip to HBM.
+        int base = 0;
+        for (int bi = 0; bi < s.nbatch; bi++) {
+            const int bend = s.batch_end[bi];
+            const int p = base + lane;
+            uint32_t mine = HARC_NONE; int j = 0, dir = 0;
+            uint64_t mrd[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) mrd[w] = 0;
+            if (p < bend) {
+                const uint32_t e = s.probe_tab[p];
+                j = (int)(e & 0xFF); dir = (int)((e >> 8) & 1);
+                const int l = (int)((e >> 9) & 1);
+                const int off = dir ? 2 * (s.ds[l] - j) : 2 * (s.ds[l] + j);
+                uint64_t src[W];
+#pragma unroll
+                for (int w = 0; w < W; w++) src[w] = dir ? rref[w] : ref[w];
+                const uint64_t key = extract_bits<W>(src, off, s.kbits[l]);
+                const uint64_t cap = s.cap[l];
+                HashSlot *tab = s.slots[l];
+                const uint32_t *ids = s.ids[l];
+                if (cap) {
+                    uint64_t sl = __umul64hi(mix64(key), cap);
+                    for (;;) {
+                        const uint4 raw = *reinterpret_cast<const uint4 *>(&tab[sl]);
+                        np++;
+                        const uint64_t k2 = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+                        const uint32_t sst = raw.z, cw = raw.w;
+                        if (cw == 0) break;
+                        if (k2 == key) {
+                            if (cw & SLOT_DEAD) break;                        // every read of this bin is already claimed
+                            uint64_t sh[W];                                   // shifted consensus: reorder.cpp:647-648
+                            if (dir) shl_words<W>(rref, 2 * j, sh); else shr_words<W>(ref, 2 * j, sh);
+                            const int nb = 2 * (L - j);
+                            const uint32_t cntb = cw & SLOT_CNT_MASK;
+                            const bool emb = (cw & SLOT_EMB) != 0;            // single-read bin: `start` IS the read id
+                            int seen = 0; uint32_t lead = 0; bool alltop = true;
+                            for (uint32_t i = cntb; i > 0 && seen < s.maxsearch; i--) {
+                                const uint32_t rid = emb ? sst : ids[sst + i - 1];
+                                // claim bit and read words are fetched together (one dependent hop instead of two)
+                                const unsigned long long cwd = s.claimed[rid >> 6];
+                                uint64_t rd[W];
+#pragma unroll
+                                for (int w = 0; w < W; w++) rd[w] = s.reads[(size_t)rid * W + w];
+                                if ((cwd >> (rid & 63)) & 1ULL) { if (alltop) lead++; continue; }
+                                alltop = false;
+                                bool own = false;                             // taken by this chain earlier in this super-round
+                                for (int k = 0; k < t; k++) own |= (s_own[wv][k] == rid);
+                                if (own) continue;
+                                seen++; nc++;
+                                int hd = 0;
+#pragma unroll
+                                for (int w = 0; w < W; w++) {
+                                    // forward: low 2(L-j) bits (mask[j], reorder.cpp:712-713); reverse: bits >= 2j below 2L (revmask[j], :714-715)
+                                    const uint64_t m = dir ? (lowmask_word(2 * L, w) & ~lowmask_word(2 * j, w)) : lowmask_word(nb, w);
+                                    hd += __popcll((sh[w] ^ rd[w]) & m);
+                                }
+                                if (hd <= s.thresh) {
+                                    mine = rid;
+#pragma unroll
+                                    for (int w = 0; w < W; w++) mrd[w] = rd[w];
+                                    break;
+                                }
+                            }
+                            // hints only (the claim bitmap stays the truth): claimed reads at the top of a bin are never looked at again
+                            if (lead) {
+                                uint32_t *cp = reinterpret_cast<uint32_t *>(&tab[sl]) + 3;
+                                if (lead == cntb) atomicOr(cp, SLOT_DEAD); else if (!emb) atomicMin(cp, cntb - lead);
+                            }
+                            break;
+                        }
+                        if (++sl == cap) sl = 0;
+                    }
+                }
+            }
+            const unsigned long long m = __ballot(mine != HARC_NONE);
+            if (m) {
+                const int srcl = __ffsll((long long)m) - 1;
+                found = __shfl(mine, srcl, 64); fj = __shfl(j, srcl, 64); fdir = __shfl(dir, srcl, 64);
+#pragma unroll
+                for (int w = 0; w < W; w++) frd[w] = shfl_u64(mrd[w], srcl);
+                nuse += (uint32_t)(base + srcl + 1);
+                break;
+            }
+            base = bend;
+        }
+        if (found == HARC_NONE) { nuse += (uint32_t)s.nprobe; needseed = true; break; }
+        if (lane == 0) {
+            s.steps[(size_t)c * 64 + t] = make_uint2(found, (uint32_t)fj | ((uint32_t)fdir << 8));
+            atomicMin(&s.bid[found], ((uint32_t)t << 20) | c);
+            s_own[wv][t] = found;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cons_update<W>(st, frd, L, fdir, fj, lane);
+        nst++;
+    }
+    if (nst > 0) cons_store<W>(st, B1, L, lane);
+    np = wave_sum_u32(np); nc = wave_sum_u32(nc);
+    if (lane == 0) {
+        cst.x += np; cst.y += nc; cst.z += nuse; s.cstat[c] = cst;
+        h.mode = 0;
+        h.nsteps = (uint32_t)nst;
+        h.flags = needseed ? (h.flags | CH_NEEDSEED) : (h.flags & ~CH_NEEDSEED);
+        s.hdr[c] = h;
+    }
+}
+
+// (B) one wave per chain, lane t = step t of the super-round
+__global__ __launch_bounds__(256) void k_resolve(S1Args s)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= s.K) return;
     ChainHdr h = s.hdr[c];
     if (!(h.flags & CH_ACTIVE)) return;
-    const int L = s.L;
-    uint64_t ref[W];
-    const uint32_t kind = h.upd >> 16;
-    if (kind) {
-        const int shift = (int)(h.upd & 0xFF), rev = (int)((h.upd >> 8) & 1);
-        const uint32_t par = (h.flags & CH_PARITY) ? 1u : 0u;
-        const uint4 *src = s.cnt + ((size_t)par * s.K + c) * s.Lp;
-        uint4 *dst = s.cnt + ((size_t)(par ^ 1u) * s.K + c) * s.Lp;
-        uint64_t rw[W];
-#pragma unroll
-        for (int w = 0; w < W; w++) rw[w] = s.reads[(size_t)h.cur * W + w];
-#pragma unroll
-        for (int t = 0; t < (W + 1) / 2; t++) {
-            const int col = lane + 64 * t;
-            const bool valid = col < L;
-            int v = 0;
-            if (valid) {
-                const int sc = rev ? (L - 1 - col) : col;
-                const int pc = (int)((sel0<W>(rw, sc >> 5) >> (2 * (sc & 31))) & 3);
-                v = ((pc & 1) << 1) | (pc >> 1);                 // packed code A0 G1 C2 T3 -> count row A0 C1 G2 T3
-                if (rev) v = 3 - v;
-                uint4 q = make_uint4(0, 0, 0, 0);
-                if (kind == 1 && col < L - shift) {
-                    q = src[col + shift];
-                    q.x += (v == 0); q.y += (v == 1); q.z += (v == 2); q.w += (v == 3);
-                    uint32_t mx = 0; int ind = 0;                // first strict maximum: ties A<C<G<T (reorder.cpp:893-899)
-                    if (q.x > mx) { mx = q.x; ind = 0; }
-                    if (q.y > mx) { mx = q.y; ind = 1; }
-                    if (q.z > mx) { mx = q.z; ind = 2; }
-                    if (q.w > mx) { mx = q.w; ind = 3; }
-                    v = ind;
-                } else {
-                    q.x = (v == 0); q.y = (v == 1); q.z = (v == 2); q.w = (v == 3);
-                }
-                dst[col] = q;
-            }
-            // consensus -> packed words by ballot: code bit0 = row>>1, bit1 = row&1
-            const unsigned long long b0 = __ballot(valid && (v >> 1)), b1 = __ballot(valid && (v & 1));
-            ref[2 * t] = spread32(b0) | (spread32(b1) << 1);
-            if (2 * t + 1 < W) ref[2 * t + 1] = spread32(b0 >> 32) | (spread32(b1 >> 32) << 1);
-        }
-        if (lane < W) s.ref[(size_t)c * W + lane] = sel0<W>(ref, lane);
-        h.flags ^= CH_PARITY;
-        h.upd = 0;
-    } else {
-#pragma unroll
-        for (int w = 0; w < W; w++) ref[w] = s.ref[(size_t)c * W + w];
+    const int n = (int)(h.nsteps & 0xFF);
+    uint2 sp = make_uint2(HARC_NONE, 0);
+    bool mineb = false;
+    if (lane < n) {
+        sp = s.steps[(size_t)c * 64 + lane];
+        mineb = s.bid[sp.x] == (((uint32_t)lane << 20) | c);
     }
-    uint64_t rref[W];
-    rc_words<W>(ref, L, rref);
-
-    uint32_t found = HARC_NONE; int fj = 0, fdir = 0;
-    uint32_t np = 0, nc = 0, nuse = (uint32_t)s.nprobe;
-    for (int base = 0; base < s.nprobe; base += 64) {
-        const int p = base + lane;
-        uint32_t mine = HARC_NONE; int j = 0, dir = 0;
-        if (p < s.nprobe) {
-            const uint32_t e = s.probe_tab[p];
-            j = (int)(e & 0xFF); dir = (int)((e >> 8) & 1);
-            const int l = (int)((e >> 9) & 1);
-            const int off = dir ? 2 * (s.ds[l] - j) : 2 * (s.ds[l] + j);
-            uint64_t src[W];
-#pragma unroll
-            for (int w = 0; w < W; w++) src[w] = dir ? rref[w] : ref[w];
-            const uint64_t key = extract_bits<W>(src, off, s.kbits[l]);
-            const uint64_t cap = s.cap[l];
-            const HashSlot *tab = s.slots[l];
-            const uint32_t *ids = s.ids[l];
-            if (cap) {
-                uint64_t sl = __umul64hi(mix64(key), cap);
-                for (;;) {
-                    const uint4 raw = *reinterpret_cast<const uint4 *>(&tab[sl]);
-                    np++;
-                    const uint64_t k2 = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
-                    const uint32_t st = raw.z, cntb = raw.w;
-                    if (cntb == 0) break;
-                    if (k2 == key) {
-                        // shifted consensus for this (shift, direction): reorder.cpp:647-648
-                        uint64_t sh[W];
-                        if (dir) shl_words<W>(rref, 2 * j, sh); else shr_words<W>(ref, 2 * j, sh);
-                        const int nb = 2 * (L - j);
-                        int seen = 0;
-                        for (uint32_t i = st + cntb; i > st && seen < s.maxsearch; i--) {
-                            const uint32_t rid = ids[i - 1];
-                            if ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) continue;
-                            seen++; nc++;
-                            int hd = 0;
-#pragma unroll
-                            for (int w = 0; w < W; w++) {
-                                const uint64_t rd = s.reads[(size_t)rid * W + w];
-                                // forward: low 2(L-j) bits (mask[j], reorder.cpp:712-713); reverse: bits >= 2j below 2L (revmask[j], :714-715)
-                                const uint64_t m = dir ? (lowmask_word(2 * L, w) & ~lowmask_word(2 * j, w)) : lowmask_word(nb, w);
-                                hd += __popcll((sh[w] ^ rd) & m);
-                            }
-                            if (hd <= s.thresh) { mine = rid; break; }
-                        }
-                        break;
-                    }
-                    if (++sl == cap) sl = 0;
-                }
-            }
-        }
-        const unsigned long long m = __ballot(mine != HARC_NONE);
-        if (m) {
-            const int srcl = __ffsll((long long)m) - 1;
-            found = __shfl(mine, srcl, 64); fj = __shfl(j, srcl, 64); fdir = __shfl(dir, srcl, 64);
-            nuse = (uint32_t)(base + srcl + 1);
-            break;
-        }
+    const unsigned long long lost = __ballot(lane < n && !mineb);
+    const int v = lost ? (__ffsll((long long)lost) - 1) : n;     // steps kept: those before the first lost bid
+    if (mineb) s.bid[sp.x] = HARC_NONE;                          // every bid this chain holds is withdrawn, kept or not
+    const bool cut = v < n;
+    const uint32_t pre = (v > 0 && (h.flags & CH_PREVUNM)) ? 1u : 0u;
+    const uint32_t nrec = (uint32_t)v + pre;
+    unsigned long long at0 = 0;
+    if (nrec) {
+        if (lane == 0) at0 = atomicAdd(s.logcount, (unsigned long long)nrec);
+        at0 = shfl_u64(at0, 0);
     }
-    np = wave_sum_u32(np); nc = wave_sum_u32(nc);
+    if (lane == 0 && pre) {                                      // the pending seed opens a contig (reorder.cpp:564-570)
+        LogRec r; r.chain = c; r.seq = h.n_main; r.rid = h.prev; r.meta = (uint32_t)(s.L & 0xFF);
+        s.log[at0] = r;
+    }
+    if (lane < v) {
+        atomicOr(&s.claimed[sp.x >> 6], 1ULL << (sp.x & 63));
+        LogRec r; r.chain = c; r.seq = h.n_main + pre + (uint32_t)lane; r.rid = sp.x;
+        r.meta = (sp.y & 0xFF) | (1u << 8) | (((sp.y >> 8) & 1u) << 9);
+        s.log[at0 + pre + (uint32_t)lane] = r;
+    }
+    const uint32_t lastrid = __shfl(sp.x, v > 0 ? v - 1 : 0, 64);
     if (lane == 0) {
-        uint4 st = s.cstat[c]; st.x += np; st.y += nc; st.z += nuse; s.cstat[c] = st;
+        h.n_main += nrec;
+        if (v > 0) { h.cur = lastrid; h.flags &= ~CH_PREVUNM; }
+        if (cut) {
+            h.mode = v > 0 ? 1u : 0u; h.nsteps = ((uint32_t)v << 8); h.flags &= ~CH_NEEDSEED;
+            atomicAdd(&s.stats[ST_CONFLICTS], 1ULL);
+        } else if (n > 0) { h.flags ^= CH_PARITY; h.mode = 0; h.nsteps = 0; }
         s.hdr[c] = h;
-        s.prop[c] = make_uint2(found, (uint32_t)fj | ((uint32_t)fdir << 8));
-        if (found != HARC_NONE) atomicMin(&s.bid[found], c);
+        s.need[c] = (!cut && (h.flags & CH_NEEDSEED)) ? 1 : 0;
     }
 }
 
-// pass 1 (one thread per chain): the lowest chain id bidding for a read claims it (reorder.cpp:545-578 made deterministic);
-// chains without a candidate are listed, in chain order, for k_reseed.
-__global__ __launch_bounds__(256) void k_resolve(S1Args s)
-{
-    __shared__ uint32_t sm[8];
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    uint32_t need = 0, nrec = 0, conflict = 0;
-    ChainHdr h; uint2 p = make_uint2(HARC_NONE, 0);
-    bool act = false, won = false;
-    if (c < s.K) {
-        h = s.hdr[c];
-        act = (h.flags & CH_ACTIVE) != 0;
-        if (act) {
-            p = s.prop[c];
-            if (p.x == HARC_NONE) need = 1;
-            else if (s.bid[p.x] == c) { won = true; nrec = (h.flags & CH_PREVUNM) ? 2u : 1u; }
-            else conflict = 1;
-        }
-    }
-    // log slots: one atomic per wave
-    uint32_t wtot; const uint32_t wex = wave_excl_scan_u32(nrec, &wtot);
-    unsigned long long wbase = 0;
-    if (wtot) {
-        if ((threadIdx.x & 63) == 0) wbase = atomicAdd(s.logcount, (unsigned long long)wtot);
-        wbase = __shfl(wbase, 0, 64);
-    }
-    if (won) {
-        const uint32_t rid = p.x;
-        s.bid[rid] = HARC_NONE;
-        atomicOr(&s.claimed[rid >> 6], 1ULL << (rid & 63));
-        unsigned long long at = wbase + wex;
-        if (h.flags & CH_PREVUNM) {                              // the pending seed opens a contig (reorder.cpp:564-570)
-            LogRec r; r.chain = c; r.seq = h.n_main++; r.rid = h.prev; r.meta = (uint32_t)(s.L & 0xFF);
-            s.log[at++] = r;
-        }
-        LogRec r; r.chain = c; r.seq = h.n_main++; r.rid = rid;
-        r.meta = (p.y & 0xFF) | (1u << 8) | (((p.y >> 8) & 1u) << 9);
-        s.log[at] = r;
-        h.cur = rid; h.flags &= ~CH_PREVUNM; h.upd = (1u << 16) | (p.y & 0x1FF);
-        s.hdr[c] = h;
-    }
-    uint32_t ntot; const uint32_t lrank = block_excl_scan_u32<256>(need, sm, &ntot);
-    if (need) s.needseg[(size_t)blockIdx.x * 256 + lrank] = c;
-    if (threadIdx.x == 0) s.blockcnt[blockIdx.x] = ntot;
-    const uint32_t cw = wave_sum_u32(conflict);
-    if ((threadIdx.x & 63) == 0 && cw) atomicAdd(&s.stats[ST_CONFLICTS], (unsigned long long)cw);
-}
-
-// pass 2 (one workgroup): chains without a candidate take new seeds, in chain order, from the single descending cursor over
-// unclaimed reads (reorder.cpp:650-688); when the cursor runs out they finish.
+// (C) one workgroup: new seeds, in chain order, from the single descending cursor over unclaimed reads (reorder.cpp:650-688);
+// when the cursor runs out the remaining chains finish.
 __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
 {
-    __shared__ uint32_t sbase[4096 + 1];
     __shared__ uint32_t sm[20];
     __shared__ long long scursor;
     const int t = threadIdx.x;
-    const uint32_t nb = (s.K + 255) / 256;                        // <= 4096 (K <= 2^20)
-    uint32_t v[4], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const uint32_t idx = (uint32_t)t * 4 + k; v[k] = idx < nb ? s.blockcnt[idx] : 0; sum += v[k]; }
-    uint32_t R; uint32_t tb = block_excl_scan_u32<1024>(sum, sm, &R);
-#pragma unroll
-    for (int k = 0; k < 4; k++) { sbase[t * 4 + k] = tb; tb += v[k]; }
-    if (t == 1023) sbase[4096] = tb;
-    __syncthreads();
+    const uint32_t chunk = (s.K + 1023) / 1024;                   // chains per thread, contiguous
+    const uint32_t c0 = (uint32_t)t * chunk, c1 = (c0 + chunk < s.K) ? c0 + chunk : s.K;
+    uint32_t mycnt = 0;
+    for (uint32_t c = c0; c < c1; c++) mycnt += s.need[c];
+    uint32_t R; const uint32_t rbase = block_excl_scan_u32<1024>(mycnt, sm, &R);
     if (R == 0) return;
-
-    auto chain_of_rank = [&](uint32_t r) -> uint32_t {            // largest b with sbase[b] <= r
-        uint32_t lo = 0, hi = nb;                                 // invariant sbase[lo] <= r < sbase[hi]
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sbase[mid] <= r) lo = mid; else hi = mid; }
-        return s.needseg[(size_t)lo * 256 + (r - sbase[lo])];
-    };
 
     long long cursor = *s.cursor;
     uint32_t assigned = 0;
@@ -425,16 +567,7 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
             bits &= ~(1ULL << b);
             const uint32_t id = (uint32_t)(wi * 64 + b), r = assigned + off + k;
             k++; newclaim |= 1ULL << b;
-            const uint32_t c = chain_of_rank(r);
-            ChainHdr h = s.hdr[c];
-            if (h.flags & CH_PREVUNM) {                           // previous seed found nothing: singleton (reorder.cpp:681-684)
-                const unsigned long long at = atomicAdd(s.logcount, 1ULL);
-                LogRec rec; rec.chain = c; rec.seq = h.n_sing++; rec.rid = h.prev; rec.meta = 1u << 10;
-                s.log[at] = rec;
-            }
-            h.cur = id; h.prev = id; h.flags |= CH_PREVUNM; h.upd = 2u << 16;
-            s.hdr[c] = h;
-            atomicAdd(&s.stats[ST_UNMATCHED], 1ULL);
+            s.seedbuf[r] = id;
             if (r == R - 1) scursor = (long long)id - 1;
         }
         if (newclaim) s.claimed[wi] |= newclaim;                  // this workgroup is the only writer of the bitmap in this launch
@@ -443,18 +576,28 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
         else { assigned += total; cursor = (cwd - 1023) * 64 - 1; }
         __syncthreads();
     }
-    // cursor exhausted: the remaining chains are done (reorder.cpp:670-677)
-    for (uint32_t r = assigned + (uint32_t)t; r < R; r += 1024) {
-        const uint32_t c = chain_of_rank(r);
+    __threadfence();
+    __syncthreads();
+    uint32_t r = rbase;
+    for (uint32_t c = c0; c < c1; c++) {
+        if (!s.need[c]) continue;
         ChainHdr h = s.hdr[c];
-        if (h.flags & CH_PREVUNM) {
+        if (h.flags & CH_PREVUNM) {                               // previous seed found nothing: singleton (reorder.cpp:672-684)
             const unsigned long long at = atomicAdd(s.logcount, 1ULL);
             LogRec rec; rec.chain = c; rec.seq = h.n_sing++; rec.rid = h.prev; rec.meta = 1u << 10;
             s.log[at] = rec;
         }
-        h.flags &= ~(CH_ACTIVE | CH_PREVUNM);
+        if (r < assigned) {
+            const uint32_t id = s.seedbuf[r];
+            h.cur = id; h.prev = id; h.flags = (h.flags | CH_PREVUNM) & ~CH_NEEDSEED; h.mode = 2; h.nsteps = 0;
+            atomicAdd(&s.stats[ST_UNMATCHED], 1ULL);
+        } else {                                                  // no reads left (reorder.cpp:670-677)
+            h.flags &= ~(CH_ACTIVE | CH_PREVUNM | CH_NEEDSEED);
+            atomicAdd(&s.stats[ST_ACTIVE], ~0ULL);                // -1
+        }
         s.hdr[c] = h;
-        atomicAdd(&s.stats[ST_ACTIVE], ~0ULL);                    // -1
+        s.need[c] = 0;
+        r++;
     }
     if (t == 0) *s.cursor = cursor < -1 ? -1 : cursor;
 }
@@ -518,7 +661,7 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     RC_TRY(prim_excl_scan_u32(c, h0, b0, n));
     hipLaunchKernelGGL(k_bin_starts, dim3(g), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins);
     HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
-    hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, bs, d->d_nbins, n, d->slots, d->cap);
+    hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, d->ids, bs, d->d_nbins, n, d->slots, d->cap);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&d->nbins, d->d_nbins, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -546,9 +689,9 @@ static std::vector<uint16_t> make_probe_table(const harc_amd_params &P)
 
 static uint32_t auto_chains(uint32_t N)
 {
-    // one chain per ~1024 reads keeps chains sparse on the genome (conflicts <0.5 % below ~1 chain / kb);
+    // one chain per ~2048 reads keeps chains sparse on the genome (every chain costs about one extra contig);
     // 65536 waves is several full waves of occupancy on 256 CUs
-    uint32_t k = N / 1024;
+    uint32_t k = N / 2048;
     if (k > 65536) k = 65536;
     if (k < 1) k = 1;
     return k;
@@ -562,6 +705,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (K > HARC_MAXK) K = HARC_MAXK;
     if (N == 0 || K > N) K = 1;                                  // floor(N/K)=0: only chain 0 ever runs (reorder.cpp:484-490)
     c->C.chains = K;
+    int nsteps = P.num_steps > 0 ? P.num_steps : 16;
+    if (nsteps > 64) nsteps = 64;
     hipEvent_t e0, e1, e2;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
     HIP_TRY(hipEventRecord(e0, c->stream));
@@ -583,26 +728,33 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // ---- chain state
     S1Args a; memset(&a, 0, sizeof a);
     a.L = P.readlen; a.maxmatch = P.maxmatch; a.thresh = P.thresh; a.maxsearch = P.maxsearch;
-    a.Lp = ((W + 1) / 2) * 64;
+    a.Lp = ((W + 1) / 2) * 64; a.S = nsteps;
     for (int l = 0; l < 2; l++) { a.ds[l] = P.dict_start[l]; a.de[l] = P.dict_end[l]; a.kbits[l] = 2 * (P.dict_end[l] - P.dict_start[l] + 1); }
     a.N = N; a.K = K; a.reads = c->d_reads;
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
     const size_t nwords = (size_t)N / 64 + 2;
     const uint32_t nblk = (K + 255) / 256;
     RC_TRY(dalloc(c, &a.claimed, nwords)); RC_TRY(dalloc(c, &a.bid, (size_t)N + 1)); RC_TRY(dalloc(c, &a.hdr, K));
-    RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.ref, (size_t)K * W)); RC_TRY(dalloc(c, &a.prop, K));
-    RC_TRY(dalloc(c, &a.log, (size_t)N + 1)); RC_TRY(dalloc(c, &a.logcount, 1)); RC_TRY(dalloc(c, &a.blockcnt, nblk));
-    RC_TRY(dalloc(c, &a.needseg, (size_t)nblk * 256)); RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N));
+    RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.steps, (size_t)K * 64)); RC_TRY(dalloc(c, &a.need, (size_t)K + 1024));
+    RC_TRY(dalloc(c, &a.seedbuf, K));
+    RC_TRY(dalloc(c, &a.log, (size_t)N + 1)); RC_TRY(dalloc(c, &a.logcount, 1));
+    RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N));
     RC_TRY(dalloc(c, &a.cstat, K)); HIP_TRY(hipMemsetAsync(a.cstat, 0, (size_t)K * 16, c->stream));
     std::vector<uint16_t> tab = make_probe_table(P);
     uint16_t *d_tab = nullptr; RC_TRY(dalloc(c, &d_tab, tab.size() + 1));
     HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream));
     a.probe_tab = d_tab; a.nprobe = (int)tab.size();
+    {   // 16,16,32,64,64,... probes per batch
+        const int sizes[] = { 16, 16, 32, 64, 64, 64, 64, 64, 64, 64, 64, 64 };
+        int e = 0; a.nbatch = 0;
+        while (e < a.nprobe && a.nbatch < 12) { e += sizes[a.nbatch]; if (e > a.nprobe) e = a.nprobe; a.batch_end[a.nbatch++] = e; }
+        if (e < a.nprobe) a.batch_end[a.nbatch - 1] = a.nprobe;   // not reachable for readlen <= 255 (<= 4*127 probes needs <= 10 batches)
+    }
     HIP_TRY(hipMemsetAsync(a.claimed, 0, nwords * 8, c->stream));
     HIP_TRY(hipMemsetAsync(a.bid, 0xFF, ((size_t)N + 1) * 4, c->stream));
     HIP_TRY(hipMemsetAsync(a.logcount, 0, 8, c->stream));
     HIP_TRY(hipMemsetAsync(a.stats, 0, ST_N * 8, c->stream));
-    HIP_TRY(hipMemsetAsync(a.blockcnt, 0, nblk * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(a.need, 0, (size_t)K + 1024, c->stream));
     const long long cur0 = (long long)N - 1;
     HIP_TRY(hipMemcpyAsync(a.cursor, &cur0, 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_init_chains, dim3(nblk), dim3(256), 0, c->stream, a);
@@ -614,13 +766,13 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     std::vector<hipEvent_t> ev;
     const bool prof = P.profile != 0;
     uint64_t rounds = 0, launches = 0;
-    const int batch = 32;
+    const int batch = 8;
     for (;;) {
         for (int r = 0; r < batch; r++) {
             if (prof) { hipEvent_t a0, a1; HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1)); ev.push_back(a0); ev.push_back(a1); HIP_TRY(hipEventRecord(a0, c->stream)); }
-            hipLaunchKernelGGL((k_propose<W>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL((k_steps<W>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
             if (prof) HIP_TRY(hipEventRecord(ev.back(), c->stream));
-            hipLaunchKernelGGL(k_resolve, dim3(nblk), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL(k_resolve, dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
             hipLaunchKernelGGL(k_reseed, dim3(1), dim3(1024), 0, c->stream, a);
             launches++;
         }
@@ -668,7 +820,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     hipHostFree(h_stats);
 
     // free everything stage II does not need
-    void *tofree[] = { a.claimed, a.bid, a.hdr, a.cnt, a.ref, a.prop, a.log, a.logcount, a.blockcnt, a.needseg, a.cursor, a.stats, a.cstat, d_tab,
+    void *tofree[] = { a.claimed, a.bid, a.hdr, a.cnt, a.steps, a.need, a.seedbuf, a.log, a.logcount, a.cursor, a.stats, a.cstat, d_tab,
                        nmain, nsing, bmain, bsing, dict[0].slots, dict[0].ids, dict[0].d_nbins, dict[1].slots, dict[1].ids, dict[1].d_nbins };
     for (void *p : tofree) if (p) harc_dev_free(c, p);
     c->have_s1 = true;

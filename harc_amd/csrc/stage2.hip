@@ -100,7 +100,7 @@ __global__ void k_count_big_bins(const HashSlot *slots, uint64_t cap, uint32_t m
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cap) return;
-    if (slots[i].count > maxsearch) atomicAdd(out, 1ULL);
+    if ((slots[i].count & SLOT_CNT_MASK) > maxsearch) atomicAdd(out, 1ULL);
 }
 
 // ---------------------------------------------------------------------------------------------- contig structure
@@ -179,9 +179,11 @@ __global__ __launch_bounds__(256) void k_realign_propose(S2Args s)
             }
             uint32_t st = 0, cnt = 0, np = 0;
             if (!dict_lookup(s.slots[l], s.cap[l], key, &st, &cnt, &np)) continue;
+            const bool emb = (cnt & SLOT_EMB) != 0;
+            cnt &= SLOT_CNT_MASK;
             const uint32_t lim = cnt > (uint32_t)s.maxsearch ? (uint32_t)s.maxsearch : cnt;   // static window: top maxsearch ids of the bin
             for (uint32_t t = 0; t < lim; t++) {
-                const uint32_t rid = s.ids[l][st + cnt - 1 - t];
+                const uint32_t rid = emb ? st : s.ids[l][st + cnt - 1 - t];
                 const uint64_t *r = s.cand3 + (size_t)rid * W3;
                 int hd = 0;
                 for (int w = 0; w < W3; w++) {                                // 3-bit window word w, built on the fly

@@ -55,7 +55,9 @@ typedef struct harc_amd_params {
     int32_t dict_end[2];      /* `dict1_end`,`dict2_end` */
     int32_t device;           /* HIP device ordinal */
     int32_t profile;          /* 1: time every launch of the dominant kernel with HIP events on the context's stream */
-    int32_t reserved[4];
+    int32_t num_steps;        /* S: speculative chain steps per launch of the chain kernel (1..64; 0 = auto).  Output is independent
+                                 of S when num_chains = 1; for num_chains > 1 the pair (K,S) defines the schedule */
+    int32_t reserved[3];
 } harc_amd_params;
 
 /* Counters: the three numbers the reference prints (reorder.cpp:701, encoder.cpp:506-508) + kernel-side statistics. */

@@ -19,11 +19,11 @@
  *
  * Parallel semantics.  The reference is a race for num_thr>1 (reorder.cpp:545-552, encoder.cpp:282-283).  K chains /
  * E shards are therefore DEFINED here, deterministically, so that K=1,E=1 is the reference at num_thr=1:
- *   stage I, K chains, round-synchronous: every round (1) each live chain proposes its first admissible candidate
- *   against the frozen claim state, priority order exactly reorder.cpp:517-649; (2) pass 1: each proposed read goes to
- *   the lowest chain id, losers retry next round; (3) pass 2: chains without a candidate reseed in ascending chain id
- *   from ONE global descending cursor (reorder.cpp:652-668).  Seeds c*floor(N/K) (reorder.cpp:490).  Output = per-chain
- *   streams concatenated in chain order (reorder.cpp:778-821).
+ *   stage I, K chains x S steps, super-round-synchronous (see stage1_run): every chain walks up to S steps against the frozen
+ *   claim state, candidate priority exactly reorder.cpp:517-649; a read goes to the smallest (step, chain) bid, a chain keeps
+ *   the steps before its first lost bid; chains out of candidates reseed in ascending chain id from ONE global descending
+ *   cursor (reorder.cpp:652-668).  Seeds c*floor(N/K) (reorder.cpp:490).  Output = per-chain streams concatenated in chain
+ *   order (reorder.cpp:778-821).
  *   stage II, E shards: shard ranges encoder.cpp:171-180; singleton claims resolve to the minimum
  *   (shard, contig, j, direction, dict) tuple, which is what the sequential loop below produces.
  */
@@ -36,6 +36,7 @@
 #define MAXW 8          /* ceil(2*255/64) */
 #define MAXL 255
 #define NONE 0xFFFFFFFFu
+#define MAXSTEPS 64
 
 /* ------------------------------------------------------------------ parameters (harc:52-60) */
 typedef struct {
@@ -147,7 +148,10 @@ typedef struct {
     uint8_t *cons;         /* consensus, idx codes A0 C1 G2 T3 */
     vec32 m_order, m_meta; /* main stream: order; meta = pos | flag<<8 | rc<<9 */
     vec32 s_order;         /* singleton stream */
-    uint32_t p_rid; int p_j, p_dir;   /* proposal of the current round */
+    uint32_t p_rid; int p_j, p_dir;   /* proposal of the current step */
+    /* super-round: up to MAXSTEPS speculative steps against the frozen claim state */
+    uint32_t s_rid[MAXSTEPS]; uint8_t s_j[MAXSTEPS], s_dir[MAXSTEPS]; int nsteps, need_reseed;
+    int32_t *count0; uint8_t *cons0;  /* state at the start of the super-round (rollback point) */
 } chain_t;
 
 typedef struct {
@@ -187,7 +191,8 @@ static void cons_update(chain_t *c, const uint64_t *r, int L, int rev, int shift
 
 /* scan one bin: ids from highest to lowest, only unclaimed ones, at most maxsearch of them (reorder.cpp:540) */
 static uint32_t scan_bin(dict_t *d, uint32_t bin, const uint64_t *reads, int W, const uint8_t *claimed,
-                         const uint64_t *refsh, const uint64_t *mask, int thresh, int maxsearch, uint64_t *cands)
+                         const uint64_t *refsh, const uint64_t *mask, int thresh, int maxsearch, uint64_t *cands,
+                         const uint32_t *own, int nown)
 {
     uint32_t s = d->start[bin], e = d->live_end[bin];
     while (e > s && claimed[d->ids[e - 1]]) e--;
@@ -196,6 +201,9 @@ static uint32_t scan_bin(dict_t *d, uint32_t bin, const uint64_t *reads, int W, 
     for (uint32_t i = e; i > s && seen < maxsearch; i--) {
         uint32_t rid = d->ids[i - 1];
         if (claimed[rid]) continue;
+        int mine = 0;                                             /* reads this chain already took earlier in the same super-round */
+        for (int k = 0; k < nown; k++) if (own[k] == rid) mine = 1;
+        if (mine) continue;
         seen++; (*cands)++;
         const uint64_t *r = reads + (size_t)rid * W;
         int hd = 0;
@@ -206,7 +214,7 @@ static uint32_t scan_bin(dict_t *d, uint32_t bin, const uint64_t *reads, int W, 
 }
 
 static void propose(chain_t *c, dict_t *dict, const uint64_t *reads, const uint8_t *claimed, const params_t *p,
-                    const uint64_t *mask, const uint64_t *revmask, stage1_out_t *st)
+                    const uint64_t *mask, const uint64_t *revmask, stage1_out_t *st, const uint32_t *own, int nown)
 {
     int L = p->L, W = p->W;
     uint64_t ref[MAXW] = { 0 }, rev[MAXW] = { 0 }, topmask;
@@ -224,7 +232,7 @@ static void propose(chain_t *c, dict_t *dict, const uint64_t *reads, const uint8
             st->probes++;
             uint32_t bin = dict_lookup(&dict[l], key);
             if (bin == NONE) continue;
-            uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, ref, mask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands);
+            uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, ref, mask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands, own, nown);
             if (rid != NONE) { c->p_rid = rid; c->p_j = j; c->p_dir = 0; return; }
         }
         for (int l = 0; l < 2; l++) {                             /* reverse, reorder.cpp:585-643 */
@@ -233,7 +241,7 @@ static void propose(chain_t *c, dict_t *dict, const uint64_t *reads, const uint8
             st->probes++;
             uint32_t bin = dict_lookup(&dict[l], key);
             if (bin == NONE) continue;
-            uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, rev, revmask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands);
+            uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, rev, revmask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands, own, nown);
             if (rid != NONE) { c->p_rid = rid; c->p_j = j; c->p_dir = 1; return; }
         }
         /* revref <<= 2; ref >>= 2  (reorder.cpp:647-648), bitset<2L> semantics */
@@ -250,12 +258,22 @@ static void emit_main(chain_t *c, uint32_t order, int flag, int pos, int rc)
     vpush(&c->m_meta, (uint32_t)pos | ((uint32_t)flag << 8) | ((uint32_t)rc << 9));
 }
 
-/* reads: N x W packed words.  K chains. */
-static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint32_t K, stage1_out_t *out)
+/* reads: N x W packed words.  K chains, S speculative steps per super-round.
+ *
+ * One super-round: (A) every live chain walks up to S steps on its own against the FROZEN claim state (its own picks of this
+ * super-round excluded), bidding (step, chain) for every read it takes; it stops early when a step finds no candidate.
+ * (B) a read goes to the smallest (step, chain) bid; a chain keeps its steps up to (not including) the first one it did not
+ * win, rolls its consensus back to that point and retries from there in the next super-round.  (C) chains that ran out of
+ * candidates without losing a bid reseed, in chain order, from the one global descending cursor.
+ * K=1 is the reference at num_thr=1 for every S (nothing to lose, the chain just runs until it needs a new seed); S=1 is the
+ * plain round-synchronous schedule. */
+static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint32_t K, uint32_t nsteps, stage1_out_t *out)
 {
     int L = p->L, W = p->W;
     memset(out, 0, sizeof *out);
     if (K == 0) K = 1;
+    if (nsteps == 0) nsteps = 1;
+    if (nsteps > MAXSTEPS) nsteps = MAXSTEPS;
     dict_t dict[2];
     uint64_t *keys = malloc(8 * ((size_t)N + 1));
     for (int l = 0; l < 2; l++) {
@@ -277,6 +295,7 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
     for (uint32_t c = 0; c < K; c++) {                            /* reorder.cpp:476-497 */
         chain_t *x = &ch[c];
         x->count = malloc(sizeof(int32_t) * 4 * L); x->cons = malloc(L);
+        x->count0 = malloc(sizeof(int32_t) * 4 * L); x->cons0 = malloc(L);
         uint32_t cur = firstread;
         if (N == 0 || claimed[cur]) x->active = 0;
         else {
@@ -288,26 +307,45 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
     int64_t remainingpos = (int64_t)N - 1;
     while (nactive) {
         out->rounds++;
-        /* (1) propose against the frozen state */
-        for (uint32_t c = 0; c < K; c++) if (ch[c].active) propose(&ch[c], dict, reads, claimed, p, mask, revmask, out);
-        for (uint32_t c = 0; c < K; c++) if (ch[c].active && ch[c].p_rid != NONE && bid[ch[c].p_rid] == NONE) bid[ch[c].p_rid] = c;
-        /* (2) pass 1: winners claim (reorder.cpp:560-578 / :624-642) */
+        /* (A) speculative steps against the frozen state */
         for (uint32_t c = 0; c < K; c++) {
             chain_t *x = &ch[c];
-            if (!x->active || x->p_rid == NONE) continue;
-            if (bid[x->p_rid] != c) { out->conflicts++; continue; }
-            uint32_t k = x->p_rid;
-            claimed[k] = 1; x->cur = k;
-            cons_update(x, reads + (size_t)k * W, L, x->p_dir, x->p_j);
-            if (x->prev_unmatched) emit_main(x, x->prev, 0, L & 0xFF, 0);
-            emit_main(x, k, 1, x->p_j, x->p_dir);
-            x->prev_unmatched = 0;
+            if (!x->active) continue;
+            memcpy(x->count0, x->count, sizeof(int32_t) * 4 * L); memcpy(x->cons0, x->cons, L);
+            x->nsteps = 0; x->need_reseed = 0;
+            for (uint32_t t = 0; t < nsteps; t++) {
+                propose(x, dict, reads, claimed, p, mask, revmask, out, x->s_rid, x->nsteps);
+                if (x->p_rid == NONE) { x->need_reseed = 1; break; }
+                x->s_rid[t] = x->p_rid; x->s_j[t] = (uint8_t)x->p_j; x->s_dir[t] = (uint8_t)x->p_dir; x->nsteps = (int)t + 1;
+                uint32_t key = (t << 20) | c;
+                if (key < bid[x->p_rid]) bid[x->p_rid] = key;
+                cons_update(x, reads + (size_t)x->p_rid * W, L, x->p_dir, x->p_j);
+            }
         }
-        for (uint32_t c = 0; c < K; c++) if (ch[c].active && ch[c].p_rid != NONE) bid[ch[c].p_rid] = NONE;
-        /* (3) pass 2: reseed from the global descending cursor (reorder.cpp:650-688) */
+        /* (B) keep the steps before the first lost bid (reorder.cpp:560-578 / :624-642 for each kept step) */
         for (uint32_t c = 0; c < K; c++) {
             chain_t *x = &ch[c];
-            if (!x->active || x->p_rid != NONE) continue;
+            if (!x->active) continue;
+            int v = 0;
+            while (v < x->nsteps && bid[x->s_rid[v]] == (((uint32_t)v << 20) | c)) v++;
+            if (v < x->nsteps) {                                  /* lost a bid: roll back and replay the kept steps */
+                out->conflicts++; x->need_reseed = 0;
+                memcpy(x->count, x->count0, sizeof(int32_t) * 4 * L); memcpy(x->cons, x->cons0, L);
+                for (int t = 0; t < v; t++) cons_update(x, reads + (size_t)x->s_rid[t] * W, L, x->s_dir[t], x->s_j[t]);
+            }
+            for (int t = 0; t < v; t++) {
+                uint32_t k = x->s_rid[t];
+                claimed[k] = 1; x->cur = k;
+                if (x->prev_unmatched) emit_main(x, x->prev, 0, L & 0xFF, 0);
+                emit_main(x, k, 1, x->s_j[t], x->s_dir[t]);
+                x->prev_unmatched = 0;
+            }
+        }
+        for (uint32_t c = 0; c < K; c++) if (ch[c].active) for (int t = 0; t < ch[c].nsteps; t++) bid[ch[c].s_rid[t]] = NONE;
+        /* (C) reseed from the global descending cursor (reorder.cpp:650-688) */
+        for (uint32_t c = 0; c < K; c++) {
+            chain_t *x = &ch[c];
+            if (!x->active || !x->need_reseed) continue;
             int found = 0;
             while (remainingpos >= 0) {
                 if (!claimed[remainingpos]) { found = 1; break; }
@@ -335,7 +373,7 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
             out->flag[M] = (m >> 8) & 1 ? '1' : '0'; out->rc[M] = (m >> 9) & 1 ? 'r' : 'd';
         }
         for (size_t i = 0; i < ch[c].s_order.n; i++) out->order_s[S++] = ch[c].s_order.v[i];
-        free(ch[c].count); free(ch[c].cons); free(ch[c].m_order.v); free(ch[c].m_meta.v); free(ch[c].s_order.v);
+        free(ch[c].count); free(ch[c].cons); free(ch[c].count0); free(ch[c].cons0); free(ch[c].m_order.v); free(ch[c].m_meta.v); free(ch[c].s_order.v);
     }
     free(ch); free(claimed); free(bid); free(mask); free(revmask);
     dict_free(&dict[0]); dict_free(&dict[1]);
@@ -373,7 +411,7 @@ static void bput(bytes *b, const void *src, size_t n)
 static void bputc(bytes *b, char c) { bput(b, &c, 1); }
 
 /* ------------------------------------------------------------------ stage I, file contract of reorder.out <basedir> */
-int harc_oracle_reorder(const char *basedir, int L, uint32_t K, uint32_t *unmatched_out, uint64_t *stats4)
+int harc_oracle_reorder(const char *basedir, int L, uint32_t K, uint32_t S, uint32_t *unmatched_out, uint64_t *stats4)
 {
     if (L < 1 || L > MAXL) return -2;
     params_t p; params_init(&p, L);
@@ -385,7 +423,7 @@ int harc_oracle_reorder(const char *basedir, int L, uint32_t K, uint32_t *unmatc
     uint64_t *reads = calloc((size_t)N * p.W + 1, 8);
     for (uint32_t i = 0; i < N; i++) pack_read((const char *)txt + (size_t)i * (L + 1), L, p.W, reads + (size_t)i * p.W);   /* reorder.cpp:252 stride */
     free(txt);
-    stage1_out_t o; stage1_run(reads, N, &p, K, &o);
+    stage1_out_t o; stage1_run(reads, N, &p, K, S, &o);
     /* writetofile (reorder.cpp:722-830) */
     bytes dna = { 0 }, dna_s = { 0 };
     char s[MAXL + 2];
@@ -402,13 +440,13 @@ int harc_oracle_reorder(const char *basedir, int L, uint32_t K, uint32_t *unmatc
 }
 
 /* in-memory stage I for timing (cpu_baseline "port"): reads = N*L ASCII, no separators */
-int harc_oracle_stage1_mem(const char *ascii, uint32_t N, int L, uint32_t K, uint32_t *order, uint8_t *flag, uint8_t *pos,
+int harc_oracle_stage1_mem(const char *ascii, uint32_t N, int L, uint32_t K, uint32_t nsteps, uint32_t *order, uint8_t *flag, uint8_t *pos,
                            uint8_t *rc, uint32_t *M, uint32_t *order_s, uint32_t *S, uint32_t *unmatched, uint64_t *stats4)
 {
     params_t p; params_init(&p, L);
     uint64_t *reads = calloc((size_t)N * p.W + 1, 8);
     for (uint32_t i = 0; i < N; i++) pack_read(ascii + (size_t)i * L, L, p.W, reads + (size_t)i * p.W);
-    stage1_out_t o; stage1_run(reads, N, &p, K, &o);
+    stage1_out_t o; stage1_run(reads, N, &p, K, nsteps, &o);
     if (order) memcpy(order, o.order, 4 * (size_t)o.M);
     if (flag) memcpy(flag, o.flag, o.M);
     if (pos) memcpy(pos, o.pos, o.M);

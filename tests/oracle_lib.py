@@ -22,12 +22,12 @@ def load():
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     lib = C.CDLL(so)
     u32p, u64p, u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
-    lib.harc_oracle_reorder.argtypes = [C.c_char_p, C.c_int, C.c_uint32, u32p, u64p]
+    lib.harc_oracle_reorder.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, u32p, u64p]
     lib.harc_oracle_encoder.argtypes = [C.c_char_p, C.c_int, C.c_uint32, u32p, u32p]
     lib.harc_oracle_pack_order.argtypes = [C.c_char_p]
     lib.harc_oracle_decoder.argtypes = [C.c_char_p, C.c_uint32]
     lib.harc_oracle_preprocess.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p]
-    lib.harc_oracle_stage1_mem.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_uint32, u32p, u8p, u8p, u8p, u32p, u32p, u32p, u32p, u64p]
+    lib.harc_oracle_stage1_mem.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, u32p, u8p, u8p, u8p, u32p, u32p, u32p, u32p, u64p]
     _lib = lib
     return lib
 

@@ -70,42 +70,43 @@ def test_fused_compress_and_pack_order_match_reference(case, tmp_path):
             harc_amd.pack_order(base, _L(g))
 
 
-def _oracle_pipeline(oracle, reads_txt, L, K, E, d):
+def _oracle_pipeline(oracle, reads_txt, L, K, E, d, S=1):
     base = ol.stage_dir(d, {})
     assert oracle.harc_oracle_preprocess(reads_txt, len(reads_txt), L, base.encode()) == 0
     inputs = ol.read_dir(base)
-    assert oracle.harc_oracle_reorder(base.encode(), L, K, None, None) == 0
+    assert oracle.harc_oracle_reorder(base.encode(), L, K, S, None, None) == 0
     s1 = ol.read_dir(base)
     assert oracle.harc_oracle_encoder(base.encode(), L, E, None, None) == 0
     return inputs, s1, ol.read_dir(base), base
 
 
+@pytest.mark.parametrize("S", [1, 4, 16, 64])
 @pytest.mark.parametrize("case,K,E", [("L100_err_5k", 4, 3), ("L100_err_5k", 64, 8), ("L150_err_3k", 16, 2), ("L63_err_3k", 7, 5),
                                         ("L100_repeat_dup_4k", 32, 4), ("L100_three", 8, 8), ("L100_allN_20", 2, 2),
                                         ("L255_err_1k", 5, 3), ("L100_lowcov_4k", 128, 1), ("L40_err_3k", 300, 2), ("L101_err_3k", 9, 4)])
-def test_K_chains_E_shards_match_oracle(case, K, E, oracle, tmp_path):
+def test_K_chains_E_shards_match_oracle(case, K, E, S, oracle, tmp_path):
     import harc_amd
     g = ol.load_golden(case)
     L = _L(g)
     (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
-    inputs, s1, s2, _ = _oracle_pipeline(oracle, g["reads.txt"], L, K, E, tmp_path / "o")
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, g["reads.txt"], L, K, E, tmp_path / "o", S)
     base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
-    harc_amd.reorder(base, L, num_chains=K)
-    assert_same(ol.read_dir(base), s1, ol.STAGE1_FILES, f"{case} K={K}: stage I vs oracle")
+    harc_amd.reorder(base, L, num_chains=K, num_steps=S)
+    assert_same(ol.read_dir(base), s1, ol.STAGE1_FILES, f"{case} K={K} S={S}: stage I vs oracle")
     harc_amd.encoder(base, L, num_thr=E)
     fs = ol.stage2_files(E)
     assert_same(ol.read_dir(base), s2, fs, f"{case} K={K} E={E}: stage II vs oracle")
 
 
-@pytest.mark.parametrize("n,L,glen,err,K,E", [(60000, 100, 300000, 0.01, 64, 8), (40000, 100, 2000000, 0.0, 40, 3), (30000, 150, 200000, 0.01, 0, 8)])
-def test_medium_vs_oracle_and_roundtrip(n, L, glen, err, K, E, oracle, tmp_path):
+@pytest.mark.parametrize("n,L,glen,err,K,E,S", [(60000, 100, 300000, 0.01, 64, 8, 16), (40000, 100, 2000000, 0.0, 40, 3, 5), (30000, 150, 200000, 0.01, 0, 8, 0)])
+def test_medium_vs_oracle_and_roundtrip(n, L, glen, err, K, E, S, oracle, tmp_path):
     import harc_amd
     txt = gen.reads_text(1234 + n, n, L, glen, err=err)
     (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
-    Ko = K if K else max(1, (txt.count(b"\n") - sum(1 for l in txt.split(b"\n") if b"N" in l)) // 1024)
-    inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, L, Ko, E, tmp_path / "o")
+    Ko = K if K else max(1, (txt.count(b"\n") - sum(1 for l in txt.split(b"\n") if b"N" in l)) // 2048)   # auto_chains() in stage1.hip
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, L, Ko, E, tmp_path / "o", S if S else 16)
     base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
-    harc_amd.compress(base, L, num_thr=E, num_chains=K)
+    harc_amd.compress(base, L, num_thr=E, num_chains=K, num_steps=S)
     fs = ol.stage2_files(E)
     assert_same(ol.read_dir(base), s2, fs, "fused compress vs oracle")
     assert oracle.harc_oracle_decoder(base.encode(), E) == 0

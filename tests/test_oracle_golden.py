@@ -21,13 +21,14 @@ def test_preprocess_matches_reference(case, oracle, tmp_path):
         assert got[f] == g["stage1/" + f], f
 
 
+@pytest.mark.parametrize("S", [1, 16])
 @pytest.mark.parametrize("case", CASES)
-def test_stage1_K1_bit_exact(case, oracle, tmp_path):
+def test_stage1_K1_bit_exact(case, S, oracle, tmp_path):
     g = ol.load_golden(case)
     L = len(g["reads.txt"].split(b"\n")[0])
     base = ol.stage_dir(tmp_path, {k: g["stage1/" + k] for k in ["input_clean.dna", "numreads.bin"]})
     unmatched = C.c_uint32(0)
-    assert oracle.harc_oracle_reorder(base.encode(), L, 1, C.byref(unmatched), None) == 0
+    assert oracle.harc_oracle_reorder(base.encode(), L, 1, S, C.byref(unmatched), None) == 0
     got = ol.read_dir(base)
     for f in ol.STAGE1_FILES:
         assert got[f] == g["stage1/" + f], f"{case}: {f} differs from reference"
