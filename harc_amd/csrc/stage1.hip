@@ -9,6 +9,7 @@
 //
 // Integer / HBM-latency bound; no MFMA.  Wave = 64 everywhere.
 #include "devutil.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------ kernel argument block
 struct S1Args {
@@ -371,6 +372,7 @@ template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
 
     uint32_t np = 0, nc = 0, nuse = 0;
     int nst = 0; bool needseed = false;
+    int lastp = (int)h.pad0;                                     // priority index of this chain's previous hit
     for (int t = 0; t < s.S; t++) {
         uint64_t ref[W], rref[W];
         cons_pack<W>(st, L, lane, ref);
@@ -382,8 +384,14 @@ template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
         // Probes are issued in priority order in batches: every probe behind the first hit of a batch is speculative traffic,
         // every extra batch is a serial round trip to HBM.
         int base = 0;
-        for (int bi = 0; bi < s.nbatch; bi++) {
-            const int bend = s.batch_end[bi];
+        for (int bi = 0; base < s.nprobe; bi++) {
+            // first batch: twice the priority index of the chain's previous hit (high coverage -> hits at small shifts -> narrow first
+            // batch); every later batch is a full wave.  s.nbatch > 0 (HARC_AMD_BATCHES) overrides with a fixed schedule.
+            int bend;
+            if (s.nbatch > 0) bend = s.batch_end[bi < s.nbatch ? bi : s.nbatch - 1];
+            else { int w0 = bi == 0 ? ((2 * lastp + 16 + 15) & ~15) : 64; if (w0 > 64) w0 = 64; bend = base + w0; }
+            if (bend > s.nprobe) bend = s.nprobe;
+            if (bend <= base) bend = s.nprobe;
             const int p = base + lane;
             uint32_t mine = HARC_NONE; int j = 0, dir = 0;
             uint64_t mrd[W];
@@ -462,6 +470,7 @@ template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
 #pragma unroll
                 for (int w = 0; w < W; w++) frd[w] = shfl_u64(mrd[w], srcl);
                 nuse += (uint32_t)(base + srcl + 1);
+                lastp = base + srcl;
                 break;
             }
             base = bend;
@@ -483,6 +492,7 @@ template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
         cst.x += np; cst.y += nc; cst.z += nuse; s.cstat[c] = cst;
         h.mode = 0;
         h.nsteps = (uint32_t)nst;
+        h.pad0 = (uint32_t)lastp;
         h.flags = needseed ? (h.flags | CH_NEEDSEED) : (h.flags & ~CH_NEEDSEED);
         s.hdr[c] = h;
     }
@@ -653,7 +663,13 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     if (n == 0) return HARC_AMD_OK;
     uint64_t *k1 = nullptr; uint32_t *h0 = nullptr, *b0 = nullptr, *bs = nullptr;
     RC_TRY(dalloc(c, &k1, n)); RC_TRY(dalloc(c, &h0, n)); RC_TRY(dalloc(c, &b0, n)); RC_TRY(dalloc(c, &bs, n));
-    d->cap = 2ull * n + 2;
+    {   // load factor 1/4 when HBM allows (fewer dependent re-probes: the chain kernel is latency-bound), else 1/3, else 1/2
+        unsigned long long m = 4;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) { while (m > 2 && (double)m * n * sizeof(HashSlot) > 0.25 * (double)fr) m--; }
+        if (const char *e = getenv("HARC_AMD_CAPMULT")) m = strtoull(e, nullptr, 10);
+        d->cap = (m < 2 ? 2 : m) * n + 2;
+    }
     RC_TRY(dalloc(c, &d->slots, d->cap)); RC_TRY(dalloc(c, &d->ids, n)); RC_TRY(dalloc(c, &d->d_nbins, 1));
     const unsigned g = (n + 255) / 256;
     RC_TRY(prim_sort_pairs_u64_u32(c, keys, k1, ids, d->ids, n, kbits));        // stable: ids ascending inside a bin (reorder.cpp:372-384)
@@ -744,11 +760,13 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     uint16_t *d_tab = nullptr; RC_TRY(dalloc(c, &d_tab, tab.size() + 1));
     HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream));
     a.probe_tab = d_tab; a.nprobe = (int)tab.size();
-    {   // 16,16,32,64,64,... probes per batch
-        const int sizes[] = { 16, 16, 32, 64, 64, 64, 64, 64, 64, 64, 64, 64 };
-        int e = 0; a.nbatch = 0;
-        while (e < a.nprobe && a.nbatch < 12) { e += sizes[a.nbatch]; if (e > a.nprobe) e = a.nprobe; a.batch_end[a.nbatch++] = e; }
-        if (e < a.nprobe) a.batch_end[a.nbatch - 1] = a.nprobe;   // not reachable for readlen <= 255 (<= 4*127 probes needs <= 10 batches)
+    a.nbatch = 0;                                                // adaptive batches (k_steps) unless a fixed schedule is forced
+    if (const char *e = getenv("HARC_AMD_BATCHES")) {             // tuning knob, e.g. "32,64"; the last size repeats
+        int sizes[12], k = 0, last = 64; const char *q = e;
+        while (*q && k < 12) { int v = atoi(q); if (v < 1) v = 1; if (v > 64) v = 64; sizes[k++] = last = v; while (*q && *q != ',') q++; if (*q == ',') q++; }
+        for (; k < 12; k++) sizes[k] = last;
+        int en = 0;
+        while (en < a.nprobe && a.nbatch < 12) { en += sizes[a.nbatch]; if (en > a.nprobe) en = a.nprobe; a.batch_end[a.nbatch++] = en; }
     }
     HIP_TRY(hipMemsetAsync(a.claimed, 0, nwords * 8, c->stream));
     HIP_TRY(hipMemsetAsync(a.bid, 0xFF, ((size_t)N + 1) * 4, c->stream));

@@ -6,6 +6,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# On a GPU box initialise torch's HIP runtime BEFORE libharc_amd.so is loaded: torch bundles its own libamdhip64 and refuses to
+# see the device when another copy of the runtime was initialised first in the same process.
+try:
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+except Exception:  # pragma: no cover
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
