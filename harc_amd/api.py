@@ -75,6 +75,7 @@ def lib():
     l.harc_amd_get_counters.argtypes = [ctx, C.POINTER(Counters)]
     for f in ("harc_amd_reorder_files", "harc_amd_encoder_files", "harc_amd_compress_files", "harc_amd_pack_order_files"):
         getattr(l, f).argtypes = [PP, C.c_char_p]
+    l.harc_amd_preprocess_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     _lib = l
     return l
 
@@ -108,6 +109,11 @@ def compress(basedir, readlen, num_thr=1, num_chains=1, **kw):
     """harc:65-69 fused: stage I -> stage II in HBM"""
     p = default_params(readlen, num_thr=num_thr, num_chains=num_chains, **kw)
     _check(lib().harc_amd_compress_files(C.byref(p), os.fsencode(basedir)))
+
+
+def preprocess(fastq, basedir, readlen):
+    """== `preprocess.out <fastq> <basedir> False False <readlen>` (src/preprocess.cpp:22-137): the N split"""
+    _check(lib().harc_amd_preprocess_files(os.fsencode(fastq), os.fsencode(basedir), readlen))
 
 
 def pack_order(basedir, readlen=100, **kw):

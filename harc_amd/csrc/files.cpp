@@ -158,3 +158,51 @@ extern "C" int harc_amd_pack_order_files(const harc_amd_params *params, const ch
     RC_TRY(spit_stream(g.c, HARC_AMD_P_ORDER_TAIL, 0, od + "read_order.bin.tail"));
     return HARC_AMD_OK;
 }
+
+// preprocess.out <fastq> <basedir> <preserve_order> <preserve_quality> <readlen>   (src/preprocess.cpp:50-137)
+// Splits the FASTQ into output/input_clean.dna (reads without N), output/input_N.dna, output/read_order_N.bin and
+// output/numreads.bin.  Quality / id side files (-q) are outside the hot path and not produced here.
+extern "C" int harc_amd_preprocess_files(const char *fastq, const char *basedir, int32_t readlen)
+{
+    if (!fastq || !basedir || readlen < 1 || readlen > 255) { harc_set_error("preprocess: bad arguments"); return HARC_AMD_EINVAL; }
+    FILE *in = fopen(fastq, "rb");
+    if (!in) { harc_set_error("cannot open %s", fastq); return HARC_AMD_EIO; }
+    const std::string od = std::string(basedir) + "/output/";
+    FILE *fc = fopen((od + "input_clean.dna").c_str(), "wb"), *fn = fopen((od + "input_N.dna").c_str(), "wb"),
+         *fo = fopen((od + "read_order_N.bin").c_str(), "wb");
+    if (!fc || !fn || !fo) { if (fc) fclose(fc); if (fn) fclose(fn); if (fo) fclose(fo); fclose(in); harc_set_error("cannot create files under %s", od.c_str()); return HARC_AMD_EIO; }
+    std::vector<char> buf(1 << 16);
+    std::string line;
+    uint64_t readnum = 0, nclean = 0; int li = 0, rc = HARC_AMD_OK;
+    auto flush_line = [&]() {
+        if (li == 1) {
+            if ((int)line.size() != readlen) {                    // preprocess.cpp:92-97
+                printf("Read length not fixed. Found two different read lengths: %d and %zu\n", readlen, line.size());
+                harc_set_error("read length not fixed"); rc = HARC_AMD_EINVAL; return;
+            }
+            if (line.find('N') != std::string::npos) {
+                fwrite(line.data(), 1, line.size(), fn); fputc('\n', fn);
+                const uint32_t rn = (uint32_t)readnum; fwrite(&rn, 4, 1, fo);          // low 4 bytes of the counter, preprocess.cpp:102
+            } else { fwrite(line.data(), 1, line.size(), fc); fputc('\n', fc); nclean++; }
+        }
+        if (li == 3) readnum++;
+        li = (li + 1) & 3;
+        line.clear();
+    };
+    size_t got;
+    while (rc == HARC_AMD_OK && (got = fread(buf.data(), 1, buf.size(), in)) > 0) {
+        size_t s = 0;
+        for (size_t i = 0; i < got && rc == HARC_AMD_OK; i++)
+            if (buf[i] == '\n') { line.append(buf.data() + s, i - s); s = i + 1; flush_line(); }
+        if (s < got) line.append(buf.data() + s, got - s);
+    }
+    if (rc == HARC_AMD_OK && !line.empty()) flush_line();
+    fclose(in); fclose(fc); fclose(fn); fclose(fo);
+    if (rc != HARC_AMD_OK) return rc;
+    if (readnum > 4294967290ull) { printf("Too many reads. HARC supports at most 4294967290 reads\n"); harc_set_error("too many reads"); return HARC_AMD_EINVAL; }   // :122-126
+    const uint32_t n32 = (uint32_t)nclean;
+    RC_TRY(spit(od + "numreads.bin", &n32, 4));
+    printf("Read length: %d\nTotal number of reads: %llu\nTotal number of reads without N: %llu\nPreprocessing Done!\n", readlen,
+           (unsigned long long)readnum, (unsigned long long)nclean);
+    return HARC_AMD_OK;
+}

@@ -159,6 +159,9 @@ int harc_amd_reorder_files(const harc_amd_params *params, const char *basedir);
 int harc_amd_encoder_files(const harc_amd_params *params, const char *basedir);
 int harc_amd_compress_files(const harc_amd_params *params, const char *basedir);
 int harc_amd_pack_order_files(const harc_amd_params *params, const char *basedir);
+/* == `preprocess.out <fastq> <basedir> <preserve_order> <preserve_quality> <readlen>` (src/preprocess.cpp:22-137, harc:50),
+   the N split only; host code, feeds the boundary */
+int harc_amd_preprocess_files(const char *fastq, const char *basedir, int32_t readlen);
 
 #ifdef __cplusplus
 }

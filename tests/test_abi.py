@@ -43,3 +43,30 @@ def test_no_cpu_fallback():
     with pytest.raises(harc_amd.HarcAmdError) as e:
         harc_amd.HarcAmd(harc_amd.default_params(100))
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("case", ["L100_err_5k", "L150_err_3k", "L100_allN_20", "L100_one"])
+def test_preprocess_matches_reference_files(case, tmp_path):
+    """harc_amd_preprocess_files is host code (no device needed): same four files as the reference's preprocess.out"""
+    import harc_amd
+    from tests import oracle_lib as ol
+    g = ol.load_golden(case)
+    reads = g["reads.txt"].split()
+    L = len(reads[0])
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(b"".join(b"@T.%d\n%s\n+\n%s\n" % (i, r, b"H" * L) for i, r in enumerate(reads)))
+    base = ol.stage_dir(tmp_path, {})
+    harc_amd.preprocess(str(fq), base, L)
+    got = ol.read_dir(base)
+    for f in ["input_clean.dna", "input_N.dna", "numreads.bin", "read_order_N.bin"]:
+        assert got[f] == g["stage1/" + f], f
+
+
+def test_preprocess_rejects_variable_length(tmp_path):
+    import harc_amd
+    from tests import oracle_lib as ol
+    fq = tmp_path / "bad.fastq"
+    fq.write_bytes(b"@a\nACGT\n+\nHHHH\n@b\nACG\n+\nHHH\n")
+    base = ol.stage_dir(tmp_path, {})
+    with pytest.raises(harc_amd.HarcAmdError):
+        harc_amd.preprocess(str(fq), base, 4)          # preprocess.cpp:92-97

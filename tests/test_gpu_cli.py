@@ -1,0 +1,50 @@
+"""The drop-in driver: ./harc -c FASTQ [-p] [-t N] [-k K] end to end on the GPU; the archive is unpacked and decoded with the
+oracle's restatement of decoder.cpp (the reference's own -d would read the same files)."""
+import os
+import shutil
+import subprocess
+import tarfile
+
+import pytest
+
+from tests import gen
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("flags,E", [([], 8), (["-t", "3", "-k", "1"], 3), (["-p", "-t", "2"], 2)])
+def test_harc_c_roundtrip(flags, E, oracle, tmp_path):
+    L = 100
+    txt = gen.reads_text(99, 20000, L, 150000, err=0.01)
+    reads = txt.split()
+    fq = tmp_path / "sample.fastq"
+    fq.write_bytes(b"".join(b"@T.%d\n%s\n+\n%s\n" % (i, r, b"H" * L) for i, r in enumerate(reads)))
+    r = subprocess.run([os.path.join(ROOT, "harc"), "-c", str(fq)] + flags, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "were unmatched" in r.stdout and "singleton reads were aligned" in r.stdout        # the reference's counters (reorder.cpp:701, encoder.cpp:506-508)
+    arc = tmp_path / "sample.harc"
+    assert arc.exists() and not (tmp_path / "output").exists()
+    out = tmp_path / "x" / "output"
+    out.mkdir(parents=True)
+    with tarfile.open(arc) as tf:
+        tf.extractall(out)
+    for s in ["read_noise", "read_noisepos", "read_pos", "read_seq", "read_rev"]:
+        with tarfile.open(out / (s + ".tar")) as tf:
+            tf.extractall(out)
+    assert len([f for f in os.listdir(out) if f.startswith("read_pos.txt")]) == E              # harc:171 discovers num_thr_e this way
+    if "-p" in flags:
+        assert (out / "read_order.bin").exists() and (out / "read_order.bin.tail").exists() and (out / "read_order_N.bin").exists()
+    else:
+        assert not (out / "read_order.bin").exists()
+    assert oracle.harc_oracle_decoder(str(tmp_path / "x").encode(), E) == 0
+    assert sorted((out / "output.dna").read_bytes().split()) == sorted(reads)
+
+
+def test_harc_refuses_existing_output_dir(tmp_path):
+    fq = tmp_path / "s.fastq"
+    fq.write_bytes(b"@a\nACGT\n+\nHHHH\n")
+    (tmp_path / "output").mkdir()
+    r = subprocess.run([os.path.join(ROOT, "harc"), "-c", str(fq)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 1 and "already exists" in r.stdout                                   # harc:38-41
