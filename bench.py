@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--chains", type=int, default=0)
     ap.add_argument("--shards", type=int, default=8, help="num_thr of the reference = encoder shards per GPU (harc:195 default 8)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket exchange even at world size 1 (exercises the N>1 path on one GPU)")
     ap.add_argument("--cpu-sample", type=int, default=0)
     args = ap.parse_args()
 
@@ -127,9 +128,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)        # nccl == RCCL on ROCm
 
     import harc_amd
@@ -143,7 +147,7 @@ def main():
     p = harc_amd.default_params(L, num_thr=args.shards, num_chains=args.chains, device=local, profile=1)
     h = harc_amd.HarcAmd(p)
     sharder = None
-    if world > 1:
+    if dist is not None:
         from harc_amd import multigpu
         sharder = multigpu.BucketSharder(h, dist, dev, L)
         packed = sharder.pack(clean)                              # local 2-bit reads, resident in HBM before the clock starts
@@ -224,11 +228,12 @@ def main():
         ns = args.cpu_sample or min(n, 3_300_000 if err > 0 or G // max(1, n) < 10 else 1_000_000)
         Gs = max(L * 4, int(G * (ns / n)))
         out["cpu_baseline"] = cpu_baseline(ns, L, Gs, err, 999, dev)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     h.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)                        # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ void harc_set_error(const char *fmt, ...)
 }
 extern "C" const char *harc_amd_last_error(void) { return g_err; }
 
-int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes)
+int harc_raw_alloc(harc_amd_ctx *c, void **p, size_t bytes)
 {
     *p = nullptr;
     if (bytes == 0) bytes = 16;
@@ -22,7 +22,7 @@ int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes)
     if (c->dev_bytes > c->dev_peak) c->dev_peak = c->dev_bytes;
     return HARC_AMD_OK;
 }
-void harc_dev_free(harc_amd_ctx *c, void *p)
+void harc_raw_free(harc_amd_ctx *c, void *p)
 {
     if (!p) return;
     for (size_t i = 0; i < c->owned.size(); i++)
@@ -31,6 +31,67 @@ void harc_dev_free(harc_amd_ctx *c, void *p)
     if (it != c->sizes.end()) { c->dev_bytes -= it->second; c->sizes.erase(it); }
     (void)hipFree(p);
 }
+static size_t pool_in_use(const harc_amd_ctx *c)
+{
+    size_t u = 0;
+    for (size_t i = 0; i <= c->pool_cur && i < c->pool.size(); i++) u += c->pool[i].used;
+    return u;
+}
+int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes)
+{
+    *p = nullptr;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    for (;;) {
+        if (c->pool_cur < c->pool.size()) {
+            harc_amd_ctx::PoolChunk &k = c->pool[c->pool_cur];
+            if (k.used + bytes <= k.size) { *p = k.base + k.used; k.used += bytes; break; }
+            if (c->pool_cur + 1 < c->pool.size()) { c->pool_cur++; c->pool[c->pool_cur].used = 0; continue; }
+        }
+        size_t want = bytes;
+        const size_t grow = c->pool_total < ((size_t)8 << 30) ? c->pool_total : ((size_t)8 << 30);
+        if (want < grow) want = grow;
+        if (want < ((size_t)64 << 20)) want = (size_t)64 << 20;
+        void *base = nullptr;
+        hipError_t e = hipMalloc(&base, want);
+        if (e != hipSuccess && want > bytes) { want = bytes; e = hipMalloc(&base, want); }
+        if (e != hipSuccess) { harc_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return HARC_AMD_ENOMEM; }
+        c->pool.push_back({ (char *)base, want, 0 });
+        c->pool_total += want;
+        c->pool_cur = c->pool.size() - 1;
+    }
+    const size_t live = c->dev_bytes + pool_in_use(c);
+    if (live > c->dev_peak) c->dev_peak = live;
+    return HARC_AMD_OK;
+}
+void harc_dev_free(harc_amd_ctx *c, void *p) { (void)c; (void)p; }   // pool memory is released by mark, not by pointer
+harc_mark_t harc_pool_mark(harc_amd_ctx *c)
+{
+    if (c->pool.empty()) return 0;
+    return ((harc_mark_t)c->pool_cur << 48) | (harc_mark_t)c->pool[c->pool_cur].used;
+}
+void harc_pool_release(harc_amd_ctx *c, harc_mark_t m)
+{
+    if (c->pool.empty()) return;
+    const size_t cur = (size_t)(m >> 48), used = (size_t)(m & (((harc_mark_t)1 << 48) - 1));
+    for (size_t i = cur + 1; i < c->pool.size(); i++) c->pool[i].used = 0;
+    c->pool[cur].used = used;
+    c->pool_cur = cur;
+}
+int harc_host_alloc(harc_amd_ctx *c, void **p, size_t bytes)
+{
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (bytes == 0) bytes = 64;
+    for (auto &k : c->harena) if (k.used + bytes <= k.size) { *p = k.base + k.used; k.used += bytes; return HARC_AMD_OK; }
+    size_t want = bytes < ((size_t)16 << 20) ? ((size_t)16 << 20) : bytes + (bytes >> 2);
+    void *base = nullptr;
+    hipError_t e = hipHostMalloc(&base, want, hipHostMallocDefault);
+    if (e != hipSuccess) { harc_set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return HARC_AMD_ENOMEM; }
+    c->harena.push_back({ (char *)base, want, bytes });
+    *p = base;
+    return HARC_AMD_OK;
+}
+void harc_host_reset(harc_amd_ctx *c) { for (auto &k : c->harena) k.used = 0; }
 int harc_d2h(harc_amd_ctx *c, std::vector<uint8_t> &dst, const void *d_src, size_t bytes)
 {
     dst.resize(bytes);
@@ -93,22 +154,24 @@ extern "C" void harc_amd_destroy(harc_amd_ctx *c)
     (void)hipSetDevice(c->P.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     for (void *p : c->owned) (void)hipFree(p);
+    for (auto &k : c->pool) (void)hipFree(k.base);
+    for (auto &k : c->harena) (void)hipHostFree(k.base);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 static void drop_results(harc_amd_ctx *c)
 {
-    void *ps[] = { c->d_order, c->d_flag, c->d_pos, c->d_rc, c->d_order_s, c->d_oreads, c->d_sreads };
-    for (void *p : ps) if (p) harc_dev_free(c, p);
+    harc_pool_release(c, 0);                                     // every per-run buffer lives in the pool
     c->d_order = nullptr; c->d_flag = c->d_pos = c->d_rc = nullptr; c->d_order_s = nullptr; c->d_oreads = nullptr; c->d_sreads = nullptr;
     c->have_s1 = c->have_s2 = c->s1_from_files = false; c->M = c->S = 0;
     c->out.clear();
+    harc_host_reset(c);
 }
 
 static int upload(harc_amd_ctx *c, const void *host, size_t bytes, char **d)
 {
-    RC_TRY(harc_dev_alloc(c, (void **)d, bytes + 16));
+    RC_TRY(harc_raw_alloc(c, (void **)d, bytes + 16));
     if (bytes) HIP_TRY(hipMemcpyAsync(*d, host, bytes, hipMemcpyHostToDevice, c->stream));
     return HARC_AMD_OK;
 }
@@ -118,9 +181,9 @@ extern "C" int harc_amd_set_reads_ascii_device(harc_amd_ctx *c, const char *d_as
     if (!c || (n && !d_ascii) || stride < (uint32_t)c->P.readlen) return HARC_AMD_EINVAL;
     HIP_TRY(hipSetDevice(c->P.device));
     drop_results(c);
-    if (c->d_reads) { harc_dev_free(c, c->d_reads); c->d_reads = nullptr; }
+    if (c->d_reads) { harc_raw_free(c, c->d_reads); c->d_reads = nullptr; }
     c->N = n;
-    RC_TRY(dalloc(c, &c->d_reads, (size_t)n * c->W + 1));
+    RC_TRY(harc_raw_alloc(c, (void **)&c->d_reads, ((size_t)n * c->W + 1) * 8));
     RC_TRY(s1_pack_ascii(c, d_ascii, n, stride, c->d_reads));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->C.n_clean = n;
@@ -134,7 +197,7 @@ extern "C" int harc_amd_set_reads_ascii(harc_amd_ctx *c, const char *ascii, uint
     const size_t bytes = n ? (size_t)(n - 1) * stride + c->P.readlen : 0;
     RC_TRY(upload(c, ascii, bytes, &d));
     int r = harc_amd_set_reads_ascii_device(c, d, n, stride);
-    harc_dev_free(c, d);
+    harc_raw_free(c, d);
     return r;
 }
 extern "C" int harc_amd_set_reads_packed_device(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n)
@@ -142,9 +205,9 @@ extern "C" int harc_amd_set_reads_packed_device(harc_amd_ctx *c, const uint64_t 
     if (!c || (n && !d_packed)) return HARC_AMD_EINVAL;
     HIP_TRY(hipSetDevice(c->P.device));
     drop_results(c);
-    if (c->d_reads) { harc_dev_free(c, c->d_reads); c->d_reads = nullptr; }
+    if (c->d_reads) { harc_raw_free(c, c->d_reads); c->d_reads = nullptr; }
     c->N = n;
-    RC_TRY(dalloc(c, &c->d_reads, (size_t)n * c->W + 1));
+    RC_TRY(harc_raw_alloc(c, (void **)&c->d_reads, ((size_t)n * c->W + 1) * 8));
     if (n) HIP_TRY(hipMemcpyAsync(c->d_reads, d_packed, (size_t)n * c->W * 8, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->C.n_clean = n;
@@ -154,9 +217,9 @@ extern "C" int harc_amd_set_nreads_ascii_device(harc_amd_ctx *c, const char *d_a
 {
     if (!c || (n && !d_ascii) || stride < (uint32_t)c->P.readlen) return HARC_AMD_EINVAL;
     HIP_TRY(hipSetDevice(c->P.device));
-    if (c->d_nreads3) { harc_dev_free(c, c->d_nreads3); c->d_nreads3 = nullptr; }
+    if (c->d_nreads3) { harc_raw_free(c, c->d_nreads3); c->d_nreads3 = nullptr; }
     c->NN = n; c->have_s2 = false;
-    RC_TRY(dalloc(c, &c->d_nreads3, (size_t)n * c->W3 + 1));
+    RC_TRY(harc_raw_alloc(c, (void **)&c->d_nreads3, ((size_t)n * c->W3 + 1) * 8));
     RC_TRY(s1_pack3_ascii(c, d_ascii, n, stride, c->d_nreads3));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->C.n_N = n;
@@ -170,7 +233,7 @@ extern "C" int harc_amd_set_nreads_ascii(harc_amd_ctx *c, const char *ascii, uin
     const size_t bytes = n ? (size_t)(n - 1) * stride + c->P.readlen : 0;
     RC_TRY(upload(c, ascii, bytes, &d));
     int r = harc_amd_set_nreads_ascii_device(c, d, n, stride);
-    harc_dev_free(c, d);
+    harc_raw_free(c, d);
     return r;
 }
 
@@ -193,13 +256,13 @@ extern "C" int harc_amd_set_stage1_streams(harc_amd_ctx *c, const char *temp_dna
         HIP_TRY(hipMemcpyAsync(c->d_rc, rc, M, hipMemcpyHostToDevice, c->stream));
         char *d = nullptr; RC_TRY(upload(c, temp_dna, (size_t)(M - 1) * (L + 1) + L, &d));
         RC_TRY(s1_pack_ascii(c, d, M, (uint32_t)L + 1, c->d_oreads));
-        HIP_TRY(hipStreamSynchronize(c->stream)); harc_dev_free(c, d);
+        HIP_TRY(hipStreamSynchronize(c->stream)); harc_raw_free(c, d);
     }
     if (S) {
         HIP_TRY(hipMemcpyAsync(c->d_order_s, order_s, (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
         char *d = nullptr; RC_TRY(upload(c, temp_dna_s, (size_t)(S - 1) * (L + 1) + L, &d));
         RC_TRY(s1_pack_ascii(c, d, S, (uint32_t)L + 1, c->d_sreads));
-        HIP_TRY(hipStreamSynchronize(c->stream)); harc_dev_free(c, d);
+        HIP_TRY(hipStreamSynchronize(c->stream)); harc_raw_free(c, d);
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_s1 = true; c->s1_from_files = true;
@@ -272,8 +335,9 @@ extern "C" int harc_amd_get_stream(harc_amd_ctx *c, int32_t id, int32_t shard, c
     if (it == c->out.end()) {
         if (id >= HARC_AMD_S1_ORDER && id <= HARC_AMD_S1_DNA_SINGLETON) {
             if (!c->have_s1 || shard != 0) { harc_set_error("stream %d not available", id); return HARC_AMD_ESTATE; }
-            std::vector<uint8_t> &b = c->out[key];
+            std::vector<uint8_t> &b = out_buf(c, id, shard);
             const int L = c->P.readlen;
+            bool made_oriented = false;
             switch (id) {
             case HARC_AMD_S1_ORDER: RC_TRY(harc_d2h(c, b, c->d_order, (size_t)c->M * 4)); break;
             case HARC_AMD_S1_FLAG: RC_TRY(harc_d2h(c, b, c->d_flag, c->M)); break;
@@ -281,26 +345,29 @@ extern "C" int harc_amd_get_stream(harc_amd_ctx *c, int32_t id, int32_t shard, c
             case HARC_AMD_S1_RC: RC_TRY(harc_d2h(c, b, c->d_rc, c->M)); break;
             case HARC_AMD_S1_ORDER_SINGLETON: RC_TRY(harc_d2h(c, b, c->d_order_s, (size_t)c->S * 4)); break;
             case HARC_AMD_S1_DNA: {
-                if (!c->d_oreads) RC_TRY(stage1_make_oriented(c));
+                if (!c->d_oreads) { RC_TRY(stage1_make_oriented(c)); made_oriented = true; }
+                const harc_mark_t mk = harc_pool_mark(c);
                 char *d = nullptr; RC_TRY(dalloc(c, &d, (size_t)c->M * (L + 1) + 1));
                 RC_TRY(s1_unpack_to_ascii(c, c->d_oreads, c->M, d));
                 RC_TRY(harc_d2h(c, b, d, (size_t)c->M * (L + 1)));
-                HIP_TRY(hipStreamSynchronize(c->stream)); harc_dev_free(c, d);
+                HIP_TRY(hipStreamSynchronize(c->stream)); harc_pool_release(c, mk); (void)made_oriented;
                 break; }
             case HARC_AMD_S1_DNA_SINGLETON: {
+                const harc_mark_t mk = harc_pool_mark(c);
                 uint64_t *sr = c->d_sreads; bool tmp = false;
                 if (!sr) { RC_TRY(dalloc(c, &sr, (size_t)c->S * c->W + 1)); tmp = true; RC_TRY(s1_orient(c, c->d_reads, c->d_order_s, nullptr, c->S, sr)); }
                 char *d = nullptr; RC_TRY(dalloc(c, &d, (size_t)c->S * (L + 1) + 1));
                 RC_TRY(s1_unpack_to_ascii(c, sr, c->S, d));
                 RC_TRY(harc_d2h(c, b, d, (size_t)c->S * (L + 1)));
-                HIP_TRY(hipStreamSynchronize(c->stream)); harc_dev_free(c, d); if (tmp) harc_dev_free(c, sr);
+                HIP_TRY(hipStreamSynchronize(c->stream)); harc_pool_release(c, mk); (void)tmp;
                 break; }
             }
             HIP_TRY(hipStreamSynchronize(c->stream));
             it = c->out.find(key);
         } else { harc_set_error("stream %d shard %d not available", id, shard); return HARC_AMD_ESTATE; }
     }
-    *ptr = it->second.data(); *len = it->second.size();
+    if (it->second.ptr) { *ptr = it->second.ptr; *len = it->second.len; }
+    else { *ptr = it->second.own.data(); *len = it->second.own.size(); }
     return HARC_AMD_OK;
 }
 

@@ -77,9 +77,14 @@ struct harc_amd_ctx {
     harc_amd_params P;
     int W = 0, W3 = 0;
     hipStream_t stream = nullptr;
-    size_t dev_bytes = 0, dev_peak = 0;
-    std::vector<void *> owned;             // every live device allocation (freed in destroy)
+    size_t dev_bytes = 0, dev_peak = 0;    // raw allocations + pool high-water mark
+    std::vector<void *> owned;             // raw allocations (inputs, rocPRIM scratch), freed in destroy
     std::map<void *, size_t> sizes;
+    // Device pool: hipMalloc/hipFree of multi-GB buffers cost more than the kernels they serve, so every per-run buffer is a bump
+    // allocation out of a few large chunks that persist across runs; stack discipline through harc_pool_mark / harc_pool_release.
+    struct PoolChunk { char *base; size_t size, used; };
+    std::vector<PoolChunk> pool;
+    size_t pool_cur = 0, pool_total = 0;
 
     // inputs
     uint32_t N = 0;  uint64_t *d_reads = nullptr;      // N x W, 2-bit
@@ -94,7 +99,12 @@ struct harc_amd_ctx {
     bool s1_from_files = false;
     bool have_s2 = false;
 
-    std::map<std::pair<int, int>, std::vector<uint8_t>> out;   // (stream id, shard) -> bytes
+    // (stream id, shard) -> bytes: either a slice of the pinned host arena (ptr/len) or an owned vector
+    struct OutBuf { const uint8_t *ptr = nullptr; size_t len = 0; std::vector<uint8_t> own; };
+    std::map<std::pair<int, int>, OutBuf> out;
+    // pinned host arena for the output streams (device -> host at PCIe rate, no per-run allocation); reset with the results
+    struct HostChunk { char *base; size_t size, used; };
+    std::vector<HostChunk> harena;
     harc_amd_counters C;
 
     // scratch for rocPRIM
@@ -106,6 +116,11 @@ int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes);
 void harc_dev_free(harc_amd_ctx *c, void *p);
 template <class T> static inline int dalloc(harc_amd_ctx *c, T **p, size_t n) { return harc_dev_alloc(c, (void **)p, n * sizeof(T) + 16); }
 int harc_tmp_reserve(harc_amd_ctx *c, size_t bytes);
+int harc_raw_alloc(harc_amd_ctx *c, void **p, size_t bytes);     // plain hipMalloc, for buffers that outlive a run
+void harc_raw_free(harc_amd_ctx *c, void *p);
+typedef unsigned long long harc_mark_t;
+harc_mark_t harc_pool_mark(harc_amd_ctx *c);
+void harc_pool_release(harc_amd_ctx *c, harc_mark_t m);          // everything allocated after the mark becomes reusable
 
 // ---- primitives (prims.hip): thin wrappers over rocPRIM device-wide sort / scan
 int prim_sort_pairs_u64_u32(harc_amd_ctx *c, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit);
@@ -124,10 +139,14 @@ int stage1_run(harc_amd_ctx *c);
 int stage1_make_oriented(harc_amd_ctx *c);      // d_oreads from d_reads/d_order/d_rc
 int s1_orient(harc_amd_ctx *c, const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, uint64_t *out);
 // exact key->bin table over n keys (ids must hold 0..n-1 on entry); allocates d->slots / d->ids / d->d_nbins
-int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, uint32_t n, unsigned kbits);
+int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n);
+int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, uint32_t n, unsigned kbits);   // after harc_dict_alloc
 void harc_dict_free(harc_amd_ctx *c, DictDev *d);
 int stage2_run(harc_amd_ctx *c);
 int pack_order_run(harc_amd_ctx *c);
 
-static inline std::vector<uint8_t> &out_buf(harc_amd_ctx *c, int id, int shard) { return c->out[std::make_pair(id, shard)]; }
+static inline std::vector<uint8_t> &out_buf(harc_amd_ctx *c, int id, int shard) { harc_amd_ctx::OutBuf &o = c->out[std::make_pair(id, shard)]; o.ptr = nullptr; o.len = 0; return o.own; }
+static inline void out_slice(harc_amd_ctx *c, int id, int shard, const void *p, size_t n) { harc_amd_ctx::OutBuf &o = c->out[std::make_pair(id, shard)]; o.own.clear(); o.ptr = (const uint8_t *)p; o.len = n; }
+int harc_host_alloc(harc_amd_ctx *c, void **p, size_t bytes);    // pinned, valid until the results are dropped
+void harc_host_reset(harc_amd_ctx *c);
 int harc_d2h(harc_amd_ctx *c, std::vector<uint8_t> &dst, const void *d_src, size_t bytes);

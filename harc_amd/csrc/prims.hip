@@ -6,10 +6,10 @@
 int harc_tmp_reserve(harc_amd_ctx *c, size_t bytes)
 {
     if (bytes <= c->tmp_bytes) return HARC_AMD_OK;
-    if (c->d_tmp) harc_dev_free(c, c->d_tmp);
+    if (c->d_tmp) harc_raw_free(c, c->d_tmp);
     c->d_tmp = nullptr; c->tmp_bytes = 0;
     size_t want = bytes + (bytes >> 3) + 4096;
-    RC_TRY(harc_dev_alloc(c, &c->d_tmp, want));
+    RC_TRY(harc_raw_alloc(c, &c->d_tmp, want));
     c->tmp_bytes = want;
     return HARC_AMD_OK;
 }

@@ -657,20 +657,26 @@ template <int W> __global__ void k_orient(const uint64_t *reads, const uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, uint32_t n, unsigned kbits)
+int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n)
 {
     d->cap = 0; d->slots = nullptr; d->ids = nullptr; d->d_nbins = nullptr;
     if (n == 0) return HARC_AMD_OK;
-    uint64_t *k1 = nullptr; uint32_t *h0 = nullptr, *b0 = nullptr, *bs = nullptr;
-    RC_TRY(dalloc(c, &k1, n)); RC_TRY(dalloc(c, &h0, n)); RC_TRY(dalloc(c, &b0, n)); RC_TRY(dalloc(c, &bs, n));
     {   // load factor 1/4 when HBM allows (fewer dependent re-probes: the chain kernel is latency-bound), else 1/3, else 1/2
         unsigned long long m = 4;
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) { while (m > 2 && (double)m * n * sizeof(HashSlot) > 0.25 * (double)fr) m--; }
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) { fr += c->pool_total; while (m > 2 && (double)m * n * sizeof(HashSlot) > 0.2 * (double)fr) m--; }
         if (const char *e = getenv("HARC_AMD_CAPMULT")) m = strtoull(e, nullptr, 10);
         d->cap = (m < 2 ? 2 : m) * n + 2;
     }
     RC_TRY(dalloc(c, &d->slots, d->cap)); RC_TRY(dalloc(c, &d->ids, n)); RC_TRY(dalloc(c, &d->d_nbins, 1));
+    return HARC_AMD_OK;
+}
+int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, uint32_t n, unsigned kbits)
+{
+    if (n == 0) return HARC_AMD_OK;
+    const harc_mark_t mk = harc_pool_mark(c);
+    uint64_t *k1 = nullptr; uint32_t *h0 = nullptr, *b0 = nullptr, *bs = nullptr;
+    RC_TRY(dalloc(c, &k1, n)); RC_TRY(dalloc(c, &h0, n)); RC_TRY(dalloc(c, &b0, n)); RC_TRY(dalloc(c, &bs, n));
     const unsigned g = (n + 255) / 256;
     RC_TRY(prim_sort_pairs_u64_u32(c, keys, k1, ids, d->ids, n, kbits));        // stable: ids ascending inside a bin (reorder.cpp:372-384)
     hipLaunchKernelGGL(k_mark_heads, dim3(g), dim3(256), 0, c->stream, k1, n, h0);
@@ -679,9 +685,8 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
     hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, d->ids, bs, d->d_nbins, n, d->slots, d->cap);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&d->nbins, d->d_nbins, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    harc_dev_free(c, k1); harc_dev_free(c, h0); harc_dev_free(c, b0); harc_dev_free(c, bs);
+    HIP_TRY(hipStreamSynchronize(c->stream));                                    // temporaries are reused after this point
+    harc_pool_release(c, mk);
     return HARC_AMD_OK;
 }
 void harc_dict_free(harc_amd_ctx *c, DictDev *d)
@@ -727,9 +732,16 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
     HIP_TRY(hipEventRecord(e0, c->stream));
 
+    // ---- pool layout: [stage-I results, worst case][dictionaries][index scratch -> released][chain state] ; all but the results
+    //      are released at the end so that stage II starts right above them
+    RC_TRY(dalloc(c, &c->d_order, (size_t)N + 1)); RC_TRY(dalloc(c, &c->d_flag, (size_t)N + 1)); RC_TRY(dalloc(c, &c->d_pos, (size_t)N + 1));
+    RC_TRY(dalloc(c, &c->d_rc, (size_t)N + 1)); RC_TRY(dalloc(c, &c->d_order_s, (size_t)N + 1));
+    const harc_mark_t mark_results = harc_pool_mark(c);
     // ---- dictionaries (constructdictionary, reorder.cpp:277-394)
     DictDev dict[2];
     if (N) {
+        RC_TRY(harc_dict_alloc(c, &dict[0], N)); RC_TRY(harc_dict_alloc(c, &dict[1], N));
+        const harc_mark_t mk = harc_pool_mark(c);
         uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
         RC_TRY(dalloc(c, &k0, N)); RC_TRY(dalloc(c, &i0, N));
         for (int l = 0; l < 2; l++) {
@@ -737,7 +749,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             hipLaunchKernelGGL((k_keygen<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[l], kbits, k0, i0);
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, N, (unsigned)kbits));
         }
-        harc_dev_free(c, k0); harc_dev_free(c, i0);
+        harc_pool_release(c, mk);
     }
     HIP_TRY(hipEventRecord(e1, c->stream));
 
@@ -818,8 +830,6 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if ((unsigned long long)M + S != nlog || nlog != N) { harc_set_error("stage I bookkeeping: M=%u S=%u log=%llu N=%u", M, S, nlog, N); return HARC_AMD_ENODEVICE; }
     c->M = M; c->S = S;
-    RC_TRY(dalloc(c, &c->d_order, (size_t)M + 1)); RC_TRY(dalloc(c, &c->d_flag, (size_t)M + 1)); RC_TRY(dalloc(c, &c->d_pos, (size_t)M + 1));
-    RC_TRY(dalloc(c, &c->d_rc, (size_t)M + 1)); RC_TRY(dalloc(c, &c->d_order_s, (size_t)S + 1));
     if (nlog) hipLaunchKernelGGL(k_s1_scatter, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, c->stream, a.log, nlog, bmain, bsing,
                                  c->d_order, c->d_flag, c->d_pos, c->d_rc, c->d_order_s);
     HIP_TRY(hipGetLastError());
@@ -837,10 +847,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
     hipHostFree(h_stats);
 
-    // free everything stage II does not need
-    void *tofree[] = { a.claimed, a.bid, a.hdr, a.cnt, a.steps, a.need, a.seedbuf, a.log, a.logcount, a.cursor, a.stats, a.cstat, d_tab,
-                       nmain, nsing, bmain, bsing, dict[0].slots, dict[0].ids, dict[0].d_nbins, dict[1].slots, dict[1].ids, dict[1].d_nbins };
-    for (void *p : tofree) if (p) harc_dev_free(c, p);
+    harc_pool_release(c, mark_results);                          // stage II starts right above the results
     c->have_s1 = true;
     return HARC_AMD_OK;
 }
@@ -882,7 +889,6 @@ int stage1_run(harc_amd_ctx *c)
 
 int stage1_make_oriented(harc_amd_ctx *c)
 {
-    if (c->d_oreads) { harc_dev_free(c, c->d_oreads); c->d_oreads = nullptr; }
-    RC_TRY(dalloc(c, &c->d_oreads, (size_t)c->M * c->W + 1));
+    if (!c->d_oreads) RC_TRY(dalloc(c, &c->d_oreads, (size_t)c->M * c->W + 1));
     return s1_orient(c, c->d_reads, c->d_order, c->d_rc, c->M, c->d_oreads);
 }

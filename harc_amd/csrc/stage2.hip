@@ -363,6 +363,7 @@ int stage2_run(harc_amd_ctx *c)
     // drop earlier stage-II outputs
     for (auto it = c->out.begin(); it != c->out.end();) { if (it->first.first >= HARC_AMD_S2_SEQ) it = c->out.erase(it); else ++it; }
 
+    const harc_mark_t mark_s2 = harc_pool_mark(c);
     S2Args a; memset(&a, 0, sizeof a);
     a.L = L; a.W = W; a.W3 = W3; a.thresh_s = P.thresh_s; a.maxsearch = P.maxsearch;
     if (L > 50) { a.ds[0] = 0; a.de[0] = 20; a.ds[1] = 21; a.de[1] = 41; }                     // encoder.cpp:132-145
@@ -390,6 +391,8 @@ int stage2_run(harc_amd_ctx *c)
     unsigned long long *d_big = nullptr; RC_TRY(dalloc(c, &d_big, 1));
     HIP_TRY(hipMemsetAsync(d_big, 0, 8, c->stream));
     if (T) {
+        RC_TRY(harc_dict_alloc(c, &dict[0], T)); RC_TRY(harc_dict_alloc(c, &dict[1], T));
+        const harc_mark_t mk = harc_pool_mark(c);
         uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
         RC_TRY(dalloc(c, &k0, T)); RC_TRY(dalloc(c, &i0, T));
         for (int l = 0; l < 2; l++) {
@@ -397,7 +400,8 @@ int stage2_run(harc_amd_ctx *c)
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, T, (unsigned)a.kbits[l]));
             hipLaunchKernelGGL(k_count_big_bins, G256(dict[l].cap), dict[l].slots, dict[l].cap, (uint32_t)P.maxsearch, d_big);
         }
-        harc_dev_free(c, k0); harc_dev_free(c, i0);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        harc_pool_release(c, mk);
     }
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
 
@@ -503,40 +507,51 @@ int stage2_run(harc_amd_ctx *c)
     for (uint32_t e = 0; e <= E; e++) if (sh_i[e] < M) HIP_TRY(hipMemcpyAsync(&sh_nm[e], nmoff + sh_f[e], 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
 
-    // ---- packbits per shard + device -> host
-    uint8_t *packed = nullptr; RC_TRY(dalloc(c, &packed, (size_t)total / 4 + (size_t)F / 8 + (size_t)US * L / 4 + 64));
-    std::vector<uint8_t> h_noise, h_noisepos, h_pos, h_rc, h_cons_tail;
-    RC_TRY(harc_d2h(c, h_noise, noise, (size_t)nmtot + F)); RC_TRY(harc_d2h(c, h_noisepos, noisepos, (size_t)nmtot)); RC_TRY(harc_d2h(c, h_pos, posb, F));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // ---- packbits per shard into ONE device buffer, then a handful of device -> pinned-host copies; per-shard streams are slices
+    std::vector<uint64_t> seq_off(E), seq_nb(E), seq_tl(E), rev_off(E), rev_nb(E), rev_tl(E);
+    uint64_t poff = 0;
     for (uint32_t e = 0; e < E; e++) {
-        const uint64_t c0 = sh_col[e], c1 = sh_col[e + 1], nb = (c1 - c0) / 4, tl = (c1 - c0) % 4;
-        std::vector<uint8_t> seq, tail(tl), rev, rtail;
-        if (nb) { hipLaunchKernelGGL(k_pack2_bytes, G256(nb), cons + c0, nb, packed); RC_TRY(harc_d2h(c, seq, packed, nb)); }
-        if (tl) { hipLaunchKernelGGL(k_bases_to_ascii, G256(tl), cons + c0 + 4 * nb, tl, packed + nb); RC_TRY(harc_d2h(c, tail, packed + nb, tl)); }
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        const uint32_t f0 = sh_f[e], f1 = sh_f[e + 1]; const uint64_t rb = (f1 - f0) / 8, rt = (f1 - f0) % 8;
-        if (rb) { hipLaunchKernelGGL(k_pack1_bytes, G256(rb), rcb + f0, rb, packed); RC_TRY(harc_d2h(c, rev, packed, rb)); }
-        if (rt) RC_TRY(harc_d2h(c, rtail, rcb + f0 + 8 * rb, rt));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        out_buf(c, HARC_AMD_S2_SEQ, e) = seq; out_buf(c, HARC_AMD_S2_SEQ_TAIL, e) = tail;
-        out_buf(c, HARC_AMD_S2_REV, e) = rev; out_buf(c, HARC_AMD_S2_REV_TAIL, e) = rtail;
-        put(c, HARC_AMD_S2_POS, e, h_pos.data() + f0, f1 - f0);
-        put(c, HARC_AMD_S2_NOISE, e, h_noise.data() + sh_nm[e] + f0, (sh_nm[e + 1] + f1) - (sh_nm[e] + f0));
-        put(c, HARC_AMD_S2_NOISEPOS, e, h_noisepos.data() + sh_nm[e], sh_nm[e + 1] - sh_nm[e]);
+        const uint64_t cc = sh_col[e + 1] - sh_col[e]; seq_nb[e] = cc / 4; seq_tl[e] = cc % 4; seq_off[e] = poff; poff += (seq_nb[e] + seq_tl[e] + 15) & ~15ull;
+        const uint64_t ff = sh_f[e + 1] - sh_f[e]; rev_nb[e] = ff / 8; rev_tl[e] = ff % 8; rev_off[e] = poff; poff += (rev_nb[e] + rev_tl[e] + 15) & ~15ull;
     }
-    {   // whole-job streams
-        const uint64_t sb = (uint64_t)US * L / 4, st = (uint64_t)US * L % 4;
-        std::vector<uint8_t> sing, stail(st);
-        if (sb) { hipLaunchKernelGGL(k_pack2_bytes, G256(sb), sing_bases, sb, packed); RC_TRY(harc_d2h(c, sing, packed, sb)); }
-        if (st) { hipLaunchKernelGGL(k_bases_to_ascii, G256(st), sing_bases + 4 * sb, st, packed + sb); RC_TRY(harc_d2h(c, stail, packed + sb, st)); }
-        RC_TRY(harc_d2h(c, out_buf(c, HARC_AMD_S2_ORDER, 0), order_out, ((size_t)n_nonN + US) * 4));
-        RC_TRY(harc_d2h(c, out_buf(c, HARC_AMD_S2_ORDER_N_PE, 0), orderN_out, ((size_t)n_N_aligned + UN) * 4));
-        RC_TRY(harc_d2h(c, out_buf(c, HARC_AMD_S2_INPUT_N, 0), ntext, (size_t)UN * (L + 1)));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        out_buf(c, HARC_AMD_S2_SINGLETON, 0) = sing; out_buf(c, HARC_AMD_S2_SINGLETON_TAIL, 0) = stail;
-        char meta[32]; const int ml = snprintf(meta, sizeof meta, "%d\n", L);
-        put(c, HARC_AMD_S2_META, 0, (const uint8_t *)meta, (size_t)ml);
+    const uint64_t sing_nb = (uint64_t)US * L / 4, sing_tl = (uint64_t)US * L % 4, sing_off = poff;
+    poff += (sing_nb + sing_tl + 15) & ~15ull;
+    uint8_t *packed = nullptr; RC_TRY(dalloc(c, &packed, (size_t)poff + 64));
+    for (uint32_t e = 0; e < E; e++) {
+        const uint64_t c0 = sh_col[e]; const uint32_t f0 = sh_f[e];
+        if (seq_nb[e]) hipLaunchKernelGGL(k_pack2_bytes, G256(seq_nb[e]), cons + c0, seq_nb[e], packed + seq_off[e]);
+        if (seq_tl[e]) hipLaunchKernelGGL(k_bases_to_ascii, G256(seq_tl[e]), cons + c0 + 4 * seq_nb[e], seq_tl[e], packed + seq_off[e] + seq_nb[e]);
+        if (rev_nb[e]) hipLaunchKernelGGL(k_pack1_bytes, G256(rev_nb[e]), rcb + f0, rev_nb[e], packed + rev_off[e]);
+        if (rev_tl[e]) HIP_TRY(hipMemcpyAsync(packed + rev_off[e] + rev_nb[e], rcb + f0 + 8 * rev_nb[e], rev_tl[e], hipMemcpyDeviceToDevice, c->stream));
     }
+    if (sing_nb) hipLaunchKernelGGL(k_pack2_bytes, G256(sing_nb), sing_bases, sing_nb, packed + sing_off);
+    if (sing_tl) hipLaunchKernelGGL(k_bases_to_ascii, G256(sing_tl), sing_bases + 4 * sing_nb, sing_tl, packed + sing_off + sing_nb);
+    HIP_TRY(hipGetLastError());
+    uint8_t *h_packed = nullptr, *h_noise = nullptr, *h_noisepos = nullptr, *h_pos = nullptr, *h_order = nullptr, *h_orderN = nullptr, *h_ntext = nullptr, *h_meta = nullptr;
+    const size_t n_order = ((size_t)n_nonN + US) * 4, n_orderN = ((size_t)n_N_aligned + UN) * 4, n_ntext = (size_t)UN * (L + 1);
+    RC_TRY(harc_host_alloc(c, (void **)&h_packed, (size_t)poff)); RC_TRY(harc_host_alloc(c, (void **)&h_noise, (size_t)nmtot + F));
+    RC_TRY(harc_host_alloc(c, (void **)&h_noisepos, (size_t)nmtot)); RC_TRY(harc_host_alloc(c, (void **)&h_pos, F));
+    RC_TRY(harc_host_alloc(c, (void **)&h_order, n_order)); RC_TRY(harc_host_alloc(c, (void **)&h_orderN, n_orderN));
+    RC_TRY(harc_host_alloc(c, (void **)&h_ntext, n_ntext)); RC_TRY(harc_host_alloc(c, (void **)&h_meta, 32));
+    if (poff) HIP_TRY(hipMemcpyAsync(h_packed, packed, (size_t)poff, hipMemcpyDeviceToHost, c->stream));
+    if (nmtot + F) HIP_TRY(hipMemcpyAsync(h_noise, noise, (size_t)nmtot + F, hipMemcpyDeviceToHost, c->stream));
+    if (nmtot) HIP_TRY(hipMemcpyAsync(h_noisepos, noisepos, (size_t)nmtot, hipMemcpyDeviceToHost, c->stream));
+    if (F) HIP_TRY(hipMemcpyAsync(h_pos, posb, F, hipMemcpyDeviceToHost, c->stream));
+    if (n_order) HIP_TRY(hipMemcpyAsync(h_order, order_out, n_order, hipMemcpyDeviceToHost, c->stream));
+    if (n_orderN) HIP_TRY(hipMemcpyAsync(h_orderN, orderN_out, n_orderN, hipMemcpyDeviceToHost, c->stream));
+    if (n_ntext) HIP_TRY(hipMemcpyAsync(h_ntext, ntext, n_ntext, hipMemcpyDeviceToHost, c->stream));
+    for (uint32_t e = 0; e < E; e++) {
+        const uint32_t f0 = sh_f[e], f1 = sh_f[e + 1];
+        out_slice(c, HARC_AMD_S2_SEQ, e, h_packed + seq_off[e], seq_nb[e]); out_slice(c, HARC_AMD_S2_SEQ_TAIL, e, h_packed + seq_off[e] + seq_nb[e], seq_tl[e]);
+        out_slice(c, HARC_AMD_S2_REV, e, h_packed + rev_off[e], rev_nb[e]); out_slice(c, HARC_AMD_S2_REV_TAIL, e, h_packed + rev_off[e] + rev_nb[e], rev_tl[e]);
+        out_slice(c, HARC_AMD_S2_POS, e, h_pos + f0, f1 - f0);
+        out_slice(c, HARC_AMD_S2_NOISE, e, h_noise + sh_nm[e] + f0, (sh_nm[e + 1] + f1) - (sh_nm[e] + f0));
+        out_slice(c, HARC_AMD_S2_NOISEPOS, e, h_noisepos + sh_nm[e], sh_nm[e + 1] - sh_nm[e]);
+    }
+    out_slice(c, HARC_AMD_S2_SINGLETON, 0, h_packed + sing_off, sing_nb); out_slice(c, HARC_AMD_S2_SINGLETON_TAIL, 0, h_packed + sing_off + sing_nb, sing_tl);
+    out_slice(c, HARC_AMD_S2_ORDER, 0, h_order, n_order); out_slice(c, HARC_AMD_S2_ORDER_N_PE, 0, h_orderN, n_orderN);
+    out_slice(c, HARC_AMD_S2_INPUT_N, 0, h_ntext, n_ntext);
+    { const int ml = snprintf((char *)h_meta, 32, "%d\n", L); out_slice(c, HARC_AMD_S2_META, 0, h_meta, (size_t)ml); }
     unsigned long long big = 0;
     HIP_TRY(hipMemcpyAsync(&big, d_big, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -544,10 +559,7 @@ int stage2_run(harc_amd_ctx *c)
     c->C.aligned_singletons = (uint64_t)S - US;                   // encoder.cpp:506-508
     c->C.aligned_N = (uint64_t)NN - UN;
 
-    void *tofree[] = { cand3, cand_order, best, d_big, head, u0, u1, d64, gstart, chead, cons, t0, t1, tup0, tup, rid0, rid, f.ref, f.kind, f.g, fidx_orig,
-                       nm, nonN, nonNrank, nmoff, ls, ln, rs, rn, noise, noisepos, posb, rcb, order_out, orderN_out, sing_bases, ntext, packed };
-    for (void *p : tofree) if (p) harc_dev_free(c, p);
-    harc_dict_free(c, &dict[0]); harc_dict_free(c, &dict[1]);
+    harc_pool_release(c, mark_s2);
     return HARC_AMD_OK;
 }
 
@@ -555,14 +567,16 @@ int pack_order_run(harc_amd_ctx *c)
 {
     auto it = c->out.find(std::make_pair((int)HARC_AMD_S2_ORDER, 0));
     if (it == c->out.end()) { harc_set_error("pack_order: no read_order.bin"); return HARC_AMD_ESTATE; }
-    const std::vector<uint8_t> &in = it->second;
-    const uint32_t n = (uint32_t)(in.size() / 4);
+    const uint8_t *in_p = it->second.ptr ? it->second.ptr : it->second.own.data();
+    const size_t in_len = it->second.ptr ? it->second.len : it->second.own.size();
+    const uint32_t n = (uint32_t)(in_len / 4);
     if (n == 0) { harc_set_error("pack_order: empty read_order.bin (the reference evaluates log2(0), pack_order.cpp:36)"); return HARC_AMD_EINVAL; }
     int numbits = 0; { uint32_t x = n; while (x) { numbits++; x >>= 1; } }        // (int)(log2(n)+1)
     const uint32_t ng = n / 32;
     uint32_t *d_in = nullptr, *d_out = nullptr;
+    const harc_mark_t mk = harc_pool_mark(c);
     RC_TRY(dalloc(c, &d_in, (size_t)n + 1)); RC_TRY(dalloc(c, &d_out, (size_t)ng * numbits + 1));
-    HIP_TRY(hipMemcpyAsync(d_in, in.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_in, in_p, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     if (ng) hipLaunchKernelGGL(k_pack_order, G256((uint64_t)ng * numbits), d_in, ng, numbits, d_out);
     std::vector<uint8_t> body;
     RC_TRY(harc_d2h(c, body, d_out, (size_t)ng * numbits * 4));
@@ -571,7 +585,7 @@ int pack_order_run(harc_amd_ctx *c)
     o.resize(8 + body.size());
     memcpy(o.data(), &numbits, 4); memcpy(o.data() + 4, &n, 4);                   // pack_order.cpp:37-38
     if (!body.empty()) memcpy(o.data() + 8, body.data(), body.size());
-    put(c, HARC_AMD_P_ORDER_TAIL, 0, in.data() + (size_t)ng * 32 * 4, (size_t)(n % 32) * 4);
-    harc_dev_free(c, d_in); harc_dev_free(c, d_out);
+    { std::vector<uint8_t> tailv(in_p + (size_t)ng * 32 * 4, in_p + (size_t)ng * 32 * 4 + (size_t)(n % 32) * 4); out_buf(c, HARC_AMD_P_ORDER_TAIL, 0) = tailv; }
+    harc_pool_release(c, mk);
     return HARC_AMD_OK;
 }
