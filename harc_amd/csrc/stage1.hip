@@ -402,10 +402,13 @@ template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
                 j = (int)(e & 0xFF); dir = (int)((e >> 8) & 1);
                 const int l = (int)((e >> 9) & 1);
                 const int off = dir ? 2 * (s.ds[l] - j) : 2 * (s.ds[l] + j);
-                uint64_t src[W];
-#pragma unroll
-                for (int w = 0; w < W; w++) src[w] = dir ? rref[w] : ref[w];
-                const uint64_t key = extract_bits<W>(src, off, s.kbits[l]);
+                uint64_t key;
+                {   // key = kbits bits of the (reverse) consensus at bit `off`
+                    const int wi = off >> 6, shb = off & 63;
+                    const uint64_t lo = dir ? sel0<W>(rref, wi) : sel0<W>(ref, wi), hi = dir ? sel0<W>(rref, wi + 1) : sel0<W>(ref, wi + 1);
+                    key = shb ? ((lo >> shb) | (hi << (64 - shb))) : lo;
+                    if (s.kbits[l] < 64) key &= ((uint64_t)1 << s.kbits[l]) - 1;
+                }
                 const uint64_t cap = s.cap[l];
                 HashSlot *tab = s.slots[l];
                 const uint32_t *ids = s.ids[l];
@@ -419,9 +422,8 @@ template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
                         if (cw == 0) break;
                         if (k2 == key) {
                             if (cw & SLOT_DEAD) break;                        // every read of this bin is already claimed
-                            uint64_t sh[W];                                   // shifted consensus: reorder.cpp:647-648
-                            if (dir) shl_words<W>(rref, 2 * j, sh); else shr_words<W>(ref, 2 * j, sh);
                             const int nb = 2 * (L - j);
+                            const int sws = (2 * j) >> 6, sbs = (2 * j) & 63;     // the consensus is shifted by 2j bits (reorder.cpp:647-648)
                             const uint32_t cntb = cw & SLOT_CNT_MASK;
                             const bool emb = (cw & SLOT_EMB) != 0;            // single-read bin: `start` IS the read id
                             int seen = 0; uint32_t lead = 0; bool alltop = true;
@@ -429,9 +431,8 @@ template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
                                 const uint32_t rid = emb ? sst : ids[sst + i - 1];
                                 // claim bit and read words are fetched together (one dependent hop instead of two)
                                 const unsigned long long cwd = s.claimed[rid >> 6];
-                                uint64_t rd[W];
 #pragma unroll
-                                for (int w = 0; w < W; w++) rd[w] = s.reads[(size_t)rid * W + w];
+                                for (int w = 0; w < W; w++) mrd[w] = s.reads[(size_t)rid * W + w];
                                 if ((cwd >> (rid & 63)) & 1ULL) { if (alltop) lead++; continue; }
                                 alltop = false;
                                 bool own = false;                             // taken by this chain earlier in this super-round
@@ -441,16 +442,19 @@ template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
                                 int hd = 0;
 #pragma unroll
                                 for (int w = 0; w < W; w++) {
-                                    // forward: low 2(L-j) bits (mask[j], reorder.cpp:712-713); reverse: bits >= 2j below 2L (revmask[j], :714-715)
-                                    const uint64_t m = dir ? (lowmask_word(2 * L, w) & ~lowmask_word(2 * j, w)) : lowmask_word(nb, w);
-                                    hd += __popcll((sh[w] ^ rd[w]) & m);
+                                    uint64_t shw, m;
+                                    if (dir) {                                // reverse: (revref << 2j), bits >= 2j below 2L (revmask[j], :714-715)
+                                        const uint64_t hi = sel0<W>(rref, w - sws), lo = sel0<W>(rref, w - sws - 1);
+                                        shw = sbs ? ((hi << sbs) | (lo >> (64 - sbs))) : hi;
+                                        m = lowmask_word(2 * L, w) & ~lowmask_word(2 * j, w);
+                                    } else {                                  // forward: (ref >> 2j), low 2(L-j) bits (mask[j], :712-713)
+                                        const uint64_t lo = sel0<W>(ref, w + sws), hi = sel0<W>(ref, w + sws + 1);
+                                        shw = sbs ? ((lo >> sbs) | (hi << (64 - sbs))) : lo;
+                                        m = lowmask_word(nb, w);
+                                    }
+                                    hd += __popcll((shw ^ mrd[w]) & m);
                                 }
-                                if (hd <= s.thresh) {
-                                    mine = rid;
-#pragma unroll
-                                    for (int w = 0; w < W; w++) mrd[w] = rd[w];
-                                    break;
-                                }
+                                if (hd <= s.thresh) { mine = rid; break; }
                             }
                             // hints only (the claim bitmap stays the truth): claimed reads at the top of a bin are never looked at again
                             if (lead) {
@@ -498,44 +502,49 @@ template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
     }
 }
 
-// (B) one wave per chain, lane t = step t of the super-round
-__global__ __launch_bounds__(256) void k_resolve(S1Args s)
+// (B) G lanes per chain (G = 16/32/64 >= S), lane t of the group = step t of the super-round
+template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= s.K) return;
-    ChainHdr h = s.hdr[c];
-    if (!(h.flags & CH_ACTIVE)) return;
-    const int n = (int)(h.nsteps & 0xFF);
+    constexpr int CPW = 64 / G;                                   // chains per wave
+    const int lane = threadIdx.x & 63, sub = lane / G, sl = lane % G;
+    const uint32_t c = (blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + sub;
+    ChainHdr h; h.flags = 0; h.nsteps = 0;
+    if (c < s.K) h = s.hdr[c];
+    const bool act = c < s.K && (h.flags & CH_ACTIVE);
+    const int n = act ? (int)(h.nsteps & 0xFF) : 0;
     uint2 sp = make_uint2(HARC_NONE, 0);
     bool mineb = false;
-    if (lane < n) {
-        sp = s.steps[(size_t)c * 64 + lane];
-        mineb = s.bid[sp.x] == (((uint32_t)lane << 20) | c);
+    if (sl < n) {
+        sp = s.steps[(size_t)c * 64 + sl];
+        mineb = s.bid[sp.x] == (((uint32_t)sl << 20) | c);
     }
-    const unsigned long long lost = __ballot(lane < n && !mineb);
+    unsigned long long lost = __ballot(sl < n && !mineb);
+    if (G < 64) lost = (lost >> (sub * G)) & ((1ULL << (G & 63)) - 1ULL);
     const int v = lost ? (__ffsll((long long)lost) - 1) : n;     // steps kept: those before the first lost bid
     if (mineb) s.bid[sp.x] = HARC_NONE;                          // every bid this chain holds is withdrawn, kept or not
     const bool cut = v < n;
     const uint32_t pre = (v > 0 && (h.flags & CH_PREVUNM)) ? 1u : 0u;
     const uint32_t nrec = (uint32_t)v + pre;
-    unsigned long long at0 = 0;
-    if (nrec) {
-        if (lane == 0) at0 = atomicAdd(s.logcount, (unsigned long long)nrec);
-        at0 = shfl_u64(at0, 0);
+    // log space: one atomic per wave
+    uint32_t wtot; const uint32_t wex = wave_excl_scan_u32(sl == 0 ? nrec : 0u, &wtot);
+    unsigned long long wbase = 0;
+    if (wtot) {
+        if (lane == 0) wbase = atomicAdd(s.logcount, (unsigned long long)wtot);
+        wbase = shfl_u64(wbase, 0);
     }
-    if (lane == 0 && pre) {                                      // the pending seed opens a contig (reorder.cpp:564-570)
+    const unsigned long long at0 = wbase + __shfl(wex, sub * G, 64);
+    if (act && sl == 0 && pre) {                                 // the pending seed opens a contig (reorder.cpp:564-570)
         LogRec r; r.chain = c; r.seq = h.n_main; r.rid = h.prev; r.meta = (uint32_t)(s.L & 0xFF);
         s.log[at0] = r;
     }
-    if (lane < v) {
+    if (sl < v) {
         atomicOr(&s.claimed[sp.x >> 6], 1ULL << (sp.x & 63));
-        LogRec r; r.chain = c; r.seq = h.n_main + pre + (uint32_t)lane; r.rid = sp.x;
+        LogRec r; r.chain = c; r.seq = h.n_main + pre + (uint32_t)sl; r.rid = sp.x;
         r.meta = (sp.y & 0xFF) | (1u << 8) | (((sp.y >> 8) & 1u) << 9);
-        s.log[at0 + pre + (uint32_t)lane] = r;
+        s.log[at0 + pre + (uint32_t)sl] = r;
     }
-    const uint32_t lastrid = __shfl(sp.x, v > 0 ? v - 1 : 0, 64);
-    if (lane == 0) {
+    const uint32_t lastrid = __shfl(sp.x, sub * G + (v > 0 ? v - 1 : 0), 64);
+    if (act && sl == 0) {
         h.n_main += nrec;
         if (v > 0) { h.cur = lastrid; h.flags &= ~CH_PREVUNM; }
         if (cut) {
@@ -802,7 +811,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (prof) { hipEvent_t a0, a1; HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1)); ev.push_back(a0); ev.push_back(a1); HIP_TRY(hipEventRecord(a0, c->stream)); }
             hipLaunchKernelGGL((k_steps<W>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
             if (prof) HIP_TRY(hipEventRecord(ev.back(), c->stream));
-            hipLaunchKernelGGL(k_resolve, dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
+            if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
+            else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve<32>), dim3((K + 7) / 8), dim3(256), 0, c->stream, a);
+            else hipLaunchKernelGGL((k_resolve<64>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
             hipLaunchKernelGGL(k_reseed, dim3(1), dim3(1024), 0, c->stream, a);
             launches++;
         }
