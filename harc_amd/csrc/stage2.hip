@@ -134,73 +134,135 @@ __global__ void k_contig_heads(const uint8_t *head, const uint32_t *cid, uint32_
     if (head[i]) chead[cid[i]] = i;
 }
 
-// buildcontig (encoder.cpp:619-652): column x <- first strict maximum over A,C,G,T of the reads covering it
-__global__ __launch_bounds__(256) void k_consensus(S2Args s)
+// per contig: end column, and bit 63 = "no realignment" (the last contig of a shard, encoder.cpp:438-441)
+__global__ void k_contig_info(S2Args s, unsigned long long *cinfo)
 {
-    const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (x >= s.total) return;
-    long long i = ub_le(s.gstart, (long long)s.M, x);
-    uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
-    for (; i >= 0; i--) {
-        const uint64_t g = s.gstart[i];
-        if (g + (uint64_t)s.L <= x) break;                        // reads are sorted by gstart; nothing further left can cover x
-        const int v = pc_to_idx(base2_at(s.oreads + (size_t)i * s.W, (int)(x - g)));
-        cA += (v == 0); cC += (v == 1); cG += (v == 2); cT += (v == 3);
-    }
-    uint32_t mx = 0; int ind = 0;
-    if (cA > mx) { mx = cA; ind = 0; }
-    if (cC > mx) { mx = cC; ind = 1; }
-    if (cG > mx) { mx = cG; ind = 2; }
-    if (cT > mx) { mx = cT; ind = 3; }
-    s.cons[x] = (uint8_t)ind;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= s.nC) return;
+    const bool lastc = (k + 1 == s.nC) || (s.chead[k + 1] % s.q) == 0;
+    const unsigned long long cend = (k + 1 == s.nC) ? s.total : s.gstart[s.chead[k + 1]];
+    cinfo[k] = cend | ((unsigned long long)lastc << 63);
 }
 
-// singleton / N-read realignment, phase 1 (encoder.cpp:252-410): one thread per window start x.
+// buildcontig (encoder.cpp:619-652): column x <- first strict maximum over A,C,G,T of the reads covering it.
+// One thread per strip of 8 columns (one binary search per strip).  Byte written: base | 4 when a realignment window may
+// start at x (fits in its contig, encoder.cpp:252, and the contig is not the last of its shard).
+#define CSTRIP 8
+__global__ __launch_bounds__(256) void k_consensus(S2Args s, const uint32_t *cid, const unsigned long long *cinfo, int want_windows)
+{
+    const uint64_t x0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * CSTRIP;
+    if (x0 >= s.total) return;
+    long long i = ub_le(s.gstart, (long long)s.M, x0);
+    uint32_t kprev = HARC_NONE; unsigned long long cend = 0; bool lastc = true;
+    uint8_t outb[CSTRIP];
+#pragma unroll
+    for (int c = 0; c < CSTRIP; c++) {
+        const uint64_t x = x0 + c;
+        outb[c] = 0;
+        if (x >= s.total) continue;
+        while (i + 1 < (long long)s.M && s.gstart[i + 1] <= x) i++;
+        uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
+        for (long long ii = i; ii >= 0; ii--) {
+            const uint64_t g = s.gstart[ii];
+            if (g + (uint64_t)s.L <= x) break;                    // reads are sorted by gstart; nothing further left can cover x
+            const int v = pc_to_idx(base2_at(s.oreads + (size_t)ii * s.W, (int)(x - g)));
+            cA += (v == 0); cC += (v == 1); cG += (v == 2); cT += (v == 3);
+        }
+        uint32_t mx = 0; int ind = 0;
+        if (cA > mx) { mx = cA; ind = 0; }
+        if (cC > mx) { mx = cC; ind = 1; }
+        if (cG > mx) { mx = cG; ind = 2; }
+        if (cT > mx) { mx = cT; ind = 3; }
+        int valid = 0;
+        if (want_windows) {
+            const uint32_t k = cid[i] + (uint32_t)s.head[i] - 1u;    // cid = exclusive scan of the head flags: a head's own contig index
+            if (k != kprev) { const unsigned long long ci = cinfo[k]; kprev = k; cend = ci & ~(1ULL << 63); lastc = (ci >> 63) != 0; }
+            valid = (!lastc && x + (uint64_t)s.L <= cend) ? 1 : 0;
+        }
+        outb[c] = (uint8_t)(ind | (valid << 2));
+    }
+    if (x0 + CSTRIP <= s.total) {
+        uint2 w;
+        w.x = (uint32_t)outb[0] | ((uint32_t)outb[1] << 8) | ((uint32_t)outb[2] << 16) | ((uint32_t)outb[3] << 24);
+        w.y = (uint32_t)outb[4] | ((uint32_t)outb[5] << 8) | ((uint32_t)outb[6] << 16) | ((uint32_t)outb[7] << 24);
+        *reinterpret_cast<uint2 *>(s.cons + x0) = w;
+    } else {
+        for (int c = 0; c < CSTRIP && x0 + c < s.total; c++) s.cons[x0 + c] = outb[c];
+    }
+}
+
+// singleton / N-read realignment, phase 1 (encoder.cpp:252-410).  A workgroup stages 2048 + L consensus bytes in LDS; each thread
+// owns 8 consecutive window starts and rolls its four dictionary keys (forward / reverse x 2 dictionaries) from one window to the next.
+#define RSTRIP 8
+#define RTILE (256 * RSTRIP)
 __global__ __launch_bounds__(256) void k_realign_propose(S2Args s)
 {
-    const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (x >= s.total) return;
-    // which contig? largest k with gstart[chead[k]] <= x  (binary search over contig heads)
-    long long lo = 0, hi = s.nC;
-    while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if (s.gstart[s.chead[mid]] <= x) lo = mid; else hi = mid; }
-    const uint32_t k = (uint32_t)lo;
-    const bool lastc = (k + 1 == s.nC) || (s.chead[k + 1] % s.q) == 0;      // last contig of a shard: no realignment (:438-441)
-    if (lastc) return;
-    const uint64_t cend = s.gstart[s.chead[k + 1]];
-    if (x + (uint64_t)s.L > cend) return;                                   // window must fit in the contig (:252)
-    const uint8_t *win = s.cons + x;
+    __shared__ uint32_t tile32[(RTILE + 256 + 8) / 4];
+    uint8_t *tile = reinterpret_cast<uint8_t *>(tile32);
+    const uint64_t X0 = (uint64_t)blockIdx.x * RTILE;
     const int L = s.L, W3 = s.W3;
-    for (int dir = 0; dir < 2; dir++) {
-        for (int l = 0; l < 2; l++) {
-            uint64_t key = 0;
-            for (int b = s.ds[l]; b <= s.de[l]; b++) {
-                const int idx = dir ? 3 - (int)win[L - 1 - b] : (int)win[b];
-                key |= (uint64_t)idx_to_c3(idx) << (3 * (b - s.ds[l]));
-            }
-            uint32_t st = 0, cnt = 0, np = 0;
-            if (!dict_lookup(s.slots[l], s.cap[l], key, &st, &cnt, &np)) continue;
-            const bool emb = (cnt & SLOT_EMB) != 0;
-            cnt &= SLOT_CNT_MASK;
-            const uint32_t lim = cnt > (uint32_t)s.maxsearch ? (uint32_t)s.maxsearch : cnt;   // static window: top maxsearch ids of the bin
-            for (uint32_t t = 0; t < lim; t++) {
-                const uint32_t rid = emb ? st : s.ids[l][st + cnt - 1 - t];
-                const uint64_t *r = s.cand3 + (size_t)rid * W3;
-                int hd = 0;
-                for (int w = 0; w < W3; w++) {                                // 3-bit window word w, built on the fly
-                    uint64_t v = 0;
-                    const int b0 = (64 * w) / 3, b1 = (64 * w + 63) / 3;
-                    for (int b = b0; b <= b1 && b < L; b++) {
-                        const int idx = dir ? 3 - (int)win[L - 1 - b] : (int)win[b];
-                        const uint64_t c3 = (uint64_t)idx_to_c3(idx);
-                        const int sh = 3 * b - 64 * w;
-                        v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
+    const int ntile = RTILE + L + 1;
+    for (int d = threadIdx.x; d < (ntile + 3) / 4; d += 256) {
+        const uint64_t g = X0 + 4ull * d;
+        uint32_t v = 0;
+        if (g + 4 <= s.total) v = *reinterpret_cast<const uint32_t *>(s.cons + g);
+        else for (int k = 0; k < 4; k++) if (g + k < s.total) v |= (uint32_t)s.cons[g + k] << (8 * k);
+        tile32[d] = v;
+    }
+    __syncthreads();
+    const int t0 = threadIdx.x * RSTRIP;
+    if (X0 + t0 >= s.total) return;
+    const int n0 = s.de[0] - s.ds[0] + 1, n1 = s.de[1] - s.ds[1] + 1;
+    const uint64_t m0 = (n0 * 3 < 64) ? ((1ULL << (3 * n0)) - 1) : ~0ULL, m1 = (n1 * 3 < 64) ? ((1ULL << (3 * n1)) - 1) : ~0ULL;
+    uint64_t kf0 = 0, kf1 = 0, kr0 = 0, kr1 = 0;
+    for (int b = 0; b < n0; b++) {
+        kf0 |= (uint64_t)idx_to_c3(tile[t0 + s.ds[0] + b] & 3) << (3 * b);
+        kr0 |= (uint64_t)idx_to_c3(3 - (tile[t0 + L - 1 - s.ds[0] - b] & 3)) << (3 * b);
+    }
+    for (int b = 0; b < n1; b++) {
+        kf1 |= (uint64_t)idx_to_c3(tile[t0 + s.ds[1] + b] & 3) << (3 * b);
+        kr1 |= (uint64_t)idx_to_c3(3 - (tile[t0 + L - 1 - s.ds[1] - b] & 3)) << (3 * b);
+    }
+    for (int c = 0; c < RSTRIP; c++) {
+        const int tx = t0 + c;
+        const uint64_t x = X0 + tx;
+        if (x >= s.total) break;
+        if (tile[tx] & 4) {
+            const uint8_t *win = tile + tx;
+            for (int dir = 0; dir < 2; dir++) {
+                for (int l = 0; l < 2; l++) {
+                    const uint64_t key = dir ? (l ? kr1 : kr0) : (l ? kf1 : kf0);
+                    uint32_t st = 0, cnt = 0, np = 0;
+                    if (!dict_lookup(s.slots[l], s.cap[l], key, &st, &cnt, &np)) continue;
+                    const bool emb = (cnt & SLOT_EMB) != 0;
+                    cnt &= SLOT_CNT_MASK;
+                    const uint32_t lim = cnt > (uint32_t)s.maxsearch ? (uint32_t)s.maxsearch : cnt;   // static window: top maxsearch ids of the bin
+                    for (uint32_t t = 0; t < lim; t++) {
+                        const uint32_t rid = emb ? st : s.ids[l][st + cnt - 1 - t];
+                        const uint64_t *r = s.cand3 + (size_t)rid * W3;
+                        int hd = 0;
+                        for (int w = 0; w < W3; w++) {                        // 3-bit window word w, built on the fly
+                            uint64_t v = 0;
+                            const int b0 = (64 * w) / 3, b1 = (64 * w + 63) / 3;
+                            for (int b = b0; b <= b1 && b < L; b++) {
+                                const int idx = dir ? 3 - (int)(win[L - 1 - b] & 3) : (int)(win[b] & 3);
+                                const uint64_t c3 = (uint64_t)idx_to_c3(idx);
+                                const int sh = 3 * b - 64 * w;
+                                v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
+                            }
+                            hd += __popcll(v ^ r[w]);
+                            if (hd > s.thresh_s) break;
+                        }
+                        if (hd <= s.thresh_s) atomicMin(&s.best[rid], (unsigned long long)((x << 2) | ((uint64_t)dir << 1) | (uint64_t)l));
                     }
-                    hd += __popcll(v ^ r[w]);
-                    if (hd > s.thresh_s) break;
                 }
-                if (hd <= s.thresh_s) atomicMin(&s.best[rid], (unsigned long long)((x << 2) | ((uint64_t)dir << 1) | (uint64_t)l));
             }
         }
+        // roll the keys to window x+1
+        kf0 = (kf0 >> 3) | ((uint64_t)idx_to_c3(tile[tx + 1 + s.de[0]] & 3) << (3 * (n0 - 1)));
+        kf1 = (kf1 >> 3) | ((uint64_t)idx_to_c3(tile[tx + 1 + s.de[1]] & 3) << (3 * (n1 - 1)));
+        kr0 = ((kr0 << 3) & m0) | (uint64_t)idx_to_c3(3 - (tile[tx + L - s.ds[0]] & 3));
+        kr1 = ((kr1 << 3) & m1) | (uint64_t)idx_to_c3(3 - (tile[tx + L - s.ds[1]] & 3));
     }
 }
 
@@ -256,7 +318,7 @@ __global__ void k_count_noise(S2Args s, FinalArrays f, uint32_t F, uint32_t *nm,
     if (i >= F) return;
     const uint32_t ref = f.ref[i]; const int kind = f.kind[i]; const uint64_t g = f.g[i];
     uint32_t n = 0;
-    for (int j = 0; j < s.L; j++) n += (final_base(s, ref, kind, j) != (int)s.cons[g + j]);
+    for (int j = 0; j < s.L; j++) n += (final_base(s, ref, kind, j) != (int)(s.cons[g + j] & 3));
     nm[i] = n;
     nonN[i] = (kind != 0 && ref >= s.S) ? 0u : 1u;                // N reads are exactly the candidates with index >= S
 }
@@ -270,7 +332,7 @@ __global__ void k_emit(S2Args s, FinalArrays f, uint32_t F, const uint64_t *nmof
     uint64_t np = nmoff[i], nz = nmoff[i] + i;                    // one '\n' per earlier read
     int prevj = 0;
     for (int j = 0; j < s.L; j++) {
-        const int b = final_base(s, ref, kind, j), cb = (int)s.cons[g + j];
+        const int b = final_base(s, ref, kind, j), cb = (int)(s.cons[g + j] & 3);
         if (b != cb) { noise[nz++] = (uint8_t)enc_noise(cb, b); noisepos[np++] = (uint8_t)(j - prevj); prevj = j; }
     }
     noise[nz] = '\n';
@@ -316,7 +378,7 @@ __global__ void k_pack2_bytes(const uint8_t *bases, uint64_t nbytes_out, uint8_t
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nbytes_out) return;
     const uint8_t *b = bases + 4 * i;
-    out[i] = (uint8_t)(b[0] | (b[1] << 2) | (b[2] << 4) | (b[3] << 6));
+    out[i] = (uint8_t)((b[0] & 3) | ((b[1] & 3) << 2) | ((b[2] & 3) << 4) | ((b[3] & 3) << 6));
 }
 __global__ void k_pack1_bytes(const uint8_t *rc, uint64_t nbytes_out, uint8_t *out)
 {
@@ -433,8 +495,10 @@ int stage2_run(harc_amd_ctx *c)
     uint8_t *cons = nullptr; RC_TRY(dalloc(c, &cons, (size_t)total + 8));
     a.cons = cons;
     if (total) {
-        hipLaunchKernelGGL(k_consensus, G256(total), a);
-        if (T) hipLaunchKernelGGL(k_realign_propose, G256(total), a);
+        unsigned long long *cinfo = nullptr; RC_TRY(dalloc(c, &cinfo, (size_t)nC + 1));
+        hipLaunchKernelGGL(k_contig_info, G256(nC), a, cinfo);
+        hipLaunchKernelGGL(k_consensus, G256((total + CSTRIP - 1) / CSTRIP), a, (const uint32_t *)u1, (const unsigned long long *)cinfo, T ? 1 : 0);
+        if (T) hipLaunchKernelGGL(k_realign_propose, dim3((unsigned)((total + RTILE - 1) / RTILE)), dim3(256), 0, c->stream, a);
     }
     HIP_TRY(hipGetLastError());
 
