@@ -202,7 +202,7 @@ def main():
     launches = max(1, agg["launches"])
     avg_ms = agg["propose_ms"] / launches
     achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = {"kernel": "k_propose", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+    roofline = {"kernel": "k_steps", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": None,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "launches": launches,
                 "alg_bytes_per_launch": round(alg_bytes / launches, 1),

@@ -121,7 +121,7 @@ template <int NT> __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32
 __device__ __forceinline__ bool dict_lookup(const HashSlot *tab, uint64_t cap, uint64_t key, uint32_t *start, uint32_t *count, uint32_t *nprobe)
 {
     if (!cap) return false;
-    uint64_t sl = __umul64hi(mix64(key), cap);
+    uint64_t sl = __umul64hi(mix64(key), cap);                   // classic linear probing (tables built with bucketed = false)
     for (;;) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(&tab[sl]);
         (*nprobe)++;

@@ -71,6 +71,7 @@ struct DictDev {
     uint32_t *ids = nullptr;   // read ids sorted by (key, id)
     uint32_t *d_nbins = nullptr;
     uint32_t nbins = 0;
+    bool bucketed = false;     // probing starts at a 64-B bucket of 4 slots (fetched whole by a latency-bound k_steps) instead of at the hashed slot
 };
 
 struct harc_amd_ctx {

@@ -170,7 +170,7 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
 }
 // one thread per bin: claim an empty slot by CAS on the (start,count) word; keys are unique so no key compare is needed
 __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, const uint32_t *nbins_p, uint32_t n,
-                               HashSlot *slots, uint64_t cap)
+                               HashSlot *slots, uint64_t cap, int bucketed)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nbins = *nbins_p;
@@ -182,7 +182,7 @@ __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, cons
     const uint32_t cnt = en - st;
     const unsigned long long meta = cnt == 1 ? ((unsigned long long)sids[st] | ((unsigned long long)(1u | SLOT_EMB) << 32))
                                              : ((unsigned long long)st | ((unsigned long long)(cnt & SLOT_CNT_MASK) << 32));
-    uint64_t sl = __umul64hi(mix64(key), cap);
+    uint64_t sl = bucketed ? (__umul64hi(mix64(key), cap >> 2) << 2) : __umul64hi(mix64(key), cap);   // bucketed: start at a 64-B bucket of 4 slots
     for (;;) {
         unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
         if (atomicCAS(mp, 0ULL, meta) == 0ULL) { slots[sl].key = key; return; }
@@ -326,7 +326,10 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t x, int src)
 //      slot -> bin scan from the highest unclaimed id (<= maxsearch of them) -> XOR+popcount Hamming on the packed words;
 //      the lowest lane with a hit is the step's read;
 //  (3) lane 0 records the step and bids for the read with atomicMin(step<<20 | chain); the counts are updated in registers.
-template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
+#ifndef HARC_STEPS_WAVES
+#define HARC_STEPS_WAVES 4
+#endif
+template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) void k_steps(S1Args s)
 {
     __shared__ uint32_t s_own[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -413,57 +416,67 @@ template <int W> __global__ __launch_bounds__(256) void k_steps(S1Args s)
                 HashSlot *tab = s.slots[l];
                 const uint32_t *ids = s.ids[l];
                 if (cap) {
-                    uint64_t sl = __umul64hi(mix64(key), cap);
+                    // QUAD (few chains, latency-bound): the table is bucketed and a whole 64-B bucket of 4 slots is fetched per round trip;
+                    // otherwise (many chains, request-rate-bound) classic linear probing, one 16-B slot per request
+                    uint64_t sl = QUAD ? (__umul64hi(mix64(key), cap >> 2) << 2) : __umul64hi(mix64(key), cap);
                     for (;;) {
-                        const uint4 raw = *reinterpret_cast<const uint4 *>(&tab[sl]);
-                        np++;
-                        const uint64_t k2 = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
-                        const uint32_t sst = raw.z, cw = raw.w;
-                        if (cw == 0) break;
-                        if (k2 == key) {
-                            if (cw & SLOT_DEAD) break;                        // every read of this bin is already claimed
-                            const int nb = 2 * (L - j);
-                            const int sws = (2 * j) >> 6, sbs = (2 * j) & 63;     // the consensus is shifted by 2j bits (reorder.cpp:647-648)
-                            const uint32_t cntb = cw & SLOT_CNT_MASK;
-                            const bool emb = (cw & SLOT_EMB) != 0;            // single-read bin: `start` IS the read id
-                            int seen = 0; uint32_t lead = 0; bool alltop = true;
-                            for (uint32_t i = cntb; i > 0 && seen < s.maxsearch; i--) {
-                                const uint32_t rid = emb ? sst : ids[sst + i - 1];
-                                // claim bit and read words are fetched together (one dependent hop instead of two)
-                                const unsigned long long cwd = s.claimed[rid >> 6];
+                        constexpr int NQ = QUAD ? 4 : 1;
+                        uint4 rawq[NQ];
 #pragma unroll
-                                for (int w = 0; w < W; w++) mrd[w] = s.reads[(size_t)rid * W + w];
-                                if ((cwd >> (rid & 63)) & 1ULL) { if (alltop) lead++; continue; }
-                                alltop = false;
-                                bool own = false;                             // taken by this chain earlier in this super-round
-                                for (int k = 0; k < t; k++) own |= (s_own[wv][k] == rid);
-                                if (own) continue;
-                                seen++; nc++;
-                                int hd = 0;
+                        for (int q = 0; q < NQ; q++) rawq[q] = *reinterpret_cast<const uint4 *>(&tab[sl + q]);
+                        int state = 0, qhit = 0;                              // 1 = an empty slot ends the search, 2 = key found
+                        uint32_t sst = 0, cw = 0;
 #pragma unroll
-                                for (int w = 0; w < W; w++) {
-                                    uint64_t shw, m;
-                                    if (dir) {                                // reverse: (revref << 2j), bits >= 2j below 2L (revmask[j], :714-715)
-                                        const uint64_t hi = sel0<W>(rref, w - sws), lo = sel0<W>(rref, w - sws - 1);
-                                        shw = sbs ? ((hi << sbs) | (lo >> (64 - sbs))) : hi;
-                                        m = lowmask_word(2 * L, w) & ~lowmask_word(2 * j, w);
-                                    } else {                                  // forward: (ref >> 2j), low 2(L-j) bits (mask[j], :712-713)
-                                        const uint64_t lo = sel0<W>(ref, w + sws), hi = sel0<W>(ref, w + sws + 1);
-                                        shw = sbs ? ((lo >> sbs) | (hi << (64 - sbs))) : lo;
-                                        m = lowmask_word(nb, w);
-                                    }
-                                    hd += __popcll((shw ^ mrd[w]) & m);
-                                }
-                                if (hd <= s.thresh) { mine = rid; break; }
+                        for (int q = 0; q < NQ; q++) {
+                            if (state == 0) {
+                                np++;
+                                if (rawq[q].w == 0) state = 1;
+                                else if (((uint64_t)rawq[q].x | ((uint64_t)rawq[q].y << 32)) == key) { state = 2; qhit = q; sst = rawq[q].z; cw = rawq[q].w; }
                             }
-                            // hints only (the claim bitmap stays the truth): claimed reads at the top of a bin are never looked at again
-                            if (lead) {
-                                uint32_t *cp = reinterpret_cast<uint32_t *>(&tab[sl]) + 3;
-                                if (lead == cntb) atomicOr(cp, SLOT_DEAD); else if (!emb) atomicMin(cp, cntb - lead);
-                            }
-                            break;
                         }
-                        if (++sl == cap) sl = 0;
+                        if (state == 2 && !(cw & SLOT_DEAD)) {                // SLOT_DEAD: every read of this bin is already claimed
+                        const int nb = 2 * (L - j);
+                        const int sws = (2 * j) >> 6, sbs = (2 * j) & 63;     // the consensus is shifted by 2j bits (reorder.cpp:647-648)
+                        const uint32_t cntb = cw & SLOT_CNT_MASK;
+                        const bool emb = (cw & SLOT_EMB) != 0;            // single-read bin: `start` IS the read id
+                        int seen = 0; uint32_t lead = 0; bool alltop = true;
+                        for (uint32_t i = cntb; i > 0 && seen < s.maxsearch; i--) {
+                            const uint32_t rid = emb ? sst : ids[sst + i - 1];
+                            // claim bit and read words are fetched together (one dependent hop instead of two)
+                            const unsigned long long cwd = s.claimed[rid >> 6];
+#pragma unroll
+                            for (int w = 0; w < W; w++) mrd[w] = s.reads[(size_t)rid * W + w];
+                            if ((cwd >> (rid & 63)) & 1ULL) { if (alltop) lead++; continue; }
+                            alltop = false;
+                            bool own = false;                             // taken by this chain earlier in this super-round
+                            for (int k = 0; k < t; k++) own |= (s_own[wv][k] == rid);
+                            if (own) continue;
+                            seen++; nc++;
+                            int hd = 0;
+#pragma unroll
+                            for (int w = 0; w < W; w++) {
+                                uint64_t shw, m;
+                                if (dir) {                                // reverse: (revref << 2j), bits >= 2j below 2L (revmask[j], :714-715)
+                                    const uint64_t hi = sel0<W>(rref, w - sws), lo = sel0<W>(rref, w - sws - 1);
+                                    shw = sbs ? ((hi << sbs) | (lo >> (64 - sbs))) : hi;
+                                    m = lowmask_word(2 * L, w) & ~lowmask_word(2 * j, w);
+                                } else {                                  // forward: (ref >> 2j), low 2(L-j) bits (mask[j], :712-713)
+                                    const uint64_t lo = sel0<W>(ref, w + sws), hi = sel0<W>(ref, w + sws + 1);
+                                    shw = sbs ? ((lo >> sbs) | (hi << (64 - sbs))) : lo;
+                                    m = lowmask_word(nb, w);
+                                }
+                                hd += __popcll((shw ^ mrd[w]) & m);
+                            }
+                            if (hd <= s.thresh) { mine = rid; break; }
+                        }
+                        // hints only (the claim bitmap stays the truth): claimed reads at the top of a bin are never looked at again
+                        if (lead) {
+                            uint32_t *cp = reinterpret_cast<uint32_t *>(&tab[sl + qhit]) + 3;
+                            if (lead == cntb) atomicOr(cp, SLOT_DEAD); else if (!emb) atomicMin(cp, cntb - lead);
+                        }
+                        }
+                        if (state) break;
+                        sl += NQ; if (sl >= cap) sl = 0;
                     }
                 }
             }
@@ -675,7 +688,7 @@ int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n)
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) { fr += c->pool_total; while (m > 2 && (double)m * n * sizeof(HashSlot) > 0.2 * (double)fr) m--; }
         if (const char *e = getenv("HARC_AMD_CAPMULT")) m = strtoull(e, nullptr, 10);
-        d->cap = (m < 2 ? 2 : m) * n + 2;
+        d->cap = (((m < 2 ? 2 : m) * n + 4) + 3) & ~3ull;           // whole 64-B buckets of 4 slots
     }
     RC_TRY(dalloc(c, &d->slots, d->cap)); RC_TRY(dalloc(c, &d->ids, n)); RC_TRY(dalloc(c, &d->d_nbins, 1));
     return HARC_AMD_OK;
@@ -692,7 +705,7 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     RC_TRY(prim_excl_scan_u32(c, h0, b0, n));
     hipLaunchKernelGGL(k_bin_starts, dim3(g), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins);
     HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
-    hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, d->ids, bs, d->d_nbins, n, d->slots, d->cap);
+    hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, d->ids, bs, d->d_nbins, n, d->slots, d->cap, d->bucketed ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));                                    // temporaries are reused after this point
     harc_pool_release(c, mk);
@@ -737,6 +750,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     c->C.chains = K;
     int nsteps = P.num_steps > 0 ? P.num_steps : 16;
     if (nsteps > 64) nsteps = 64;
+    // few chains -> every launch is a chain of dependent HBM round trips: fetch whole buckets; many chains -> request-rate bound: single slots
+    bool quad = K <= 16384;
+    if (const char *e = getenv("HARC_AMD_QUAD")) quad = atoi(e) != 0;
     hipEvent_t e0, e1, e2;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
     HIP_TRY(hipEventRecord(e0, c->stream));
@@ -750,6 +766,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     DictDev dict[2];
     if (N) {
         RC_TRY(harc_dict_alloc(c, &dict[0], N)); RC_TRY(harc_dict_alloc(c, &dict[1], N));
+        dict[0].bucketed = dict[1].bucketed = quad;
         const harc_mark_t mk = harc_pool_mark(c);
         uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
         RC_TRY(dalloc(c, &k0, N)); RC_TRY(dalloc(c, &i0, N));
@@ -809,7 +826,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     for (;;) {
         for (int r = 0; r < batch; r++) {
             if (prof) { hipEvent_t a0, a1; HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1)); ev.push_back(a0); ev.push_back(a1); HIP_TRY(hipEventRecord(a0, c->stream)); }
-            hipLaunchKernelGGL((k_steps<W>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
+            if (quad) hipLaunchKernelGGL((k_steps<W, true>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
+            else hipLaunchKernelGGL((k_steps<W, false>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
             if (prof) HIP_TRY(hipEventRecord(ev.back(), c->stream));
             if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
             else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve<32>), dim3((K + 7) / 8), dim3(256), 0, c->stream, a);

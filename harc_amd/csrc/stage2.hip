@@ -121,7 +121,7 @@ __global__ void k_heads2(uint32_t M, uint8_t *head, const uint32_t *hmax, uint32
     if (r > 0 && (r % 10000001u) == 0) head[i] = 1;
     hidx[i] = head[i] ? 1u : 0u;                                  // reused as the flag array for the contig-id scan
 }
-__global__ void k_steps(const uint8_t *head, const uint8_t *pos, uint32_t M, int L, uint64_t *d)
+__global__ void k_col_steps(const uint8_t *head, const uint8_t *pos, uint32_t M, int L, uint64_t *d)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
@@ -477,7 +477,7 @@ int stage2_run(harc_amd_ctx *c)
         RC_TRY(prim_incl_max_u32(c, u0, u1, M));
         hipLaunchKernelGGL(k_heads2, G256(M), M, head, u1, u0);                  // u0 := head flags as u32
         RC_TRY(prim_excl_scan_u32(c, u0, u1, M));                                // u1 := contig id
-        hipLaunchKernelGGL(k_steps, G256(M), head, c->d_pos, M, L, d64);
+        hipLaunchKernelGGL(k_col_steps, G256(M), head, c->d_pos, M, L, d64);
         RC_TRY(prim_incl_scan_u64(c, d64, gstart, M));
         uint32_t lastcid = 0, lasthead = 0; uint64_t lastg = 0;
         HIP_TRY(hipMemcpyAsync(&lastcid, u1 + (M - 1), 4, hipMemcpyDeviceToHost, c->stream));
