@@ -154,8 +154,12 @@ def main():
         del clean
     else:
         h.set_reads_ascii_device(clean.data_ptr(), clean.shape[0], L)
-        del clean
     h.set_nreads_ascii_device(withN.data_ptr(), withN.shape[0], L)
+    # order-independent signature of the inputs this rank will encode (for the round-trip check after the timed region)
+    sig_N = h.reads_signature_device(withN.data_ptr(), withN.shape[0], L)
+    sig_clean = None if sharder is not None else h.reads_signature_device(clean.data_ptr(), clean.shape[0], L)
+    if sharder is None:
+        del clean
     torch.cuda.synchronize()
 
     def step():
@@ -192,6 +196,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     c = h.counters()
+    # round trip at full size, outside the timed region: decode the streams of the last step on the GPU (decoder.cpp:90-169
+    # restated in verify.hip) and compare the multiset signature with the inputs' (single GPU: all reads; sharded: count only,
+    # the shard's clean reads came from other ranks)
+    dsig = h.decode_signature()
+    if sig_clean is not None:
+        want = (sig_clean[0] + sig_N[0], (sig_clean[1] + sig_N[1]) % (1 << 64), sig_clean[2] ^ sig_N[2])
+        roundtrip = {"ok": bool(dsig == want), "reads_decoded": dsig[0], "check": "multiset signature (sum, xor of 64-bit read hashes) of GPU-decoded streams == inputs"}
+    else:
+        roundtrip = {"ok": bool(dsig[0] == c.n_clean + c.n_N), "reads_decoded": dsig[0], "check": "decoded read count == shard size (sharded run)"}
     total_reads = n * world * args.steps
     value = total_reads / dt / 1e6
 
@@ -219,6 +232,7 @@ def main():
                    "error_rate": err, "chains_per_gpu": int(c.chains), "encoder_shards_per_gpu": args.shards,
                    "parallelism": "single GPU" if world == 1 else f"minimizer-bucket shard x{world}, one RCCL all-to-all"},
         "roofline": roofline,
+        "roundtrip": roundtrip,
         "phases_ms_last_step": {"index": round(c.index_ms, 2), "chain": round(c.chain_ms, 2), "encode": round(c.encode_ms, 2)},
         "counters_last_step": {"unmatched": int(c.unmatched), "singletons_aligned": int(c.aligned_singletons), "N_aligned": int(c.aligned_N),
                                "rounds": int(c.rounds), "conflicts": int(c.conflicts), "contigs": int(c.contigs),

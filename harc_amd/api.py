@@ -76,6 +76,8 @@ def lib():
     for f in ("harc_amd_reorder_files", "harc_amd_encoder_files", "harc_amd_compress_files", "harc_amd_pack_order_files"):
         getattr(l, f).argtypes = [PP, C.c_char_p]
     l.harc_amd_preprocess_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
+    l.harc_amd_decode_signature.argtypes = [ctx, C.POINTER(C.c_uint64)]
+    l.harc_amd_reads_signature_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     _lib = l
     return l
 
@@ -176,6 +178,17 @@ class HarcAmd:
 
     def pack_order(self):
         _check(lib().harc_amd_pack_order(self._ctx))
+
+    def decode_signature(self):
+        """(count, sum, xor) of the reads decoded on the GPU from this context's stage-II streams"""
+        sig = (C.c_uint64 * 3)()
+        _check(lib().harc_amd_decode_signature(self._ctx, sig))
+        return tuple(int(x) for x in sig)
+
+    def reads_signature_device(self, d_ascii, n, stride):
+        sig = (C.c_uint64 * 3)()
+        _check(lib().harc_amd_reads_signature_device(self._ctx, C.c_void_p(d_ascii), n, stride, sig))
+        return tuple(int(x) for x in sig)
 
     def stream(self, name, shard=0):
         ptr, ln = C.c_void_p(), C.c_size_t()

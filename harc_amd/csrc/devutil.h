@@ -90,6 +90,16 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t x, int src)
+{
+    const uint32_t lo = __shfl((uint32_t)x, src, 64), hi = __shfl((uint32_t)(x >> 32), src, 64);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t shfl_u64_any(uint64_t x, int xormask)
+{
+    const uint32_t lo = __shfl_xor((uint32_t)x, xormask, 64), hi = __shfl_xor((uint32_t)(x >> 32), xormask, 64);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
 // exclusive prefix sum over the 64 lanes; *total = wave sum
 __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *total)
 {

@@ -314,11 +314,6 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
         ref[w] = (bs ? ((lo >> bs) | (hi << (64 - bs))) : lo) & lowmask_word(2 * L, w);
     }
 }
-__device__ __forceinline__ uint64_t shfl_u64(uint64_t x, int src)
-{
-    const uint32_t lo = __shfl((uint32_t)x, src, 64), hi = __shfl((uint32_t)(x >> 32), src, 64);
-    return (uint64_t)lo | ((uint64_t)hi << 32);
-}
 
 // The dominant kernel.  One wave per chain, 4 chains per 256-thread workgroup.  Per step:
 //  (1) consensus -> packed words (ballots), reverse complement;

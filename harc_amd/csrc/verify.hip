@@ -1,0 +1,186 @@
+// verify.hip -- decode side on the GPU, used as the size-independent round-trip check.
+//
+// decoder.cpp:90-169 restated data-parallel: the start column of read i in its shard's consensus stream is (sum of the pos bytes
+// up to i) - readlen, its noise entries sit between the (i-1)-th and i-th '\n' of read_noise, the mismatch positions are the
+// running sum of its read_noisepos bytes (decoder.cpp:100-108), the read is reverse-complemented when its read_rev bit is set
+// (:109-129).  Instead of writing 100 B per read back to the host, every decoded read is hashed and the hashes are summed and
+// xored: an order-independent signature of the decoded multiset that is compared with the same signature of the input reads.
+#include "devutil.h"
+
+__device__ __forceinline__ uint64_t read_hash_step(uint64_t h, int code) { return (h ^ (uint64_t)code) * 1099511628211ULL; }   // FNV-1a over codes A0 C1 G2 T3 N4
+#define READ_HASH_INIT 1469598103934665603ULL
+
+__device__ __forceinline__ void sig_accumulate(uint64_t h, bool valid, unsigned long long *sig)
+{
+    // sig[0] count, sig[1] sum, sig[2] xor ; wave-level reduction first
+    unsigned long long s = valid ? h : 0, x = valid ? h : 0, n = valid ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += shfl_u64_any(s, o); x ^= shfl_u64_any(x, o); n += shfl_u64_any(n, o);
+    }
+    if ((threadIdx.x & 63) == 0 && n) { atomicAdd(&sig[0], n); atomicAdd(&sig[1], s); atomicXor(&sig[2], x); }
+}
+
+__global__ void k_sig_ascii(const char *ascii, uint32_t n, uint32_t stride, int L, unsigned long long *sig)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t h = READ_HASH_INIT;
+    if (i < n) {
+        const char *s = ascii + (size_t)i * stride;
+        for (int j = 0; j < L; j++) { const char ch = s[j]; h = read_hash_step(h, ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4); }
+        h = mix64(h);
+    }
+    sig_accumulate(h, i < n, sig);
+}
+// 2-bit packed stream (A0 C1 G2 T3, 4 per byte, encoder.cpp:540-541) + ASCII tail -> one code per byte
+__global__ void k_unpack_seq(const uint8_t *packed, uint64_t nb, const uint8_t *tail, uint64_t ntail, uint8_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4 * nb) out[i] = (packed[i >> 2] >> (2 * (i & 3))) & 3;
+    else if (i < 4 * nb + ntail) { const uint8_t ch = tail[i - 4 * nb]; out[i] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3; }
+}
+__global__ void k_pos_to_u64(const uint8_t *pos, uint32_t n, uint64_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pos[i];
+}
+__global__ void k_nl_flags(const uint8_t *noise, uint64_t n, uint32_t *flag)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = noise[i] == '\n' ? 1u : 0u;
+}
+__global__ void k_nl_positions(const uint8_t *noise, const uint32_t *rank, uint64_t n, uint64_t *nlpos)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && noise[i] == '\n') nlpos[rank[i]] = i;
+}
+// one thread per read of a shard: decode, hash
+__global__ void k_decode_sig(const uint8_t *seqb, uint64_t seqlen, const uint64_t *possum, const uint8_t *noise, const uint8_t *noisepos,
+                             const uint64_t *nlpos, const uint8_t *revb, uint64_t nrevb, const uint8_t *revtail, uint32_t n, int L,
+                             unsigned long long *sig, unsigned int *err)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t h = READ_HASH_INIT;
+    bool ok = i < n;
+    if (ok) {
+        const uint64_t start = possum[i] - (uint64_t)L;                       // decoder.cpp:93-98
+        if (possum[i] < (uint64_t)L || start + L > seqlen) { atomicAdd(err, 1u); ok = false; }
+        else {
+            uint8_t buf[256];
+            for (int j = 0; j < L; j++) buf[j] = seqb[start + j];
+            const uint64_t n0 = i ? nlpos[i - 1] + 1 : 0, n1 = nlpos[i];
+            uint64_t np = n0 - i;                                             // noisepos bytes consumed by earlier reads
+            int p = 0;
+            for (uint64_t k = n0; k < n1; k++) {                              // decoder.cpp:100-108
+                p += noisepos[np++];
+                const int ref = buf[p] & 3, code = noise[k] - '0';
+                // dec_noise (decoder.cpp setglobalarrays): A:{C,G,T,N} C:{A,G,T,N} G:{T,A,C,N} T:{G,C,A,N}
+                const unsigned tab = ref == 0 ? 0x4321u : ref == 1 ? 0x4320u : ref == 2 ? 0x4103u : 0x4012u;
+                if (p < L) buf[p] = (uint8_t)((tab >> (4 * code)) & 0xF); else atomicAdd(err, 1u);
+            }
+            const bool rev = i < 8 * nrevb ? ((revb[i >> 3] >> (i & 7)) & 1) : (revtail[i - 8 * nrevb] == 'r');
+            if (!rev) for (int j = 0; j < L; j++) h = read_hash_step(h, buf[j]);
+            else for (int j = L - 1; j >= 0; j--) h = read_hash_step(h, buf[j] == 4 ? 4 : 3 - buf[j]);   // decoder.cpp:109-129
+            h = mix64(h);
+        }
+    }
+    sig_accumulate(h, ok, sig);
+}
+// unaligned singletons: 2-bit packed, L bases each, back to back (encoder.cpp:484-491)
+__global__ void k_sig_codes(const uint8_t *codes, uint32_t n, int L, unsigned long long *sig)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t h = READ_HASH_INIT;
+    if (i < n) { for (int j = 0; j < L; j++) h = read_hash_step(h, codes[(size_t)i * L + j]); h = mix64(h); }
+    sig_accumulate(h, i < n, sig);
+}
+
+#define G256(n) dim3((unsigned)((((uint64_t)(n)) + 255) / 256)), dim3(256), 0, c->stream
+
+static bool get_out(harc_amd_ctx *c, int id, int shard, const uint8_t **p, size_t *n)
+{
+    auto it = c->out.find(std::make_pair(id, shard));
+    if (it == c->out.end()) return false;
+    if (it->second.ptr) { *p = it->second.ptr; *n = it->second.len; } else { *p = it->second.own.data(); *n = it->second.own.size(); }
+    return true;
+}
+static int up(harc_amd_ctx *c, const uint8_t *h, size_t n, uint8_t **d)
+{
+    RC_TRY(dalloc(c, d, n + 16));
+    if (n) HIP_TRY(hipMemcpyAsync(*d, h, n, hipMemcpyHostToDevice, c->stream));
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_reads_signature_device(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride, uint64_t *sig3)
+{
+    if (!c || !sig3 || (n && !d_ascii) || stride < (uint32_t)c->P.readlen) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    const harc_mark_t mk = harc_pool_mark(c);
+    unsigned long long *d_sig = nullptr; RC_TRY(dalloc(c, &d_sig, 4));
+    HIP_TRY(hipMemsetAsync(d_sig, 0, 32, c->stream));
+    if (n) hipLaunchKernelGGL(k_sig_ascii, G256(n), d_ascii, n, stride, c->P.readlen, d_sig);
+    HIP_TRY(hipMemcpyAsync(sig3, d_sig, 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    harc_pool_release(c, mk);
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_decode_signature(harc_amd_ctx *c, uint64_t *sig3)
+{
+    if (!c || !sig3) return HARC_AMD_EINVAL;
+    if (!c->have_s2) { harc_set_error("harc_amd_decode_signature: encode first"); return HARC_AMD_ESTATE; }
+    HIP_TRY(hipSetDevice(c->P.device));
+    const int L = c->P.readlen;
+    const harc_mark_t mk0 = harc_pool_mark(c);
+    unsigned long long *d_sig = nullptr; unsigned int *d_err = nullptr;
+    RC_TRY(dalloc(c, &d_sig, 4)); RC_TRY(dalloc(c, &d_err, 4));
+    HIP_TRY(hipMemsetAsync(d_sig, 0, 32, c->stream)); HIP_TRY(hipMemsetAsync(d_err, 0, 16, c->stream));
+    for (int e = 0; e < c->P.num_thr; e++) {
+        const uint8_t *seq, *seqt, *pos, *noise, *npz, *rev, *revt; size_t nseq, nseqt, npos, nnoise, nnp, nrev, nrevt;
+        if (!get_out(c, HARC_AMD_S2_SEQ, e, &seq, &nseq) || !get_out(c, HARC_AMD_S2_SEQ_TAIL, e, &seqt, &nseqt) || !get_out(c, HARC_AMD_S2_POS, e, &pos, &npos) ||
+            !get_out(c, HARC_AMD_S2_NOISE, e, &noise, &nnoise) || !get_out(c, HARC_AMD_S2_NOISEPOS, e, &npz, &nnp) ||
+            !get_out(c, HARC_AMD_S2_REV, e, &rev, &nrev) || !get_out(c, HARC_AMD_S2_REV_TAIL, e, &revt, &nrevt)) { harc_set_error("shard %d streams missing", e); return HARC_AMD_ESTATE; }
+        if (npos == 0) continue;
+        if (npos > 0xFFFFFFFFull || 8 * nrev + nrevt != npos) { harc_set_error("shard %d: rev stream does not match pos stream", e); return HARC_AMD_EIO; }
+        const harc_mark_t mk = harc_pool_mark(c);
+        const uint32_t n = (uint32_t)npos;
+        uint8_t *d_seq, *d_seqt, *d_pos, *d_noise, *d_np, *d_rev, *d_revt, *seqb; uint64_t *p64, *possum, *nlpos; uint32_t *fl, *rk;
+        RC_TRY(up(c, seq, nseq, &d_seq)); RC_TRY(up(c, seqt, nseqt, &d_seqt)); RC_TRY(up(c, pos, npos, &d_pos)); RC_TRY(up(c, noise, nnoise, &d_noise));
+        RC_TRY(up(c, npz, nnp, &d_np)); RC_TRY(up(c, rev, nrev, &d_rev)); RC_TRY(up(c, revt, nrevt, &d_revt));
+        const uint64_t seqlen = 4 * (uint64_t)nseq + nseqt;
+        RC_TRY(dalloc(c, &seqb, (size_t)seqlen + 16)); RC_TRY(dalloc(c, &p64, (size_t)n + 1)); RC_TRY(dalloc(c, &possum, (size_t)n + 1));
+        RC_TRY(dalloc(c, &nlpos, (size_t)n + 1)); RC_TRY(dalloc(c, &fl, nnoise + 1)); RC_TRY(dalloc(c, &rk, nnoise + 1));
+        if (seqlen) hipLaunchKernelGGL(k_unpack_seq, G256(seqlen), d_seq, (uint64_t)nseq, d_seqt, (uint64_t)nseqt, seqb);
+        hipLaunchKernelGGL(k_pos_to_u64, G256(n), d_pos, n, p64);
+        RC_TRY(prim_incl_scan_u64(c, p64, possum, n));
+        if (nnoise) {
+            hipLaunchKernelGGL(k_nl_flags, G256(nnoise), d_noise, (uint64_t)nnoise, fl);
+            RC_TRY(prim_excl_scan_u32(c, fl, rk, nnoise));
+            hipLaunchKernelGGL(k_nl_positions, G256(nnoise), d_noise, rk, (uint64_t)nnoise, nlpos);
+        }
+        hipLaunchKernelGGL(k_decode_sig, G256(n), seqb, seqlen, possum, d_noise, d_np, nlpos, d_rev, (uint64_t)nrev, d_revt, n, L, d_sig, d_err);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        harc_pool_release(c, mk);
+    }
+    {   // unaligned singletons and unaligned N reads (decoder.cpp:148-169)
+        const uint8_t *sg, *sgt, *nt; size_t nsg, nsgt, nnt;
+        if (!get_out(c, HARC_AMD_S2_SINGLETON, 0, &sg, &nsg) || !get_out(c, HARC_AMD_S2_SINGLETON_TAIL, 0, &sgt, &nsgt) || !get_out(c, HARC_AMD_S2_INPUT_N, 0, &nt, &nnt)) {
+            harc_set_error("singleton streams missing"); return HARC_AMD_ESTATE;
+        }
+        const uint64_t nb = 4 * (uint64_t)nsg + nsgt;
+        uint8_t *d_sg, *d_sgt, *codes, *d_nt;
+        RC_TRY(up(c, sg, nsg, &d_sg)); RC_TRY(up(c, sgt, nsgt, &d_sgt)); RC_TRY(up(c, nt, nnt, &d_nt)); RC_TRY(dalloc(c, &codes, (size_t)nb + 16));
+        if (nb) hipLaunchKernelGGL(k_unpack_seq, G256(nb), d_sg, (uint64_t)nsg, d_sgt, (uint64_t)nsgt, codes);
+        const uint32_t ns = (uint32_t)(nb / L), nn = (uint32_t)(nnt / (L + 1));
+        if (ns) hipLaunchKernelGGL(k_sig_codes, G256(ns), codes, ns, L, d_sig);
+        if (nn) hipLaunchKernelGGL(k_sig_ascii, G256(nn), (const char *)d_nt, nn, (uint32_t)L + 1, L, d_sig);
+    }
+    unsigned int err = 0;
+    HIP_TRY(hipMemcpyAsync(sig3, d_sig, 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    harc_pool_release(c, mk0);
+    if (err) { harc_set_error("decode: %u reads with inconsistent pos/noise streams", err); return HARC_AMD_EIO; }
+    return HARC_AMD_OK;
+}

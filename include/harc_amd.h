@@ -154,6 +154,13 @@ int harc_amd_pack_order(harc_amd_ctx *ctx);   /* pack_order.cpp:20-77 on HARC_AM
 int harc_amd_get_stream(harc_amd_ctx *ctx, int32_t stream_id, int32_t shard, const void **ptr, size_t *len);
 int harc_amd_get_counters(harc_amd_ctx *ctx, harc_amd_counters *out);
 
+/* ---- round-trip check at any size (decode side, decoder.cpp:90-169, restated on the GPU).
+   Signature of a read multiset: sig[0] = number of reads, sig[1] = sum and sig[2] = xor of a 64-bit hash of every read
+   (FNV-1a over the bases A0 C1 G2 T3 N4, then a 64-bit finaliser).  Order-independent, so the decoded output of any
+   (num_chains, num_steps, num_thr) can be compared with the input reads without materialising either. */
+int harc_amd_decode_signature(harc_amd_ctx *ctx, uint64_t sig[3]);         /* decodes the context's stage-II streams */
+int harc_amd_reads_signature_device(harc_amd_ctx *ctx, const char *d_ascii, uint32_t n_reads, uint32_t stride, uint64_t sig[3]);
+
 /* ---- file contract: drop-ins for the reference's stage programs.  basedir as argv[1] of those programs. */
 int harc_amd_reorder_files(const harc_amd_params *params, const char *basedir);
 int harc_amd_encoder_files(const harc_amd_params *params, const char *basedir);

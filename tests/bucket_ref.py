@@ -39,3 +39,21 @@ def bucket_ref(packed, L, nb):
             h = _mix64(np.minimum(fw, rv))
             best = np.minimum(best, h)
     return (best % np.uint64(nb)).astype(np.int64)
+
+
+def reads_signature(lines):
+    """numpy restatement of the read-multiset signature of harc_amd/csrc/verify.hip: (count, sum, xor) of
+    mix64(FNV-1a over base codes A0 C1 G2 T3 N4).  lines: iterable of equal-length byte strings."""
+    arr = np.frombuffer(b"".join(lines), dtype=np.uint8).reshape(len(lines), -1) if len(lines) else np.zeros((0, 1), dtype=np.uint8)
+    code = np.full(256, 4, dtype=np.uint64)
+    for ch, v in zip(b"ACGT", range(4)):
+        code[ch] = v
+    h = np.full(arr.shape[0], np.uint64(1469598103934665603))
+    prime = np.uint64(1099511628211)
+    with np.errstate(over="ignore"):
+        for j in range(arr.shape[1] if len(lines) else 0):
+            h = (h ^ code[arr[:, j]]) * prime
+    h = _mix64(h)
+    s = int(h.sum(dtype=np.uint64)) if len(lines) else 0
+    x = int(np.bitwise_xor.reduce(h)) if len(lines) else 0
+    return (len(lines), s, x)

@@ -159,3 +159,35 @@ def test_bucket_kernel_matches_numpy_restatement():
         b = torch.empty((reads.shape[0],), dtype=torch.int32, device="cuda")
         h.bucket_reads_device(packed.data_ptr(), reads.shape[0], 8, b.data_ptr())
         assert (b.cpu().numpy() == bucket_ref(pack2(reads), 100, 8)).all()
+
+
+@pytest.mark.parametrize("case,K,S,E", [("L100_err_5k", 1, 16, 1), ("L100_err_5k", 16, 8, 4), ("L150_err_3k", 8, 16, 3), ("L63_err_3k", 5, 4, 2),
+                                          ("L255_err_1k", 3, 16, 2), ("L100_allN_20", 1, 1, 2), ("L100_repeat_dup_4k", 32, 16, 8)])
+def test_gpu_decoder_signature_matches_oracle_decoder_and_inputs(case, K, S, E, oracle, tmp_path):
+    """decode side on the GPU (verify.hip) == the oracle's restatement of decoder.cpp == the input reads, as multiset signatures"""
+    import torch
+    import harc_amd
+    from tests.bucket_ref import reads_signature
+    g = ol.load_golden(case)
+    L = _L(g)
+    clean, withN = g["stage1/input_clean.dna"], g["stage1/input_N.dna"]
+    p = harc_amd.default_params(L, num_thr=E, num_chains=K, num_steps=S)
+    with harc_amd.HarcAmd(p) as h:
+        h.set_reads_ascii(clean, len(clean) // (L + 1), L + 1)
+        h.set_nreads_ascii(withN, len(withN) // (L + 1), L + 1)
+        h.reorder(); h.encode()
+        sig = h.decode_signature()
+        allreads = torch.frombuffer(bytearray(g["reads.txt"]), dtype=torch.uint8).cuda()
+        sig_in = h.reads_signature_device(allreads.data_ptr(), len(g["reads.txt"]) // (L + 1), L + 1)
+        # write the streams and decode them with the oracle (CPU restatement of decoder.cpp)
+        base = ol.stage_dir(tmp_path, {})
+        names = {"S2_SEQ": "read_seq.txt.%d", "S2_SEQ_TAIL": "read_seq.txt.%d.tail", "S2_POS": "read_pos.txt.%d", "S2_NOISE": "read_noise.txt.%d",
+                 "S2_NOISEPOS": "read_noisepos.txt.%d", "S2_REV": "read_rev.txt.%d", "S2_REV_TAIL": "read_rev.txt.%d.tail"}
+        files = {fmt % e: h.stream(k, e) for k, fmt in names.items() for e in range(E)}
+        files.update({"read_singleton.txt": h.stream("S2_SINGLETON"), "read_singleton.txt.tail": h.stream("S2_SINGLETON_TAIL"),
+                      "input_N.dna": h.stream("S2_INPUT_N"), "read_meta.txt": h.stream("S2_META")})
+        ol.stage_dir(tmp_path, files)
+    assert oracle.harc_oracle_decoder(base.encode(), E) == 0
+    dec = ol.read_dir(base)["output.dna"].split()
+    assert sig == reads_signature(dec)                          # GPU decoder == oracle decoder
+    assert sig == sig_in == reads_signature(g["reads.txt"].split())   # == the input multiset
