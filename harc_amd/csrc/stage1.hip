@@ -321,6 +321,7 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
 //      slot -> bin scan from the highest unclaimed id (<= maxsearch of them) -> XOR+popcount Hamming on the packed words;
 //      the lowest lane with a hit is the step's read;
 //  (3) lane 0 records the step and bids for the read with atomicMin(step<<20 | chain); the counts are updated in registers.
+#define HARC_BIGBIN 4u      // bins with more reads than this are scanned by the whole wave
 #ifndef HARC_STEPS_WAVES
 #define HARC_STEPS_WAVES 4
 #endif
@@ -391,14 +392,15 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
             if (bend > s.nprobe) bend = s.nprobe;
             if (bend <= base) bend = s.nprobe;
             const int p = base + lane;
-            uint32_t mine = HARC_NONE; int j = 0, dir = 0;
+            uint32_t mine = HARC_NONE; int j = 0, dir = 0, l = 0;
+            bool big = false; uint32_t b_sst = 0, b_cnt = 0; uint64_t b_slot = 0;   // a bin too large for one lane: scanned by the whole wave below
             uint64_t mrd[W];
 #pragma unroll
             for (int w = 0; w < W; w++) mrd[w] = 0;
             if (p < bend) {
                 const uint32_t e = s.probe_tab[p];
                 j = (int)(e & 0xFF); dir = (int)((e >> 8) & 1);
-                const int l = (int)((e >> 9) & 1);
+                l = (int)((e >> 9) & 1);
                 const int off = dir ? 2 * (s.ds[l] - j) : 2 * (s.ds[l] + j);
                 uint64_t key;
                 {   // key = kbits bits of the (reverse) consensus at bit `off`
@@ -429,6 +431,9 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
                                 else if (((uint64_t)rawq[q].x | ((uint64_t)rawq[q].y << 32)) == key) { state = 2; qhit = q; sst = rawq[q].z; cw = rawq[q].w; }
                             }
                         }
+                        if (state == 2 && !(cw & SLOT_DEAD) && (cw & SLOT_CNT_MASK) > HARC_BIGBIN && !(cw & SLOT_EMB)) {
+                            big = true; b_sst = sst; b_cnt = cw & SLOT_CNT_MASK; b_slot = sl + qhit;
+                        } else
                         if (state == 2 && !(cw & SLOT_DEAD)) {                // SLOT_DEAD: every read of this bin is already claimed
                         const int nb = 2 * (L - j);
                         const int sws = (2 * j) >> 6, sbs = (2 * j) & 63;     // the consensus is shifted by 2j bits (reorder.cpp:647-648)
@@ -475,14 +480,82 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
                     }
                 }
             }
-            const unsigned long long m = __ballot(mine != HARC_NONE);
-            if (m) {
-                const int srcl = __ffsll((long long)m) - 1;
-                found = __shfl(mine, srcl, 64); fj = __shfl(j, srcl, 64); fdir = __shfl(dir, srcl, 64);
+            // ---- the best hit of the lanes that scanned their (small) bins themselves
+            int winlane = 64;
+            {
+                const unsigned long long msmall = __ballot(mine != HARC_NONE);
+                if (msmall) {
+                    winlane = __ffsll((long long)msmall) - 1;
+                    found = __shfl(mine, winlane, 64); fj = __shfl(j, winlane, 64); fdir = __shfl(dir, winlane, 64);
 #pragma unroll
-                for (int w = 0; w < W; w++) frd[w] = shfl_u64(mrd[w], srcl);
-                nuse += (uint32_t)(base + srcl + 1);
-                lastp = base + srcl;
+                    for (int w = 0; w < W; w++) frd[w] = shfl_u64(mrd[w], winlane);
+                }
+            }
+            // ---- big bins (low-complexity k-mers, repeats): the whole wave scans the bin, 64 candidates per round trip, in the same
+            //      order and with the same maxsearch window as the lane-serial scan.  Only lanes that outrank the best hit so far matter.
+            {
+                unsigned long long bigm = __ballot(big);
+                if (winlane < 64) bigm &= (1ULL << winlane) - 1ULL;
+                while (bigm) {
+                    const int bl = __ffsll((long long)bigm) - 1;
+                    bigm &= bigm - 1;
+                    const uint32_t o_sst = __shfl(b_sst, bl, 64), o_cnt = __shfl(b_cnt, bl, 64);
+                    const int o_j = __shfl(j, bl, 64), o_dir = __shfl(dir, bl, 64), o_l = __shfl(l, bl, 64);
+                    const uint64_t o_slot = shfl_u64(b_slot, bl);
+                    const uint32_t *oids = s.ids[o_l];
+                    uint64_t osh[W];
+                    if (o_dir) shl_words<W>(rref, 2 * o_j, osh); else shr_words<W>(ref, 2 * o_j, osh);
+                    int seen = 0; uint32_t pos = o_cnt, lead = 0; bool alltop = true, bighit = false;
+                    while (pos > 0 && seen < s.maxsearch) {
+                        const bool valid = (uint32_t)lane < pos;
+                        uint32_t rid = 0; bool clm = true;
+                        if (valid) {
+                            rid = oids[o_sst + pos - 1 - lane];
+                            const unsigned long long cwd = s.claimed[rid >> 6];
+#pragma unroll
+                            for (int w = 0; w < W; w++) mrd[w] = s.reads[(size_t)rid * W + w];     // mrd is free: the small winner is already in frd
+                            clm = ((cwd >> (rid & 63)) & 1ULL) != 0;
+                        }
+                        bool own = false;
+                        if (valid && !clm) for (int k = 0; k < t; k++) own |= (s_own[wv][k] == rid);
+                        const bool un = valid && !clm && !own;
+                        const unsigned long long um = __ballot(un);
+                        const int rank = __popcll(um & ((1ULL << lane) - 1ULL));
+                        const bool elig = un && (seen + rank < s.maxsearch);
+                        int hd = 1 << 20;
+                        if (elig) {
+                            hd = 0; nc++;
+#pragma unroll
+                            for (int w = 0; w < W; w++) {
+                                const uint64_t m = o_dir ? (lowmask_word(2 * L, w) & ~lowmask_word(2 * o_j, w)) : lowmask_word(2 * (L - o_j), w);
+                                hd += __popcll((osh[w] ^ mrd[w]) & m);
+                            }
+                        }
+                        const unsigned long long pm = __ballot(elig && hd <= s.thresh);
+                        if (alltop) {
+                            const unsigned long long cm = __ballot(valid && clm), vm = __ballot(valid);
+                            if (cm == vm) lead += (uint32_t)__popcll(vm); else { lead += (uint32_t)(__ffsll((long long)~cm) - 1); alltop = false; }
+                        }
+                        if (pm) {
+                            const int wl = __ffsll((long long)pm) - 1;
+                            found = __shfl(rid, wl, 64); fj = o_j; fdir = o_dir; winlane = bl; bighit = true;
+#pragma unroll
+                            for (int w = 0; w < W; w++) frd[w] = shfl_u64(mrd[w], wl);
+                            break;
+                        }
+                        seen += __popcll(um);
+                        pos -= pos > 64 ? 64 : pos;
+                    }
+                    if (lead && lane == 0) {
+                        uint32_t *cp = reinterpret_cast<uint32_t *>(&s.slots[o_l][o_slot]) + 3;
+                        if (lead == o_cnt) atomicOr(cp, SLOT_DEAD); else atomicMin(cp, o_cnt - lead);
+                    }
+                    if (bighit) break;
+                }
+            }
+            if (found != HARC_NONE) {
+                nuse += (uint32_t)(base + winlane + 1);
+                lastp = base + winlane;
                 break;
             }
             base = bend;

@@ -37,3 +37,27 @@ def reads_text(*a, **kw):
     out[:, :L] = r
     out[:, L] = 10
     return out.tobytes()
+
+
+def reads_text_lowcomplexity(seed, n, L, genome_len, n_repeat=60, n_polya=12, err=0.0):
+    """genome with `n_repeat` copies of one 300-bp element and `n_polya` poly-A runs of 150 bp: dictionary bins with
+    hundreds to thousands of reads (the maxsearch window and the wave-cooperative bin scan of k_steps)"""
+    rs = np.random.RandomState(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rs.randint(0, 4, size=genome_len)].copy()
+    rep = acgt[rs.randint(0, 4, size=300)]
+    for p in rs.randint(0, genome_len - 400, size=n_repeat):
+        genome[p:p + 300] = rep
+    for p in rs.randint(0, genome_len - 400, size=n_polya):
+        genome[p:p + 150] = ord("A")
+    starts = rs.randint(0, genome_len - L, size=n)
+    r = genome[starts[:, None] + np.arange(L)[None, :]].copy()
+    if err > 0:
+        e = rs.random_sample((n, L)) < err
+        r[e] = acgt[rs.randint(0, 4, size=int(e.sum()))]
+    odd = np.arange(n) % 2 == 1
+    r[odd] = _COMP[r[odd][:, ::-1]]
+    out = np.empty((n, L + 1), dtype=np.uint8)
+    out[:, :L] = r
+    out[:, L] = 10
+    return out.tobytes()

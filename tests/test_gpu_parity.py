@@ -191,3 +191,23 @@ def test_gpu_decoder_signature_matches_oracle_decoder_and_inputs(case, K, S, E, 
     dec = ol.read_dir(base)["output.dna"].split()
     assert sig == reads_signature(dec)                          # GPU decoder == oracle decoder
     assert sig == sig_in == reads_signature(g["reads.txt"].split())   # == the input multiset
+
+
+@pytest.mark.parametrize("n,glen,K,S,E,err", [(30000, 60000, 16, 16, 4, 0.0), (30000, 60000, 1, 64, 1, 0.002), (40000, 40000, 64, 8, 2, 0.0)])
+def test_low_complexity_big_bins_match_oracle(n, glen, K, S, E, err, oracle, tmp_path):
+    """repeats and poly-A runs: bins far above maxsearch, scanned by the whole wave in k_steps -- same bytes as the oracle's serial scan"""
+    import harc_amd
+    txt = gen.reads_text_lowcomplexity(4321, n, 100, glen, err=err)
+    (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, K, E, tmp_path / "o", S)
+    base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.reorder(base, 100, num_chains=K, num_steps=S)
+    assert_same(ol.read_dir(base), s1, ol.STAGE1_FILES, "low-complexity stage I vs oracle")
+    harc_amd.encoder(base, 100, num_thr=E)
+    got = ol.read_dir(base)
+    # stage II: identical unless a stage-II bin exceeds maxsearch (static vs sliding window, DESIGN.md section 2) -- then lossless only
+    fs = ol.stage2_files(E)
+    if all(got[f] == s2[f] for f in fs):
+        return
+    assert oracle.harc_oracle_decoder(base.encode(), E) == 0
+    assert sorted(ol.read_dir(base)["output.dna"].split()) == sorted(txt.split())
