@@ -224,6 +224,13 @@ def main():
                 "candidates_per_read": round(agg["cands"] / max(1, agg["steps_alg"]), 3),
                 "Gslots_per_s": round(agg["probes"] / (agg["propose_ms"] * 1e-3) / 1e9, 2) if agg["propose_ms"] > 0 else None,
                 "note": "random-access regime: 16-B slots and 32-B reads fetched as >=64-B sectors; see DESIGN.md"}
+    try:                                                          # HBM bytes per launch from the committed PMC passes of the same command
+        tr = json.load(open(os.path.join(ROOT, "profiles", "k_steps_traffic_r01.json"))).get(args.workload)
+        if tr and world == 1:
+            roofline["traffic"] = round((tr["fetch_kb_per_launch"] + tr["write_kb_per_launch"]) * 1024.0, 1)
+            roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this command, profiles/k_steps_traffic_r01.json"
+    except Exception:
+        pass
     out = {
         "metric": "Mreads/s reorder+encode, 100 bp", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
