@@ -170,7 +170,7 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
 }
 // one thread per bin: claim an empty slot by CAS on the (start,count) word; keys are unique so no key compare is needed
 __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, const uint32_t *nbins_p, uint32_t n,
-                               HashSlot *slots, uint64_t cap, int bucketed)
+                               HashSlot *slots, uint64_t cap, int bucketed, uint32_t bigthresh)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nbins = *nbins_p;
@@ -181,7 +181,7 @@ __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, cons
     // single-read bins (the common case) carry the read id in `start`: one dependent load less on every hit
     const uint32_t cnt = en - st;
     const unsigned long long meta = cnt == 1 ? ((unsigned long long)sids[st] | ((unsigned long long)(1u | SLOT_EMB) << 32))
-                                             : ((unsigned long long)st | ((unsigned long long)(cnt & SLOT_CNT_MASK) << 32));
+                                             : ((unsigned long long)st | ((unsigned long long)((cnt & SLOT_CNT_MASK) | ((bigthresh && cnt > bigthresh) ? SLOT_BIG : 0u)) << 32));
     uint64_t sl = bucketed ? (__umul64hi(mix64(key), cap >> 2) << 2) : __umul64hi(mix64(key), cap);   // bucketed: start at a 64-B bucket of 4 slots
     for (;;) {
         unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
@@ -773,7 +773,7 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     RC_TRY(prim_excl_scan_u32(c, h0, b0, n));
     hipLaunchKernelGGL(k_bin_starts, dim3(g), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins);
     HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
-    hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, d->ids, bs, d->d_nbins, n, d->slots, d->cap, d->bucketed ? 1 : 0);
+    hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, d->ids, bs, d->d_nbins, n, d->slots, d->cap, d->bucketed ? 1 : 0, d->bigthresh);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));                                    // temporaries are reused after this point
     harc_pool_release(c, mk);

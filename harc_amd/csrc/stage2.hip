@@ -32,6 +32,8 @@ struct S2Args {
     const uint32_t *chead;             // nC: read index of each contig head
     const HashSlot *slots[2]; uint64_t cap[2]; const uint32_t *ids[2];
     unsigned long long *best;          // T
+    uint4 *events;                     // probes that hit a bin larger than maxsearch: {tuple lo, tuple hi, dict, slot index lo} (+ slot hi in w>>?)
+    unsigned int *nevents; uint32_t maxevents;
 };
 
 // ---------------------------------------------------------------------------------------------- small device helpers
@@ -234,9 +236,15 @@ __global__ __launch_bounds__(256) void k_realign_propose(S2Args s)
                     const uint64_t key = dir ? (l ? kr1 : kr0) : (l ? kf1 : kf0);
                     uint32_t st = 0, cnt = 0, np = 0;
                     if (!dict_lookup(s.slots[l], s.cap[l], key, &st, &cnt, &np)) continue;
+                    if (cnt & SLOT_BIG) {                                     // > maxsearch reads: the visible window slides as reads get claimed
+                        const unsigned int at = atomicAdd(s.nevents, 1u);     // (encoder.cpp:293) -> exact sequential pass k_realign_big
+                        const unsigned long long tp = (x << 2) | ((uint64_t)dir << 1) | (uint64_t)l;
+                        if (at < s.maxevents) s.events[at] = make_uint4((uint32_t)tp, (uint32_t)(tp >> 32), st, cnt & SLOT_CNT_MASK);
+                        continue;
+                    }
                     const bool emb = (cnt & SLOT_EMB) != 0;
                     cnt &= SLOT_CNT_MASK;
-                    const uint32_t lim = cnt > (uint32_t)s.maxsearch ? (uint32_t)s.maxsearch : cnt;   // static window: top maxsearch ids of the bin
+                    const uint32_t lim = cnt;                                 // <= maxsearch: the whole bin is always visible
                     for (uint32_t t = 0; t < lim; t++) {
                         const uint32_t rid = emb ? st : s.ids[l][st + cnt - 1 - t];
                         const uint64_t *r = s.cand3 + (size_t)rid * W3;
@@ -266,6 +274,61 @@ __global__ __launch_bounds__(256) void k_realign_propose(S2Args s)
     }
 }
 
+// Bins larger than maxsearch, exact: the reference scans, at every probe, the maxsearch highest ids of the bin that are STILL
+// unclaimed at that moment (encoder.cpp:293 after the removals of :321-336).  The probes that hit such a bin were recorded by
+// k_realign_propose; here ONE wave replays them in tuple order (= the order of the sequential reference), 64 candidates per
+// round trip, against best[] = "claimed at tuple" (a read is unclaimed at tuple t iff best[rid] > t).
+__global__ __launch_bounds__(64) void k_realign_big(S2Args s, const unsigned long long *etuple, const uint32_t *eidx, uint32_t nev)
+{
+    __shared__ unsigned long long swin[2][HARC_MAXW3];
+    const int lane = threadIdx.x;
+    const int L = s.L, W3 = s.W3;
+    for (uint32_t e = 0; e < nev; e++) {
+        const unsigned long long tp = etuple[e];
+        const uint4 ev = s.events[eidx[e]];
+        const uint64_t x = tp >> 2; const int dir = (int)((tp >> 1) & 1), l = (int)(tp & 1);
+        const uint32_t st = ev.z, cnt = ev.w;
+        // 3-bit window words (forward or reverse complement), lanes 0..W3-1 build one word each
+        if (lane < W3) {
+            const uint8_t *win = s.cons + x;
+            unsigned long long v = 0;
+            const int b0 = (64 * lane) / 3, b1 = (64 * lane + 63) / 3;
+            for (int b = b0; b <= b1 && b < L; b++) {
+                const int idx = dir ? 3 - (int)(win[L - 1 - b] & 3) : (int)(win[b] & 3);
+                const unsigned long long c3 = (unsigned long long)idx_to_c3(idx);
+                const int sh = 3 * b - 64 * lane;
+                v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
+            }
+            swin[e & 1][lane] = v;
+        }
+        __syncthreads();
+        int seen = 0; uint32_t pos = cnt;
+        while (pos > 0 && seen < s.maxsearch) {
+            const bool valid = (uint32_t)lane < pos;
+            uint32_t rid = 0; bool un = false;
+            if (valid) { rid = s.ids[l][st + pos - 1 - lane]; un = __hip_atomic_load(&s.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tp; }
+            const unsigned long long um = __ballot(un);
+            const int rank = __popcll(um & ((1ULL << lane) - 1ULL));
+            if (un && seen + rank < s.maxsearch) {
+                const uint64_t *r = s.cand3 + (size_t)rid * W3;
+                int hd = 0;
+                for (int w = 0; w < W3; w++) { hd += __popcll(swin[e & 1][w] ^ r[w]); if (hd > s.thresh_s) break; }
+                if (hd <= s.thresh_s) __hip_atomic_store(&s.best[rid], tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every passing candidate of the window is taken (encoder.cpp:296-317)
+            }
+            seen += __popcll(um);
+            pos -= pos > 64 ? 64 : pos;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__global__ void k_event_keys(const uint4 *ev, uint32_t n, unsigned long long *key, uint32_t *idx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = (unsigned long long)ev[i].x | ((unsigned long long)ev[i].y << 32); idx[i] = i;
+}
 __global__ void k_acc_flags(const unsigned long long *best, uint32_t T, uint32_t *flag)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -447,6 +510,9 @@ int stage2_run(harc_amd_ctx *c)
     if (T) hipLaunchKernelGGL(k_cand_order, G256(T), c->d_order_s, S, T, cand_order);
     HIP_TRY(hipMemsetAsync(best, 0xFF, ((size_t)T + 1) * 8, c->stream));
     a.cand3 = cand3; a.cand_order = cand_order; a.best = best;
+    a.maxevents = 1u << 22;                                       // 64 MB of events; more than that fails loudly
+    RC_TRY(dalloc(c, &a.events, (size_t)a.maxevents)); RC_TRY(dalloc(c, &a.nevents, 4));
+    HIP_TRY(hipMemsetAsync(a.nevents, 0, 16, c->stream));
 
     // ---- dictionaries over the candidates (encoder.cpp:886-992)
     DictDev dict[2];
@@ -454,6 +520,7 @@ int stage2_run(harc_amd_ctx *c)
     HIP_TRY(hipMemsetAsync(d_big, 0, 8, c->stream));
     if (T) {
         RC_TRY(harc_dict_alloc(c, &dict[0], T)); RC_TRY(harc_dict_alloc(c, &dict[1], T));
+        dict[0].bigthresh = dict[1].bigthresh = (uint32_t)P.maxsearch;
         const harc_mark_t mk = harc_pool_mark(c);
         uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
         RC_TRY(dalloc(c, &k0, T)); RC_TRY(dalloc(c, &i0, T));
@@ -498,7 +565,20 @@ int stage2_run(harc_amd_ctx *c)
         unsigned long long *cinfo = nullptr; RC_TRY(dalloc(c, &cinfo, (size_t)nC + 1));
         hipLaunchKernelGGL(k_contig_info, G256(nC), a, cinfo);
         hipLaunchKernelGGL(k_consensus, G256((total + CSTRIP - 1) / CSTRIP), a, (const uint32_t *)u1, (const unsigned long long *)cinfo, T ? 1 : 0);
-        if (T) hipLaunchKernelGGL(k_realign_propose, dim3((unsigned)((total + RTILE - 1) / RTILE)), dim3(256), 0, c->stream, a);
+        if (T) {
+            hipLaunchKernelGGL(k_realign_propose, dim3((unsigned)((total + RTILE - 1) / RTILE)), dim3(256), 0, c->stream, a);
+            unsigned int nev = 0;
+            HIP_TRY(hipMemcpyAsync(&nev, a.nevents, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (nev > a.maxevents) { harc_set_error("stage II: %u probes hit bins larger than maxsearch (event buffer %u)", nev, a.maxevents); return HARC_AMD_ENOMEM; }
+            if (nev) {                                                        // exact sliding-window replay in tuple order
+                unsigned long long *tk0 = nullptr, *tk1 = nullptr; uint32_t *ti0 = nullptr, *ti1 = nullptr;
+                RC_TRY(dalloc(c, &tk0, nev)); RC_TRY(dalloc(c, &tk1, nev)); RC_TRY(dalloc(c, &ti0, nev)); RC_TRY(dalloc(c, &ti1, nev));
+                hipLaunchKernelGGL(k_event_keys, G256(nev), a.events, nev, tk0, ti0);
+                RC_TRY(prim_sort_pairs_u64_u32(c, (const uint64_t *)tk0, (uint64_t *)tk1, ti0, ti1, nev, 64));
+                hipLaunchKernelGGL(k_realign_big, dim3(1), dim3(64), 0, c->stream, a, (const unsigned long long *)tk1, (const uint32_t *)ti1, nev);
+            }
+        }
     }
     HIP_TRY(hipGetLastError());
 

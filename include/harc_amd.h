@@ -75,7 +75,8 @@ typedef struct harc_amd_counters {
     double propose_ms;                /* sum of their HIP-event durations (params.profile=1), else 0 */
     double index_ms, chain_ms, encode_ms, total_ms;   /* host wall-clock of the phases, stream-synchronised */
     uint64_t contigs, seq_bases;      /* stage II */
-    uint64_t bins_over_maxsearch;     /* stage-II dictionary bins larger than maxsearch (static window) */
+    uint64_t bins_over_maxsearch;     /* stage-II dictionary bins larger than maxsearch: their probes are replayed sequentially
+                                         (sliding window of encoder.cpp:293, exact) */
     uint64_t device_bytes_peak;
     uint64_t useful_probes;           /* dictionary keys a strictly sequential scan (reorder.cpp:517-649) would have looked up:
                                          priority index of the winning probe + 1, or all probes of the step on a miss */

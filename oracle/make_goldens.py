@@ -70,6 +70,8 @@ CASES = {
     "L100_one": dict(seed=10, n=1, L=100, genome_len=1000),
     "L100_allN_20": dict(seed=11, n=20, L=100, genome_len=1000, err=0.2, n_frac=1.0),
     "L100_three": dict(seed=12, n=3, L=100, genome_len=120),
+    # stage-II dictionary bins above maxsearch (2500 N reads sharing their first 50 bases): the sliding window of encoder.cpp:293
+    "L100_bigbin2_5k": dict(custom="bigbin_stage2", seed=77, L=100),
 }
 
 
@@ -94,7 +96,12 @@ def make_case(name, kw):
     L = kw["L"]
     subprocess.check_call([os.path.join(HERE, "build_ref.sh")])
     subprocess.check_call([os.path.join(HERE, "build_ref.sh"), str(L), "1"])
-    reads = gen_reads(**kw)
+    if kw.get("custom") == "bigbin_stage2":
+        sys.path.insert(0, os.path.dirname(HERE))
+        from tests import gen as tgen
+        reads = tgen.reads_text_bigbin_stage2(kw["seed"]).decode().split()
+    else:
+        reads = gen_reads(**kw)
     wd = tempfile.mkdtemp(prefix="harc_gold_")
     try:
         os.makedirs(os.path.join(wd, "output"))

@@ -61,3 +61,24 @@ def reads_text_lowcomplexity(seed, n, L, genome_len, n_repeat=60, n_polya=12, er
     out[:, :L] = r
     out[:, L] = 10
     return out.tobytes()
+
+
+def reads_text_bigbin_stage2(seed, n_clean=3000, n_dupN=2500, L=100, genome_len=5000):
+    """stage-II bins above maxsearch: n_dupN reads with N that all share their first 50 bases (copies of one genome window
+    with an N and a substitution in the second half), next to n_clean ordinary reads that build the contig they realign to"""
+    rs = np.random.RandomState(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rs.randint(0, 4, size=genome_len)]
+    starts = rs.randint(0, genome_len - L, size=n_clean)
+    clean = genome[starts[:, None] + np.arange(L)[None, :]].copy()
+    p = genome_len // 2
+    dup = np.tile(genome[p:p + L], (n_dupN, 1)).copy()
+    dup[np.arange(n_dupN), rs.randint(50, L, size=n_dupN)] = ord("N")
+    sub = rs.randint(50, L, size=n_dupN)
+    dup[np.arange(n_dupN), sub] = np.where(dup[np.arange(n_dupN), sub] == ord("N"), ord("N"), acgt[rs.randint(0, 4, size=n_dupN)])
+    allr = np.concatenate([clean, dup])
+    rs.shuffle(allr)
+    out = np.empty((allr.shape[0], L + 1), dtype=np.uint8)
+    out[:, :L] = allr
+    out[:, L] = 10
+    return out.tobytes()
