@@ -76,6 +76,7 @@ def lib():
     for f in ("harc_amd_reorder_files", "harc_amd_encoder_files", "harc_amd_compress_files", "harc_amd_pack_order_files"):
         getattr(l, f).argtypes = [PP, C.c_char_p]
     l.harc_amd_preprocess_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
+    l.harc_amd_decoder_files.argtypes = [PP, C.c_char_p, C.c_int32]
     l.harc_amd_decode_signature.argtypes = [ctx, C.POINTER(C.c_uint64)]
     l.harc_amd_reads_signature_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     _lib = l
@@ -116,6 +117,12 @@ def compress(basedir, readlen, num_thr=1, num_chains=1, **kw):
 def preprocess(fastq, basedir, readlen):
     """== `preprocess.out <fastq> <basedir> False False <readlen>` (src/preprocess.cpp:22-137): the N split"""
     _check(lib().harc_amd_preprocess_files(os.fsencode(fastq), os.fsencode(basedir), readlen))
+
+
+def decoder(basedir, num_thr_e, device=0):
+    """== `decoder.out <basedir> <num_thr> <num_thr_e>` (src/decoder.cpp:44-172): output/output.dna"""
+    p = default_params(100, device=device)
+    _check(lib().harc_amd_decoder_files(C.byref(p), os.fsencode(basedir), num_thr_e))
 
 
 def pack_order(basedir, readlen=100, **kw):

@@ -6,6 +6,8 @@
 // (:109-129).  Instead of writing 100 B per read back to the host, every decoded read is hashed and the hashes are summed and
 // xored: an order-independent signature of the decoded multiset that is compared with the same signature of the input reads.
 #include "devutil.h"
+#include <string>
+#include <stdlib.h>
 
 __device__ __forceinline__ uint64_t read_hash_step(uint64_t h, int code) { return (h ^ (uint64_t)code) * 1099511628211ULL; }   // FNV-1a over codes A0 C1 G2 T3 N4
 #define READ_HASH_INIT 1469598103934665603ULL
@@ -182,5 +184,157 @@ extern "C" int harc_amd_decode_signature(harc_amd_ctx *c, uint64_t *sig3)
     HIP_TRY(hipStreamSynchronize(c->stream));
     harc_pool_release(c, mk0);
     if (err) { harc_set_error("decode: %u reads with inconsistent pos/noise streams", err); return HARC_AMD_EIO; }
+    return HARC_AMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder.out drop-in (non -p)
+// Same decode as k_decode_sig, but the read is written as a text line into tmp[i] and flagged when it contains N
+// (decoder.cpp:110-129 routes those to a separate file that is appended after the singletons, :141-169).
+__global__ void k_decode_text(const uint8_t *seqb, uint64_t seqlen, const uint64_t *possum, const uint8_t *noise, const uint8_t *noisepos,
+                              const uint64_t *nlpos, const uint8_t *revb, uint64_t nrevb, const uint8_t *revtail, uint32_t n, int L,
+                              char *tmp, uint32_t *isN, unsigned int *err)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t start = possum[i] - (uint64_t)L;
+    char *o = tmp + (size_t)i * (L + 1);
+    if (possum[i] < (uint64_t)L || start + L > seqlen) { atomicAdd(err, 1u); isN[i] = 0; for (int j = 0; j < L; j++) o[j] = 'A'; o[L] = '\n'; return; }
+    uint8_t buf[256];
+    for (int j = 0; j < L; j++) buf[j] = seqb[start + j];
+    const uint64_t n0 = i ? nlpos[i - 1] + 1 : 0, n1 = nlpos[i];
+    uint64_t np = n0 - i;
+    int p = 0; bool hasN = false;
+    for (uint64_t k = n0; k < n1; k++) {
+        p += noisepos[np++];
+        const int ref = buf[p < L ? p : 0] & 3, code = noise[k] - '0';
+        const unsigned tab = ref == 0 ? 0x4321u : ref == 1 ? 0x4320u : ref == 2 ? 0x4103u : 0x4012u;
+        if (p < L) { buf[p] = (uint8_t)((tab >> (4 * code)) & 0xF); hasN |= buf[p] == 4; } else atomicAdd(err, 1u);
+    }
+    const bool rev = i < 8 * nrevb ? ((revb[i >> 3] >> (i & 7)) & 1) : (revtail[i - 8 * nrevb] == 'r');
+    if (!rev) for (int j = 0; j < L; j++) o[j] = "ACGTN"[buf[j]];
+    else for (int j = 0; j < L; j++) { const int b = buf[L - 1 - j]; o[j] = "ACGTN"[b == 4 ? 4 : 3 - b]; }
+    o[L] = '\n';
+    isN[i] = hasN ? 1u : 0u;
+}
+// stable split of the lines: reads without N to outA[rankA], reads with N to outN[i - rankA]
+__global__ void k_split_lines(const char *tmp, const uint32_t *isN, const uint32_t *rankN, uint32_t n, int L, char *outA, char *outN)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t LL = (uint64_t)L + 1;
+    if (gid >= (uint64_t)n * LL) return;
+    const uint32_t i = (uint32_t)(gid / LL); const uint32_t j = (uint32_t)(gid % LL);
+    const char ch = tmp[gid];
+    if (isN[i]) outN[(uint64_t)rankN[i] * LL + j] = ch; else outA[(uint64_t)(i - rankN[i]) * LL + j] = ch;
+}
+__global__ void k_codes_to_lines(const uint8_t *codes, uint32_t n, int L, char *out)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t LL = (uint64_t)L + 1;
+    if (gid >= (uint64_t)n * LL) return;
+    const uint32_t i = (uint32_t)(gid / LL); const uint32_t j = (uint32_t)(gid % LL);
+    out[gid] = j == (uint32_t)L ? '\n' : "ACGT"[codes[(uint64_t)i * L + j] & 3];
+}
+
+static bool slurp_file(const std::string &path, std::vector<uint8_t> &out)
+{
+    out.clear();
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    out.resize((size_t)n);
+    const bool ok = n == 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+// decoder.out <basedir> <num_thr> <num_thr_e>  (src/decoder.cpp:44-172, harc:188): writes output/output.dna
+extern "C" int harc_amd_decoder_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e)
+{
+    if (!params || !basedir || num_thr_e < 1) return HARC_AMD_EINVAL;
+    const std::string od = std::string(basedir) + "/output/";
+    std::vector<uint8_t> meta;
+    if (!slurp_file(od + "read_meta.txt", meta)) { harc_set_error("cannot read %sread_meta.txt", od.c_str()); return HARC_AMD_EIO; }
+    meta.push_back(0);
+    const int L = atoi((const char *)meta.data());                              // getDataParams, decoder.cpp:324-333
+    harc_amd_params P = *params;
+    if (harc_amd_default_params(L, &P) != HARC_AMD_OK) return HARC_AMD_EINVAL;
+    P.device = params->device; P.num_thr = num_thr_e;
+    harc_amd_ctx *c = nullptr;
+    RC_TRY(harc_amd_create(&P, &c));
+    struct Guard { harc_amd_ctx *c; ~Guard() { harc_amd_destroy(c); } } guard{ c };
+    FILE *fo = fopen((od + "output.dna").c_str(), "wb");
+    if (!fo) { harc_set_error("cannot create %soutput.dna", od.c_str()); return HARC_AMD_EIO; }
+    struct FG { FILE *f; ~FG() { if (f) fclose(f); } } fg{ fo };
+    std::vector<std::vector<uint8_t>> nparts((size_t)num_thr_e);
+    unsigned int *d_err = nullptr; RC_TRY(dalloc(c, &d_err, 4));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 16, c->stream));
+    for (int e = 0; e < num_thr_e; e++) {
+        const std::string sfx = "." + std::to_string(e);
+        std::vector<uint8_t> seq, seqt, pos, noise, npz, rev, revt;
+        if (!slurp_file(od + "read_seq.txt" + sfx, seq) || !slurp_file(od + "read_seq.txt" + sfx + ".tail", seqt) || !slurp_file(od + "read_pos.txt" + sfx, pos) ||
+            !slurp_file(od + "read_noise.txt" + sfx, noise) || !slurp_file(od + "read_noisepos.txt" + sfx, npz) ||
+            !slurp_file(od + "read_rev.txt" + sfx, rev) || !slurp_file(od + "read_rev.txt" + sfx + ".tail", revt)) { harc_set_error("shard %d: stream files missing", e); return HARC_AMD_EIO; }
+        if (pos.empty()) continue;
+        if (pos.size() > 0xFFFFFFFFull || 8 * rev.size() + revt.size() != pos.size()) { harc_set_error("shard %d: rev stream does not match pos stream", e); return HARC_AMD_EIO; }
+        const harc_mark_t mk = harc_pool_mark(c);
+        const uint32_t n = (uint32_t)pos.size();
+        uint8_t *d_seq, *d_seqt, *d_pos, *d_noise, *d_np, *d_rev, *d_revt, *seqb; uint64_t *p64, *possum, *nlpos; uint32_t *fl, *rk, *isN, *rkN; char *tmp, *outA, *outN;
+        RC_TRY(up(c, seq.data(), seq.size(), &d_seq)); RC_TRY(up(c, seqt.data(), seqt.size(), &d_seqt)); RC_TRY(up(c, pos.data(), pos.size(), &d_pos));
+        RC_TRY(up(c, noise.data(), noise.size(), &d_noise)); RC_TRY(up(c, npz.data(), npz.size(), &d_np)); RC_TRY(up(c, rev.data(), rev.size(), &d_rev)); RC_TRY(up(c, revt.data(), revt.size(), &d_revt));
+        const uint64_t seqlen = 4 * (uint64_t)seq.size() + seqt.size();
+        const size_t nnoise = noise.size(), LL = (size_t)L + 1;
+        RC_TRY(dalloc(c, &seqb, (size_t)seqlen + 16)); RC_TRY(dalloc(c, &p64, (size_t)n + 1)); RC_TRY(dalloc(c, &possum, (size_t)n + 1)); RC_TRY(dalloc(c, &nlpos, (size_t)n + 1));
+        RC_TRY(dalloc(c, &fl, nnoise + 1)); RC_TRY(dalloc(c, &rk, nnoise + 1)); RC_TRY(dalloc(c, &isN, (size_t)n + 1)); RC_TRY(dalloc(c, &rkN, (size_t)n + 1));
+        RC_TRY(dalloc(c, &tmp, (size_t)n * LL + 16)); RC_TRY(dalloc(c, &outA, (size_t)n * LL + 16)); RC_TRY(dalloc(c, &outN, (size_t)n * LL + 16));
+        if (seqlen) hipLaunchKernelGGL(k_unpack_seq, G256(seqlen), d_seq, (uint64_t)seq.size(), d_seqt, (uint64_t)seqt.size(), seqb);
+        hipLaunchKernelGGL(k_pos_to_u64, G256(n), d_pos, n, p64);
+        RC_TRY(prim_incl_scan_u64(c, p64, possum, n));
+        if (nnoise) {
+            hipLaunchKernelGGL(k_nl_flags, G256(nnoise), d_noise, (uint64_t)nnoise, fl);
+            RC_TRY(prim_excl_scan_u32(c, fl, rk, nnoise));
+            hipLaunchKernelGGL(k_nl_positions, G256(nnoise), d_noise, rk, (uint64_t)nnoise, nlpos);
+        }
+        HIP_TRY(hipMemsetAsync(isN, 0, ((size_t)n + 1) * 4, c->stream));
+        hipLaunchKernelGGL(k_decode_text, G256(n), seqb, seqlen, possum, d_noise, d_np, nlpos, d_rev, (uint64_t)rev.size(), d_revt, n, L, tmp, isN, d_err);
+        RC_TRY(prim_excl_scan_u32(c, isN, rkN, (size_t)n + 1));
+        hipLaunchKernelGGL(k_split_lines, G256((uint64_t)n * LL), tmp, isN, rkN, n, L, outA, outN);
+        uint32_t nN = 0;
+        HIP_TRY(hipMemcpyAsync(&nN, rkN + n, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<uint8_t> hA((size_t)(n - nN) * LL);
+        nparts[(size_t)e].resize((size_t)nN * LL);
+        if (!hA.empty()) HIP_TRY(hipMemcpyAsync(hA.data(), outA, hA.size(), hipMemcpyDeviceToHost, c->stream));
+        if (nN) HIP_TRY(hipMemcpyAsync(nparts[(size_t)e].data(), outN, nparts[(size_t)e].size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (!hA.empty() && fwrite(hA.data(), 1, hA.size(), fo) != hA.size()) { harc_set_error("short write on output.dna"); return HARC_AMD_EIO; }
+        harc_pool_release(c, mk);
+    }
+    {   // singletons (decoder.cpp:148-158), then the N reads of every shard (:159-165), then input_N.dna (:166-168)
+        std::vector<uint8_t> sg, sgt, nt;
+        if (!slurp_file(od + "read_singleton.txt", sg) || !slurp_file(od + "read_singleton.txt.tail", sgt)) { harc_set_error("singleton files missing"); return HARC_AMD_EIO; }
+        slurp_file(od + "input_N.dna", nt);
+        const uint64_t nb = 4 * (uint64_t)sg.size() + sgt.size();
+        const uint32_t ns = (uint32_t)(nb / L);
+        if (ns) {
+            const harc_mark_t mk = harc_pool_mark(c);
+            uint8_t *d_sg, *d_sgt, *codes; char *lines;
+            RC_TRY(up(c, sg.data(), sg.size(), &d_sg)); RC_TRY(up(c, sgt.data(), sgt.size(), &d_sgt)); RC_TRY(dalloc(c, &codes, (size_t)nb + 16));
+            RC_TRY(dalloc(c, &lines, (size_t)ns * (L + 1) + 16));
+            hipLaunchKernelGGL(k_unpack_seq, G256(nb), d_sg, (uint64_t)sg.size(), d_sgt, (uint64_t)sgt.size(), codes);
+            hipLaunchKernelGGL(k_codes_to_lines, G256((uint64_t)ns * (L + 1)), codes, ns, L, lines);
+            std::vector<uint8_t> hs((size_t)ns * (L + 1));
+            HIP_TRY(hipMemcpyAsync(hs.data(), lines, hs.size(), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (fwrite(hs.data(), 1, hs.size(), fo) != hs.size()) { harc_set_error("short write on output.dna"); return HARC_AMD_EIO; }
+            harc_pool_release(c, mk);
+        }
+        for (auto &p : nparts) if (!p.empty() && fwrite(p.data(), 1, p.size(), fo) != p.size()) { harc_set_error("short write on output.dna"); return HARC_AMD_EIO; }
+        if (!nt.empty() && fwrite(nt.data(), 1, nt.size(), fo) != nt.size()) { harc_set_error("short write on output.dna"); return HARC_AMD_EIO; }
+    }
+    unsigned int err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err) { harc_set_error("decoder: %u reads with inconsistent pos/noise streams", err); return HARC_AMD_EIO; }
+    printf("Decoding done\n");                                                 // decoder.cpp:170
     return HARC_AMD_OK;
 }

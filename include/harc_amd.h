@@ -170,6 +170,9 @@ int harc_amd_pack_order_files(const harc_amd_params *params, const char *basedir
 /* == `preprocess.out <fastq> <basedir> <preserve_order> <preserve_quality> <readlen>` (src/preprocess.cpp:22-137, harc:50),
    the N split only; host code, feeds the boundary */
 int harc_amd_preprocess_files(const char *fastq, const char *basedir, int32_t readlen);
+/* == `decoder.out <basedir> <num_thr> <num_thr_e>` (src/decoder.cpp:44-172, harc:188; non -p): reads the stage-II stream files of
+   num_thr_e shards under <basedir>/output and writes output/output.dna, byte-identical to the reference decoder */
+int harc_amd_decoder_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e);
 
 #ifdef __cplusplus
 }

@@ -227,3 +227,28 @@ def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, oracle, tmp_p
     assert_same(ol.read_dir(base), s2, fs, "stage II with bins above maxsearch vs oracle")
     # the case really exercises the window: more than maxsearch N reads get aligned
     assert len(s2["read_order_N_pe.bin"]) // 4 == 2500 and len(s2["input_N.dna"]) < 1500 * 101
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_decoder_matches_reference_decoder(case, tmp_path):
+    """harc_amd_decoder_files == decoder.out: output.dna byte-identical to the REAL reference decoder's on the reference's streams"""
+    import harc_amd
+    g = ol.load_golden(case)
+    base = ol.stage_dir(tmp_path, {k[len("stage2/"):]: v for k, v in g.items() if k.startswith("stage2/")})
+    harc_amd.decoder(base, 1)
+    assert ol.read_dir(base)["output.dna"] == g["decoded.txt"]
+
+
+@pytest.mark.parametrize("case,K,S,E", [("L100_err_5k", 16, 8, 4), ("L150_err_3k", 8, 16, 3), ("L100_bigbin2_5k", 4, 16, 8), ("L100_allN_20", 2, 4, 2)])
+def test_decoder_matches_oracle_decoder_E_shards(case, K, S, E, oracle, tmp_path):
+    import harc_amd
+    g = ol.load_golden(case)
+    L = _L(g)
+    base = ol.stage_dir(tmp_path, {k: g["stage1/" + k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.compress(base, L, num_thr=E, num_chains=K, num_steps=S)
+    harc_amd.decoder(base, E)
+    mine = ol.read_dir(base)["output.dna"]
+    os.remove(os.path.join(base, "output", "output.dna"))
+    assert oracle.harc_oracle_decoder(base.encode(), E) == 0
+    assert mine == ol.read_dir(base)["output.dna"]
+    assert sorted(mine.split()) == sorted(g["reads.txt"].split())
