@@ -14,6 +14,7 @@
 #define HARC_MAXW 8      // ceil(2*255/64) words of a 2-bit read
 #define HARC_MAXW3 12    // ceil(3*255/64) words of a 3-bit read
 #define HARC_MAXK (1u << 20)
+#define HARC_NSUGG 4      // look-ahead seeds handed to a chain at every reseed (oracle: NSUGG)
 
 void harc_set_error(const char *fmt, ...);
 
@@ -40,8 +41,8 @@ struct ChainHdr {
                         // `nsteps>>8` kept steps (after a lost bid), 2 = reset from reads[cur] (fresh seed)
     uint32_t n_main;    // records emitted to the main stream so far
     uint32_t n_sing;    // records emitted to the singleton stream so far
-    uint32_t nsteps;    // low byte: steps walked in the last k_steps launch; next byte: steps to replay
-    uint32_t pad0;
+    uint32_t nsteps;    // byte0: steps walked in the last k_steps launch; byte1: steps to replay; byte2: look-ahead seeds consumed; byte3: look-ahead seeds held
+    uint32_t pad0;      // low 16 bits: priority index of the chain's previous hit; bits 16-23: look-ahead position reached by the last walk
 };
 #define CH_ACTIVE 1u
 #define CH_PREVUNM 2u

@@ -26,8 +26,10 @@ struct S1Args {
     uint4 *cnt;                      // [2][K][Lp] column counts (A,C,G,T) -- reorder.cpp:467 `count`
     uint2 *steps;                    // [K][64] steps of the current super-round: {rid, shift | dir<<8}
     uint8_t *need;                   // per chain: wants a new seed (set by k_resolve, consumed by k_reseed)
-    uint32_t *seedbuf;               // [K] seeds found by k_reseed, by rank
+    uint32_t *seedbuf;               // [K * (1 + HARC_NSUGG)] seeds, then look-ahead seeds, found by k_reseed, by rank
+    uint32_t *sugg;                  // [K][HARC_NSUGG] look-ahead seeds of every chain, highest id first
     int S;                           // speculative steps per super-round (1..64)
+    int nsugg_per_seed;              // look-ahead seeds per reseed (HARC_NSUGG; 0 disables them: experiments only, the oracle uses the same value)
     LogRec *log;
     unsigned long long *logcount;
     long long *cursor;               // reorder.cpp `remainingpos`, one for all chains
@@ -363,7 +365,8 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
 #pragma unroll
                 for (int w = 0; w < W; w++) rw[w] = shfl_u64(mrw[w], t);
                 const uint32_t y = __shfl(sp.y, t, 64);
-                cons_update<W>(st, rw, L, (int)((y >> 8) & 1), (int)(y & 0xFF), lane);
+                if ((y >> 16) & 1) cons_reset<W>(st, rw, L, lane);          // the step took a look-ahead seed
+                else cons_update<W>(st, rw, L, (int)((y >> 8) & 1), (int)(y & 0xFF), lane);
             }
         }
     }
@@ -371,7 +374,8 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
 
     uint32_t np = 0, nc = 0, nuse = 0;
     int nst = 0; bool needseed = false;
-    int lastp = (int)h.pad0;                                     // priority index of this chain's previous hit
+    int lastp = (int)(h.pad0 & 0xFFFF);                          // priority index of this chain's previous hit
+    int spos = (int)((h.nsteps >> 16) & 0xFF); const int nsugg = (int)(h.nsteps >> 24);   // look-ahead seeds: next to try / held
     for (int t = 0; t < s.S; t++) {
         uint64_t ref[W], rref[W];
         cons_pack<W>(st, L, lane, ref);
@@ -560,7 +564,37 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
             }
             base = bend;
         }
-        if (found == HARC_NONE) { nuse += (uint32_t)s.nprobe; needseed = true; break; }
+        if (found == HARC_NONE) {
+            // no candidate: go on from the chain's look-ahead seeds (highest id first, skipping what was claimed meanwhile) -- the new
+            // seed of reorder.cpp:652-668 without waiting for the next k_reseed
+            nuse += (uint32_t)s.nprobe;
+            uint32_t sid = HARC_NONE;
+            if (spos < nsugg) {
+                const int idx = spos + lane;
+                uint32_t id = 0; bool okc = false;
+                if (idx < nsugg) {
+                    id = s.sugg[(size_t)c * HARC_NSUGG + idx];
+                    okc = !((s.claimed[id >> 6] >> (id & 63)) & 1ULL);
+                    for (int k = 0; k < t; k++) okc = okc && (s_own[wv][k] != id);
+                }
+                const unsigned long long sm = __ballot(okc);
+                if (sm) { const int f = __ffsll((long long)sm) - 1; sid = __shfl(id, f, 64); spos += f + 1; } else spos = nsugg;
+            }
+            if (sid == HARC_NONE) { needseed = true; break; }
+            if (lane == 0) {
+                s.steps[(size_t)c * 64 + t] = make_uint2(sid, (1u << 16) | ((uint32_t)spos << 24));
+                atomicMin(&s.bid[sid], ((uint32_t)t << 20) | c);
+                s_own[wv][t] = sid;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint64_t rw[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) rw[w] = s.reads[(size_t)sid * W + w];
+            cons_reset<W>(st, rw, L, lane);
+            nst++;
+            continue;
+        }
         if (lane == 0) {
             s.steps[(size_t)c * 64 + t] = make_uint2(found, (uint32_t)fj | ((uint32_t)fdir << 8));
             atomicMin(&s.bid[found], ((uint32_t)t << 20) | c);
@@ -576,8 +610,8 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
     if (lane == 0) {
         cst.x += np; cst.y += nc; cst.z += nuse; s.cstat[c] = cst;
         h.mode = 0;
-        h.nsteps = (uint32_t)nst;
-        h.pad0 = (uint32_t)lastp;
+        h.nsteps = (h.nsteps & 0xFFFF0000u) | (uint32_t)nst;
+        h.pad0 = ((uint32_t)lastp & 0xFFFFu) | ((uint32_t)spos << 16);
         h.flags = needseed ? (h.flags | CH_NEEDSEED) : (h.flags & ~CH_NEEDSEED);
         s.hdr[c] = h;
     }
@@ -587,9 +621,9 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
 template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
 {
     constexpr int CPW = 64 / G;                                   // chains per wave
-    const int lane = threadIdx.x & 63, sub = lane / G, sl = lane % G;
+    const int lane = threadIdx.x & 63, sub = lane / G, sl = lane % G, g0 = sub * G;
     const uint32_t c = (blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + sub;
-    ChainHdr h; h.flags = 0; h.nsteps = 0;
+    ChainHdr h; h.flags = 0; h.nsteps = 0; h.n_main = 0; h.n_sing = 0; h.prev = 0; h.pad0 = 0;
     if (c < s.K) h = s.hdr[c];
     const bool act = c < s.K && (h.flags & CH_ACTIVE);
     const int n = act ? (int)(h.nsteps & 0xFF) : 0;
@@ -600,45 +634,74 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
         mineb = s.bid[sp.x] == (((uint32_t)sl << 20) | c);
     }
     unsigned long long lost = __ballot(sl < n && !mineb);
-    if (G < 64) lost = (lost >> (sub * G)) & ((1ULL << (G & 63)) - 1ULL);
+    if (G < 64) lost = (lost >> g0) & ((1ULL << (G & 63)) - 1ULL);
     const int v = lost ? (__ffsll((long long)lost) - 1) : n;     // steps kept: those before the first lost bid
     if (mineb) s.bid[sp.x] = HARC_NONE;                          // every bid this chain holds is withdrawn, kept or not
     const bool cut = v < n;
-    const uint32_t pre = (v > 0 && (h.flags & CH_PREVUNM)) ? 1u : 0u;
-    const uint32_t nrec = (uint32_t)v + pre;
-    // log space: one atomic per wave
-    uint32_t wtot; const uint32_t wex = wave_excl_scan_u32(sl == 0 ? nrec : 0u, &wtot);
+    // what every kept step emits (reorder.cpp:560-578 for a match, :678-687 for a new seed)
+    const bool kept = sl < v;
+    const bool seedk = kept && ((sp.y >> 16) & 1);
+    const uint32_t pkind = __shfl_up((uint32_t)seedk, 1, 64), prid = __shfl_up(sp.x, 1, 64);
+    const bool punm = sl == 0 ? ((h.flags & CH_PREVUNM) != 0) : (pkind != 0);      // a seed is pending before this step
+    const uint32_t pid = sl == 0 ? h.prev : prid;
+    const uint32_t nm = kept ? (seedk ? 0u : (punm ? 2u : 1u)) : 0u;               // main-stream records
+    const uint32_t ns = (kept && seedk && punm) ? 1u : 0u;                          // singleton-stream records
+    uint32_t tm, ts, tr;
+    const uint32_t em = wave_excl_scan_u32(nm, &tm), es = wave_excl_scan_u32(ns, &ts), er = wave_excl_scan_u32(nm + ns, &tr);
+    const uint32_t em0 = __shfl(em, g0, 64), es0 = __shfl(es, g0, 64);
     unsigned long long wbase = 0;
-    if (wtot) {
-        if (lane == 0) wbase = atomicAdd(s.logcount, (unsigned long long)wtot);
+    if (tr) {
+        if (lane == 0) wbase = atomicAdd(s.logcount, (unsigned long long)tr);
         wbase = shfl_u64(wbase, 0);
     }
-    const unsigned long long at0 = wbase + __shfl(wex, sub * G, 64);
-    if (act && sl == 0 && pre) {                                 // the pending seed opens a contig (reorder.cpp:564-570)
-        LogRec r; r.chain = c; r.seq = h.n_main; r.rid = h.prev; r.meta = (uint32_t)(s.L & 0xFF);
-        s.log[at0] = r;
-    }
-    if (sl < v) {
+    if (kept) {
         atomicOr(&s.claimed[sp.x >> 6], 1ULL << (sp.x & 63));
-        LogRec r; r.chain = c; r.seq = h.n_main + pre + (uint32_t)sl; r.rid = sp.x;
-        r.meta = (sp.y & 0xFF) | (1u << 8) | (((sp.y >> 8) & 1u) << 9);
-        s.log[at0 + pre + (uint32_t)sl] = r;
+        unsigned long long at = wbase + er;
+        if (seedk) {
+            if (punm) { LogRec r; r.chain = c; r.seq = h.n_sing + (es - es0); r.rid = pid; r.meta = 1u << 10; s.log[at] = r; }
+        } else {
+            uint32_t seq = h.n_main + (em - em0);
+            if (punm) { LogRec r; r.chain = c; r.seq = seq++; r.rid = pid; r.meta = (uint32_t)(s.L & 0xFF); s.log[at++] = r; }   // the pending seed opens a contig
+            LogRec r; r.chain = c; r.seq = seq; r.rid = sp.x;
+            r.meta = (sp.y & 0xFF) | (1u << 8) | (((sp.y >> 8) & 1u) << 9);
+            s.log[at] = r;
+        }
     }
-    const uint32_t lastrid = __shfl(sp.x, sub * G + (v > 0 ? v - 1 : 0), 64);
+    // group totals and the last kept step
+    const int lastl = g0 + (v > 0 ? v - 1 : 0);
+    const uint32_t gm = __shfl(em + nm, lastl, 64) - em0, gs = __shfl(es + ns, lastl, 64) - es0;
+    const uint32_t lastrid = __shfl(sp.x, lastl, 64), lastseed = __shfl((uint32_t)seedk, lastl, 64);
+    unsigned long long seedmask = __ballot(seedk);
+    if (G < 64) seedmask = (seedmask >> g0) & ((1ULL << (G & 63)) - 1ULL);
+    const int nseed = __popcll(seedmask);
+    const int lastseedlane = seedmask ? (63 - __clzll((long long)seedmask)) : 0;
+    const uint32_t lastsidx = __shfl(sp.y >> 24, g0 + lastseedlane, 64);
     if (act && sl == 0) {
-        h.n_main += nrec;
-        if (v > 0) { h.cur = lastrid; h.flags &= ~CH_PREVUNM; }
+        if (v > 0) {
+            h.n_main += gm; h.n_sing += gs;
+            h.cur = lastrid;
+            if (lastseed) { h.prev = lastrid; h.flags |= CH_PREVUNM; } else h.flags &= ~CH_PREVUNM;
+        }
+        if (nseed) atomicAdd(&s.stats[ST_UNMATCHED], (unsigned long long)nseed);
+        uint32_t spos = (h.nsteps >> 16) & 0xFF;
+        if (cut) { if (nseed) spos = lastsidx; }                 // look-ahead seeds of dropped steps stay available
+        else spos = (h.pad0 >> 16) & 0xFF;
+        const uint32_t keep = (h.nsteps & 0xFF000000u) | (spos << 16);
         if (cut) {
-            h.mode = v > 0 ? 1u : 0u; h.nsteps = ((uint32_t)v << 8); h.flags &= ~CH_NEEDSEED;
+            h.mode = v > 0 ? 1u : 0u; h.nsteps = keep | ((uint32_t)v << 8); h.flags &= ~CH_NEEDSEED;
             atomicAdd(&s.stats[ST_CONFLICTS], 1ULL);
-        } else if (n > 0) { h.flags ^= CH_PARITY; h.mode = 0; h.nsteps = 0; }
+        } else {
+            if (n > 0) { h.flags ^= CH_PARITY; h.mode = 0; }
+            h.nsteps = keep;
+        }
         s.hdr[c] = h;
         s.need[c] = (!cut && (h.flags & CH_NEEDSEED)) ? 1 : 0;
     }
 }
 
 // (C) one workgroup: new seeds, in chain order, from the single descending cursor over unclaimed reads (reorder.cpp:650-688);
-// when the cursor runs out the remaining chains finish.
+// when the cursor runs out the remaining chains finish.  Every reseeded chain also gets HARC_NSUGG look-ahead seeds: the next
+// unclaimed ids below the cursor (not claimed, the cursor does not move), which k_steps uses when the chain is stuck again.
 __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
 {
     __shared__ uint32_t sm[20];
@@ -676,6 +739,29 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
         else { assigned += total; cursor = (cwd - 1023) * 64 - 1; }
         __syncthreads();
     }
+    // look-ahead: the next assigned * HARC_NSUGG unclaimed ids below the cursor, nothing claimed, cursor untouched
+    const uint32_t want = assigned * (uint32_t)s.nsugg_per_seed;
+    uint32_t got = 0;
+    long long look = cursor;
+    __threadfence();
+    __syncthreads();
+    if (want && look >= 0) {                                      // ONE chunk only (the 1024 words ending at the cursor's word): bounded cost
+        const long long cwd = look >> 6, wi = cwd - t;
+        unsigned long long bits = 0;
+        if (wi >= 0) {
+            bits = ~s.claimed[wi];
+            if (wi == cwd) { const int top = (int)(look & 63); if (top < 63) bits &= (2ULL << top) - 1ULL; }
+        }
+        uint32_t total; const uint32_t off = block_excl_scan_u32<1024>((uint32_t)__popcll(bits), sm, &total);
+        uint32_t k = 0;
+        while (bits && off + k < want) {
+            const int b = 63 - __clzll((long long)bits);
+            bits &= ~(1ULL << b);
+            s.seedbuf[R + off + k] = (uint32_t)(wi * 64 + b);
+            k++;
+        }
+        got = total >= want ? want : total;
+    }
     __threadfence();
     __syncthreads();
     uint32_t r = rbase;
@@ -689,7 +775,11 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
         }
         if (r < assigned) {
             const uint32_t id = s.seedbuf[r];
-            h.cur = id; h.prev = id; h.flags = (h.flags | CH_PREVUNM) & ~CH_NEEDSEED; h.mode = 2; h.nsteps = 0;
+            h.cur = id; h.prev = id; h.flags = (h.flags | CH_PREVUNM) & ~CH_NEEDSEED; h.mode = 2;
+            const uint32_t first = r * (uint32_t)s.nsugg_per_seed;
+            const uint32_t ng = first >= got ? 0u : (got - first < (uint32_t)s.nsugg_per_seed ? got - first : (uint32_t)s.nsugg_per_seed);
+            for (uint32_t q = 0; q < ng; q++) s.sugg[(size_t)c * HARC_NSUGG + q] = s.seedbuf[R + first + q];
+            h.nsteps = ng << 24;                                  // nothing walked, nothing to replay, look-ahead position 0
             atomicAdd(&s.stats[ST_UNMATCHED], 1ULL);
         } else {                                                  // no reads left (reorder.cpp:670-677)
             h.flags &= ~(CH_ACTIVE | CH_PREVUNM | CH_NEEDSEED);
@@ -851,6 +941,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     S1Args a; memset(&a, 0, sizeof a);
     a.L = P.readlen; a.maxmatch = P.maxmatch; a.thresh = P.thresh; a.maxsearch = P.maxsearch;
     a.Lp = ((W + 1) / 2) * 64; a.S = nsteps;
+    a.nsugg_per_seed = HARC_NSUGG;
+    if (const char *e = getenv("HARC_AMD_NSUGG")) { a.nsugg_per_seed = atoi(e); if (a.nsugg_per_seed < 0) a.nsugg_per_seed = 0; if (a.nsugg_per_seed > HARC_NSUGG) a.nsugg_per_seed = HARC_NSUGG; }
     for (int l = 0; l < 2; l++) { a.ds[l] = P.dict_start[l]; a.de[l] = P.dict_end[l]; a.kbits[l] = 2 * (P.dict_end[l] - P.dict_start[l] + 1); }
     a.N = N; a.K = K; a.reads = c->d_reads;
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
@@ -858,7 +950,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const uint32_t nblk = (K + 255) / 256;
     RC_TRY(dalloc(c, &a.claimed, nwords)); RC_TRY(dalloc(c, &a.bid, (size_t)N + 1)); RC_TRY(dalloc(c, &a.hdr, K));
     RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.steps, (size_t)K * 64)); RC_TRY(dalloc(c, &a.need, (size_t)K + 1024));
-    RC_TRY(dalloc(c, &a.seedbuf, K));
+    RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + HARC_NSUGG))); RC_TRY(dalloc(c, &a.sugg, (size_t)K * HARC_NSUGG));
     RC_TRY(dalloc(c, &a.log, (size_t)N + 1)); RC_TRY(dalloc(c, &a.logcount, 1));
     RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N));
     RC_TRY(dalloc(c, &a.cstat, K)); HIP_TRY(hipMemsetAsync(a.cstat, 0, (size_t)K * 16, c->stream));

@@ -37,6 +37,7 @@
 #define MAXL 255
 #define NONE 0xFFFFFFFFu
 #define MAXSTEPS 64
+#define NSUGG 4           /* look-ahead seeds handed to a chain at every reseed */
 
 /* ------------------------------------------------------------------ parameters (harc:52-60) */
 typedef struct {
@@ -150,7 +151,8 @@ typedef struct {
     vec32 s_order;         /* singleton stream */
     uint32_t p_rid; int p_j, p_dir;   /* proposal of the current step */
     /* super-round: up to MAXSTEPS speculative steps against the frozen claim state */
-    uint32_t s_rid[MAXSTEPS]; uint8_t s_j[MAXSTEPS], s_dir[MAXSTEPS]; int nsteps, need_reseed;
+    uint32_t s_rid[MAXSTEPS]; uint8_t s_j[MAXSTEPS], s_dir[MAXSTEPS], s_kind[MAXSTEPS], s_sidx[MAXSTEPS]; int nsteps, need_reseed;
+    uint32_t sugg[NSUGG]; int nsugg, sugg_pos;   /* unclaimed ids right below the cursor at the chain's last reseed, highest first */
     int32_t *count0; uint8_t *cons0;  /* state at the start of the super-round (rollback point) */
 } chain_t;
 
@@ -313,14 +315,33 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
             if (!x->active) continue;
             memcpy(x->count0, x->count, sizeof(int32_t) * 4 * L); memcpy(x->cons0, x->cons, L);
             x->nsteps = 0; x->need_reseed = 0;
+            int spos = x->sugg_pos;
             for (uint32_t t = 0; t < nsteps; t++) {
                 propose(x, dict, reads, claimed, p, mask, revmask, out, x->s_rid, x->nsteps);
-                if (x->p_rid == NONE) { x->need_reseed = 1; break; }
-                x->s_rid[t] = x->p_rid; x->s_j[t] = (uint8_t)x->p_j; x->s_dir[t] = (uint8_t)x->p_dir; x->nsteps = (int)t + 1;
                 uint32_t key = (t << 20) | c;
-                if (key < bid[x->p_rid]) bid[x->p_rid] = key;
-                cons_update(x, reads + (size_t)x->p_rid * W, L, x->p_dir, x->p_j);
+                if (x->p_rid != NONE) {
+                    x->s_rid[t] = x->p_rid; x->s_j[t] = (uint8_t)x->p_j; x->s_dir[t] = (uint8_t)x->p_dir; x->s_kind[t] = 0; x->s_sidx[t] = 0;
+                    x->nsteps = (int)t + 1;
+                    if (key < bid[x->p_rid]) bid[x->p_rid] = key;
+                    cons_update(x, reads + (size_t)x->p_rid * W, L, x->p_dir, x->p_j);
+                    continue;
+                }
+                /* no candidate: continue from the chain's look-ahead seeds, highest id first, skipping what got claimed meanwhile
+                   (for K=1 this is exactly "the highest unclaimed id below the previous seed", reorder.cpp:652-668) */
+                uint32_t sid = NONE;
+                while (spos < x->nsugg) {
+                    uint32_t id = x->sugg[spos++];
+                    int mine = 0;
+                    for (int k = 0; k < x->nsteps; k++) if (x->s_rid[k] == id) mine = 1;
+                    if (!claimed[id] && !mine) { sid = id; break; }
+                }
+                if (sid == NONE) { x->need_reseed = 1; break; }
+                x->s_rid[t] = sid; x->s_j[t] = 0; x->s_dir[t] = 0; x->s_kind[t] = 1; x->s_sidx[t] = (uint8_t)spos;
+                x->nsteps = (int)t + 1;
+                if (key < bid[sid]) bid[sid] = key;
+                cons_reset(x, reads + (size_t)sid * W, L);
             }
+            x->p_j = spos;                                        /* scratch: look-ahead position reached by this walk */
         }
         /* (B) keep the steps before the first lost bid (reorder.cpp:560-578 / :624-642 for each kept step) */
         for (uint32_t c = 0; c < K; c++) {
@@ -331,14 +352,23 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
             if (v < x->nsteps) {                                  /* lost a bid: roll back and replay the kept steps */
                 out->conflicts++; x->need_reseed = 0;
                 memcpy(x->count, x->count0, sizeof(int32_t) * 4 * L); memcpy(x->cons, x->cons0, L);
-                for (int t = 0; t < v; t++) cons_update(x, reads + (size_t)x->s_rid[t] * W, L, x->s_dir[t], x->s_j[t]);
-            }
+                for (int t = 0; t < v; t++) {
+                    if (x->s_kind[t]) cons_reset(x, reads + (size_t)x->s_rid[t] * W, L);
+                    else cons_update(x, reads + (size_t)x->s_rid[t] * W, L, x->s_dir[t], x->s_j[t]);
+                }
+                for (int t = v - 1; t >= 0; t--) if (x->s_kind[t]) { x->sugg_pos = x->s_sidx[t]; break; }   /* look-ahead seeds of dropped steps stay available */
+            } else x->sugg_pos = x->p_j;
             for (int t = 0; t < v; t++) {
                 uint32_t k = x->s_rid[t];
                 claimed[k] = 1; x->cur = k;
-                if (x->prev_unmatched) emit_main(x, x->prev, 0, L & 0xFF, 0);
-                emit_main(x, k, 1, x->s_j[t], x->s_dir[t]);
-                x->prev_unmatched = 0;
+                if (x->s_kind[t]) {                               /* a new seed (reorder.cpp:678-687) */
+                    if (x->prev_unmatched) vpush(&x->s_order, x->prev);
+                    out->unmatched++; x->prev_unmatched = 1; x->prev = k;
+                } else {
+                    if (x->prev_unmatched) emit_main(x, x->prev, 0, L & 0xFF, 0);
+                    emit_main(x, k, 1, x->s_j[t], x->s_dir[t]);
+                    x->prev_unmatched = 0;
+                }
             }
         }
         for (uint32_t c = 0; c < K; c++) if (ch[c].active) for (int t = 0; t < ch[c].nsteps; t++) bid[ch[c].s_rid[t]] = NONE;
@@ -352,11 +382,27 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
                 remainingpos--;
             }
             if (x->prev_unmatched) vpush(&x->s_order, x->prev);
-            if (!found) { x->active = 0; nactive--; continue; }
+            x->nsugg = 0; x->sugg_pos = 0;
+            if (!found) { x->active = 0; nactive--; x->need_reseed = 0; continue; }
             uint32_t cur = (uint32_t)remainingpos; remainingpos--;
             claimed[cur] = 1; out->unmatched++;
             x->cur = cur; cons_reset(x, reads + (size_t)cur * W, L);
             x->prev_unmatched = 1; x->prev = cur;
+            x->need_reseed = 2;                                   /* got a seed: entitled to look-ahead seeds below */
+        }
+        /* look-ahead: the next NSUGG unclaimed ids below the cursor for the first reseeded chain, the NSUGG after those for the
+           second, ...; nothing is claimed and the cursor does not move (an unused look-ahead read is found again later) */
+        {
+            int64_t look = remainingpos;
+            /* the look-ahead only inspects one bitmap chunk of the GPU's k_reseed: the 1024 64-bit words ending at the cursor's word */
+            int64_t lim = remainingpos >= 0 ? ((remainingpos >> 6) - 1023) * 64 : 0;
+            if (lim < 0) lim = 0;
+            for (uint32_t c = 0; c < K; c++) {
+                chain_t *x = &ch[c];
+                if (!x->active || x->need_reseed != 2) continue;
+                x->need_reseed = 0;
+                while (x->nsugg < NSUGG && look >= lim) { if (!claimed[look]) x->sugg[x->nsugg++] = (uint32_t)look; look--; }
+            }
         }
     }
     /* concatenate per-chain streams in chain order (reorder.cpp:778-821) */
