@@ -154,32 +154,51 @@ __global__ __launch_bounds__(256) void k_consensus(S2Args s, const uint32_t *cid
 {
     const uint64_t x0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * CSTRIP;
     if (x0 >= s.total) return;
-    long long i = ub_le(s.gstart, (long long)s.M, x0);
+    const int L = s.L;
+    const uint64_t xl = (x0 + CSTRIP - 1 < s.total ? x0 + CSTRIP - 1 : s.total - 1);        // last column of the strip
+    const long long ihi = ub_le(s.gstart, (long long)s.M, xl);                                // last read starting at or before it
+    uint32_t cnt[CSTRIP][4];
+#pragma unroll
+    for (int c = 0; c < CSTRIP; c++) { cnt[c][0] = cnt[c][1] = cnt[c][2] = cnt[c][3] = 0; }
+    // every read overlapping the strip is visited once and feeds all the columns it covers (its 2-bit words are loaded once)
+    for (long long ii = ihi; ii >= 0; ii--) {
+        const uint64_t g = s.gstart[ii];
+        if (g + (uint64_t)L <= x0) break;                         // sorted by gstart: nothing further left reaches the strip
+        const uint64_t *r = s.oreads + (size_t)ii * s.W;
+        const long long o0 = (long long)x0 - (long long)g;        // offset of column x0 inside the read (may be negative)
+        const int j0 = o0 < 0 ? 0 : (int)o0;
+        const int w0 = j0 >> 5;
+        const uint64_t wa = r[w0], wb = (w0 + 1 < s.W) ? r[w0 + 1] : 0;
+#pragma unroll
+        for (int c = 0; c < CSTRIP; c++) {
+            const long long o = o0 + c;
+            if (o >= 0 && o < L && x0 + c <= xl) {
+                const int j = (int)o, wj = j >> 5;
+                const uint64_t word = wj == w0 ? wa : wb;
+                const int v = pc_to_idx((int)((word >> (2 * (j & 31))) & 3));
+                cnt[c][0] += (v == 0); cnt[c][1] += (v == 1); cnt[c][2] += (v == 2); cnt[c][3] += (v == 3);
+            }
+        }
+    }
     uint32_t kprev = HARC_NONE; unsigned long long cend = 0; bool lastc = true;
+    long long i = ub_le(s.gstart, (long long)s.M, x0);
     uint8_t outb[CSTRIP];
 #pragma unroll
     for (int c = 0; c < CSTRIP; c++) {
         const uint64_t x = x0 + c;
         outb[c] = 0;
         if (x >= s.total) continue;
-        while (i + 1 < (long long)s.M && s.gstart[i + 1] <= x) i++;
-        uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
-        for (long long ii = i; ii >= 0; ii--) {
-            const uint64_t g = s.gstart[ii];
-            if (g + (uint64_t)s.L <= x) break;                    // reads are sorted by gstart; nothing further left can cover x
-            const int v = pc_to_idx(base2_at(s.oreads + (size_t)ii * s.W, (int)(x - g)));
-            cA += (v == 0); cC += (v == 1); cG += (v == 2); cT += (v == 3);
-        }
         uint32_t mx = 0; int ind = 0;
-        if (cA > mx) { mx = cA; ind = 0; }
-        if (cC > mx) { mx = cC; ind = 1; }
-        if (cG > mx) { mx = cG; ind = 2; }
-        if (cT > mx) { mx = cT; ind = 3; }
+        if (cnt[c][0] > mx) { mx = cnt[c][0]; ind = 0; }
+        if (cnt[c][1] > mx) { mx = cnt[c][1]; ind = 1; }
+        if (cnt[c][2] > mx) { mx = cnt[c][2]; ind = 2; }
+        if (cnt[c][3] > mx) { mx = cnt[c][3]; ind = 3; }
         int valid = 0;
         if (want_windows) {
+            while (i + 1 < (long long)s.M && s.gstart[i + 1] <= x) i++;
             const uint32_t k = cid[i] + (uint32_t)s.head[i] - 1u;    // cid = exclusive scan of the head flags: a head's own contig index
             if (k != kprev) { const unsigned long long ci = cinfo[k]; kprev = k; cend = ci & ~(1ULL << 63); lastc = (ci >> 63) != 0; }
-            valid = (!lastc && x + (uint64_t)s.L <= cend) ? 1 : 0;
+            valid = (!lastc && x + (uint64_t)L <= cend) ? 1 : 0;
         }
         outb[c] = (uint8_t)(ind | (valid << 2));
     }
