@@ -982,7 +982,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     std::vector<hipEvent_t> ev;
     const bool prof = P.profile != 0;
     uint64_t rounds = 0, launches = 0;
-    const int batch = 8;
+    const int batch = getenv("HARC_AMD_BATCHSYNC") ? atoi(getenv("HARC_AMD_BATCHSYNC")) : 8;
     for (;;) {
         for (int r = 0; r < batch; r++) {
             if (prof) { hipEvent_t a0, a1; HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1)); ev.push_back(a0); ev.push_back(a1); HIP_TRY(hipEventRecord(a0, c->stream)); }

@@ -1,8 +1,8 @@
 # scratch: K sweep (compression vs throughput) -- python tools_ksweep.py N L G err "K1,K2,..."
 import sys, time, lzma, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
 import harc_amd
-from tools_perf_probe_lib import synth
+from perf_probe_lib import synth
 n, L, G, err = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])
 Ks = [int(x) for x in sys.argv[5].split(',')]
 E = 8

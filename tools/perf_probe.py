@@ -1,6 +1,6 @@
 # scratch perf probe (not part of the product): python tools_perf_probe.py N L G err K E
 import sys, time, torch, ctypes as C
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
 import harc_amd
 
 def synth(n, L, G, err, seed=1, dev='cuda'):

@@ -1,6 +1,6 @@
 # scratch: repeat-heavy genome (interspersed repeat copies + poly-A runs) -> big dictionary bins
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
 import harc_amd
 dev='cuda'
 g = torch.Generator(device=dev); g.manual_seed(5)
