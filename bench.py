@@ -144,6 +144,7 @@ def main():
     clean = reads[~hasN].contiguous()
     withN = reads[hasN].contiguous()
     del reads, hasN
+    torch.cuda.synchronize()                                      # libharc_amd works on its own stream: its inputs must be complete
     p = harc_amd.default_params(L, num_thr=args.shards, num_chains=args.chains, device=local, profile=1)
     h = harc_amd.HarcAmd(p)
     sharder = None

@@ -2,6 +2,7 @@
 #include "internal.h"
 #include <stdarg.h>
 #include <chrono>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 void harc_set_error(const char *fmt, ...)
@@ -56,6 +57,7 @@ int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes)
         hipError_t e = hipMalloc(&base, want);
         if (e != hipSuccess && want > bytes) { want = bytes; e = hipMalloc(&base, want); }
         if (e != hipSuccess) { harc_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return HARC_AMD_ENOMEM; }
+        if (getenv("HARC_AMD_POISON")) (void)hipMemset(base, 0xA5, want);   // debugging aid: make reads of uninitialised pool memory show
         c->pool.push_back({ (char *)base, want, 0 });
         c->pool_total += want;
         c->pool_cur = c->pool.size() - 1;

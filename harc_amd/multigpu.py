@@ -24,6 +24,8 @@ class BucketSharder:
         """[n, L] uint8 ASCII (device) -> [n, W] int64 2-bit packed (reorder.cpp:184-209 layout), HIP kernel k_pack2"""
         n = ascii_reads.shape[0]
         out = torch.empty((n, self.W), dtype=torch.int64, device=self.device)
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()             # libharc_amd runs on its own stream: its inputs must be complete
         if n:
             self.ctx.pack_reads_device(ascii_reads.data_ptr(), n, ascii_reads.stride(0), out.data_ptr())
         return out
@@ -33,6 +35,8 @@ class BucketSharder:
             return self.bucket_fn(packed, self.world)
         n = packed.shape[0]
         b = torch.empty((n,), dtype=torch.int32, device=self.device)
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
         if n:
             self.ctx.bucket_reads_device(packed.data_ptr(), n, self.world, b.data_ptr())
         return b.long()
@@ -54,5 +58,7 @@ class BucketSharder:
 
     def exchange_and_set(self, packed):
         recv = self.exchange(packed)
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()             # the all-to-all (RCCL stream, ordered behind torch's) must have landed
         self.ctx.set_reads_packed_device(recv.data_ptr(), recv.shape[0])
         return recv.shape[0]

@@ -18,7 +18,8 @@
  *
  * Conventions: every function returns 0 on success, a negative HARC_AMD_E* code otherwise (the reference's
  * programs return 0 / print a message; the bash driver runs under `set -e`, harc:2).  No exceptions cross the ABI.
- * Input buffers are caller-owned and may be released after the call returns.  Output buffers returned by
+ * Input buffers are caller-owned and may be released after the call returns.  Device input buffers must be COMPLETE when
+ * the call is made: the library works on its own HIP stream and does not wait for the caller's streams.  Output buffers returned by
  * harc_amd_get_stream are library-owned host memory, valid until the next harc_amd_reorder/encode/pack_order on
  * the same context or harc_amd_destroy.  One context per host thread; one HIP device per context.
  *

@@ -252,3 +252,27 @@ def test_decoder_matches_oracle_decoder_E_shards(case, K, S, E, oracle, tmp_path
     assert oracle.harc_oracle_decoder(base.encode(), E) == 0
     assert mine == ol.read_dir(base)["output.dna"]
     assert sorted(mine.split()) == sorted(g["reads.txt"].split())
+
+
+@pytest.mark.parametrize("n,world,K,S", [(120000, 2, 256, 16), (160000, 4, 0, 16), (700000, 2, 512, 16)])
+def test_minimizer_shard_input_matches_oracle(n, world, K, S, oracle, tmp_path):
+    """what one GPU sees after the bucket exchange: only the reads of one minimizer bucket (short islands, a reseed every ~15 reads).
+    Stresses k_reseed / look-ahead seeds; must be the oracle's bytes and must not depend on timing."""
+    import numpy as np
+    import harc_amd
+    from tests.bucket_ref import pack2, bucket_ref
+    arr = gen.reads_array(2024, n, 100, n * 2, err=0.0)
+    keep = bucket_ref(pack2(arr), 100, world) == 0
+    sel = arr[keep]
+    txt = b"".join(bytes(r) + b"\n" for r in sel)
+    (tmp_path / "o").mkdir(); (tmp_path / "g1").mkdir(); (tmp_path / "g2").mkdir()
+    nclean = sel.shape[0]
+    Ko = K if K else max(1, nclean // 2048)
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, Ko, 4, tmp_path / "o", S)
+    outs = []
+    for d in ("g1", "g2"):
+        base = ol.stage_dir(tmp_path / d, {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+        harc_amd.reorder(base, 100, num_chains=K, num_steps=S)
+        outs.append(ol.read_dir(base))
+    assert outs[0] == outs[1], "two runs on the same input differ"
+    assert_same(outs[0], s1, ol.STAGE1_FILES, "minimizer-shard input, stage I vs oracle")
