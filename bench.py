@@ -205,7 +205,12 @@ def main():
         want = (sig_clean[0] + sig_N[0], (sig_clean[1] + sig_N[1]) % (1 << 64), sig_clean[2] ^ sig_N[2])
         roundtrip = {"ok": bool(dsig == want), "reads_decoded": dsig[0], "check": "multiset signature (sum, xor of 64-bit read hashes) of GPU-decoded streams == inputs"}
     else:
-        roundtrip = {"ok": bool(dsig[0] == c.n_clean + c.n_N), "reads_decoded": dsig[0], "check": "decoded read count == shard size (sharded run)"}
+        want = h.input_signature()                                 # the shard this rank received through the all-to-all + its own N reads
+        roundtrip = {"ok": bool(dsig == want), "reads_decoded": dsig[0], "check": "multiset signature of GPU-decoded streams == this rank's shard (2-bit reads held by the library)"}
+    if dist is not None:
+        okt = torch.tensor([1 if roundtrip["ok"] else 0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        roundtrip["ok"] = bool(int(okt.item()))
     total_reads = n * world * args.steps
     value = total_reads / dt / 1e6
 

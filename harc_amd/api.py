@@ -78,6 +78,7 @@ def lib():
     l.harc_amd_preprocess_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     l.harc_amd_decoder_files.argtypes = [PP, C.c_char_p, C.c_int32]
     l.harc_amd_decode_signature.argtypes = [ctx, C.POINTER(C.c_uint64)]
+    l.harc_amd_input_signature.argtypes = [ctx, C.POINTER(C.c_uint64)]
     l.harc_amd_reads_signature_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     _lib = l
     return l
@@ -190,6 +191,11 @@ class HarcAmd:
         """(count, sum, xor) of the reads decoded on the GPU from this context's stage-II streams"""
         sig = (C.c_uint64 * 3)()
         _check(lib().harc_amd_decode_signature(self._ctx, sig))
+        return tuple(int(x) for x in sig)
+
+    def input_signature(self):
+        sig = (C.c_uint64 * 3)()
+        _check(lib().harc_amd_input_signature(self._ctx, sig))
         return tuple(int(x) for x in sig)
 
     def reads_signature_device(self, d_ascii, n, stride):

@@ -338,3 +338,48 @@ extern "C" int harc_amd_decoder_files(const harc_amd_params *params, const char 
     printf("Decoding done\n");                                                 // decoder.cpp:170
     return HARC_AMD_OK;
 }
+
+// signature of the reads the context currently holds (2-bit clean reads + 3-bit N reads): the other side of the round-trip check
+// when the inputs never existed as ASCII on this GPU (the shard received through the all-to-all)
+__global__ void k_sig_packed2(const uint64_t *reads, uint32_t n, int L, int W, unsigned long long *sig)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t h = READ_HASH_INIT;
+    if (i < n) {
+        const uint64_t *r = reads + (size_t)i * W;
+        for (int j = 0; j < L; j++) { const int pc = (int)((r[j >> 5] >> (2 * (j & 31))) & 3); h = read_hash_step(h, ((pc & 1) << 1) | (pc >> 1)); }
+        h = mix64(h);
+    }
+    sig_accumulate(h, i < n, sig);
+}
+__global__ void k_sig_packed3(const uint64_t *reads, uint32_t n, int L, int W3, unsigned long long *sig)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t h = READ_HASH_INIT;
+    if (i < n) {
+        const uint64_t *r = reads + (size_t)i * W3;
+        for (int j = 0; j < L; j++) {
+            const int off = 3 * j, wi = off >> 6, sh = off & 63;
+            uint64_t v = r[wi] >> sh;
+            if (sh > 61 && wi + 1 < W3) v |= r[wi + 1] << (64 - sh);
+            const int c3 = (int)(v & 7);
+            h = read_hash_step(h, c3 == 0 ? 0 : c3 == 4 ? 1 : c3 == 2 ? 2 : c3 == 6 ? 3 : 4);
+        }
+        h = mix64(h);
+    }
+    sig_accumulate(h, i < n, sig);
+}
+extern "C" int harc_amd_input_signature(harc_amd_ctx *c, uint64_t *sig3)
+{
+    if (!c || !sig3) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    const harc_mark_t mk = harc_pool_mark(c);
+    unsigned long long *d_sig = nullptr; RC_TRY(dalloc(c, &d_sig, 4));
+    HIP_TRY(hipMemsetAsync(d_sig, 0, 32, c->stream));
+    if (c->N && c->d_reads) hipLaunchKernelGGL(k_sig_packed2, G256(c->N), c->d_reads, c->N, c->P.readlen, c->W, d_sig);
+    if (c->NN && c->d_nreads3) hipLaunchKernelGGL(k_sig_packed3, G256(c->NN), c->d_nreads3, c->NN, c->P.readlen, c->W3, d_sig);
+    HIP_TRY(hipMemcpyAsync(sig3, d_sig, 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    harc_pool_release(c, mk);
+    return HARC_AMD_OK;
+}

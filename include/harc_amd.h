@@ -162,6 +162,7 @@ int harc_amd_get_counters(harc_amd_ctx *ctx, harc_amd_counters *out);
    (num_chains, num_steps, num_thr) can be compared with the input reads without materialising either. */
 int harc_amd_decode_signature(harc_amd_ctx *ctx, uint64_t sig[3]);         /* decodes the context's stage-II streams */
 int harc_amd_reads_signature_device(harc_amd_ctx *ctx, const char *d_ascii, uint32_t n_reads, uint32_t stride, uint64_t sig[3]);
+int harc_amd_input_signature(harc_amd_ctx *ctx, uint64_t sig[3]);           /* of the clean + N reads the context currently holds */
 
 /* ---- file contract: drop-ins for the reference's stage programs.  basedir as argv[1] of those programs. */
 int harc_amd_reorder_files(const harc_amd_params *params, const char *basedir);

@@ -276,3 +276,15 @@ def test_minimizer_shard_input_matches_oracle(n, world, K, S, oracle, tmp_path):
         outs.append(ol.read_dir(base))
     assert outs[0] == outs[1], "two runs on the same input differ"
     assert_same(outs[0], s1, ol.STAGE1_FILES, "minimizer-shard input, stage I vs oracle")
+
+
+def test_input_signature_equals_ascii_signature():
+    import torch
+    import harc_amd
+    from tests.bucket_ref import reads_signature
+    g = ol.load_golden("L150_err_3k")
+    clean, withN = g["stage1/input_clean.dna"], g["stage1/input_N.dna"]
+    with harc_amd.HarcAmd(harc_amd.default_params(150)) as h:
+        h.set_reads_ascii(clean, len(clean) // 151, 151)
+        h.set_nreads_ascii(withN, len(withN) // 151, 151)
+        assert h.input_signature() == reads_signature(g["reads.txt"].split())
