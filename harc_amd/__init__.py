@@ -6,8 +6,8 @@ programs (``reorder.out`` / ``encoder.out`` / ``pack_order.out`` <basedir>, harc
 There is no CPU fallback: importing works anywhere, every compute call needs a gfx950 device.
 """
 from .api import (HarcAmd, HarcAmdError, Params, Counters, default_params, lib, lib_path, reorder, encoder, compress,
-                  pack_order, preprocess, decoder, STREAMS)
+                  pack_order, preprocess, decoder, compress_fastq, STREAMS)
 from ._build import build
 
 __all__ = ["HarcAmd", "HarcAmdError", "Params", "Counters", "default_params", "lib", "lib_path", "reorder", "encoder",
-           "compress", "pack_order", "preprocess", "decoder", "build", "STREAMS"]
+           "compress", "pack_order", "preprocess", "decoder", "compress_fastq", "build", "STREAMS"]

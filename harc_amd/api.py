@@ -34,7 +34,7 @@ class Counters(C.Structure):
 STREAMS = dict(S1_ORDER=0, S1_FLAG=1, S1_POS=2, S1_RC=3, S1_ORDER_SINGLETON=4, S1_DNA=5, S1_DNA_SINGLETON=6,
                S2_SEQ=10, S2_SEQ_TAIL=11, S2_POS=12, S2_NOISE=13, S2_NOISEPOS=14, S2_REV=15, S2_REV_TAIL=16,
                S2_ORDER=20, S2_ORDER_N_PE=21, S2_SINGLETON=22, S2_SINGLETON_TAIL=23, S2_INPUT_N=24, S2_META=25,
-               P_ORDER=30, P_ORDER_TAIL=31)
+               P_ORDER=30, P_ORDER_TAIL=31, IN_ORDER_N=40)
 
 _lib = None
 
@@ -77,6 +77,8 @@ def lib():
         getattr(l, f).argtypes = [PP, C.c_char_p]
     l.harc_amd_preprocess_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     l.harc_amd_decoder_files.argtypes = [PP, C.c_char_p, C.c_int32]
+    l.harc_amd_compress_fastq_files.argtypes = [PP, C.c_char_p, C.c_char_p]
+    l.harc_amd_set_fastq_device.argtypes = [ctx, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     l.harc_amd_decode_signature.argtypes = [ctx, C.POINTER(C.c_uint64)]
     l.harc_amd_input_signature.argtypes = [ctx, C.POINTER(C.c_uint64)]
     l.harc_amd_reads_signature_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
@@ -118,6 +120,12 @@ def compress(basedir, readlen, num_thr=1, num_chains=1, **kw):
 def preprocess(fastq, basedir, readlen):
     """== `preprocess.out <fastq> <basedir> False False <readlen>` (src/preprocess.cpp:22-137): the N split"""
     _check(lib().harc_amd_preprocess_files(os.fsencode(fastq), os.fsencode(basedir), readlen))
+
+
+def compress_fastq(fastq, basedir, readlen, num_thr=1, num_chains=1, **kw):
+    """harc:50-69 in one call, FASTQ parsed on the GPU"""
+    p = default_params(readlen, num_thr=num_thr, num_chains=num_chains, **kw)
+    _check(lib().harc_amd_compress_fastq_files(C.byref(p), os.fsencode(fastq), os.fsencode(basedir)))
 
 
 def decoder(basedir, num_thr_e, device=0):
@@ -162,6 +170,11 @@ class HarcAmd:
 
     def set_reads_ascii_device(self, dptr, n, stride):
         _check(lib().harc_amd_set_reads_ascii_device(self._ctx, C.c_void_p(dptr), n, stride))
+
+    def set_fastq_device(self, dptr, nbytes):
+        nrec = C.c_uint64(0)
+        _check(lib().harc_amd_set_fastq_device(self._ctx, C.c_void_p(dptr), nbytes, C.byref(nrec)))
+        return nrec.value
 
     def set_reads_packed_device(self, dptr, n):
         _check(lib().harc_amd_set_reads_packed_device(self._ctx, C.c_void_p(dptr), n))

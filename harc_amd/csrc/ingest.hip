@@ -1,0 +1,226 @@
+// ingest.hip -- FASTQ ingest on the GPU: the work of src/preprocess.cpp:81-121 (take line 2 of every
+// 4-line record, check the fixed read length, split reads with and without N, remember the original index of every N read) and of
+// readDnaFile / stringtobitset (reorder.cpp:240-263,203-209) without the single-threaded getline loop and without the
+// input_clean.dna round trip: the whole file is staged in HBM, a prefix sum over the newline flags gives the line index, one thread
+// per record classifies, two compactions pack the reads straight into the 2-bit / 3-bit stores of the context.
+#include "devutil.h"
+#include <string>
+
+// line index in two levels: newlines per 4096-byte tile -> scan of the tile counts -> positions written tile by tile
+#define NL_TILE 4096
+__device__ __forceinline__ uint32_t nl_count16(const char *txt, uint64_t n, uint64_t at, uint32_t *mask)
+{
+    uint32_t m = 0;
+    for (int k = 0; k < 16; k++) if (at + k < n && txt[at + k] == '\n') m |= 1u << k;
+    *mask = m;
+    return (uint32_t)__popc(m);
+}
+__global__ __launch_bounds__(256) void k_nl_count(const char *txt, uint64_t n, uint32_t *tilecnt)
+{
+    __shared__ uint32_t sm[8];
+    const uint64_t at = (uint64_t)blockIdx.x * NL_TILE + (uint64_t)threadIdx.x * 16;
+    uint32_t m; uint32_t cnt = nl_count16(txt, n, at, &m);
+    uint32_t tot; (void)block_excl_scan_u32<256>(cnt, sm, &tot);
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_nl_write(const char *txt, uint64_t n, const uint64_t *tilebase, uint64_t *nl)
+{
+    __shared__ uint32_t sm[8];
+    const uint64_t at = (uint64_t)blockIdx.x * NL_TILE + (uint64_t)threadIdx.x * 16;
+    uint32_t m; uint32_t cnt = nl_count16(txt, n, at, &m);
+    uint32_t tot; const uint32_t off = block_excl_scan_u32<256>(cnt, sm, &tot);
+    uint64_t o = tilebase[blockIdx.x] + off;
+    while (m) { const int k = __ffs((int)m) - 1; m &= m - 1; nl[o++] = at + k; }
+}
+// record r = lines 4r .. 4r+3 ; sequence = line 4r+1 = bytes (nl[4r], nl[4r+1]).  flags: bit0 = has N, err counts bad lengths
+__global__ void k_classify(const char *txt, const uint64_t *nl, uint32_t nrec, int L, uint32_t *isN, uint32_t *isClean, unsigned int *err)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const uint64_t s = nl[4ull * r] + 1, e = nl[4ull * r + 1];
+    uint64_t len = e - s;
+    if (len && txt[e - 1] == '\r') len--;                         // tolerate CRLF
+    if (len != (uint64_t)L) { atomicAdd(err, 1u); isN[r] = 0; isClean[r] = 0; return; }    // preprocess.cpp:92-97
+    bool hasN = false;
+    for (int j = 0; j < L; j++) hasN |= txt[s + j] == 'N';        // preprocess.cpp:98
+    isN[r] = hasN ? 1u : 0u; isClean[r] = hasN ? 0u : 1u;
+}
+// clean reads -> 2-bit words (one thread per (record, word)); N reads -> 3-bit words; original index of N reads (read_order_N.bin)
+__global__ void k_ingest_pack2(const char *txt, const uint64_t *nl, const uint32_t *isClean, const uint32_t *rankC, uint32_t nrec, int L, int W, uint64_t *out)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)nrec * W) return;
+    const uint32_t r = (uint32_t)(gid / W); const int w = (int)(gid % W);
+    if (!isClean[r]) return;
+    const char *s = txt + nl[4ull * r] + 1;
+    uint64_t v = 0;
+    for (int k = 0; k < 32; k++) {
+        const int b = 32 * w + k;
+        if (b < L) { const char ch = s[b]; v |= (uint64_t)(ch == 'A' ? 0 : ch == 'G' ? 1 : ch == 'C' ? 2 : 3) << (2 * k); }
+    }
+    out[(size_t)rankC[r] * W + w] = v;
+}
+__global__ void k_ingest_pack3(const char *txt, const uint64_t *nl, const uint32_t *isN, const uint32_t *rankN, uint32_t nrec, int L, int W3, uint64_t *out, uint32_t *orderN)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)nrec * W3) return;
+    const uint32_t r = (uint32_t)(gid / W3); const int w = (int)(gid % W3);
+    if (!isN[r]) return;
+    const char *s = txt + nl[4ull * r] + 1;
+    uint64_t v = 0;
+    const int b0 = (64 * w) / 3, b1 = (64 * w + 63) / 3;
+    for (int b = b0; b <= b1 && b < L; b++) {
+        const char ch = s[b];
+        const uint64_t c3 = ch == 'A' ? 0 : ch == 'N' ? 1 : ch == 'G' ? 2 : ch == 'C' ? 4 : 6;
+        const int sh = 3 * b - 64 * w;
+        v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
+    }
+    out[(size_t)rankN[r] * W3 + w] = v;
+    if (w == 0) orderN[rankN[r]] = r;                             // preprocess.cpp:102
+}
+
+#define G256(n) dim3((unsigned)((((uint64_t)(n)) + 255) / 256)), dim3(256), 0, c->stream
+
+// FASTQ text already in device memory -> the context's clean reads (2-bit) and N reads (3-bit); the original indices of the N reads
+// (read_order_N.bin, u32 each) are returned through harc_amd_get_stream(HARC_AMD_IN_ORDER_N)
+extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes, uint64_t *n_records_out)
+{
+    if (!c || (nbytes && !d_txt)) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    const int L = c->P.readlen;
+    // drop previous inputs / results
+    {
+        // same effect as harc_amd_set_reads_* on an empty set
+        RC_TRY(harc_amd_set_reads_packed_device(c, nullptr, 0));
+        RC_TRY(harc_amd_set_nreads_ascii_device(c, nullptr, 0, (uint32_t)L));
+    }
+    if (nbytes == 0) { if (n_records_out) *n_records_out = 0; out_buf(c, HARC_AMD_IN_ORDER_N, 0).clear(); return HARC_AMD_OK; }
+    const harc_mark_t mk = harc_pool_mark(c);
+    // line index: nls[k] = byte position of the k-th newline
+    const uint64_t ntiles = (nbytes + NL_TILE - 1) / NL_TILE;
+    uint32_t *tilecnt = nullptr; uint64_t *tilebase = nullptr;
+    RC_TRY(dalloc(c, &tilecnt, (size_t)ntiles + 1)); RC_TRY(dalloc(c, &tilebase, (size_t)ntiles + 1));
+    HIP_TRY(hipMemsetAsync(tilecnt + ntiles, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_nl_count, dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_txt, nbytes, tilecnt);
+    RC_TRY(prim_excl_scan_u32_to_u64(c, tilecnt, tilebase, (size_t)ntiles + 1));
+    uint64_t nlines = 0; char lastch = 0;
+    HIP_TRY(hipMemcpyAsync(&nlines, tilebase + ntiles, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&lastch, d_txt + nbytes - 1, 1, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint64_t *nl = nullptr; RC_TRY(dalloc(c, &nl, (size_t)nlines + 8));
+    hipLaunchKernelGGL(k_nl_write, dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_txt, nbytes, (const uint64_t *)tilebase, nl + 1);
+    uint64_t total_lines = nlines;
+    if (lastch != '\n') {                                         // last line without a newline: it ends at nbytes
+        HIP_TRY(hipMemcpyAsync(nl + 1 + nlines, &nbytes, 8, hipMemcpyHostToDevice, c->stream));
+        total_lines++;
+    }
+    const uint64_t nrec64 = total_lines / 4;                      // a trailing partial record is ignored, as by the getline loop
+    if (nrec64 > 4294967290ull) { harc_set_error("Too many reads. HARC supports at most 4294967290 reads"); harc_pool_release(c, mk); return HARC_AMD_EINVAL; }   // preprocess.cpp:122-126
+    const uint32_t nrec = (uint32_t)nrec64;
+    // record r: sequence between nl'[4r+1] and nl'[4r+2] in the shifted array => pass nl+? : k_classify expects nl[4r] = newline before the
+    // sequence line = end of line 4r = shifted index 4r+1
+    const uint64_t *nls = nl + 1;
+    uint32_t *isN = nullptr, *isC = nullptr, *rkN = nullptr, *rkC = nullptr; unsigned int *d_err = nullptr;
+    RC_TRY(dalloc(c, &isN, (size_t)nrec + 1)); RC_TRY(dalloc(c, &isC, (size_t)nrec + 1)); RC_TRY(dalloc(c, &rkN, (size_t)nrec + 1)); RC_TRY(dalloc(c, &rkC, (size_t)nrec + 1));
+    RC_TRY(dalloc(c, &d_err, 4));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 16, c->stream));
+    HIP_TRY(hipMemsetAsync(isN, 0, ((size_t)nrec + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(isC, 0, ((size_t)nrec + 1) * 4, c->stream));
+    if (nrec) hipLaunchKernelGGL(k_classify, G256(nrec), d_txt, nls, nrec, L, isN, isC, d_err);
+    RC_TRY(prim_excl_scan_u32(c, isN, rkN, (size_t)nrec + 1)); RC_TRY(prim_excl_scan_u32(c, isC, rkC, (size_t)nrec + 1));
+    uint32_t nN = 0, nC = 0; unsigned int err = 0;
+    HIP_TRY(hipMemcpyAsync(&nN, rkN + nrec, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&nC, rkC + nrec, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err) {
+        printf("Read length not fixed. Found reads whose length is not %d\n", L);
+        harc_set_error("read length not fixed (%u records differ from %d)", err, L); harc_pool_release(c, mk); return HARC_AMD_EINVAL;
+    }
+    // the packed stores outlive the scratch: raw allocations (as harc_amd_set_reads_*)
+    if (c->d_reads) { harc_raw_free(c, c->d_reads); c->d_reads = nullptr; }
+    if (c->d_nreads3) { harc_raw_free(c, c->d_nreads3); c->d_nreads3 = nullptr; }
+    RC_TRY(harc_raw_alloc(c, (void **)&c->d_reads, ((size_t)nC * c->W + 1) * 8));
+    RC_TRY(harc_raw_alloc(c, (void **)&c->d_nreads3, ((size_t)nN * c->W3 + 1) * 8));
+    uint32_t *orderN = nullptr; RC_TRY(dalloc(c, &orderN, (size_t)nN + 1));
+    if (nrec) {
+        hipLaunchKernelGGL(k_ingest_pack2, G256((uint64_t)nrec * c->W), d_txt, nls, isC, rkC, nrec, L, c->W, c->d_reads);
+        hipLaunchKernelGGL(k_ingest_pack3, G256((uint64_t)nrec * c->W3), d_txt, nls, isN, rkN, nrec, L, c->W3, c->d_nreads3, orderN);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<uint8_t> &ob = out_buf(c, HARC_AMD_IN_ORDER_N, 0);
+    RC_TRY(harc_d2h(c, ob, orderN, (size_t)nN * 4));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->N = nC; c->NN = nN; c->C.n_clean = nC; c->C.n_N = nN;
+    if (n_records_out) *n_records_out = nrec;
+    harc_pool_release(c, mk);
+    return HARC_AMD_OK;
+}
+
+// FASTQ file -> every stage-II file under <basedir>/output (+ read_order_N.bin, numreads.bin): harc:50-69 without input_clean.dna
+extern "C" int harc_amd_compress_fastq_files(const harc_amd_params *params, const char *fastq, const char *basedir)
+{
+    if (!params || !fastq || !basedir) return HARC_AMD_EINVAL;
+    harc_amd_ctx *c = nullptr;
+    RC_TRY(harc_amd_create(params, &c));
+    struct Guard { harc_amd_ctx *c; ~Guard() { harc_amd_destroy(c); } } guard{ c };
+    FILE *f = fopen(fastq, "rb");
+    if (!f) { harc_set_error("cannot open %s", fastq); return HARC_AMD_EIO; }
+    fseek(f, 0, SEEK_END); const long long fsz = ftell(f); fseek(f, 0, SEEK_SET);
+    char *d_txt = nullptr;
+    if (harc_raw_alloc(c, (void **)&d_txt, (size_t)fsz + 16) != HARC_AMD_OK) { fclose(f); return HARC_AMD_ENOMEM; }
+    {   // stream the file through two pinned buffers
+        const size_t CH = (size_t)64 << 20;
+        char *hb[2] = { nullptr, nullptr };
+        if (hipHostMalloc((void **)&hb[0], CH) != hipSuccess || hipHostMalloc((void **)&hb[1], CH) != hipSuccess) { fclose(f); harc_set_error("hipHostMalloc failed"); return HARC_AMD_ENOMEM; }
+        hipEvent_t ev[2]; (void)hipEventCreate(&ev[0]); (void)hipEventCreate(&ev[1]);
+        size_t off = 0; int k = 0; bool used[2] = { false, false };
+        while (off < (size_t)fsz) {
+            if (used[k]) (void)hipEventSynchronize(ev[k]);
+            const size_t want = (size_t)fsz - off < CH ? (size_t)fsz - off : CH;
+            if (fread(hb[k], 1, want, f) != want) { fclose(f); harc_set_error("short read on %s", fastq); return HARC_AMD_EIO; }
+            (void)hipMemcpyAsync(d_txt + off, hb[k], want, hipMemcpyHostToDevice, c->stream);
+            (void)hipEventRecord(ev[k], c->stream); used[k] = true;
+            off += want; k ^= 1;
+        }
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); (void)hipHostFree(hb[0]); (void)hipHostFree(hb[1]);
+    }
+    fclose(f);
+    uint64_t nrec = 0;
+    int rc = harc_amd_set_fastq_device(c, d_txt, (uint64_t)fsz, &nrec);
+    harc_raw_free(c, d_txt);
+    if (rc != HARC_AMD_OK) return rc;
+    printf("Read length: %d\nTotal number of reads: %llu\nTotal number of reads without N: %llu\nPreprocessing Done!\n", params->readlen,
+           (unsigned long long)nrec, (unsigned long long)c->N);                                           // preprocess.cpp:133-136
+    const std::string od = std::string(basedir) + "/output/";
+    auto spit = [&](const std::string &name, const void *p, size_t n) -> int {
+        FILE *o = fopen((od + name).c_str(), "wb");
+        if (!o) { harc_set_error("cannot create %s%s", od.c_str(), name.c_str()); return HARC_AMD_EIO; }
+        if (n && fwrite(p, 1, n, o) != n) { fclose(o); harc_set_error("short write"); return HARC_AMD_EIO; }
+        fclose(o); return HARC_AMD_OK;
+    };
+    {
+        const void *p; size_t n;
+        RC_TRY(harc_amd_get_stream(c, HARC_AMD_IN_ORDER_N, 0, &p, &n)); RC_TRY(spit("read_order_N.bin", p, n));
+        const uint32_t n32 = c->N; RC_TRY(spit("numreads.bin", &n32, 4));
+    }
+    RC_TRY(harc_amd_reorder(c));
+    RC_TRY(harc_amd_encode(c));
+    harc_amd_counters C; harc_amd_get_counters(c, &C);
+    printf("Reordering done, %llu were unmatched\n", (unsigned long long)C.unmatched);
+    printf("Encoding done:\n%llu singleton reads were aligned\n%llu reads with N were aligned\n", (unsigned long long)C.aligned_singletons, (unsigned long long)C.aligned_N);
+    static const struct { int id; const char *name; bool per_shard; } files[] = {
+        { HARC_AMD_S2_SEQ, "read_seq.txt", true }, { HARC_AMD_S2_POS, "read_pos.txt", true }, { HARC_AMD_S2_NOISE, "read_noise.txt", true },
+        { HARC_AMD_S2_NOISEPOS, "read_noisepos.txt", true }, { HARC_AMD_S2_REV, "read_rev.txt", true } };
+    for (int e = 0; e < params->num_thr; e++) {
+        for (auto &fd : files) { const void *p; size_t n; RC_TRY(harc_amd_get_stream(c, fd.id, e, &p, &n)); RC_TRY(spit(std::string(fd.name) + "." + std::to_string(e), p, n)); }
+        const void *p; size_t n;
+        RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_SEQ_TAIL, e, &p, &n)); RC_TRY(spit("read_seq.txt." + std::to_string(e) + ".tail", p, n));
+        RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_REV_TAIL, e, &p, &n)); RC_TRY(spit("read_rev.txt." + std::to_string(e) + ".tail", p, n));
+    }
+    static const struct { int id; const char *name; } whole[] = {
+        { HARC_AMD_S2_ORDER, "read_order.bin" }, { HARC_AMD_S2_ORDER_N_PE, "read_order_N_pe.bin" }, { HARC_AMD_S2_INPUT_N, "input_N.dna" },
+        { HARC_AMD_S2_META, "read_meta.txt" }, { HARC_AMD_S2_SINGLETON, "read_singleton.txt" }, { HARC_AMD_S2_SINGLETON_TAIL, "read_singleton.txt.tail" } };
+    for (auto &fd : whole) { const void *p; size_t n; RC_TRY(harc_amd_get_stream(c, fd.id, 0, &p, &n)); RC_TRY(spit(fd.name, p, n)); }
+    return HARC_AMD_OK;
+}

@@ -4,6 +4,7 @@
 //   harc_amd_stage compress <basedir> <readlen> [num_thr] [num_chains]     == both, stage I -> II handed over in HBM
 //   harc_amd_stage pack_order <basedir> <readlen>                          == src/pack_order.out <basedir> (harc:112)
 //   harc_amd_stage decoder <basedir> <readlen ignored> <num_thr_e>         == src/decoder.out <basedir> <num_thr> <num_thr_e> (harc:188)
+//   harc_amd_stage compressfq <basedir> <readlen> <fastq> [num_thr] [num_chains]  == preprocess + reorder + encoder, FASTQ parsed on the GPU
 //   harc_amd_stage preprocess <basedir> <readlen> <fastq>                  == src/preprocess.out <fastq> <basedir> .. <readlen> (harc:50)
 // readlen / num_thr arrive as arguments instead of the compile-time macros of src/config.h (harc:52-63).
 #include <stdio.h>
@@ -18,13 +19,20 @@ int main(int argc, char **argv)
     int rl = atoi(argv[3]);
     if (!strcmp(argv[1], "decoder") && (rl < 1 || rl > 255)) rl = 100;     // the decoder takes readlen from read_meta.txt (decoder.cpp:324-333)
     if (harc_amd_default_params(rl, &P) != 0) { fprintf(stderr, "%s\n", harc_amd_last_error()); return 1; }
-    if (strcmp(argv[1], "preprocess") && strcmp(argv[1], "decoder")) {
+    if (strcmp(argv[1], "preprocess") && strcmp(argv[1], "decoder") && strcmp(argv[1], "compressfq")) {
         if (argc > 4) P.num_thr = atoi(argv[4]);
         if (argc > 5) P.num_chains = atoi(argv[5]);
         if (argc > 6) P.num_steps = atoi(argv[6]);
     }
     int rc;
     if (!strcmp(argv[1], "preprocess")) { if (argc < 5) { fprintf(stderr, "preprocess needs <fastq>\n"); return 2; } rc = harc_amd_preprocess_files(argv[4], argv[2], atoi(argv[3])); }
+    else if (!strcmp(argv[1], "compressfq")) {                    // compressfq <basedir> <readlen> <fastq> [num_thr] [num_chains] [num_steps]
+        if (argc < 5) { fprintf(stderr, "compressfq needs <fastq>\n"); return 2; }
+        if (argc > 5) P.num_thr = atoi(argv[5]);
+        if (argc > 6) P.num_chains = atoi(argv[6]);
+        if (argc > 7) P.num_steps = atoi(argv[7]);
+        rc = harc_amd_compress_fastq_files(&P, argv[4], argv[2]);
+    }
     else if (!strcmp(argv[1], "decoder")) rc = harc_amd_decoder_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1);
     else if (!strcmp(argv[1], "reorder")) rc = harc_amd_reorder_files(&P, argv[2]);
     else if (!strcmp(argv[1], "encoder")) rc = harc_amd_encoder_files(&P, argv[2]);

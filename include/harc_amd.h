@@ -110,7 +110,9 @@ enum {
     HARC_AMD_S2_META = 25,          /* read_meta.txt */
     /* -p (pack_order.cpp) */
     HARC_AMD_P_ORDER = 30,          /* read_order.bin packed */
-    HARC_AMD_P_ORDER_TAIL = 31      /* read_order.bin.tail */
+    HARC_AMD_P_ORDER_TAIL = 31,     /* read_order.bin.tail */
+    /* FASTQ ingest (preprocess.cpp:102) */
+    HARC_AMD_IN_ORDER_N = 40        /* read_order_N.bin: original index (u32) of every read with N, after harc_amd_set_fastq_device */
 };
 
 typedef struct harc_amd_ctx harc_amd_ctx;
@@ -133,6 +135,10 @@ int harc_amd_set_reads_packed_device(harc_amd_ctx *ctx, const uint64_t *d_packed
 /* reads containing N = the lines of input_N.dna (preprocess.cpp:98-103); host ASCII */
 int harc_amd_set_nreads_ascii(harc_amd_ctx *ctx, const char *ascii, uint32_t n_reads, uint32_t stride);
 int harc_amd_set_nreads_ascii_device(harc_amd_ctx *ctx, const char *d_ascii, uint32_t n_reads, uint32_t stride);
+/* FASTQ text (4-line records) already in device memory: preprocess.cpp:81-121 + readDnaFile on the GPU -- takes line 2 of every
+   record, checks the fixed read length, packs reads without N into the 2-bit store and reads with N into the 3-bit store; the
+   original indices of the N reads become stream HARC_AMD_IN_ORDER_N.  Replaces harc_amd_set_reads_* + harc_amd_set_nreads_*. */
+int harc_amd_set_fastq_device(harc_amd_ctx *ctx, const char *d_fastq, uint64_t n_bytes, uint64_t *n_records_out);
 /* stage-II inputs when stage I ran elsewhere (the file family of reorder.cpp:722-830): host buffers.
    dna/dna_s are text with stride readlen+1 */
 int harc_amd_set_stage1_streams(harc_amd_ctx *ctx, const char *temp_dna, const uint8_t *flag, const uint8_t *pos,
@@ -169,6 +175,9 @@ int harc_amd_reorder_files(const harc_amd_params *params, const char *basedir);
 int harc_amd_encoder_files(const harc_amd_params *params, const char *basedir);
 int harc_amd_compress_files(const harc_amd_params *params, const char *basedir);
 int harc_amd_pack_order_files(const harc_amd_params *params, const char *basedir);
+/* harc:50-69 in one call: FASTQ file -> read_order_N.bin, numreads.bin and every stage-II file, parsed on the GPU, no
+   input_clean.dna / temp.dna round trips */
+int harc_amd_compress_fastq_files(const harc_amd_params *params, const char *fastq, const char *basedir);
 /* == `preprocess.out <fastq> <basedir> <preserve_order> <preserve_quality> <readlen>` (src/preprocess.cpp:22-137, harc:50),
    the N split only; host code, feeds the boundary */
 int harc_amd_preprocess_files(const char *fastq, const char *basedir, int32_t readlen);

@@ -288,3 +288,36 @@ def test_input_signature_equals_ascii_signature():
         h.set_reads_ascii(clean, len(clean) // 151, 151)
         h.set_nreads_ascii(withN, len(withN) // 151, 151)
         assert h.input_signature() == reads_signature(g["reads.txt"].split())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fastq_ingest_on_gpu_matches_reference(case, tmp_path):
+    """harc_amd_compress_fastq_files: FASTQ parsed and split on the GPU (preprocess.cpp + readDnaFile), then reorder + encode --
+    the reference's read_order_N.bin / numreads.bin and stage-II files, byte for byte (K=1, E=1)"""
+    import harc_amd
+    g = ol.load_golden(case)
+    L = _L(g)
+    reads = g["reads.txt"].split()
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(b"".join(b"@T.%d some comment\n%s\n+\n%s\n" % (i, r, b"H" * L) for i, r in enumerate(reads)))
+    base = ol.stage_dir(tmp_path, {})
+    harc_amd.compress_fastq(str(fq), base, L, num_thr=1, num_chains=1)
+    got = ol.read_dir(base)
+    assert got["read_order_N.bin"] == g["stage1/read_order_N.bin"] and got["numreads.bin"] == g["stage1/numreads.bin"]
+    fs = ol.stage2_files(1)
+    assert_same(got, {f: g["stage2/" + f] for f in fs}, fs, f"{case}: FASTQ -> streams vs reference")
+
+
+def test_fastq_ingest_edge_cases(tmp_path):
+    import harc_amd
+    base = ol.stage_dir(tmp_path, {})
+    bad = tmp_path / "bad.fastq"
+    bad.write_bytes(b"@a\nACGTACGTAC\n+\nHHHHHHHHHH\n@b\nACGTACG\n+\nHHHHHHH\n")
+    with pytest.raises(harc_amd.HarcAmdError):
+        harc_amd.compress_fastq(str(bad), base, 10)                      # preprocess.cpp:92-97
+    ok = tmp_path / "ok.fastq"
+    ok.write_bytes(b"@a\r\nACGTACGTAC\r\n+\r\nHHHHHHHHHH\r\n@b\nACNTACGTAC\n+\nHHHHHHHHHH")   # CRLF record, no final newline
+    harc_amd.compress_fastq(str(ok), base, 10)
+    got = ol.read_dir(base)
+    assert got["numreads.bin"] == (1).to_bytes(4, "little") and got["read_order_N.bin"] == (1).to_bytes(4, "little")
+    assert got["input_N.dna"] == b"ACNTACGTAC\n"
