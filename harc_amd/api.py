@@ -77,6 +77,7 @@ def lib():
         getattr(l, f).argtypes = [PP, C.c_char_p]
     l.harc_amd_preprocess_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     l.harc_amd_decoder_files.argtypes = [PP, C.c_char_p, C.c_int32]
+    l.harc_amd_decoder_preserve_files.argtypes = [PP, C.c_char_p, C.c_int32]
     l.harc_amd_compress_fastq_files.argtypes = [PP, C.c_char_p, C.c_char_p]
     l.harc_amd_set_fastq_device.argtypes = [ctx, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     l.harc_amd_decode_signature.argtypes = [ctx, C.POINTER(C.c_uint64)]
@@ -128,10 +129,12 @@ def compress_fastq(fastq, basedir, readlen, num_thr=1, num_chains=1, **kw):
     _check(lib().harc_amd_compress_fastq_files(C.byref(p), os.fsencode(fastq), os.fsencode(basedir)))
 
 
-def decoder(basedir, num_thr_e, device=0):
-    """== `decoder.out <basedir> <num_thr> <num_thr_e>` (src/decoder.cpp:44-172): output/output.dna"""
+def decoder(basedir, num_thr_e, device=0, preserve_order=False):
+    """== `decoder.out <basedir> <num_thr> <num_thr_e>` (src/decoder.cpp:44-172): output/output.dna;
+    preserve_order: the -p chain unpack_order + decoder_preserve + merge_N (harc:183-185)"""
     p = default_params(100, device=device)
-    _check(lib().harc_amd_decoder_files(C.byref(p), os.fsencode(basedir), num_thr_e))
+    f = lib().harc_amd_decoder_preserve_files if preserve_order else lib().harc_amd_decoder_files
+    _check(f(C.byref(p), os.fsencode(basedir), num_thr_e))
 
 
 def pack_order(basedir, readlen=100, **kw):

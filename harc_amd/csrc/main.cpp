@@ -17,9 +17,9 @@ int main(int argc, char **argv)
     if (argc < 4) { fprintf(stderr, "usage: %s reorder|encoder|compress|pack_order <basedir> <readlen> [num_thr] [num_chains]\n", argv[0]); return 2; }
     harc_amd_params P;
     int rl = atoi(argv[3]);
-    if (!strcmp(argv[1], "decoder") && (rl < 1 || rl > 255)) rl = 100;     // the decoder takes readlen from read_meta.txt (decoder.cpp:324-333)
+    if (!strncmp(argv[1], "decoder", 7) && (rl < 1 || rl > 255)) rl = 100;     // the decoder takes readlen from read_meta.txt (decoder.cpp:324-333)
     if (harc_amd_default_params(rl, &P) != 0) { fprintf(stderr, "%s\n", harc_amd_last_error()); return 1; }
-    if (strcmp(argv[1], "preprocess") && strcmp(argv[1], "decoder") && strcmp(argv[1], "compressfq")) {
+    if (strcmp(argv[1], "preprocess") && strncmp(argv[1], "decoder", 7) && strcmp(argv[1], "compressfq")) {
         if (argc > 4) P.num_thr = atoi(argv[4]);
         if (argc > 5) P.num_chains = atoi(argv[5]);
         if (argc > 6) P.num_steps = atoi(argv[6]);
@@ -33,6 +33,7 @@ int main(int argc, char **argv)
         if (argc > 7) P.num_steps = atoi(argv[7]);
         rc = harc_amd_compress_fastq_files(&P, argv[4], argv[2]);
     }
+    else if (!strcmp(argv[1], "decoder_preserve")) rc = harc_amd_decoder_preserve_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1);
     else if (!strcmp(argv[1], "decoder")) rc = harc_amd_decoder_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1);
     else if (!strcmp(argv[1], "reorder")) rc = harc_amd_reorder_files(&P, argv[2]);
     else if (!strcmp(argv[1], "encoder")) rc = harc_amd_encoder_files(&P, argv[2]);

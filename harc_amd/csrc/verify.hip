@@ -383,3 +383,167 @@ extern "C" int harc_amd_input_signature(harc_amd_ctx *c, uint64_t *sig3)
     harc_pool_release(c, mk);
     return HARC_AMD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ -p decode chain
+// unpack_order.out + decoder_preserve.out + merge_N.out (harc:183-185) in one call: every read goes back to its line of the original
+// FASTQ.  read_order.bin (packed, pack_order.cpp) tells the original clean-read index of every decoded clean read in stream order,
+// read_order_N_pe.bin the index among the N reads of every decoded / left-over N read, read_order_N.bin the original line of every
+// N read (merge_N.cpp:37-57).
+__global__ void k_unpack_order(const uint32_t *packed, uint32_t ngroups, int numbits, uint32_t *out)      // unpack_order.cpp:34-62
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)ngroups * 32) return;
+    const uint32_t g = (uint32_t)(gid >> 5); const int k = (int)(gid & 31);
+    const uint32_t *w = packed + (size_t)g * numbits;
+    const int bit = k * numbits, wi = bit >> 5, sh = bit & 31;
+    uint64_t v = w[wi];
+    if (sh + numbits > 32) v |= (uint64_t)w[wi + 1] << 32;
+    out[gid] = (uint32_t)((v >> sh) & (numbits == 32 ? 0xFFFFFFFFull : ((1ull << numbits) - 1)));
+}
+__global__ void k_permute_lines(const char *src, const uint32_t *order, uint32_t n, int L, char *dst, uint32_t ndst, unsigned int *err)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t LL = (uint64_t)L + 1;
+    if (gid >= (uint64_t)n * LL) return;
+    const uint32_t i = (uint32_t)(gid / LL);
+    const uint32_t o = order[i];
+    if (o >= ndst) { if (gid % LL == 0) atomicAdd(err, 1u); return; }
+    dst[(uint64_t)o * LL + gid % LL] = src[gid];
+}
+__global__ void k_mark_N(const uint32_t *orderN, uint32_t nN, uint32_t total, uint32_t *flag, unsigned int *err)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nN) return;
+    if (orderN[m] >= total) { atomicAdd(err, 1u); return; }
+    flag[orderN[m]] = 1u;
+}
+__global__ void k_merge_lines(const char *clean, const char *withN, const uint32_t *flag, const uint32_t *rankN, uint32_t total, int L, char *out)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t LL = (uint64_t)L + 1;
+    if (gid >= (uint64_t)total * LL) return;
+    const uint32_t p = (uint32_t)(gid / LL); const uint64_t j = gid % LL;
+    out[gid] = flag[p] ? withN[(uint64_t)rankN[p] * LL + j] : clean[(uint64_t)(p - rankN[p]) * LL + j];
+}
+
+extern "C" int harc_amd_decoder_preserve_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e)
+{
+    if (!params || !basedir || num_thr_e < 1) return HARC_AMD_EINVAL;
+    const std::string od = std::string(basedir) + "/output/";
+    std::vector<uint8_t> meta, pord, ptail, ordNpe, ordN;
+    if (!slurp_file(od + "read_meta.txt", meta)) { harc_set_error("cannot read %sread_meta.txt", od.c_str()); return HARC_AMD_EIO; }
+    meta.push_back(0);
+    const int L = atoi((const char *)meta.data());
+    harc_amd_params P = *params;
+    if (harc_amd_default_params(L, &P) != HARC_AMD_OK) return HARC_AMD_EINVAL;
+    P.device = params->device; P.num_thr = num_thr_e;
+    if (!slurp_file(od + "read_order.bin", pord) || !slurp_file(od + "read_order.bin.tail", ptail) || !slurp_file(od + "read_order_N_pe.bin", ordNpe) ||
+        !slurp_file(od + "read_order_N.bin", ordN)) { harc_set_error("order files missing: was the archive made with -p?"); return HARC_AMD_EIO; }
+    harc_amd_ctx *c = nullptr;
+    RC_TRY(harc_amd_create(&P, &c));
+    struct Guard { harc_amd_ctx *c; ~Guard() { harc_amd_destroy(c); } } guard{ c };
+    const size_t LL = (size_t)L + 1;
+    // ---- unpack_order
+    uint32_t nC = 0; int numbits = 0;
+    if (pord.size() >= 8) { memcpy(&numbits, pord.data(), 4); memcpy(&nC, pord.data() + 4, 4); }
+    const uint32_t ng = nC / 32, ntail = nC % 32;
+    if (nC && (numbits < 1 || numbits > 32 || pord.size() != 8 + (size_t)ng * numbits * 4 || ptail.size() != (size_t)ntail * 4)) { harc_set_error("read_order.bin is not a pack_order file"); return HARC_AMD_EIO; }
+    const uint32_t nN = (uint32_t)(ordN.size() / 4);
+    if (ordNpe.size() != ordN.size()) { harc_set_error("read_order_N_pe.bin and read_order_N.bin disagree"); return HARC_AMD_EIO; }
+    const uint32_t total = nC + nN;
+    uint32_t *d_order = nullptr, *d_ordNpe = nullptr, *d_ordN = nullptr; unsigned int *d_err = nullptr;
+    char *cl = nullptr, *nlines = nullptr;
+    RC_TRY(dalloc(c, &d_order, (size_t)nC + 32)); RC_TRY(dalloc(c, &d_ordNpe, (size_t)nN + 1)); RC_TRY(dalloc(c, &d_ordN, (size_t)nN + 1)); RC_TRY(dalloc(c, &d_err, 4));
+    RC_TRY(dalloc(c, &cl, (size_t)nC * LL + 16)); RC_TRY(dalloc(c, &nlines, (size_t)nN * LL + 16));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 16, c->stream));
+    if (ng) {
+        uint8_t *d_p = nullptr; RC_TRY(up(c, pord.data() + 8, (size_t)ng * numbits * 4, &d_p));
+        hipLaunchKernelGGL(k_unpack_order, G256((uint64_t)ng * 32), (const uint32_t *)d_p, ng, numbits, d_order);
+    }
+    if (ntail) HIP_TRY(hipMemcpyAsync(d_order + (size_t)ng * 32, ptail.data(), (size_t)ntail * 4, hipMemcpyHostToDevice, c->stream));
+    if (nN) { HIP_TRY(hipMemcpyAsync(d_ordNpe, ordNpe.data(), (size_t)nN * 4, hipMemcpyHostToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(d_ordN, ordN.data(), (size_t)nN * 4, hipMemcpyHostToDevice, c->stream)); }
+    // ---- decode every shard into the two line arrays (stream order)
+    uint64_t cA = 0, cN = 0;
+    for (int e = 0; e < num_thr_e; e++) {
+        const std::string sfx = "." + std::to_string(e);
+        std::vector<uint8_t> seq, seqt, pos, noise, npz, rev, revt;
+        if (!slurp_file(od + "read_seq.txt" + sfx, seq) || !slurp_file(od + "read_seq.txt" + sfx + ".tail", seqt) || !slurp_file(od + "read_pos.txt" + sfx, pos) ||
+            !slurp_file(od + "read_noise.txt" + sfx, noise) || !slurp_file(od + "read_noisepos.txt" + sfx, npz) ||
+            !slurp_file(od + "read_rev.txt" + sfx, rev) || !slurp_file(od + "read_rev.txt" + sfx + ".tail", revt)) { harc_set_error("shard %d: stream files missing", e); return HARC_AMD_EIO; }
+        if (pos.empty()) continue;
+        if (pos.size() > 0xFFFFFFFFull || 8 * rev.size() + revt.size() != pos.size()) { harc_set_error("shard %d: rev stream does not match pos stream", e); return HARC_AMD_EIO; }
+        const harc_mark_t mk = harc_pool_mark(c);
+        const uint32_t n = (uint32_t)pos.size();
+        uint8_t *d_seq, *d_seqt, *d_pos, *d_noise, *d_np, *d_rev, *d_revt, *seqb; uint64_t *p64, *possum, *nlpos; uint32_t *fl, *rk, *isN, *rkN; char *tmp, *outA, *outN;
+        RC_TRY(up(c, seq.data(), seq.size(), &d_seq)); RC_TRY(up(c, seqt.data(), seqt.size(), &d_seqt)); RC_TRY(up(c, pos.data(), pos.size(), &d_pos));
+        RC_TRY(up(c, noise.data(), noise.size(), &d_noise)); RC_TRY(up(c, npz.data(), npz.size(), &d_np)); RC_TRY(up(c, rev.data(), rev.size(), &d_rev)); RC_TRY(up(c, revt.data(), revt.size(), &d_revt));
+        const uint64_t seqlen = 4 * (uint64_t)seq.size() + seqt.size();
+        const size_t nnoise = noise.size();
+        RC_TRY(dalloc(c, &seqb, (size_t)seqlen + 16)); RC_TRY(dalloc(c, &p64, (size_t)n + 1)); RC_TRY(dalloc(c, &possum, (size_t)n + 1)); RC_TRY(dalloc(c, &nlpos, (size_t)n + 1));
+        RC_TRY(dalloc(c, &fl, nnoise + 1)); RC_TRY(dalloc(c, &rk, nnoise + 1)); RC_TRY(dalloc(c, &isN, (size_t)n + 1)); RC_TRY(dalloc(c, &rkN, (size_t)n + 1));
+        RC_TRY(dalloc(c, &tmp, (size_t)n * LL + 16)); RC_TRY(dalloc(c, &outA, (size_t)n * LL + 16)); RC_TRY(dalloc(c, &outN, (size_t)n * LL + 16));
+        if (seqlen) hipLaunchKernelGGL(k_unpack_seq, G256(seqlen), d_seq, (uint64_t)seq.size(), d_seqt, (uint64_t)seqt.size(), seqb);
+        hipLaunchKernelGGL(k_pos_to_u64, G256(n), d_pos, n, p64);
+        RC_TRY(prim_incl_scan_u64(c, p64, possum, n));
+        if (nnoise) {
+            hipLaunchKernelGGL(k_nl_flags, G256(nnoise), d_noise, (uint64_t)nnoise, fl);
+            RC_TRY(prim_excl_scan_u32(c, fl, rk, nnoise));
+            hipLaunchKernelGGL(k_nl_positions, G256(nnoise), d_noise, rk, (uint64_t)nnoise, nlpos);
+        }
+        HIP_TRY(hipMemsetAsync(isN, 0, ((size_t)n + 1) * 4, c->stream));
+        hipLaunchKernelGGL(k_decode_text, G256(n), seqb, seqlen, possum, d_noise, d_np, nlpos, d_rev, (uint64_t)rev.size(), d_revt, n, L, tmp, isN, d_err);
+        RC_TRY(prim_excl_scan_u32(c, isN, rkN, (size_t)n + 1));
+        hipLaunchKernelGGL(k_split_lines, G256((uint64_t)n * LL), tmp, isN, rkN, n, L, outA, outN);
+        uint32_t nNs = 0;
+        HIP_TRY(hipMemcpyAsync(&nNs, rkN + n, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint32_t nAs = n - nNs;
+        if (cA + nAs > nC || cN + nNs > nN) { harc_set_error("streams hold more reads than the order files"); return HARC_AMD_EIO; }
+        if (nAs) HIP_TRY(hipMemcpyAsync(cl + cA * LL, outA, (size_t)nAs * LL, hipMemcpyDeviceToDevice, c->stream));
+        if (nNs) HIP_TRY(hipMemcpyAsync(nlines + cN * LL, outN, (size_t)nNs * LL, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        cA += nAs; cN += nNs;
+        harc_pool_release(c, mk);
+    }
+    {   // singletons, then the N reads that were not aligned
+        std::vector<uint8_t> sg, sgt, nt;
+        if (!slurp_file(od + "read_singleton.txt", sg) || !slurp_file(od + "read_singleton.txt.tail", sgt)) { harc_set_error("singleton files missing"); return HARC_AMD_EIO; }
+        slurp_file(od + "input_N.dna", nt);
+        const uint64_t nb = 4 * (uint64_t)sg.size() + sgt.size();
+        const uint32_t ns = (uint32_t)(nb / L), nu = (uint32_t)(nt.size() / LL);
+        if (cA + ns != nC || cN + nu != nN) { harc_set_error("read counts do not add up: clean %llu+%u vs %u, N %llu+%u vs %u", (unsigned long long)cA, ns, nC, (unsigned long long)cN, nu, nN); return HARC_AMD_EIO; }
+        if (ns) {
+            uint8_t *d_sg, *d_sgt, *codes;
+            RC_TRY(up(c, sg.data(), sg.size(), &d_sg)); RC_TRY(up(c, sgt.data(), sgt.size(), &d_sgt)); RC_TRY(dalloc(c, &codes, (size_t)nb + 16));
+            hipLaunchKernelGGL(k_unpack_seq, G256(nb), d_sg, (uint64_t)sg.size(), d_sgt, (uint64_t)sgt.size(), codes);
+            hipLaunchKernelGGL(k_codes_to_lines, G256((uint64_t)ns * LL), codes, ns, L, cl + cA * LL);
+        }
+        if (nu) HIP_TRY(hipMemcpyAsync(nlines + cN * LL, nt.data(), (size_t)nu * LL, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    // ---- restore_order (decoder_preserve.cpp:246-290) + merge_N (merge_N.cpp:37-57)
+    char *clp = nullptr, *nlp = nullptr, *outl = nullptr; uint32_t *flag = nullptr, *rankN = nullptr;
+    RC_TRY(dalloc(c, &clp, (size_t)nC * LL + 16)); RC_TRY(dalloc(c, &nlp, (size_t)nN * LL + 16)); RC_TRY(dalloc(c, &outl, (size_t)total * LL + 16));
+    RC_TRY(dalloc(c, &flag, (size_t)total + 1)); RC_TRY(dalloc(c, &rankN, (size_t)total + 1));
+    HIP_TRY(hipMemsetAsync(flag, 0, ((size_t)total + 1) * 4, c->stream));
+    if (nC) hipLaunchKernelGGL(k_permute_lines, G256((uint64_t)nC * LL), cl, d_order, nC, L, clp, nC, d_err);
+    if (nN) {
+        hipLaunchKernelGGL(k_permute_lines, G256((uint64_t)nN * LL), nlines, d_ordNpe, nN, L, nlp, nN, d_err);
+        hipLaunchKernelGGL(k_mark_N, G256(nN), d_ordN, nN, total, flag, d_err);
+    }
+    RC_TRY(prim_excl_scan_u32(c, flag, rankN, (size_t)total + 1));
+    if (total) hipLaunchKernelGGL(k_merge_lines, G256((uint64_t)total * LL), clp, nlp, flag, rankN, total, L, outl);
+    std::vector<uint8_t> host((size_t)total * LL);
+    unsigned int err = 0;
+    if (!host.empty()) HIP_TRY(hipMemcpyAsync(host.data(), outl, host.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err) { harc_set_error("decoder -p: %u inconsistent order / stream entries", err); return HARC_AMD_EIO; }
+    FILE *fo = fopen((od + "output.dna").c_str(), "wb");
+    if (!fo) { harc_set_error("cannot create %soutput.dna", od.c_str()); return HARC_AMD_EIO; }
+    const bool okw = host.empty() || fwrite(host.data(), 1, host.size(), fo) == host.size();
+    fclose(fo);
+    if (!okw) { harc_set_error("short write on output.dna"); return HARC_AMD_EIO; }
+    printf("Decoding done\n");
+    return HARC_AMD_OK;
+}

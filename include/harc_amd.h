@@ -184,6 +184,9 @@ int harc_amd_preprocess_files(const char *fastq, const char *basedir, int32_t re
 /* == `decoder.out <basedir> <num_thr> <num_thr_e>` (src/decoder.cpp:44-172, harc:188; non -p): reads the stage-II stream files of
    num_thr_e shards under <basedir>/output and writes output/output.dna, byte-identical to the reference decoder */
 int harc_amd_decoder_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e);
+/* == `unpack_order.out` + `decoder_preserve.out` + `merge_N.out` (harc:183-185, -p): needs read_order.bin(+.tail) as written by
+   pack_order, read_order_N_pe.bin and read_order_N.bin; writes output/output.dna = the reads in their original FASTQ order */
+int harc_amd_decoder_preserve_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 #
 #   oracle/build_ref.sh            -> tools (preprocess, decoder, pack_order, unpack_order, merge_N, generators)
 #   oracle/build_ref.sh L T        -> reorder_L<L>_t<T>.out, encoder_L<L>_t<T>.out
+#   oracle/build_ref.sh preserve L E  -> decoder_preserve_L<L>_e<E>.out (the -p decoder, harc:173-178; num_thr 1)
 set -e
 REF=${HARC_REFERENCE:-/root/reference}
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -21,6 +22,14 @@ if [ $# -eq 0 ]; then
   [ -x "$OUT/merge_N.out" ] || g++ "$REF/src/merge_N.cpp" -w -O3 -std=c++11 -o "$OUT/merge_N.out"
   [ -x "$OUT/gen_fastq_noRC" ] || g++ -w -std=c++11 -O3 -o "$OUT/gen_fastq_noRC" "$REF/util/gen_fastq_noRC/gen_fastq_noRC.cpp"
   [ -x "$OUT/gen_fastq" ] || g++ -w -std=c++11 -O3 -o "$OUT/gen_fastq" "$REF/util/gen_fastq/gen_fastq.cpp"
+  exit 0
+fi
+if [ "$1" = preserve ]; then
+  L=$2; E=$3
+  CFG="$OUT/cfgp_L${L}_e${E}"
+  mkdir -p "$CFG"
+  { echo "#define readlen $L"; echo "#define MAX_BIN_SIZE 7"; echo "#define num_thr 1"; echo "#define num_thr_e $E"; } > "$CFG/config.h"   # harc:174-177
+  [ -x "$OUT/decoder_preserve_L${L}_e${E}.out" ] || g++ "$REF/src/decoder_preserve.cpp" -I"$CFG" $CXXFLAGS -o "$OUT/decoder_preserve_L${L}_e${E}.out"
   exit 0
 fi
 L=$1; T=$2

@@ -40,10 +40,17 @@ def test_harc_c_roundtrip(flags, E, oracle, tmp_path):
         assert not (out / "read_order.bin").exists()
     assert oracle.harc_oracle_decoder(str(tmp_path / "x").encode(), E) == 0
     assert sorted((out / "output.dna").read_bytes().split()) == sorted(reads)
-    if "-p" not in flags:                                                                       # ./harc -d on the same archive (GPU decoder)
-        r = subprocess.run([os.path.join(ROOT, "harc"), "-d", str(arc)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    r = subprocess.run([os.path.join(ROOT, "harc"), "-d", str(arc)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)   # GPU decoder
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert (tmp_path / "sample.dna.d").read_bytes() == (out / "output.dna").read_bytes()
+    if "-p" in flags:                                                                           # ./harc -d -p: the FASTQ's own order
+        os.remove(tmp_path / "sample.dna.d")
+        r = subprocess.run([os.path.join(ROOT, "harc"), "-d", str(arc), "-p"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
-        assert (tmp_path / "sample.dna.d").read_bytes() == (out / "output.dna").read_bytes()
+        assert (tmp_path / "sample.dna.d").read_bytes() == txt
+    else:
+        r = subprocess.run([os.path.join(ROOT, "harc"), "-d", str(arc), "-p"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 1 and "Not compressed using -p flag" in r.stdout                 # harc:149-153
 
 
 def test_harc_refuses_existing_output_dir(tmp_path):

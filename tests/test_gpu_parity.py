@@ -254,6 +254,59 @@ def test_decoder_matches_oracle_decoder_E_shards(case, K, S, E, oracle, tmp_path
     assert sorted(mine.split()) == sorted(g["reads.txt"].split())
 
 
+def _fastq(reads, L):
+    return b"".join(b"@T.%d\n%s\n+\n%s\n" % (i, r, b"H" * L) for i, r in enumerate(reads))
+
+
+@pytest.mark.parametrize("case,K,S,E", [(c, 1 + (i % 3) * 7, 16 if i % 2 else 4, 1 + i % 4) for i, c in enumerate(CASES)])
+def test_preserve_order_roundtrip_is_the_input_file(case, K, S, E, tmp_path):
+    """-p: compress (FASTQ ingest on the GPU, stage I, stage II, pack_order) then unpack_order + decoder_preserve + merge_N in
+    harc_amd_decoder_preserve_files gives back the sequence lines of the FASTQ in their original order, N reads included
+    (harc:112-113, harc:183-185, merge_N.cpp:37-57)"""
+    import harc_amd
+    g = ol.load_golden(case)
+    L = _L(g)
+    reads = g["reads.txt"].split()
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(_fastq(reads, L))
+    base = str(tmp_path)
+    os.makedirs(os.path.join(base, "output"))
+    harc_amd.compress_fastq(str(fq), base, L, num_thr=E, num_chains=K, num_steps=S)
+    if len(ol.read_dir(base)["read_order.bin"]) == 0:
+        pytest.skip("no clean reads: pack_order.cpp:36 is undefined on an empty order")
+    harc_amd.pack_order(base, L)
+    for f in ("input_clean.dna",):
+        if os.path.exists(os.path.join(base, "output", f)):
+            os.remove(os.path.join(base, "output", f))
+    harc_amd.decoder(base, E, preserve_order=True)
+    assert ol.read_dir(base)["output.dna"] == g["reads.txt"]
+
+
+@pytest.mark.parametrize("case,E", [("L100_err_5k", 2), ("L100_repeat_dup_4k", 3), ("L100_bigbin2_5k", 1), ("L150_err_3k", 2), ("L63_err_3k", 1)])
+def test_preserve_order_decoder_matches_reference_chain(case, E, tmp_path):
+    """same archive through the REAL reference's unpack_order.out, decoder_preserve.out and merge_N.out (oracle/_ref): same bytes"""
+    import shutil, subprocess
+    import harc_amd
+    g = ol.load_golden(case)
+    L = _L(g)
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    dp = os.path.join(ref, "decoder_preserve_L%d_e%d.out" % (L, E))
+    if not os.path.exists(dp):
+        pytest.skip("oracle/_ref not built")
+    reads = g["reads.txt"].split()
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(_fastq(reads, L))
+    a, b = tmp_path / "a", tmp_path / "b"
+    os.makedirs(a / "output")
+    harc_amd.compress_fastq(str(fq), str(a), L, num_thr=E, num_chains=5, num_steps=16)
+    harc_amd.pack_order(str(a), L)
+    shutil.copytree(a, b)
+    harc_amd.decoder(str(a), E, preserve_order=True)
+    for exe in ("unpack_order.out", os.path.basename(dp), "merge_N.out"):
+        subprocess.run([os.path.join(ref, exe), str(b)], check=True, stdout=subprocess.DEVNULL)
+    assert (a / "output" / "output.dna").read_bytes() == (b / "output" / "output.dna").read_bytes() == g["reads.txt"]
+
+
 @pytest.mark.parametrize("n,world,K,S", [(120000, 2, 256, 16), (160000, 4, 0, 16), (700000, 2, 512, 16)])
 def test_minimizer_shard_input_matches_oracle(n, world, K, S, oracle, tmp_path):
     """what one GPU sees after the bucket exchange: only the reads of one minimizer bucket (short islands, a reseed every ~15 reads).
