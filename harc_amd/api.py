@@ -77,6 +77,7 @@ def lib():
         getattr(l, f).argtypes = [PP, C.c_char_p]
     l.harc_amd_preprocess_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     l.harc_amd_decoder_files.argtypes = [PP, C.c_char_p, C.c_int32]
+    l.harc_amd_compress_fastq_files_ex.argtypes = [PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
     l.harc_amd_decoder_preserve_files.argtypes = [PP, C.c_char_p, C.c_int32]
     l.harc_amd_compress_fastq_files.argtypes = [PP, C.c_char_p, C.c_char_p]
     l.harc_amd_set_fastq_device.argtypes = [ctx, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -123,10 +124,11 @@ def preprocess(fastq, basedir, readlen):
     _check(lib().harc_amd_preprocess_files(os.fsencode(fastq), os.fsencode(basedir), readlen))
 
 
-def compress_fastq(fastq, basedir, readlen, num_thr=1, num_chains=1, **kw):
-    """harc:50-69 in one call, FASTQ parsed on the GPU"""
+def compress_fastq(fastq, basedir, readlen, num_thr=1, num_chains=1, preserve_order=False, preserve_quality=False, **kw):
+    """harc:50-69 in one call, FASTQ parsed on the GPU; preserve_quality (-q) also writes output.quality / output.id
+    (preprocess.cpp:61-118, reorder_quality.cpp)"""
     p = default_params(readlen, num_thr=num_thr, num_chains=num_chains, **kw)
-    _check(lib().harc_amd_compress_fastq_files(C.byref(p), os.fsencode(fastq), os.fsencode(basedir)))
+    _check(lib().harc_amd_compress_fastq_files_ex(C.byref(p), os.fsencode(fastq), os.fsencode(basedir), int(preserve_order), int(preserve_quality)))
 
 
 def decoder(basedir, num_thr_e, device=0, preserve_order=False):

@@ -81,6 +81,33 @@ __global__ void k_ingest_pack3(const char *txt, const uint64_t *nl, const uint32
 
 #define G256(n) dim3((unsigned)((((uint64_t)(n)) + 255) / 256)), dim3(256), 0, c->stream
 
+// nls[k] = byte position of the newline that ends line k (a last line without one ends at nbytes); nls[-1] = (u64)-1 so that line k
+// starts at nls[k-1]+1 for every k.  Pool memory: the caller brackets it with harc_pool_mark / release.
+static int build_line_index(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes, const uint64_t **nls_out, uint64_t *total_lines_out)
+{
+    const uint64_t ntiles = (nbytes + NL_TILE - 1) / NL_TILE;
+    uint32_t *tilecnt = nullptr; uint64_t *tilebase = nullptr;
+    RC_TRY(dalloc(c, &tilecnt, (size_t)ntiles + 1)); RC_TRY(dalloc(c, &tilebase, (size_t)ntiles + 1));
+    HIP_TRY(hipMemsetAsync(tilecnt + ntiles, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_nl_count, dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_txt, nbytes, tilecnt);
+    RC_TRY(prim_excl_scan_u32_to_u64(c, tilecnt, tilebase, (size_t)ntiles + 1));
+    uint64_t nlines = 0; char lastch = 0;
+    HIP_TRY(hipMemcpyAsync(&nlines, tilebase + ntiles, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&lastch, d_txt + nbytes - 1, 1, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint64_t *nl = nullptr; RC_TRY(dalloc(c, &nl, (size_t)nlines + 8));
+    HIP_TRY(hipMemsetAsync(nl, 0xFF, 8, c->stream));
+    hipLaunchKernelGGL(k_nl_write, dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_txt, nbytes, (const uint64_t *)tilebase, nl + 1);
+    uint64_t total_lines = nlines;
+    if (lastch != '\n') {                                         // last line without a newline: it ends at nbytes
+        HIP_TRY(hipMemcpyAsync(nl + 1 + nlines, &nbytes, 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        total_lines++;
+    }
+    *nls_out = nl + 1; *total_lines_out = total_lines;
+    return HARC_AMD_OK;
+}
+
 // FASTQ text already in device memory -> the context's clean reads (2-bit) and N reads (3-bit); the original indices of the N reads
 // (read_order_N.bin, u32 each) are returned through harc_amd_get_stream(HARC_AMD_IN_ORDER_N)
 extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes, uint64_t *n_records_out)
@@ -96,30 +123,11 @@ extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uin
     }
     if (nbytes == 0) { if (n_records_out) *n_records_out = 0; out_buf(c, HARC_AMD_IN_ORDER_N, 0).clear(); return HARC_AMD_OK; }
     const harc_mark_t mk = harc_pool_mark(c);
-    // line index: nls[k] = byte position of the k-th newline
-    const uint64_t ntiles = (nbytes + NL_TILE - 1) / NL_TILE;
-    uint32_t *tilecnt = nullptr; uint64_t *tilebase = nullptr;
-    RC_TRY(dalloc(c, &tilecnt, (size_t)ntiles + 1)); RC_TRY(dalloc(c, &tilebase, (size_t)ntiles + 1));
-    HIP_TRY(hipMemsetAsync(tilecnt + ntiles, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_nl_count, dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_txt, nbytes, tilecnt);
-    RC_TRY(prim_excl_scan_u32_to_u64(c, tilecnt, tilebase, (size_t)ntiles + 1));
-    uint64_t nlines = 0; char lastch = 0;
-    HIP_TRY(hipMemcpyAsync(&nlines, tilebase + ntiles, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&lastch, d_txt + nbytes - 1, 1, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    uint64_t *nl = nullptr; RC_TRY(dalloc(c, &nl, (size_t)nlines + 8));
-    hipLaunchKernelGGL(k_nl_write, dim3((unsigned)ntiles), dim3(256), 0, c->stream, d_txt, nbytes, (const uint64_t *)tilebase, nl + 1);
-    uint64_t total_lines = nlines;
-    if (lastch != '\n') {                                         // last line without a newline: it ends at nbytes
-        HIP_TRY(hipMemcpyAsync(nl + 1 + nlines, &nbytes, 8, hipMemcpyHostToDevice, c->stream));
-        total_lines++;
-    }
+    const uint64_t *nls = nullptr; uint64_t total_lines = 0;
+    RC_TRY(build_line_index(c, d_txt, nbytes, &nls, &total_lines));
     const uint64_t nrec64 = total_lines / 4;                      // a trailing partial record is ignored, as by the getline loop
     if (nrec64 > 4294967290ull) { harc_set_error("Too many reads. HARC supports at most 4294967290 reads"); harc_pool_release(c, mk); return HARC_AMD_EINVAL; }   // preprocess.cpp:122-126
     const uint32_t nrec = (uint32_t)nrec64;
-    // record r: sequence between nl'[4r+1] and nl'[4r+2] in the shifted array => pass nl+? : k_classify expects nl[4r] = newline before the
-    // sequence line = end of line 4r = shifted index 4r+1
-    const uint64_t *nls = nl + 1;
     uint32_t *isN = nullptr, *isC = nullptr, *rkN = nullptr, *rkC = nullptr; unsigned int *d_err = nullptr;
     RC_TRY(dalloc(c, &isN, (size_t)nrec + 1)); RC_TRY(dalloc(c, &isC, (size_t)nrec + 1)); RC_TRY(dalloc(c, &rkN, (size_t)nrec + 1)); RC_TRY(dalloc(c, &rkC, (size_t)nrec + 1));
     RC_TRY(dalloc(c, &d_err, 4));
@@ -156,8 +164,151 @@ extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uin
     return HARC_AMD_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ -q: ids and quality values
+// preprocess.cpp:61-118 + reorder_quality.cpp as gathers over the line index.  `rec[p]` names the record whose
+// line `k` (0 = id, 3 = quality) becomes output line p.
+__global__ void k_q_idflags(const uint32_t *isN, uint32_t nid, uint32_t *idC, uint32_t *idN)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nid) return;
+    const uint32_t prevN = r ? isN[r - 1] : 0u;                    // preprocess.cpp:83-88 runs before :98-110 of the same record
+    idC[r] = prevN ? 0u : 1u; idN[r] = prevN;
+}
+__global__ void k_q_compact(const uint32_t *flag, const uint32_t *rank, uint32_t n, uint32_t *out)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && flag[r]) out[rank[r]] = r;
+}
+__global__ void k_q_gather(const uint32_t *src, uint32_t nsrc, const uint32_t *order, uint32_t n, uint32_t *out, unsigned int *err)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t o = order[p];
+    if (o >= nsrc) { atomicAdd(err, 1u); out[p] = 0; return; }
+    out[p] = src[o];
+}
+__global__ void k_q_iota(uint32_t *out, uint32_t n) { const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; if (p < n) out[p] = p; }
+__global__ void k_q_linelen(const uint64_t *nls, const uint32_t *rec, uint32_t n, int k, int want, uint32_t *len, unsigned int *err)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int64_t li = 4ll * rec[p] + k;
+    const uint64_t l = nls[li] - (nls[li - 1] + 1);
+    if (want >= 0 && l != (uint64_t)want) atomicAdd(err, 1u);      // reorder_quality.cpp:78-79 reads quality values at a (readlen+1) stride
+    len[p] = (uint32_t)l + 1;
+}
+// one wave per output line
+__global__ __launch_bounds__(256) void k_q_copy(const char *txt, const uint64_t *nls, const uint32_t *rec, const uint64_t *off, uint32_t n, int k, char *out)
+{
+    const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t li = 4ll * rec[p] + k;
+    const uint64_t s = nls[li - 1] + 1, l = nls[li] - s;
+    char *o = out + off[p];
+    for (uint64_t j = lane; j < l; j += 64) o[j] = txt[s + j];
+    if (lane == 0) o[l] = '\n';
+}
+
+static int emit_lines(harc_amd_ctx *c, const char *d_txt, const uint64_t *nls, const uint32_t *rec, uint64_t n, int k, int want, FILE *fo)
+{
+    const uint32_t CH = 1u << 23;
+    unsigned int *d_err = nullptr; RC_TRY(dalloc(c, &d_err, 4));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 16, c->stream));
+    std::vector<uint8_t> host;
+    for (uint64_t at = 0; at < n; at += CH) {
+        const harc_mark_t mk = harc_pool_mark(c);
+        const uint32_t m = (uint32_t)(n - at < CH ? n - at : CH);
+        uint32_t *len = nullptr; uint64_t *off = nullptr;
+        RC_TRY(dalloc(c, &len, (size_t)m + 1)); RC_TRY(dalloc(c, &off, (size_t)m + 1));
+        HIP_TRY(hipMemsetAsync(len + m, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_q_linelen, G256(m), nls, rec + at, m, k, want, len, d_err);
+        RC_TRY(prim_excl_scan_u32_to_u64(c, len, off, (size_t)m + 1));
+        uint64_t total = 0; unsigned int err = 0;
+        HIP_TRY(hipMemcpyAsync(&total, off + m, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (err) { harc_set_error("-q without -p needs quality lines of exactly readlen characters (%u differ)", err); harc_pool_release(c, mk); return HARC_AMD_EINVAL; }
+        char *out = nullptr; RC_TRY(dalloc(c, &out, (size_t)total + 16));
+        hipLaunchKernelGGL(k_q_copy, dim3((m + 3) / 4), dim3(256), 0, c->stream, d_txt, nls, rec + at, (const uint64_t *)off, m, k, out);
+        RC_TRY(harc_d2h(c, host, out, (size_t)total));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        harc_pool_release(c, mk);
+        if (total && fwrite(host.data(), 1, (size_t)total, fo) != (size_t)total) { harc_set_error("short write"); return HARC_AMD_EIO; }
+    }
+    return HARC_AMD_OK;
+}
+
+static int emit_quality_and_ids(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes, bool preserve_order, const std::string &od)
+{
+    FILE *fq = fopen((od + "output.quality").c_str(), "wb"), *fi = fopen((od + "output.id").c_str(), "wb");
+    struct Closer { FILE *a, *b; ~Closer() { if (a) fclose(a); if (b) fclose(b); } } closer{ fq, fi };
+    if (!fq || !fi) { harc_set_error("cannot create %soutput.quality / output.id", od.c_str()); return HARC_AMD_EIO; }
+    if (nbytes == 0) return HARC_AMD_OK;
+    const int L = c->P.readlen;
+    const harc_mark_t mk = harc_pool_mark(c);
+    struct Rel { harc_amd_ctx *c; harc_mark_t mk; ~Rel() { harc_pool_release(c, mk); } } rel{ c, mk };
+    const uint64_t *nls = nullptr; uint64_t total_lines = 0;
+    RC_TRY(build_line_index(c, d_txt, nbytes, &nls, &total_lines));
+    const uint32_t nrec = (uint32_t)(total_lines / 4);
+    const uint32_t nid = nrec + (total_lines % 4 ? 1u : 0u);       // the id line of a truncated last record is still written (case 0 of the getline loop)
+    if (preserve_order) {                                          // preprocess.cpp:64-69: both files in file order
+        uint32_t *rec = nullptr; RC_TRY(dalloc(c, &rec, (size_t)nid + 1));
+        hipLaunchKernelGGL(k_q_iota, G256((size_t)nid + 1), rec, nid + 1);
+        RC_TRY(emit_lines(c, d_txt, nls, rec, nrec, 3, -1, fq));
+        RC_TRY(emit_lines(c, d_txt, nls, rec, nid, 0, -1, fi));
+        return HARC_AMD_OK;
+    }
+    const void *ho = nullptr, *hn = nullptr; size_t ho_len = 0, hn_len = 0;
+    RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_ORDER, 0, &ho, &ho_len)); RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_ORDER_N_PE, 0, &hn, &hn_len));
+    const uint32_t nC = c->N, nN = c->NN;
+    if (ho_len != (size_t)nC * 4 || hn_len != (size_t)nN * 4) { harc_set_error("-q: order streams do not match the read counts"); return HARC_AMD_ESTATE; }
+    uint32_t *isN, *isC, *rk, *idC, *idN, *cleanrec, *nrecs, *idcrec, *idnrec, *d_ord, *d_ordn, *qrec, *irec; unsigned int *d_err;
+    RC_TRY(dalloc(c, &isN, (size_t)nid + 1)); RC_TRY(dalloc(c, &isC, (size_t)nid + 1)); RC_TRY(dalloc(c, &rk, (size_t)nid + 2));
+    RC_TRY(dalloc(c, &idC, (size_t)nid + 1)); RC_TRY(dalloc(c, &idN, (size_t)nid + 1));
+    RC_TRY(dalloc(c, &cleanrec, (size_t)nC + 1)); RC_TRY(dalloc(c, &nrecs, (size_t)nN + 1)); RC_TRY(dalloc(c, &idcrec, (size_t)nid + 1)); RC_TRY(dalloc(c, &idnrec, (size_t)nid + 1));
+    RC_TRY(dalloc(c, &d_ord, (size_t)nC + 1)); RC_TRY(dalloc(c, &d_ordn, (size_t)nN + 1)); RC_TRY(dalloc(c, &qrec, (size_t)nC + nN + 1)); RC_TRY(dalloc(c, &irec, (size_t)nC + nid + 1));
+    RC_TRY(dalloc(c, &d_err, 4));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 16, c->stream));
+    HIP_TRY(hipMemsetAsync(isN, 0, ((size_t)nid + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(isC, 0, ((size_t)nid + 1) * 4, c->stream));
+    if (nrec) hipLaunchKernelGGL(k_classify, G256(nrec), d_txt, nls, nrec, L, isN, isC, d_err);
+    if (nC) HIP_TRY(hipMemcpyAsync(d_ord, ho, ho_len, hipMemcpyHostToDevice, c->stream));
+    if (nN) HIP_TRY(hipMemcpyAsync(d_ordn, hn, hn_len, hipMemcpyHostToDevice, c->stream));
+    // quality: clean records gathered by read_order.bin, then N records gathered by read_order_N_pe.bin (reorder_quality.cpp:47-133)
+    RC_TRY(prim_excl_scan_u32(c, isC, rk, (size_t)nrec + 1));
+    if (nrec) hipLaunchKernelGGL(k_q_compact, G256(nrec), isC, rk, nrec, cleanrec);
+    RC_TRY(prim_excl_scan_u32(c, isN, rk, (size_t)nrec + 1));
+    if (nrec) hipLaunchKernelGGL(k_q_compact, G256(nrec), isN, rk, nrec, nrecs);
+    if (nC) hipLaunchKernelGGL(k_q_gather, G256(nC), cleanrec, nC, d_ord, nC, qrec, d_err);
+    if (nN) hipLaunchKernelGGL(k_q_gather, G256(nN), nrecs, nN, d_ordn, nN, qrec + nC, d_err);
+    // ids: routed by the PREVIOUS record's N flag; the clean list gathered by read_order.bin, the N list appended as it is
+    // (reorder_id_N writes its result over input_N.quality, reorder_quality.cpp:208, so reorder_id appends input_N.id untouched, :181)
+    uint32_t nidC = 0, nidN = 0;
+    if (nid) {
+        hipLaunchKernelGGL(k_q_idflags, G256(nid), isN, nid, idC, idN);
+        HIP_TRY(hipMemsetAsync(idC + nid, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(idN + nid, 0, 4, c->stream));
+        RC_TRY(prim_excl_scan_u32(c, idC, rk, (size_t)nid + 1));
+        hipLaunchKernelGGL(k_q_compact, G256(nid), idC, rk, nid, idcrec);
+        HIP_TRY(hipMemcpyAsync(&nidC, rk + nid, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        RC_TRY(prim_excl_scan_u32(c, idN, rk, (size_t)nid + 1));
+        hipLaunchKernelGGL(k_q_compact, G256(nid), idN, rk, nid, idnrec);
+        nidN = nid - nidC;
+    }
+    if (nC) hipLaunchKernelGGL(k_q_gather, G256(nC), idcrec, nidC, d_ord, nC, irec, d_err);
+    if (nidN) HIP_TRY(hipMemcpyAsync(irec + nC, idnrec, (size_t)nidN * 4, hipMemcpyDeviceToDevice, c->stream));
+    unsigned int err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err) { harc_set_error("-q: order files and FASTQ disagree (%u entries)", err); return HARC_AMD_ESTATE; }
+    RC_TRY(emit_lines(c, d_txt, nls, qrec, (uint64_t)nC + nN, 3, L, fq));
+    RC_TRY(emit_lines(c, d_txt, nls, irec, (uint64_t)nC + nidN, 0, -1, fi));
+    return HARC_AMD_OK;
+}
+
 // FASTQ file -> every stage-II file under <basedir>/output (+ read_order_N.bin, numreads.bin): harc:50-69 without input_clean.dna
-extern "C" int harc_amd_compress_fastq_files(const harc_amd_params *params, const char *fastq, const char *basedir)
+extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order, int32_t preserve_quality)
 {
     if (!params || !fastq || !basedir) return HARC_AMD_EINVAL;
     harc_amd_ctx *c = nullptr;
@@ -188,7 +339,7 @@ extern "C" int harc_amd_compress_fastq_files(const harc_amd_params *params, cons
     fclose(f);
     uint64_t nrec = 0;
     int rc = harc_amd_set_fastq_device(c, d_txt, (uint64_t)fsz, &nrec);
-    harc_raw_free(c, d_txt);
+    if (!preserve_quality || rc != HARC_AMD_OK) { harc_raw_free(c, d_txt); d_txt = nullptr; }
     if (rc != HARC_AMD_OK) return rc;
     printf("Read length: %d\nTotal number of reads: %llu\nTotal number of reads without N: %llu\nPreprocessing Done!\n", params->readlen,
            (unsigned long long)nrec, (unsigned long long)c->N);                                           // preprocess.cpp:133-136
@@ -222,5 +373,15 @@ extern "C" int harc_amd_compress_fastq_files(const harc_amd_params *params, cons
         { HARC_AMD_S2_ORDER, "read_order.bin" }, { HARC_AMD_S2_ORDER_N_PE, "read_order_N_pe.bin" }, { HARC_AMD_S2_INPUT_N, "input_N.dna" },
         { HARC_AMD_S2_META, "read_meta.txt" }, { HARC_AMD_S2_SINGLETON, "read_singleton.txt" }, { HARC_AMD_S2_SINGLETON_TAIL, "read_singleton.txt.tail" } };
     for (auto &fd : whole) { const void *p; size_t n; RC_TRY(harc_amd_get_stream(c, fd.id, 0, &p, &n)); RC_TRY(spit(fd.name, p, n)); }
+    if (preserve_quality) {
+        if (!preserve_order) printf("Reordering quality values and ids\n");                                 // harc:122
+        rc = emit_quality_and_ids(c, d_txt, (uint64_t)fsz, preserve_order != 0, od);
+        harc_raw_free(c, d_txt);
+        if (rc != HARC_AMD_OK) return rc;
+    }
     return HARC_AMD_OK;
+}
+extern "C" int harc_amd_compress_fastq_files(const harc_amd_params *params, const char *fastq, const char *basedir)
+{
+    return harc_amd_compress_fastq_files_ex(params, fastq, basedir, 0, 0);
 }

@@ -4,7 +4,8 @@
 //   harc_amd_stage compress <basedir> <readlen> [num_thr] [num_chains]     == both, stage I -> II handed over in HBM
 //   harc_amd_stage pack_order <basedir> <readlen>                          == src/pack_order.out <basedir> (harc:112)
 //   harc_amd_stage decoder <basedir> <readlen ignored> <num_thr_e>         == src/decoder.out <basedir> <num_thr> <num_thr_e> (harc:188)
-//   harc_amd_stage compressfq <basedir> <readlen> <fastq> [num_thr] [num_chains]  == preprocess + reorder + encoder, FASTQ parsed on the GPU
+//   harc_amd_stage compressfq <basedir> <readlen> <fastq> [num_thr] [num_chains] [num_steps] [preserve_order] [preserve_quality]
+//                                                                          == preprocess + reorder + encoder (+ reorder_quality), FASTQ parsed on the GPU
 //   harc_amd_stage preprocess <basedir> <readlen> <fastq>                  == src/preprocess.out <fastq> <basedir> .. <readlen> (harc:50)
 // readlen / num_thr arrive as arguments instead of the compile-time macros of src/config.h (harc:52-63).
 #include <stdio.h>
@@ -31,7 +32,8 @@ int main(int argc, char **argv)
         if (argc > 5) P.num_thr = atoi(argv[5]);
         if (argc > 6) P.num_chains = atoi(argv[6]);
         if (argc > 7) P.num_steps = atoi(argv[7]);
-        rc = harc_amd_compress_fastq_files(&P, argv[4], argv[2]);
+        const int po = argc > 8 && !strcmp(argv[8], "True"), pq = argc > 9 && !strcmp(argv[9], "True");     // preprocess.out's argv[3], argv[4] (harc:50)
+        rc = harc_amd_compress_fastq_files_ex(&P, argv[4], argv[2], po, pq);
     }
     else if (!strcmp(argv[1], "decoder_preserve")) rc = harc_amd_decoder_preserve_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1);
     else if (!strcmp(argv[1], "decoder")) rc = harc_amd_decoder_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1);

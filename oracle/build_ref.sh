@@ -7,6 +7,7 @@
 #
 #   oracle/build_ref.sh            -> tools (preprocess, decoder, pack_order, unpack_order, merge_N, generators)
 #   oracle/build_ref.sh L T        -> reorder_L<L>_t<T>.out, encoder_L<L>_t<T>.out
+#   oracle/build_ref.sh quality L     -> reorder_quality_L<L>.out (-q without -p, harc:121-124)
 #   oracle/build_ref.sh preserve L E  -> decoder_preserve_L<L>_e<E>.out (the -p decoder, harc:173-178; num_thr 1)
 set -e
 REF=${HARC_REFERENCE:-/root/reference}
@@ -22,6 +23,14 @@ if [ $# -eq 0 ]; then
   [ -x "$OUT/merge_N.out" ] || g++ "$REF/src/merge_N.cpp" -w -O3 -std=c++11 -o "$OUT/merge_N.out"
   [ -x "$OUT/gen_fastq_noRC" ] || g++ -w -std=c++11 -O3 -o "$OUT/gen_fastq_noRC" "$REF/util/gen_fastq_noRC/gen_fastq_noRC.cpp"
   [ -x "$OUT/gen_fastq" ] || g++ -w -std=c++11 -O3 -o "$OUT/gen_fastq" "$REF/util/gen_fastq/gen_fastq.cpp"
+  exit 0
+fi
+if [ "$1" = quality ]; then
+  L=$2
+  CFG="$OUT/cfgq_L${L}"
+  mkdir -p "$CFG"
+  echo "#define readlen $L" > "$CFG/config.h"
+  [ -x "$OUT/reorder_quality_L${L}.out" ] || g++ "$REF/src/reorder_quality.cpp" -I"$CFG" -w -march=x86-64-v2 -O3 -std=c++11 -o "$OUT/reorder_quality_L${L}.out"   # harc:123
   exit 0
 fi
 if [ "$1" = preserve ]; then

@@ -846,3 +846,65 @@ int harc_oracle_preprocess(const char *reads_txt, size_t len, int L, const char 
     free(clean.v); free(withN.v); free(orderN.v);
     return 0;
 }
+
+/* ------------------------------------------------------------------ -q: ids and quality values (preprocess.cpp:61-118, reorder_quality.cpp)
+ * fastq: the whole FASTQ text.  preserve_order != 0: output.id / output.quality are lines 1 and 4 of every record in file order
+ * (preprocess.cpp:64-69: both "final" files are written directly).  preserve_order == 0: preprocess splits the lines into clean / N
+ * files, then reorder_quality.out gathers them by the post-encoding orders:
+ *     output.quality = quality_clean[read_order.bin[p]] for every p, then quality_N[read_order_N_pe.bin[i]] for every i
+ *     output.id      = id_clean[read_order.bin[p]], then the N-id list AS IT IS (file order)
+ * (reorder_quality.cpp:47-98 builds reverse_index and walks it bin by bin, which is this gather; :100-133 likewise for the N part).
+ * The id side follows the reference to the letter, quirks included (pinned by tests/golden/q_*):
+ *   - the id line is routed by flag_N BEFORE the record's own sequence line has updated it (preprocess.cpp:83-88 vs :98-110), i.e.
+ *     by whether the PREVIOUS record had an N;
+ *   - reorder_id_N writes its permuted ids to `infile_N` = input_N.quality, not to input_N.id (reorder_quality.cpp:208), so
+ *     reorder_id appends input_N.id unpermuted (:181).
+ * Returns -2 where the reference itself divides by zero (numreads/4 or numreads/8 == 0, reorder_quality.cpp:61,151). */
+typedef struct { const char *p; size_t n; } span;
+int harc_oracle_quality(const char *fastq, size_t len, int L, int preserve_order, const char *basedir)
+{
+    size_t nlines = 0, cap = 1024; span *ln = malloc(cap * sizeof(span));
+    for (size_t s = 0; s < len;) {
+        const char *e = memchr(fastq + s, '\n', len - s);
+        size_t n = e ? (size_t)(e - (fastq + s)) : len - s;
+        if (nlines == cap) { cap *= 2; ln = realloc(ln, cap * sizeof(span)); }
+        ln[nlines].p = fastq + s; ln[nlines].n = n; nlines++;
+        s += n + 1;
+    }
+    const size_t nrec = nlines / 4;
+    bytes oq = { 0 }, oi = { 0 };
+    int rc = 0;
+    if (preserve_order) {
+        for (size_t r = 0; r < nrec; r++) {
+            bput(&oi, ln[4 * r].p, ln[4 * r].n); bputc(&oi, '\n');
+            bput(&oq, ln[4 * r + 3].p, ln[4 * r + 3].n); bputc(&oq, '\n');
+        }
+        /* a dangling id line of a truncated last record is still written by the getline loop (case 0 runs before EOF is met) */
+        if (nlines % 4 >= 1) { bput(&oi, ln[4 * nrec].p, ln[4 * nrec].n); bputc(&oi, '\n'); }
+    } else {
+        span *qc = malloc((nrec + 1) * sizeof(span)), *qn = malloc((nrec + 1) * sizeof(span)), *ic = malloc((nrec + 2) * sizeof(span)), *in = malloc((nrec + 2) * sizeof(span));
+        size_t nqc = 0, nqn = 0, nic = 0, nin = 0; int flag_N = 0;
+        for (size_t r = 0; r < nrec; r++) {
+            if (!flag_N) ic[nic++] = ln[4 * r]; else in[nin++] = ln[4 * r];          /* preprocess.cpp:83-88: flag_N of the previous record */
+            flag_N = memchr(ln[4 * r + 1].p, 'N', ln[4 * r + 1].n) != NULL;             /* :98-110 */
+            if (ln[4 * r + 3].n != (size_t)L) rc = -3;                                 /* reorder_quality.cpp:78-79 assumes the (readlen+1) stride */
+            if (!flag_N) qc[nqc++] = ln[4 * r + 3]; else qn[nqn++] = ln[4 * r + 3];     /* :112-117 */
+        }
+        if (nlines % 4 >= 1) { if (!flag_N) ic[nic++] = ln[4 * nrec]; else in[nin++] = ln[4 * nrec]; }   /* id line of a truncated last record */
+        size_t no, nno; uint8_t *ob = slurp(basedir, "read_order.bin", &no), *nb = slurp(basedir, "read_order_N_pe.bin", &nno);
+        const uint32_t *ord = (const uint32_t *)ob, *ordn = (const uint32_t *)nb;
+        const size_t numreads = nqc, numreads_N = nqn;                               /* getDataParams, reorder_quality.cpp:221-237 */
+        if (numreads / 8 == 0) rc = -2;
+        if (no / 4 != numreads || nno / 4 != numreads_N) rc = rc ? rc : -4;
+        if (rc == 0) {
+            for (size_t p = 0; p < numreads; p++) { bput(&oq, qc[ord[p]].p, qc[ord[p]].n); bputc(&oq, '\n'); }
+            for (size_t i = 0; i < numreads_N; i++) { bput(&oq, qn[ordn[i]].p, qn[ordn[i]].n); bputc(&oq, '\n'); }
+            for (size_t p = 0; p < numreads; p++) { bput(&oi, ic[ord[p]].p, ic[ord[p]].n); bputc(&oi, '\n'); }      /* nic >= numreads always */
+            for (size_t i = 0; i < nin; i++) { bput(&oi, in[i].p, in[i].n); bputc(&oi, '\n'); }                          /* f << f_N.rdbuf(), :181 */
+        }
+        free(ob); free(nb); free(qc); free(qn); free(ic); free(in);
+    }
+    if (rc == 0) { spit(basedir, "output.quality", oq.v, oq.n, "wb"); spit(basedir, "output.id", oi.v, oi.n, "wb"); }
+    free(oq.v); free(oi.v); free(ln);
+    return rc;
+}

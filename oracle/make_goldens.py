@@ -151,7 +151,72 @@ def make_case(name, kw):
         shutil.rmtree(wd)
 
 
+# -q cases: ids and quality values (preprocess.cpp:61-118, reorder_quality.cpp).  Each fixture holds in.fastq, p/output.{quality,id}
+# (preprocess.out <fastq> <dir> True True L) and np/output.{quality,id} + the two order files reorder_quality.out consumed
+# (preprocess False True -> reorder -> encoder at num_thr=1 -> reorder_quality.out).
+QCASES = {
+    "q_L100_lastN_1500": dict(seed=21, n=1500, L=100, genome_len=9000, err=0.004, last="N"),
+    "q_L100_lastclean_1500": dict(seed=22, n=1500, L=100, genome_len=9000, err=0.004, last="clean"),
+    "q_L63_1200": dict(seed=23, n=1200, L=63, genome_len=5000, err=0.006, last="clean"),
+}
+
+
+def make_qcase(name, kw):
+    L = kw["L"]
+    last = kw["last"]
+    kw = {k: v for k, v in kw.items() if k != "last"}
+    subprocess.check_call([os.path.join(HERE, "build_ref.sh")])
+    subprocess.check_call([os.path.join(HERE, "build_ref.sh"), str(L), "1"])
+    subprocess.check_call([os.path.join(HERE, "build_ref.sh"), "quality", str(L)])
+    reads = gen_reads(**kw)
+    rs = np.random.RandomState(kw["seed"] + 1000)
+    if last == "N":
+        reads[-1] = reads[-1][:10] + "N" + reads[-1][11:]
+    else:
+        reads[-1] = reads[-1].replace("N", "A")
+    recs = []
+    for i, r in enumerate(reads):
+        q = "".join("#" if c == "N" else "FHJ5"[rs.randint(0, 4)] for c in r)
+        rid = "@SRR%d.%d %s/%d" % (kw["seed"], i, "x" * rs.randint(0, 9), 1 + (i & 1))
+        recs.append(f"{rid}\n{r}\n+\n{q}\n")
+    fastq = "".join(recs).encode()
+    out = {}
+    for mode, po in (("p", "True"), ("np", "False")):
+        wd = tempfile.mkdtemp(prefix="harc_goldq_")
+        try:
+            os.makedirs(os.path.join(wd, "output"))
+            fq = os.path.join(wd, "in.fastq")
+            with open(fq, "wb") as f:
+                f.write(fastq)
+            run([os.path.join(REF, "preprocess.out"), fq, wd, po, "True", str(L)], wd)
+            if mode == "np":
+                run([os.path.join(REF, f"reorder_L{L}_t1.out"), wd], wd)
+                run([os.path.join(REF, f"encoder_L{L}_t1.out"), wd], wd)
+                run([os.path.join(REF, f"reorder_quality_L{L}.out"), wd], wd)
+                for f in ("read_order.bin", "read_order_N_pe.bin"):
+                    out[mode + "/" + f] = open(os.path.join(wd, "output", f), "rb").read()
+            for f in ("output.quality", "output.id"):
+                out[mode + "/" + f] = open(os.path.join(wd, "output", f), "rb").read()
+        finally:
+            shutil.rmtree(wd)
+    tarpath = os.path.join(GOLD, name + ".tar.xz")
+    with tarfile.open(tarpath, "w:xz", preset=9) as tf:
+        def add(arc, data):
+            ti = tarfile.TarInfo(arc)
+            ti.size = len(data)
+            ti.mtime = 0
+            tf.addfile(ti, io.BytesIO(data))
+        add("in.fastq", fastq)
+        for k, v in out.items():
+            add(k, v)
+        add("meta.json", json.dumps(dict(name=name, L=L, n_reads=len(reads), gen=kw, last=last), indent=1).encode())
+    print(name, os.path.getsize(tarpath), "bytes")
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or (list(CASES) + list(QCASES))
     for n in names:
-        make_case(n, CASES[n])
+        if n in QCASES:
+            make_qcase(n, QCASES[n])
+        else:
+            make_case(n, CASES[n])

@@ -27,13 +27,19 @@ def load():
     lib.harc_oracle_pack_order.argtypes = [C.c_char_p]
     lib.harc_oracle_decoder.argtypes = [C.c_char_p, C.c_uint32]
     lib.harc_oracle_preprocess.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p]
+    lib.harc_oracle_quality.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p]
     lib.harc_oracle_stage1_mem.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, u32p, u8p, u8p, u8p, u32p, u32p, u32p, u32p, u64p]
     _lib = lib
     return lib
 
 
 def golden_cases():
-    return sorted(f[:-7] for f in os.listdir(GOLDEN_DIR) if f.endswith(".tar.xz"))
+    return sorted(f[:-7] for f in os.listdir(GOLDEN_DIR) if f.endswith(".tar.xz") and not f.startswith("q_"))
+
+
+def quality_cases():
+    """-q fixtures (ids + quality values), oracle/make_goldens.py QCASES"""
+    return sorted(f[:-7] for f in os.listdir(GOLDEN_DIR) if f.endswith(".tar.xz") and f.startswith("q_"))
 
 
 def load_golden(name):

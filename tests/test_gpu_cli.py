@@ -59,3 +59,31 @@ def test_harc_refuses_existing_output_dir(tmp_path):
     (tmp_path / "output").mkdir()
     r = subprocess.run([os.path.join(ROOT, "harc"), "-c", str(fq)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 1 and "already exists" in r.stdout                                   # harc:38-41
+
+
+@pytest.mark.parametrize("flags", [["-q", "-t", "2"], ["-p", "-q", "-t", "3"]])
+def test_harc_q_writes_quality_and_ids(flags, tmp_path):
+    """-q: <name>.quality and <name>.id next to the archive (harc:116-128); in file order with -p, else lined up with ./harc -d"""
+    import numpy as np
+    L = 100
+    reads = gen.reads_text(7, 12000, L, 90000, err=0.01).split()
+    rs = np.random.RandomState(3)
+    quals = [bytes(35 if c == 78 else 50 + int(x) for c, x in zip(r, rs.randint(0, 20, L))) for r in reads]
+    ids = [b"@run.%d/%d" % (i, 1 + i % 2) for i in range(len(reads))]
+    fq = tmp_path / "s.fastq"
+    fq.write_bytes(b"".join(b"%s\n%s\n+\n%s\n" % t for t in zip(ids, reads, quals)))
+    r = subprocess.run([os.path.join(ROOT, "harc"), "-c", str(fq)] + flags, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    q = (tmp_path / "s.quality").read_bytes().split(b"\n")[:-1]
+    i = (tmp_path / "s.id").read_bytes().split(b"\n")[:-1]
+    assert not (tmp_path / "output").exists()
+    if "-p" in flags:
+        assert q == quals and i == ids
+        return
+    assert sorted(q) == sorted(quals) and len(i) == len(ids)
+    r = subprocess.run([os.path.join(ROOT, "harc"), "-d", str(tmp_path / "s.harc")], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    dec = (tmp_path / "s.dna.d").read_bytes().split()
+    da = np.frombuffer(b"".join(dec), dtype=np.uint8).reshape(-1, L)
+    qa = np.frombuffer(b"".join(q), dtype=np.uint8).reshape(-1, L)
+    assert ((da == ord("N")) == (qa == ord("#"))).all()

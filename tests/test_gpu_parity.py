@@ -374,3 +374,73 @@ def test_fastq_ingest_edge_cases(tmp_path):
     got = ol.read_dir(base)
     assert got["numreads.bin"] == (1).to_bytes(4, "little") and got["read_order_N.bin"] == (1).to_bytes(4, "little")
     assert got["input_N.dna"] == b"ACNTACGTAC\n"
+
+
+# ------------------------------------------------------------------------------------------------ -q
+@pytest.mark.parametrize("case", ol.quality_cases())
+def test_quality_ids_match_reference_golden(case, tmp_path):
+    """K=1, E=1 gives the reference's own orders, so output.quality / output.id must be the REAL reference's bytes (reorder_quality.out
+    after preprocess / reorder / encoder at num_thr=1), and with -p the files preprocess.out writes directly"""
+    import json
+    import harc_amd
+    g = ol.load_golden(case)
+    L = json.loads(g["meta.json"])["L"]
+    for mode, po in (("np", False), ("p", True)):
+        d = tmp_path / mode
+        os.makedirs(d / "output")
+        (d / "in.fastq").write_bytes(g["in.fastq"])
+        harc_amd.compress_fastq(str(d / "in.fastq"), str(d), L, num_thr=1, num_chains=1, num_steps=16, preserve_order=po, preserve_quality=True)
+        got = ol.read_dir(str(d))
+        if not po:
+            assert got["read_order.bin"] == g["np/read_order.bin"] and got["read_order_N_pe.bin"] == g["np/read_order_N_pe.bin"]
+        assert got["output.quality"] == g[mode + "/output.quality"], mode
+        assert got["output.id"] == g[mode + "/output.id"], mode
+
+
+@pytest.mark.parametrize("K,S,E,trunc", [(7, 16, 3, 0), (64, 8, 2, 1), (3, 4, 8, 2)])
+def test_quality_ids_match_oracle_any_schedule(K, S, E, trunc, oracle, tmp_path):
+    """other (K, S, E): the gather must follow this run's own orders -- checked against the oracle's restatement fed with the
+    GPU's order files; trunc: the FASTQ ends in a partial record (1 = dangling id line, 2 = id + sequence, no newline at the end)"""
+    import harc_amd
+    L = 100
+    reads = gen.reads_text(4242, 30000, L, 200000, err=0.006).split()
+    import numpy as np
+    rs = np.random.RandomState(5)
+    recs = []
+    for i, r in enumerate(reads):
+        q = bytes(35 if c == 78 else 40 + int(x) for c, x in zip(r, rs.randint(0, 30, L)))
+        recs.append(b"@id.%d %s\n%s\n+\n%s\n" % (i, b"y" * int(rs.randint(0, 12)), r, q))
+    fq = b"".join(recs)
+    if trunc == 1:
+        fq += b"@dangling id\n"
+    elif trunc == 2:
+        fq += b"@dangling id\n" + reads[0][:50]
+    (tmp_path / "in.fastq").write_bytes(fq)
+    os.makedirs(tmp_path / "output")
+    harc_amd.compress_fastq(str(tmp_path / "in.fastq"), str(tmp_path), L, num_thr=E, num_chains=K, num_steps=S, preserve_quality=True)
+    got = ol.read_dir(str(tmp_path))
+    o = tmp_path / "o"
+    ol.stage_dir(o, {f: got[f] for f in ("read_order.bin", "read_order_N_pe.bin")})
+    assert oracle.harc_oracle_quality(fq, len(fq), L, 0, str(o).encode()) == 0
+    exp = ol.read_dir(str(o))
+    assert got["output.quality"] == exp["output.quality"]
+    assert got["output.id"] == exp["output.id"]
+    # and it is a permutation of the input's quality lines that lines up with the decoded reads
+    harc_amd.decoder(str(tmp_path), E)
+    dec = ol.read_dir(str(tmp_path))["output.dna"].split()
+    ql = got["output.quality"].split(b"\n")[:-1]
+    assert len(dec) == len(ql) == len(reads)
+    da = np.frombuffer(b"".join(dec), dtype=np.uint8).reshape(-1, L)
+    qa = np.frombuffer(b"".join(ql), dtype=np.uint8).reshape(-1, L)
+    assert ((da == ord("N")) == (qa == ord("#"))).all()            # quality line p belongs to decoded read p
+    assert sorted(ql) == sorted(r.split(b"\n")[3] for r in recs)
+
+
+def test_quality_wrong_length_rejected(tmp_path):
+    import harc_amd
+    reads = gen.reads_text(1, 2000, 100, 20000).split()
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"H" * (99 if i == 700 else 100)) for i, r in enumerate(reads))
+    (tmp_path / "in.fastq").write_bytes(fq)
+    os.makedirs(tmp_path / "output")
+    with pytest.raises(harc_amd.HarcAmdError):
+        harc_amd.compress_fastq(str(tmp_path / "in.fastq"), str(tmp_path), 100, preserve_quality=True)

@@ -67,3 +67,38 @@ def test_pack_order_and_decoder(case, oracle, tmp_path):
         assert got["read_order.bin.tail"] == g["packed/read_order.bin.tail"]
     else:
         assert oracle.harc_oracle_pack_order(base.encode()) == -3
+
+
+@pytest.mark.parametrize("case", ol.quality_cases())
+def test_quality_and_ids_match_reference(case, oracle, tmp_path):
+    """-q: oracle restatement of preprocess.cpp:61-118 + reorder_quality.cpp == the reference's output.quality / output.id,
+    with -p (file order) and without (gathered by the post-encoding orders, id routed by the previous record's N flag)"""
+    import json
+    g = ol.load_golden(case)
+    L = json.loads(g["meta.json"])["L"]
+    fq = g["in.fastq"]
+    base = ol.stage_dir(tmp_path / "p", {})
+    assert oracle.harc_oracle_quality(fq, len(fq), L, 1, base.encode()) == 0
+    got = ol.read_dir(base)
+    assert got["output.quality"] == g["p/output.quality"] and got["output.id"] == g["p/output.id"]
+    base = ol.stage_dir(tmp_path / "np", {f: g["np/" + f] for f in ("read_order.bin", "read_order_N_pe.bin")})
+    assert oracle.harc_oracle_quality(fq, len(fq), L, 0, base.encode()) == 0
+    got = ol.read_dir(base)
+    assert got["output.quality"] == g["np/output.quality"], "quality"
+    assert got["output.id"] == g["np/output.id"], "id"
+
+
+def test_quality_full_pipeline_orders_match_reference(oracle, tmp_path):
+    """the order files inside the -q fixture are what the oracle pipeline (K=1, E=1) produces from the same FASTQ"""
+    import json
+    case = ol.quality_cases()[0]
+    g = ol.load_golden(case)
+    L = json.loads(g["meta.json"])["L"]
+    lines = g["in.fastq"].split(b"\n")
+    reads = b"".join(l + b"\n" for l in lines[1::4])
+    base = ol.stage_dir(tmp_path, {})
+    assert oracle.harc_oracle_preprocess(reads, len(reads), L, base.encode()) == 0
+    assert oracle.harc_oracle_reorder(base.encode(), L, 1, 16, None, None) == 0
+    assert oracle.harc_oracle_encoder(base.encode(), L, 1, None, None) == 0
+    got = ol.read_dir(base)
+    assert got["read_order.bin"] == g["np/read_order.bin"] and got["read_order_N_pe.bin"] == g["np/read_order_N_pe.bin"]
