@@ -444,3 +444,92 @@ def test_quality_wrong_length_rejected(tmp_path):
     os.makedirs(tmp_path / "output")
     with pytest.raises(harc_amd.HarcAmdError):
         harc_amd.compress_fastq(str(tmp_path / "in.fastq"), str(tmp_path), 100, preserve_quality=True)
+
+
+# ------------------------------------------------------------------------------------------------ against the REAL reference's programs
+# oracle/_ref/*.out are the reference's own sources compiled by oracle/build_ref.sh (they travel to the GPU box as binaries).
+_REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+
+
+def _ref_exe(name):
+    p = os.path.join(_REF, name)
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref/%s not built" % name)
+    return p
+
+
+def _run_ref(exe, *args, cwd):
+    import subprocess
+    subprocess.run([exe] + [str(a) for a in args], cwd=str(cwd), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
+
+
+@pytest.mark.parametrize("K,S", [(64, 16), (500, 8)])
+def test_P4_reference_encoder_on_gpu_stage1_files(K, S, oracle, tmp_path):
+    """the 7 stage-I files of a K-chain GPU run, fed to the REAL encoder.out (-t 1), give byte-identical stage-II
+    streams to the GPU encoder at E=1"""
+    import shutil
+    import harc_amd
+    L = 100
+    enc = _ref_exe("encoder_L100_t1.out")
+    txt = gen.reads_text(31, 60000, L, 400000, err=0.008)
+    a, b = tmp_path / "a", tmp_path / "b"
+    ol.stage_dir(a, {})
+    assert oracle.harc_oracle_preprocess(txt, len(txt), L, str(a).encode()) == 0
+    harc_amd.reorder(str(a), L, num_thr=1, num_chains=K, num_steps=S)
+    shutil.copytree(a, b)
+    harc_amd.encoder(str(a), L, num_thr=1)
+    _run_ref(enc, b, cwd=b)
+    ga, gb = ol.read_dir(str(a)), ol.read_dir(str(b))
+    for f in ol.stage2_files(1):
+        assert ga[f] == gb[f], f
+
+
+@pytest.mark.parametrize("K,E", [(0, 8), (33, 3)])
+def test_P3_reference_decoder_reads_our_archives(K, E, tmp_path):
+    """streams written by this build (any K, E) are decoded by the REAL decoder.out to the same bytes as by
+    harc_amd_decoder_files, and to the input multiset"""
+    import shutil
+    import harc_amd
+    L = 100
+    dec = _ref_exe("decoder.out")
+    reads = gen.reads_text(32, 80000, L, 500000, err=0.01).split()
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(_fastq(reads, L))
+    a, b = tmp_path / "a", tmp_path / "b"
+    os.makedirs(a / "output")
+    harc_amd.compress_fastq(str(fq), str(a), L, num_thr=E, num_chains=K)
+    shutil.copytree(a, b)
+    harc_amd.decoder(str(a), E)
+    _run_ref(dec, b, 2, E, cwd=b)
+    mine, ref = (a / "output" / "output.dna").read_bytes(), (b / "output" / "output.dna").read_bytes()
+    assert mine == ref
+    assert sorted(mine.split()) == sorted(reads)
+
+
+def test_P5_stream_sizes_vs_reference_t8(tmp_path):
+    """at the default schedule the streams are not larger than the reference's own multi-threaded run by more than
+    the stated margin (xz -6 of every stage-II stream as the stand-in for bsc / 7z): GPU default <= 1.05 x reference -t 8"""
+    import lzma
+    import shutil
+    import harc_amd
+    L = 100
+    reo, enc, pre = _ref_exe("reorder_L100_t8.out"), _ref_exe("encoder_L100_t8.out"), _ref_exe("preprocess.out")
+    reads = gen.reads_text(33, 400000, L, 1500000, err=0.008).split()
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(_fastq(reads, L))
+    a, b = tmp_path / "a", tmp_path / "b"
+    os.makedirs(a / "output"); os.makedirs(b / "output")
+    harc_amd.compress_fastq(str(fq), str(a), L, num_thr=8, num_chains=0)
+    _run_ref(pre, fq, b, "False", "False", L, cwd=b)
+    _run_ref(reo, b, cwd=b)
+    _run_ref(enc, b, cwd=b)
+
+    def size(d):
+        tot = 0
+        for f, v in ol.read_dir(str(d)).items():
+            if f.startswith(("read_seq", "read_pos", "read_noise", "read_noisepos", "read_rev", "read_singleton", "input_N", "read_meta")):
+                tot += len(lzma.compress(v, preset=6))
+        return tot
+    sa, sb = size(a), size(b)
+    print("stream sizes xz-6: gpu default", sa, "reference -t 8", sb, "ratio %.3f" % (sa / sb))
+    assert sa <= 1.05 * sb
