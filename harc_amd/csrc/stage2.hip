@@ -497,8 +497,6 @@ __global__ void k_pack_order(const uint32_t *order, uint32_t ngroups, int numbit
 // ---------------------------------------------------------------------------------------------- host side
 #define G256(n) dim3((unsigned)((((uint64_t)(n)) + 255) / 256)), dim3(256), 0, c->stream
 
-static void put(harc_amd_ctx *c, int id, int shard, const uint8_t *p, size_t n) { std::vector<uint8_t> &b = out_buf(c, id, shard); b.assign(p, p + n); }
-
 int stage2_run(harc_amd_ctx *c)
 {
     const harc_amd_params &P = c->P;
