@@ -30,12 +30,15 @@ WORKLOADS = {
     "c3": (350_000_000, 100, 3_100_000_000, 0.0, "configs[2] stand-in: 350M x 100bp error-free, 3.1 Gbp i.i.d. genome (11.3x), odd reads RC"),
     "c3s": (50_000_000, 100, 443_000_000, 0.0, "configs[2] at 1/7 scale: 50M x 100bp error-free, 443 Mbp i.i.d. genome (11.3x)"),
     "c1": (1_000_000, 100, 35_000_000, 0.0, "configs[0] stand-in: 1M x 100bp error-free, 35 Mbp i.i.d. genome (2.9x)"),
+    "c4": (810_000_000, 101, 3_100_000_000, 0.01, "configs[3] stand-in on ONE GPU: 810M x 101bp, 3.1 Gbp i.i.d. genome (26x), 1% substitutions (1/4 N), odd reads RC"),
+    "c4s": (50_000_000, 101, 191_000_000, 0.01, "configs[3] at 1/16 scale: 50M x 101bp, 191 Mbp i.i.d. genome (26x), 1% substitutions (1/4 N)"),
+    "c5s": (250_000_000, 150, 194_000_000, 0.01, "configs[4] at 1/16 scale: 250M x 150bp, 194 Mbp i.i.d. genome (193x), 1% substitutions (1/4 N), -p (pack_order inside the step)"),
     "mini": (200_000, 100, 400_000, 0.005, "smoke-sized: 200k x 100bp, 0.4 Mbp genome"),
 }
 
 
-def synth_reads(n, L, G, err, seed, dev):
-    """[n, L] uint8 ASCII reads: uniform starts on an i.i.d. genome, substitutions (a quarter become N, as
+def synth_chunks(n, L, G, err, seed, dev):
+    """yields [m, L] uint8 ASCII reads, 4 M at a time: uniform starts on an i.i.d. genome, substitutions (a quarter become N, as
     gen_fastq_noRC.cpp:67-71), odd reads reverse-complemented (gen_fastq.cpp:105-113)."""
     g = torch.Generator(device=dev)
     g.manual_seed(4242 + G)                                      # the genome is the same on every rank
@@ -48,7 +51,6 @@ def synth_reads(n, L, G, err, seed, dev):
         m = min(1 << 28, G - s)
         genome[s:s + m] = lut[torch.randint(0, 4, (m,), generator=g, device=dev)]
     g.manual_seed(seed)                                          # the reads differ per rank
-    out = torch.empty((n, L), dtype=torch.uint8, device=dev)
     ar = torch.arange(L, device=dev)
     CH = 4_000_000
     for s in range(0, n, CH):
@@ -64,9 +66,12 @@ def synth_reads(n, L, G, err, seed, dev):
             r = torch.where(isN, torch.full_like(r, ord("N")), r)
         odd = (torch.arange(s, s + m, device=dev) % 2) == 1
         r = torch.where(odd[:, None], comp[r.flip(1).long()], r)
-        out[s:s + m] = r
+        yield r
     del genome
-    return out
+
+
+def synth_reads(n, L, G, err, seed, dev):
+    return torch.cat(list(synth_chunks(n, L, G, err, seed, dev)))
 
 
 def cpu_baseline(n_sample, L, G_sample, err, seed, dev):
@@ -139,35 +144,58 @@ def main():
     import harc_amd
     n, L, G, err, desc = WORKLOADS[args.workload]
     # weak scaling: same reads per GPU, genome (and so coverage) per GPU constant; every rank samples the WHOLE genome
-    reads = synth_reads(n, L, G * world, err, 1000 + rank, dev)
-    hasN = (reads == ord("N")).any(1)
-    clean = reads[~hasN].contiguous()
-    withN = reads[hasN].contiguous()
-    del reads, hasN
-    torch.cuda.synchronize()                                      # libharc_amd works on its own stream: its inputs must be complete
     p = harc_amd.default_params(L, num_thr=args.shards, num_chains=args.chains, device=local, profile=1)
     h = harc_amd.HarcAmd(p)
+    # inputs, 4 M reads at a time so that config-3/4-sized sets never exist as ASCII: clean reads are packed to 2 bits per base
+    # (k_pack2) as they are made, reads with N are kept as text for stage II; the order-independent signature of both is taken on
+    # the way (for the round-trip check after the timed region)
+    Wd = (2 * L + 63) // 64
+    packed = torch.empty((n, Wd), dtype=torch.int64, device=dev)
+    nclean, nparts = 0, []
+    sig_clean, sig_N = [0, 0, 0], [0, 0, 0]
+
+    def acc(sig, t):
+        c3 = h.reads_signature_device(t.data_ptr(), t.shape[0], L)
+        sig[0] += c3[0]; sig[1] = (sig[1] + c3[1]) % (1 << 64); sig[2] ^= c3[2]
+    for r in synth_chunks(n, L, G * world, err, 1000 + rank, dev):
+        hasN = (r == ord("N")).any(1)
+        cl = r[~hasN].contiguous()
+        wn = r[hasN].contiguous()
+        torch.cuda.synchronize()                                  # libharc_amd works on its own stream: its inputs must be complete
+        if cl.shape[0]:
+            h.pack_reads_device(cl.data_ptr(), cl.shape[0], cl.stride(0), packed[nclean:].data_ptr())
+            acc(sig_clean, cl)
+            nclean += cl.shape[0]
+        if wn.shape[0]:
+            acc(sig_N, wn)
+            nparts.append(wn)
+        del r, hasN, cl, wn
+    withN = torch.cat(nparts) if nparts else torch.empty((0, L), dtype=torch.uint8, device=dev)
+    del nparts
+    packed = packed[:nclean]
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     sharder = None
     if dist is not None:
         from harc_amd import multigpu
-        sharder = multigpu.BucketSharder(h, dist, dev, L)
-        packed = sharder.pack(clean)                              # local 2-bit reads, resident in HBM before the clock starts
-        del clean
+        sharder = multigpu.BucketSharder(h, dist, dev, L)         # local 2-bit reads stay resident in HBM; the exchange is inside the step
+        sig_clean = None
     else:
-        h.set_reads_ascii_device(clean.data_ptr(), clean.shape[0], L)
+        h.set_reads_packed_device(packed.data_ptr(), nclean)      # the library keeps its own copy
+        del packed
     h.set_nreads_ascii_device(withN.data_ptr(), withN.shape[0], L)
-    # order-independent signature of the inputs this rank will encode (for the round-trip check after the timed region)
-    sig_N = h.reads_signature_device(withN.data_ptr(), withN.shape[0], L)
-    sig_clean = None if sharder is not None else h.reads_signature_device(clean.data_ptr(), clean.shape[0], L)
-    if sharder is None:
-        del clean
+    del withN
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()                                      # hand torch's cached blocks back: the library allocates with hipMalloc
+    with_pack_order = args.workload == "c5s"
 
     def step():
         if sharder is not None:
             sharder.exchange_and_set(packed)                      # bucket -> one all-to-all(v) over xGMI -> this GPU's shard
         h.reorder()
         h.encode()
+        if with_pack_order:
+            h.pack_order()                                        # -p: pack_order.cpp:20-77 on read_order.bin
 
     def barrier():
         torch.cuda.synchronize()
