@@ -27,6 +27,7 @@ struct S1Args {
     uint2 *steps;                    // [K][64] steps of the current super-round: {rid, shift | dir<<8}
     uint8_t *need;                   // per chain: wants a new seed (set by k_resolve, consumed by k_reseed)
     uint32_t *seedbuf;               // [K * (1 + HARC_NSUGG)] seeds, then look-ahead seeds, found by k_reseed, by rank
+    uint32_t *needlist;              // [K] chains that want a seed, ascending (k_reseed scratch)
     uint32_t *sugg;                  // [K][HARC_NSUGG] look-ahead seeds of every chain, highest id first
     int S;                           // speculative steps per super-round (1..64)
     int nsugg_per_seed;              // look-ahead seeds per reseed (HARC_NSUGG; 0 disables them: experiments only, the oracle uses the same value)
@@ -707,12 +708,20 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
     __shared__ uint32_t sm[20];
     __shared__ long long scursor;
     const int t = threadIdx.x;
-    const uint32_t chunk = (s.K + 1023) / 1024;                   // chains per thread, contiguous
-    const uint32_t c0 = (uint32_t)t * chunk, c1 = (c0 + chunk < s.K) ? c0 + chunk : s.K;
+    // chains per thread, contiguous and a multiple of 8 so that the need bytes are read as 64-bit words (the array is padded with zeros)
+    const uint32_t chunk = (((s.K + 1023) / 1024) + 7) & ~7u;
+    const uint32_t c0 = (uint32_t)t * chunk;
     uint32_t mycnt = 0;
-    for (uint32_t c = c0; c < c1; c++) mycnt += s.need[c];
+    if (c0 < s.K) for (uint32_t c = c0; c < c0 + chunk; c += 8) mycnt += (uint32_t)__popcll(*(const unsigned long long *)(s.need + c));
     uint32_t R; const uint32_t rbase = block_excl_scan_u32<1024>(mycnt, sm, &R);
     if (R == 0) return;
+    if (mycnt) {                                                  // needlist[rank] = chain, ascending
+        uint32_t r = rbase;
+        for (uint32_t c = c0; c < c0 + chunk; c += 8) {
+            unsigned long long w = *(const unsigned long long *)(s.need + c);
+            while (w) { const int b = __ffsll((long long)w) - 1; w &= w - 1; s.needlist[r++] = c + (uint32_t)(b >> 3); }
+        }
+    }
 
     long long cursor = *s.cursor;
     uint32_t assigned = 0;
@@ -764,9 +773,8 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
     }
     __threadfence();
     __syncthreads();
-    uint32_t r = rbase;
-    for (uint32_t c = c0; c < c1; c++) {
-        if (!s.need[c]) continue;
+    for (uint32_t r = (uint32_t)t; r < R; r += 1024) {            // one needy chain per thread and pass
+        const uint32_t c = s.needlist[r];
         ChainHdr h = s.hdr[c];
         if (h.flags & CH_PREVUNM) {                               // previous seed found nothing: singleton (reorder.cpp:672-684)
             const unsigned long long at = atomicAdd(s.logcount, 1ULL);
@@ -787,7 +795,6 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
         }
         s.hdr[c] = h;
         s.need[c] = 0;
-        r++;
     }
     if (t == 0) *s.cursor = cursor < -1 ? -1 : cursor;
 }
@@ -949,8 +956,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const size_t nwords = (size_t)N / 64 + 2;
     const uint32_t nblk = (K + 255) / 256;
     RC_TRY(dalloc(c, &a.claimed, nwords)); RC_TRY(dalloc(c, &a.bid, (size_t)N + 1)); RC_TRY(dalloc(c, &a.hdr, K));
-    RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.steps, (size_t)K * 64)); RC_TRY(dalloc(c, &a.need, (size_t)K + 1024));
-    RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + HARC_NSUGG))); RC_TRY(dalloc(c, &a.sugg, (size_t)K * HARC_NSUGG));
+    RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.steps, (size_t)K * 64)); RC_TRY(dalloc(c, &a.need, (size_t)K + 8192 + 1024));
+    RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + HARC_NSUGG))); RC_TRY(dalloc(c, &a.needlist, (size_t)K + 16)); RC_TRY(dalloc(c, &a.sugg, (size_t)K * HARC_NSUGG));
     RC_TRY(dalloc(c, &a.log, (size_t)N + 1)); RC_TRY(dalloc(c, &a.logcount, 1));
     RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N));
     RC_TRY(dalloc(c, &a.cstat, K)); HIP_TRY(hipMemsetAsync(a.cstat, 0, (size_t)K * 16, c->stream));
@@ -970,7 +977,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     HIP_TRY(hipMemsetAsync(a.bid, 0xFF, ((size_t)N + 1) * 4, c->stream));
     HIP_TRY(hipMemsetAsync(a.logcount, 0, 8, c->stream));
     HIP_TRY(hipMemsetAsync(a.stats, 0, ST_N * 8, c->stream));
-    HIP_TRY(hipMemsetAsync(a.need, 0, (size_t)K + 1024, c->stream));
+    HIP_TRY(hipMemsetAsync(a.need, 0, (size_t)K + 8192 + 1024, c->stream));
     const long long cur0 = (long long)N - 1;
     HIP_TRY(hipMemcpyAsync(a.cursor, &cur0, 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_init_chains, dim3(nblk), dim3(256), 0, c->stream, a);

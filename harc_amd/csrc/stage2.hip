@@ -8,7 +8,7 @@
 //                             atomicMin of the (column, direction, dictionary) tuple per candidate read: the sequential
 //                             first-come claim of the reference at num_thr=1 is exactly the minimum tuple
 //   list.insert  :310-313  -> a merge by rank (two binary searches) of the reads with the accepted candidates
-//   writecontig  :654-717  -> k_count_noise / k_emit (noise, noisepos, pos, order routing, rc)
+//   writecontig  :654-717  -> k_noise<W, false/true> (sizes, then noise, noisepos, pos, order routing, rc) on packed words
 //   packbits     :512-616  -> k_pack2_bytes / k_pack1_bytes
 // Shard e of num_thr owns reordered reads [e*q, (e+1)*q) (:171-180); its streams are slices of the global arrays.
 #include "devutil.h"
@@ -386,36 +386,105 @@ __global__ void k_merge_acc(const uint64_t *gstart, uint32_t M, const uint64_t *
     f.ref[at] = rid[k]; f.kind[at] = (tup[k] & 2) ? 2 : 1; f.g[at] = x;
 }
 
-// base j (A C G T N = 0..4) of final element f as it is written to the contig (candidates reverse-complemented when kind 2)
-__device__ __forceinline__ int final_base(const S2Args &s, uint32_t ref, int kind, int j)
+// The noise pass works on packed words: `cons2` is the consensus on the global column axis in the reads' own 2-bit code (A0 G1 C2 T3,
+// 32 columns per word), so a read is compared with W funnel-shifted words and the mismatching columns are the set bits of
+// ((x | x>>1) & 0x55..) with x = read ^ consensus; an N of a candidate read is a mismatch wherever it stands.
+__global__ void k_pack_cons2(const uint8_t *cons, uint64_t total, uint64_t nwords, uint64_t *cons2)
 {
-    if (kind == 0) return pc_to_idx(base2_at(s.oreads + (size_t)ref * s.W, j));
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint64_t v = 0;
+    const uint64_t c0 = w * 32;
+    if (c0 + 32 <= total) {
+        const uint4 q0 = *(const uint4 *)(cons + c0), q1 = *(const uint4 *)(cons + c0 + 16);
+        const uint32_t qq[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+#pragma unroll
+        for (int k = 0; k < 32; k++) { const uint32_t idx = (qq[k >> 2] >> (8 * (k & 3))) & 3; v |= (uint64_t)(((idx & 1) << 1) | (idx >> 1)) << (2 * k); }
+    } else {
+        for (int k = 0; k < 32 && c0 + k < total; k++) { const uint32_t idx = cons[c0 + k] & 3; v |= (uint64_t)(((idx & 1) << 1) | (idx >> 1)) << (2 * k); }
+    }
+    cons2[w] = v;
+}
+// final element -> W words of 2-bit code as written to the contig (candidates reverse-complemented when kind 2) + N mask (both bits of
+// the field set); 3-bit code A0 N1 G2 C4 T6 -> 2-bit code = c3 >> 1, N = c3 & 1
+template <int W> __device__ __forceinline__ void final_words(const S2Args &s, uint32_t ref, int kind, uint64_t (&rd)[W], uint64_t (&nmk)[W])
+{
+    if (kind == 0) {
+        const uint64_t *r = s.oreads + (size_t)ref * W;
+#pragma unroll
+        for (int w = 0; w < W; w++) { rd[w] = r[w]; nmk[w] = 0; }
+        return;
+    }
+    constexpr int W3M = (3 * 32 * W + 63) / 64;
+    uint64_t x3[W3M + 1];
     const uint64_t *r = s.cand3 + (size_t)ref * s.W3;
-    if (kind == 1) return c3_to_idx5(c3_at(r, s.W3, j));
-    return comp5(c3_to_idx5(c3_at(r, s.W3, s.L - 1 - j)));
+#pragma unroll
+    for (int w = 0; w <= W3M; w++) x3[w] = w < s.W3 ? r[w] : 0;
+    uint64_t a[W], n[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) { a[w] = 0; n[w] = 0; }
+#pragma unroll
+    for (int j = 0; j < 32 * W; j++) {
+        const int off = 3 * j, wi = off >> 6, sh = off & 63;
+        uint64_t v = x3[wi] >> sh;
+        if (sh > 61) v |= x3[wi + 1] << (64 - sh);
+        const uint64_t c3 = v & 7;
+        a[j >> 5] |= (c3 >> 1) << (2 * (j & 31));
+        n[j >> 5] |= ((c3 & 1) * 3) << (2 * (j & 31));
+    }
+#pragma unroll
+    for (int w = 0; w < W; w++) { const uint64_t lm = lowmask_word(2 * s.L, w); a[w] &= lm; n[w] &= lm; }
+    if (kind == 1) {
+#pragma unroll
+        for (int w = 0; w < W; w++) { rd[w] = a[w]; nmk[w] = n[w]; }
+    } else {
+        uint64_t t[W];
+        rc_words<W>(a, s.L, rd);
+        rc_words<W>(n, s.L, t);                                   // reversed and complemented; undo the complement
+#pragma unroll
+        for (int w = 0; w < W; w++) nmk[w] = ~t[w] & lowmask_word(2 * s.L, w);
+    }
 }
-__global__ void k_count_noise(S2Args s, FinalArrays f, uint32_t F, uint32_t *nm, uint32_t *nonN)
+template <int W> __device__ __forceinline__ void cons_words(const uint64_t *cons2, uint64_t g, uint64_t (&cw)[W])
+{
+    const uint64_t bit = 2 * g, wi = bit >> 6; const int sh = (int)(bit & 63);
+    uint64_t lo = cons2[wi];
+#pragma unroll
+    for (int w = 0; w < W; w++) { const uint64_t hi = cons2[wi + w + 1]; cw[w] = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo; lo = hi; }
+}
+template <int W, bool EMIT> __global__ void k_noise(S2Args s, FinalArrays f, const uint64_t *cons2, uint32_t F, uint32_t *nm, uint32_t *nonN,
+                                                    const uint64_t *nmoff, const uint32_t *nonNrank,
+                                                    uint8_t *noise, uint8_t *noisepos, uint8_t *posb, uint8_t *rcb, uint32_t *order_out, uint32_t *orderN_out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F) return;
     const uint32_t ref = f.ref[i]; const int kind = f.kind[i]; const uint64_t g = f.g[i];
-    uint32_t n = 0;
-    for (int j = 0; j < s.L; j++) n += (final_base(s, ref, kind, j) != (int)(s.cons[g + j] & 3));
-    nm[i] = n;
-    nonN[i] = (kind != 0 && ref >= s.S) ? 0u : 1u;                // N reads are exactly the candidates with index >= S
-}
-// writecontig (encoder.cpp:654-717)
-__global__ void k_emit(S2Args s, FinalArrays f, uint32_t F, const uint64_t *nmoff, const uint32_t *nonNrank,
-                       uint8_t *noise, uint8_t *noisepos, uint8_t *posb, uint8_t *rcb, uint32_t *order_out, uint32_t *orderN_out)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= F) return;
-    const uint32_t ref = f.ref[i]; const int kind = f.kind[i]; const uint64_t g = f.g[i];
+    uint64_t rd[W], nk[W], cw[W], mm[W];
+    final_words<W>(s, ref, kind, rd, nk);
+    cons_words<W>(cons2, g, cw);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const uint64_t x = rd[w] ^ cw[w];
+        mm[w] = ((x | (x >> 1) | nk[w]) & 0x5555555555555555ULL) & lowmask_word(2 * s.L, w);
+        cnt += (uint32_t)__popcll(mm[w]);
+    }
+    if (!EMIT) {                                                  // writecontig's sizes first (encoder.cpp:654-717)
+        nm[i] = cnt;
+        nonN[i] = (kind != 0 && ref >= s.S) ? 0u : 1u;            // N reads are exactly the candidates with index >= S
+        return;
+    }
     uint64_t np = nmoff[i], nz = nmoff[i] + i;                    // one '\n' per earlier read
     int prevj = 0;
-    for (int j = 0; j < s.L; j++) {
-        const int b = final_base(s, ref, kind, j), cb = (int)(s.cons[g + j] & 3);
-        if (b != cb) { noise[nz++] = (uint8_t)enc_noise(cb, b); noisepos[np++] = (uint8_t)(j - prevj); prevj = j; }
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        uint64_t m = mm[w];
+        while (m) {
+            const int b = __ffsll((long long)m) - 1; m &= m - 1;
+            const int j = 32 * w + (b >> 1);
+            const int rb = ((nk[w] >> b) & 1) ? 4 : pc_to_idx((int)((rd[w] >> b) & 3)), cb = pc_to_idx((int)((cw[w] >> b) & 3));
+            noise[nz++] = (uint8_t)enc_noise(cb, rb); noisepos[np++] = (uint8_t)(j - prevj); prevj = j;
+        }
     }
     noise[nz] = '\n';
     const bool is_head = (kind == 0) && s.head[ref];
@@ -424,6 +493,14 @@ __global__ void k_emit(S2Args s, FinalArrays f, uint32_t F, const uint64_t *nmof
     const uint32_t ov = kind == 0 ? s.order[ref] : s.cand_order[ref];
     const bool isN = (kind != 0 && ref >= s.S);
     if (isN) orderN_out[i - nonNrank[i]] = ov; else order_out[nonNrank[i]] = ov;
+}
+template <bool EMIT> static void launch_noise(harc_amd_ctx *c, const S2Args &a, const FinalArrays &f, const uint64_t *cons2, uint32_t F, uint32_t *nm, uint32_t *nonN,
+                                              const uint64_t *nmoff, const uint32_t *nonNrank, uint8_t *noise, uint8_t *noisepos, uint8_t *posb, uint8_t *rcb,
+                                              uint32_t *order_out, uint32_t *orderN_out)
+{
+#define NOISE_CASE(WW) case WW: hipLaunchKernelGGL((k_noise<WW, EMIT>), dim3((F + 255) / 256), dim3(256), 0, c->stream, a, f, cons2, F, nm, nonN, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out); break;
+    switch (a.W) { NOISE_CASE(1) NOISE_CASE(2) NOISE_CASE(3) NOISE_CASE(4) NOISE_CASE(5) NOISE_CASE(6) NOISE_CASE(7) NOISE_CASE(8) }
+#undef NOISE_CASE
 }
 
 // unaligned candidates (encoder.cpp:484-499): singletons -> order + bases; N reads -> order_N + text
@@ -628,7 +705,12 @@ int stage2_run(harc_amd_ctx *c)
     uint32_t *nm = nullptr, *nonN = nullptr, *nonNrank = nullptr; uint64_t *nmoff = nullptr;
     RC_TRY(dalloc(c, &nm, (size_t)F + 1)); RC_TRY(dalloc(c, &nonN, (size_t)F + 1)); RC_TRY(dalloc(c, &nonNrank, (size_t)F + 1)); RC_TRY(dalloc(c, &nmoff, (size_t)F + 1));
     HIP_TRY(hipMemsetAsync(nm, 0, ((size_t)F + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(nonN, 0, ((size_t)F + 1) * 4, c->stream));
-    if (F) hipLaunchKernelGGL(k_count_noise, G256(F), a, f, F, nm, nonN);
+    uint64_t *cons2 = nullptr;
+    const uint64_t ncw = (total + 31) / 32;
+    RC_TRY(dalloc(c, &cons2, (size_t)ncw + 2 * W + 4));
+    HIP_TRY(hipMemsetAsync(cons2 + ncw, 0, ((size_t)2 * W + 4) * 8, c->stream));
+    if (ncw) hipLaunchKernelGGL(k_pack_cons2, G256(ncw), (const uint8_t *)a.cons, total, ncw, cons2);
+    if (F) launch_noise<false>(c, a, f, cons2, F, nm, nonN, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     RC_TRY(prim_excl_scan_u32_to_u64(c, nm, nmoff, (size_t)F + 1));
     RC_TRY(prim_excl_scan_u32(c, nonN, nonNrank, (size_t)F + 1));
     uint64_t nmtot = 0; uint32_t n_nonN = 0;
@@ -651,7 +733,7 @@ int stage2_run(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &noise, (size_t)nmtot + F + 1)); RC_TRY(dalloc(c, &noisepos, (size_t)nmtot + 1)); RC_TRY(dalloc(c, &posb, (size_t)F + 1)); RC_TRY(dalloc(c, &rcb, (size_t)F + 8));
     RC_TRY(dalloc(c, &order_out, (size_t)n_nonN + US + 1)); RC_TRY(dalloc(c, &orderN_out, (size_t)n_N_aligned + UN + 1));
     RC_TRY(dalloc(c, &sing_bases, (size_t)US * L + 8)); RC_TRY(dalloc(c, &ntext, (size_t)UN * (L + 1) + 1));
-    if (F) hipLaunchKernelGGL(k_emit, G256(F), a, f, F, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out);
+    if (F) launch_noise<true>(c, a, f, cons2, F, nullptr, nullptr, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out);
     if (T) hipLaunchKernelGGL(k_left_emit, G256(T), a, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned, sing_bases, ntext);
     HIP_TRY(hipGetLastError());
 
