@@ -39,7 +39,14 @@ struct S1Args {
     int nprobe;
     int nbatch, batch_end[12];       // probe batches: [0,batch_end[0]), [batch_end[0],batch_end[1]) ... each at most 64 wide
     uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups
+    unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
 };
+#ifdef HARC_TIMING
+#define TICK(k) do { const long long tn_ = clock64(); tacc[k] += (unsigned long long)(tn_ - tlast); tlast = tn_; } while (0)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(v, o, 64); v = x > v ? x : v; } return v; }
+#else
+#define TICK(k) do { } while (0)
+#endif
 enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_USEFUL = 5, ST_N = 8 };
 
 // ------------------------------------------------------------------------------------------------ packing kernels
@@ -326,12 +333,15 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
 //  (3) lane 0 records the step and bids for the read with atomicMin(step<<20 | chain); the counts are updated in registers.
 #define HARC_BIGBIN 4u      // bins with more reads than this are scanned by the whole wave
 #ifndef HARC_STEPS_WAVES
-#define HARC_STEPS_WAVES 4
+#define HARC_STEPS_WAVES 4       // many chains: 4 waves / SIMD (128 VGPRs, a few spills)
 #endif
-template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) void k_steps(S1Args s)
+#ifndef HARC_STEPS_WAVES_Q
+#define HARC_STEPS_WAVES_Q 3     // few chains (bucketed table): never more than ~3 waves / SIMD anyway -> 144 VGPRs, nothing in scratch
+#endif
+template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_WAVES_Q : HARC_STEPS_WAVES) void k_steps(S1Args s)
 {
-    __shared__ uint32_t s_own[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t ownreg = HARC_NONE;                                 // lane t: the read this chain took at step t of this super-round
     const uint32_t c = blockIdx.x * 4 + wv;
     if (c >= s.K) return;
     ChainHdr h = s.hdr[c];
@@ -375,12 +385,17 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
 
     uint32_t np = 0, nc = 0, nuse = 0;
     int nst = 0; bool needseed = false;
+#ifdef HARC_TIMING
+    unsigned long long tacc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; long long tlast = clock64();
+#endif
     int lastp = (int)(h.pad0 & 0xFFFF);                          // priority index of this chain's previous hit
     int spos = (int)((h.nsteps >> 16) & 0xFF); const int nsugg = (int)(h.nsteps >> 24);   // look-ahead seeds: next to try / held
     for (int t = 0; t < s.S; t++) {
         uint64_t ref[W], rref[W];
+        TICK(0);
         cons_pack<W>(st, L, lane, ref);
         rc_words<W>(ref, L, rref);
+        TICK(1);
         uint32_t found = HARC_NONE; int fj = 0, fdir = 0;
         uint64_t frd[W];
 #pragma unroll
@@ -398,6 +413,9 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
             if (bend <= base) bend = s.nprobe;
             const int p = base + lane;
             uint32_t mine = HARC_NONE; int j = 0, dir = 0, l = 0;
+#ifdef HARC_TIMING
+            uint32_t it_slot = 0, it_scan = 0; tacc[8]++;
+#endif
             bool big = false; uint32_t b_sst = 0, b_cnt = 0; uint64_t b_slot = 0;   // a bin too large for one lane: scanned by the whole wave below
             uint64_t mrd[W];
 #pragma unroll
@@ -423,6 +441,9 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
                     uint64_t sl = QUAD ? (__umul64hi(mix64(key), cap >> 2) << 2) : __umul64hi(mix64(key), cap);
                     for (;;) {
                         constexpr int NQ = QUAD ? 4 : 1;
+#ifdef HARC_TIMING
+                        it_slot++;
+#endif
                         uint4 rawq[NQ];
 #pragma unroll
                         for (int q = 0; q < NQ; q++) rawq[q] = *reinterpret_cast<const uint4 *>(&tab[sl + q]);
@@ -446,6 +467,9 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
                         const bool emb = (cw & SLOT_EMB) != 0;            // single-read bin: `start` IS the read id
                         int seen = 0; uint32_t lead = 0; bool alltop = true;
                         for (uint32_t i = cntb; i > 0 && seen < s.maxsearch; i--) {
+#ifdef HARC_TIMING
+                            it_scan++;
+#endif
                             const uint32_t rid = emb ? sst : ids[sst + i - 1];
                             // claim bit and read words are fetched together (one dependent hop instead of two)
                             const unsigned long long cwd = s.claimed[rid >> 6];
@@ -454,7 +478,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
                             if ((cwd >> (rid & 63)) & 1ULL) { if (alltop) lead++; continue; }
                             alltop = false;
                             bool own = false;                             // taken by this chain earlier in this super-round
-                            for (int k = 0; k < t; k++) own |= (s_own[wv][k] == rid);
+                            for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
                             if (own) continue;
                             seen++; nc++;
                             int hd = 0;
@@ -485,6 +509,10 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
                     }
                 }
             }
+            TICK(2);
+#ifdef HARC_TIMING
+            tacc[6] += wave_max_u32(it_slot); tacc[7] += wave_max_u32(it_scan); tacc[9] += wave_sum_u32(it_scan); tacc[10] += (unsigned long long)__popcll(__ballot(p < bend));
+#endif
             // ---- the best hit of the lanes that scanned their (small) bins themselves
             int winlane = 64;
             {
@@ -522,7 +550,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
                             clm = ((cwd >> (rid & 63)) & 1ULL) != 0;
                         }
                         bool own = false;
-                        if (valid && !clm) for (int k = 0; k < t; k++) own |= (s_own[wv][k] == rid);
+                        if (valid && !clm) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
                         const bool un = valid && !clm && !own;
                         const unsigned long long um = __ballot(un);
                         const int rank = __popcll(um & ((1ULL << lane) - 1ULL));
@@ -558,6 +586,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
                     if (bighit) break;
                 }
             }
+            TICK(3);
             if (found != HARC_NONE) {
                 nuse += (uint32_t)(base + winlane + 1);
                 lastp = base + winlane;
@@ -576,7 +605,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
                 if (idx < nsugg) {
                     id = s.sugg[(size_t)c * HARC_NSUGG + idx];
                     okc = !((s.claimed[id >> 6] >> (id & 63)) & 1ULL);
-                    for (int k = 0; k < t; k++) okc = okc && (s_own[wv][k] != id);
+                    for (int k = 0; k < t; k++) okc = okc && ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) != id);
                 }
                 const unsigned long long sm = __ballot(okc);
                 if (sm) { const int f = __ffsll((long long)sm) - 1; sid = __shfl(id, f, 64); spos += f + 1; } else spos = nsugg;
@@ -585,10 +614,8 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
             if (lane == 0) {
                 s.steps[(size_t)c * 64 + t] = make_uint2(sid, (1u << 16) | ((uint32_t)spos << 24));
                 atomicMin(&s.bid[sid], ((uint32_t)t << 20) | c);
-                s_own[wv][t] = sid;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            if (lane == t) ownreg = sid;
             uint64_t rw[W];
 #pragma unroll
             for (int w = 0; w < W; w++) rw[w] = s.reads[(size_t)sid * W + w];
@@ -599,13 +626,16 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, HARC_STEPS_WAVES) 
         if (lane == 0) {
             s.steps[(size_t)c * 64 + t] = make_uint2(found, (uint32_t)fj | ((uint32_t)fdir << 8));
             atomicMin(&s.bid[found], ((uint32_t)t << 20) | c);
-            s_own[wv][t] = found;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (lane == t) ownreg = found;
+        TICK(4);
         cons_update<W>(st, frd, L, fdir, fj, lane);
         nst++;
+        TICK(5);
     }
+#ifdef HARC_TIMING
+    if (lane == 0) { for (int k = 0; k < 6; k++) atomicAdd(&s.dbg[k], tacc[k]); atomicAdd(&s.dbg[6], (unsigned long long)nst); atomicAdd(&s.dbg[7], 1ULL); for (int k = 6; k < 11; k++) atomicAdd(&s.dbg[k + 2], tacc[k]); }
+#endif
     if (nst > 0) cons_store<W>(st, B1, L, lane);
     np = wave_sum_u32(np); nc = wave_sum_u32(nc);
     if (lane == 0) {
@@ -961,6 +991,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &a.log, (size_t)N + 1)); RC_TRY(dalloc(c, &a.logcount, 1));
     RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N));
     RC_TRY(dalloc(c, &a.cstat, K)); HIP_TRY(hipMemsetAsync(a.cstat, 0, (size_t)K * 16, c->stream));
+    RC_TRY(dalloc(c, &a.dbg, 16)); HIP_TRY(hipMemsetAsync(a.dbg, 0, 16 * 8, c->stream));
     std::vector<uint16_t> tab = make_probe_table(P);
     uint16_t *d_tab = nullptr; RC_TRY(dalloc(c, &d_tab, tab.size() + 1));
     HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream));
@@ -1041,6 +1072,17 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     c->C.propose_ms = pms;
     for (hipEvent_t e : ev) hipEventDestroy(e);
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+#ifdef HARC_TIMING
+    {
+        unsigned long long d[16];
+        HIP_TRY(hipMemcpy(d, a.dbg, sizeof d, hipMemcpyDeviceToHost));
+        const double st = (double)(d[6] ? d[6] : 1);
+        fprintf(stderr, "[k_steps timing] steps %llu waves-launched %llu; cycles/step: top %.0f pack+rc %.0f probe+smallscan %.0f coop %.0f bid %.0f update %.0f\n",
+                d[6], d[7], d[0] / st, d[1] / st, d[2] / st, d[3] / st, d[4] / st, d[5] / st);
+        fprintf(stderr, "[k_steps timing] per step: batches %.2f  max-lane slot iterations %.2f  max-lane scan iterations %.2f  total scan iterations %.2f  lanes probing %.1f\n",
+                d[10] / st, d[8] / st, d[9] / st, d[11] / st, d[12] / st);
+    }
+#endif
     hipHostFree(h_stats);
 
     harc_pool_release(c, mark_results);                          // stage II starts right above the results
