@@ -65,7 +65,8 @@ struct HashSlot {       // 16 B, one global_load_dwordx4
 #define SLOT_DEAD 0x80000000u      // hint: every read of the bin is claimed
 #define SLOT_EMB 0x40000000u       // bin holds exactly one read and `start` is its id
 #define SLOT_BIG 0x20000000u       // (stage II only) more than maxsearch reads: handled by the sequential sliding-window pass
-#define SLOT_CNT_MASK 0x1FFFFFFFu
+#define SLOT_OVF 0x10000000u       // (bucketed tables, slot 0 of a 4-slot bucket) some key that hashes to this bucket or passed through it lives further on
+#define SLOT_CNT_MASK 0x0FFFFFFFu
 
 struct DictDev {
     HashSlot *slots = nullptr;
@@ -73,7 +74,7 @@ struct DictDev {
     uint32_t *ids = nullptr;   // read ids sorted by (key, id)
     uint32_t *d_nbins = nullptr;
     uint32_t nbins = 0;
-    bool bucketed = false;
+    bool bucketed = false;     // probing goes bucket by bucket (64 B = 4 slots); a full bucket without SLOT_OVF ends an unsuccessful search
     uint32_t bigthresh = 0;    // > 0: bins with more entries get SLOT_BIG     // probing starts at a 64-B bucket of 4 slots (fetched whole by a latency-bound k_steps) instead of at the hashed slot
 };
 

@@ -196,6 +196,8 @@ __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, cons
     for (;;) {
         unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
         if (atomicCAS(mp, 0ULL, meta) == 0ULL) { slots[sl].key = key; return; }
+        // leaving a bucket whose four slots are all taken: flag it, so that a search that finds a full bucket WITHOUT the flag can stop
+        if (bucketed && (sl & 3) == 3) atomicOr(&slots[sl - 3].count, SLOT_OVF);
         if (++sl == cap) sl = 0;
     }
 }
@@ -436,29 +438,34 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                 HashSlot *tab = s.slots[l];
                 const uint32_t *ids = s.ids[l];
                 if (cap) {
-                    // QUAD (few chains, latency-bound): the table is bucketed and a whole 64-B bucket of 4 slots is fetched per round trip;
-                    // otherwise (many chains, request-rate-bound) classic linear probing, one 16-B slot per request
-                    uint64_t sl = QUAD ? (__umul64hi(mix64(key), cap >> 2) << 2) : __umul64hi(mix64(key), cap);
+                    // The table is bucketed (64 B = 4 slots).  QUAD (few chains, latency-bound): the whole bucket in one round trip; otherwise
+                    // (many chains, 128 VGPRs) two slots at a time -- the second pair is the same 64-B sector.  A full bucket ends the
+                    // search unless its overflow flag says that keys went on to the next one.
+                    uint64_t sl = __umul64hi(mix64(key), cap >> 2) << 2;
                     for (;;) {
-                        constexpr int NQ = QUAD ? 4 : 1;
-#ifdef HARC_TIMING
-                        it_slot++;
-#endif
-                        uint4 rawq[NQ];
+                        constexpr int NQ = QUAD ? 4 : 2;
+                        int state = 0, qhit = 0;                              // 1 = the key is not in the table, 2 = key found
+                        uint32_t sst = 0, cw = 0, w0 = 0;
 #pragma unroll
-                        for (int q = 0; q < NQ; q++) rawq[q] = *reinterpret_cast<const uint4 *>(&tab[sl + q]);
-                        int state = 0, qhit = 0;                              // 1 = an empty slot ends the search, 2 = key found
-                        uint32_t sst = 0, cw = 0;
-#pragma unroll
-                        for (int q = 0; q < NQ; q++) {
+                        for (int hp = 0; hp < 4 / NQ; hp++) {
                             if (state == 0) {
-                                np++;
-                                if (rawq[q].w == 0) state = 1;
-                                else if (((uint64_t)rawq[q].x | ((uint64_t)rawq[q].y << 32)) == key) { state = 2; qhit = q; sst = rawq[q].z; cw = rawq[q].w; }
+                                uint4 rawq[NQ];
+#pragma unroll
+                                for (int q = 0; q < NQ; q++) rawq[q] = *reinterpret_cast<const uint4 *>(&tab[sl + hp * NQ + q]);
+                                if (hp == 0) w0 = rawq[0].w;
+#pragma unroll
+                                for (int q = 0; q < NQ; q++) {
+                                    if (state == 0) {
+                                        np++;
+                                        if (rawq[q].w == 0) state = 1;
+                                        else if (((uint64_t)rawq[q].x | ((uint64_t)rawq[q].y << 32)) == key) { state = 2; qhit = hp * NQ + q; sst = rawq[q].z; cw = rawq[q].w; }
+                                    }
+                                }
                             }
                         }
+                        if (state == 0 && !(w0 & SLOT_OVF)) state = 1;
                         if (state == 2 && !(cw & SLOT_DEAD) && (cw & SLOT_CNT_MASK) > HARC_BIGBIN && !(cw & SLOT_EMB)) {
-                            big = true; b_sst = sst; b_cnt = cw & SLOT_CNT_MASK; b_slot = sl + qhit;
+                            big = true; b_sst = sst; b_cnt = cw & (SLOT_CNT_MASK | SLOT_OVF); b_slot = sl + qhit;
                         } else
                         if (state == 2 && !(cw & SLOT_DEAD)) {                // SLOT_DEAD: every read of this bin is already claimed
                         const int nb = 2 * (L - j);
@@ -501,11 +508,11 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                         // hints only (the claim bitmap stays the truth): claimed reads at the top of a bin are never looked at again
                         if (lead) {
                             uint32_t *cp = reinterpret_cast<uint32_t *>(&tab[sl + qhit]) + 3;
-                            if (lead == cntb) atomicOr(cp, SLOT_DEAD); else if (!emb) atomicMin(cp, cntb - lead);
+                            if (lead == cntb) atomicOr(cp, SLOT_DEAD); else if (!emb) atomicMin(cp, (cntb - lead) | (cw & SLOT_OVF));
                         }
                         }
                         if (state) break;
-                        sl += NQ; if (sl >= cap) sl = 0;
+                        sl += 4; if (sl >= cap) sl = 0;
                     }
                 }
             }
@@ -532,7 +539,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                 while (bigm) {
                     const int bl = __ffsll((long long)bigm) - 1;
                     bigm &= bigm - 1;
-                    const uint32_t o_sst = __shfl(b_sst, bl, 64), o_cnt = __shfl(b_cnt, bl, 64);
+                    const uint32_t o_sst = __shfl(b_sst, bl, 64), o_raw = __shfl(b_cnt, bl, 64), o_cnt = o_raw & SLOT_CNT_MASK;
                     const int o_j = __shfl(j, bl, 64), o_dir = __shfl(dir, bl, 64), o_l = __shfl(l, bl, 64);
                     const uint64_t o_slot = shfl_u64(b_slot, bl);
                     const uint32_t *oids = s.ids[o_l];
@@ -581,7 +588,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                     }
                     if (lead && lane == 0) {
                         uint32_t *cp = reinterpret_cast<uint32_t *>(&s.slots[o_l][o_slot]) + 3;
-                        if (lead == o_cnt) atomicOr(cp, SLOT_DEAD); else atomicMin(cp, o_cnt - lead);
+                        if (lead == o_cnt) atomicOr(cp, SLOT_DEAD); else atomicMin(cp, (o_cnt - lead) | (o_raw & SLOT_OVF));
                     }
                     if (bighit) break;
                 }
@@ -961,7 +968,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     DictDev dict[2];
     if (N) {
         RC_TRY(harc_dict_alloc(c, &dict[0], N)); RC_TRY(harc_dict_alloc(c, &dict[1], N));
-        dict[0].bucketed = dict[1].bucketed = quad;
+        dict[0].bucketed = dict[1].bucketed = true;
         const harc_mark_t mk = harc_pool_mark(c);
         uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
         RC_TRY(dalloc(c, &k0, N)); RC_TRY(dalloc(c, &i0, N));
