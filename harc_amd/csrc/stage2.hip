@@ -32,6 +32,9 @@ struct S2Args {
     const uint32_t *chead;             // nC: read index of each contig head
     const HashSlot *slots[2]; uint64_t cap[2]; const uint32_t *ids[2];
     unsigned long long *best;          // T
+    const uint32_t *bloom[2]; int bloom_shift[2];   // one-hash bitmap over the keys of each dictionary (16 bits per key): most windows match nothing
+    const uint64_t *cons2;             // consensus, 2-bit code A0 G1 C2 T3, 32 columns per word (k_pack_cons2)
+    const uint64_t *cand2, *candN;     // T x W: the candidates in the same 2-bit code (N -> 0) and their N masks (both bits of the field set)
     uint4 *events;                     // probes that hit a bin larger than maxsearch: {tuple lo, tuple hi, dict, slot index lo} (+ slot hi in w>>?)
     unsigned int *nevents; uint32_t maxevents;
 };
@@ -212,16 +215,70 @@ __global__ __launch_bounds__(256) void k_consensus(S2Args s, const uint32_t *cid
     }
 }
 
+// exact key -> (start,count) lookup in a bucketed table (64 B = 4 slots, overflow flag in slot 0: see k_table_insert); two slots at a time
+__device__ __forceinline__ bool dict_lookup_b(const HashSlot *tab, uint64_t cap, uint64_t key, uint32_t *start, uint32_t *count)
+{
+    uint64_t sl = __umul64hi(mix64(key), cap >> 2) << 2;
+    for (;;) {
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(&tab[sl]), r1 = *reinterpret_cast<const uint4 *>(&tab[sl + 1]);
+        if (r0.w == 0) return false;
+        if (((uint64_t)r0.x | ((uint64_t)r0.y << 32)) == key) { *start = r0.z; *count = r0.w; return true; }
+        if (r1.w == 0) return false;
+        if (((uint64_t)r1.x | ((uint64_t)r1.y << 32)) == key) { *start = r1.z; *count = r1.w; return true; }
+        const uint4 r2 = *reinterpret_cast<const uint4 *>(&tab[sl + 2]), r3 = *reinterpret_cast<const uint4 *>(&tab[sl + 3]);
+        if (r2.w == 0) return false;
+        if (((uint64_t)r2.x | ((uint64_t)r2.y << 32)) == key) { *start = r2.z; *count = r2.w; return true; }
+        if (r3.w == 0) return false;
+        if (((uint64_t)r3.x | ((uint64_t)r3.y << 32)) == key) { *start = r3.z; *count = r3.w; return true; }
+        if (!(r0.w & SLOT_OVF)) return false;
+        sl += 4; if (sl >= cap) sl = 0;
+    }
+}
+__global__ void k_bloom_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, int shift)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t b = mix64(keys[i] ^ 0x9E3779B97F4A7C15ULL) >> shift;
+    atomicOr(&bloom[b >> 5], 1u << (b & 31));
+}
+// candidates in the reads' 2-bit code + N mask (3-bit code A0 N1 G2 C4 T6: code = c3 >> 1, N = c3 & 1); one thread per (read, word)
+__global__ void k_cand2_from3(const uint64_t *cand3, uint32_t T, int L, int W, int W3, uint64_t *cand2, uint64_t *candN)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)T * W) return;
+    const uint32_t i = (uint32_t)(gid / W); const int w = (int)(gid % W);
+    const uint64_t *r = cand3 + (size_t)i * W3;
+    uint64_t a = 0, n = 0;
+    for (int k = 0; k < 32; k++) {
+        const int j = 32 * w + k;
+        if (j >= L) break;
+        const uint64_t c3 = (uint64_t)c3_at(r, W3, j);
+        a |= (c3 >> 1) << (2 * k);
+        n |= ((c3 & 1) * 3) << (2 * k);
+    }
+    cand2[gid] = a; candN[gid] = n;
+}
+template <int W> __device__ __forceinline__ void cons_words(const uint64_t *cons2, uint64_t g, uint64_t (&cw)[W])
+{
+    const uint64_t bit = 2 * g, wi = bit >> 6; const int sh = (int)(bit & 63);
+    uint64_t lo = cons2[wi];
+#pragma unroll
+    for (int w = 0; w < W; w++) { const uint64_t hi = cons2[wi + w + 1]; cw[w] = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo; lo = hi; }
+}
+
 // singleton / N-read realignment, phase 1 (encoder.cpp:252-410).  A workgroup stages 2048 + L consensus bytes in LDS; each thread
 // owns 8 consecutive window starts and rolls its four dictionary keys (forward / reverse x 2 dictionaries) from one window to the next.
+// A key first meets a one-hash bitmap (cache-resident, most windows end there), then the bucketed table; a candidate is compared on
+// packed words: the 3-bit Hamming distance of encoder.cpp:300-312 equals, position by position, popcount of the 2-bit XOR where the
+// read has a base, and 1 + popcount(window code) where it has an N (N = 001 against A 000, G 010, C 100, T 110).
 #define RSTRIP 8
 #define RTILE (256 * RSTRIP)
-__global__ __launch_bounds__(256) void k_realign_propose(S2Args s)
+template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args s)
 {
     __shared__ uint32_t tile32[(RTILE + 256 + 8) / 4];
     uint8_t *tile = reinterpret_cast<uint8_t *>(tile32);
     const uint64_t X0 = (uint64_t)blockIdx.x * RTILE;
-    const int L = s.L, W3 = s.W3;
+    const int L = s.L;
     const int ntile = RTILE + L + 1;
     for (int d = threadIdx.x; d < (ntile + 3) / 4; d += 256) {
         const uint64_t g = X0 + 4ull * d;
@@ -249,38 +306,49 @@ __global__ __launch_bounds__(256) void k_realign_propose(S2Args s)
         const uint64_t x = X0 + tx;
         if (x >= s.total) break;
         if (tile[tx] & 4) {
-            const uint8_t *win = tile + tx;
-            for (int dir = 0; dir < 2; dir++) {
-                for (int l = 0; l < 2; l++) {
-                    const uint64_t key = dir ? (l ? kr1 : kr0) : (l ? kf1 : kf0);
-                    uint32_t st = 0, cnt = 0, np = 0;
-                    if (!dict_lookup(s.slots[l], s.cap[l], key, &st, &cnt, &np)) continue;
+            // the four probes of the window: bitmap first (all four loads in flight together)
+            const uint64_t keys[4] = { kf0, kf1, kr0, kr1 };               // order of encoder.cpp: direction, then dictionary
+            bool pass[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int l = k & 1;
+                const uint64_t b = mix64(keys[k] ^ 0x9E3779B97F4A7C15ULL) >> s.bloom_shift[l];
+                pass[k] = (s.bloom[l][b >> 5] >> (b & 31)) & 1u;
+            }
+            if (pass[0] | pass[1] | pass[2] | pass[3]) {
+                uint64_t cw[W], rv[W];
+                bool havew = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (!pass[k]) continue;
+                    const int dir = k >> 1, l = k & 1;
+                    uint32_t st = 0, cnt = 0;
+                    if (!dict_lookup_b(s.slots[l], s.cap[l], keys[k], &st, &cnt)) continue;
+                    const unsigned long long tp = (x << 2) | ((uint64_t)dir << 1) | (uint64_t)l;
                     if (cnt & SLOT_BIG) {                                     // > maxsearch reads: the visible window slides as reads get claimed
                         const unsigned int at = atomicAdd(s.nevents, 1u);     // (encoder.cpp:293) -> exact sequential pass k_realign_big
-                        const unsigned long long tp = (x << 2) | ((uint64_t)dir << 1) | (uint64_t)l;
                         if (at < s.maxevents) s.events[at] = make_uint4((uint32_t)tp, (uint32_t)(tp >> 32), st, cnt & SLOT_CNT_MASK);
                         continue;
                     }
+                    if (!havew) {                                             // window words, forward and reverse complement
+                        cons_words<W>(s.cons2, x, cw);
+#pragma unroll
+                        for (int w = 0; w < W; w++) cw[w] &= lowmask_word(2 * L, w);
+                        rc_words<W>(cw, L, rv);
+                        havew = true;
+                    }
                     const bool emb = (cnt & SLOT_EMB) != 0;
-                    cnt &= SLOT_CNT_MASK;
-                    const uint32_t lim = cnt;                                 // <= maxsearch: the whole bin is always visible
-                    for (uint32_t t = 0; t < lim; t++) {
+                    cnt &= SLOT_CNT_MASK;                                     // <= maxsearch: the whole bin is always visible
+                    for (uint32_t t = 0; t < cnt; t++) {
                         const uint32_t rid = emb ? st : s.ids[l][st + cnt - 1 - t];
-                        const uint64_t *r = s.cand3 + (size_t)rid * W3;
+                        const uint64_t *a2 = s.cand2 + (size_t)rid * W, *n2 = s.candN + (size_t)rid * W;
                         int hd = 0;
-                        for (int w = 0; w < W3; w++) {                        // 3-bit window word w, built on the fly
-                            uint64_t v = 0;
-                            const int b0 = (64 * w) / 3, b1 = (64 * w + 63) / 3;
-                            for (int b = b0; b <= b1 && b < L; b++) {
-                                const int idx = dir ? 3 - (int)(win[L - 1 - b] & 3) : (int)(win[b] & 3);
-                                const uint64_t c3 = (uint64_t)idx_to_c3(idx);
-                                const int sh = 3 * b - 64 * w;
-                                v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
-                            }
-                            hd += __popcll(v ^ r[w]);
-                            if (hd > s.thresh_s) break;
+#pragma unroll
+                        for (int w = 0; w < W; w++) {
+                            const uint64_t av = a2[w], nv = n2[w], wv = dir ? rv[w] : cw[w];
+                            hd += __popcll((av ^ wv) & ~nv) + __popcll(nv & 0x5555555555555555ULL) + __popcll(wv & nv);
                         }
-                        if (hd <= s.thresh_s) atomicMin(&s.best[rid], (unsigned long long)((x << 2) | ((uint64_t)dir << 1) | (uint64_t)l));
+                        if (hd <= s.thresh_s) atomicMin(&s.best[rid], tp);
                     }
                 }
             }
@@ -445,13 +513,6 @@ template <int W> __device__ __forceinline__ void final_words(const S2Args &s, ui
         for (int w = 0; w < W; w++) nmk[w] = ~t[w] & lowmask_word(2 * s.L, w);
     }
 }
-template <int W> __device__ __forceinline__ void cons_words(const uint64_t *cons2, uint64_t g, uint64_t (&cw)[W])
-{
-    const uint64_t bit = 2 * g, wi = bit >> 6; const int sh = (int)(bit & 63);
-    uint64_t lo = cons2[wi];
-#pragma unroll
-    for (int w = 0; w < W; w++) { const uint64_t hi = cons2[wi + w + 1]; cw[w] = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo; lo = hi; }
-}
 template <int W, bool EMIT> __global__ void k_noise(S2Args s, FinalArrays f, const uint64_t *cons2, uint32_t F, uint32_t *nm, uint32_t *nonN,
                                                     const uint64_t *nmoff, const uint32_t *nonNrank,
                                                     uint8_t *noise, uint8_t *noisepos, uint8_t *posb, uint8_t *rcb, uint32_t *order_out, uint32_t *orderN_out)
@@ -604,6 +665,10 @@ int stage2_run(harc_amd_ctx *c)
     if (T) hipLaunchKernelGGL(k_cand_order, G256(T), c->d_order_s, S, T, cand_order);
     HIP_TRY(hipMemsetAsync(best, 0xFF, ((size_t)T + 1) * 8, c->stream));
     a.cand3 = cand3; a.cand_order = cand_order; a.best = best;
+    uint64_t *cand2 = nullptr, *candN = nullptr;
+    RC_TRY(dalloc(c, &cand2, (size_t)T * W + 1)); RC_TRY(dalloc(c, &candN, (size_t)T * W + 1));
+    if (T) hipLaunchKernelGGL(k_cand2_from3, G256((size_t)T * W), (const uint64_t *)cand3, T, L, W, W3, cand2, candN);
+    a.cand2 = cand2; a.candN = candN;
     a.maxevents = 1u << 22;                                       // 64 MB of events; more than that fails loudly
     RC_TRY(dalloc(c, &a.events, (size_t)a.maxevents)); RC_TRY(dalloc(c, &a.nevents, 4));
     HIP_TRY(hipMemsetAsync(a.nevents, 0, 16, c->stream));
@@ -612,21 +677,30 @@ int stage2_run(harc_amd_ctx *c)
     DictDev dict[2];
     unsigned long long *d_big = nullptr; RC_TRY(dalloc(c, &d_big, 1));
     HIP_TRY(hipMemsetAsync(d_big, 0, 8, c->stream));
+    uint32_t *bloom[2] = { nullptr, nullptr }; int bloom_shift[2] = { 63, 63 };
     if (T) {
         RC_TRY(harc_dict_alloc(c, &dict[0], T)); RC_TRY(harc_dict_alloc(c, &dict[1], T));
         dict[0].bigthresh = dict[1].bigthresh = (uint32_t)P.maxsearch;
+        dict[0].bucketed = dict[1].bucketed = true;
+        int lb = 16; while (lb < 36 && (1ULL << lb) < 16ULL * T) lb++;           // 16 bits per key: ~6 % of absent keys pass
+        for (int l = 0; l < 2; l++) {
+            RC_TRY(dalloc(c, &bloom[l], ((size_t)1 << (lb - 5)) + 1));
+            HIP_TRY(hipMemsetAsync(bloom[l], 0, ((size_t)1 << (lb - 5)) * 4, c->stream));
+            bloom_shift[l] = 64 - lb;
+        }
         const harc_mark_t mk = harc_pool_mark(c);
         uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
         RC_TRY(dalloc(c, &k0, T)); RC_TRY(dalloc(c, &i0, T));
         for (int l = 0; l < 2; l++) {
             hipLaunchKernelGGL(k_key3, G256(T), cand3, T, W3, 3 * a.ds[l], a.kbits[l], k0, i0);
+            hipLaunchKernelGGL(k_bloom_set, G256(T), (const uint64_t *)k0, T, bloom[l], bloom_shift[l]);
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, T, (unsigned)a.kbits[l]));
             hipLaunchKernelGGL(k_count_big_bins, G256(dict[l].cap), dict[l].slots, dict[l].cap, (uint32_t)P.maxsearch, d_big);
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
         harc_pool_release(c, mk);
     }
-    for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
+    for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; a.bloom[l] = bloom[l]; a.bloom_shift[l] = bloom_shift[l]; }
 
     // ---- contig structure on the global column axis
     uint8_t *head = nullptr; uint32_t *u0 = nullptr, *u1 = nullptr; uint64_t *d64 = nullptr, *gstart = nullptr; uint32_t *chead = nullptr;
@@ -655,12 +729,23 @@ int stage2_run(harc_amd_ctx *c)
     // ---- consensus + realignment proposals
     uint8_t *cons = nullptr; RC_TRY(dalloc(c, &cons, (size_t)total + 8));
     a.cons = cons;
+    uint64_t *cons2 = nullptr;
+    const uint64_t ncw = (total + 31) / 32;
+    RC_TRY(dalloc(c, &cons2, (size_t)ncw + 2 * W + 4));
+    HIP_TRY(hipMemsetAsync(cons2 + ncw, 0, ((size_t)2 * W + 4) * 8, c->stream));
+    a.cons2 = cons2;
     if (total) {
         unsigned long long *cinfo = nullptr; RC_TRY(dalloc(c, &cinfo, (size_t)nC + 1));
         hipLaunchKernelGGL(k_contig_info, G256(nC), a, cinfo);
         hipLaunchKernelGGL(k_consensus, G256((total + CSTRIP - 1) / CSTRIP), a, (const uint32_t *)u1, (const unsigned long long *)cinfo, T ? 1 : 0);
+        hipLaunchKernelGGL(k_pack_cons2, G256(ncw), (const uint8_t *)a.cons, total, ncw, cons2);
         if (T) {
-            hipLaunchKernelGGL(k_realign_propose, dim3((unsigned)((total + RTILE - 1) / RTILE)), dim3(256), 0, c->stream, a);
+            const dim3 rg((unsigned)((total + RTILE - 1) / RTILE));
+            switch (W) {
+#define REALIGN_CASE(WW) case WW: hipLaunchKernelGGL((k_realign_propose<WW>), rg, dim3(256), 0, c->stream, a); break;
+                REALIGN_CASE(1) REALIGN_CASE(2) REALIGN_CASE(3) REALIGN_CASE(4) REALIGN_CASE(5) REALIGN_CASE(6) REALIGN_CASE(7) REALIGN_CASE(8)
+#undef REALIGN_CASE
+            }
             unsigned int nev = 0;
             HIP_TRY(hipMemcpyAsync(&nev, a.nevents, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -705,11 +790,6 @@ int stage2_run(harc_amd_ctx *c)
     uint32_t *nm = nullptr, *nonN = nullptr, *nonNrank = nullptr; uint64_t *nmoff = nullptr;
     RC_TRY(dalloc(c, &nm, (size_t)F + 1)); RC_TRY(dalloc(c, &nonN, (size_t)F + 1)); RC_TRY(dalloc(c, &nonNrank, (size_t)F + 1)); RC_TRY(dalloc(c, &nmoff, (size_t)F + 1));
     HIP_TRY(hipMemsetAsync(nm, 0, ((size_t)F + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(nonN, 0, ((size_t)F + 1) * 4, c->stream));
-    uint64_t *cons2 = nullptr;
-    const uint64_t ncw = (total + 31) / 32;
-    RC_TRY(dalloc(c, &cons2, (size_t)ncw + 2 * W + 4));
-    HIP_TRY(hipMemsetAsync(cons2 + ncw, 0, ((size_t)2 * W + 4) * 8, c->stream));
-    if (ncw) hipLaunchKernelGGL(k_pack_cons2, G256(ncw), (const uint8_t *)a.cons, total, ncw, cons2);
     if (F) launch_noise<false>(c, a, f, cons2, F, nm, nonN, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     RC_TRY(prim_excl_scan_u32_to_u64(c, nm, nmoff, (size_t)F + 1));
     RC_TRY(prim_excl_scan_u32(c, nonN, nonNrank, (size_t)F + 1));
