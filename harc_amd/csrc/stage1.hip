@@ -27,12 +27,13 @@ struct S1Args {
     uint2 *steps;                    // [K][64] steps of the current super-round: {rid, shift | dir<<8}
     uint8_t *need;                   // per chain: wants a new seed (set by k_resolve, consumed by k_reseed)
     uint32_t *seedbuf;               // [K * (1 + HARC_NSUGG)] seeds, then look-ahead seeds, found by k_reseed, by rank
-    uint32_t *needlist;              // [K] chains that want a seed, ascending (k_reseed scratch)
+    uint32_t *needrank;              // [K] rank of a chain among those that want a seed (k_reseed -> the next k_steps, which applies the seed)
+    uint32_t *rmeta;                 // [4] k_reseed's result: chains that wanted a seed, seeds found, look-ahead seeds found
+    uint2 *cst2;                     // per chain: x seeds taken (= unmatched reads, reorder.cpp:701), y lost bids
     uint32_t *sugg;                  // [K][HARC_NSUGG] look-ahead seeds of every chain, highest id first
     int S;                           // speculative steps per super-round (1..64)
     int nsugg_per_seed;              // look-ahead seeds per reseed (HARC_NSUGG; 0 disables them: experiments only, the oracle uses the same value)
-    LogRec *log;
-    unsigned long long *logcount;
+    LogRec *log;                     // [N] indexed by read id: every read is emitted exactly once, by exactly one chain
     long long *cursor;               // reorder.cpp `remainingpos`, one for all chains
     unsigned long long *stats;       // [0] unmatched [1] conflicts [2] active chains [3] probes [4] candidates
     const uint16_t *probe_tab;       // the probes of one chain step in priority order: shift | dir<<8 | dict<<9
@@ -219,10 +220,9 @@ __global__ void k_init_chains(S1Args s)
         const uint32_t seed = c * step;
         atomicOr(&s.claimed[seed >> 6], 1ULL << (seed & 63));
         h.cur = seed; h.prev = seed; h.flags = CH_ACTIVE | CH_PREVUNM; h.mode = 2;
-        atomicAdd(&s.stats[ST_UNMATCHED], 1ULL);
-        atomicAdd(&s.stats[ST_ACTIVE], 1ULL);
     }
     s.hdr[c] = h;
+    s.cst2[c] = make_uint2(act ? 1u : 0u, 0u);
     s.need[c] = 0;
 }
 
@@ -349,6 +349,27 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
     ChainHdr h = s.hdr[c];
     uint4 cst = s.cstat[c];
     if (!(h.flags & CH_ACTIVE)) return;
+    if (s.need[c]) {
+        // the chain asked for a seed last super-round and k_reseed ranked it: take seed number `rank` (reorder.cpp:650-688), or finish
+        const uint32_t r = s.needrank[c], R = s.rmeta[0], assigned = s.rmeta[1], got = s.rmeta[2];
+        if (h.flags & CH_PREVUNM) {                               // previous seed found nothing: singleton (reorder.cpp:672-684)
+            if (lane == 0) { LogRec rec; rec.chain = c; rec.seq = h.n_sing; rec.rid = h.prev; rec.meta = 1u << 10; s.log[h.prev] = rec; }
+            h.n_sing++;
+        }
+        if (r < assigned) {
+            const uint32_t id = s.seedbuf[r];
+            h.cur = id; h.prev = id; h.flags = (h.flags | CH_PREVUNM) & ~CH_NEEDSEED; h.mode = 2;
+            const uint32_t first = r * (uint32_t)s.nsugg_per_seed;
+            const uint32_t ng = first >= got ? 0u : (got - first < (uint32_t)s.nsugg_per_seed ? got - first : (uint32_t)s.nsugg_per_seed);
+            if ((uint32_t)lane < ng) s.sugg[(size_t)c * HARC_NSUGG + lane] = s.seedbuf[R + first + lane];
+            h.nsteps = ng << 24;                                  // nothing walked, nothing to replay, look-ahead position 0
+            if (lane == 0) { uint2 q = s.cst2[c]; q.x++; s.cst2[c] = q; s.need[c] = 0; }
+        } else {                                                  // no reads left (reorder.cpp:670-677)
+            h.flags &= ~(CH_ACTIVE | CH_PREVUNM | CH_NEEDSEED);
+            if (lane == 0) { atomicAdd(&s.stats[ST_ACTIVE], ~0ULL); s.need[c] = 0; s.hdr[c] = h; }
+            return;
+        }
+    }
     const int L = s.L;
     constexpr int LP = ConsState<W>::LP;
     const uint32_t par = (h.flags & CH_PARITY) ? 1u : 0u;
@@ -610,7 +631,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                 const int idx = spos + lane;
                 uint32_t id = 0; bool okc = false;
                 if (idx < nsugg) {
-                    id = s.sugg[(size_t)c * HARC_NSUGG + idx];
+                    id = __hip_atomic_load(&s.sugg[(size_t)c * HARC_NSUGG + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // may have been written by this wave above
                     okc = !((s.claimed[id >> 6] >> (id & 63)) & 1ULL);
                     for (int k = 0; k < t; k++) okc = okc && ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) != id);
                 }
@@ -684,25 +705,19 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
     const uint32_t pid = sl == 0 ? h.prev : prid;
     const uint32_t nm = kept ? (seedk ? 0u : (punm ? 2u : 1u)) : 0u;               // main-stream records
     const uint32_t ns = (kept && seedk && punm) ? 1u : 0u;                          // singleton-stream records
-    uint32_t tm, ts, tr;
-    const uint32_t em = wave_excl_scan_u32(nm, &tm), es = wave_excl_scan_u32(ns, &ts), er = wave_excl_scan_u32(nm + ns, &tr);
+    uint32_t tm, ts;
+    const uint32_t em = wave_excl_scan_u32(nm, &tm), es = wave_excl_scan_u32(ns, &ts);
     const uint32_t em0 = __shfl(em, g0, 64), es0 = __shfl(es, g0, 64);
-    unsigned long long wbase = 0;
-    if (tr) {
-        if (lane == 0) wbase = atomicAdd(s.logcount, (unsigned long long)tr);
-        wbase = shfl_u64(wbase, 0);
-    }
-    if (kept) {
+    if (kept) {                                                   // the record of a read lives at log[read id]: no shared counter
         atomicOr(&s.claimed[sp.x >> 6], 1ULL << (sp.x & 63));
-        unsigned long long at = wbase + er;
         if (seedk) {
-            if (punm) { LogRec r; r.chain = c; r.seq = h.n_sing + (es - es0); r.rid = pid; r.meta = 1u << 10; s.log[at] = r; }
+            if (punm) { LogRec r; r.chain = c; r.seq = h.n_sing + (es - es0); r.rid = pid; r.meta = 1u << 10; s.log[pid] = r; }
         } else {
             uint32_t seq = h.n_main + (em - em0);
-            if (punm) { LogRec r; r.chain = c; r.seq = seq++; r.rid = pid; r.meta = (uint32_t)(s.L & 0xFF); s.log[at++] = r; }   // the pending seed opens a contig
+            if (punm) { LogRec r; r.chain = c; r.seq = seq++; r.rid = pid; r.meta = (uint32_t)(s.L & 0xFF); s.log[pid] = r; }   // the pending seed opens a contig
             LogRec r; r.chain = c; r.seq = seq; r.rid = sp.x;
             r.meta = (sp.y & 0xFF) | (1u << 8) | (((sp.y >> 8) & 1u) << 9);
-            s.log[at] = r;
+            s.log[sp.x] = r;
         }
     }
     // group totals and the last kept step
@@ -720,19 +735,18 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
             h.cur = lastrid;
             if (lastseed) { h.prev = lastrid; h.flags |= CH_PREVUNM; } else h.flags &= ~CH_PREVUNM;
         }
-        if (nseed) atomicAdd(&s.stats[ST_UNMATCHED], (unsigned long long)nseed);
         uint32_t spos = (h.nsteps >> 16) & 0xFF;
         if (cut) { if (nseed) spos = lastsidx; }                 // look-ahead seeds of dropped steps stay available
         else spos = (h.pad0 >> 16) & 0xFF;
         const uint32_t keep = (h.nsteps & 0xFF000000u) | (spos << 16);
         if (cut) {
             h.mode = v > 0 ? 1u : 0u; h.nsteps = keep | ((uint32_t)v << 8); h.flags &= ~CH_NEEDSEED;
-            atomicAdd(&s.stats[ST_CONFLICTS], 1ULL);
         } else {
             if (n > 0) { h.flags ^= CH_PARITY; h.mode = 0; }
             h.nsteps = keep;
         }
         s.hdr[c] = h;
+        if (nseed || cut) { uint2 q = s.cst2[c]; q.x += (uint32_t)nseed; q.y += cut ? 1u : 0u; s.cst2[c] = q; }
         s.need[c] = (!cut && (h.flags & CH_NEEDSEED)) ? 1 : 0;
     }
 }
@@ -740,6 +754,7 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
 // (C) one workgroup: new seeds, in chain order, from the single descending cursor over unclaimed reads (reorder.cpp:650-688);
 // when the cursor runs out the remaining chains finish.  Every reseeded chain also gets HARC_NSUGG look-ahead seeds: the next
 // unclaimed ids below the cursor (not claimed, the cursor does not move), which k_steps uses when the chain is stuck again.
+// The kernel only ranks the chains and finds the ids; every chain applies its own seed at the top of the next k_steps.
 __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
 {
     __shared__ uint32_t sm[20];
@@ -752,11 +767,11 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
     if (c0 < s.K) for (uint32_t c = c0; c < c0 + chunk; c += 8) mycnt += (uint32_t)__popcll(*(const unsigned long long *)(s.need + c));
     uint32_t R; const uint32_t rbase = block_excl_scan_u32<1024>(mycnt, sm, &R);
     if (R == 0) return;
-    if (mycnt) {                                                  // needlist[rank] = chain, ascending
+    if (mycnt) {                                                  // rank of every chain that wants a seed, ascending chain id
         uint32_t r = rbase;
         for (uint32_t c = c0; c < c0 + chunk; c += 8) {
             unsigned long long w = *(const unsigned long long *)(s.need + c);
-            while (w) { const int b = __ffsll((long long)w) - 1; w &= w - 1; s.needlist[r++] = c + (uint32_t)(b >> 3); }
+            while (w) { const int b = __ffsll((long long)w) - 1; w &= w - 1; s.needrank[c + (uint32_t)(b >> 3)] = r++; }
         }
     }
 
@@ -810,52 +825,34 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
     }
     __threadfence();
     __syncthreads();
-    for (uint32_t r = (uint32_t)t; r < R; r += 1024) {            // one needy chain per thread and pass
-        const uint32_t c = s.needlist[r];
-        ChainHdr h = s.hdr[c];
-        if (h.flags & CH_PREVUNM) {                               // previous seed found nothing: singleton (reorder.cpp:672-684)
-            const unsigned long long at = atomicAdd(s.logcount, 1ULL);
-            LogRec rec; rec.chain = c; rec.seq = h.n_sing++; rec.rid = h.prev; rec.meta = 1u << 10;
-            s.log[at] = rec;
-        }
-        if (r < assigned) {
-            const uint32_t id = s.seedbuf[r];
-            h.cur = id; h.prev = id; h.flags = (h.flags | CH_PREVUNM) & ~CH_NEEDSEED; h.mode = 2;
-            const uint32_t first = r * (uint32_t)s.nsugg_per_seed;
-            const uint32_t ng = first >= got ? 0u : (got - first < (uint32_t)s.nsugg_per_seed ? got - first : (uint32_t)s.nsugg_per_seed);
-            for (uint32_t q = 0; q < ng; q++) s.sugg[(size_t)c * HARC_NSUGG + q] = s.seedbuf[R + first + q];
-            h.nsteps = ng << 24;                                  // nothing walked, nothing to replay, look-ahead position 0
-            atomicAdd(&s.stats[ST_UNMATCHED], 1ULL);
-        } else {                                                  // no reads left (reorder.cpp:670-677)
-            h.flags &= ~(CH_ACTIVE | CH_PREVUNM | CH_NEEDSEED);
-            atomicAdd(&s.stats[ST_ACTIVE], ~0ULL);                // -1
-        }
-        s.hdr[c] = h;
-        s.need[c] = 0;
-    }
+    // the chains take their seeds themselves at the top of the next k_steps (rank -> seedbuf)
+    if (t == 0) { s.rmeta[0] = R; s.rmeta[1] = assigned; s.rmeta[2] = got; }
     if (t == 0) *s.cursor = cursor < -1 ? -1 : cursor;
 }
 
 // ------------------------------------------------------------------------------------------------ finalisation
-__global__ void k_chain_counts(const ChainHdr *hdr, const uint4 *cstat, uint32_t K, uint32_t *nmain, uint32_t *nsing, unsigned long long *stats)
+__global__ void k_chain_counts(const ChainHdr *hdr, const uint4 *cstat, const uint2 *cst2, uint32_t K, uint32_t *nmain, uint32_t *nsing, unsigned long long *stats)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t np = 0, nc = 0, nu = 0;
-    if (c < K) { nmain[c] = hdr[c].n_main; nsing[c] = hdr[c].n_sing; const uint4 st = cstat[c]; np = st.x; nc = st.y; nu = st.z; }
-    np = wave_sum_u32(np); nc = wave_sum_u32(nc); nu = wave_sum_u32(nu);
+    uint32_t np = 0, nc = 0, nu = 0, um = 0, cf = 0;
+    if (c < K) { nmain[c] = hdr[c].n_main; nsing[c] = hdr[c].n_sing; const uint4 st = cstat[c]; np = st.x; nc = st.y; nu = st.z; const uint2 q = cst2[c]; um = q.x; cf = q.y; }
+    np = wave_sum_u32(np); nc = wave_sum_u32(nc); nu = wave_sum_u32(nu); um = wave_sum_u32(um); cf = wave_sum_u32(cf);
     if ((threadIdx.x & 63) == 0) {
+        if (um) atomicAdd(&stats[ST_UNMATCHED], (unsigned long long)um);
+        if (cf) atomicAdd(&stats[ST_CONFLICTS], (unsigned long long)cf);
         if (np) atomicAdd(&stats[ST_PROBES], (unsigned long long)np);
         if (nc) atomicAdd(&stats[ST_CANDS], (unsigned long long)nc);
         if (nu) atomicAdd(&stats[ST_USEFUL], (unsigned long long)nu);
     }
 }
 // per-chain streams concatenated in chain order (reorder.cpp:778-821)
-__global__ void k_s1_scatter(const LogRec *log, unsigned long long nlog, const uint32_t *base_main, const uint32_t *base_sing,
-                             uint32_t *order, uint8_t *flag, uint8_t *pos, uint8_t *rc, uint32_t *order_s)
+__global__ void k_s1_scatter(const LogRec *log, unsigned long long nlog, uint32_t K, const uint32_t *base_main, const uint32_t *base_sing,
+                             uint32_t *order, uint8_t *flag, uint8_t *pos, uint8_t *rc, uint32_t *order_s, unsigned long long *bad)
 {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nlog) return;
     const LogRec r = log[i];
+    if (r.chain >= K || r.rid != (uint32_t)i) { atomicAdd(bad, 1ULL); return; }      // a read nobody emitted (the log starts as 0xFF)
     if (r.meta & (1u << 10)) order_s[base_sing[r.chain] + r.seq] = r.rid;
     else {
         const uint32_t at = base_main[r.chain] + r.seq;
@@ -994,8 +991,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const uint32_t nblk = (K + 255) / 256;
     RC_TRY(dalloc(c, &a.claimed, nwords)); RC_TRY(dalloc(c, &a.bid, (size_t)N + 1)); RC_TRY(dalloc(c, &a.hdr, K));
     RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.steps, (size_t)K * 64)); RC_TRY(dalloc(c, &a.need, (size_t)K + 8192 + 1024));
-    RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + HARC_NSUGG))); RC_TRY(dalloc(c, &a.needlist, (size_t)K + 16)); RC_TRY(dalloc(c, &a.sugg, (size_t)K * HARC_NSUGG));
-    RC_TRY(dalloc(c, &a.log, (size_t)N + 1)); RC_TRY(dalloc(c, &a.logcount, 1));
+    RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + HARC_NSUGG))); RC_TRY(dalloc(c, &a.needrank, (size_t)K + 16)); RC_TRY(dalloc(c, &a.rmeta, 4)); RC_TRY(dalloc(c, &a.cst2, (size_t)K + 1)); RC_TRY(dalloc(c, &a.sugg, (size_t)K * HARC_NSUGG));
+    RC_TRY(dalloc(c, &a.log, (size_t)N + 1));
     RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N));
     RC_TRY(dalloc(c, &a.cstat, K)); HIP_TRY(hipMemsetAsync(a.cstat, 0, (size_t)K * 16, c->stream));
     RC_TRY(dalloc(c, &a.dbg, 16)); HIP_TRY(hipMemsetAsync(a.dbg, 0, 16 * 8, c->stream));
@@ -1013,11 +1010,16 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     }
     HIP_TRY(hipMemsetAsync(a.claimed, 0, nwords * 8, c->stream));
     HIP_TRY(hipMemsetAsync(a.bid, 0xFF, ((size_t)N + 1) * 4, c->stream));
-    HIP_TRY(hipMemsetAsync(a.logcount, 0, 8, c->stream));
+    HIP_TRY(hipMemsetAsync(a.log, 0xFF, ((size_t)N + 1) * sizeof(LogRec), c->stream));
+    HIP_TRY(hipMemsetAsync(a.rmeta, 0, 16, c->stream));
     HIP_TRY(hipMemsetAsync(a.stats, 0, ST_N * 8, c->stream));
     HIP_TRY(hipMemsetAsync(a.need, 0, (size_t)K + 8192 + 1024, c->stream));
     const long long cur0 = (long long)N - 1;
     HIP_TRY(hipMemcpyAsync(a.cursor, &cur0, 8, hipMemcpyHostToDevice, c->stream));
+    {   // chains alive at the start: all of them when floor(N/K) > 0, else only chain 0 (reorder.cpp:484-490)
+        const unsigned long long act0 = N == 0 ? 0ULL : (N / K > 0 ? (unsigned long long)K : 1ULL);
+        HIP_TRY(hipMemcpyAsync(a.stats + ST_ACTIVE, &act0, 8, hipMemcpyHostToDevice, c->stream));
+    }
     hipLaunchKernelGGL(k_init_chains, dim3(nblk), dim3(256), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
 
@@ -1053,21 +1055,22 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     uint32_t *nmain = nullptr, *nsing = nullptr, *bmain = nullptr, *bsing = nullptr;
     RC_TRY(dalloc(c, &nmain, (size_t)K + 1)); RC_TRY(dalloc(c, &nsing, (size_t)K + 1)); RC_TRY(dalloc(c, &bmain, (size_t)K + 1)); RC_TRY(dalloc(c, &bsing, (size_t)K + 1));
     HIP_TRY(hipMemsetAsync(nmain, 0, ((size_t)K + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(nsing, 0, ((size_t)K + 1) * 4, c->stream));
-    hipLaunchKernelGGL(k_chain_counts, dim3(nblk), dim3(256), 0, c->stream, a.hdr, a.cstat, K, nmain, nsing, a.stats);
+    hipLaunchKernelGGL(k_chain_counts, dim3(nblk), dim3(256), 0, c->stream, a.hdr, a.cstat, (const uint2 *)a.cst2, K, nmain, nsing, a.stats);
     RC_TRY(prim_excl_scan_u32(c, nmain, bmain, (size_t)K + 1));
     RC_TRY(prim_excl_scan_u32(c, nsing, bsing, (size_t)K + 1));
-    uint32_t M = 0, S = 0; unsigned long long nlog = 0;
+    uint32_t M = 0, S = 0; const unsigned long long nlog = N;
     HIP_TRY(hipMemcpyAsync(&M, bmain + K, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&S, bsing + K, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&nlog, a.logcount, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((unsigned long long)M + S != nlog) { harc_set_error("stage I bookkeeping: M=%u S=%u N=%u", M, S, N); return HARC_AMD_ENODEVICE; }
+    c->M = M; c->S = S;
+    unsigned long long *d_bad = a.stats + ST_N - 1;               // last statistics word: records that nobody wrote
+    if (nlog) hipLaunchKernelGGL(k_s1_scatter, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, c->stream, a.log, nlog, K, bmain, bsing,
+                                 c->d_order, c->d_flag, c->d_pos, c->d_rc, c->d_order_s, d_bad);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((unsigned long long)M + S != nlog || nlog != N) { harc_set_error("stage I bookkeeping: M=%u S=%u log=%llu N=%u", M, S, nlog, N); return HARC_AMD_ENODEVICE; }
-    c->M = M; c->S = S;
-    if (nlog) hipLaunchKernelGGL(k_s1_scatter, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, c->stream, a.log, nlog, bmain, bsing,
-                                 c->d_order, c->d_flag, c->d_pos, c->d_rc, c->d_order_s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h_stats[ST_N - 1]) { harc_set_error("stage I bookkeeping: %llu reads were never emitted", h_stats[ST_N - 1]); return HARC_AMD_ENODEVICE; }
 
     c->C.n_main = M; c->C.n_singleton = S; c->C.unmatched = h_stats[ST_UNMATCHED]; c->C.conflicts = h_stats[ST_CONFLICTS];
     c->C.probes = h_stats[ST_PROBES]; c->C.candidates = h_stats[ST_CANDS]; c->C.useful_probes = h_stats[ST_USEFUL]; c->C.rounds = rounds; c->C.propose_launches = launches;
