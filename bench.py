@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("HARC_BENCH_WORKLOAD", "c2"))
     ap.add_argument("--chains", type=int, default=0)
+    ap.add_argument("--super-steps", type=int, default=0, help="steps per super-round (num_steps, default 16)")
     ap.add_argument("--shards", type=int, default=8, help="num_thr of the reference = encoder shards per GPU (harc:195 default 8)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket exchange even at world size 1 (exercises the N>1 path on one GPU)")
@@ -144,7 +145,7 @@ def main():
     import harc_amd
     n, L, G, err, desc = WORKLOADS[args.workload]
     # weak scaling: same reads per GPU, genome (and so coverage) per GPU constant; every rank samples the WHOLE genome
-    p = harc_amd.default_params(L, num_thr=args.shards, num_chains=args.chains, device=local, profile=1)
+    p = harc_amd.default_params(L, num_thr=args.shards, num_chains=args.chains, device=local, profile=1, num_steps=args.super_steps)
     h = harc_amd.HarcAmd(p)
     # inputs, 4 M reads at a time so that config-3/4-sized sets never exist as ASCII: clean reads are packed to 2 bits per base
     # (k_pack2) as they are made, reads with N are kept as text for stage II; the order-independent signature of both is taken on

@@ -1046,6 +1046,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
+        if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] round %llu: %llu chains alive\n", (unsigned long long)rounds, h_stats[ST_ACTIVE]);
         if (h_stats[ST_ACTIVE] == 0) break;
         if (rounds > (uint64_t)N * 2 + 1024) { harc_set_error("stage I did not converge after %llu rounds", (unsigned long long)rounds); return HARC_AMD_ENODEVICE; }
     }
