@@ -901,13 +901,14 @@ int pack_order_run(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &d_in, (size_t)n + 1)); RC_TRY(dalloc(c, &d_out, (size_t)ng * numbits + 1));
     HIP_TRY(hipMemcpyAsync(d_in, in_p, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     if (ng) hipLaunchKernelGGL(k_pack_order, G256((uint64_t)ng * numbits), d_in, ng, numbits, d_out);
-    std::vector<uint8_t> body;
-    RC_TRY(harc_d2h(c, body, d_out, (size_t)ng * numbits * 4));
+    // header + body straight into the pinned output arena (one device->host copy, no staging vectors)
+    const size_t body_bytes = (size_t)ng * numbits * 4;
+    uint8_t *hp = nullptr;
+    RC_TRY(harc_host_alloc(c, (void **)&hp, 8 + body_bytes));
+    memcpy(hp, &numbits, 4); memcpy(hp + 4, &n, 4);                               // pack_order.cpp:37-38
+    if (body_bytes) HIP_TRY(hipMemcpyAsync(hp + 8, d_out, body_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<uint8_t> &o = out_buf(c, HARC_AMD_P_ORDER, 0);
-    o.resize(8 + body.size());
-    memcpy(o.data(), &numbits, 4); memcpy(o.data() + 4, &n, 4);                   // pack_order.cpp:37-38
-    if (!body.empty()) memcpy(o.data() + 8, body.data(), body.size());
+    out_slice(c, HARC_AMD_P_ORDER, 0, hp, 8 + body_bytes);
     { std::vector<uint8_t> tailv(in_p + (size_t)ng * 32 * 4, in_p + (size_t)ng * 32 * 4 + (size_t)(n % 32) * 4); out_buf(c, HARC_AMD_P_ORDER_TAIL, 0) = tailv; }
     harc_pool_release(c, mk);
     return HARC_AMD_OK;
