@@ -16,9 +16,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    so = os.environ.get("HARC_ORACLE_LIB") or os.path.join(ORACLE_DIR, "liboracle.so")      # override: e.g. the ASan/UBSan build (make -C oracle asan)
     src = os.path.join(ORACLE_DIR, "harc_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    if "HARC_ORACLE_LIB" not in os.environ and (not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     lib = C.CDLL(so)
     u32p, u64p, u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
