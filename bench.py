@@ -145,7 +145,10 @@ def main():
     import harc_amd
     n, L, G, err, desc = WORKLOADS[args.workload]
     # weak scaling: same reads per GPU, genome (and so coverage) per GPU constant; every rank samples the WHOLE genome
-    p = harc_amd.default_params(L, num_thr=args.shards, num_chains=args.chains, device=local, profile=1, num_steps=args.super_steps)
+    # a minimizer-bucket shard is already fragmented into islands of ~10 overlapping reads: twice as many chains cost +0.3 % (8 GPUs) to
+    # +1.2 % (2 GPUs) of consensus bases there and save 38 % of the chain time (tools/shard_sim.py); one GPU keeps one chain per 2048 reads
+    rpc = 1024 if (world > 1 or args.force_dist) else 0
+    p = harc_amd.default_params(L, num_thr=args.shards, num_chains=args.chains, device=local, profile=1, num_steps=args.super_steps, reads_per_chain=rpc)
     h = harc_amd.HarcAmd(p)
     # inputs, 4 M reads at a time so that config-3/4-sized sets never exist as ASCII: clean reads are packed to 2 bits per base
     # (k_pack2) as they are made, reads with N are kept as text for stage II; the order-independent signature of both is taken on
@@ -271,7 +274,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64 (2-bit packed bases, XOR+popcount)", "data": "synthetic",
         "config": {"workload": args.workload, "description": desc, "reads_per_gpu": n, "readlen": L, "genome_bp": G * world,
-                   "error_rate": err, "chains_per_gpu": int(c.chains), "encoder_shards_per_gpu": args.shards,
+                   "error_rate": err, "chains_per_gpu": int(c.chains), "reads_per_chain": rpc or 2048, "encoder_shards_per_gpu": args.shards,
                    "parallelism": "single GPU" if world == 1 else f"minimizer-bucket shard x{world}, one RCCL all-to-all"},
         "roofline": roofline,
         "roundtrip": roundtrip,

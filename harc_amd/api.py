@@ -15,7 +15,7 @@ class Params(C.Structure):
     """harc_amd_params == src/config.h macros (harc:52-63)"""
     _fields_ = [("readlen", C.c_int32), ("num_thr", C.c_int32), ("num_chains", C.c_int32), ("maxmatch", C.c_int32),
                 ("thresh", C.c_int32), ("thresh_s", C.c_int32), ("maxsearch", C.c_int32), ("dict_start", C.c_int32 * 2),
-                ("dict_end", C.c_int32 * 2), ("device", C.c_int32), ("profile", C.c_int32), ("num_steps", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("dict_end", C.c_int32 * 2), ("device", C.c_int32), ("profile", C.c_int32), ("num_steps", C.c_int32), ("reads_per_chain", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Counters(C.Structure):
@@ -93,10 +93,11 @@ def _check(rc):
         raise HarcAmdError(rc, lib().harc_amd_last_error().decode(errors="replace"))
 
 
-def default_params(readlen, num_thr=8, num_chains=0, device=0, profile=0, num_steps=0):
+def default_params(readlen, num_thr=8, num_chains=0, device=0, profile=0, num_steps=0, reads_per_chain=0):
     p = Params()
     _check(lib().harc_amd_default_params(readlen, C.byref(p)))
     p.num_thr, p.num_chains, p.device, p.profile, p.num_steps = num_thr, num_chains, device, profile, num_steps
+    p.reads_per_chain = reads_per_chain
     return p
 
 

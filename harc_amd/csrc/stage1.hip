@@ -929,11 +929,11 @@ static std::vector<uint16_t> make_probe_table(const harc_amd_params &P)
     return t;
 }
 
-static uint32_t auto_chains(uint32_t N)
+static uint32_t auto_chains(uint32_t N, int reads_per_chain)
 {
     // one chain per ~2048 reads keeps chains sparse on the genome (every chain costs about one extra contig);
     // 65536 waves is several full waves of occupancy on 256 CUs
-    uint32_t k = N / 2048;
+    uint32_t k = N / (uint32_t)(reads_per_chain > 0 ? reads_per_chain : 2048);
     if (k > 65536) k = 65536;
     if (k < 1) k = 1;
     return k;
@@ -943,7 +943,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
 {
     const harc_amd_params &P = c->P;
     const uint32_t N = c->N;
-    uint32_t K = P.num_chains > 0 ? (uint32_t)P.num_chains : auto_chains(N);
+    uint32_t K = P.num_chains > 0 ? (uint32_t)P.num_chains : auto_chains(N, P.reads_per_chain);
     if (K > HARC_MAXK) K = HARC_MAXK;
     if (N == 0 || K > N) K = 1;                                  // floor(N/K)=0: only chain 0 ever runs (reorder.cpp:484-490)
     c->C.chains = K;

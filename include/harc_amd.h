@@ -58,7 +58,9 @@ typedef struct harc_amd_params {
     int32_t profile;          /* 1: time every launch of the dominant kernel with HIP events on the context's stream */
     int32_t num_steps;        /* S: speculative chain steps per launch of the chain kernel (1..64; 0 = auto).  Output is independent
                                  of S when num_chains = 1; for num_chains > 1 the pair (K,S) defines the schedule */
-    int32_t reserved[3];
+    int32_t reads_per_chain;  /* auto mode (num_chains = 0): one chain per this many reads, capped at 65536 chains; 0 = 2048.  Inputs that are
+                                 already fragmented (one minimizer bucket of a multi-GPU shard) lose nothing with 1024 and run faster. */
+    int32_t reserved[2];
 } harc_amd_params;
 
 /* Counters: the three numbers the reference prints (reorder.cpp:701, encoder.cpp:506-508) + kernel-side statistics. */

@@ -20,8 +20,8 @@ for r in range(world):
 shard = torch.cat(parts).contiguous()
 import hashlib
 print("shard reads", shard.shape[0], hashlib.md5(shard.cpu().numpy().tobytes()).hexdigest(), flush=True)
-for it, K in enumerate([0, 0, 700, 2843, 1400, 1450]):
-    p = harc_amd.default_params(L, num_thr=8, num_chains=K); h = harc_amd.HarcAmd(p)
+for it, (K, rpc) in enumerate([(0, 0), (0, 0), (0, 1024), (0, 512), (0, 256)]):
+    p = harc_amd.default_params(L, num_thr=8, num_chains=K, reads_per_chain=rpc); h = harc_amd.HarcAmd(p)
     torch.cuda.synchronize(); t0 = time.time()
     h.set_reads_packed_device(shard.data_ptr(), shard.shape[0]); h.reorder(); h.encode()
     torch.cuda.synchronize(); dt = time.time() - t0
