@@ -283,7 +283,7 @@ def main():
                                "rounds": int(c.rounds), "conflicts": int(c.conflicts), "contigs": int(c.contigs),
                                "seq_bases": int(c.seq_bases), "device_bytes_peak": int(c.device_bytes_peak)},
     }
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:             # the CPU baseline is reported at N=1 only
         ns = args.cpu_sample or min(n, 3_300_000 if err > 0 or G // max(1, n) < 10 else 1_000_000)
         Gs = max(L * 4, int(G * (ns / n)))
         out["cpu_baseline"] = cpu_baseline(ns, L, Gs, err, 999, dev)
