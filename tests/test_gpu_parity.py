@@ -533,3 +533,22 @@ def test_P5_stream_sizes_vs_reference_t8(tmp_path):
     sa, sb = size(a), size(b)
     print("stream sizes xz-6: gpu default", sa, "reference -t 8", sb, "ratio %.3f" % (sa / sb))
     assert sa <= 1.05 * sb
+
+
+def test_preserve_order_decoder_needs_order_files(tmp_path):
+    """-d -p on streams that were not kept with their order files fails loudly (harc:146-153), it does not guess"""
+    import harc_amd
+    g = ol.load_golden("L100_err_5k")
+    base = ol.stage_dir(tmp_path, {k[len("stage2/"):]: v for k, v in g.items() if k.startswith("stage2/") and "read_order" not in k})
+    with pytest.raises(harc_amd.HarcAmdError) as e:
+        harc_amd.decoder(base, 1, preserve_order=True)
+    assert "order" in str(e.value)
+    # a packed order that does not match the streams is refused too
+    base2 = ol.stage_dir(tmp_path / "b", {k[len("stage2/"):]: v for k, v in g.items() if k.startswith("stage2/")})
+    for k, v in g.items():
+        if k.startswith("packed/"):
+            (tmp_path / "b" / "output" / k[len("packed/"):]).write_bytes(v)
+    bad = bytearray(g["packed/read_order.bin"]); bad[4:8] = (int.from_bytes(bad[4:8], "little") - 5).to_bytes(4, "little")
+    (tmp_path / "b" / "output" / "read_order.bin").write_bytes(bytes(bad))
+    with pytest.raises(harc_amd.HarcAmdError):
+        harc_amd.decoder(base2, 1, preserve_order=True)
