@@ -191,6 +191,7 @@ __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, cons
     const uint64_t key = skeys[st];
     // single-read bins (the common case) carry the read id in `start`: one dependent load less on every hit
     const uint32_t cnt = en - st;
+    if (cnt > SLOT_CNT_MASK) { atomicAdd(const_cast<uint32_t *>(nbins_p) + 1, 1u); return; }     // does not fit the count field: the build fails loudly
     const unsigned long long meta = cnt == 1 ? ((unsigned long long)sids[st] | ((unsigned long long)(1u | SLOT_EMB) << 32))
                                              : ((unsigned long long)st | ((unsigned long long)((cnt & SLOT_CNT_MASK) | ((bigthresh && cnt > bigthresh) ? SLOT_BIG : 0u)) << 32));
     uint64_t sl = bucketed ? (__umul64hi(mix64(key), cap >> 2) << 2) : __umul64hi(mix64(key), cap);   // bucketed: start at a 64-B bucket of 4 slots
@@ -889,7 +890,7 @@ int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n)
         if (const char *e = getenv("HARC_AMD_CAPMULT")) m = strtoull(e, nullptr, 10);
         d->cap = (((m < 2 ? 2 : m) * n + 4) + 3) & ~3ull;           // whole 64-B buckets of 4 slots
     }
-    RC_TRY(dalloc(c, &d->slots, d->cap)); RC_TRY(dalloc(c, &d->ids, n)); RC_TRY(dalloc(c, &d->d_nbins, 1));
+    RC_TRY(dalloc(c, &d->slots, d->cap)); RC_TRY(dalloc(c, &d->ids, n)); RC_TRY(dalloc(c, &d->d_nbins, 2));
     return HARC_AMD_OK;
 }
 int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, uint32_t n, unsigned kbits)
@@ -899,6 +900,7 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     uint64_t *k1 = nullptr; uint32_t *h0 = nullptr, *b0 = nullptr, *bs = nullptr;
     RC_TRY(dalloc(c, &k1, n)); RC_TRY(dalloc(c, &h0, n)); RC_TRY(dalloc(c, &b0, n)); RC_TRY(dalloc(c, &bs, n));
     const unsigned g = (n + 255) / 256;
+    HIP_TRY(hipMemsetAsync(d->d_nbins, 0, 8, c->stream));
     RC_TRY(prim_sort_pairs_u64_u32(c, keys, k1, ids, d->ids, n, kbits));        // stable: ids ascending inside a bin (reorder.cpp:372-384)
     hipLaunchKernelGGL(k_mark_heads, dim3(g), dim3(256), 0, c->stream, k1, n, h0);
     RC_TRY(prim_excl_scan_u32(c, h0, b0, n));
@@ -906,8 +908,11 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
     hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, d->ids, bs, d->d_nbins, n, d->slots, d->cap, d->bucketed ? 1 : 0, d->bigthresh);
     HIP_TRY(hipGetLastError());
+    uint32_t nb2[2] = { 0, 0 };
+    HIP_TRY(hipMemcpyAsync(nb2, d->d_nbins, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));                                    // temporaries are reused after this point
     harc_pool_release(c, mk);
+    if (nb2[1]) { harc_set_error("dictionary: %u bins hold more than %u reads with the same k-mer (count field of the slot)", nb2[1], SLOT_CNT_MASK); return HARC_AMD_EINVAL; }
     return HARC_AMD_OK;
 }
 void harc_dict_free(harc_amd_ctx *c, DictDev *d)
