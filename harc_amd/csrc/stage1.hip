@@ -463,11 +463,13 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                     // The table is bucketed (64 B = 4 slots).  QUAD (few chains, latency-bound): the whole bucket in one round trip; otherwise
                     // (many chains, 128 VGPRs) two slots at a time -- the second pair is the same 64-B sector.  A full bucket ends the
                     // search unless its overflow flag says that keys went on to the next one.
+                    // phase 1: every lane finishes its slot search (the dependent bucket fetches of all lanes overlap) ...
                     uint64_t sl = __umul64hi(mix64(key), cap >> 2) << 2;
+                    int state = 0, qhit = 0;                                  // 1 = the key is not in the table, 2 = key found
+                    uint32_t sst = 0, cw = 0;
                     for (;;) {
                         constexpr int NQ = QUAD ? 4 : 2;
-                        int state = 0, qhit = 0;                              // 1 = the key is not in the table, 2 = key found
-                        uint32_t sst = 0, cw = 0, w0 = 0;
+                        uint32_t w0 = 0;
 #pragma unroll
                         for (int hp = 0; hp < 4 / NQ; hp++) {
                             if (state == 0) {
@@ -486,6 +488,11 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                             }
                         }
                         if (state == 0 && !(w0 & SLOT_OVF)) state = 1;
+                        if (state) break;
+                        sl += 4; if (sl >= cap) sl = 0;
+                    }
+                    // ... phase 2: the lanes that found their key scan their bins together
+                    {
                         if (state == 2 && !(cw & SLOT_DEAD) && (cw & SLOT_CNT_MASK) > HARC_BIGBIN && !(cw & SLOT_EMB)) {
                             big = true; b_sst = sst; b_cnt = cw & (SLOT_CNT_MASK | SLOT_OVF); b_slot = sl + qhit;
                         } else
@@ -533,8 +540,6 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                             if (lead == cntb) atomicOr(cp, SLOT_DEAD); else if (!emb) atomicMin(cp, (cntb - lead) | (cw & SLOT_OVF));
                         }
                         }
-                        if (state) break;
-                        sl += 4; if (sl >= cap) sl = 0;
                     }
                 }
             }
