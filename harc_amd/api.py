@@ -69,6 +69,7 @@ def lib():
                                               C.c_char_p, C.c_char_p, C.c_uint32]
     l.harc_amd_pack_reads_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     l.harc_amd_bucket_reads_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    l.harc_amd_partition_reads_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     for f in ("harc_amd_reorder", "harc_amd_encode", "harc_amd_pack_order"):
         getattr(l, f).argtypes = [ctx]
     l.harc_amd_get_stream.argtypes = [ctx, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -193,6 +194,9 @@ class HarcAmd:
 
     def pack_reads_device(self, d_ascii, n, stride, d_out):
         _check(lib().harc_amd_pack_reads_device(self._ctx, C.c_void_p(d_ascii), n, stride, C.c_void_p(d_out)))
+
+    def partition_reads_device(self, d_packed, n, n_buckets, d_out, d_counts):
+        _check(lib().harc_amd_partition_reads_device(self._ctx, C.c_void_p(d_packed), n, n_buckets, C.c_void_p(d_out), C.c_void_p(d_counts)))
 
     def bucket_reads_device(self, d_packed, n, n_buckets, d_out):
         _check(lib().harc_amd_bucket_reads_device(self._ctx, C.c_void_p(d_packed), n, n_buckets, C.c_void_p(d_out)))

@@ -280,6 +280,12 @@ extern "C" int harc_amd_pack_reads_device(harc_amd_ctx *c, const char *d_ascii, 
     HIP_TRY(hipStreamSynchronize(c->stream));
     return HARC_AMD_OK;
 }
+extern "C" int harc_amd_partition_reads_device(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint64_t *d_out, uint64_t *d_counts)
+{
+    if (!c || nb == 0 || nb > 4096 || !d_counts || (n && (!d_packed || !d_out))) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    return s1_partition_reads(c, d_packed, n, nb, d_out, reinterpret_cast<unsigned long long *>(d_counts));
+}
 extern "C" int harc_amd_bucket_reads_device(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint32_t *d_out)
 {
     if (!c || nb == 0 || (n && (!d_packed || !d_out))) return HARC_AMD_EINVAL;

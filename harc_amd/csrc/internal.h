@@ -140,6 +140,7 @@ int s1_pack_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t str
 int s1_pack3_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride, uint64_t *d_out);              // 3-bit
 int s1_unpack_to_ascii(harc_amd_ctx *c, const uint64_t *d_reads, uint32_t n, char *d_out);                           // n x (L+1) text
 int s1_bucket_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint32_t *d_out);
+int s1_partition_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint64_t *d_out, unsigned long long *d_counts);
 int stage1_run(harc_amd_ctx *c);
 int stage1_make_oriented(harc_amd_ctx *c);      // d_oreads from d_reads/d_order/d_rc
 int s1_orient(harc_amd_ctx *c, const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, uint64_t *out);

@@ -151,6 +151,49 @@ int s1_bucket_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint3
     return HARC_AMD_OK;
 }
 
+// stable partition of the packed reads by bucket (the send buffer of the all-to-all): bucket -> one radix pass on (bucket, index)
+// -> gather; counts[b] = reads of bucket b
+__global__ void k_bucket_keys(const uint32_t *bucket, uint32_t n, uint64_t *keys, uint32_t *idx, unsigned long long *counts)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n;
+    const uint32_t b = in ? bucket[i] : 0xFFFFFFFFu;
+    if (in) { keys[i] = b; idx[i] = i; }
+    // one atomic per distinct bucket per wave
+    unsigned long long todo = __ballot(in);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lb = __shfl(b, leader, 64);
+        const unsigned long long same = __ballot(in && b == lb);
+        if ((threadIdx.x & 63) == leader) atomicAdd(&counts[lb], (unsigned long long)__popcll(same));
+        todo &= ~same;
+    }
+}
+__global__ void k_gather_reads(const uint64_t *reads, const uint32_t *idx, uint32_t n, int W, uint64_t *out)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n * W) return;
+    const uint32_t i = (uint32_t)(gid / W); const int w = (int)(gid % W);
+    out[gid] = reads[(size_t)idx[i] * W + w];
+}
+int s1_partition_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint64_t *d_out, unsigned long long *d_counts)
+{
+    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nb * 8, c->stream));
+    if (!n) return HARC_AMD_OK;
+    const harc_mark_t mk = harc_pool_mark(c);
+    uint32_t *b = nullptr, *i0 = nullptr, *i1 = nullptr; uint64_t *k0 = nullptr, *k1 = nullptr;
+    RC_TRY(dalloc(c, &b, n)); RC_TRY(dalloc(c, &i0, n)); RC_TRY(dalloc(c, &i1, n)); RC_TRY(dalloc(c, &k0, n)); RC_TRY(dalloc(c, &k1, n));
+    hipLaunchKernelGGL(k_bucket, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_packed, n, c->P.readlen, c->W, nb, b);
+    hipLaunchKernelGGL(k_bucket_keys, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)b, n, k0, i0, d_counts);
+    unsigned bits = 1; while ((1u << bits) < nb) bits++;
+    RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i0, i1, n, bits));                 // stable: original order inside a bucket
+    hipLaunchKernelGGL(k_gather_reads, dim3((unsigned)(((uint64_t)n * c->W + 255) / 256)), dim3(256), 0, c->stream, d_packed, (const uint32_t *)i1, n, c->W, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    harc_pool_release(c, mk);
+    return HARC_AMD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ index build
 // key_l(read) = bases [ds_l, de_l] of the read (reorder.cpp:295-299)
 template <int W> __global__ void k_keygen(const uint64_t *reads, uint32_t n, int off, int nbits, uint64_t *keys, uint32_t *ids)

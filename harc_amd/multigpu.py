@@ -41,13 +41,23 @@ class BucketSharder:
             self.ctx.bucket_reads_device(packed.data_ptr(), n, self.world, b.data_ptr())
         return b.long()
 
+    def partition(self, packed):
+        """-> (send [n, W] grouped by destination, original order inside a group; counts [world] int64)"""
+        if self.bucket_fn is None:                                    # HIP: k_bucket + one radix pass + gather (harc_amd_partition_reads_device)
+            n = packed.shape[0]
+            send = torch.empty_like(packed)
+            counts = torch.zeros((self.world,), dtype=torch.int64, device=self.device)
+            torch.cuda.current_stream().synchronize()                 # libharc_amd runs on its own stream: its inputs must be complete
+            self.ctx.partition_reads_device(packed.data_ptr(), n, self.world, send.data_ptr(), counts.data_ptr())
+            return send, counts
+        b = self.buckets(packed)                                      # CPU tests: the same in torch
+        order = torch.sort(b, stable=True).indices
+        return packed[order].contiguous(), torch.bincount(b, minlength=self.world).to(torch.int64)
+
     def exchange(self, packed):
         """one all-to-all(v): -> [m, W] int64, the reads of every rank whose bucket is this rank"""
         dist, world = self.dist, self.world
-        b = self.buckets(packed)
-        order = torch.sort(b, stable=True).indices
-        send = packed[order].contiguous()
-        counts = torch.bincount(b, minlength=world).to(torch.int64)
+        send, counts = self.partition(packed)
         recv_counts = torch.empty_like(counts)
         dist.all_to_all_single(recv_counts, counts)                 # 8 B per peer: how many reads each rank sends me
         sc, rc = counts.tolist(), recv_counts.tolist()

@@ -154,6 +154,9 @@ int harc_amd_pack_reads_device(harc_amd_ctx *ctx, const char *d_ascii, uint32_t 
 /* bucket[i] = hash(canonical minimizer, k=15, of the whole read i) % n_buckets: reads that overlap by >= ~half a read
    share a minimizer with high probability and land on the same GPU */
 int harc_amd_bucket_reads_device(harc_amd_ctx *ctx, const uint64_t *d_packed, uint32_t n_reads, uint32_t n_buckets, uint32_t *d_bucket_out);
+/* the send buffer of the all-to-all in one call: reads grouped by bucket (bucket 0 first, original order inside a bucket) and the
+   number of reads per bucket (n_buckets u64, device memory) */
+int harc_amd_partition_reads_device(harc_amd_ctx *ctx, const uint64_t *d_packed, uint32_t n_reads, uint32_t n_buckets, uint64_t *d_packed_out, uint64_t *d_counts_out);
 
 /* ---- compute (all on params.device, asynchronous internally, synchronised before return) */
 int harc_amd_reorder(harc_amd_ctx *ctx);      /* index build + chaining: reorder.cpp:277-703 */

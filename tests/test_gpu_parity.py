@@ -552,3 +552,27 @@ def test_preserve_order_decoder_needs_order_files(tmp_path):
     (tmp_path / "b" / "output" / "read_order.bin").write_bytes(bytes(bad))
     with pytest.raises(harc_amd.HarcAmdError):
         harc_amd.decoder(base2, 1, preserve_order=True)
+
+
+def test_partition_kernel_is_a_stable_sort_by_bucket():
+    """harc_amd_partition_reads_device == torch.sort(stable) of the k_bucket values + gather: what BucketSharder sends"""
+    import numpy as np
+    import torch
+    import harc_amd
+    from tests.bucket_ref import pack2, bucket_ref
+    reads = gen.reads_array(77, 50000, 100, 300000, err=0.002)
+    reads = reads[~(reads == ord("N")).any(1)]
+    pk = pack2(reads)
+    dev = torch.device("cuda", 0)
+    packed = torch.from_numpy(pk.view(np.int64)).to(dev)
+    h = harc_amd.HarcAmd(harc_amd.default_params(100))
+    for world in (1, 2, 5, 8):
+        send = torch.empty_like(packed)
+        counts = torch.zeros((world,), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        h.partition_reads_device(packed.data_ptr(), packed.shape[0], world, send.data_ptr(), counts.data_ptr())
+        b = bucket_ref(pk, 100, world)
+        order = np.argsort(b, kind="stable")
+        assert (send.cpu().numpy() == pk[order]).all()             # both int64 views of the packed words
+        assert (counts.cpu().numpy() == np.bincount(b, minlength=world)).all()
+    h.close()
