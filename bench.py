@@ -126,6 +126,11 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0)
     args = ap.parse_args()
 
+    # stdout carries the JSON line and nothing else: whatever C libraries print (RCCL's version banner, the library's counters) goes to
+    # stderr from here on
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -292,7 +297,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)                        # the ONE JSON line, last thing on stdout
+        real_stdout.write(json.dumps(out) + "\n")                 # the ONE JSON line: the only thing on stdout
+        real_stdout.flush()
 
 
 if __name__ == "__main__":
