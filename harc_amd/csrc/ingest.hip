@@ -125,7 +125,10 @@ extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uin
     const harc_mark_t mk = harc_pool_mark(c);
     const uint64_t *nls = nullptr; uint64_t total_lines = 0;
     RC_TRY(build_line_index(c, d_txt, nbytes, &nls, &total_lines));
-    const uint64_t nrec64 = total_lines / 4;                      // a trailing partial record is ignored, as by the getline loop
+    // a truncated last record still counts as a read when its sequence line is there: the getline loop handles line 2 before it meets
+    // the end of the file (preprocess.cpp:90-111); only `readnum` (case 3, :118) misses it
+    const uint64_t nfull = total_lines / 4;
+    const uint64_t nrec64 = nfull + ((total_lines % 4) >= 2 ? 1 : 0);
     if (nrec64 > 4294967290ull) { harc_set_error("Too many reads. HARC supports at most 4294967290 reads"); harc_pool_release(c, mk); return HARC_AMD_EINVAL; }   // preprocess.cpp:122-126
     const uint32_t nrec = (uint32_t)nrec64;
     uint32_t *isN = nullptr, *isC = nullptr, *rkN = nullptr, *rkC = nullptr; unsigned int *d_err = nullptr;
@@ -159,7 +162,7 @@ extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uin
     RC_TRY(harc_d2h(c, ob, orderN, (size_t)nN * 4));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->N = nC; c->NN = nN; c->C.n_clean = nC; c->C.n_N = nN;
-    if (n_records_out) *n_records_out = nrec;
+    if (n_records_out) *n_records_out = nfull;                    // what preprocess.cpp:134 prints: complete records
     harc_pool_release(c, mk);
     return HARC_AMD_OK;
 }
@@ -253,6 +256,9 @@ static int emit_quality_and_ids(harc_amd_ctx *c, const char *d_txt, uint64_t nby
     RC_TRY(build_line_index(c, d_txt, nbytes, &nls, &total_lines));
     const uint32_t nrec = (uint32_t)(total_lines / 4);
     const uint32_t nid = nrec + (total_lines % 4 ? 1u : 0u);       // the id line of a truncated last record is still written (case 0 of the getline loop)
+    if (!preserve_order && (total_lines % 4) >= 2) {               // that read has no quality line: reorder_quality.cpp would walk off its arrays
+        harc_set_error("-q without -p: the last FASTQ record is truncated (its read is kept, its quality line is missing)"); return HARC_AMD_EINVAL;
+    }
     if (preserve_order) {                                          // preprocess.cpp:64-69: both files in file order
         uint32_t *rec = nullptr; RC_TRY(dalloc(c, &rec, (size_t)nid + 1));
         hipLaunchKernelGGL(k_q_iota, G256((size_t)nid + 1), rec, nid + 1);
