@@ -612,3 +612,29 @@ def test_partition_kernel_is_a_stable_sort_by_bucket():
         assert (send.cpu().numpy() == pk[order]).all()             # both int64 views of the packed words
         assert (counts.cpu().numpy() == np.bincount(b, minlength=world)).all()
     h.close()
+
+
+_FUZZ_L = [20, 31, 32, 33, 47, 50, 51, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 191, 192, 193, 223, 224, 225, 254]
+
+
+@pytest.mark.parametrize("L", _FUZZ_L)
+def test_read_lengths_at_word_boundaries_match_oracle(L, oracle, tmp_path):
+    """every packed-word boundary of the 2-bit (W = ceil(2L/64)) and 3-bit (W3 = ceil(3L/64)) stores, with a schedule drawn from L:
+    all stage-I / stage-II files equal the oracle's, the decoder gives the input multiset back, and -p its order"""
+    import numpy as np
+    import harc_amd
+    rs = np.random.RandomState(L)
+    n = int(rs.randint(1500, 4000))
+    K, S, E = int(rs.choice([1, 2, 7, 33, 200])), int(rs.choice([1, 3, 16, 64])), int(rs.choice([1, 2, 5, 8]))
+    txt = gen.reads_text(1000 + L, n, L, int(n * L / rs.choice([4, 15, 40])), err=float(rs.choice([0.0, 0.005, 0.02])))
+    (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, L, K, E, tmp_path / "o", S)
+    base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna", "read_order_N.bin"]})
+    harc_amd.reorder(base, L, num_chains=K, num_steps=S)
+    assert_same(ol.read_dir(base), s1, ol.STAGE1_FILES, f"L={L} K={K} S={S}: stage I vs oracle")
+    harc_amd.encoder(base, L, num_thr=E)
+    assert_same(ol.read_dir(base), s2, ol.stage2_files(E), f"L={L} K={K} E={E}: stage II vs oracle")
+    if len(ol.read_dir(base)["read_order.bin"]):
+        harc_amd.pack_order(base, L)
+        harc_amd.decoder(base, E, preserve_order=True)
+        assert ol.read_dir(base)["output.dna"] == txt
