@@ -14,7 +14,9 @@
 #define HARC_MAXW 8      // ceil(2*255/64) words of a 2-bit read
 #define HARC_MAXW3 12    // ceil(3*255/64) words of a 3-bit read
 #define HARC_MAXK (1u << 20)
+#ifndef HARC_NSUGG
 #define HARC_NSUGG 4      // look-ahead seeds handed to a chain at every reseed (oracle: NSUGG)
+#endif
 
 void harc_set_error(const char *fmt, ...);
 
