@@ -195,7 +195,9 @@ int harc_amd_preprocess_files(const char *fastq, const char *basedir, int32_t re
    num_thr_e shards under <basedir>/output and writes output/output.dna, byte-identical to the reference decoder */
 int harc_amd_decoder_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e);
 /* == `unpack_order.out` + `decoder_preserve.out` + `merge_N.out` (harc:183-185, -p): needs read_order.bin(+.tail) as written by
-   pack_order, read_order_N_pe.bin and read_order_N.bin; writes output/output.dna = the reads in their original FASTQ order */
+   pack_order, read_order_N_pe.bin and read_order_N.bin; writes output/output.dna = the reads in their original FASTQ order.
+   Everything is held in HBM at once (about 3 x (readlen+1) bytes per read, ~900 M reads of 100 bp on one MI355X; the reference bins
+   through host memory instead, decoder_preserve.cpp:249-253); larger archives fail with HARC_AMD_ENOMEM */
 int harc_amd_decoder_preserve_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e);
 
 #ifdef __cplusplus
