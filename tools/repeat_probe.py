@@ -16,6 +16,7 @@ st = torch.randint(0, G - L, (n,), generator=g, device=dev)
 reads = genome[st[:, None] + torch.arange(L, device=dev)[None, :]].contiguous()
 p = harc_amd.default_params(L, num_thr=8)
 h = harc_amd.HarcAmd(p)
+torch.cuda.synchronize()          # the library works on its own stream: inputs must be complete
 h.set_reads_ascii_device(reads.data_ptr(), n, L)
 sig_in = h.reads_signature_device(reads.data_ptr(), n, L)
 for it in range(2):
