@@ -22,5 +22,5 @@ sig_in = h.reads_signature_device(reads.data_ptr(), n, L)
 for it in range(2):
     t0 = time.time(); h.reorder(); t1 = time.time(); h.encode(); t2 = time.time()
     c = h.counters()
-    print(f"copies={ncopy} iter {it}: reorder {t1-t0:.3f}s encode {t2-t1:.3f}s -> {n/(t2-t0)/1e6:.2f} Mreads/s rounds={c.rounds} cands={c.candidates} probes={c.probes} unmatched={c.unmatched} bigbins2={c.bins_over_maxsearch}", flush=True)
+    print(f"copies={ncopy} iter {it}: reorder {t1-t0:.3f}s encode {t2-t1:.3f}s -> {n/(t2-t0)/1e6:.2f} Mreads/s rounds={c.rounds} cands={c.candidates} probes={c.probes} unmatched={c.unmatched} conflicts={c.conflicts} chain_ms={c.chain_ms:.0f} bigbins2={c.bins_over_maxsearch}", flush=True)
 print("roundtrip", h.decode_signature() == sig_in)
