@@ -879,6 +879,49 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
     if (t == 0) *s.cursor = cursor < -1 ? -1 : cursor;
 }
 
+// ------------------------------------------------------------------------------------------------ big bins stay short
+// The reference deletes a read from its bins when it is claimed (reorder.cpp:396-432); here the claim bitmap is the truth and a bin
+// only shrinks from the top (hints).  In repeats and low-complexity sequence a bin holds thousands of reads and every scan would wade
+// through the claimed ones again: between super-rounds one wave per large bin packs the unclaimed ids to the front of the bin (order
+// kept) and lowers the count.  What a scan sees -- the unclaimed reads of the bin, highest id first -- does not change.
+#define HARC_LARGEBIN 128u
+__global__ void k_list_large(const HashSlot *slots, uint64_t cap, uint32_t dict, unsigned long long *list, unsigned int *nlist, uint32_t maxlist)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const uint32_t cw = slots[i].count;
+    if (!cw || (cw & SLOT_EMB) || (cw & SLOT_CNT_MASK) <= HARC_LARGEBIN) return;
+    const unsigned int at = atomicAdd(nlist, 1u);
+    if (at < maxlist) list[at] = (i << 1) | dict;
+}
+__global__ __launch_bounds__(64) void k_compact_bins(S1Args s, const unsigned long long *list, uint32_t nlist)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nlist) return;
+    const int lane = threadIdx.x;
+    const unsigned long long e = list[b];
+    const int l = (int)(e & 1); const uint64_t si = e >> 1;
+    HashSlot *slot = &s.slots[l][si];
+    const uint32_t cw = slot->count;
+    if (cw & SLOT_DEAD) return;
+    const uint32_t cnt = cw & SLOT_CNT_MASK, st = slot->start;
+    if (cnt <= 64) return;                                        // one cooperative batch anyway
+    uint32_t *ids = const_cast<uint32_t *>(s.ids[l]) + st;
+    uint32_t out = 0;
+    for (uint32_t pos = 0; pos < cnt; pos += 64) {
+        const bool valid = pos + lane < cnt;
+        uint32_t rid = 0; bool un = false;
+        if (valid) { rid = ids[pos + lane]; un = !((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL); }
+        const unsigned long long um = __ballot(un);
+        if (un) ids[out + (uint32_t)__popcll(um & ((1ULL << lane) - 1ULL))] = rid;     // out <= pos: never ahead of the reads of this pass
+        out += (uint32_t)__popcll(um);
+    }
+    if (lane == 0 && out < cnt) {
+        if (out == 0) atomicOr(&slot->count, SLOT_DEAD);
+        else slot->count = out | (cw & ~SLOT_CNT_MASK);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ finalisation
 __global__ void k_chain_counts(const ChainHdr *hdr, const uint4 *cstat, const uint2 *cst2, uint32_t K, uint32_t *nmain, uint32_t *nsing, unsigned long long *stats)
 {
@@ -1029,6 +1072,18 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         }
         harc_pool_release(c, mk);
     }
+    // bins large enough to be worth compacting between super-rounds (none on ordinary data)
+    unsigned long long *d_large = nullptr; unsigned int *d_nlarge = nullptr; uint32_t nlarge = 0;
+    const uint32_t maxlarge = 2 * (N / HARC_LARGEBIN) + 16;
+    if (N) {
+        RC_TRY(dalloc(c, &d_large, maxlarge)); RC_TRY(dalloc(c, &d_nlarge, 4));
+        HIP_TRY(hipMemsetAsync(d_nlarge, 0, 16, c->stream));
+        for (int l = 0; l < 2; l++)
+            hipLaunchKernelGGL(k_list_large, dim3((unsigned)((dict[l].cap + 255) / 256)), dim3(256), 0, c->stream, (const HashSlot *)dict[l].slots, dict[l].cap, (uint32_t)l, d_large, d_nlarge, maxlarge);
+        HIP_TRY(hipMemcpyAsync(&nlarge, d_nlarge, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (nlarge > maxlarge) nlarge = maxlarge;
+    }
     HIP_TRY(hipEventRecord(e1, c->stream));
 
     // ---- chain state
@@ -1093,6 +1148,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve<32>), dim3((K + 7) / 8), dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((k_resolve<64>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
             hipLaunchKernelGGL(k_reseed, dim3(1), dim3(1024), 0, c->stream, a);
+            if (nlarge) hipLaunchKernelGGL(k_compact_bins, dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge);
             launches++;
         }
         rounds += batch;
