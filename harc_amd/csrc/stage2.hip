@@ -363,47 +363,47 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args
 
 // Bins larger than maxsearch, exact: the reference scans, at every probe, the maxsearch highest ids of the bin that are STILL
 // unclaimed at that moment (encoder.cpp:293 after the removals of :321-336).  The probes that hit such a bin were recorded by
-// k_realign_propose; here ONE wave replays them in tuple order (= the order of the sequential reference), 64 candidates per
+// k_realign_propose; here ONE workgroup replays them in tuple order (= the order of the sequential reference), 1024 candidates per
 // round trip, against best[] = "claimed at tuple" (a read is unclaimed at tuple t iff best[rid] > t).
-__global__ __launch_bounds__(64) void k_realign_big(S2Args s, const unsigned long long *etuple, const uint32_t *eidx, uint32_t nev)
+__global__ __launch_bounds__(1024) void k_realign_big(S2Args s, const unsigned long long *etuple, const uint32_t *eidx, uint32_t nev)
 {
     __shared__ unsigned long long swin[2][HARC_MAXW3];
-    const int lane = threadIdx.x;
+    __shared__ uint32_t sm[20];
+    const int t = threadIdx.x;
     const int L = s.L, W3 = s.W3;
     for (uint32_t e = 0; e < nev; e++) {
         const unsigned long long tp = etuple[e];
         const uint4 ev = s.events[eidx[e]];
         const uint64_t x = tp >> 2; const int dir = (int)((tp >> 1) & 1), l = (int)(tp & 1);
         const uint32_t st = ev.z, cnt = ev.w;
-        // 3-bit window words (forward or reverse complement), lanes 0..W3-1 build one word each
-        if (lane < W3) {
+        // 3-bit window words (forward or reverse complement), threads 0..W3-1 build one word each
+        if (t < W3) {
             const uint8_t *win = s.cons + x;
             unsigned long long v = 0;
-            const int b0 = (64 * lane) / 3, b1 = (64 * lane + 63) / 3;
+            const int b0 = (64 * t) / 3, b1 = (64 * t + 63) / 3;
             for (int b = b0; b <= b1 && b < L; b++) {
                 const int idx = dir ? 3 - (int)(win[L - 1 - b] & 3) : (int)(win[b] & 3);
                 const unsigned long long c3 = (unsigned long long)idx_to_c3(idx);
-                const int sh = 3 * b - 64 * lane;
+                const int sh = 3 * b - 64 * t;
                 v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
             }
-            swin[e & 1][lane] = v;
+            swin[e & 1][t] = v;
         }
         __syncthreads();
-        int seen = 0; uint32_t pos = cnt;
-        while (pos > 0 && seen < s.maxsearch) {
-            const bool valid = (uint32_t)lane < pos;
+        uint32_t seen = 0, pos = cnt;                             // block-uniform
+        while (pos > 0 && seen < (uint32_t)s.maxsearch) {         // 1024 candidates per round trip, highest id first
+            const bool valid = (uint32_t)t < pos;
             uint32_t rid = 0; bool un = false;
-            if (valid) { rid = s.ids[l][st + pos - 1 - lane]; un = __hip_atomic_load(&s.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tp; }
-            const unsigned long long um = __ballot(un);
-            const int rank = __popcll(um & ((1ULL << lane) - 1ULL));
-            if (un && seen + rank < s.maxsearch) {
+            if (valid) { rid = s.ids[l][st + pos - 1 - t]; un = __hip_atomic_load(&s.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tp; }
+            uint32_t total; const uint32_t rank = block_excl_scan_u32<1024>(un ? 1u : 0u, sm, &total);
+            if (un && seen + rank < (uint32_t)s.maxsearch) {
                 const uint64_t *r = s.cand3 + (size_t)rid * W3;
                 int hd = 0;
                 for (int w = 0; w < W3; w++) { hd += __popcll(swin[e & 1][w] ^ r[w]); if (hd > s.thresh_s) break; }
                 if (hd <= s.thresh_s) __hip_atomic_store(&s.best[rid], tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every passing candidate of the window is taken (encoder.cpp:296-317)
             }
-            seen += __popcll(um);
-            pos -= pos > 64 ? 64 : pos;
+            seen += total;
+            pos -= pos > 1024 ? 1024 : pos;
         }
         __threadfence_block();
         __syncthreads();
@@ -755,7 +755,7 @@ int stage2_run(harc_amd_ctx *c)
                 RC_TRY(dalloc(c, &tk0, nev)); RC_TRY(dalloc(c, &tk1, nev)); RC_TRY(dalloc(c, &ti0, nev)); RC_TRY(dalloc(c, &ti1, nev));
                 hipLaunchKernelGGL(k_event_keys, G256(nev), a.events, nev, tk0, ti0);
                 RC_TRY(prim_sort_pairs_u64_u32(c, (const uint64_t *)tk0, (uint64_t *)tk1, ti0, ti1, nev, 64));
-                hipLaunchKernelGGL(k_realign_big, dim3(1), dim3(64), 0, c->stream, a, (const unsigned long long *)tk1, (const uint32_t *)ti1, nev);
+                hipLaunchKernelGGL(k_realign_big, dim3(1), dim3(1024), 0, c->stream, a, (const unsigned long long *)tk1, (const uint32_t *)ti1, nev);
             }
         }
     }
