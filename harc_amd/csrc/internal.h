@@ -77,6 +77,7 @@ struct DictDev {
     uint32_t *d_nbins = nullptr;
     uint32_t nbins = 0;
     bool bucketed = false;     // probing goes bucket by bucket (64 B = 4 slots); a full bucket without SLOT_OVF ends an unsuccessful search
+    unsigned long long *large_list = nullptr; unsigned int *large_n = nullptr; uint32_t large_max = 0, large_tag = 0;   // stage I: bins worth compacting, listed at insert time
     uint32_t bigthresh = 0;    // > 0: bins with more entries get SLOT_BIG     // probing starts at a 64-B bucket of 4 slots (fetched whole by a latency-bound k_steps) instead of at the hashed slot
 };
 

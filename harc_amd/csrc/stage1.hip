@@ -222,9 +222,11 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
     if (head[i]) binstart[binidx[i]] = i;
     if (i == n - 1) *nbins = binidx[i] + head[i];
 }
+#define HARC_LARGEBIN 128u   // stage-I bins with more reads than this are compacted between super-rounds (k_compact_bins)
 // one thread per bin: claim an empty slot by CAS on the (start,count) word; keys are unique so no key compare is needed
 __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, const uint32_t *nbins_p, uint32_t n,
-                               HashSlot *slots, uint64_t cap, int bucketed, uint32_t bigthresh)
+                               HashSlot *slots, uint64_t cap, int bucketed, uint32_t bigthresh,
+                               unsigned long long *large_list, unsigned int *large_n, uint32_t large_max, uint32_t large_tag)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nbins = *nbins_p;
@@ -240,7 +242,14 @@ __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, cons
     uint64_t sl = bucketed ? (__umul64hi(mix64(key), cap >> 2) << 2) : __umul64hi(mix64(key), cap);   // bucketed: start at a 64-B bucket of 4 slots
     for (;;) {
         unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
-        if (atomicCAS(mp, 0ULL, meta) == 0ULL) { slots[sl].key = key; return; }
+        if (atomicCAS(mp, 0ULL, meta) == 0ULL) {
+            slots[sl].key = key;
+            if (large_list && cnt > HARC_LARGEBIN) {              // remembered for k_compact_bins: (slot index, dictionary)
+                const unsigned int at = atomicAdd(large_n, 1u);
+                if (at < large_max) large_list[at] = ((unsigned long long)sl << 1) | large_tag;
+            }
+            return;
+        }
         // leaving a bucket whose four slots are all taken: flag it, so that a search that finds a full bucket WITHOUT the flag can stop
         if (bucketed && (sl & 3) == 3) atomicOr(&slots[sl - 3].count, SLOT_OVF);
         if (++sl == cap) sl = 0;
@@ -884,16 +893,6 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
 // only shrinks from the top (hints).  In repeats and low-complexity sequence a bin holds thousands of reads and every scan would wade
 // through the claimed ones again: between super-rounds one wave per large bin packs the unclaimed ids to the front of the bin (order
 // kept) and lowers the count.  What a scan sees -- the unclaimed reads of the bin, highest id first -- does not change.
-#define HARC_LARGEBIN 128u
-__global__ void k_list_large(const HashSlot *slots, uint64_t cap, uint32_t dict, unsigned long long *list, unsigned int *nlist, uint32_t maxlist)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cap) return;
-    const uint32_t cw = slots[i].count;
-    if (!cw || (cw & SLOT_EMB) || (cw & SLOT_CNT_MASK) <= HARC_LARGEBIN) return;
-    const unsigned int at = atomicAdd(nlist, 1u);
-    if (at < maxlist) list[at] = (i << 1) | dict;
-}
 __global__ __launch_bounds__(64) void k_compact_bins(S1Args s, const unsigned long long *list, uint32_t nlist)
 {
     const uint32_t b = blockIdx.x;
@@ -997,7 +996,8 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     RC_TRY(prim_excl_scan_u32(c, h0, b0, n));
     hipLaunchKernelGGL(k_bin_starts, dim3(g), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins);
     HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
-    hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, d->ids, bs, d->d_nbins, n, d->slots, d->cap, d->bucketed ? 1 : 0, d->bigthresh);
+    hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, d->ids, bs, d->d_nbins, n, d->slots, d->cap, d->bucketed ? 1 : 0, d->bigthresh,
+                       d->large_list, d->large_n, d->large_max, d->large_tag);
     HIP_TRY(hipGetLastError());
     uint32_t nb2[2] = { 0, 0 };
     HIP_TRY(hipMemcpyAsync(nb2, d->d_nbins, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1059,9 +1059,14 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const harc_mark_t mark_results = harc_pool_mark(c);
     // ---- dictionaries (constructdictionary, reorder.cpp:277-394)
     DictDev dict[2];
+    unsigned long long *d_large = nullptr; unsigned int *d_nlarge = nullptr;
+    const uint32_t maxlarge = 2 * (N / HARC_LARGEBIN) + 16;
     if (N) {
         RC_TRY(harc_dict_alloc(c, &dict[0], N)); RC_TRY(harc_dict_alloc(c, &dict[1], N));
         dict[0].bucketed = dict[1].bucketed = true;
+        RC_TRY(dalloc(c, &d_large, maxlarge)); RC_TRY(dalloc(c, &d_nlarge, 4));
+        HIP_TRY(hipMemsetAsync(d_nlarge, 0, 16, c->stream));
+        for (int l = 0; l < 2; l++) { dict[l].large_list = d_large; dict[l].large_n = d_nlarge; dict[l].large_max = maxlarge; dict[l].large_tag = (uint32_t)l; }
         const harc_mark_t mk = harc_pool_mark(c);
         uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
         RC_TRY(dalloc(c, &k0, N)); RC_TRY(dalloc(c, &i0, N));
@@ -1072,14 +1077,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         }
         harc_pool_release(c, mk);
     }
-    // bins large enough to be worth compacting between super-rounds (none on ordinary data)
-    unsigned long long *d_large = nullptr; unsigned int *d_nlarge = nullptr; uint32_t nlarge = 0;
-    const uint32_t maxlarge = 2 * (N / HARC_LARGEBIN) + 16;
+    // bins large enough to be worth compacting between super-rounds were listed by k_table_insert (none on ordinary data)
+    uint32_t nlarge = 0;
     if (N) {
-        RC_TRY(dalloc(c, &d_large, maxlarge)); RC_TRY(dalloc(c, &d_nlarge, 4));
-        HIP_TRY(hipMemsetAsync(d_nlarge, 0, 16, c->stream));
-        for (int l = 0; l < 2; l++)
-            hipLaunchKernelGGL(k_list_large, dim3((unsigned)((dict[l].cap + 255) / 256)), dim3(256), 0, c->stream, (const HashSlot *)dict[l].slots, dict[l].cap, (uint32_t)l, d_large, d_nlarge, maxlarge);
         HIP_TRY(hipMemcpyAsync(&nlarge, d_nlarge, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (nlarge > maxlarge) nlarge = maxlarge;
