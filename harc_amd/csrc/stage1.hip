@@ -811,7 +811,8 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
 
 // (C) one workgroup: new seeds, in chain order, from the single descending cursor over unclaimed reads (reorder.cpp:650-688);
 // when the cursor runs out the remaining chains finish.  Every reseeded chain also gets HARC_NSUGG look-ahead seeds: the next
-// unclaimed ids below the cursor (not claimed, the cursor does not move), which k_steps uses when the chain is stuck again.
+// unclaimed ids below the cursor (not claimed; the cursor moves below them, so they are this chain's until it takes them or finds
+// them taken by a walk), which k_steps uses when the chain is stuck again.
 // The kernel only ranks the chains and finds the ids; every chain applies its own seed at the top of the next k_steps.
 __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
 {
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
         else { assigned += total; cursor = (cwd - 1023) * 64 - 1; }
         __syncthreads();
     }
-    // look-ahead: the next assigned * HARC_NSUGG unclaimed ids below the cursor, nothing claimed, cursor untouched
+    // look-ahead: the next assigned * HARC_NSUGG unclaimed ids below the cursor; nothing is claimed, the cursor moves below them
     const uint32_t want = assigned * (uint32_t)s.nsugg_per_seed;
     uint32_t got = 0;
     long long look = cursor;
@@ -872,17 +873,20 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
             if (wi == cwd) { const int top = (int)(look & 63); if (top < 63) bits &= (2ULL << top) - 1ULL; }
         }
         uint32_t total; const uint32_t off = block_excl_scan_u32<1024>((uint32_t)__popcll(bits), sm, &total);
+        got = total >= want ? want : total;
         uint32_t k = 0;
         while (bits && off + k < want) {
             const int b = 63 - __clzll((long long)bits);
             bits &= ~(1ULL << b);
-            s.seedbuf[R + off + k] = (uint32_t)(wi * 64 + b);
-            k++;
+            const uint32_t id = (uint32_t)(wi * 64 + b);
+            s.seedbuf[R + off + k] = id;
+            if (off + k == got - 1) scursor = (long long)id - 1;     // the cursor goes below the last look-ahead seed handed out:
+            k++;                                                    // those reads belong to their chains now, later reseeds do not hand them out again
         }
-        got = total >= want ? want : total;
     }
     __threadfence();
     __syncthreads();
+    if (got) cursor = scursor;
     // the chains take their seeds themselves at the top of the next k_steps (rank -> seedbuf)
     if (t == 0) { s.rmeta[0] = R; s.rmeta[1] = assigned; s.rmeta[2] = got; }
     if (t == 0) *s.cursor = cursor < -1 ? -1 : cursor;

@@ -391,9 +391,10 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
             x->need_reseed = 2;                                   /* got a seed: entitled to look-ahead seeds below */
         }
         /* look-ahead: the next NSUGG unclaimed ids below the cursor for the first reseeded chain, the NSUGG after those for the
-           second, ...; nothing is claimed and the cursor does not move (an unused look-ahead read is found again later) */
+           second, ...; nothing is claimed, and the cursor moves below the last one handed out: a look-ahead read stays with its
+           chain until the chain takes it or finds it claimed by a walk (later reseeds do not hand it out again) */
         {
-            int64_t look = remainingpos;
+            int64_t look = remainingpos, last_taken = -1;
             /* the look-ahead only inspects one bitmap chunk of the GPU's k_reseed: the 1024 64-bit words ending at the cursor's word */
             int64_t lim = remainingpos >= 0 ? ((remainingpos >> 6) - 1023) * 64 : 0;
             if (lim < 0) lim = 0;
@@ -401,8 +402,9 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
                 chain_t *x = &ch[c];
                 if (!x->active || x->need_reseed != 2) continue;
                 x->need_reseed = 0;
-                while (x->nsugg < NSUGG && look >= lim) { if (!claimed[look]) x->sugg[x->nsugg++] = (uint32_t)look; look--; }
+                while (x->nsugg < NSUGG && look >= lim) { if (!claimed[look]) { x->sugg[x->nsugg++] = (uint32_t)look; last_taken = look; } look--; }
             }
+            if (last_taken >= 0) remainingpos = last_taken - 1;
         }
     }
     /* concatenate per-chain streams in chain order (reorder.cpp:778-821) */
