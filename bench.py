@@ -27,6 +27,7 @@ import torch  # noqa: E402  (device memory, streams and torch.distributed only)
 WORKLOADS = {
     # name: (reads per GPU, read length, genome bp per GPU, error rate, description == BASELINE.json config)
     "c2": (3_300_000, 100, 6_300_000, 0.005, "configs[1] stand-in: 3.3M x 100bp, 6.3 Mbp i.i.d. genome (~52x), 0.5% substitutions (1/4 N), odd reads RC"),
+    "c2r": (3_300_000, 100, 6_300_000, 0.005, "c2 with a repeat-spiked genome: 2000 copies of one 300-bp element and 200 poly-A runs of 150 bp (hot dictionary bins)"),
     "c3": (350_000_000, 100, 3_100_000_000, 0.0, "configs[2] stand-in: 350M x 100bp error-free, 3.1 Gbp i.i.d. genome (11.3x), odd reads RC"),
     "c3s": (50_000_000, 100, 443_000_000, 0.0, "configs[2] at 1/7 scale: 50M x 100bp error-free, 443 Mbp i.i.d. genome (11.3x)"),
     "c1": (1_000_000, 100, 35_000_000, 0.0, "configs[0] stand-in: 1M x 100bp error-free, 35 Mbp i.i.d. genome (2.9x)"),
@@ -38,7 +39,7 @@ WORKLOADS = {
 }
 
 
-def synth_chunks(n, L, G, err, seed, dev):
+def synth_chunks(n, L, G, err, seed, dev, spike=None):
     """yields [m, L] uint8 ASCII reads, 4 M at a time: uniform starts on an i.i.d. genome, substitutions (a quarter become N, as
     gen_fastq_noRC.cpp:67-71), odd reads reverse-complemented (gen_fastq.cpp:105-113)."""
     g = torch.Generator(device=dev)
@@ -51,6 +52,13 @@ def synth_chunks(n, L, G, err, seed, dev):
     for s in range(0, G, 1 << 28):
         m = min(1 << 28, G - s)
         genome[s:s + m] = lut[torch.randint(0, 4, (m,), generator=g, device=dev)]
+    if spike:                                                    # (copies of one 300-bp element, poly-A runs of 150 bp): hot dictionary bins
+        ncopy, npolya = spike
+        rep = lut[torch.randint(0, 4, (300,), generator=g, device=dev)]
+        for p in torch.randint(0, G - 400, (ncopy,), generator=g, device=dev).tolist():
+            genome[p:p + 300] = rep
+        for p in torch.randint(0, G - 400, (npolya,), generator=g, device=dev).tolist():
+            genome[p:p + 150] = ord("A")
     g.manual_seed(seed)                                          # the reads differ per rank
     ar = torch.arange(L, device=dev)
     CH = 4_000_000
@@ -71,8 +79,11 @@ def synth_chunks(n, L, G, err, seed, dev):
     del genome
 
 
-def synth_reads(n, L, G, err, seed, dev):
-    return torch.cat(list(synth_chunks(n, L, G, err, seed, dev)))
+def synth_reads(n, L, G, err, seed, dev, spike=None):
+    return torch.cat(list(synth_chunks(n, L, G, err, seed, dev, spike)))
+
+
+SPIKES = {"c2r": (2000, 200)}                                   # workload -> (copies of a 300-bp repeat, poly-A runs) put into the genome
 
 
 def cpu_baseline(n_sample, L, G_sample, err, seed, dev):
@@ -167,7 +178,7 @@ def main():
     def acc(sig, t):
         c3 = h.reads_signature_device(t.data_ptr(), t.shape[0], L)
         sig[0] += c3[0]; sig[1] = (sig[1] + c3[1]) % (1 << 64); sig[2] ^= c3[2]
-    for r in synth_chunks(n, L, G * world, err, 1000 + rank, dev):
+    for r in synth_chunks(n, L, G * world, err, 1000 + rank, dev, SPIKES.get(args.workload)):
         hasN = (r == ord("N")).any(1)
         cl = r[~hasN].contiguous()
         wn = r[hasN].contiguous()
