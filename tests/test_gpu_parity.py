@@ -638,3 +638,20 @@ def test_read_lengths_at_word_boundaries_match_oracle(L, oracle, tmp_path):
         harc_amd.pack_order(base, L)
         harc_amd.decoder(base, E, preserve_order=True)
         assert ol.read_dir(base)["output.dna"] == txt
+
+
+def test_reads_per_chain_is_the_auto_chain_count(tmp_path):
+    """harc_amd_params.reads_per_chain only chooses K in auto mode: same bytes as the explicit num_chains = N / reads_per_chain"""
+    import harc_amd
+    txt = gen.reads_text(91, 40000, 100, 250000, err=0.0)
+    n = len(txt.split())
+    outs = []
+    for kw in (dict(num_chains=0, reads_per_chain=512), dict(num_chains=n // 512), dict(num_chains=0), dict(num_chains=n // 2048)):
+        h = harc_amd.HarcAmd(harc_amd.default_params(100, num_thr=2, **kw))
+        h.set_reads_ascii(txt, n, 101)
+        h.set_nreads_ascii(b"", 0, 101)
+        h.reorder(); h.encode()
+        outs.append((h.counters().chains, h.stream("S1_ORDER"), h.stream("S2_SEQ", 0), h.stream("S2_NOISE", 1)))
+        h.close()
+    assert outs[0] == outs[1] and outs[0][0] == n // 512
+    assert outs[2] == outs[3] and outs[2][0] == n // 2048
