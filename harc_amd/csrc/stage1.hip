@@ -386,7 +386,9 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
 //      slot -> bin scan from the highest unclaimed id (<= maxsearch of them) -> XOR+popcount Hamming on the packed words;
 //      the lowest lane with a hit is the step's read;
 //  (3) lane 0 records the step and bids for the read with atomicMin(step<<20 | chain); the counts are updated in registers.
+#ifndef HARC_BIGBIN
 #define HARC_BIGBIN 4u      // bins with more reads than this are scanned by the whole wave
+#endif
 #ifndef HARC_STEPS_WAVES
 #define HARC_STEPS_WAVES 4       // many chains: 4 waves / SIMD (128 VGPRs, a few spills)
 #endif

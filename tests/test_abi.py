@@ -70,3 +70,18 @@ def test_preprocess_rejects_variable_length(tmp_path):
     base = ol.stage_dir(tmp_path, {})
     with pytest.raises(harc_amd.HarcAmdError):
         harc_amd.preprocess(str(fq), base, 4)          # preprocess.cpp:92-97
+
+
+def test_harc_driver_usage_without_gpu(tmp_path):
+    """the bash driver's argument handling mirrors the reference's (harc:208-230): -h prints the usage, no mode is an error,
+    a read longer than 255 is refused before anything touches the GPU (harc:46-49)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "harc"), "-h"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and "Compression" in r.stdout and "-p Preserve order of reads" in r.stdout
+    r = subprocess.run([os.path.join(root, "harc"), "-t", "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 or "required" in r.stdout
+    fq = tmp_path / "long.fastq"
+    fq.write_bytes(b"@a\n" + b"A" * 300 + b"\n+\n" + b"H" * 300 + b"\n")
+    r = subprocess.run([os.path.join(root, "harc"), "-c", str(fq)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 1 and "Maximum read length exceeded" in r.stdout
