@@ -85,6 +85,14 @@ def lib():
     l.harc_amd_decode_signature.argtypes = [ctx, C.POINTER(C.c_uint64)]
     l.harc_amd_input_signature.argtypes = [ctx, C.POINTER(C.c_uint64)]
     l.harc_amd_reads_signature_device.argtypes = [ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    l.harc_amd_comm_get_id.argtypes = [C.c_char_p, C.c_size_t]
+    l.harc_amd_comm_init.argtypes = [ctx, C.c_char_p, C.c_size_t, C.c_int32, C.c_int32]
+    l.harc_amd_comm_init_mailbox.argtypes = [ctx, C.c_char_p, C.c_int32, C.c_int32]
+    l.harc_amd_comm_barrier.argtypes = [ctx]
+    l.harc_amd_comm_destroy.argtypes = [ctx]
+    l.harc_amd_shard_exchange.argtypes = [ctx, C.POINTER(C.c_uint64)]
+    l.harc_amd_compress_fastq_shard_files.argtypes = [PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
+    l.harc_amd_merge_shard_files.argtypes = [C.c_char_p, C.c_int32]
     _lib = l
     return l
 
@@ -131,6 +139,30 @@ def compress_fastq(fastq, basedir, readlen, num_thr=1, num_chains=1, preserve_or
     (preprocess.cpp:61-118, reorder_quality.cpp)"""
     p = default_params(readlen, num_thr=num_thr, num_chains=num_chains, **kw)
     _check(lib().harc_amd_compress_fastq_files_ex(C.byref(p), os.fsencode(fastq), os.fsencode(basedir), int(preserve_order), int(preserve_quality)))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_get_id():
+    """rank 0 of a multi-GPU run: the bytes every rank hands to HarcAmd.comm_init (== ncclGetUniqueId)"""
+    b = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().harc_amd_comm_get_id(b, COMM_ID_BYTES))
+    return b.raw
+
+
+def compress_fastq_shard(fastq, basedir, readlen, world, rank, comm_spec, num_thr=1, num_chains=0, preserve_order=False,
+                         preserve_quality=False, **kw):
+    """one rank of `./harc -c -g <world>`: slice of the FASTQ -> exchange -> this GPU's shard files"""
+    kw.setdefault("reads_per_chain", 1024)
+    p = default_params(readlen, num_thr=num_thr, num_chains=num_chains, **kw)
+    _check(lib().harc_amd_compress_fastq_shard_files(C.byref(p), os.fsencode(fastq), os.fsencode(basedir), int(preserve_order),
+                                                     int(preserve_quality), world, rank, os.fsencode(comm_spec)))
+
+
+def merge_shards(basedir, world):
+    """after every rank has finished: the whole-job files of the archive (host code)"""
+    _check(lib().harc_amd_merge_shard_files(os.fsencode(basedir), world))
 
 
 def decoder(basedir, num_thr_e, device=0, preserve_order=False):
@@ -200,6 +232,25 @@ class HarcAmd:
 
     def bucket_reads_device(self, d_packed, n, n_buckets, d_out):
         _check(lib().harc_amd_bucket_reads_device(self._ctx, C.c_void_p(d_packed), n, n_buckets, C.c_void_p(d_out)))
+
+    def comm_init(self, comm_id, world, rank):
+        """join the RCCL communicator of the run (comm_id from comm_get_id() on rank 0)"""
+        _check(lib().harc_amd_comm_init(self._ctx, comm_id, len(comm_id), world, rank))
+
+    def comm_init_mailbox(self, directory, world, rank):
+        _check(lib().harc_amd_comm_init_mailbox(self._ctx, os.fsencode(directory), world, rank))
+
+    def comm_barrier(self):
+        _check(lib().harc_amd_comm_barrier(self._ctx))
+
+    def comm_destroy(self):
+        _check(lib().harc_amd_comm_destroy(self._ctx))
+
+    def shard_exchange(self):
+        """bucket the context's own reads, ONE all-to-all(v); -> info tuple (see include/harc_amd.h)"""
+        info = (C.c_uint64 * 8)()
+        _check(lib().harc_amd_shard_exchange(self._ctx, info))
+        return tuple(int(x) for x in info)
 
     def reorder(self):
         _check(lib().harc_amd_reorder(self._ctx))

@@ -155,6 +155,7 @@ extern "C" void harc_amd_destroy(harc_amd_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->P.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    delete c->comm; c->comm = nullptr;
     for (void *p : c->owned) (void)hipFree(p);
     for (auto &k : c->pool) (void)hipFree(k.base);
     for (auto &k : c->harena) (void)hipHostFree(k.base);
@@ -167,8 +168,26 @@ static void drop_results(harc_amd_ctx *c)
     harc_pool_release(c, 0);                                     // every per-run buffer lives in the pool
     c->d_order = nullptr; c->d_flag = c->d_pos = c->d_rc = nullptr; c->d_order_s = nullptr; c->d_oreads = nullptr; c->d_sreads = nullptr;
     c->have_s1 = c->have_s2 = c->s1_from_files = false; c->M = c->S = 0;
-    c->out.clear();
+    // results go; what came with the inputs (HARC_AMD_IN_ORDER_N, owned bytes) stays until the inputs are replaced
+    for (auto it = c->out.begin(); it != c->out.end();) { if (it->first.first < HARC_AMD_IN_ORDER_N) it = c->out.erase(it); else ++it; }
     harc_host_reset(c);
+}
+
+int harc_in_reserve(harc_amd_ctx *c, harc_amd_ctx::InBuf *b, size_t bytes)
+{
+    if (b->p && b->cap >= bytes) return HARC_AMD_OK;
+    if (b->p) { harc_raw_free(c, b->p); b->p = nullptr; b->cap = 0; }
+    RC_TRY(harc_raw_alloc(c, &b->p, bytes));
+    b->cap = bytes;
+    return HARC_AMD_OK;
+}
+void harc_reset_shard(harc_amd_ctx *c)
+{
+    c->d_reads = (uint64_t *)c->own_reads.p; c->N = c->N_own;
+    c->d_nreads3 = (uint64_t *)c->own_nreads3.p; c->NN = c->NN_own;
+    c->d_gid = c->d_ngid = nullptr;
+    memset(c->shard_info, 0, sizeof c->shard_info);
+    c->C.n_clean = c->N; c->C.n_N = c->NN;
 }
 
 static int upload(harc_amd_ctx *c, const void *host, size_t bytes, char **d)
@@ -183,12 +202,12 @@ extern "C" int harc_amd_set_reads_ascii_device(harc_amd_ctx *c, const char *d_as
     if (!c || (n && !d_ascii) || stride < (uint32_t)c->P.readlen) return HARC_AMD_EINVAL;
     HIP_TRY(hipSetDevice(c->P.device));
     drop_results(c);
-    if (c->d_reads) { harc_raw_free(c, c->d_reads); c->d_reads = nullptr; }
-    c->N = n;
-    RC_TRY(harc_raw_alloc(c, (void **)&c->d_reads, ((size_t)n * c->W + 1) * 8));
+    c->out.erase(std::make_pair((int)HARC_AMD_IN_ORDER_N, 0));
+    RC_TRY(harc_in_reserve(c, &c->own_reads, ((size_t)n * c->W + 1) * 8));
+    c->N_own = n; c->nrec_own = (uint64_t)n + c->NN_own;
+    harc_reset_shard(c);
     RC_TRY(s1_pack_ascii(c, d_ascii, n, stride, c->d_reads));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->C.n_clean = n;
     return HARC_AMD_OK;
 }
 extern "C" int harc_amd_set_reads_ascii(harc_amd_ctx *c, const char *ascii, uint32_t n, uint32_t stride)
@@ -207,24 +226,24 @@ extern "C" int harc_amd_set_reads_packed_device(harc_amd_ctx *c, const uint64_t 
     if (!c || (n && !d_packed)) return HARC_AMD_EINVAL;
     HIP_TRY(hipSetDevice(c->P.device));
     drop_results(c);
-    if (c->d_reads) { harc_raw_free(c, c->d_reads); c->d_reads = nullptr; }
-    c->N = n;
-    RC_TRY(harc_raw_alloc(c, (void **)&c->d_reads, ((size_t)n * c->W + 1) * 8));
+    c->out.erase(std::make_pair((int)HARC_AMD_IN_ORDER_N, 0));
+    RC_TRY(harc_in_reserve(c, &c->own_reads, ((size_t)n * c->W + 1) * 8));
+    c->N_own = n; c->nrec_own = (uint64_t)n + c->NN_own;
+    harc_reset_shard(c);
     if (n) HIP_TRY(hipMemcpyAsync(c->d_reads, d_packed, (size_t)n * c->W * 8, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->C.n_clean = n;
     return HARC_AMD_OK;
 }
 extern "C" int harc_amd_set_nreads_ascii_device(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride)
 {
     if (!c || (n && !d_ascii) || stride < (uint32_t)c->P.readlen) return HARC_AMD_EINVAL;
     HIP_TRY(hipSetDevice(c->P.device));
-    if (c->d_nreads3) { harc_raw_free(c, c->d_nreads3); c->d_nreads3 = nullptr; }
-    c->NN = n; c->have_s2 = false;
-    RC_TRY(harc_raw_alloc(c, (void **)&c->d_nreads3, ((size_t)n * c->W3 + 1) * 8));
+    c->have_s2 = false;
+    RC_TRY(harc_in_reserve(c, &c->own_nreads3, ((size_t)n * c->W3 + 1) * 8));
+    c->NN_own = n; c->nrec_own = (uint64_t)c->N_own + n;
+    harc_reset_shard(c);
     RC_TRY(s1_pack3_ascii(c, d_ascii, n, stride, c->d_nreads3));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->C.n_N = n;
     return HARC_AMD_OK;
 }
 extern "C" int harc_amd_set_nreads_ascii(harc_amd_ctx *c, const char *ascii, uint32_t n, uint32_t stride)

@@ -1,0 +1,209 @@
+// comm.cpp -- transports of the multi-GPU exchange (one process per GPU; BASELINE.json north_star: "reads shard by k-mer hash bucket
+// across the 8 GPUs of one node with a single RCCL all-to-all over xGMI").
+//
+//   RcclComm     ncclCommInitRank on the context's device; the all-to-all(v) is ONE ncclGroupStart .. ncclGroupEnd of
+//                ncclSend / ncclRecv pairs, one pair per (array, peer): point-to-point chunks, each over its own xGMI link, no ring.
+//                librccl.so.1 is opened on first use (a 570 MB library that single-GPU runs never need; inside a torch process the
+//                loader hands back the copy torch already mapped, same SONAME).
+//   MailboxComm  every chunk goes through a file of a shared directory.  Test transport: lets two ranks that share ONE GPU (which
+//                RCCL refuses: "duplicate GPU") run the whole sharded path on a one-GPU box.  Never chosen implicitly.
+#include "internal.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <stdlib.h>
+#include <time.h>
+#include <unistd.h>
+#include <string>
+
+// ------------------------------------------------------------------------------------------------ RCCL
+namespace {
+struct RcclApi {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.h) return HARC_AMD_OK;
+    void *h = nullptr;
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) { harc_set_error("cannot load librccl.so.1: %s", dlerror()); return HARC_AMD_ENODEVICE; }
+#define SYM(field, name) do { g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); \
+        if (!g_rccl.field) { harc_set_error("librccl: symbol %s missing", name); dlclose(h); return HARC_AMD_ENODEVICE; } } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+    SYM(AllGather, "ncclAllGather"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.h = h;
+    return HARC_AMD_OK;
+}
+#define NCCL_TRY(expr)                                                                                             \
+    do {                                                                                                           \
+        ncclResult_t _r = (expr);                                                                                  \
+        if (_r != ncclSuccess) {                                                                                   \
+            harc_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, g_rccl.GetErrorString(_r));               \
+            return HARC_AMD_ENODEVICE;                                                                             \
+        }                                                                                                          \
+    } while (0)
+
+struct RcclComm : HarcComm {
+    ncclComm_t comm = nullptr;
+    uint64_t *d_ag = nullptr; size_t ag_cap = 0;               // small device buffer for the count all-gather
+    ~RcclComm() override { if (comm) g_rccl.CommDestroy(comm); if (d_ag) (void)hipFree(d_ag); }
+    const char *name() const override { return "rccl"; }
+    int allgather_u64(harc_amd_ctx *c, const uint64_t *in, int n, uint64_t *out) override
+    {
+        const size_t need = (size_t)(world + 1) * n * 8;
+        if (need > ag_cap) { if (d_ag) (void)hipFree(d_ag); d_ag = nullptr; HIP_TRY(hipMalloc((void **)&d_ag, need)); ag_cap = need; }
+        uint64_t *d_in = d_ag, *d_out = d_ag + n;
+        HIP_TRY(hipMemcpyAsync(d_in, in, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        NCCL_TRY(g_rccl.AllGather(d_in, d_out, (size_t)n, ncclUint64, comm, c->stream));
+        HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)world * n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return HARC_AMD_OK;
+    }
+    int alltoallv(harc_amd_ctx *c, int narr, const void *const *send, const size_t *const *soff, const size_t *const *sbytes,
+                  void *const *recv, const size_t *const *roff, const size_t *const *rbytes) override
+    {
+        NCCL_TRY(g_rccl.GroupStart());
+        for (int a = 0; a < narr; a++)
+            for (int p = 0; p < world; p++) {
+                // zero-byte chunks are skipped on both sides: sender and receiver see the same count matrix
+                if (sbytes[a][p]) NCCL_TRY(g_rccl.Send((const char *)send[a] + soff[a][p], sbytes[a][p], ncclUint8, p, comm, c->stream));
+                if (rbytes[a][p]) NCCL_TRY(g_rccl.Recv((char *)recv[a] + roff[a][p], rbytes[a][p], ncclUint8, p, comm, c->stream));
+            }
+        NCCL_TRY(g_rccl.GroupEnd());
+        return HARC_AMD_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ mailbox (tests)
+struct MailboxComm : HarcComm {
+    std::string dir;
+    uint64_t seq = 0;
+    double timeout_s = 300.0;
+    const char *name() const override { return "mailbox"; }
+    static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+    std::string path(const char *kind, uint64_t s, int src, int dst, int arr) const
+    {
+        char b[128]; snprintf(b, sizeof b, "/%s.%llu.%d.%d.%d", kind, (unsigned long long)s, src, dst, arr);
+        return dir + b;
+    }
+    int put(const std::string &p, const void *data, size_t n) const
+    {
+        const std::string tmp = p + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f) { harc_set_error("mailbox: cannot create %s", tmp.c_str()); return HARC_AMD_EIO; }
+        const bool ok = n == 0 || fwrite(data, 1, n, f) == n;
+        fclose(f);
+        if (!ok || rename(tmp.c_str(), p.c_str()) != 0) { harc_set_error("mailbox: cannot write %s", p.c_str()); return HARC_AMD_EIO; }
+        return HARC_AMD_OK;
+    }
+    int get(const std::string &p, void *data, size_t n) const
+    {
+        const double t0 = now();
+        FILE *f = nullptr;
+        while (!(f = fopen(p.c_str(), "rb"))) {
+            if (now() - t0 > timeout_s) { harc_set_error("mailbox: timed out waiting for %s", p.c_str()); return HARC_AMD_EIO; }
+            usleep(2000);
+        }
+        const bool ok = n == 0 || fread(data, 1, n, f) == n;
+        fclose(f);
+        if (!ok) { harc_set_error("mailbox: short read on %s", p.c_str()); return HARC_AMD_EIO; }
+        return HARC_AMD_OK;
+    }
+    int allgather_u64(harc_amd_ctx *, const uint64_t *in, int n, uint64_t *out) override
+    {
+        const uint64_t s = seq++;
+        RC_TRY(put(path("ag", s, rank, 0, 0), in, (size_t)n * 8));
+        for (int p = 0; p < world; p++) RC_TRY(get(path("ag", s, p, 0, 0), out + (size_t)p * n, (size_t)n * 8));
+        return HARC_AMD_OK;
+    }
+    int alltoallv(harc_amd_ctx *c, int narr, const void *const *send, const size_t *const *soff, const size_t *const *sbytes,
+                  void *const *recv, const size_t *const *roff, const size_t *const *rbytes) override
+    {
+        const uint64_t s = seq++;
+        std::vector<char> h;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int a = 0; a < narr; a++)
+            for (int p = 0; p < world; p++) {
+                h.resize(sbytes[a][p]);
+                if (sbytes[a][p]) HIP_TRY(hipMemcpy(h.data(), (const char *)send[a] + soff[a][p], sbytes[a][p], hipMemcpyDeviceToHost));
+                RC_TRY(put(path("xx", s, rank, p, a), h.data(), h.size()));
+            }
+        for (int a = 0; a < narr; a++)
+            for (int p = 0; p < world; p++) {
+                h.resize(rbytes[a][p]);
+                RC_TRY(get(path("xx", s, p, rank, a), h.data(), h.size()));
+                if (rbytes[a][p]) HIP_TRY(hipMemcpy((char *)recv[a] + roff[a][p], h.data(), rbytes[a][p], hipMemcpyHostToDevice));
+            }
+        return HARC_AMD_OK;
+    }
+};
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ C-ABI
+extern "C" int harc_amd_comm_get_id(uint8_t *id, size_t id_bytes)
+{
+    if (!id || id_bytes < sizeof(ncclUniqueId)) { harc_set_error("harc_amd_comm_get_id: buffer of at least %zu bytes needed", sizeof(ncclUniqueId)); return HARC_AMD_EINVAL; }
+    RC_TRY(rccl_load());
+    ncclUniqueId u;
+    NCCL_TRY(g_rccl.GetUniqueId(&u));
+    memset(id, 0, id_bytes);
+    memcpy(id, &u, sizeof u);
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_comm_init(harc_amd_ctx *c, const uint8_t *id, size_t id_bytes, int32_t world, int32_t rank)
+{
+    if (!c || !id || id_bytes < sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world) { harc_set_error("harc_amd_comm_init: bad arguments"); return HARC_AMD_EINVAL; }
+    HIP_TRY(hipSetDevice(c->P.device));
+    RC_TRY(rccl_load());
+    delete c->comm; c->comm = nullptr;
+    RcclComm *r = new RcclComm();
+    r->world = world; r->rank = rank;
+    ncclUniqueId u; memcpy(&u, id, sizeof u);
+    ncclResult_t e = g_rccl.CommInitRank(&r->comm, world, u, rank);
+    if (e != ncclSuccess) { r->comm = nullptr; delete r; harc_set_error("ncclCommInitRank(world %d, rank %d) failed: %s", world, rank, g_rccl.GetErrorString(e)); return HARC_AMD_ENODEVICE; }
+    c->comm = r;
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_comm_init_mailbox(harc_amd_ctx *c, const char *dir, int32_t world, int32_t rank)
+{
+    if (!c || !dir || world < 1 || rank < 0 || rank >= world) { harc_set_error("harc_amd_comm_init_mailbox: bad arguments"); return HARC_AMD_EINVAL; }
+    delete c->comm; c->comm = nullptr;
+    MailboxComm *m = new MailboxComm();
+    m->world = world; m->rank = rank; m->dir = dir;
+    if (const char *e = getenv("HARC_AMD_MAILBOX_TIMEOUT")) m->timeout_s = atof(e);
+    c->comm = m;
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_comm_destroy(harc_amd_ctx *c)
+{
+    if (!c) return HARC_AMD_EINVAL;
+    (void)hipSetDevice(c->P.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    delete c->comm; c->comm = nullptr;
+    return HARC_AMD_OK;
+}
+
+extern "C" int harc_amd_comm_barrier(harc_amd_ctx *c)
+{
+    if (!c || !c->comm) { harc_set_error("harc_amd_comm_barrier: no communicator"); return HARC_AMD_ESTATE; }
+    HIP_TRY(hipSetDevice(c->P.device));
+    std::vector<uint64_t> all((size_t)c->comm->world);
+    const uint64_t one = 1;
+    return c->comm->allgather_u64(c, &one, 1, all.data());
+}

@@ -206,3 +206,98 @@ extern "C" int harc_amd_preprocess_files(const char *fastq, const char *basedir,
            (unsigned long long)readnum, (unsigned long long)nclean);
     return HARC_AMD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ multi-GPU: merge of the rank parts
+// Every rank of harc_amd_compress_fastq_shard_files leaves, under <basedir>/output/.shard/, its part of the files that exist once per
+// archive.  The layout the decoders expect (encoder.cpp:457-503, decoder.cpp:141-169, decoder_preserve.cpp:212-290):
+//   read_order.bin       = [aligned clean reads, shard by shard][unaligned singletons in read_singleton.txt order]
+//   read_order_N_pe.bin  = [aligned N reads, shard by shard][unaligned N reads in input_N.dna order]
+// so the aligned halves of all ranks come first, in rank order (= shard order rank*E + e), then the unaligned halves in rank order,
+// and read_singleton.txt / input_N.dna are the rank parts in the same rank order.  read_singleton.txt packs 4 bases per byte
+// (encoder.cpp:527-548) with up to 3 bases of ASCII tail: the parts are re-packed across the joints.
+namespace {
+struct Appender {
+    FILE *f = nullptr; std::string path;
+    int open(const std::string &p) { path = p; f = fopen(p.c_str(), "wb"); if (!f) { harc_set_error("cannot create %s", p.c_str()); return HARC_AMD_EIO; } return HARC_AMD_OK; }
+    int add(const void *p, size_t n) { if (n && fwrite(p, 1, n, f) != n) { harc_set_error("short write on %s", path.c_str()); return HARC_AMD_EIO; } return HARC_AMD_OK; }
+    int add_file(const std::string &src, bool must_exist)
+    {
+        FILE *in = fopen(src.c_str(), "rb");
+        if (!in) { if (must_exist) { harc_set_error("cannot open %s", src.c_str()); return HARC_AMD_EIO; } return HARC_AMD_OK; }
+        std::vector<char> buf((size_t)4 << 20); size_t got; int rc = HARC_AMD_OK;
+        while (rc == HARC_AMD_OK && (got = fread(buf.data(), 1, buf.size(), in)) > 0) rc = add(buf.data(), got);
+        fclose(in);
+        return rc;
+    }
+    ~Appender() { if (f) fclose(f); }
+};
+}
+
+extern "C" int harc_amd_merge_shard_files(const char *basedir, int32_t world)
+{
+    if (!basedir || world < 1) { harc_set_error("merge_shard_files: bad arguments"); return HARC_AMD_EINVAL; }
+    const std::string od = std::string(basedir) + "/output/", sd = od + ".shard/";
+    auto part = [&](const char *stem, int r) { return sd + stem + "." + std::to_string(r); };
+    // totals (and the proof that every rank finished)
+    int L = 0; unsigned long long nrec = 0, nclean = 0, unmatched = 0, al_s = 0, al_N = 0;
+    for (int r = 0; r < world; r++) {
+        std::vector<char> st;
+        if (!slurp(part("stats", r), st, true)) { harc_set_error("rank %d left no result under %s", r, sd.c_str()); return HARC_AMD_EIO; }
+        st.push_back(0);
+        int l = 0; unsigned long long v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (sscanf(st.data(), "%d %llu %llu %llu %llu %llu %llu %llu %llu", &l, &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]) != 9) { harc_set_error("stats of rank %d unreadable", r); return HARC_AMD_EIO; }
+        if (r && l != L) { harc_set_error("ranks disagree on the read length (%d vs %d)", L, l); return HARC_AMD_EINVAL; }
+        L = l; nrec += v[0]; nclean += v[1]; unmatched += v[3]; al_s += v[4]; al_N += v[5];
+    }
+    if (nrec > 4294967290ull) { printf("Too many reads. HARC supports at most 4294967290 reads\n"); harc_set_error("too many reads"); return HARC_AMD_EINVAL; }
+    printf("Read length: %d\nTotal number of reads: %llu\nTotal number of reads without N: %llu\nPreprocessing Done!\n", L, nrec, nclean);   // preprocess.cpp:133-136
+    printf("Reordering done, %llu were unmatched\n", unmatched);                                                    // reorder.cpp:701
+    printf("Encoding done:\n%llu singleton reads were aligned\n%llu reads with N were aligned\n", al_s, al_N);      // encoder.cpp:506-508
+    {
+        Appender o, on, in_n, oN;
+        RC_TRY(o.open(od + "read_order.bin")); RC_TRY(on.open(od + "read_order_N_pe.bin")); RC_TRY(in_n.open(od + "input_N.dna")); RC_TRY(oN.open(od + "read_order_N.bin"));
+        for (int r = 0; r < world; r++) { RC_TRY(o.add_file(part("order_a", r), true)); RC_TRY(on.add_file(part("orderN_a", r), true)); }
+        for (int r = 0; r < world; r++) {
+            RC_TRY(o.add_file(part("order_u", r), true)); RC_TRY(on.add_file(part("orderN_u", r), true));
+            RC_TRY(in_n.add_file(part("input_N", r), true)); RC_TRY(oN.add_file(part("order_N", r), true));
+        }
+    }
+    {   // read_singleton.txt: 2 bits per base across the joints (A0 C1 G2 T3, first base in the low bits: encoder.cpp:540-541)
+        Appender sg; RC_TRY(sg.open(od + "read_singleton.txt"));
+        unsigned pend = 0; int npend = 0;                          // bases waiting for a full byte
+        std::vector<char> in, tail; std::vector<uint8_t> outb;
+        auto code = [](char ch) -> unsigned { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u; };
+        for (int r = 0; r < world; r++) {
+            if (!slurp(part("singleton", r), in, true) || !slurp(part("singleton_tail", r), tail, true)) return HARC_AMD_EIO;
+            if (npend == 0) RC_TRY(sg.add(in.data(), in.size()));
+            else {
+                outb.resize(in.size());
+                const int sh = 2 * npend;
+                for (size_t i = 0; i < in.size(); i++) { const unsigned b = (uint8_t)in[i]; outb[i] = (uint8_t)(pend | (b << sh)); pend = b >> (8 - sh); }
+                RC_TRY(sg.add(outb.data(), outb.size()));
+            }
+            for (char ch : tail) {
+                pend |= code(ch) << (2 * npend);
+                if (++npend == 4) { const uint8_t b = (uint8_t)pend; RC_TRY(sg.add(&b, 1)); pend = 0; npend = 0; }
+            }
+        }
+        char t[4]; for (int k = 0; k < npend; k++) t[k] = "ACGT"[(pend >> (2 * k)) & 3];
+        RC_TRY(spit(od + "read_singleton.txt.tail", t, (size_t)npend));
+    }
+    { const uint32_t n32 = (uint32_t)nclean; RC_TRY(spit(od + "numreads.bin", &n32, 4)); }
+    { char m[32]; const int ml = snprintf(m, sizeof m, "%d\n", L); RC_TRY(spit(od + "read_meta.txt", m, (size_t)ml)); }
+    {   // -q -p: quality values and ids in file order = the slices in rank order
+        FILE *probe = fopen(part("quality", 0).c_str(), "rb");
+        if (probe) {
+            fclose(probe);
+            Appender q, i; RC_TRY(q.open(od + "output.quality")); RC_TRY(i.open(od + "output.id"));
+            for (int r = 0; r < world; r++) { RC_TRY(q.add_file(part("quality", r), true)); RC_TRY(i.add_file(part("id", r), true)); }
+        }
+    }
+    // the parts are gone from the archive
+    static const char *stems[] = { "stats", "order_a", "order_u", "orderN_a", "orderN_u", "input_N", "order_N", "singleton", "singleton_tail", "quality", "id" };
+    for (int r = 0; r < world; r++) for (const char *s : stems) (void)remove(part(s, r).c_str());
+    (void)remove((sd + "comm_id").c_str());
+    (void)remove(sd.substr(0, sd.size() - 1).c_str());            // rmdir when empty (a mailbox directory, if any, is the caller's)
+    return HARC_AMD_OK;
+}

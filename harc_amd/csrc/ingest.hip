@@ -5,6 +5,8 @@
 // per record classifies, two compactions pack the reads straight into the 2-bit / 3-bit stores of the context.
 #include "devutil.h"
 #include <string>
+#include <sys/stat.h>
+#include <unistd.h>
 
 // line index in two levels: newlines per 4096-byte tile -> scan of the tile counts -> positions written tile by tile
 #define NL_TILE 4096
@@ -148,10 +150,11 @@ extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uin
         harc_set_error("read length not fixed (%u records differ from %d)", err, L); harc_pool_release(c, mk); return HARC_AMD_EINVAL;
     }
     // the packed stores outlive the scratch: raw allocations (as harc_amd_set_reads_*)
-    if (c->d_reads) { harc_raw_free(c, c->d_reads); c->d_reads = nullptr; }
-    if (c->d_nreads3) { harc_raw_free(c, c->d_nreads3); c->d_nreads3 = nullptr; }
-    RC_TRY(harc_raw_alloc(c, (void **)&c->d_reads, ((size_t)nC * c->W + 1) * 8));
-    RC_TRY(harc_raw_alloc(c, (void **)&c->d_nreads3, ((size_t)nN * c->W3 + 1) * 8));
+    RC_TRY(harc_in_reserve(c, &c->own_reads, ((size_t)nC * c->W + 1) * 8));
+    RC_TRY(harc_in_reserve(c, &c->own_nreads3, ((size_t)nN * c->W3 + 1) * 8));
+    c->N_own = nC; c->NN_own = nN;
+    harc_reset_shard(c);
+    c->nrec_own = nrec64;
     uint32_t *orderN = nullptr; RC_TRY(dalloc(c, &orderN, (size_t)nN + 1));
     if (nrec) {
         hipLaunchKernelGGL(k_ingest_pack2, G256((uint64_t)nrec * c->W), d_txt, nls, isC, rkC, nrec, L, c->W, c->d_reads);
@@ -161,7 +164,6 @@ extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uin
     std::vector<uint8_t> &ob = out_buf(c, HARC_AMD_IN_ORDER_N, 0);
     RC_TRY(harc_d2h(c, ob, orderN, (size_t)nN * 4));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->N = nC; c->NN = nN; c->C.n_clean = nC; c->C.n_N = nN;
     if (n_records_out) *n_records_out = nfull;                    // what preprocess.cpp:134 prints: complete records
     harc_pool_release(c, mk);
     return HARC_AMD_OK;
@@ -243,9 +245,9 @@ static int emit_lines(harc_amd_ctx *c, const char *d_txt, const uint64_t *nls, c
     return HARC_AMD_OK;
 }
 
-static int emit_quality_and_ids(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes, bool preserve_order, const std::string &od)
+static int emit_quality_and_ids(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes, bool preserve_order, const std::string &od, const char *qname, const char *iname)
 {
-    FILE *fq = fopen((od + "output.quality").c_str(), "wb"), *fi = fopen((od + "output.id").c_str(), "wb");
+    FILE *fq = fopen((od + qname).c_str(), "wb"), *fi = fopen((od + iname).c_str(), "wb");
     struct Closer { FILE *a, *b; ~Closer() { if (a) fclose(a); if (b) fclose(b); } } closer{ fq, fi };
     if (!fq || !fi) { harc_set_error("cannot create %soutput.quality / output.id", od.c_str()); return HARC_AMD_EIO; }
     if (nbytes == 0) return HARC_AMD_OK;
@@ -313,6 +315,64 @@ static int emit_quality_and_ids(harc_amd_ctx *c, const char *d_txt, uint64_t nby
     return HARC_AMD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ file drivers
+// bytes [lo, hi) of the file -> device memory, through two pinned buffers; *d_txt is a raw allocation of the context
+static int load_file_range(harc_amd_ctx *c, FILE *f, const char *name, uint64_t lo, uint64_t hi, char **d_txt)
+{
+    *d_txt = nullptr;
+    const uint64_t n = hi - lo;
+    RC_TRY(harc_raw_alloc(c, (void **)d_txt, (size_t)n + 16));
+    const size_t CH = (size_t)64 << 20;
+    struct Pinned {
+        char *hb[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr };
+        ~Pinned() { for (int k = 0; k < 2; k++) { if (ev[k]) (void)hipEventDestroy(ev[k]); if (hb[k]) (void)hipHostFree(hb[k]); } }
+    } pb;
+    int rc = HARC_AMD_OK;
+    for (int k = 0; k < 2 && rc == HARC_AMD_OK; k++)
+        if (hipHostMalloc((void **)&pb.hb[k], CH) != hipSuccess || hipEventCreate(&pb.ev[k]) != hipSuccess) { harc_set_error("hipHostMalloc / hipEventCreate failed"); rc = HARC_AMD_ENOMEM; }
+    if (rc == HARC_AMD_OK && fseeko(f, (off_t)lo, SEEK_SET) != 0) { harc_set_error("cannot seek in %s", name); rc = HARC_AMD_EIO; }
+    size_t off = 0; int k = 0; bool used[2] = { false, false };
+    while (rc == HARC_AMD_OK && off < (size_t)n) {
+        if (used[k]) (void)hipEventSynchronize(pb.ev[k]);
+        const size_t want = (size_t)n - off < CH ? (size_t)n - off : CH;
+        if (fread(pb.hb[k], 1, want, f) != want) { harc_set_error("short read on %s", name); rc = HARC_AMD_EIO; break; }
+        if (hipMemcpyAsync(*d_txt + off, pb.hb[k], want, hipMemcpyHostToDevice, c->stream) != hipSuccess) { harc_set_error("upload of %s failed", name); rc = HARC_AMD_ENODEVICE; break; }
+        (void)hipEventRecord(pb.ev[k], c->stream); used[k] = true;
+        off += want; k ^= 1;
+    }
+    (void)hipStreamSynchronize(c->stream);                        // before the pinned buffers go
+    if (rc != HARC_AMD_OK) { harc_raw_free(c, *d_txt); *d_txt = nullptr; }
+    return rc;
+}
+static int spit_file(const std::string &path, const void *p, size_t n)
+{
+    FILE *o = fopen(path.c_str(), "wb");
+    if (!o) { harc_set_error("cannot create %s", path.c_str()); return HARC_AMD_EIO; }
+    if (n && fwrite(p, 1, n, o) != n) { fclose(o); harc_set_error("short write on %s", path.c_str()); return HARC_AMD_EIO; }
+    fclose(o);
+    return HARC_AMD_OK;
+}
+static int spit_stream_to(harc_amd_ctx *c, int id, int shard, const std::string &path)
+{
+    const void *p; size_t n;
+    RC_TRY(harc_amd_get_stream(c, id, shard, &p, &n));
+    return spit_file(path, p, n);
+}
+// read_{seq,pos,noise,noisepos,rev}.txt.<first_shard + e> (+ .tail): the per-shard family of encoder.cpp:190-196
+static int write_shard_family(harc_amd_ctx *c, const std::string &od, int first_shard)
+{
+    static const struct { int id; const char *name; } files[] = {
+        { HARC_AMD_S2_SEQ, "read_seq.txt" }, { HARC_AMD_S2_POS, "read_pos.txt" }, { HARC_AMD_S2_NOISE, "read_noise.txt" },
+        { HARC_AMD_S2_NOISEPOS, "read_noisepos.txt" }, { HARC_AMD_S2_REV, "read_rev.txt" } };
+    for (int e = 0; e < c->P.num_thr; e++) {
+        const std::string sfx = "." + std::to_string(first_shard + e);
+        for (auto &fd : files) RC_TRY(spit_stream_to(c, fd.id, e, od + fd.name + sfx));
+        RC_TRY(spit_stream_to(c, HARC_AMD_S2_SEQ_TAIL, e, od + "read_seq.txt" + sfx + ".tail"));
+        RC_TRY(spit_stream_to(c, HARC_AMD_S2_REV_TAIL, e, od + "read_rev.txt" + sfx + ".tail"));
+    }
+    return HARC_AMD_OK;
+}
+
 // FASTQ file -> every stage-II file under <basedir>/output (+ read_order_N.bin, numreads.bin): harc:50-69 without input_clean.dna
 extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order, int32_t preserve_quality)
 {
@@ -322,66 +382,32 @@ extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, c
     struct Guard { harc_amd_ctx *c; ~Guard() { harc_amd_destroy(c); } } guard{ c };
     FILE *f = fopen(fastq, "rb");
     if (!f) { harc_set_error("cannot open %s", fastq); return HARC_AMD_EIO; }
-    fseek(f, 0, SEEK_END); const long long fsz = ftell(f); fseek(f, 0, SEEK_SET);
+    struct FClose { FILE *f; ~FClose() { fclose(f); } } fcl{ f };
+    fseeko(f, 0, SEEK_END); const uint64_t fsz = (uint64_t)ftello(f);
     char *d_txt = nullptr;
-    if (harc_raw_alloc(c, (void **)&d_txt, (size_t)fsz + 16) != HARC_AMD_OK) { fclose(f); return HARC_AMD_ENOMEM; }
-    {   // stream the file through two pinned buffers
-        const size_t CH = (size_t)64 << 20;
-        char *hb[2] = { nullptr, nullptr };
-        if (hipHostMalloc((void **)&hb[0], CH) != hipSuccess || hipHostMalloc((void **)&hb[1], CH) != hipSuccess) { fclose(f); harc_set_error("hipHostMalloc failed"); return HARC_AMD_ENOMEM; }
-        hipEvent_t ev[2]; (void)hipEventCreate(&ev[0]); (void)hipEventCreate(&ev[1]);
-        size_t off = 0; int k = 0; bool used[2] = { false, false };
-        while (off < (size_t)fsz) {
-            if (used[k]) (void)hipEventSynchronize(ev[k]);
-            const size_t want = (size_t)fsz - off < CH ? (size_t)fsz - off : CH;
-            if (fread(hb[k], 1, want, f) != want) { fclose(f); harc_set_error("short read on %s", fastq); return HARC_AMD_EIO; }
-            (void)hipMemcpyAsync(d_txt + off, hb[k], want, hipMemcpyHostToDevice, c->stream);
-            (void)hipEventRecord(ev[k], c->stream); used[k] = true;
-            off += want; k ^= 1;
-        }
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); (void)hipHostFree(hb[0]); (void)hipHostFree(hb[1]);
-    }
-    fclose(f);
+    RC_TRY(load_file_range(c, f, fastq, 0, fsz, &d_txt));
     uint64_t nrec = 0;
-    int rc = harc_amd_set_fastq_device(c, d_txt, (uint64_t)fsz, &nrec);
+    int rc = harc_amd_set_fastq_device(c, d_txt, fsz, &nrec);
     if (!preserve_quality || rc != HARC_AMD_OK) { harc_raw_free(c, d_txt); d_txt = nullptr; }
     if (rc != HARC_AMD_OK) return rc;
     printf("Read length: %d\nTotal number of reads: %llu\nTotal number of reads without N: %llu\nPreprocessing Done!\n", params->readlen,
            (unsigned long long)nrec, (unsigned long long)c->N);                                           // preprocess.cpp:133-136
     const std::string od = std::string(basedir) + "/output/";
-    auto spit = [&](const std::string &name, const void *p, size_t n) -> int {
-        FILE *o = fopen((od + name).c_str(), "wb");
-        if (!o) { harc_set_error("cannot create %s%s", od.c_str(), name.c_str()); return HARC_AMD_EIO; }
-        if (n && fwrite(p, 1, n, o) != n) { fclose(o); harc_set_error("short write"); return HARC_AMD_EIO; }
-        fclose(o); return HARC_AMD_OK;
-    };
-    {
-        const void *p; size_t n;
-        RC_TRY(harc_amd_get_stream(c, HARC_AMD_IN_ORDER_N, 0, &p, &n)); RC_TRY(spit("read_order_N.bin", p, n));
-        const uint32_t n32 = c->N; RC_TRY(spit("numreads.bin", &n32, 4));
-    }
+    RC_TRY(spit_stream_to(c, HARC_AMD_IN_ORDER_N, 0, od + "read_order_N.bin"));
+    { const uint32_t n32 = c->N; RC_TRY(spit_file(od + "numreads.bin", &n32, 4)); }
     RC_TRY(harc_amd_reorder(c));
     RC_TRY(harc_amd_encode(c));
     harc_amd_counters C; harc_amd_get_counters(c, &C);
     printf("Reordering done, %llu were unmatched\n", (unsigned long long)C.unmatched);
     printf("Encoding done:\n%llu singleton reads were aligned\n%llu reads with N were aligned\n", (unsigned long long)C.aligned_singletons, (unsigned long long)C.aligned_N);
-    static const struct { int id; const char *name; bool per_shard; } files[] = {
-        { HARC_AMD_S2_SEQ, "read_seq.txt", true }, { HARC_AMD_S2_POS, "read_pos.txt", true }, { HARC_AMD_S2_NOISE, "read_noise.txt", true },
-        { HARC_AMD_S2_NOISEPOS, "read_noisepos.txt", true }, { HARC_AMD_S2_REV, "read_rev.txt", true } };
-    for (int e = 0; e < params->num_thr; e++) {
-        for (auto &fd : files) { const void *p; size_t n; RC_TRY(harc_amd_get_stream(c, fd.id, e, &p, &n)); RC_TRY(spit(std::string(fd.name) + "." + std::to_string(e), p, n)); }
-        const void *p; size_t n;
-        RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_SEQ_TAIL, e, &p, &n)); RC_TRY(spit("read_seq.txt." + std::to_string(e) + ".tail", p, n));
-        RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_REV_TAIL, e, &p, &n)); RC_TRY(spit("read_rev.txt." + std::to_string(e) + ".tail", p, n));
-    }
+    RC_TRY(write_shard_family(c, od, 0));
     static const struct { int id; const char *name; } whole[] = {
         { HARC_AMD_S2_ORDER, "read_order.bin" }, { HARC_AMD_S2_ORDER_N_PE, "read_order_N_pe.bin" }, { HARC_AMD_S2_INPUT_N, "input_N.dna" },
         { HARC_AMD_S2_META, "read_meta.txt" }, { HARC_AMD_S2_SINGLETON, "read_singleton.txt" }, { HARC_AMD_S2_SINGLETON_TAIL, "read_singleton.txt.tail" } };
-    for (auto &fd : whole) { const void *p; size_t n; RC_TRY(harc_amd_get_stream(c, fd.id, 0, &p, &n)); RC_TRY(spit(fd.name, p, n)); }
+    for (auto &fd : whole) RC_TRY(spit_stream_to(c, fd.id, 0, od + fd.name));
     if (preserve_quality) {
         if (!preserve_order) printf("Reordering quality values and ids\n");                                 // harc:122
-        rc = emit_quality_and_ids(c, d_txt, (uint64_t)fsz, preserve_order != 0, od);
+        rc = emit_quality_and_ids(c, d_txt, fsz, preserve_order != 0, od, "output.quality", "output.id");
         harc_raw_free(c, d_txt);
         if (rc != HARC_AMD_OK) return rc;
     }
@@ -390,4 +416,111 @@ extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, c
 extern "C" int harc_amd_compress_fastq_files(const harc_amd_params *params, const char *fastq, const char *basedir)
 {
     return harc_amd_compress_fastq_files_ex(params, fastq, basedir, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ one rank of a multi-GPU run
+// first byte >= pos at which a FASTQ record starts: a line that begins with '@' whose second successor begins with '+'.  (A quality
+// line may begin with '@' too, but then the line two further on is a sequence line, which never begins with '+'.)
+static int record_start_at_or_after(FILE *f, uint64_t pos, uint64_t fsz, uint64_t *out)
+{
+    if (pos == 0) { *out = 0; return HARC_AMD_OK; }
+    if (pos >= fsz) { *out = fsz; return HARC_AMD_OK; }
+    std::vector<char> buf;
+    for (size_t win = (size_t)1 << 16;; win <<= 1) {
+        const uint64_t lo = pos - 1;                              // the byte before pos tells whether pos starts a line
+        const uint64_t n = fsz - lo < win ? fsz - lo : win;
+        buf.resize((size_t)n);
+        if (fseeko(f, (off_t)lo, SEEK_SET) != 0 || fread(buf.data(), 1, (size_t)n, f) != (size_t)n) { harc_set_error("cannot read the FASTQ file around byte %llu", (unsigned long long)pos); return HARC_AMD_EIO; }
+        std::vector<size_t> ls;                                   // line starts inside the window (offsets into buf)
+        for (size_t i = 0; i + 1 < (size_t)n; i++) if (buf[i] == '\n') ls.push_back(i + 1);
+        for (size_t k = 0; k + 2 < ls.size(); k++)
+            if (buf[ls[k]] == '@' && buf[ls[k + 2]] == '+') { *out = lo + ls[k]; return HARC_AMD_OK; }
+        if (lo + n >= fsz) { *out = fsz; return HARC_AMD_OK; }   // no further record
+    }
+}
+static int rendezvous(harc_amd_ctx *c, const char *spec, int world, int rank)
+{
+    if (!spec) { harc_set_error("comm_spec missing"); return HARC_AMD_EINVAL; }
+    if (!strncmp(spec, "mailbox:", 8)) return harc_amd_comm_init_mailbox(c, spec + 8, world, rank);
+    if (strncmp(spec, "rccl:", 5)) { harc_set_error("comm_spec must be rccl:<file> or mailbox:<dir>"); return HARC_AMD_EINVAL; }
+    const std::string path = spec + 5;
+    uint8_t id[HARC_AMD_COMM_ID_BYTES];
+    if (rank == 0) {
+        RC_TRY(harc_amd_comm_get_id(id, sizeof id));
+        RC_TRY(spit_file(path + ".tmp", id, sizeof id));
+        if (rename((path + ".tmp").c_str(), path.c_str()) != 0) { harc_set_error("cannot publish %s", path.c_str()); return HARC_AMD_EIO; }
+    } else {
+        FILE *f = nullptr;
+        for (int tries = 0; !(f = fopen(path.c_str(), "rb")); tries++) {
+            if (tries > 150000) { harc_set_error("rank %d: no communicator id at %s after 300 s", rank, path.c_str()); return HARC_AMD_EIO; }
+            usleep(2000);
+        }
+        const bool ok = fread(id, 1, sizeof id, f) == sizeof id;
+        fclose(f);
+        if (!ok) { harc_set_error("short communicator id in %s", path.c_str()); return HARC_AMD_EIO; }
+    }
+    return harc_amd_comm_init(c, id, sizeof id, world, rank);
+}
+
+extern "C" int harc_amd_compress_fastq_shard_files(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order,
+                                                   int32_t preserve_quality, int32_t world, int32_t rank, const char *comm_spec)
+{
+    if (!params || !fastq || !basedir || world < 1 || rank < 0 || rank >= world) { harc_set_error("compress_fastq_shard: bad arguments"); return HARC_AMD_EINVAL; }
+    if (preserve_quality && !preserve_order) { harc_set_error("multi-GPU -q needs -p (quality values and ids stay in file order)"); return HARC_AMD_EINVAL; }
+    harc_amd_ctx *c = nullptr;
+    RC_TRY(harc_amd_create(params, &c));
+    struct Guard { harc_amd_ctx *c; ~Guard() { harc_amd_destroy(c); } } guard{ c };
+    FILE *f = fopen(fastq, "rb");
+    if (!f) { harc_set_error("cannot open %s", fastq); return HARC_AMD_EIO; }
+    struct FClose { FILE *f; ~FClose() { fclose(f); } } fcl{ f };
+    fseeko(f, 0, SEEK_END); const uint64_t fsz = (uint64_t)ftello(f);
+    uint64_t lo = 0, hi = fsz;
+    RC_TRY(record_start_at_or_after(f, fsz / (uint64_t)world * (uint64_t)rank, fsz, &lo));
+    if (rank + 1 < world) RC_TRY(record_start_at_or_after(f, fsz / (uint64_t)world * (uint64_t)(rank + 1), fsz, &hi));
+    char *d_txt = nullptr;
+    RC_TRY(load_file_range(c, f, fastq, lo, hi, &d_txt));
+    uint64_t nrec_full = 0;
+    int rc = harc_amd_set_fastq_device(c, d_txt, hi - lo, &nrec_full);
+    if (!preserve_quality || rc != HARC_AMD_OK) { harc_raw_free(c, d_txt); d_txt = nullptr; }
+    if (rc != HARC_AMD_OK) return rc;
+    const std::string od = std::string(basedir) + "/output/", sd = od + ".shard/", r = "." + std::to_string(rank);
+    (void)mkdir(sd.c_str(), 0777);                                // every rank tries; the first one wins
+    const uint64_t n_clean_own = c->N_own;
+    std::vector<uint32_t> orderN;                                 // read_order_N.bin of this slice, local record numbers
+    { const void *p; size_t n; RC_TRY(harc_amd_get_stream(c, HARC_AMD_IN_ORDER_N, 0, &p, &n)); orderN.assign((const uint32_t *)p, (const uint32_t *)p + n / 4); }
+    if (preserve_quality) {                                       // file order (preprocess.cpp:64-69): the slices are concatenated by the merge
+        RC_TRY(emit_quality_and_ids(c, d_txt, hi - lo, true, sd, ("quality" + r).c_str(), ("id" + r).c_str()));
+        harc_raw_free(c, d_txt); d_txt = nullptr;
+    }
+    RC_TRY(rendezvous(c, comm_spec, world, rank));
+    uint64_t info[8];
+    RC_TRY(harc_amd_shard_exchange(c, info));
+    for (auto &x : orderN) x += (uint32_t)info[5];                // records of the lower ranks come first in the file
+    RC_TRY(spit_file(sd + "order_N" + r, orderN.data(), orderN.size() * 4));
+    RC_TRY(harc_amd_reorder(c));
+    RC_TRY(harc_amd_encode(c));
+    harc_amd_counters C; harc_amd_get_counters(c, &C);
+    RC_TRY(write_shard_family(c, od, rank * params->num_thr));
+    {   // whole-job files: this rank's part, aligned and unaligned halves apart (the merge interleaves them as encoder.cpp:457-503 does)
+        const void *po, *pn, *ps, *pt, *pi; size_t no, nn, ns, nt, ni;
+        RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_ORDER, 0, &po, &no)); RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_ORDER_N_PE, 0, &pn, &nn));
+        RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_SINGLETON, 0, &ps, &ns)); RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_SINGLETON_TAIL, 0, &pt, &nt));
+        RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_INPUT_N, 0, &pi, &ni));
+        const int L = params->readlen;
+        const size_t US = (4 * ns + nt) / (size_t)L, UN = ni / (size_t)(L + 1);
+        if (no < US * 4 || nn < UN * 4) { harc_set_error("shard %d: order streams shorter than the unaligned reads", rank); return HARC_AMD_ESTATE; }
+        RC_TRY(spit_file(sd + "order_a" + r, po, no - US * 4)); RC_TRY(spit_file(sd + "order_u" + r, (const char *)po + (no - US * 4), US * 4));
+        RC_TRY(spit_file(sd + "orderN_a" + r, pn, nn - UN * 4)); RC_TRY(spit_file(sd + "orderN_u" + r, (const char *)pn + (nn - UN * 4), UN * 4));
+        RC_TRY(spit_file(sd + "singleton" + r, ps, ns)); RC_TRY(spit_file(sd + "singleton_tail" + r, pt, nt));
+        RC_TRY(spit_file(sd + "input_N" + r, pi, ni));
+    }
+    {
+        char line[512];
+        const int n = snprintf(line, sizeof line, "%d %llu %llu %llu %llu %llu %llu %llu %llu\n", params->readlen, (unsigned long long)nrec_full,
+                               (unsigned long long)n_clean_own, (unsigned long long)c->NN_own, (unsigned long long)C.unmatched,
+                               (unsigned long long)C.aligned_singletons, (unsigned long long)C.aligned_N, (unsigned long long)c->N, (unsigned long long)c->NN);
+        RC_TRY(spit_file(sd + "stats" + r, line, (size_t)n));       // written last: its presence says that the rank is done
+    }
+    RC_TRY(harc_amd_comm_barrier(c));                             // nobody leaves (and tears the communicator down) while a peer is still exchanging
+    return HARC_AMD_OK;
 }

@@ -94,9 +94,19 @@ struct harc_amd_ctx {
     std::vector<PoolChunk> pool;
     size_t pool_cur = 0, pool_total = 0;
 
-    // inputs
+    // inputs.  d_reads / d_nreads3 are what the stages read: the context's own inputs (installed by harc_amd_set_*), or, after
+    // harc_amd_shard_exchange, the shard this GPU received through the all-to-all (the own inputs stay, a later exchange starts from them)
     uint32_t N = 0;  uint64_t *d_reads = nullptr;      // N x W, 2-bit
     uint32_t NN = 0; uint64_t *d_nreads3 = nullptr;    // NN x W3, 3-bit (reads with N)
+    struct InBuf { void *p = nullptr; size_t cap = 0; };  // raw allocation kept across runs, grown when too small
+    InBuf own_reads, own_nreads3;                       // the context's own inputs
+    uint32_t N_own = 0, NN_own = 0;
+    uint64_t nrec_own = 0;                              // FASTQ records behind the own inputs (harc_amd_set_fastq_device), else N_own + NN_own
+    // multi-GPU (shard.hip, comm.cpp)
+    struct HarcComm *comm = nullptr;
+    InBuf x_reads, x_nreads3, x_gid, x_ngid;            // the received shard and the global ids of its reads
+    uint32_t *d_gid = nullptr, *d_ngid = nullptr;       // non-null after an exchange: stage II writes global ids into its order streams
+    uint64_t shard_info[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  // [0] clean reads of the whole job [1] N reads [2] records [3] this rank's first clean id [4] first N id [5] first record
     // stage-I result, device
     bool have_s1 = false;
     uint32_t M = 0, S = 0;
@@ -118,6 +128,21 @@ struct harc_amd_ctx {
     // scratch for rocPRIM
     void *d_tmp = nullptr; size_t tmp_bytes = 0;
 };
+
+// ---- transport of the multi-GPU exchange (comm.cpp): RCCL in production, a directory of files for tests on one GPU
+struct HarcComm {
+    int world = 1, rank = 0;
+    virtual ~HarcComm() {}
+    // every rank contributes n u64 (host memory); out = world * n values, rank-major
+    virtual int allgather_u64(harc_amd_ctx *c, const uint64_t *in, int n, uint64_t *out) = 0;
+    // ONE all-to-all(v) over `narr` device arrays at once: for array a, the chunk for peer p is send[a] + soff[a][p] (sbytes[a][p] bytes),
+    // the chunk from peer p lands at recv[a] + roff[a][p] (rbytes[a][p] bytes); enqueued on c->stream
+    virtual int alltoallv(harc_amd_ctx *c, int narr, const void *const *send, const size_t *const *soff, const size_t *const *sbytes,
+                          void *const *recv, const size_t *const *roff, const size_t *const *rbytes) = 0;
+    virtual const char *name() const = 0;
+};
+int harc_in_reserve(harc_amd_ctx *c, harc_amd_ctx::InBuf *b, size_t bytes);   // raw allocation reused across runs
+void harc_reset_shard(harc_amd_ctx *c);                                       // stages read the context's own inputs again
 
 // ---- device memory helpers (api.cpp)
 int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes);
@@ -144,6 +169,11 @@ int s1_pack3_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t st
 int s1_unpack_to_ascii(harc_amd_ctx *c, const uint64_t *d_reads, uint32_t n, char *d_out);                           // n x (L+1) text
 int s1_bucket_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint32_t *d_out);
 int s1_partition_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint64_t *d_out, unsigned long long *d_counts);
+// the same for either read store (three_bit: reads with N, canonical minimizer over the windows without N), with the global id
+// gid0 + (index of the read) travelling along; d_gid_out may be null
+int shard_partition(harc_amd_ctx *c, const uint64_t *d_words, uint32_t n, int nwords, bool three_bit, uint32_t nb, uint32_t gid0,
+                    uint64_t *d_out, uint32_t *d_gid_out, unsigned long long *d_counts);
+int shard_map_ids(harc_amd_ctx *c, uint32_t *d_v, uint64_t n, const uint32_t *d_map, uint32_t nmap, unsigned int *d_err);   // v[i] = map[v[i]]
 int stage1_run(harc_amd_ctx *c);
 int stage1_make_oriented(harc_amd_ctx *c);      // d_oreads from d_reads/d_order/d_rc
 int s1_orient(harc_amd_ctx *c, const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, uint64_t *out);

@@ -7,6 +7,9 @@
 //   harc_amd_stage compressfq <basedir> <readlen> <fastq> [num_thr] [num_chains] [num_steps] [preserve_order] [preserve_quality]
 //                                                                          == preprocess + reorder + encoder (+ reorder_quality), FASTQ parsed on the GPU
 //   harc_amd_stage preprocess <basedir> <readlen> <fastq>                  == src/preprocess.out <fastq> <basedir> .. <readlen> (harc:50)
+//   harc_amd_stage compressfq_shard <basedir> <readlen> <fastq> <num_thr> <num_chains> <num_steps> <preserve_order> <preserve_quality>
+//                                   <world> <rank> <comm_spec> [device]    one rank of `./harc -c -g <world>` (one process per GPU)
+//   harc_amd_stage merge_shards <basedir> <world>                          the whole-job files of the archive from the rank parts
 // readlen / num_thr arrive as arguments instead of the compile-time macros of src/config.h (harc:52-63).
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,11 +19,16 @@
 int main(int argc, char **argv)
 {
     if (argc < 4) { fprintf(stderr, "usage: %s reorder|encoder|compress|pack_order <basedir> <readlen> [num_thr] [num_chains]\n", argv[0]); return 2; }
+    if (!strcmp(argv[1], "merge_shards")) {
+        const int rcm = harc_amd_merge_shard_files(argv[2], atoi(argv[3]));
+        if (rcm != 0) { fprintf(stderr, "harc_amd_stage merge_shards failed (%d): %s\n", rcm, harc_amd_last_error()); return 1; }
+        return 0;
+    }
     harc_amd_params P;
     int rl = atoi(argv[3]);
     if (!strncmp(argv[1], "decoder", 7) && (rl < 1 || rl > 255)) rl = 100;     // the decoder takes readlen from read_meta.txt (decoder.cpp:324-333)
     if (harc_amd_default_params(rl, &P) != 0) { fprintf(stderr, "%s\n", harc_amd_last_error()); return 1; }
-    if (strcmp(argv[1], "preprocess") && strncmp(argv[1], "decoder", 7) && strcmp(argv[1], "compressfq")) {
+    if (strcmp(argv[1], "preprocess") && strncmp(argv[1], "decoder", 7) && strncmp(argv[1], "compressfq", 10)) {
         if (argc > 4) P.num_thr = atoi(argv[4]);
         if (argc > 5) P.num_chains = atoi(argv[5]);
         if (argc > 6) P.num_steps = atoi(argv[6]);
@@ -34,6 +42,14 @@ int main(int argc, char **argv)
         if (argc > 7) P.num_steps = atoi(argv[7]);
         const int po = argc > 8 && !strcmp(argv[8], "True"), pq = argc > 9 && !strcmp(argv[9], "True");     // preprocess.out's argv[3], argv[4] (harc:50)
         rc = harc_amd_compress_fastq_files_ex(&P, argv[4], argv[2], po, pq);
+    }
+    else if (!strcmp(argv[1], "compressfq_shard")) {
+        if (argc < 13) { fprintf(stderr, "compressfq_shard needs <fastq> <num_thr> <num_chains> <num_steps> <p> <q> <world> <rank> <comm_spec> [device]\n"); return 2; }
+        P.num_thr = atoi(argv[5]); P.num_chains = atoi(argv[6]); P.num_steps = atoi(argv[7]);
+        const int po = !strcmp(argv[8], "True"), pq = !strcmp(argv[9], "True"), world = atoi(argv[10]), rank = atoi(argv[11]);
+        P.device = argc > 13 ? atoi(argv[13]) : rank;                 // one process per GPU: rank r drives device r unless told otherwise
+        P.reads_per_chain = 1024;                                     // a bucket shard is fragmented already (multi-GPU)
+        rc = harc_amd_compress_fastq_shard_files(&P, argv[4], argv[2], po, pq, world, rank, argv[12]);
     }
     else if (!strcmp(argv[1], "decoder_preserve")) rc = harc_amd_decoder_preserve_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1);
     else if (!strcmp(argv[1], "decoder")) rc = harc_amd_decoder_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1);

@@ -816,6 +816,18 @@ int stage2_run(harc_amd_ctx *c)
     if (F) launch_noise<true>(c, a, f, cons2, F, nullptr, nullptr, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out);
     if (T) hipLaunchKernelGGL(k_left_emit, G256(T), a, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned, sing_bases, ntext);
     HIP_TRY(hipGetLastError());
+    if (c->d_gid && !c->s1_from_files) {
+        // multi-GPU shard (harc_amd_shard_exchange): the order streams carry the GLOBAL ids of the reads, so that the merged archive
+        // restores the original order like a single-GPU one (decoder_preserve.cpp:246-290, :212-244)
+        unsigned int *d_merr = nullptr; RC_TRY(dalloc(c, &d_merr, 4));
+        HIP_TRY(hipMemsetAsync(d_merr, 0, 16, c->stream));
+        RC_TRY(shard_map_ids(c, order_out, (uint64_t)n_nonN + US, c->d_gid, c->N, d_merr));
+        RC_TRY(shard_map_ids(c, orderN_out, (uint64_t)n_N_aligned + UN, c->d_ngid, c->NN, d_merr));
+        unsigned int merr = 0;
+        HIP_TRY(hipMemcpyAsync(&merr, d_merr, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (merr) { harc_set_error("stage II: %u order entries outside the shard", merr); return HARC_AMD_ENODEVICE; }
+    }
 
     // ---- shard boundaries in final-list / column / noise coordinates
     std::vector<uint32_t> sh_i(E + 1), sh_f(E + 1); std::vector<uint64_t> sh_col(E + 1), sh_nm(E + 1);

@@ -158,6 +158,29 @@ int harc_amd_bucket_reads_device(harc_amd_ctx *ctx, const uint64_t *d_packed, ui
    number of reads per bucket (n_buckets u64, device memory) */
 int harc_amd_partition_reads_device(harc_amd_ctx *ctx, const uint64_t *d_packed, uint32_t n_reads, uint32_t n_buckets, uint64_t *d_packed_out, uint64_t *d_counts_out);
 
+/* ---- multi-GPU run: one process (one context) per GPU, RCCL over xGMI.  The reference has no counterpart (its parallelism is OpenMP
+   threads over one address space, reorder.cpp:455-457); what it fixes is the archive contract the merged result must meet: stream
+   files read_*.txt.<shard> discovered by their count (harc:171, decoder.cpp:90-140), read_order.bin = original index of every
+   decoded clean read in stream order, singletons last (decoder_preserve.cpp:246-290), read_order_N_pe.bin likewise for the reads
+   with N (:212-244), read_order_N.bin = original record of every N read (merge_N.cpp:37-57).
+   Bootstrap mirrors ncclGetUniqueId / ncclCommInitRank: rank 0 obtains an id, the caller ships the bytes to the other ranks (a
+   file, MPI, torch.distributed, ...), every rank calls harc_amd_comm_init. */
+#define HARC_AMD_COMM_ID_BYTES 128
+int harc_amd_comm_get_id(uint8_t *id, size_t id_bytes);                                   /* id_bytes >= HARC_AMD_COMM_ID_BYTES */
+int harc_amd_comm_init(harc_amd_ctx *ctx, const uint8_t *id, size_t id_bytes, int32_t world, int32_t rank);   /* ncclCommInitRank on params.device */
+/* test transport: chunks travel through files of a shared directory, so that several ranks can share ONE GPU (RCCL refuses that) */
+int harc_amd_comm_init_mailbox(harc_amd_ctx *ctx, const char *dir, int32_t world, int32_t rank);
+int harc_amd_comm_barrier(harc_amd_ctx *ctx);
+int harc_amd_comm_destroy(harc_amd_ctx *ctx);
+/* The context holds this rank's slice of the job (harc_amd_set_reads_* / set_nreads_* / set_fastq_device).  Reads are bucketed by
+   the hash of their canonical minimizer, grouped by destination and moved with ONE all-to-all(v) -- ncclGroupStart, ncclSend /
+   ncclRecv per peer, ncclGroupEnd -- carrying 8W + 4 bytes per clean read (packed read + u32 global id) and 8 W3 + 4 per read with N.
+   Afterwards harc_amd_reorder / harc_amd_encode work on the shard and HARC_AMD_S2_ORDER / HARC_AMD_S2_ORDER_N_PE hold GLOBAL ids
+   (clean read i of rank r = sum of the clean reads of ranks < r, + i).  The slice itself stays with the context: calling the
+   function again repeats the exchange.  info (8 u64, may be NULL): [0] clean reads of the whole job [1] reads with N [2] FASTQ
+   records [3] this rank's first clean id [4] first N id [5] first record [6] clean reads received [7] N reads received. */
+int harc_amd_shard_exchange(harc_amd_ctx *ctx, uint64_t *info);
+
 /* ---- compute (all on params.device, asynchronous internally, synchronised before return) */
 int harc_amd_reorder(harc_amd_ctx *ctx);      /* index build + chaining: reorder.cpp:277-703 */
 int harc_amd_encode(harc_amd_ctx *ctx);       /* encoder.cpp:154-616 on the stage-I result held in HBM (or set_stage1_streams) */
@@ -199,6 +222,17 @@ int harc_amd_decoder_files(const harc_amd_params *params, const char *basedir, i
    Everything is held in HBM at once (about 3 x (readlen+1) bytes per read, ~900 M reads of 100 bp on one MI355X; the reference bins
    through host memory instead, decoder_preserve.cpp:249-253); larger archives fail with HARC_AMD_ENOMEM */
 int harc_amd_decoder_preserve_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e);
+/* One rank of a multi-GPU `./harc -c -g <world>`: reads its slice of the FASTQ file (cut at record boundaries near rank/world of the
+   file), joins the communicator named by comm_spec -- "rccl:<file>" (rank 0 writes the ncclUniqueId there, the others wait for it) or
+   "mailbox:<dir>" (test transport) --, exchanges, compresses its shard and writes read_*.txt.<rank*num_thr + e> into
+   <basedir>/output plus its part of the whole-job files under <basedir>/output/.shard/.  preserve_quality needs preserve_order
+   (quality values and ids then stay in file order, preprocess.cpp:64-69). */
+int harc_amd_compress_fastq_shard_files(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order,
+                                        int32_t preserve_quality, int32_t world, int32_t rank, const char *comm_spec);
+/* After every rank has finished: the whole-job files of the archive (read_singleton.txt(+.tail), input_N.dna, read_order.bin,
+   read_order_N_pe.bin, read_order_N.bin, numreads.bin, read_meta.txt, output.quality / output.id) from the parts under .shard/,
+   laid out as encoder.cpp:457-503 writes them: aligned reads of all shards first, then the unaligned ones.  Host code. */
+int harc_amd_merge_shard_files(const char *basedir, int32_t world);
 
 #ifdef __cplusplus
 }

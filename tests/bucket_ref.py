@@ -57,3 +57,56 @@ def reads_signature(lines):
     s = int(h.sum(dtype=np.uint64)) if len(lines) else 0
     x = int(np.bitwise_xor.reduce(h)) if len(lines) else 0
     return (len(lines), s, x)
+
+
+def bucket3_ref(reads_ascii, nb, gid0=0):
+    """numpy restatement of harc_amd/csrc/shard.hip k_bucket3: the shard key of a read WITH N -- canonical minimizer (k = 15) over the
+    windows that hold no N, packed code A0 G1 C2 T3 as for clean reads; no such window: hash of the read's global id.
+    reads_ascii: [n, L] uint8"""
+    n, L = reads_ascii.shape
+    K = min(L, 15)
+    kmask = np.uint64((1 << (2 * K)) - 1)
+    fw = np.zeros(n, dtype=np.uint64); rv = np.zeros(n, dtype=np.uint64)
+    best = np.full(n, np.uint64(0xFFFFFFFFFFFFFFFF))
+    valid = np.zeros(n, dtype=np.int64)
+    anyw = np.zeros(n, dtype=bool)
+    for b in range(L):
+        ch = reads_ascii[:, b]
+        isn = ch == ord("N")
+        pc = _PC[ch]
+        fw = ((fw << np.uint64(2)) | pc) & kmask
+        rv = (rv >> np.uint64(2)) | ((np.uint64(3) - pc) << np.uint64(2 * (K - 1)))
+        fw[isn] = 0; rv[isn] = 0
+        valid = np.where(isn, 0, valid + 1)
+        ok = valid >= K
+        h = _mix64(np.minimum(fw, rv))
+        best = np.where(ok, np.minimum(best, h), best)
+        anyw |= ok
+    fallback = _mix64((np.uint64(gid0) + np.arange(n, dtype=np.uint64)))
+    best = np.where(anyw, best, fallback)
+    return (best % np.uint64(nb)).astype(np.int64)
+
+
+def shard_plan(slices, L, world):
+    """What harc_amd_shard_exchange must deliver.  slices: list (one per rank) of [n_r, L] uint8 reads in file order.
+    -> per destination rank r: dict(clean=[m, L] reads, gid=global clean ids, withN=[k, L], ngid=global N ids) in the order of
+    arrival: source-rank-major, original order inside a source."""
+    cl, nn = [], []
+    for s in slices:
+        hasN = (s == ord("N")).any(1)
+        cl.append(s[~hasN]); nn.append(s[hasN])
+    coff = np.concatenate([[0], np.cumsum([c.shape[0] for c in cl])]).astype(np.int64)
+    noff = np.concatenate([[0], np.cumsum([c.shape[0] for c in nn])]).astype(np.int64)
+    out = []
+    for r in range(world):
+        parts, gids, nparts, ngids = [], [], [], []
+        for s in range(len(slices)):
+            b = bucket_ref(pack2(cl[s]), L, world) if cl[s].shape[0] else np.zeros(0, dtype=np.int64)
+            sel = np.nonzero(b == r)[0]
+            parts.append(cl[s][sel]); gids.append(coff[s] + sel)
+            b3 = bucket3_ref(nn[s], world, int(noff[s])) if nn[s].shape[0] else np.zeros(0, dtype=np.int64)
+            sel3 = np.nonzero(b3 == r)[0]
+            nparts.append(nn[s][sel3]); ngids.append(noff[s] + sel3)
+        out.append(dict(clean=np.concatenate(parts), gid=np.concatenate(gids).astype(np.uint32),
+                        withN=np.concatenate(nparts), ngid=np.concatenate(ngids).astype(np.uint32)))
+    return out
