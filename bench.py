@@ -2,14 +2,16 @@
 """bench.py -- Mreads/s of HARC reorder+encode (100 bp) on 1/2/4/8 MI355X, with the roofline of the dominant kernel and
 the reference's CPU path timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c1|mini] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1|c2r|c2d|mini ...] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one pass of the hot path over the synthetic batch: index build + chaining (reorder.cpp:277-703) + encoding
 (encoder.cpp:154-616), from 2-bit packed reads resident in HBM to every stage-II stream resident in host memory.
-N>1: every rank owns a batch of the same size drawn from a genome N times larger (weak scaling); reads are sharded
-by a canonical-minimizer bucket with ONE all-to-all over xGMI (RCCL), then each GPU chains and encodes its shard
-independently (BASELINE.json north_star; DESIGN.md "Multi-GPU").  Prints ONE JSON line on rank 0.
+Default workload: c3 = BASELINE.json configs[2] (350 M x 100 bp error-free, 11.3x), the configuration the metric is quoted on.
+N>1: every rank owns a batch of the same size drawn from a genome N times larger (weak scaling); inside every step the reads
+are sharded by a canonical-minimizer bucket with ONE all-to-all over xGMI -- harc_amd_shard_exchange: RCCL send/recv inside
+libharc_amd.so, packed read + u32 global id per read -- then each GPU chains and encodes its shard independently
+(BASELINE.json north_star; DESIGN.md "Multi-GPU").  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -28,6 +30,7 @@ WORKLOADS = {
     # name: (reads per GPU, read length, genome bp per GPU, error rate, description == BASELINE.json config)
     "c2": (3_300_000, 100, 6_300_000, 0.005, "configs[1] stand-in: 3.3M x 100bp, 6.3 Mbp i.i.d. genome (~52x), 0.5% substitutions (1/4 N), odd reads RC"),
     "c2r": (3_300_000, 100, 6_300_000, 0.005, "c2 with a repeat-spiked genome: 2000 copies of one 300-bp element and 200 poly-A runs of 150 bp (hot dictionary bins)"),
+    "c2d": (3_300_000, 100, 6_300_000, 0.005, "c2 with a diverged repeat family: 10000 copies of one 300-bp element, each with 12 % of its bases substituted, 300 poly-A runs and 300 (CA)n runs of 150 bp"),
     "c3": (350_000_000, 100, 3_100_000_000, 0.0, "configs[2] stand-in: 350M x 100bp error-free, 3.1 Gbp i.i.d. genome (11.3x), odd reads RC"),
     "c3s": (50_000_000, 100, 443_000_000, 0.0, "configs[2] at 1/7 scale: 50M x 100bp error-free, 443 Mbp i.i.d. genome (11.3x)"),
     "c1": (1_000_000, 100, 35_000_000, 0.0, "configs[0] stand-in: 1M x 100bp error-free, 35 Mbp i.i.d. genome (2.9x)"),
@@ -52,13 +55,20 @@ def synth_chunks(n, L, G, err, seed, dev, spike=None):
     for s in range(0, G, 1 << 28):
         m = min(1 << 28, G - s)
         genome[s:s + m] = lut[torch.randint(0, 4, (m,), generator=g, device=dev)]
-    if spike:                                                    # (copies of one 300-bp element, poly-A runs of 150 bp): hot dictionary bins
-        ncopy, npolya = spike
-        rep = lut[torch.randint(0, 4, (300,), generator=g, device=dev)]
-        for p in torch.randint(0, G - 400, (ncopy,), generator=g, device=dev).tolist():
-            genome[p:p + 300] = rep
+    if spike:                                                    # repeats and low-complexity runs: hot dictionary bins
+        ncopy, div, npolya, nstr = spike
+        rep = torch.randint(0, 4, (300,), generator=g, device=dev)
+        pos = torch.randperm(G // 400, generator=g, device=dev)[:ncopy] * 400     # distinct 400-bp slots: copies never overlap
+        cp = rep[None, :].repeat(ncopy, 1)
+        if div > 0:                                              # every copy diverged from the element on its own
+            mut = torch.rand((ncopy, 300), generator=g, device=dev) < div
+            cp = torch.where(mut, (cp + torch.randint(1, 4, (ncopy, 300), generator=g, device=dev)) % 4, cp)
+        genome[(pos[:, None] + torch.arange(300, device=dev)[None, :]).reshape(-1)] = lut[cp.reshape(-1)]
         for p in torch.randint(0, G - 400, (npolya,), generator=g, device=dev).tolist():
             genome[p:p + 150] = ord("A")
+        ca = torch.tensor(list(b"CA" * 75), dtype=torch.uint8, device=dev)
+        for p in torch.randint(0, G - 400, (nstr,), generator=g, device=dev).tolist():
+            genome[p:p + 150] = ca
     g.manual_seed(seed)                                          # the reads differ per rank
     ar = torch.arange(L, device=dev)
     CH = 4_000_000
@@ -83,45 +93,96 @@ def synth_reads(n, L, G, err, seed, dev, spike=None):
     return torch.cat(list(synth_chunks(n, L, G, err, seed, dev, spike)))
 
 
-SPIKES = {"c2r": (2000, 200)}                                   # workload -> (copies of a 300-bp repeat, poly-A runs) put into the genome
+# workload -> (copies of a 300-bp element, per-copy divergence, poly-A runs, (CA)n runs) put into the genome
+SPIKES = {"c2r": (2000, 0.0, 200, 0), "c2d": (10000, 0.12, 300, 300)}
 
 
-def cpu_baseline(n_sample, L, G_sample, err, seed, dev):
-    """The reference itself (oracle/_ref, built from /root/reference by oracle/build_ref.sh) timed on this box's host cores on
-    a bounded sample of the workload; falls back to the C port (oracle/liboracle.so) when the prebuilt reference is absent."""
-    ncpu = os.cpu_count() or 1
-    refdir = os.path.join(ROOT, "oracle", "_ref")
-    reads = synth_reads(n_sample, L, G_sample, err, seed, dev).cpu().numpy()
-    hasN = (reads == ord("N")).any(1)
+def stage_files(reads_np, d):
+    """[n, L] uint8 reads -> the input files of the reference's reorder.out / encoder.out under <d>/output"""
     import numpy as np
-    nl = np.full((reads.shape[0], 1), 10, dtype=np.uint8)
-    lines = np.concatenate([reads, nl], axis=1)
-    clean, withN = lines[~hasN], lines[hasN]
-    thr = max([t for t in (1, 8, 16, 32, 64) if t <= ncpu and os.path.exists(os.path.join(refdir, f"reorder_L{L}_t{t}.out"))], default=0)
+    hasN = (reads_np == ord("N")).any(1)
+    nl = np.full((reads_np.shape[0], 1), 10, dtype=np.uint8)
+    lines = np.concatenate([reads_np, nl], axis=1)
+    od = os.path.join(d, "output")
+    os.makedirs(od)
+    lines[~hasN].tofile(os.path.join(od, "input_clean.dna"))
+    lines[hasN].tofile(os.path.join(od, "input_N.dna"))
+    np.array([int((~hasN).sum())], dtype=np.uint32).tofile(os.path.join(od, "numreads.bin"))
+    return od
+
+
+def run_reference(reads_np, L, thr):
+    """reorder.out + encoder.out of the REAL reference (oracle/_ref, built from /root/reference by oracle/build_ref.sh) at -t thr on
+    these reads -> (wall seconds, {stage-II file: bytes})"""
+    refdir = os.path.join(ROOT, "oracle", "_ref")
     tmp = "/dev/shm" if os.path.isdir("/dev/shm") else None
     with tempfile.TemporaryDirectory(dir=tmp, prefix="harc_cpu_") as d:
-        od = os.path.join(d, "output")
-        os.makedirs(od)
-        clean.tofile(os.path.join(od, "input_clean.dna"))
-        withN.tofile(os.path.join(od, "input_N.dna"))
-        np.array([clean.shape[0]], dtype=np.uint32).tofile(os.path.join(od, "numreads.bin"))
-        if thr:
-            t0 = time.time()
-            subprocess.check_call([os.path.join(refdir, f"reorder_L{L}_t{thr}.out"), d], cwd=d, stdout=subprocess.DEVNULL)
-            subprocess.check_call([os.path.join(refdir, f"encoder_L{L}_t{thr}.out"), d], cwd=d, stdout=subprocess.DEVNULL)
-            dt = time.time() - t0
-            kind, cores = "reference", thr
-        else:
-            from tests import oracle_lib as ol
-            o = ol.load()
+        od = stage_files(reads_np, d)
+        t0 = time.time()
+        subprocess.check_call([os.path.join(refdir, f"reorder_L{L}_t{thr}.out"), d], cwd=d, stdout=subprocess.DEVNULL)
+        subprocess.check_call([os.path.join(refdir, f"encoder_L{L}_t{thr}.out"), d], cwd=d, stdout=subprocess.DEVNULL)
+        dt = time.time() - t0
+        files = {}
+        for f in os.listdir(od):
+            if f.startswith(("read_seq", "read_pos", "read_noise", "read_rev.txt.", "read_singleton", "read_meta")) or f == "input_N.dna":
+                files[f] = open(os.path.join(od, f), "rb").read()
+    return dt, files
+
+
+def cpu_baseline(reads_np, L, desc):
+    """The reference itself timed on this box's host cores on a bounded sample of the workload; falls back to the C port
+    (oracle/liboracle.so, one core) when the prebuilt reference is absent."""
+    ncpu = os.cpu_count() or 1
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    thr = max([t for t in (1, 8, 16, 32, 64) if t <= ncpu and os.path.exists(os.path.join(refdir, f"reorder_L{L}_t{t}.out"))], default=0)
+    n_sample = reads_np.shape[0]
+    if thr:
+        dt, _ = run_reference(reads_np, L, thr)
+        kind, cores = "reference", thr
+    else:
+        from tests import oracle_lib as ol
+        o = ol.load()
+        tmp = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        with tempfile.TemporaryDirectory(dir=tmp, prefix="harc_cpu_") as d:
+            stage_files(reads_np, d)
             t0 = time.time()
             assert o.harc_oracle_reorder(d.encode(), L, 1, 1, None, None) == 0
             assert o.harc_oracle_encoder(d.encode(), L, 1, None, None) == 0
             dt = time.time() - t0
-            kind, cores = "port", 1
+        kind, cores = "port", 1
     return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": kind,
-            "sample": f"{n_sample} reads of the same generator on a {G_sample} bp genome (same coverage and error rate), "
-                      f"reorder+encode wall {dt:.1f}s" + (f", ./harc -t {thr} stage programs" if thr else ", scalar C port")}
+            "sample": f"{desc}, reorder+encode wall {dt:.1f}s" + (f", ./harc -t {thr} stage programs" if thr else ", scalar C port")}
+
+
+def xz_size(blobs):
+    import lzma
+    return sum(len(lzma.compress(b, preset=6)) for b in blobs)
+
+
+def gpu_run_sample(harc_amd, reads_t, L, dev_index, shards, **kw):
+    """one untimed reorder+encode of a sample on a fresh context -> (context, counters, seconds)"""
+    hasN = (reads_t == ord("N")).any(1)
+    cl, wn = reads_t[~hasN].contiguous(), reads_t[hasN].contiguous()
+    p = harc_amd.default_params(L, num_thr=shards, device=dev_index, **kw)
+    h = harc_amd.HarcAmd(p)
+    torch.cuda.synchronize()
+    h.set_reads_ascii_device(cl.data_ptr(), cl.shape[0], L)
+    h.set_nreads_ascii_device(wn.data_ptr(), wn.shape[0], L)
+    h.reorder(); h.encode()                                        # warm-up: pool growth, first-launch costs
+    t0 = time.perf_counter()
+    h.reorder(); h.encode()
+    dt = time.perf_counter() - t0
+    return h, h.counters(), dt
+
+
+def stage2_blobs(h, shards):
+    out = []
+    for e in range(shards):
+        for sid in ("S2_SEQ", "S2_SEQ_TAIL", "S2_POS", "S2_NOISE", "S2_NOISEPOS", "S2_REV", "S2_REV_TAIL"):
+            out.append(h.stream(sid, e))
+    for sid in ("S2_SINGLETON", "S2_SINGLETON_TAIL", "S2_INPUT_N", "S2_META"):
+        out.append(h.stream(sid))
+    return out
 
 
 def main():
@@ -129,11 +190,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=os.environ.get("HARC_BENCH_WORKLOAD", "c2"))
+    ap.add_argument("--workload", default=os.environ.get("HARC_BENCH_WORKLOAD", "c3"))
     ap.add_argument("--chains", type=int, default=0)
     ap.add_argument("--super-steps", type=int, default=0, help="steps per super-round (num_steps, default 16)")
     ap.add_argument("--shards", type=int, default=8, help="num_thr of the reference = encoder shards per GPU (harc:195 default 8)")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (reference baseline, size comparison) and the exact-mode sample")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket exchange even at world size 1 (exercises the N>1 path on one GPU)")
     ap.add_argument("--cpu-sample", type=int, default=0)
     args = ap.parse_args()
@@ -161,10 +222,11 @@ def main():
 
     import harc_amd
     n, L, G, err, desc = WORKLOADS[args.workload]
+    spike = SPIKES.get(args.workload)
     # weak scaling: same reads per GPU, genome (and so coverage) per GPU constant; every rank samples the WHOLE genome
     # a minimizer-bucket shard is already fragmented into islands of ~10 overlapping reads: twice as many chains cost +0.3 % (8 GPUs) to
     # +1.2 % (2 GPUs) of consensus bases there and save 38 % of the chain time (tools/shard_sim.py); one GPU keeps one chain per 2048 reads
-    rpc = 1024 if (world > 1 or args.force_dist) else 0
+    rpc = 1024 if dist is not None else 0
     p = harc_amd.default_params(L, num_thr=args.shards, num_chains=args.chains, device=local, profile=1, num_steps=args.super_steps, reads_per_chain=rpc)
     h = harc_amd.HarcAmd(p)
     # inputs, 4 M reads at a time so that config-3/4-sized sets never exist as ASCII: clean reads are packed to 2 bits per base
@@ -173,46 +235,44 @@ def main():
     Wd = (2 * L + 63) // 64
     packed = torch.empty((n, Wd), dtype=torch.int64, device=dev)
     nclean, nparts = 0, []
-    sig_clean, sig_N = [0, 0, 0], [0, 0, 0]
+    sig_in = [0, 0, 0]
 
     def acc(sig, t):
         c3 = h.reads_signature_device(t.data_ptr(), t.shape[0], L)
         sig[0] += c3[0]; sig[1] = (sig[1] + c3[1]) % (1 << 64); sig[2] ^= c3[2]
-    for r in synth_chunks(n, L, G * world, err, 1000 + rank, dev, SPIKES.get(args.workload)):
+    for r in synth_chunks(n, L, G * world, err, 1000 + rank, dev, spike):
         hasN = (r == ord("N")).any(1)
         cl = r[~hasN].contiguous()
         wn = r[hasN].contiguous()
         torch.cuda.synchronize()                                  # libharc_amd works on its own stream: its inputs must be complete
         if cl.shape[0]:
             h.pack_reads_device(cl.data_ptr(), cl.shape[0], cl.stride(0), packed[nclean:].data_ptr())
-            acc(sig_clean, cl)
+            acc(sig_in, cl)
             nclean += cl.shape[0]
         if wn.shape[0]:
-            acc(sig_N, wn)
+            acc(sig_in, wn)
             nparts.append(wn)
         del r, hasN, cl, wn
     withN = torch.cat(nparts) if nparts else torch.empty((0, L), dtype=torch.uint8, device=dev)
     del nparts
     packed = packed[:nclean]
     torch.cuda.synchronize()
-    torch.cuda.empty_cache()
-    sharder = None
-    if dist is not None:
-        from harc_amd import multigpu
-        sharder = multigpu.BucketSharder(h, dist, dev, L)         # local 2-bit reads stay resident in HBM; the exchange is inside the step
-        sig_clean = None
-    else:
-        h.set_reads_packed_device(packed.data_ptr(), nclean)      # the library keeps its own copy
-        del packed
+    # this rank's slice of the job is installed ONCE (the library keeps its own copy): on one GPU it is the whole input, on N GPUs the
+    # exchange inside every step starts from it
+    h.set_reads_packed_device(packed.data_ptr(), nclean)
     h.set_nreads_ascii_device(withN.data_ptr(), withN.shape[0], L)
-    del withN
+    del packed, withN
     torch.cuda.synchronize()
     torch.cuda.empty_cache()                                      # hand torch's cached blocks back: the library allocates with hipMalloc
+    if dist is not None:
+        from harc_amd import multigpu
+        multigpu.init_comm(h, dist, dev)                          # ncclUniqueId from the library, broadcast over the process group
+        sig_in = list(multigpu.allreduce_signature(dist, tuple(sig_in), dev))    # the whole job's reads, BEFORE any exchange
     with_pack_order = args.workload == "c5s"
 
     def step():
-        if sharder is not None:
-            sharder.exchange_and_set(packed)                      # bucket -> one all-to-all(v) over xGMI -> this GPU's shard
+        if dist is not None:
+            h.shard_exchange()                                    # bucket -> ONE all-to-all(v) over xGMI (RCCL inside the library) -> this GPU's shard
         h.reorder()
         h.encode()
         if with_pack_order:
@@ -226,7 +286,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    agg = dict(propose_ms=0.0, launches=0, steps_alg=0, useful=0, cands=0, probes=0, rounds=0)
+    agg = dict(propose_ms=0.0, launches=0, steps_alg=0, useful=0, cands=0, cands_seq=0, probes=0, rounds=0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -235,6 +295,7 @@ def main():
         agg["propose_ms"] += c.propose_ms
         agg["launches"] += c.propose_launches
         agg["cands"] += c.candidates
+        agg["cands_seq"] += c.candidates_seq
         agg["probes"] += c.probes
         agg["useful"] += c.useful_probes
         agg["rounds"] += c.rounds
@@ -247,26 +308,26 @@ def main():
         dt = float(tt.item())
     c = h.counters()
     # round trip at full size, outside the timed region: decode the streams of the last step on the GPU (decoder.cpp:90-169
-    # restated in verify.hip) and compare the multiset signature with the inputs' (single GPU: all reads; sharded: count only,
-    # the shard's clean reads came from other ranks)
+    # restated in verify.hip) and compare the multiset signature (count, sum, xor of 64-bit read hashes) with the inputs'.  N GPUs:
+    # the signatures of all ranks' INPUT slices (taken before the first exchange) against the signatures of all ranks' decoded
+    # shards -- a read lost, duplicated or altered anywhere between the slice and the streams (the all-to-all included) shows.
     dsig = h.decode_signature()
-    if sig_clean is not None:
-        want = (sig_clean[0] + sig_N[0], (sig_clean[1] + sig_N[1]) % (1 << 64), sig_clean[2] ^ sig_N[2])
-        roundtrip = {"ok": bool(dsig == want), "reads_decoded": dsig[0], "check": "multiset signature (sum, xor of 64-bit read hashes) of GPU-decoded streams == inputs"}
-    else:
-        want = h.input_signature()                                 # the shard this rank received through the all-to-all + its own N reads
-        roundtrip = {"ok": bool(dsig == want), "reads_decoded": dsig[0], "check": "multiset signature of GPU-decoded streams == this rank's shard (2-bit reads held by the library)"}
+    seq_bases_total, reads_total = int(c.seq_bases), n
     if dist is not None:
-        okt = torch.tensor([1 if roundtrip["ok"] else 0], device=dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        roundtrip["ok"] = bool(int(okt.item()))
+        dsig = multigpu.allreduce_signature(dist, dsig, dev)
+        sb = torch.tensor([int(c.seq_bases)], dtype=torch.int64, device=dev)
+        dist.all_reduce(sb)
+        seq_bases_total, reads_total = int(sb.item()), n * world
+    roundtrip = {"ok": bool(tuple(dsig) == tuple(sig_in)), "reads_decoded": int(dsig[0]), "reads_in": int(sig_in[0]),
+                 "check": "multiset signature (count, sum, xor of 64-bit read hashes) of the GPU-decoded streams of all ranks == the input reads of all ranks"}
     total_reads = n * world * args.steps
     value = total_reads / dt / 1e6
 
-    # roofline of the dominant kernel k_propose (DESIGN.md "Kernels"): algorithmic bytes of SURVEY.md 8(d)'s chain step
+    # roofline of the dominant kernel k_steps (DESIGN.md "Kernels"): algorithmic bytes of SURVEY.md 8(d)'s chain step
     #   49 B/read (removals 40 + claim 2 + outputs 7) + 16 B per dictionary lookup of a strictly sequential scan (L-bar, counted by
-    #   the kernel as `useful_probes`; the speculative lookups of the 64-lane batches are NOT counted) + 36 B per candidate (id + 32 B read)
-    alg_bytes = 49.0 * agg["steps_alg"] + 16.0 * agg["useful"] + 36.0 * agg["cands"]
+    #   the kernel as `useful_probes`) + 36 B per candidate that scan would test (C-bar, `candidates_seq`).  The speculative lookups and
+    #   candidates of the 64-lane batches are NOT counted; `candidates_per_read_speculative` shows them.
+    alg_bytes = 49.0 * agg["steps_alg"] + 16.0 * agg["useful"] + 36.0 * agg["cands_seq"]
     launches = max(1, agg["launches"])
     avg_ms = agg["propose_ms"] / launches
     achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -275,15 +336,17 @@ def main():
                 "avg_launch_us": round(avg_ms * 1e3, 2), "launches": launches,
                 "alg_bytes_per_launch": round(alg_bytes / launches, 1),
                 "Lbar_sequential_lookups_per_read": round(agg["useful"] / max(1, agg["steps_alg"]), 2),
+                "Cbar_sequential_candidates_per_read": round(agg["cands_seq"] / max(1, agg["steps_alg"]), 3),
                 "slots_inspected_per_read": round(agg["probes"] / max(1, agg["steps_alg"]), 2),
-                "candidates_per_read": round(agg["cands"] / max(1, agg["steps_alg"]), 3),
+                "candidates_per_read_speculative": round(agg["cands"] / max(1, agg["steps_alg"]), 3),
                 "Gslots_per_s": round(agg["probes"] / (agg["propose_ms"] * 1e-3) / 1e9, 2) if agg["propose_ms"] > 0 else None,
                 "note": "random-access regime: 16-B slots and 32-B reads fetched as >=64-B sectors; see DESIGN.md"}
     try:                                                          # HBM bytes per launch from the committed PMC passes of the same command
-        tr = json.load(open(os.path.join(ROOT, "profiles", "k_steps_traffic_r01.json"))).get(args.workload)
+        tr = json.load(open(os.path.join(ROOT, "profiles", "k_steps_traffic.json"))).get(args.workload)
         if tr and world == 1:
             roofline["traffic"] = round((tr["fetch_kb_per_launch"] + tr["write_kb_per_launch"]) * 1024.0, 1)
-            roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this command, profiles/k_steps_traffic_r01.json"
+            roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / max(1.0, roofline["alg_bytes_per_launch"]), 2)
+            roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this command, profiles/k_steps_traffic.json (" + tr.get("profile", "") + ")"
     except Exception:
         pass
     out = {
@@ -292,7 +355,9 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "u64 (2-bit packed bases, XOR+popcount)", "data": "synthetic",
         "config": {"workload": args.workload, "description": desc, "reads_per_gpu": n, "readlen": L, "genome_bp": G * world,
                    "error_rate": err, "chains_per_gpu": int(c.chains), "reads_per_chain": rpc or 2048, "encoder_shards_per_gpu": args.shards,
-                   "parallelism": "single GPU" if world == 1 else f"minimizer-bucket shard x{world}, one RCCL all-to-all"},
+                   "schedule": "throughput mode: deterministic K-chain x S-step schedule of DESIGN.md (lossless, == CPU oracle byte for byte; "
+                               "bytes differ from the reference's -t 1, which is num_chains = 1: see exact_mode)",
+                   "parallelism": "single GPU" if world == 1 else f"minimizer-bucket shard x{world}, one RCCL all-to-all (8W+4 B per read) inside every step"},
         "roofline": roofline,
         "roundtrip": roundtrip,
         "phases_ms_last_step": {"index": round(c.index_ms, 2), "chain": round(c.chain_ms, 2), "encode": round(c.encode_ms, 2)},
@@ -300,12 +365,69 @@ def main():
                                "rounds": int(c.rounds), "conflicts": int(c.conflicts), "contigs": int(c.contigs),
                                "seq_bases": int(c.seq_bases), "device_bytes_peak": int(c.device_bytes_peak)},
     }
-    if rank == 0 and world == 1 and not args.no_cpu:             # the CPU baseline is reported at N=1 only
-        ns = args.cpu_sample or min(n, 3_300_000 if err > 0 or G // max(1, n) < 10 else 1_000_000)
-        Gs = max(L * 4, int(G * (ns / n)))
-        out["cpu_baseline"] = cpu_baseline(ns, L, Gs, err, 999, dev)
     h.close()
+    del h
+    # ---- bounded side legs on rank 0 (outside the timed region): a sample of the same generator at the same coverage and error rate
+    if rank == 0 and not args.no_cpu:
+        ns = args.cpu_sample or min(n, 3_300_000 if err > 0 or G // max(1, n) < 10 else 1_000_000)
+        if spike:
+            Gs, sspike = G, spike                                 # repeat-spiked genomes are not scaled: same genome, fewer reads would change the coverage
+            ns = n
+        else:
+            Gs, sspike = max(L * 4, int(G * (ns / n))), None
+        sample = synth_reads(ns, L, Gs, err, 999, dev, sspike)
+        sdesc = f"{ns} reads of the same generator on a {Gs} bp genome (same coverage and error rate)"
+        if world > 1 or args.force_dist:
+            # the price of bucket sharding in compressed size: consensus bases of the sample compressed as `world` minimizer
+            # buckets, one after the other on this GPU with the sharded run's parameters, over the consensus bases of the same sample unsharded
+            nb = max(2, world)
+            h1, c1, _ = gpu_run_sample(harc_amd, sample, L, local, args.shards)
+            base1 = int(c1.seq_bases); h1.close()
+            hasN = (sample == ord("N")).any(1)
+            cl = sample[~hasN].contiguous()
+            pk = torch.empty((cl.shape[0], Wd), dtype=torch.int64, device=dev)
+            bk = torch.empty((cl.shape[0],), dtype=torch.int32, device=dev)
+            hb = harc_amd.HarcAmd(harc_amd.default_params(L, num_thr=args.shards, device=local, reads_per_chain=1024))
+            torch.cuda.synchronize()
+            hb.pack_reads_device(cl.data_ptr(), cl.shape[0], cl.stride(0), pk.data_ptr())
+            hb.bucket_reads_device(pk.data_ptr(), cl.shape[0], nb, bk.data_ptr())
+            sharded = 0
+            for b in range(nb):
+                sel = pk[bk == b].contiguous()
+                torch.cuda.synchronize()
+                hb.set_reads_packed_device(sel.data_ptr(), sel.shape[0])
+                hb.set_nreads_ascii_device(0, 0, L)
+                hb.reorder(); hb.encode()
+                sharded += int(hb.counters().seq_bases)
+            hb.close()
+            out["size_vs_1gpu"] = {"value": round(sharded / max(1, base1), 3), "unit": "consensus bases, bucket-sharded / unsharded",
+                                   "buckets": nb, "sample": sdesc + ", clean reads only",
+                                   "seq_bases_per_read_this_run": round(seq_bases_total / max(1, reads_total), 3)}
+            del pk, bk, cl
+        if world == 1:
+            sample_np = sample.cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(sample_np, L, sdesc)
+            # exact mode: num_chains = 1 is the reference at -t 1 byte for byte (tests/test_gpu_parity.py); its speed on a bounded sample
+            ne = min(ns, 200_000)
+            esample = synth_reads(ne, L, max(L * 4, int(Gs * (ne / ns))), err, 998, dev, None)
+            he, ce, dte = gpu_run_sample(harc_amd, esample, L, local, 1, num_chains=1)
+            out["exact_mode"] = {"value": round(ne / dte / 1e6, 4), "unit": "Mreads/s", "num_chains": 1, "num_thr": 1,
+                                 "sample": f"{ne} reads, same coverage; streams byte-identical to the reference at -t 1"}
+            he.close()
+            # compressed size against the reference's default (-t 8), xz -6 of every stage-II stream as the stand-in for bsc / 7z
+            refdir = os.path.join(ROOT, "oracle", "_ref")
+            nz = min(ns, 1_000_000)
+            if os.path.exists(os.path.join(refdir, f"reorder_L{L}_t8.out")):
+                zs = sample[:nz].contiguous() if sspike else synth_reads(nz, L, max(L * 4, int(Gs * (nz / ns))), err, 997, dev, None)
+                hz, cz, _ = gpu_run_sample(harc_amd, zs, L, local, 8)
+                ours = xz_size(stage2_blobs(hz, 8)); hz.close()
+                _, rf = run_reference(zs.cpu().numpy(), L, 8)
+                theirs = xz_size(list(rf.values()))
+                out["size_vs_reference_t8"] = {"value": round(ours / max(1, theirs), 4), "unit": "xz -6 bytes of all stage-II streams, this build (default schedule) / reference -t 8",
+                                               "ours_bytes": ours, "reference_bytes": theirs, "sample": f"{nz} reads, same coverage"}
+        del sample
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()

@@ -39,7 +39,7 @@ struct S1Args {
     const uint16_t *probe_tab;       // the probes of one chain step in priority order: shift | dir<<8 | dict<<9
     int nprobe;
     int nbatch, batch_end[12];       // probe batches: [0,batch_end[0]), [batch_end[0],batch_end[1]) ... each at most 64 wide
-    uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups
+    uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups, w sequential-equivalent candidates
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
 };
 #ifdef HARC_TIMING
@@ -48,7 +48,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { for (int o = 32; 
 #else
 #define TICK(k) do { } while (0)
 #endif
-enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_USEFUL = 5, ST_N = 8 };
+enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_USEFUL = 5, ST_CANDS_SEQ = 6, ST_N = 8 };
 
 // ------------------------------------------------------------------------------------------------ packing kernels
 // ASCII -> std::bitset<2L> words (reorder.cpp:184-209). One thread per (read, word).
@@ -461,7 +461,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
     }
     if (h.mode != 0) cons_store<W>(st, B0, L, lane);             // B0 now holds the rollback point of this super-round
 
-    uint32_t np = 0, nc = 0, nuse = 0;
+    uint32_t np = 0, nc = 0, nuse = 0, ncu = 0;       // ncu: candidates a strictly sequential scan (reorder.cpp:517-649) would have tested too
     int nst = 0; bool needseed = false;
 #ifdef HARC_TIMING
     unsigned long long tacc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; long long tlast = clock64();
@@ -494,6 +494,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
 #ifdef HARC_TIMING
             uint32_t it_slot = 0, it_scan = 0; tacc[8]++;
 #endif
+            uint32_t ncb = 0;                                             // candidates this lane tests in this batch
             bool big = false; uint32_t b_sst = 0, b_cnt = 0; uint64_t b_slot = 0;   // a bin too large for one lane: scanned by the whole wave below
             uint64_t mrd[W];
 #pragma unroll
@@ -570,7 +571,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                             bool own = false;                             // taken by this chain earlier in this super-round
                             for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
                             if (own) continue;
-                            seen++; nc++;
+                            seen++; nc++; ncb++;
                             int hd = 0;
 #pragma unroll
                             for (int w = 0; w < W; w++) {
@@ -645,7 +646,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                         const bool elig = un && (seen + rank < s.maxsearch);
                         int hd = 1 << 20;
                         if (elig) {
-                            hd = 0; nc++;
+                            hd = 0; nc++; ncu++;
 #pragma unroll
                             for (int w = 0; w < W; w++) {
                                 const uint64_t m = o_dir ? (lowmask_word(2 * L, w) & ~lowmask_word(2 * o_j, w)) : lowmask_word(2 * (L - o_j), w);
@@ -675,6 +676,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                 }
             }
             TICK(3);
+            if (lane <= winlane) ncu += ncb;                              // lanes behind the winner were speculation (winlane = 64: no hit, all count)
             if (found != HARC_NONE) {
                 nuse += (uint32_t)(base + winlane + 1);
                 lastp = base + winlane;
@@ -725,9 +727,9 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
     if (lane == 0) { for (int k = 0; k < 6; k++) atomicAdd(&s.dbg[k], tacc[k]); atomicAdd(&s.dbg[6], (unsigned long long)nst); atomicAdd(&s.dbg[7], 1ULL); for (int k = 6; k < 11; k++) atomicAdd(&s.dbg[k + 2], tacc[k]); }
 #endif
     if (nst > 0) cons_store<W>(st, B1, L, lane);
-    np = wave_sum_u32(np); nc = wave_sum_u32(nc);
+    np = wave_sum_u32(np); nc = wave_sum_u32(nc); ncu = wave_sum_u32(ncu);
     if (lane == 0) {
-        cst.x += np; cst.y += nc; cst.z += nuse; s.cstat[c] = cst;
+        cst.x += np; cst.y += nc; cst.z += nuse; cst.w += ncu; s.cstat[c] = cst;
         h.mode = 0;
         h.nsteps = (h.nsteps & 0xFFFF0000u) | (uint32_t)nst;
         h.pad0 = ((uint32_t)lastp & 0xFFFFu) | ((uint32_t)spos << 16);
@@ -931,15 +933,16 @@ __global__ __launch_bounds__(64) void k_compact_bins(S1Args s, const unsigned lo
 __global__ void k_chain_counts(const ChainHdr *hdr, const uint4 *cstat, const uint2 *cst2, uint32_t K, uint32_t *nmain, uint32_t *nsing, unsigned long long *stats)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t np = 0, nc = 0, nu = 0, um = 0, cf = 0;
-    if (c < K) { nmain[c] = hdr[c].n_main; nsing[c] = hdr[c].n_sing; const uint4 st = cstat[c]; np = st.x; nc = st.y; nu = st.z; const uint2 q = cst2[c]; um = q.x; cf = q.y; }
-    np = wave_sum_u32(np); nc = wave_sum_u32(nc); nu = wave_sum_u32(nu); um = wave_sum_u32(um); cf = wave_sum_u32(cf);
+    uint32_t np = 0, nc = 0, nu = 0, um = 0, cf = 0, ncs = 0;
+    if (c < K) { nmain[c] = hdr[c].n_main; nsing[c] = hdr[c].n_sing; const uint4 st = cstat[c]; np = st.x; nc = st.y; nu = st.z; ncs = st.w; const uint2 q = cst2[c]; um = q.x; cf = q.y; }
+    np = wave_sum_u32(np); nc = wave_sum_u32(nc); nu = wave_sum_u32(nu); um = wave_sum_u32(um); cf = wave_sum_u32(cf); ncs = wave_sum_u32(ncs);
     if ((threadIdx.x & 63) == 0) {
         if (um) atomicAdd(&stats[ST_UNMATCHED], (unsigned long long)um);
         if (cf) atomicAdd(&stats[ST_CONFLICTS], (unsigned long long)cf);
         if (np) atomicAdd(&stats[ST_PROBES], (unsigned long long)np);
         if (nc) atomicAdd(&stats[ST_CANDS], (unsigned long long)nc);
         if (nu) atomicAdd(&stats[ST_USEFUL], (unsigned long long)nu);
+        if (ncs) atomicAdd(&stats[ST_CANDS_SEQ], (unsigned long long)ncs);
     }
 }
 // per-chain streams concatenated in chain order (reorder.cpp:778-821)
@@ -1189,7 +1192,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (h_stats[ST_N - 1]) { harc_set_error("stage I bookkeeping: %llu reads were never emitted", h_stats[ST_N - 1]); return HARC_AMD_ENODEVICE; }
 
     c->C.n_main = M; c->C.n_singleton = S; c->C.unmatched = h_stats[ST_UNMATCHED]; c->C.conflicts = h_stats[ST_CONFLICTS];
-    c->C.probes = h_stats[ST_PROBES]; c->C.candidates = h_stats[ST_CANDS]; c->C.useful_probes = h_stats[ST_USEFUL]; c->C.rounds = rounds; c->C.propose_launches = launches;
+    c->C.probes = h_stats[ST_PROBES]; c->C.candidates = h_stats[ST_CANDS]; c->C.useful_probes = h_stats[ST_USEFUL]; c->C.candidates_seq = h_stats[ST_CANDS_SEQ]; c->C.rounds = rounds; c->C.propose_launches = launches;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1)); c->C.index_ms = ms;
     HIP_TRY(hipEventElapsedTime(&ms, e1, e2)); c->C.chain_ms = ms;

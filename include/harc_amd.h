@@ -83,6 +83,8 @@ typedef struct harc_amd_counters {
     uint64_t device_bytes_peak;
     uint64_t useful_probes;           /* dictionary keys a strictly sequential scan (reorder.cpp:517-649) would have looked up:
                                          priority index of the winning probe + 1, or all probes of the step on a miss */
+    uint64_t candidates_seq;          /* candidates that sequential scan would have fetched and Hamming-tested: those of the probes up to and
+                                         including the winning one (`candidates` also counts the speculative ones behind it) */
 } harc_amd_counters;
 
 /* stream ids for harc_amd_get_stream; names are the reference's file names */

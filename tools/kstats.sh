@@ -1,9 +1,10 @@
 #!/bin/bash
 # rocprofv3 kernel stats of one bench workload:  tools/kstats.sh <workload> [tag]   -> gpurun_out/<tag>/kstats_<workload>.txt
-WL=${1:-c2}; R=${2:-r01}
+WL=${1:-c3}; R=${2:-r02}; STEPS=${3:-2}
 mkdir -p gpurun_out/$R
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/rp_$WL -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu > gpurun_out/$R/kstats_${WL}_bench.json 2> gpurun_out/$R/kstats_$WL.err
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+cd /tmp && export TMPDIR=/tmp; cd "$ROOT"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/rp_$WL -- python3 bench.py --workload $WL --steps $STEPS --warmup 1 --no-cpu > gpurun_out/$R/kstats_${WL}_bench.json 2> gpurun_out/$R/kstats_$WL.err
 f=$(ls gpurun_out/$R/rp_$WL/*/*kernel_stats.csv | head -1)
 python3 - "$f" > gpurun_out/$R/kstats_$WL.txt <<PY
 import csv,sys

@@ -5,7 +5,8 @@ R=${1:-r01}
 mkdir -p gpurun_out/$R
 python bench.py --steps 5 --warmup 1 > gpurun_out/$R/bench_c2.json 2> gpurun_out/$R/bench_c2.err
 python bench.py --workload c3s --steps 3 --warmup 1 --no-cpu > gpurun_out/$R/bench_c3s.json 2> gpurun_out/$R/bench_c3s.err
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+cd /tmp && export TMPDIR=/tmp; cd "$ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/rocprof_c2 -- python3 bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/$R/rocprof_c2_bench.json 2> gpurun_out/$R/rocprof_c2.err
 f=$(ls gpurun_out/$R/rocprof_c2/*/*kernel_stats.csv | head -1)
 python3 - "$f" > gpurun_out/$R/rocprof_c2_kernel_stats.txt <<PY
