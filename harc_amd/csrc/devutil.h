@@ -9,6 +9,17 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
     return x;
 }
 
+// first slot of the 64-byte bucket (4 slots of 16 bytes) a key of a bucketed table hashes to.  32-bit arithmetic: the chain kernel is
+// bound by instruction issue, and a 64 x 64 -> 128 multiply chain per probe was a tenth of its instructions
+__device__ __forceinline__ uint64_t bucket_slot(uint64_t key, uint64_t cap)
+{
+    const uint64_t nb = cap >> 2;
+    if (nb >> 32) return __umul64hi(mix64(key), nb) << 2;        // more than 2^34 slots (256 GB): not on one GPU; kept exact
+    uint32_t h = ((uint32_t)key * 0x9E3779B1u) ^ __builtin_rotateleft32((uint32_t)(key >> 32) * 0x85EBCA77u, 16);
+    h ^= h >> 16; h *= 0x2C1B3C6Du;
+    return (uint64_t)__umulhi(h, (uint32_t)nb) << 2;
+}
+
 // a[idx] for a small register array and a lane-varying idx; out-of-range -> 0
 template <int W> __device__ __forceinline__ uint64_t sel0(const uint64_t (&a)[W], int idx)
 {

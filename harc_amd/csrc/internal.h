@@ -178,7 +178,7 @@ int stage1_run(harc_amd_ctx *c);
 int stage1_make_oriented(harc_amd_ctx *c);      // d_oreads from d_reads/d_order/d_rc
 int s1_orient(harc_amd_ctx *c, const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, uint64_t *out);
 // exact key->bin table over n keys (ids must hold 0..n-1 on entry); allocates d->slots / d->ids / d->d_nbins
-int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n);
+int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n, uint64_t cap_like);   // cap_like != 0: that many slots
 int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, uint32_t n, unsigned kbits);   // after harc_dict_alloc
 void harc_dict_free(harc_amd_ctx *c, DictDev *d);
 int stage2_run(harc_amd_ctx *c);

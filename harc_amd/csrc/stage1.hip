@@ -239,7 +239,7 @@ __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, cons
     if (cnt > SLOT_CNT_MASK) { atomicAdd(const_cast<uint32_t *>(nbins_p) + 1, 1u); return; }     // does not fit the count field: the build fails loudly
     const unsigned long long meta = cnt == 1 ? ((unsigned long long)sids[st] | ((unsigned long long)(1u | SLOT_EMB) << 32))
                                              : ((unsigned long long)st | ((unsigned long long)((cnt & SLOT_CNT_MASK) | ((bigthresh && cnt > bigthresh) ? SLOT_BIG : 0u)) << 32));
-    uint64_t sl = bucketed ? (__umul64hi(mix64(key), cap >> 2) << 2) : __umul64hi(mix64(key), cap);   // bucketed: start at a 64-B bucket of 4 slots
+    uint64_t sl = bucketed ? bucket_slot(key, cap) : __umul64hi(mix64(key), cap);   // bucketed: start at a 64-B bucket of 4 slots
     for (;;) {
         unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
         if (atomicCAS(mp, 0ULL, meta) == 0ULL) {
@@ -381,23 +381,162 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
 }
 
 // The dominant kernel.  One wave per chain, 4 chains per 256-thread workgroup.  Per step:
-//  (1) consensus -> packed words (ballots), reverse complement;
-//  (2) the probes of the step (reorder.cpp:517-649) are dealt to the lanes in priority order, in batches: key -> open-addressing
-//      slot -> bin scan from the highest unclaimed id (<= maxsearch of them) -> XOR+popcount Hamming on the packed words;
-//      the lowest lane with a hit is the step's read;
+//  (1) consensus -> packed words (ballots), reverse complement; both go to LDS, so that every lane can take the 64-bit key window and
+//      the 2L-bit Hamming window of ITS shift with a few unaligned dword reads + v_alignbit instead of select chains over registers;
+//  (2) the probes of the step (reorder.cpp:517-649) are dealt to the lanes in priority order, in batches: key -> bucketed open-addressing
+//      table -> bin scan from the highest unclaimed id (<= maxsearch of them) -> XOR+popcount Hamming on the packed words against the
+//      precomputed mask row of (direction, shift); the lowest lane with a hit is the step's read;
 //  (3) lane 0 records the step and bids for the read with atomicMin(step<<20 | chain); the counts are updated in registers.
+// The kernel is bound by instruction issue at large K (PMC: 85 % of the SIMD issue slots, profiles/r02) and by dependent HBM round
+// trips at small K: both want few instructions per step.
 #ifndef HARC_BIGBIN
 #define HARC_BIGBIN 4u      // bins with more reads than this are scanned by the whole wave
 #endif
 #ifndef HARC_STEPS_WAVES
-#define HARC_STEPS_WAVES 4       // many chains: 4 waves / SIMD (128 VGPRs, a few spills)
+#define HARC_STEPS_WAVES 4       // many chains: 4 waves / SIMD (128 VGPRs)
 #endif
 #ifndef HARC_STEPS_WAVES_Q
-#define HARC_STEPS_WAVES_Q 3     // few chains (bucketed table): never more than ~3 waves / SIMD anyway -> 144 VGPRs, nothing in scratch
+#define HARC_STEPS_WAVES_Q 3     // few chains (whole-bucket fetch): never more than ~3 waves / SIMD anyway
 #endif
+// LDS geometry of k_steps (dwords).  A packed read is NW = 2W dwords.  Window rows: [NW dwords before][NW dwords of the word][NW + 1 after]
+// -- what lies outside the word is never zeroed, the mask row of (direction, shift) removes it.
+template <int W> struct StepsLds {
+    static constexpr int NW = 2 * W;
+    static constexpr int ROW = 3 * NW + 1;
+    static constexpr int MROW = (NW + 3) & ~3;                   // mask rows are 16-byte aligned
+};
+static inline size_t steps_lds_bytes(int W, int maxmatch, int nprobe)
+{
+    const int NW = 2 * W, ROW = 3 * NW + 1, MROW = (NW + 3) & ~3;
+    return ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)2 * nprobe + 8) * 4;
+}
+// Hamming distance between a candidate read (registers) and the consensus shifted by the lane's own amount: `row` = ref or rref window
+// row in LDS, bitoff = 32 NW +- 2j, mrow = mask row of (direction, shift) (reorder.cpp:543,608 with mask[j] / revmask[j] of :706-718)
+template <int W> __device__ __forceinline__ int ham_window(const uint32_t *row, int bitoff, const uint32_t *mrow, const uint32_t (&rd)[2 * W])
+{
+    constexpr int NW = 2 * W;
+    const int i0 = bitoff >> 5, sh = bitoff & 31;
+    uint32_t d[NW + 1];
+#pragma unroll
+    for (int k = 0; k <= NW; k++) d[k] = row[i0 + k];
+    int hd = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) hd += __popc((__builtin_amdgcn_alignbit(d[k + 1], d[k], sh) ^ rd[k]) & mrow[k]);
+    return hd;
+}
+template <int W> __device__ __forceinline__ void load_read32(const uint64_t *reads, uint32_t rid, uint32_t (&rd)[2 * W])
+{
+    if (W % 2 == 0) {                                            // 16 W bytes per read: 16-byte aligned rows
+        const uint4 *p = reinterpret_cast<const uint4 *>(reads + (size_t)rid * W);
+#pragma unroll
+        for (int q = 0; q < W / 2; q++) { const uint4 v = p[q]; rd[4 * q] = v.x; rd[4 * q + 1] = v.y; rd[4 * q + 2] = v.z; rd[4 * q + 3] = v.w; }
+    } else {
+        const uint2 *p = reinterpret_cast<const uint2 *>(reads + (size_t)rid * W);
+#pragma unroll
+        for (int q = 0; q < W; q++) { const uint2 v = p[q]; rd[2 * q] = v.x; rd[2 * q + 1] = v.y; }
+    }
+}
+// updaterefcount (reorder.cpp:884-909) with the accepted read's dwords in LDS (rdl): every lane picks the bases of its own columns
+template <int W> __device__ __forceinline__ void cons_update_lds(ConsState<W> &st, const uint32_t *rdl, int L, int rev, int shift, int lane)
+{
+    constexpr int LP = ConsState<W>::LP;
+    int nb = st.base + shift; if (nb >= LP) nb -= LP;
+#pragma unroll
+    for (int t = 0; t < ConsState<W>::CT; t++) {
+        const int p = lane + 64 * t;
+        int oldl = p - st.base; if (oldl < 0) oldl += LP;
+        int newl = p - nb; if (newl < 0) newl += LP;
+        uint4 q = st.q[t]; int v = 0;
+        if (newl < L) {
+            const int sc = rev ? (L - 1 - newl) : newl;
+            const int pc = (int)((rdl[sc >> 4] >> (2 * (sc & 15))) & 3u);
+            int b = ((pc & 1) << 1) | (pc >> 1);                 // packed code A0 G1 C2 T3 -> count row A0 C1 G2 T3
+            if (rev) b = 3 - b;
+            if (oldl < L && oldl >= shift) { q.x += (b == 0); q.y += (b == 1); q.z += (b == 2); q.w += (b == 3); v = argmax4(q); }
+            else { q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3); v = b; }
+        } else q = make_uint4(0, 0, 0, 0);
+        st.q[t] = q; st.v[t] = v;
+    }
+    st.base = nb;
+}
+template <int W> __device__ __forceinline__ void cons_reset_lds(ConsState<W> &st, const uint32_t *rdl, int L, int lane)
+{
+    st.base = 0;
+#pragma unroll
+    for (int t = 0; t < ConsState<W>::CT; t++) {
+        const int i = lane + 64 * t;
+        int b = 0; uint4 q = make_uint4(0, 0, 0, 0);
+        if (i < L) {
+            const int pc = (int)((rdl[i >> 4] >> (2 * (i & 15))) & 3u);
+            b = ((pc & 1) << 1) | (pc >> 1);
+            q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3);
+        }
+        st.q[t] = q; st.v[t] = b;
+    }
+}
+
+// consensus -> the wave's window rows in LDS: rowF = packed consensus (reorder.cpp `ref`), rowR = its reverse complement (`revref`).
+// Every lane drops the 2-bit codes of its ring slots as bytes at their column (and, complemented, at the mirrored column); 2 NW lanes
+// then squeeze 16 bytes into one dword each.  (The ballot + bit-spread formulation cost 380 vector instructions per step.)
+template <int W> __device__ __forceinline__ void cons_rows(const ConsState<W> &st, int L, int lane, uint8_t *tmp, uint32_t *rowF, uint32_t *rowR)
+{
+    constexpr int CT = ConsState<W>::CT, LP = ConsState<W>::LP, NW = 2 * W;
+#pragma unroll
+    for (int t = 0; t < CT; t++) {
+        int l = lane + 64 * t - st.base; if (l < 0) l += LP;
+        if (l < L) {
+            const int v = st.v[t];
+            const int pc = ((v & 1) << 1) | (v >> 1);              // count row A0 C1 G2 T3 -> packed code A0 G1 C2 T3
+            tmp[l] = (uint8_t)pc;
+            tmp[16 * NW + (L - 1 - l)] = (uint8_t)(3 - pc);        // complement of the packed code is 3 - code
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 2 * NW) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(tmp + 16 * lane);
+        auto pk = [](uint32_t b) -> uint32_t { b = (b | (b >> 6)) & 0x000F000Fu; return (b | (b >> 12)) & 0xFFu; };   // 4 bytes of 2 bits -> 8 bits
+        const uint32_t d = pk(x.x) | (pk(x.y) << 8) | (pk(x.z) << 16) | (pk(x.w) << 24);
+        (lane < NW ? rowF + NW + lane : rowR + lane)[0] = d;       // rowR + NW + (lane - NW)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_WAVES_Q : HARC_STEPS_WAVES) void k_steps(S1Args s)
 {
+    constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
+    extern __shared__ uint32_t lds[];
+    // [mask rows: (dir, shift) -> NW dwords][window rows: 4 waves x {ref, rref}][accepted read: 4 waves][column bytes: 4 waves x 2 x 16 NW][probes]
+    uint32_t *const s_mask = lds;
+    uint32_t *const s_rows = s_mask + (size_t)2 * s.maxmatch * MROW;
+    uint32_t *const s_rdl = s_rows + 4 * 2 * ROW;
+    uint32_t *const s_tmp = s_rdl + 4 * MROW;
+    uint2 *const s_pinfo = reinterpret_cast<uint2 *>(s_tmp + 4 * 8 * NW);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int L = s.L;
+    {   // the whole workgroup, before any wave leaves: mask[j] keeps the low 2(L-j) bits, revmask[j] the bits >= 2j below 2L (reorder.cpp:706-718)
+        for (int i = threadIdx.x; i < 2 * s.maxmatch * MROW; i += 256) {
+            const int k = i % MROW, r = i / MROW, dir = r / s.maxmatch, j = r % s.maxmatch;
+            const int lo = dir ? 2 * j : 0, hi = dir ? 2 * L : 2 * (L - j);      // bits [lo, hi)
+            const int a = lo - 32 * k, b = hi - 32 * k;
+            const uint32_t mh = b >= 32 ? 0xFFFFFFFFu : (b <= 0 ? 0u : ((1u << b) - 1u)), ml = a >= 32 ? 0xFFFFFFFFu : (a <= 0 ? 0u : ((1u << a) - 1u));
+            s_mask[i] = k < NW ? (mh & ~ml) : 0u;
+        }
+        // probe p of a step (reorder.cpp:517-649 order): x = bit offset of its key window inside the wave's two rows | dir << 13 | dict << 14
+        // | shift << 16;  y = bit offset of its Hamming window | dword offset of its mask row << 16
+        for (int i = threadIdx.x; i < s.nprobe; i += 256) {
+            const uint32_t e = s.probe_tab[i];
+            const int j = (int)(e & 0xFF), dir = (int)((e >> 8) & 1), l = (int)((e >> 9) & 1);
+            const int koff = dir * ROW * 32 + 32 * NW + (dir ? 2 * (s.ds[l] - j) : 2 * (s.ds[l] + j));
+            const int hoff = dir * ROW * 32 + 32 * NW + (dir ? -2 * j : 2 * j);      // the consensus is shifted by 2j bits (reorder.cpp:647-648)
+            s_pinfo[i] = make_uint2((uint32_t)koff | ((uint32_t)dir << 13) | ((uint32_t)l << 14) | ((uint32_t)j << 16),
+                                    (uint32_t)hoff | ((uint32_t)((dir * s.maxmatch + j) * MROW) << 16));
+        }
+        for (int i = threadIdx.x; i < 4 * 2 * ROW; i += 256) s_rows[i] = 0u;
+        for (int i = threadIdx.x; i < 4 * 8 * NW; i += 256) s_tmp[i] = 0u;
+        __syncthreads();
+    }
     uint32_t ownreg = HARC_NONE;                                 // lane t: the read this chain took at step t of this super-round
     const uint32_t c = blockIdx.x * 4 + wv;
     if (c >= s.K) return;
@@ -425,7 +564,6 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
             return;
         }
     }
-    const int L = s.L;
     constexpr int LP = ConsState<W>::LP;
     const uint32_t par = (h.flags & CH_PARITY) ? 1u : 0u;
     uint4 *B0 = s.cnt + ((size_t)par * s.K + c) * LP;            // state at the start of this super-round (rollback point)
@@ -461,23 +599,17 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
     }
     if (h.mode != 0) cons_store<W>(st, B0, L, lane);             // B0 now holds the rollback point of this super-round
 
-    uint32_t np = 0, nc = 0, nuse = 0, ncu = 0;       // ncu: candidates a strictly sequential scan (reorder.cpp:517-649) would have tested too
+    uint32_t *const rowF = s_rows + (size_t)wv * 2 * ROW, *const rowR = rowF + ROW, *const rdl = s_rdl + (size_t)wv * MROW;
+    uint8_t *const coltmp = reinterpret_cast<uint8_t *>(s_tmp + (size_t)wv * 8 * NW);
+    const uint64_t kmask0 = s.kbits[0] < 64 ? (((uint64_t)1 << s.kbits[0]) - 1) : ~(uint64_t)0, kmask1 = s.kbits[1] < 64 ? (((uint64_t)1 << s.kbits[1]) - 1) : ~(uint64_t)0;
+    const uint64_t cap = s.cap[0];                               // both dictionaries have the same geometry (stage1_run_w)
+    uint32_t np = 0, nc = 0, nuse = 0, ncu = 0;                   // ncu: candidates a strictly sequential scan (reorder.cpp:517-649) would have tested too
     int nst = 0; bool needseed = false;
-#ifdef HARC_TIMING
-    unsigned long long tacc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; long long tlast = clock64();
-#endif
     int lastp = (int)(h.pad0 & 0xFFFF);                          // priority index of this chain's previous hit
     int spos = (int)((h.nsteps >> 16) & 0xFF); const int nsugg = (int)(h.nsteps >> 24);   // look-ahead seeds: next to try / held
     for (int t = 0; t < s.S; t++) {
-        uint64_t ref[W], rref[W];
-        TICK(0);
-        cons_pack<W>(st, L, lane, ref);
-        rc_words<W>(ref, L, rref);
-        TICK(1);
+        cons_rows<W>(st, L, lane, coltmp, rowF, rowR);            // consensus and its reverse complement -> the wave's window rows
         uint32_t found = HARC_NONE; int fj = 0, fdir = 0;
-        uint64_t frd[W];
-#pragma unroll
-        for (int w = 0; w < W; w++) frd[w] = 0;
         // Probes are issued in priority order in batches: every probe behind the first hit of a batch is speculative traffic,
         // every extra batch is a serial round trip to HBM.
         int base = 0;
@@ -491,102 +623,79 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
             if (bend <= base) bend = s.nprobe;
             const int p = base + lane;
             uint32_t mine = HARC_NONE; int j = 0, dir = 0, l = 0;
-#ifdef HARC_TIMING
-            uint32_t it_slot = 0, it_scan = 0; tacc[8]++;
-#endif
             uint32_t ncb = 0;                                             // candidates this lane tests in this batch
             bool big = false; uint32_t b_sst = 0, b_cnt = 0; uint64_t b_slot = 0;   // a bin too large for one lane: scanned by the whole wave below
-            uint64_t mrd[W];
+            uint32_t mrd[NW];
 #pragma unroll
-            for (int w = 0; w < W; w++) mrd[w] = 0;
-            if (p < bend) {
-                const uint32_t e = s.probe_tab[p];
-                j = (int)(e & 0xFF); dir = (int)((e >> 8) & 1);
-                l = (int)((e >> 9) & 1);
-                const int off = dir ? 2 * (s.ds[l] - j) : 2 * (s.ds[l] + j);
+            for (int k = 0; k < NW; k++) mrd[k] = 0;
+            if (p < bend && cap) {
+                const uint2 pi = s_pinfo[p];
+                j = (int)(pi.x >> 16); dir = (int)((pi.x >> 13) & 1);
+                l = (int)((pi.x >> 14) & 1);
                 uint64_t key;
-                {   // key = kbits bits of the (reverse) consensus at bit `off`
-                    const int wi = off >> 6, shb = off & 63;
-                    const uint64_t lo = dir ? sel0<W>(rref, wi) : sel0<W>(ref, wi), hi = dir ? sel0<W>(rref, wi + 1) : sel0<W>(ref, wi + 1);
-                    key = shb ? ((lo >> shb) | (hi << (64 - shb))) : lo;
-                    if (s.kbits[l] < 64) key &= ((uint64_t)1 << s.kbits[l]) - 1;
+                {   // key = kbits bits of the (reverse) consensus at bit 2 (ds +- j)
+                    const int i0 = (int)((pi.x & 0x1FFF) >> 5), shb = (int)(pi.x & 31);
+                    const uint32_t d0 = rowF[i0], d1 = rowF[i0 + 1], d2 = rowF[i0 + 2];
+                    key = ((uint64_t)__builtin_amdgcn_alignbit(d1, d0, shb) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, shb) << 32)) & (l ? kmask1 : kmask0);
                 }
-                const uint64_t cap = s.cap[l];
-                HashSlot *tab = s.slots[l];
-                const uint32_t *ids = s.ids[l];
-                if (cap) {
-                    // The table is bucketed (64 B = 4 slots).  QUAD (few chains, latency-bound): the whole bucket in one round trip; otherwise
-                    // (many chains, 128 VGPRs) two slots at a time -- the second pair is the same 64-B sector.  A full bucket ends the
-                    // search unless its overflow flag says that keys went on to the next one.
-                    // phase 1: every lane finishes its slot search (the dependent bucket fetches of all lanes overlap) ...
-                    uint64_t sl = __umul64hi(mix64(key), cap >> 2) << 2;
-                    int state = 0, qhit = 0;                                  // 1 = the key is not in the table, 2 = key found
-                    uint32_t sst = 0, cw = 0;
-                    for (;;) {
-                        constexpr int NQ = QUAD ? 4 : 2;
-                        uint32_t w0 = 0;
+                HashSlot *const tab = l ? s.slots[1] : s.slots[0];
+                // The table is bucketed (64 B = 4 slots).  QUAD (few chains, latency-bound): the whole bucket in one round trip; otherwise
+                // (many chains) two slots at a time -- the second pair is the same 64-B sector.  A full bucket ends the
+                // search unless its overflow flag says that keys went on to the next one.
+                // phase 1: every lane finishes its slot search (the dependent bucket fetches of all lanes overlap) ...
+                uint64_t sl = bucket_slot(key, cap);
+                int state = 0, qhit = 0;                                  // 1 = the key is not in the table, 2 = key found
+                uint32_t sst = 0, cw = 0;
+                for (;;) {
+                    constexpr int NQ = QUAD ? 4 : 2;
+                    uint32_t w0 = 0;
 #pragma unroll
-                        for (int hp = 0; hp < 4 / NQ; hp++) {
-                            if (state == 0) {
-                                uint4 rawq[NQ];
+                    for (int hp = 0; hp < 4 / NQ; hp++) {
+                        if (state == 0) {
+                            uint4 rawq[NQ];
 #pragma unroll
-                                for (int q = 0; q < NQ; q++) rawq[q] = *reinterpret_cast<const uint4 *>(&tab[sl + hp * NQ + q]);
-                                if (hp == 0) w0 = rawq[0].w;
+                            for (int q = 0; q < NQ; q++) rawq[q] = *reinterpret_cast<const uint4 *>(&tab[sl + hp * NQ + q]);
+                            if (hp == 0) w0 = rawq[0].w;
 #pragma unroll
-                                for (int q = 0; q < NQ; q++) {
-                                    if (state == 0) {
-                                        np++;
-                                        if (rawq[q].w == 0) state = 1;
-                                        else if (((uint64_t)rawq[q].x | ((uint64_t)rawq[q].y << 32)) == key) { state = 2; qhit = hp * NQ + q; sst = rawq[q].z; cw = rawq[q].w; }
-                                    }
+                            for (int q = 0; q < NQ; q++) {
+                                if (state == 0) {
+                                    np++;
+                                    if (rawq[q].w == 0) state = 1;
+                                    else if (rawq[q].x == (uint32_t)key && rawq[q].y == (uint32_t)(key >> 32)) { state = 2; qhit = hp * NQ + q; sst = rawq[q].z; cw = rawq[q].w; }
                                 }
                             }
                         }
-                        if (state == 0 && !(w0 & SLOT_OVF)) state = 1;
-                        if (state) break;
-                        sl += 4; if (sl >= cap) sl = 0;
                     }
-                    // ... phase 2: the lanes that found their key scan their bins together
-                    {
-                        if (state == 2 && !(cw & SLOT_DEAD) && (cw & SLOT_CNT_MASK) > HARC_BIGBIN && !(cw & SLOT_EMB)) {
-                            big = true; b_sst = sst; b_cnt = cw & (SLOT_CNT_MASK | SLOT_OVF); b_slot = sl + qhit;
-                        } else
-                        if (state == 2 && !(cw & SLOT_DEAD)) {                // SLOT_DEAD: every read of this bin is already claimed
-                        const int nb = 2 * (L - j);
-                        const int sws = (2 * j) >> 6, sbs = (2 * j) & 63;     // the consensus is shifted by 2j bits (reorder.cpp:647-648)
-                        const uint32_t cntb = cw & SLOT_CNT_MASK;
-                        const bool emb = (cw & SLOT_EMB) != 0;            // single-read bin: `start` IS the read id
-                        int seen = 0; uint32_t lead = 0; bool alltop = true;
-                        for (uint32_t i = cntb; i > 0 && seen < s.maxsearch; i--) {
-#ifdef HARC_TIMING
-                            it_scan++;
-#endif
+                    if (state == 0 && !(w0 & SLOT_OVF)) state = 1;
+                    if (state) break;
+                    sl += 4; if (sl >= cap) sl = 0;
+                }
+                // ... phase 2: the lanes that found their key scan their bins together
+                if (state == 2 && !(cw & SLOT_DEAD)) {                    // SLOT_DEAD: every read of this bin is already claimed
+                    const uint32_t cntb = cw & SLOT_CNT_MASK;
+                    const bool emb = (cw & SLOT_EMB) != 0;                // single-read bin: `start` IS the read id
+                    // the lane-serial scan below never closes the maxsearch window (reorder.cpp:540) -- its bins are no larger than that
+                    const uint32_t bigthr = (uint32_t)s.maxsearch < HARC_BIGBIN ? (uint32_t)s.maxsearch : HARC_BIGBIN;
+                    if (cntb > bigthr && !emb) { big = true; b_sst = sst; b_cnt = cw & (SLOT_CNT_MASK | SLOT_OVF); b_slot = sl + qhit; }
+                    else {
+                        const uint32_t *const ids = l ? s.ids[1] : s.ids[0];
+                        const uint32_t *const mrow = s_mask + (pi.y >> 16);
+                        const int bitoff = (int)(pi.y & 0xFFFF);
+                        uint32_t lead = 0; bool alltop = true;
+                        for (uint32_t i = cntb; i > 0; i--) {
                             const uint32_t rid = emb ? sst : ids[sst + i - 1];
                             // claim bit and read words are fetched together (one dependent hop instead of two)
                             const unsigned long long cwd = s.claimed[rid >> 6];
-#pragma unroll
-                            for (int w = 0; w < W; w++) mrd[w] = s.reads[(size_t)rid * W + w];
+                            load_read32<W>(s.reads, rid, mrd);
                             if ((cwd >> (rid & 63)) & 1ULL) { if (alltop) lead++; continue; }
                             alltop = false;
-                            bool own = false;                             // taken by this chain earlier in this super-round
-                            for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
+                            const int hd = ham_window<W>(rowF, bitoff, mrow, mrd);
+                            // taken by this chain earlier in this super-round? (not in the frozen bitmap).  Such a read is not a candidate at
+                            // all (it does not count); asked only when the distance would accept it
+                            bool own = false;
+                            if (hd <= s.thresh) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
                             if (own) continue;
-                            seen++; nc++; ncb++;
-                            int hd = 0;
-#pragma unroll
-                            for (int w = 0; w < W; w++) {
-                                uint64_t shw, m;
-                                if (dir) {                                // reverse: (revref << 2j), bits >= 2j below 2L (revmask[j], :714-715)
-                                    const uint64_t hi = sel0<W>(rref, w - sws), lo = sel0<W>(rref, w - sws - 1);
-                                    shw = sbs ? ((hi << sbs) | (lo >> (64 - sbs))) : hi;
-                                    m = lowmask_word(2 * L, w) & ~lowmask_word(2 * j, w);
-                                } else {                                  // forward: (ref >> 2j), low 2(L-j) bits (mask[j], :712-713)
-                                    const uint64_t lo = sel0<W>(ref, w + sws), hi = sel0<W>(ref, w + sws + 1);
-                                    shw = sbs ? ((lo >> sbs) | (hi << (64 - sbs))) : lo;
-                                    m = lowmask_word(nb, w);
-                                }
-                                hd += __popcll((shw ^ mrd[w]) & m);
-                            }
+                            nc++; ncb++;
                             if (hd <= s.thresh) { mine = rid; break; }
                         }
                         // hints only (the claim bitmap stays the truth): claimed reads at the top of a bin are never looked at again
@@ -594,23 +703,20 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                             uint32_t *cp = reinterpret_cast<uint32_t *>(&tab[sl + qhit]) + 3;
                             if (lead == cntb) atomicOr(cp, SLOT_DEAD); else if (!emb) atomicMin(cp, (cntb - lead) | (cw & SLOT_OVF));
                         }
-                        }
                     }
                 }
             }
-            TICK(2);
-#ifdef HARC_TIMING
-            tacc[6] += wave_max_u32(it_slot); tacc[7] += wave_max_u32(it_scan); tacc[9] += wave_sum_u32(it_scan); tacc[10] += (unsigned long long)__popcll(__ballot(p < bend));
-#endif
             // ---- the best hit of the lanes that scanned their (small) bins themselves
             int winlane = 64;
             {
                 const unsigned long long msmall = __ballot(mine != HARC_NONE);
                 if (msmall) {
                     winlane = __ffsll((long long)msmall) - 1;
-                    found = __shfl(mine, winlane, 64); fj = __shfl(j, winlane, 64); fdir = __shfl(dir, winlane, 64);
+                    found = (uint32_t)__builtin_amdgcn_readlane((int)mine, winlane); fj = __builtin_amdgcn_readlane(j, winlane); fdir = __builtin_amdgcn_readlane(dir, winlane);
+                    if (lane == winlane) {
 #pragma unroll
-                    for (int w = 0; w < W; w++) frd[w] = shfl_u64(mrd[w], winlane);
+                        for (int k = 0; k < NW; k++) rdl[k] = mrd[k];
+                    }
                 }
             }
             // ---- big bins (low-complexity k-mers, repeats): the whole wave scans the bin, 64 candidates per round trip, in the same
@@ -621,12 +727,13 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                 while (bigm) {
                     const int bl = __ffsll((long long)bigm) - 1;
                     bigm &= bigm - 1;
-                    const uint32_t o_sst = __shfl(b_sst, bl, 64), o_raw = __shfl(b_cnt, bl, 64), o_cnt = o_raw & SLOT_CNT_MASK;
-                    const int o_j = __shfl(j, bl, 64), o_dir = __shfl(dir, bl, 64), o_l = __shfl(l, bl, 64);
+                    const uint32_t o_sst = (uint32_t)__builtin_amdgcn_readlane((int)b_sst, bl), o_raw = (uint32_t)__builtin_amdgcn_readlane((int)b_cnt, bl), o_cnt = o_raw & SLOT_CNT_MASK;
+                    const int o_j = __builtin_amdgcn_readlane(j, bl), o_dir = __builtin_amdgcn_readlane(dir, bl), o_l = __builtin_amdgcn_readlane(l, bl);
                     const uint64_t o_slot = shfl_u64(b_slot, bl);
                     const uint32_t *oids = s.ids[o_l];
-                    uint64_t osh[W];
-                    if (o_dir) shl_words<W>(rref, 2 * o_j, osh); else shr_words<W>(ref, 2 * o_j, osh);
+                    const uint32_t *const orow = o_dir ? rowR : rowF;
+                    const uint32_t *const omrow = s_mask + (size_t)(o_dir * s.maxmatch + o_j) * MROW;
+                    const int obit = 32 * NW + (o_dir ? -2 * o_j : 2 * o_j);
                     int seen = 0; uint32_t pos = o_cnt, lead = 0; bool alltop = true, bighit = false;
                     while (pos > 0 && seen < s.maxsearch) {
                         const bool valid = (uint32_t)lane < pos;
@@ -634,8 +741,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                         if (valid) {
                             rid = oids[o_sst + pos - 1 - lane];
                             const unsigned long long cwd = s.claimed[rid >> 6];
-#pragma unroll
-                            for (int w = 0; w < W; w++) mrd[w] = s.reads[(size_t)rid * W + w];     // mrd is free: the small winner is already in frd
+                            load_read32<W>(s.reads, rid, mrd);                 // mrd is free: the small winner is already in LDS
                             clm = ((cwd >> (rid & 63)) & 1ULL) != 0;
                         }
                         bool own = false;
@@ -645,14 +751,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                         const int rank = __popcll(um & ((1ULL << lane) - 1ULL));
                         const bool elig = un && (seen + rank < s.maxsearch);
                         int hd = 1 << 20;
-                        if (elig) {
-                            hd = 0; nc++; ncu++;
-#pragma unroll
-                            for (int w = 0; w < W; w++) {
-                                const uint64_t m = o_dir ? (lowmask_word(2 * L, w) & ~lowmask_word(2 * o_j, w)) : lowmask_word(2 * (L - o_j), w);
-                                hd += __popcll((osh[w] ^ mrd[w]) & m);
-                            }
-                        }
+                        if (elig) { nc++; ncu++; hd = ham_window<W>(orow, obit, omrow, mrd); }
                         const unsigned long long pm = __ballot(elig && hd <= s.thresh);
                         if (alltop) {
                             const unsigned long long cm = __ballot(valid && clm), vm = __ballot(valid);
@@ -660,9 +759,11 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                         }
                         if (pm) {
                             const int wl = __ffsll((long long)pm) - 1;
-                            found = __shfl(rid, wl, 64); fj = o_j; fdir = o_dir; winlane = bl; bighit = true;
+                            found = (uint32_t)__builtin_amdgcn_readlane((int)rid, wl); fj = o_j; fdir = o_dir; winlane = bl; bighit = true;
+                            if (lane == wl) {
 #pragma unroll
-                            for (int w = 0; w < W; w++) frd[w] = shfl_u64(mrd[w], wl);
+                                for (int k = 0; k < NW; k++) rdl[k] = mrd[k];
+                            }
                             break;
                         }
                         seen += __popcll(um);
@@ -675,7 +776,6 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                     if (bighit) break;
                 }
             }
-            TICK(3);
             if (lane <= winlane) ncu += ncb;                              // lanes behind the winner were speculation (winlane = 64: no hit, all count)
             if (found != HARC_NONE) {
                 nuse += (uint32_t)(base + winlane + 1);
@@ -706,10 +806,10 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                 atomicMin(&s.bid[sid], ((uint32_t)t << 20) | c);
             }
             if (lane == t) ownreg = sid;
-            uint64_t rw[W];
-#pragma unroll
-            for (int w = 0; w < W; w++) rw[w] = s.reads[(size_t)sid * W + w];
-            cons_reset<W>(st, rw, L, lane);
+            if (lane < NW) { const uint32_t *rp = reinterpret_cast<const uint32_t *>(s.reads + (size_t)sid * W); rdl[lane] = rp[lane]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cons_reset_lds<W>(st, rdl, L, lane);
             nst++;
             continue;
         }
@@ -718,14 +818,11 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
             atomicMin(&s.bid[found], ((uint32_t)t << 20) | c);
         }
         if (lane == t) ownreg = found;
-        TICK(4);
-        cons_update<W>(st, frd, L, fdir, fj, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cons_update_lds<W>(st, rdl, L, fdir, fj, lane);
         nst++;
-        TICK(5);
     }
-#ifdef HARC_TIMING
-    if (lane == 0) { for (int k = 0; k < 6; k++) atomicAdd(&s.dbg[k], tacc[k]); atomicAdd(&s.dbg[6], (unsigned long long)nst); atomicAdd(&s.dbg[7], 1ULL); for (int k = 6; k < 11; k++) atomicAdd(&s.dbg[k + 2], tacc[k]); }
-#endif
     if (nst > 0) cons_store<W>(st, B1, L, lane);
     np = wave_sum_u32(np); nc = wave_sum_u32(nc); ncu = wave_sum_u32(ncu);
     if (lane == 0) {
@@ -978,11 +1075,12 @@ template <int W> __global__ void k_orient(const uint64_t *reads, const uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n)
+int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n, uint64_t cap_like)
 {
     d->cap = 0; d->slots = nullptr; d->ids = nullptr; d->d_nbins = nullptr;
     if (n == 0) return HARC_AMD_OK;
-    {   // load factor 1/4 when HBM allows (fewer dependent re-probes: the chain kernel is latency-bound), else 1/3, else 1/2
+    if (cap_like) d->cap = cap_like;                              // same geometry as a sibling table (k_steps addresses both dictionaries alike)
+    else {   // load factor 1/4 when HBM allows (fewer dependent re-probes: the chain kernel is latency-bound), else 1/3, else 1/2
         unsigned long long m = 4;
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) { fr += c->pool_total; while (m > 2 && (double)m * n * sizeof(HashSlot) > 0.2 * (double)fr) m--; }
@@ -1071,7 +1169,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     unsigned long long *d_large = nullptr; unsigned int *d_nlarge = nullptr;
     const uint32_t maxlarge = 2 * (N / HARC_LARGEBIN) + 16;
     if (N) {
-        RC_TRY(harc_dict_alloc(c, &dict[0], N)); RC_TRY(harc_dict_alloc(c, &dict[1], N));
+        RC_TRY(harc_dict_alloc(c, &dict[0], N, 0)); RC_TRY(harc_dict_alloc(c, &dict[1], N, dict[0].cap));
         dict[0].bucketed = dict[1].bucketed = true;
         RC_TRY(dalloc(c, &d_large, maxlarge)); RC_TRY(dalloc(c, &d_nlarge, 4));
         HIP_TRY(hipMemsetAsync(d_nlarge, 0, 16, c->stream));
@@ -1141,6 +1239,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     HIP_TRY(hipGetLastError());
 
     // ---- rounds
+    const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe);
     unsigned long long *h_stats = nullptr;
     HIP_TRY(hipHostMalloc((void **)&h_stats, ST_N * 8));
     std::vector<hipEvent_t> ev;
@@ -1150,8 +1249,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     for (;;) {
         for (int r = 0; r < batch; r++) {
             if (prof) { hipEvent_t a0, a1; HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1)); ev.push_back(a0); ev.push_back(a1); HIP_TRY(hipEventRecord(a0, c->stream)); }
-            if (quad) hipLaunchKernelGGL((k_steps<W, true>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
-            else hipLaunchKernelGGL((k_steps<W, false>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
+            if (quad) hipLaunchKernelGGL((k_steps<W, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
+            else hipLaunchKernelGGL((k_steps<W, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             if (prof) HIP_TRY(hipEventRecord(ev.back(), c->stream));
             if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
             else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve<32>), dim3((K + 7) / 8), dim3(256), 0, c->stream, a);

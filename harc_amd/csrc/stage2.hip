@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_consensus(S2Args s, const uint32_t *cid
 // exact key -> (start,count) lookup in a bucketed table (64 B = 4 slots, overflow flag in slot 0: see k_table_insert); two slots at a time
 __device__ __forceinline__ bool dict_lookup_b(const HashSlot *tab, uint64_t cap, uint64_t key, uint32_t *start, uint32_t *count)
 {
-    uint64_t sl = __umul64hi(mix64(key), cap >> 2) << 2;
+    uint64_t sl = bucket_slot(key, cap);
     for (;;) {
         const uint4 r0 = *reinterpret_cast<const uint4 *>(&tab[sl]), r1 = *reinterpret_cast<const uint4 *>(&tab[sl + 1]);
         if (r0.w == 0) return false;
@@ -679,7 +679,7 @@ int stage2_run(harc_amd_ctx *c)
     HIP_TRY(hipMemsetAsync(d_big, 0, 8, c->stream));
     uint32_t *bloom[2] = { nullptr, nullptr }; int bloom_shift[2] = { 63, 63 };
     if (T) {
-        RC_TRY(harc_dict_alloc(c, &dict[0], T)); RC_TRY(harc_dict_alloc(c, &dict[1], T));
+        RC_TRY(harc_dict_alloc(c, &dict[0], T, 0)); RC_TRY(harc_dict_alloc(c, &dict[1], T, dict[0].cap));
         dict[0].bigthresh = dict[1].bigthresh = (uint32_t)P.maxsearch;
         dict[0].bucketed = dict[1].bucketed = true;
         int lb = 16; while (lb < 36 && (1ULL << lb) < 16ULL * T) lb++;           // 16 bits per key: ~6 % of absent keys pass
