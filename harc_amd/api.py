@@ -40,7 +40,7 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(HERE, "libharc_amd.so")
+    return os.environ.get("HARC_AMD_LIB") or os.path.join(HERE, "libharc_amd.so")      # override: experiment builds of the same sources
 
 
 def lib():

@@ -393,7 +393,7 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
 #define HARC_BIGBIN 4u      // bins with more reads than this are scanned by the whole wave
 #endif
 #ifndef HARC_STEPS_WAVES
-#define HARC_STEPS_WAVES 4       // many chains: 4 waves / SIMD (128 VGPRs)
+#define HARC_STEPS_WAVES 5       // many chains: 5 waves / SIMD (96 VGPRs, 14 dwords of scratch): +5 % over 4 waves, 6 waves spill too much
 #endif
 #ifndef HARC_STEPS_WAVES_Q
 #define HARC_STEPS_WAVES_Q 3     // few chains (whole-bucket fetch): never more than ~3 waves / SIMD anyway
@@ -506,6 +506,7 @@ template <int W> __device__ __forceinline__ void cons_rows(const ConsState<W> &s
 template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_WAVES_Q : HARC_STEPS_WAVES) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
+    constexpr int FIRSTMAX = QUAD ? 64 : 32;
     extern __shared__ uint32_t lds[];
     // [mask rows: (dir, shift) -> NW dwords][window rows: 4 waves x {ref, rref}][accepted read: 4 waves][column bytes: 4 waves x 2 x 16 NW][probes]
     uint32_t *const s_mask = lds;
@@ -615,10 +616,13 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
         int base = 0;
         for (int bi = 0; base < s.nprobe; bi++) {
             // first batch: twice the priority index of the chain's previous hit (high coverage -> hits at small shifts -> narrow first
-            // batch); every later batch is a full wave.  s.nbatch > 0 (HARC_AMD_BATCHES) overrides with a fixed schedule.
+            // batch), at most FIRSTMAX probes; every later batch is a full wave.  With many chains the kernel runs at the random-access
+            // ceiling of the memory system (tools/micro/gups.hip: 26 G 32-byte requests/s beyond 16 GiB), so speculative probes cost
+            // throughput: FIRSTMAX = 32 there (+8 %); with few chains a round trip costs more than the probes.
+            // s.nbatch > 0 (HARC_AMD_BATCHES) overrides with a fixed schedule.
             int bend;
             if (s.nbatch > 0) bend = s.batch_end[bi < s.nbatch ? bi : s.nbatch - 1];
-            else { int w0 = bi == 0 ? ((2 * lastp + 16 + 15) & ~15) : 64; if (w0 > 64) w0 = 64; bend = base + w0; }
+            else { int w0 = bi == 0 ? ((2 * lastp + 16 + 15) & ~15) : 64; if (w0 > (bi == 0 ? FIRSTMAX : 64)) w0 = bi == 0 ? FIRSTMAX : 64; bend = base + w0; }
             if (bend > s.nprobe) bend = s.nprobe;
             if (bend <= base) bend = s.nprobe;
             const int p = base + lane;
@@ -1135,8 +1139,12 @@ static std::vector<uint16_t> make_probe_table(const harc_amd_params &P)
 static uint32_t auto_chains(uint32_t N, int reads_per_chain)
 {
     // one chain per ~2048 reads keeps chains sparse on the genome (every chain costs about one extra contig);
-    // 65536 waves is several full waves of occupancy on 256 CUs
+    // 65536 waves is several full waves of occupancy on 256 CUs.  Small inputs: up to 2048 chains (two waves per SIMD) while a chain
+    // still has 1024 reads to walk -- with fewer chains the kernel is a handful of waves waiting on HBM round trips; with shorter
+    // chains the streams grow (one chain per 256 reads: +10 % on the 26x test set of test_P5_stream_sizes_vs_reference_t8).
     uint32_t k = N / (uint32_t)(reads_per_chain > 0 ? reads_per_chain : 2048);
+    const uint32_t floor_k = N / 1024 < 2048 ? N / 1024 : 2048;
+    if (k < floor_k) k = floor_k;
     if (k > 65536) k = 65536;
     if (k < 1) k = 1;
     return k;

@@ -82,3 +82,10 @@ def reads_text_bigbin_stage2(seed, n_clean=3000, n_dupN=2500, L=100, genome_len=
     out[:, :L] = allr
     out[:, L] = 10
     return out.tobytes()
+
+
+def auto_chains(n_clean, reads_per_chain=2048):
+    """auto_chains() of harc_amd/csrc/stage1.hip: K when harc_amd_params.num_chains = 0"""
+    k = n_clean // reads_per_chain
+    k = max(k, min(2048, n_clean // 1024))
+    return max(1, min(k, 65536))

@@ -103,7 +103,7 @@ def test_medium_vs_oracle_and_roundtrip(n, L, glen, err, K, E, S, oracle, tmp_pa
     import harc_amd
     txt = gen.reads_text(1234 + n, n, L, glen, err=err)
     (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
-    Ko = K if K else max(1, (txt.count(b"\n") - sum(1 for l in txt.split(b"\n") if b"N" in l)) // 2048)   # auto_chains() in stage1.hip
+    Ko = K if K else gen.auto_chains(txt.count(b"\n") - sum(1 for l in txt.split(b"\n") if b"N" in l))   # auto_chains() in stage1.hip
     inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, L, Ko, E, tmp_path / "o", S if S else 16)
     base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
     harc_amd.compress(base, L, num_thr=E, num_chains=K, num_steps=S)
@@ -320,7 +320,7 @@ def test_minimizer_shard_input_matches_oracle(n, world, K, S, oracle, tmp_path):
     txt = b"".join(bytes(r) + b"\n" for r in sel)
     (tmp_path / "o").mkdir(); (tmp_path / "g1").mkdir(); (tmp_path / "g2").mkdir()
     nclean = sel.shape[0]
-    Ko = K if K else max(1, nclean // 2048)
+    Ko = K if K else gen.auto_chains(nclean)
     inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, Ko, 4, tmp_path / "o", S)
     outs = []
     for d in ("g1", "g2"):
@@ -646,12 +646,12 @@ def test_reads_per_chain_is_the_auto_chain_count(tmp_path):
     txt = gen.reads_text(91, 40000, 100, 250000, err=0.0)
     n = len(txt.split())
     outs = []
-    for kw in (dict(num_chains=0, reads_per_chain=512), dict(num_chains=n // 512), dict(num_chains=0), dict(num_chains=n // 2048)):
+    for kw in (dict(num_chains=0, reads_per_chain=64), dict(num_chains=n // 64), dict(num_chains=0), dict(num_chains=gen.auto_chains(n))):
         h = harc_amd.HarcAmd(harc_amd.default_params(100, num_thr=2, **kw))
         h.set_reads_ascii(txt, n, 101)
         h.set_nreads_ascii(b"", 0, 101)
         h.reorder(); h.encode()
         outs.append((h.counters().chains, h.stream("S1_ORDER"), h.stream("S2_SEQ", 0), h.stream("S2_NOISE", 1)))
         h.close()
-    assert outs[0] == outs[1] and outs[0][0] == n // 512
-    assert outs[2] == outs[3] and outs[2][0] == n // 2048
+    assert outs[0] == outs[1] and outs[0][0] == n // 64
+    assert outs[2] == outs[3] and outs[2][0] == gen.auto_chains(n) == n // 1024
