@@ -20,6 +20,7 @@ struct S1Args {
     HashSlot *slots[2];
     uint64_t cap[2];
     const uint32_t *ids[2];
+    const uint64_t *sk[2];           // per dictionary, parallel to ids: the OTHER dictionary's key of the read (a 64-bit sketch outside the bin's own key)
     unsigned long long *claimed;     // bitmap, bit rid&63 of word rid>>6
     uint32_t *bid;                   // per read: smallest (step<<20 | chain) bidding for it this super-round
     ChainHdr *hdr;
@@ -209,6 +210,13 @@ template <int W> __global__ void k_keygen(const uint64_t *reads, uint32_t n, int
     if (nbits < 64) v &= ((uint64_t)1 << nbits) - 1;
     keys[i] = v; ids[i] = i;
 }
+// sk[i] = key of the OTHER dictionary of read ids[i]: what the wave-cooperative bin scan compares first (coalesced, 8 bytes per
+// candidate) before it pays for the candidate's 8W bytes at a random address
+__global__ void k_sketch_gather(const uint64_t *okeys, const uint32_t *ids, uint32_t n, uint64_t *sk)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sk[i] = okeys[ids[i]];
+}
 __global__ void k_mark_heads(const uint64_t *skeys, uint32_t n, uint32_t *head)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,7 +230,7 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
     if (head[i]) binstart[binidx[i]] = i;
     if (i == n - 1) *nbins = binidx[i] + head[i];
 }
-#define HARC_LARGEBIN 128u   // stage-I bins with more reads than this are compacted between super-rounds (k_compact_bins)
+#define HARC_LARGEBIN 16u    // stage-I bins with more reads than this are compacted between super-rounds (k_compact_bins)
 // one thread per bin: claim an empty slot by CAS on the (start,count) word; keys are unique so no key compare is needed
 __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, const uint32_t *nbins_p, uint32_t n,
                                HashSlot *slots, uint64_t cap, int bucketed, uint32_t bigthresh,
@@ -393,7 +401,7 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
 #define HARC_BIGBIN 4u      // bins with more reads than this are scanned by the whole wave
 #endif
 #ifndef HARC_STEPS_WAVES
-#define HARC_STEPS_WAVES 5       // many chains: 5 waves / SIMD (96 VGPRs, 14 dwords of scratch): +5 % over 4 waves, 6 waves spill too much
+#define HARC_STEPS_WAVES 5       // many chains: 5 waves / SIMD (96 VGPRs, 16 dwords of scratch): +5 % over 4 waves, 6 waves spill too much; reads of more than 128 bases: 4
 #endif
 #ifndef HARC_STEPS_WAVES_Q
 #define HARC_STEPS_WAVES_Q 3     // few chains (whole-bucket fetch): never more than ~3 waves / SIMD anyway
@@ -503,7 +511,7 @@ template <int W> __device__ __forceinline__ void cons_rows(const ConsState<W> &s
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_WAVES_Q : HARC_STEPS_WAVES) void k_steps(S1Args s)
+template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1)) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
     constexpr int FIRSTMAX = QUAD ? 64 : 32;
@@ -604,6 +612,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
     uint8_t *const coltmp = reinterpret_cast<uint8_t *>(s_tmp + (size_t)wv * 8 * NW);
     const uint64_t kmask0 = s.kbits[0] < 64 ? (((uint64_t)1 << s.kbits[0]) - 1) : ~(uint64_t)0, kmask1 = s.kbits[1] < 64 ? (((uint64_t)1 << s.kbits[1]) - 1) : ~(uint64_t)0;
     const uint64_t cap = s.cap[0];                               // both dictionaries have the same geometry (stage1_run_w)
+    uint32_t dbg_bins = 0, dbg_iter = 0, dbg_miss = 0, dbg_surv = 0, dbg_batches = 0;   // coop scans / their 64-entry chunks / steps without a hit / sketch survivors / batches
     uint32_t np = 0, nc = 0, nuse = 0, ncu = 0;                   // ncu: candidates a strictly sequential scan (reorder.cpp:517-649) would have tested too
     int nst = 0; bool needseed = false;
     int lastp = (int)(h.pad0 & 0xFFFF);                          // priority index of this chain's previous hit
@@ -625,7 +634,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
             else { int w0 = bi == 0 ? ((2 * lastp + 16 + 15) & ~15) : 64; if (w0 > (bi == 0 ? FIRSTMAX : 64)) w0 = bi == 0 ? FIRSTMAX : 64; bend = base + w0; }
             if (bend > s.nprobe) bend = s.nprobe;
             if (bend <= base) bend = s.nprobe;
-            const int p = base + lane;
+            const int p = base + lane; dbg_batches++;
             uint32_t mine = HARC_NONE; int j = 0, dir = 0, l = 0;
             uint32_t ncb = 0;                                             // candidates this lane tests in this batch
             bool big = false; uint32_t b_sst = 0, b_cnt = 0; uint64_t b_slot = 0;   // a bin too large for one lane: scanned by the whole wave below
@@ -730,47 +739,76 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                 if (winlane < 64) bigm &= (1ULL << winlane) - 1ULL;
                 while (bigm) {
                     const int bl = __ffsll((long long)bigm) - 1;
-                    bigm &= bigm - 1;
+                    bigm &= bigm - 1; dbg_bins++;
                     const uint32_t o_sst = (uint32_t)__builtin_amdgcn_readlane((int)b_sst, bl), o_raw = (uint32_t)__builtin_amdgcn_readlane((int)b_cnt, bl), o_cnt = o_raw & SLOT_CNT_MASK;
                     const int o_j = __builtin_amdgcn_readlane(j, bl), o_dir = __builtin_amdgcn_readlane(dir, bl), o_l = __builtin_amdgcn_readlane(l, bl);
                     const uint64_t o_slot = shfl_u64(b_slot, bl);
                     const uint32_t *oids = s.ids[o_l];
+                    const uint64_t *osk = s.sk[o_l];
                     const uint32_t *const orow = o_dir ? rowR : rowF;
                     const uint32_t *const omrow = s_mask + (size_t)(o_dir * s.maxmatch + o_j) * MROW;
                     const int obit = 32 * NW + (o_dir ? -2 * o_j : 2 * o_j);
+                    // what the candidate's sketch (its key of the OTHER dictionary) must look like: that dictionary's window of the (reverse)
+                    // consensus at this shift, compared on the bases that lie inside the overlap.  More than `thresh` differing bits there
+                    // already decide the full test (reorder.cpp:543,608) -- without touching the candidate's words.
+                    uint64_t expect, smask;
+                    {
+                        const int ol = o_l ^ 1, ods = s.ds[ol], olen = s.kbits[ol] >> 1;
+                        const int koff = 32 * NW + (o_dir ? 2 * (ods - o_j) : 2 * (ods + o_j));
+                        const int i0 = koff >> 5, shb = koff & 31;
+                        const uint32_t d0 = orow[i0], d1 = orow[i0 + 1], d2 = orow[i0 + 2];
+                        expect = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, shb) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, shb) << 32);
+                        const uint64_t full = olen >= 32 ? ~(uint64_t)0 : (((uint64_t)1 << (2 * olen)) - 1);
+                        if (!o_dir) { int nv = L - o_j - ods; nv = nv < 0 ? 0 : (nv > olen ? olen : nv); smask = nv >= 32 ? ~(uint64_t)0 : (((uint64_t)1 << (2 * nv)) - 1); }
+                        else { int ns = o_j - ods; ns = ns < 0 ? 0 : (ns > olen ? olen : ns); smask = ns >= 32 ? 0 : (full & ~(((uint64_t)1 << (2 * ns)) - 1)); }
+                        smask &= full;
+                    }
+                    // bins that fit the maxsearch window (reorder.cpp:540) never close it: only the candidates that pass the sketch need
+                    // their claim bit (and their words).  Larger bins count the unclaimed reads exactly, as the lane-serial scan would.
+                    const bool fast = o_cnt <= (uint32_t)s.maxsearch;
                     int seen = 0; uint32_t pos = o_cnt, lead = 0; bool alltop = true, bighit = false;
                     while (pos > 0 && seen < s.maxsearch) {
-                        const bool valid = (uint32_t)lane < pos;
-                        uint32_t rid = 0; bool clm = true;
-                        if (valid) {
-                            rid = oids[o_sst + pos - 1 - lane];
-                            const unsigned long long cwd = s.claimed[rid >> 6];
-                            load_read32<W>(s.reads, rid, mrd);                 // mrd is free: the small winner is already in LDS
-                            clm = ((cwd >> (rid & 63)) & 1ULL) != 0;
-                        }
-                        bool own = false;
-                        if (valid && !clm) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
-                        const bool un = valid && !clm && !own;
-                        const unsigned long long um = __ballot(un);
-                        const int rank = __popcll(um & ((1ULL << lane) - 1ULL));
-                        const bool elig = un && (seen + rank < s.maxsearch);
-                        int hd = 1 << 20;
-                        if (elig) { nc++; ncu++; hd = ham_window<W>(orow, obit, omrow, mrd); }
-                        const unsigned long long pm = __ballot(elig && hd <= s.thresh);
-                        if (alltop) {
-                            const unsigned long long cm = __ballot(valid && clm), vm = __ballot(valid);
-                            if (cm == vm) lead += (uint32_t)__popcll(vm); else { lead += (uint32_t)(__ffsll((long long)~cm) - 1); alltop = false; }
-                        }
-                        if (pm) {
-                            const int wl = __ffsll((long long)pm) - 1;
-                            found = (uint32_t)__builtin_amdgcn_readlane((int)rid, wl); fj = o_j; fdir = o_dir; winlane = bl; bighit = true;
-                            if (lane == wl) {
-#pragma unroll
-                                for (int k = 0; k < NW; k++) rdl[k] = mrd[k];
+                        const bool valid = (uint32_t)lane < pos; dbg_iter++;
+                        uint32_t rid = 0; uint64_t sv = 0;
+                        if (valid) { rid = oids[o_sst + pos - 1 - lane]; sv = osk[o_sst + pos - 1 - lane]; }
+                        const bool skok = valid && __popcll((sv ^ expect) & smask) <= s.thresh;
+                        dbg_surv += (uint32_t)__popcll(__ballot(skok));
+                        bool clm = true, own = false;
+                        unsigned long long um = 0; bool elig = skok;
+                        if (!fast) {                                          // exact window: claim state of every entry of the chunk
+                            if (valid) clm = ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
+                            if (valid && !clm) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
+                            const bool un = valid && !clm && !own;
+                            um = __ballot(un);
+                            elig = un && (seen + __popcll(um & ((1ULL << lane) - 1ULL)) < s.maxsearch);
+                            if (elig) { nc++; ncu++; }
+                            if (alltop) {
+                                const unsigned long long cm = __ballot(valid && clm), vm = __ballot(valid);
+                                if (cm == vm) lead += (uint32_t)__popcll(vm); else { lead += (uint32_t)(__ffsll((long long)~cm) - 1); alltop = false; }
                             }
-                            break;
+                            elig = elig && skok;
+                        } else if (valid) { nc++; ncu++; }                    // statistics: fast mode cannot tell claimed entries apart
+                        // the entries that passed the sketch pay for their words (and, in fast mode, their claim bit)
+                        {
+                            bool ok = false;
+                            if (elig) {
+                                if (fast) clm = ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
+                                load_read32<W>(s.reads, rid, mrd);             // mrd is free: the small winner is already in LDS
+                                if (fast && !clm) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
+                                ok = !clm && !own && ham_window<W>(orow, obit, omrow, mrd) <= s.thresh;
+                            }
+                            const unsigned long long pm = __ballot(ok);
+                            if (pm) {
+                                const int wl = __ffsll((long long)pm) - 1;
+                                found = (uint32_t)__builtin_amdgcn_readlane((int)rid, wl); fj = o_j; fdir = o_dir; winlane = bl; bighit = true;
+                                if (lane == wl) {
+#pragma unroll
+                                    for (int k = 0; k < NW; k++) rdl[k] = mrd[k];
+                                }
+                            }
                         }
-                        seen += __popcll(um);
+                        if (bighit) break;
+                        if (!fast) seen += __popcll(um);
                         pos -= pos > 64 ? 64 : pos;
                     }
                     if (lead && lane == 0) {
@@ -791,7 +829,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
         if (found == HARC_NONE) {
             // no candidate: go on from the chain's look-ahead seeds (highest id first, skipping what was claimed meanwhile) -- the new
             // seed of reorder.cpp:652-668 without waiting for the next k_reseed
-            nuse += (uint32_t)s.nprobe;
+            nuse += (uint32_t)s.nprobe; dbg_miss++;
             uint32_t sid = HARC_NONE;
             if (spos < nsugg) {
                 const int idx = spos + lane;
@@ -829,6 +867,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
     }
     if (nst > 0) cons_store<W>(st, B1, L, lane);
     np = wave_sum_u32(np); nc = wave_sum_u32(nc); ncu = wave_sum_u32(ncu);
+    if (lane == 0 && s.dbg) { atomicAdd(&s.dbg[0], (unsigned long long)dbg_bins); atomicAdd(&s.dbg[1], (unsigned long long)dbg_iter); atomicAdd(&s.dbg[2], (unsigned long long)dbg_miss); atomicAdd(&s.dbg[3], (unsigned long long)dbg_surv); atomicAdd(&s.dbg[4], (unsigned long long)nst); atomicAdd(&s.dbg[5], (unsigned long long)dbg_batches); }
     if (lane == 0) {
         cst.x += np; cst.y += nc; cst.z += nuse; cst.w += ncu; s.cstat[c] = cst;
         h.mode = 0;
@@ -1013,15 +1052,16 @@ __global__ __launch_bounds__(64) void k_compact_bins(S1Args s, const unsigned lo
     const uint32_t cw = slot->count;
     if (cw & SLOT_DEAD) return;
     const uint32_t cnt = cw & SLOT_CNT_MASK, st = slot->start;
-    if (cnt <= 64) return;                                        // one cooperative batch anyway
     uint32_t *ids = const_cast<uint32_t *>(s.ids[l]) + st;
+    uint64_t *sk = const_cast<uint64_t *>(s.sk[l]) + st;
     uint32_t out = 0;
     for (uint32_t pos = 0; pos < cnt; pos += 64) {
         const bool valid = pos + lane < cnt;
-        uint32_t rid = 0; bool un = false;
-        if (valid) { rid = ids[pos + lane]; un = !((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL); }
+        uint32_t rid = 0; uint64_t sv = 0; bool un = false;
+        if (valid) { rid = ids[pos + lane]; sv = sk[pos + lane]; un = !((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL); }
         const unsigned long long um = __ballot(un);
-        if (un) ids[out + (uint32_t)__popcll(um & ((1ULL << lane) - 1ULL))] = rid;     // out <= pos: never ahead of the reads of this pass
+        const uint32_t at = out + (uint32_t)__popcll(um & ((1ULL << lane) - 1ULL));     // out <= pos: never ahead of the reads of this pass
+        if (un) { ids[at] = rid; sk[at] = sv; }
         out += (uint32_t)__popcll(um);
     }
     if (lane == 0 && out < cnt) {
@@ -1174,7 +1214,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const harc_mark_t mark_results = harc_pool_mark(c);
     // ---- dictionaries (constructdictionary, reorder.cpp:277-394)
     DictDev dict[2];
-    unsigned long long *d_large = nullptr; unsigned int *d_nlarge = nullptr;
+    unsigned long long *d_large = nullptr; unsigned int *d_nlarge = nullptr; uint64_t *d_sk[2] = { nullptr, nullptr };
     const uint32_t maxlarge = 2 * (N / HARC_LARGEBIN) + 16;
     if (N) {
         RC_TRY(harc_dict_alloc(c, &dict[0], N, 0)); RC_TRY(harc_dict_alloc(c, &dict[1], N, dict[0].cap));
@@ -1182,14 +1222,20 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         RC_TRY(dalloc(c, &d_large, maxlarge)); RC_TRY(dalloc(c, &d_nlarge, 4));
         HIP_TRY(hipMemsetAsync(d_nlarge, 0, 16, c->stream));
         for (int l = 0; l < 2; l++) { dict[l].large_list = d_large; dict[l].large_n = d_nlarge; dict[l].large_max = maxlarge; dict[l].large_tag = (uint32_t)l; }
+        RC_TRY(dalloc(c, &d_sk[0], (size_t)N + 1)); RC_TRY(dalloc(c, &d_sk[1], (size_t)N + 1));
         const harc_mark_t mk = harc_pool_mark(c);
-        uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
-        RC_TRY(dalloc(c, &k0, N)); RC_TRY(dalloc(c, &i0, N));
+        uint64_t *kk[2] = { nullptr, nullptr }; uint32_t *i0 = nullptr;
+        RC_TRY(dalloc(c, &kk[0], N)); RC_TRY(dalloc(c, &kk[1], N)); RC_TRY(dalloc(c, &i0, N));
         for (int l = 0; l < 2; l++) {
             const int kbits = 2 * (P.dict_end[l] - P.dict_start[l] + 1);
-            hipLaunchKernelGGL((k_keygen<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[l], kbits, k0, i0);
-            RC_TRY(harc_dict_build(c, &dict[l], k0, i0, N, (unsigned)kbits));
+            hipLaunchKernelGGL((k_keygen<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[l], kbits, kk[l], i0);
+            RC_TRY(harc_dict_build(c, &dict[l], kk[l], i0, N, (unsigned)kbits));
         }
+        // sketches of the bin scan: the other dictionary's key of every entry, in bin order
+        for (int l = 0; l < 2; l++)
+            hipLaunchKernelGGL(k_sketch_gather, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)kk[l ^ 1], (const uint32_t *)dict[l].ids, N, d_sk[l]);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
         harc_pool_release(c, mk);
     }
     // bins large enough to be worth compacting between super-rounds were listed by k_table_insert (none on ordinary data)
@@ -1209,7 +1255,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (const char *e = getenv("HARC_AMD_NSUGG")) { a.nsugg_per_seed = atoi(e); if (a.nsugg_per_seed < 0) a.nsugg_per_seed = 0; if (a.nsugg_per_seed > HARC_NSUGG) a.nsugg_per_seed = HARC_NSUGG; }
     for (int l = 0; l < 2; l++) { a.ds[l] = P.dict_start[l]; a.de[l] = P.dict_end[l]; a.kbits[l] = 2 * (P.dict_end[l] - P.dict_start[l] + 1); }
     a.N = N; a.K = K; a.reads = c->d_reads;
-    for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
+    for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; a.sk[l] = d_sk[l]; }
     const size_t nwords = (size_t)N / 64 + 2;
     const uint32_t nblk = (K + 255) / 256;
     RC_TRY(dalloc(c, &a.claimed, nwords)); RC_TRY(dalloc(c, &a.bid, (size_t)N + 1)); RC_TRY(dalloc(c, &a.hdr, K));
@@ -1219,6 +1265,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N));
     RC_TRY(dalloc(c, &a.cstat, K)); HIP_TRY(hipMemsetAsync(a.cstat, 0, (size_t)K * 16, c->stream));
     RC_TRY(dalloc(c, &a.dbg, 16)); HIP_TRY(hipMemsetAsync(a.dbg, 0, 16 * 8, c->stream));
+    unsigned long long *const dbg_ptr = a.dbg;
+    if (!getenv("HARC_AMD_TRACE")) a.dbg = nullptr;
     std::vector<uint16_t> tab = make_probe_table(P);
     uint16_t *d_tab = nullptr; RC_TRY(dalloc(c, &d_tab, tab.size() + 1));
     HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream));
@@ -1319,6 +1367,12 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
                 d[10] / st, d[8] / st, d[9] / st, d[11] / st, d[12] / st);
     }
 #endif
+    if (a.dbg) {
+        unsigned long long d[16];
+        HIP_TRY(hipMemcpy(d, dbg_ptr, sizeof d, hipMemcpyDeviceToHost));
+        const double stp = (double)(d[4] ? d[4] : 1);
+        fprintf(stderr, "[k_steps] steps walked %llu (of them kept %u): per step batches %.2f, cooperative bin scans %.2f, their 64-entry chunks %.2f, sketch survivors %.2f; steps without a hit %.3f\n", d[4], N, d[5] / stp, d[0] / stp, d[1] / stp, d[3] / stp, d[2] / stp);
+    }
     hipHostFree(h_stats);
 
     harc_pool_release(c, mark_results);                          // stage II starts right above the results
