@@ -13,6 +13,7 @@
 // Shard e of num_thr owns reordered reads [e*q, (e+1)*q) (:171-180); its streams are slices of the global arrays.
 #include "devutil.h"
 #include <algorithm>
+#include <stdlib.h>
 
 #define TUPLE_NONE 0xFFFFFFFFFFFFFFFFULL
 
@@ -362,60 +363,63 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args
 }
 
 // Bins larger than maxsearch, exact: the reference scans, at every probe, the maxsearch highest ids of the bin that are STILL
-// unclaimed at that moment (encoder.cpp:293 after the removals of :321-336).  The probes that hit such a bin were recorded by
-// k_realign_propose; here ONE workgroup replays them in tuple order (= the order of the sequential reference), 1024 candidates per
-// round trip, against best[] = "claimed at tuple" (a read is unclaimed at tuple t iff best[rid] > t).
-__global__ __launch_bounds__(1024) void k_realign_big(S2Args s, const unsigned long long *etuple, const uint32_t *eidx, uint32_t nev)
+// unclaimed at that moment (encoder.cpp:293 after the removals of :321-336), so what a probe sees depends on the probes before it.
+// The probes that hit such a bin were recorded by k_realign_propose as events (tuple, bin).  With c(r) = the tuple at which read r is
+// claimed (best[r]), the sequential result is the least fixed point of
+//     c(r) = min { t(e) : event e accepts r and fewer than maxsearch reads r' > r of its bin have c(r') >= t(e) }
+// (together with the claims of the ordinary bins, which never depend on a window).  Iterating from c = "unclaimed" only ever lowers c
+// and never below the sequential value (a read that looks visible with too-late claims above it is visible in the sequential run as
+// well), and a state that no event changes any more IS the sequential one.  So: one wave per event, all events at once, 64
+// candidates per round trip, repeated until a pass changes nothing -- as many passes as the deepest bin has windows of maxsearch.
+__global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, unsigned int *changed)
 {
-    __shared__ unsigned long long swin[2][HARC_MAXW3];
-    __shared__ uint32_t sm[20];
-    const int t = threadIdx.x;
+    __shared__ unsigned long long swin[4][HARC_MAXW3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t e = blockIdx.x * 4 + wv;
+    if (e >= nev) return;
     const int L = s.L, W3 = s.W3;
-    for (uint32_t e = 0; e < nev; e++) {
-        const unsigned long long tp = etuple[e];
-        const uint4 ev = s.events[eidx[e]];
-        const uint64_t x = tp >> 2; const int dir = (int)((tp >> 1) & 1), l = (int)(tp & 1);
-        const uint32_t st = ev.z, cnt = ev.w;
-        // 3-bit window words (forward or reverse complement), threads 0..W3-1 build one word each
-        if (t < W3) {
-            const uint8_t *win = s.cons + x;
-            unsigned long long v = 0;
-            const int b0 = (64 * t) / 3, b1 = (64 * t + 63) / 3;
-            for (int b = b0; b <= b1 && b < L; b++) {
-                const int idx = dir ? 3 - (int)(win[L - 1 - b] & 3) : (int)(win[b] & 3);
-                const unsigned long long c3 = (unsigned long long)idx_to_c3(idx);
-                const int sh = 3 * b - 64 * t;
-                v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
-            }
-            swin[e & 1][t] = v;
+    const uint4 ev = s.events[e];
+    const unsigned long long tp = (unsigned long long)ev.x | ((unsigned long long)ev.y << 32);
+    const uint64_t x = tp >> 2; const int dir = (int)((tp >> 1) & 1), l = (int)(tp & 1);
+    const uint32_t st = ev.z, cnt = ev.w;
+    // 3-bit window words (forward or reverse complement), lanes 0..W3-1 build one word each
+    if (lane < W3) {
+        const uint8_t *win = s.cons + x;
+        unsigned long long v = 0;
+        const int b0 = (64 * lane) / 3, b1 = (64 * lane + 63) / 3;
+        for (int b = b0; b <= b1 && b < L; b++) {
+            const int idx = dir ? 3 - (int)(win[L - 1 - b] & 3) : (int)(win[b] & 3);
+            const unsigned long long c3 = (unsigned long long)idx_to_c3(idx);
+            const int sh = 3 * b - 64 * lane;
+            v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
         }
-        __syncthreads();
-        uint32_t seen = 0, pos = cnt;                             // block-uniform
-        while (pos > 0 && seen < (uint32_t)s.maxsearch) {         // 1024 candidates per round trip, highest id first
-            const bool valid = (uint32_t)t < pos;
-            uint32_t rid = 0; bool un = false;
-            if (valid) { rid = s.ids[l][st + pos - 1 - t]; un = __hip_atomic_load(&s.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tp; }
-            uint32_t total; const uint32_t rank = block_excl_scan_u32<1024>(un ? 1u : 0u, sm, &total);
-            if (un && seen + rank < (uint32_t)s.maxsearch) {
-                const uint64_t *r = s.cand3 + (size_t)rid * W3;
-                int hd = 0;
-                for (int w = 0; w < W3; w++) { hd += __popcll(swin[e & 1][w] ^ r[w]); if (hd > s.thresh_s) break; }
-                if (hd <= s.thresh_s) __hip_atomic_store(&s.best[rid], tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every passing candidate of the window is taken (encoder.cpp:296-317)
-            }
-            seen += total;
-            pos -= pos > 1024 ? 1024 : pos;
-        }
-        __threadfence_block();
-        __syncthreads();
+        swin[wv][lane] = v;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t seen = 0, pos = cnt; bool ch = false;               // wave-uniform
+    while (pos > 0 && seen < (uint32_t)s.maxsearch) {             // highest id first
+        const bool valid = (uint32_t)lane < pos;
+        uint32_t rid = 0; unsigned long long b = 0; bool un = false;
+        if (valid) {
+            rid = s.ids[l][st + pos - 1 - lane];
+            b = __hip_atomic_load(&s.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            un = b >= tp;                                          // not claimed before this probe (claimed BY this probe in an earlier pass counts as visible)
+        }
+        const unsigned long long um = __ballot(un);
+        const uint32_t rank = (uint32_t)__popcll(um & ((1ULL << lane) - 1ULL));
+        if (un && seen + rank < (uint32_t)s.maxsearch && b > tp) {
+            const uint64_t *r = s.cand3 + (size_t)rid * W3;
+            int hd = 0;
+            for (int w = 0; w < W3; w++) { hd += __popcll(swin[wv][w] ^ r[w]); if (hd > s.thresh_s) break; }
+            if (hd <= s.thresh_s && atomicMin(&s.best[rid], tp) > tp) ch = true;      // every passing candidate of the window is taken (encoder.cpp:296-317)
+        }
+        seen += (uint32_t)__popcll(um);
+        pos -= pos > 64 ? 64 : pos;
+    }
+    if (__ballot(ch) && lane == 0) atomicOr(changed, 1u);
 }
 
-__global__ void k_event_keys(const uint4 *ev, uint32_t n, unsigned long long *key, uint32_t *idx)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    key[i] = (unsigned long long)ev[i].x | ((unsigned long long)ev[i].y << 32); idx[i] = i;
-}
 __global__ void k_acc_flags(const unsigned long long *best, uint32_t T, uint32_t *flag)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -669,7 +673,8 @@ int stage2_run(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &cand2, (size_t)T * W + 1)); RC_TRY(dalloc(c, &candN, (size_t)T * W + 1));
     if (T) hipLaunchKernelGGL(k_cand2_from3, G256((size_t)T * W), (const uint64_t *)cand3, T, L, W, W3, cand2, candN);
     a.cand2 = cand2; a.candN = candN;
-    a.maxevents = 1u << 22;                                       // 64 MB of events; more than that fails loudly
+    a.maxevents = 1u << 20;                                       // 16 MB of events to start with; the pass is repeated with a larger buffer when it asks for one
+    if (const char *e = getenv("HARC_AMD_MAXEVENTS")) { a.maxevents = (uint32_t)strtoul(e, nullptr, 10); if (a.maxevents < 1) a.maxevents = 1; }   // tests: force the growth path
     RC_TRY(dalloc(c, &a.events, (size_t)a.maxevents)); RC_TRY(dalloc(c, &a.nevents, 4));
     HIP_TRY(hipMemsetAsync(a.nevents, 0, 16, c->stream));
 
@@ -749,13 +754,32 @@ int stage2_run(harc_amd_ctx *c)
             unsigned int nev = 0;
             HIP_TRY(hipMemcpyAsync(&nev, a.nevents, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (nev > a.maxevents) { harc_set_error("stage II: %u probes hit bins larger than maxsearch (event buffer %u)", nev, a.maxevents); return HARC_AMD_ENOMEM; }
-            if (nev) {                                                        // exact sliding-window replay in tuple order
-                unsigned long long *tk0 = nullptr, *tk1 = nullptr; uint32_t *ti0 = nullptr, *ti1 = nullptr;
-                RC_TRY(dalloc(c, &tk0, nev)); RC_TRY(dalloc(c, &tk1, nev)); RC_TRY(dalloc(c, &ti0, nev)); RC_TRY(dalloc(c, &ti1, nev));
-                hipLaunchKernelGGL(k_event_keys, G256(nev), a.events, nev, tk0, ti0);
-                RC_TRY(prim_sort_pairs_u64_u32(c, (const uint64_t *)tk0, (uint64_t *)tk1, ti0, ti1, nev, 64));
-                hipLaunchKernelGGL(k_realign_big, dim3(1), dim3(1024), 0, c->stream, a, (const unsigned long long *)tk1, (const uint32_t *)ti1, nev);
+            if (nev > a.maxevents) {
+                // more probes into bins above maxsearch than the buffer holds (low-complexity reads against a long consensus): the pass
+                // is repeated with a buffer of the size it asked for (what it did to best[] is idempotent)
+                a.maxevents = nev;
+                RC_TRY(dalloc(c, &a.events, (size_t)a.maxevents));
+                HIP_TRY(hipMemsetAsync(a.nevents, 0, 16, c->stream));
+                switch (W) {
+#define REALIGN_CASE(WW) case WW: hipLaunchKernelGGL((k_realign_propose<WW>), rg, dim3(256), 0, c->stream, a); break;
+                    REALIGN_CASE(1) REALIGN_CASE(2) REALIGN_CASE(3) REALIGN_CASE(4) REALIGN_CASE(5) REALIGN_CASE(6) REALIGN_CASE(7) REALIGN_CASE(8)
+#undef REALIGN_CASE
+                }
+                HIP_TRY(hipMemcpyAsync(&nev, a.nevents, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (nev > a.maxevents) { harc_set_error("stage II: event count changed between two identical passes (%u > %u)", nev, a.maxevents); return HARC_AMD_ENODEVICE; }
+            }
+            if (nev) {                                                        // exact sliding-window semantics as a fixed point (k_realign_big)
+                unsigned int *d_changed = nullptr; RC_TRY(dalloc(c, &d_changed, 4));
+                for (uint64_t pass = 0;; pass++) {
+                    HIP_TRY(hipMemsetAsync(d_changed, 0, 16, c->stream));
+                    hipLaunchKernelGGL(k_realign_big, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, d_changed);
+                    unsigned int chg = 0;
+                    HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    if (!chg) break;
+                    if (pass > (uint64_t)T + 16) { harc_set_error("stage II: the window passes over the large bins did not settle"); return HARC_AMD_ENODEVICE; }
+                }
             }
         }
     }

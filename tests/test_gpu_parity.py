@@ -213,12 +213,16 @@ def test_low_complexity_big_bins_match_oracle(n, glen, K, S, E, err, oracle, tmp
     assert sorted(ol.read_dir(base)["output.dna"].split()) == sorted(txt.split())
 
 
-@pytest.mark.parametrize("K,S,E", [(1, 16, 1), (8, 16, 3)])
-def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, oracle, tmp_path):
-    """2500 N reads sharing their first 50 bases: both stage-II dictionaries hold a bin of 2500 > maxsearch.  The reference's
-    window slides over the still-unclaimed ids (encoder.cpp:293,321-336); the GPU replays those probes sequentially -- same bytes."""
+@pytest.mark.parametrize("K,S,E,maxev,ndup", [(1, 16, 1, 0, 2500), (8, 16, 3, 0, 2500), (4, 16, 2, 7, 2500), (3, 16, 1, 0, 5200)])
+def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, maxev, ndup, oracle, tmp_path, monkeypatch):
+    """ndup N reads sharing their first 50 bases: both stage-II dictionaries hold a bin of ndup > maxsearch.  The reference's
+    window slides over the still-unclaimed ids (encoder.cpp:293,321-336); the GPU settles those probes as a fixed point over all of them
+    at once (k_realign_big) -- same bytes as the sequential oracle.  maxev: a deliberately tiny event buffer, so that the pass has to be
+    repeated with the size it asks for; ndup = 5200: five windows deep."""
     import harc_amd
-    txt = gen.reads_text_bigbin_stage2(77)
+    if maxev:
+        monkeypatch.setenv("HARC_AMD_MAXEVENTS", str(maxev))
+    txt = gen.reads_text_bigbin_stage2(77, n_dupN=ndup)
     (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
     inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, K, E, tmp_path / "o", S)
     base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
@@ -226,7 +230,7 @@ def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, oracle, tmp_p
     fs = ol.stage2_files(E)
     assert_same(ol.read_dir(base), s2, fs, "stage II with bins above maxsearch vs oracle")
     # the case really exercises the window: more than maxsearch N reads get aligned
-    assert len(s2["read_order_N_pe.bin"]) // 4 == 2500 and len(s2["input_N.dna"]) < 1500 * 101
+    assert len(s2["read_order_N_pe.bin"]) // 4 == ndup and len(s2["input_N.dna"]) < (ndup - 1000) * 101
 
 
 @pytest.mark.parametrize("case", CASES)
