@@ -20,7 +20,8 @@ struct S1Args {
     HashSlot *slots[2];
     uint64_t cap[2];
     const uint32_t *ids[2];
-    const uint64_t *sk[2];           // per dictionary, parallel to ids: the OTHER dictionary's key of the read (a 64-bit sketch outside the bin's own key)
+    const uint2 *largetab;           // bins of more than HARC_LARGEBIN reads (SLOT_BIG; their slot's `start` indexes this table): x = first index into ids[], y = first row of `mirror`
+    uint64_t *mirror;                // the reads of those bins once more, W words per entry, in bin order: their scan is one coalesced stream
     unsigned long long *claimed;     // bitmap, bit rid&63 of word rid>>6
     uint32_t *bid;                   // per read: smallest (step<<20 | chain) bidding for it this super-round
     ChainHdr *hdr;
@@ -210,12 +211,35 @@ template <int W> __global__ void k_keygen(const uint64_t *reads, uint32_t n, int
     if (nbits < 64) v &= ((uint64_t)1 << nbits) - 1;
     keys[i] = v; ids[i] = i;
 }
-// sk[i] = key of the OTHER dictionary of read ids[i]: what the wave-cooperative bin scan compares first (coalesced, 8 bytes per
-// candidate) before it pays for the candidate's 8W bytes at a random address
-__global__ void k_sketch_gather(const uint64_t *okeys, const uint32_t *ids, uint32_t n, uint64_t *sk)
+// Bins of more than HARC_LARGEBIN reads (repeats, low-complexity sequence) get their reads copied once more in bin order, so that the
+// cooperative scan of k_steps streams 64 candidates per round trip instead of gathering them ("LDS-staged reference reads, coalesced
+// Hamming scan" of the north star, for the bins where it pays).  large_list was filled by k_table_insert: (slot index << 1) | dictionary.
+__global__ void k_large_sizes(const unsigned long long *list, uint32_t nlist, HashSlot *s0, HashSlot *s1, uint32_t *sz)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sk[i] = okeys[ids[i]];
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nlist) return;
+    const unsigned long long e = list[b];
+    const HashSlot *slot = ((e & 1) ? s1 : s0) + (e >> 1);
+    sz[b] = slot->count & SLOT_CNT_MASK;
+}
+template <int W> __global__ __launch_bounds__(64) void k_large_fill(const unsigned long long *list, uint32_t nlist, HashSlot *s0, HashSlot *s1, const uint32_t *ids0, const uint32_t *ids1,
+                                                                   const uint64_t *moff, const uint64_t *reads, uint2 *largetab, uint64_t *mirror)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nlist) return;
+    const int lane = threadIdx.x;
+    const unsigned long long e = list[b];
+    const int l = (int)(e & 1);
+    HashSlot *slot = (l ? s1 : s0) + (e >> 1);
+    const uint32_t st = slot->start, cnt = slot->count & SLOT_CNT_MASK;
+    const uint32_t *ids = (l ? ids1 : ids0) + st;
+    const uint64_t m0 = moff[b];
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        const uint32_t rid = ids[k];
+#pragma unroll
+        for (int w = 0; w < W; w++) mirror[(m0 + k) * W + w] = reads[(size_t)rid * W + w];
+    }
+    if (lane == 0) { largetab[b] = make_uint2(st, (uint32_t)m0); slot->start = b; }       // from now on the slot names its row of largetab
 }
 __global__ void k_mark_heads(const uint64_t *skeys, uint32_t n, uint32_t *head)
 {
@@ -231,6 +255,7 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
     if (i == n - 1) *nbins = binidx[i] + head[i];
 }
 #define HARC_LARGEBIN 16u    // stage-I bins with more reads than this are compacted between super-rounds (k_compact_bins)
+#define HARC_SCAN_BUDGET 32  // schedule: a walk ends after the step in which the probes it made into such bins (still holding unclaimed reads) reach this number
 // one thread per bin: claim an empty slot by CAS on the (start,count) word; keys are unique so no key compare is needed
 __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, const uint32_t *nbins_p, uint32_t n,
                                HashSlot *slots, uint64_t cap, int bucketed, uint32_t bigthresh,
@@ -397,9 +422,6 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
 //  (3) lane 0 records the step and bids for the read with atomicMin(step<<20 | chain); the counts are updated in registers.
 // The kernel is bound by instruction issue at large K (PMC: 85 % of the SIMD issue slots, profiles/r02) and by dependent HBM round
 // trips at small K: both want few instructions per step.
-#ifndef HARC_BIGBIN
-#define HARC_BIGBIN 4u      // bins with more reads than this are scanned by the whole wave
-#endif
 #ifndef HARC_STEPS_WAVES
 #define HARC_STEPS_WAVES 5       // many chains: 5 waves / SIMD (96 VGPRs, 16 dwords of scratch): +5 % over 4 waves, 6 waves spill too much; reads of more than 128 bases: 4
 #endif
@@ -511,7 +533,7 @@ template <int W> __device__ __forceinline__ void cons_rows(const ConsState<W> &s
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1)) void k_steps(S1Args s)
+template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 2 : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1))) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
     constexpr int FIRSTMAX = QUAD ? 64 : 32;
@@ -552,7 +574,8 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
     ChainHdr h = s.hdr[c];
     uint4 cst = s.cstat[c];
     if (!(h.flags & CH_ACTIVE)) return;
-    if (s.need[c]) {
+    if (COOP && !(h.flags & CH_COOP)) return;
+    if (!COOP && s.need[c]) {
         // the chain asked for a seed last super-round and k_reseed ranked it: take seed number `rank` (reorder.cpp:650-688), or finish
         const uint32_t r = s.needrank[c], R = s.rmeta[0], assigned = s.rmeta[1], got = s.rmeta[2];
         if (h.flags & CH_PREVUNM) {                               // previous seed found nothing: singleton (reorder.cpp:672-684)
@@ -578,7 +601,11 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
     uint4 *B0 = s.cnt + ((size_t)par * s.K + c) * LP;            // state at the start of this super-round (rollback point)
     uint4 *B1 = s.cnt + ((size_t)(par ^ 1u) * s.K + c) * LP;     // state at its end
     ConsState<W> st;
-    if (h.mode == 2) {                                           // fresh seed (reorder.cpp:875-883)
+    const int T0 = COOP ? (int)(h.nsteps & 0xFF) : 0;           // COOP: the one step the main kernel stopped in front of
+    if (COOP) {
+        cons_load<W>(st, T0 > 0 ? B1 : B0, L, lane);
+        if (lane < T0) ownreg = s.steps[(size_t)c * 64 + lane].x;
+    } else if (h.mode == 2) {                                    // fresh seed (reorder.cpp:875-883)
         uint64_t rw[W];
 #pragma unroll
         for (int w = 0; w < W; w++) rw[w] = s.reads[(size_t)h.cur * W + w];
@@ -606,18 +633,19 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
             }
         }
     }
-    if (h.mode != 0) cons_store<W>(st, B0, L, lane);             // B0 now holds the rollback point of this super-round
+    if (!COOP && h.mode != 0) cons_store<W>(st, B0, L, lane);    // B0 now holds the rollback point of this super-round
 
     uint32_t *const rowF = s_rows + (size_t)wv * 2 * ROW, *const rowR = rowF + ROW, *const rdl = s_rdl + (size_t)wv * MROW;
     uint8_t *const coltmp = reinterpret_cast<uint8_t *>(s_tmp + (size_t)wv * 8 * NW);
     const uint64_t kmask0 = s.kbits[0] < 64 ? (((uint64_t)1 << s.kbits[0]) - 1) : ~(uint64_t)0, kmask1 = s.kbits[1] < 64 ? (((uint64_t)1 << s.kbits[1]) - 1) : ~(uint64_t)0;
     const uint64_t cap = s.cap[0];                               // both dictionaries have the same geometry (stage1_run_w)
-    uint32_t dbg_bins = 0, dbg_iter = 0, dbg_miss = 0, dbg_surv = 0, dbg_batches = 0;   // coop scans / their 64-entry chunks / steps without a hit / sketch survivors / batches
+    uint32_t dbg_bins = 0, dbg_iter = 0, dbg_miss = 0, dbg_surv = 0, dbg_batches = 0;   // coop scans / their 64-entry chunks / steps without a hit / (unused) / batches
     uint32_t np = 0, nc = 0, nuse = 0, ncu = 0;                   // ncu: candidates a strictly sequential scan (reorder.cpp:517-649) would have tested too
-    int nst = 0; bool needseed = false;
+    int nst = 0; bool needseed = false, defer = false;
     int lastp = (int)(h.pad0 & 0xFFFF);                          // priority index of this chain's previous hit
     int spos = (int)((h.nsteps >> 16) & 0xFF); const int nsugg = (int)(h.nsteps >> 24);   // look-ahead seeds: next to try / held
-    for (int t = 0; t < s.S; t++) {
+    int bigprobes = 0;                                           // COOP: probes into large live bins made by this walk so far
+    for (int t = T0; t < s.S; t++) {
         cons_rows<W>(st, L, lane, coltmp, rowF, rowR);            // consensus and its reverse complement -> the wave's window rows
         uint32_t found = HARC_NONE; int fj = 0, fdir = 0;
         // Probes are issued in priority order in batches: every probe behind the first hit of a batch is speculative traffic,
@@ -687,15 +715,16 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                 if (state == 2 && !(cw & SLOT_DEAD)) {                    // SLOT_DEAD: every read of this bin is already claimed
                     const uint32_t cntb = cw & SLOT_CNT_MASK;
                     const bool emb = (cw & SLOT_EMB) != 0;                // single-read bin: `start` IS the read id
-                    // the lane-serial scan below never closes the maxsearch window (reorder.cpp:540) -- its bins are no larger than that
-                    const uint32_t bigthr = (uint32_t)s.maxsearch < HARC_BIGBIN ? (uint32_t)s.maxsearch : HARC_BIGBIN;
-                    if (cntb > bigthr && !emb) { big = true; b_sst = sst; b_cnt = cw & (SLOT_CNT_MASK | SLOT_OVF); b_slot = sl + qhit; }
+                    // bins of more than HARC_LARGEBIN reads (at build time) are scanned by the whole wave, and only by the COOP kernel
+                    if (cw & SLOT_BIG) { big = true; b_sst = sst; b_cnt = cw & (SLOT_CNT_MASK | SLOT_OVF | SLOT_BIG); b_slot = sl + qhit; }
                     else {
                         const uint32_t *const ids = l ? s.ids[1] : s.ids[0];
                         const uint32_t *const mrow = s_mask + (pi.y >> 16);
                         const int bitoff = (int)(pi.y & 0xFFFF);
-                        uint32_t lead = 0; bool alltop = true;
-                        for (uint32_t i = cntb; i > 0; i--) {
+                        // at most HARC_LARGEBIN reads: the maxsearch window (reorder.cpp:540) cannot close unless maxsearch itself is that small
+                        const bool exactwin = s.maxsearch < (int)HARC_LARGEBIN;
+                        uint32_t lead = 0; bool alltop = true; int seen = 0;
+                        for (uint32_t i = cntb; i > 0 && seen < s.maxsearch; i--) {
                             const uint32_t rid = emb ? sst : ids[sst + i - 1];
                             // claim bit and read words are fetched together (one dependent hop instead of two)
                             const unsigned long long cwd = s.claimed[rid >> 6];
@@ -704,11 +733,11 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                             alltop = false;
                             const int hd = ham_window<W>(rowF, bitoff, mrow, mrd);
                             // taken by this chain earlier in this super-round? (not in the frozen bitmap).  Such a read is not a candidate at
-                            // all (it does not count); asked only when the distance would accept it
+                            // all (it does not count); asked only when the answer matters
                             bool own = false;
-                            if (hd <= s.thresh) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
+                            if (exactwin || hd <= s.thresh) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
                             if (own) continue;
-                            nc++; ncb++;
+                            nc++; ncb++; if (exactwin) seen++;
                             if (hd <= s.thresh) { mine = rid; break; }
                         }
                         // hints only (the claim bitmap stays the truth): claimed reads at the top of a bin are never looked at again
@@ -732,91 +761,80 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
                     }
                 }
             }
-            // ---- big bins (low-complexity k-mers, repeats): the whole wave scans the bin, 64 candidates per round trip, in the same
-            //      order and with the same maxsearch window as the lane-serial scan.  Only lanes that outrank the best hit so far matter.
+            // ---- bins of more than HARC_LARGEBIN reads (low-complexity k-mers, repeats).  Schedule rule (the oracle has the same
+            //      one): the probes a walk makes into such bins -- not yet exhausted, up to and including the winning probe of the step --
+            //      are counted, and the walk ends after the step in which they reach HARC_SCAN_BUDGET (a boundary of a low-complexity run
+            //      costs dozens of such probes per step, a run of duplicates one).  The main kernel stops in front of the first such step
+            //      (CH_COOP); k_steps<W, QUAD, COOP = true> then goes on with the walk, the whole wave scanning the bins: 64 candidates per round trip from the bin-ordered copy of
+            //      their reads (k_large_fill), in the same order and with the same maxsearch window as a lane-serial scan, and the probes
+            //      of the step that look into the SAME bin (every shift of a poly-A consensus has the same key) share one pass over it.
             {
                 unsigned long long bigm = __ballot(big);
                 if (winlane < 64) bigm &= (1ULL << winlane) - 1ULL;
-                while (bigm) {
+                if (!COOP) { if (bigm) { defer = true; break; } }
+                else while (bigm) {
                     const int bl = __ffsll((long long)bigm) - 1;
-                    bigm &= bigm - 1; dbg_bins++;
                     const uint32_t o_sst = (uint32_t)__builtin_amdgcn_readlane((int)b_sst, bl), o_raw = (uint32_t)__builtin_amdgcn_readlane((int)b_cnt, bl), o_cnt = o_raw & SLOT_CNT_MASK;
-                    const int o_j = __builtin_amdgcn_readlane(j, bl), o_dir = __builtin_amdgcn_readlane(dir, bl), o_l = __builtin_amdgcn_readlane(l, bl);
+                    const int o_l = __builtin_amdgcn_readlane(l, bl);
                     const uint64_t o_slot = shfl_u64(b_slot, bl);
+                    unsigned long long grp = __ballot(big && l == o_l && b_slot == o_slot) & bigm;     // the probes into this bin, bl among them
+                    bigm &= ~grp;
+                    dbg_bins++;
                     const uint32_t *oids = s.ids[o_l];
-                    const uint64_t *osk = s.sk[o_l];
-                    const uint32_t *const orow = o_dir ? rowR : rowF;
-                    const uint32_t *const omrow = s_mask + (size_t)(o_dir * s.maxmatch + o_j) * MROW;
-                    const int obit = 32 * NW + (o_dir ? -2 * o_j : 2 * o_j);
-                    // what the candidate's sketch (its key of the OTHER dictionary) must look like: that dictionary's window of the (reverse)
-                    // consensus at this shift, compared on the bases that lie inside the overlap.  More than `thresh` differing bits there
-                    // already decide the full test (reorder.cpp:543,608) -- without touching the candidate's words.
-                    uint64_t expect, smask;
-                    {
-                        const int ol = o_l ^ 1, ods = s.ds[ol], olen = s.kbits[ol] >> 1;
-                        const int koff = 32 * NW + (o_dir ? 2 * (ods - o_j) : 2 * (ods + o_j));
-                        const int i0 = koff >> 5, shb = koff & 31;
-                        const uint32_t d0 = orow[i0], d1 = orow[i0 + 1], d2 = orow[i0 + 2];
-                        expect = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, shb) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, shb) << 32);
-                        const uint64_t full = olen >= 32 ? ~(uint64_t)0 : (((uint64_t)1 << (2 * olen)) - 1);
-                        if (!o_dir) { int nv = L - o_j - ods; nv = nv < 0 ? 0 : (nv > olen ? olen : nv); smask = nv >= 32 ? ~(uint64_t)0 : (((uint64_t)1 << (2 * nv)) - 1); }
-                        else { int ns = o_j - ods; ns = ns < 0 ? 0 : (ns > olen ? olen : ns); smask = ns >= 32 ? 0 : (full & ~(((uint64_t)1 << (2 * ns)) - 1)); }
-                        smask &= full;
-                    }
-                    // bins that fit the maxsearch window (reorder.cpp:540) never close it: only the candidates that pass the sketch need
-                    // their claim bit (and their words).  Larger bins count the unclaimed reads exactly, as the lane-serial scan would.
+                    const uint2 lt = s.largetab[o_sst];
+                    const uint32_t ids0 = lt.x, m0 = lt.y;
+                    // while the bin fits the maxsearch window (reorder.cpp:540) the window never closes: the claim bit is only asked of the
+                    // candidates that pass the Hamming test.  Above it the unclaimed reads are counted exactly, as the lane-serial scan would.
                     const bool fast = o_cnt <= (uint32_t)s.maxsearch;
-                    int seen = 0; uint32_t pos = o_cnt, lead = 0; bool alltop = true, bighit = false;
-                    while (pos > 0 && seen < s.maxsearch) {
+                    int seen = 0, besthit = 64; uint32_t pos = o_cnt;
+                    while (pos > 0 && seen < s.maxsearch && grp) {
                         const bool valid = (uint32_t)lane < pos; dbg_iter++;
-                        uint32_t rid = 0; uint64_t sv = 0;
-                        if (valid) { rid = oids[o_sst + pos - 1 - lane]; sv = osk[o_sst + pos - 1 - lane]; }
-                        const bool skok = valid && __popcll((sv ^ expect) & smask) <= s.thresh;
-                        dbg_surv += (uint32_t)__popcll(__ballot(skok));
-                        bool clm = true, own = false;
-                        unsigned long long um = 0; bool elig = skok;
-                        if (!fast) {                                          // exact window: claim state of every entry of the chunk
+                        const uint32_t at = pos - 1 - (uint32_t)lane;
+                        uint32_t rid = 0; bool clm = true, own = false, cand = false, checked = !fast;
+                        unsigned long long um = 0;
+                        if (valid) rid = oids[ids0 + at];
+                        if (fast) cand = valid;
+                        else {
                             if (valid) clm = ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
                             if (valid && !clm) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
                             const bool un = valid && !clm && !own;
                             um = __ballot(un);
-                            elig = un && (seen + __popcll(um & ((1ULL << lane) - 1ULL)) < s.maxsearch);
-                            if (elig) { nc++; ncu++; }
-                            if (alltop) {
-                                const unsigned long long cm = __ballot(valid && clm), vm = __ballot(valid);
-                                if (cm == vm) lead += (uint32_t)__popcll(vm); else { lead += (uint32_t)(__ffsll((long long)~cm) - 1); alltop = false; }
-                            }
-                            elig = elig && skok;
-                        } else if (valid) { nc++; ncu++; }                    // statistics: fast mode cannot tell claimed entries apart
-                        // the entries that passed the sketch pay for their words (and, in fast mode, their claim bit)
-                        {
+                            cand = un && (seen + __popcll(um & ((1ULL << lane) - 1ULL)) < s.maxsearch);
+                        }
+                        if (cand) load_read32<W>(s.mirror, m0 + at, mrd);          // mrd is free: the small winner is already in LDS
+                        unsigned long long gm = grp;
+                        while (gm) {                                               // the probes of this bin, highest priority first
+                            const int g = __ffsll((long long)gm) - 1;
+                            gm &= gm - 1;
+                            const int g_j = __builtin_amdgcn_readlane(j, g), g_dir = __builtin_amdgcn_readlane(dir, g);
+                            const uint32_t *const omrow = s_mask + (size_t)(g_dir * s.maxmatch + g_j) * MROW;
+                            const int obit = g_dir * ROW * 32 + 32 * NW + (g_dir ? -2 * g_j : 2 * g_j);
                             bool ok = false;
-                            if (elig) {
-                                if (fast) clm = ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
-                                load_read32<W>(s.reads, rid, mrd);             // mrd is free: the small winner is already in LDS
-                                if (fast && !clm) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
-                                ok = !clm && !own && ham_window<W>(orow, obit, omrow, mrd) <= s.thresh;
+                            if (cand) { nc++; ncu++; ok = ham_window<W>(rowF, obit, omrow, mrd) <= s.thresh; }   // statistics: fast mode does not tell claimed entries apart
+                            if (ok && !checked) {
+                                clm = ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
+                                if (!clm) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
+                                checked = true;
                             }
+                            ok = ok && !clm && !own;
                             const unsigned long long pm = __ballot(ok);
                             if (pm) {
                                 const int wl = __ffsll((long long)pm) - 1;
-                                found = (uint32_t)__builtin_amdgcn_readlane((int)rid, wl); fj = o_j; fdir = o_dir; winlane = bl; bighit = true;
+                                found = (uint32_t)__builtin_amdgcn_readlane((int)rid, wl); fj = g_j; fdir = g_dir; besthit = g;
                                 if (lane == wl) {
 #pragma unroll
                                     for (int k = 0; k < NW; k++) rdl[k] = mrd[k];
                                 }
+                                grp &= (1ULL << g) - 1ULL;                         // this probe is settled, the ones behind it are beaten; the ones before it go on
+                                break;
                             }
                         }
-                        if (bighit) break;
                         if (!fast) seen += __popcll(um);
                         pos -= pos > 64 ? 64 : pos;
                     }
-                    if (lead && lane == 0) {
-                        uint32_t *cp = reinterpret_cast<uint32_t *>(&s.slots[o_l][o_slot]) + 3;
-                        if (lead == o_cnt) atomicOr(cp, SLOT_DEAD); else atomicMin(cp, (o_cnt - lead) | (o_raw & SLOT_OVF));
-                    }
-                    if (bighit) break;
+                    if (besthit < 64) { winlane = besthit; bigm &= (1ULL << besthit) - 1ULL; }
                 }
+                if (COOP) bigprobes += __popcll(__ballot(big) & (winlane < 64 ? ((2ULL << winlane) - 1ULL) : ~0ULL));   // the probes up to and including the winning one
             }
             if (lane <= winlane) ncu += ncb;                              // lanes behind the winner were speculation (winlane = 64: no hit, all count)
             if (found != HARC_NONE) {
@@ -826,6 +844,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
             }
             base = bend;
         }
+        if (defer) break;
         if (found == HARC_NONE) {
             // no candidate: go on from the chain's look-ahead seeds (highest id first, skipping what was claimed meanwhile) -- the new
             // seed of reorder.cpp:652-668 without waiting for the next k_reseed
@@ -853,6 +872,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
             __builtin_amdgcn_wave_barrier();
             cons_reset_lds<W>(st, rdl, L, lane);
             nst++;
+            if (COOP && bigprobes >= HARC_SCAN_BUDGET) break;
             continue;
         }
         if (lane == 0) {
@@ -864,6 +884,7 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
         __builtin_amdgcn_wave_barrier();
         cons_update_lds<W>(st, rdl, L, fdir, fj, lane);
         nst++;
+        if (COOP && bigprobes >= HARC_SCAN_BUDGET) break;
     }
     if (nst > 0) cons_store<W>(st, B1, L, lane);
     np = wave_sum_u32(np); nc = wave_sum_u32(nc); ncu = wave_sum_u32(ncu);
@@ -871,9 +892,10 @@ template <int W, bool QUAD> __global__ __launch_bounds__(256, QUAD ? HARC_STEPS_
     if (lane == 0) {
         cst.x += np; cst.y += nc; cst.z += nuse; cst.w += ncu; s.cstat[c] = cst;
         h.mode = 0;
-        h.nsteps = (h.nsteps & 0xFFFF0000u) | (uint32_t)nst;
+        h.nsteps = (h.nsteps & 0xFFFF0000u) | (uint32_t)(T0 + nst);
         h.pad0 = ((uint32_t)lastp & 0xFFFFu) | ((uint32_t)spos << 16);
         h.flags = needseed ? (h.flags | CH_NEEDSEED) : (h.flags & ~CH_NEEDSEED);
+        h.flags = defer ? (h.flags | CH_COOP) : (h.flags & ~CH_COOP);
         s.hdr[c] = h;
     }
 }
@@ -1041,7 +1063,7 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
 // only shrinks from the top (hints).  In repeats and low-complexity sequence a bin holds thousands of reads and every scan would wade
 // through the claimed ones again: between super-rounds one wave per large bin packs the unclaimed ids to the front of the bin (order
 // kept) and lowers the count.  What a scan sees -- the unclaimed reads of the bin, highest id first -- does not change.
-__global__ __launch_bounds__(64) void k_compact_bins(S1Args s, const unsigned long long *list, uint32_t nlist)
+template <int W> __global__ __launch_bounds__(64) void k_compact_bins(S1Args s, const unsigned long long *list, uint32_t nlist)
 {
     const uint32_t b = blockIdx.x;
     if (b >= nlist) return;
@@ -1051,17 +1073,26 @@ __global__ __launch_bounds__(64) void k_compact_bins(S1Args s, const unsigned lo
     HashSlot *slot = &s.slots[l][si];
     const uint32_t cw = slot->count;
     if (cw & SLOT_DEAD) return;
-    const uint32_t cnt = cw & SLOT_CNT_MASK, st = slot->start;
-    uint32_t *ids = const_cast<uint32_t *>(s.ids[l]) + st;
-    uint64_t *sk = const_cast<uint64_t *>(s.sk[l]) + st;
+    const uint32_t cnt = cw & SLOT_CNT_MASK;
+    const uint2 lt = s.largetab[b];                               // the slot's `start` is b (k_large_fill)
+    uint32_t *ids = const_cast<uint32_t *>(s.ids[l]) + lt.x;
+    uint64_t *mir = s.mirror + (size_t)lt.y * W;
     uint32_t out = 0;
     for (uint32_t pos = 0; pos < cnt; pos += 64) {
         const bool valid = pos + lane < cnt;
-        uint32_t rid = 0; uint64_t sv = 0; bool un = false;
-        if (valid) { rid = ids[pos + lane]; sv = sk[pos + lane]; un = !((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL); }
+        uint32_t rid = 0; bool un = false; uint64_t rw[W];
+        if (valid) {
+            rid = ids[pos + lane]; un = !((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL);
+#pragma unroll
+            for (int w = 0; w < W; w++) rw[w] = mir[(size_t)(pos + lane) * W + w];
+        }
         const unsigned long long um = __ballot(un);
-        const uint32_t at = out + (uint32_t)__popcll(um & ((1ULL << lane) - 1ULL));     // out <= pos: never ahead of the reads of this pass
-        if (un) { ids[at] = rid; sk[at] = sv; }
+        const uint32_t at = out + (uint32_t)__popcll(um & ((1ULL << lane) - 1ULL));     // out <= pos: never ahead of the entries of this pass
+        if (un) {
+            ids[at] = rid;
+#pragma unroll
+            for (int w = 0; w < W; w++) mir[(size_t)at * W + w] = rw[w];
+        }
         out += (uint32_t)__popcll(um);
     }
     if (lane == 0 && out < cnt) {
@@ -1214,7 +1245,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const harc_mark_t mark_results = harc_pool_mark(c);
     // ---- dictionaries (constructdictionary, reorder.cpp:277-394)
     DictDev dict[2];
-    unsigned long long *d_large = nullptr; unsigned int *d_nlarge = nullptr; uint64_t *d_sk[2] = { nullptr, nullptr };
+    unsigned long long *d_large = nullptr; unsigned int *d_nlarge = nullptr;
     const uint32_t maxlarge = 2 * (N / HARC_LARGEBIN) + 16;
     if (N) {
         RC_TRY(harc_dict_alloc(c, &dict[0], N, 0)); RC_TRY(harc_dict_alloc(c, &dict[1], N, dict[0].cap));
@@ -1222,20 +1253,15 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         RC_TRY(dalloc(c, &d_large, maxlarge)); RC_TRY(dalloc(c, &d_nlarge, 4));
         HIP_TRY(hipMemsetAsync(d_nlarge, 0, 16, c->stream));
         for (int l = 0; l < 2; l++) { dict[l].large_list = d_large; dict[l].large_n = d_nlarge; dict[l].large_max = maxlarge; dict[l].large_tag = (uint32_t)l; }
-        RC_TRY(dalloc(c, &d_sk[0], (size_t)N + 1)); RC_TRY(dalloc(c, &d_sk[1], (size_t)N + 1));
+        dict[0].bigthresh = dict[1].bigthresh = HARC_LARGEBIN;     // SLOT_BIG: the bin gets a row of largetab and its reads in `mirror`
         const harc_mark_t mk = harc_pool_mark(c);
-        uint64_t *kk[2] = { nullptr, nullptr }; uint32_t *i0 = nullptr;
-        RC_TRY(dalloc(c, &kk[0], N)); RC_TRY(dalloc(c, &kk[1], N)); RC_TRY(dalloc(c, &i0, N));
+        uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
+        RC_TRY(dalloc(c, &k0, N)); RC_TRY(dalloc(c, &i0, N));
         for (int l = 0; l < 2; l++) {
             const int kbits = 2 * (P.dict_end[l] - P.dict_start[l] + 1);
-            hipLaunchKernelGGL((k_keygen<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[l], kbits, kk[l], i0);
-            RC_TRY(harc_dict_build(c, &dict[l], kk[l], i0, N, (unsigned)kbits));
+            hipLaunchKernelGGL((k_keygen<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[l], kbits, k0, i0);
+            RC_TRY(harc_dict_build(c, &dict[l], k0, i0, N, (unsigned)kbits));
         }
-        // sketches of the bin scan: the other dictionary's key of every entry, in bin order
-        for (int l = 0; l < 2; l++)
-            hipLaunchKernelGGL(k_sketch_gather, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)kk[l ^ 1], (const uint32_t *)dict[l].ids, N, d_sk[l]);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c->stream));
         harc_pool_release(c, mk);
     }
     // bins large enough to be worth compacting between super-rounds were listed by k_table_insert (none on ordinary data)
@@ -1243,7 +1269,24 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (N) {
         HIP_TRY(hipMemcpyAsync(&nlarge, d_nlarge, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (nlarge > maxlarge) nlarge = maxlarge;
+        if (nlarge > maxlarge) { harc_set_error("stage I: %u bins above %u reads, list of %u", nlarge, HARC_LARGEBIN, maxlarge); return HARC_AMD_ENODEVICE; }   // cannot happen: 2 N / HARC_LARGEBIN bound
+    }
+    // their reads once more, in bin order (k_large_fill); nothing on ordinary data
+    uint2 *d_largetab = nullptr; uint64_t *d_mirror = nullptr;
+    if (nlarge) {
+        uint32_t *sz = nullptr; uint64_t *moff = nullptr;
+        RC_TRY(dalloc(c, &d_largetab, nlarge)); RC_TRY(dalloc(c, &sz, (size_t)nlarge + 1)); RC_TRY(dalloc(c, &moff, (size_t)nlarge + 1));
+        HIP_TRY(hipMemsetAsync(sz + nlarge, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_large_sizes, dim3((nlarge + 255) / 256), dim3(256), 0, c->stream, (const unsigned long long *)d_large, nlarge, dict[0].slots, dict[1].slots, sz);
+        RC_TRY(prim_excl_scan_u32_to_u64(c, sz, moff, (size_t)nlarge + 1));
+        uint64_t mtotal = 0;
+        HIP_TRY(hipMemcpyAsync(&mtotal, moff + nlarge, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (mtotal > 0xFFFFFFFFull) { harc_set_error("stage I: more than 2^32 reads in large bins"); return HARC_AMD_EINVAL; }
+        RC_TRY(dalloc(c, &d_mirror, (size_t)mtotal * W + 1));
+        hipLaunchKernelGGL((k_large_fill<W>), dim3(nlarge), dim3(64), 0, c->stream, (const unsigned long long *)d_large, nlarge, dict[0].slots, dict[1].slots,
+                           (const uint32_t *)dict[0].ids, (const uint32_t *)dict[1].ids, (const uint64_t *)moff, (const uint64_t *)c->d_reads, d_largetab, d_mirror);
+        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e1, c->stream));
 
@@ -1255,7 +1298,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (const char *e = getenv("HARC_AMD_NSUGG")) { a.nsugg_per_seed = atoi(e); if (a.nsugg_per_seed < 0) a.nsugg_per_seed = 0; if (a.nsugg_per_seed > HARC_NSUGG) a.nsugg_per_seed = HARC_NSUGG; }
     for (int l = 0; l < 2; l++) { a.ds[l] = P.dict_start[l]; a.de[l] = P.dict_end[l]; a.kbits[l] = 2 * (P.dict_end[l] - P.dict_start[l] + 1); }
     a.N = N; a.K = K; a.reads = c->d_reads;
-    for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; a.sk[l] = d_sk[l]; }
+    for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
+    a.largetab = d_largetab; a.mirror = d_mirror;
     const size_t nwords = (size_t)N / 64 + 2;
     const uint32_t nblk = (K + 255) / 256;
     RC_TRY(dalloc(c, &a.claimed, nwords)); RC_TRY(dalloc(c, &a.bid, (size_t)N + 1)); RC_TRY(dalloc(c, &a.hdr, K));
@@ -1294,6 +1338,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     hipLaunchKernelGGL(k_init_chains, dim3(nblk), dim3(256), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
 
+    // SLOT_DEAD of the large bins must say "no unclaimed read" from the first super-round on (the seeds of k_init_chains are claimed)
+    if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge);
     // ---- rounds
     const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe);
     unsigned long long *h_stats = nullptr;
@@ -1305,14 +1351,16 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     for (;;) {
         for (int r = 0; r < batch; r++) {
             if (prof) { hipEvent_t a0, a1; HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1)); ev.push_back(a0); ev.push_back(a1); HIP_TRY(hipEventRecord(a0, c->stream)); }
-            if (quad) hipLaunchKernelGGL((k_steps<W, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
-            else hipLaunchKernelGGL((k_steps<W, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
+            if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
+            else hipLaunchKernelGGL((k_steps<W, false, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             if (prof) HIP_TRY(hipEventRecord(ev.back(), c->stream));
+            // the steps that have to scan a large bin (none without such bins: the launch is skipped)
+            if (nlarge) hipLaunchKernelGGL((k_steps<W, true, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
             else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve<32>), dim3((K + 7) / 8), dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((k_resolve<64>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
             hipLaunchKernelGGL(k_reseed, dim3(1), dim3(1024), 0, c->stream, a);
-            if (nlarge) hipLaunchKernelGGL(k_compact_bins, dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge);
+            if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge);
             launches++;
         }
         rounds += batch;

@@ -38,6 +38,8 @@
 #define NONE 0xFFFFFFFFu
 #define MAXSTEPS 64
 #define NSUGG 4           /* look-ahead seeds handed to a chain at every reseed */
+#define LARGEBIN 16u      /* HARC_LARGEBIN of harc_amd/csrc/stage1.hip */
+#define SCAN_BUDGET 32     /* HARC_SCAN_BUDGET: a walk ends after the step in which its probes into bins of more than LARGEBIN reads (not yet exhausted) reach this number */
 
 /* ------------------------------------------------------------------ parameters (harc:52-60) */
 typedef struct {
@@ -91,6 +93,8 @@ typedef struct {
     uint32_t *start;     /* nkeys+1 */
     uint32_t *ids;       /* ascending inside a bin (reorder.cpp:372-384) */
     uint32_t *live_end;  /* hint: entries at/above live_end[bin] are all claimed */
+    uint32_t *binof;     /* per read id: its bin */
+    uint32_t *nlive;     /* per bin: reads not yet claimed */
     uint32_t hmask; uint32_t *hslot;   /* open addressing key -> bin+1 */
 } dict_t;
 
@@ -113,14 +117,14 @@ static void dict_build(dict_t *d, const uint64_t *keys, uint32_t n)
     for (uint32_t i = 0; i < n; i++) if (i == 0 || kv[i].key != kv[i - 1].key) nk++;
     d->nkeys = nk;
     d->keys = malloc(8 * (size_t)nk); d->start = malloc(4 * ((size_t)nk + 1)); d->ids = malloc(4 * (size_t)n);
-    d->live_end = malloc(4 * (size_t)nk);
+    d->live_end = malloc(4 * (size_t)nk); d->binof = malloc(4 * (size_t)n); d->nlive = malloc(4 * (size_t)nk);
     uint32_t b = 0;
     for (uint32_t i = 0; i < n; i++) {
         if (i == 0 || kv[i].key != kv[i - 1].key) { d->keys[b] = kv[i].key; d->start[b] = i; b++; }
-        d->ids[i] = kv[i].id;
+        d->ids[i] = kv[i].id; d->binof[kv[i].id] = b - 1;
     }
     d->start[nk] = n;
-    for (uint32_t i = 0; i < nk; i++) d->live_end[i] = d->start[i + 1];
+    for (uint32_t i = 0; i < nk; i++) { d->live_end[i] = d->start[i + 1]; d->nlive[i] = d->start[i + 1] - d->start[i]; }
     uint32_t cap = 16; while (cap < 2 * nk) cap <<= 1;
     d->hmask = cap - 1; d->hslot = calloc(cap, 4);
     for (uint32_t i = 0; i < nk; i++) {
@@ -130,7 +134,7 @@ static void dict_build(dict_t *d, const uint64_t *keys, uint32_t n)
     }
     free(kv);
 }
-static void dict_free(dict_t *d) { free(d->keys); free(d->start); free(d->ids); free(d->live_end); free(d->hslot); memset(d, 0, sizeof *d); }
+static void dict_free(dict_t *d) { free(d->keys); free(d->start); free(d->ids); free(d->live_end); free(d->hslot); free(d->binof); free(d->nlive); memset(d, 0, sizeof *d); }
 static uint32_t dict_lookup(const dict_t *d, uint64_t key)
 {
     if (!d->nkeys) return NONE;
@@ -150,6 +154,7 @@ typedef struct {
     vec32 m_order, m_meta; /* main stream: order; meta = pos | flag<<8 | rc<<9 */
     vec32 s_order;         /* singleton stream */
     uint32_t p_rid; int p_j, p_dir;   /* proposal of the current step */
+    int p_big;                        /* probes of the step, up to and including the winning one, into bins of more than LARGEBIN reads that still had unclaimed ones */
     /* super-round: up to MAXSTEPS speculative steps against the frozen claim state */
     uint32_t s_rid[MAXSTEPS]; uint8_t s_j[MAXSTEPS], s_dir[MAXSTEPS], s_kind[MAXSTEPS], s_sidx[MAXSTEPS]; int nsteps, need_reseed;
     uint32_t sugg[NSUGG]; int nsugg, sugg_pos;   /* unclaimed ids right below the cursor at the chain's last reseed, highest first */
@@ -226,7 +231,7 @@ static void propose(chain_t *c, dict_t *dict, const uint64_t *reads, const uint8
         rev[(2 * k) >> 6] |= (uint64_t)idx_to_pc[3 - c->cons[i]] << ((2 * k) & 63);
     }
     topmask = ((2 * L) & 63) ? ((((uint64_t)1) << ((2 * L) & 63)) - 1) : ~(uint64_t)0;
-    c->p_rid = NONE;
+    c->p_rid = NONE; c->p_big = 0;
     for (int j = 0; j < p->maxmatch; j++) {
         for (int l = 0; l < 2; l++) {                             /* forward, reorder.cpp:520-580 */
             if (p->de[l] + j >= L) continue;
@@ -234,6 +239,7 @@ static void propose(chain_t *c, dict_t *dict, const uint64_t *reads, const uint8
             st->probes++;
             uint32_t bin = dict_lookup(&dict[l], key);
             if (bin == NONE) continue;
+            if (dict[l].start[bin + 1] - dict[l].start[bin] > LARGEBIN && dict[l].nlive[bin] > 0) c->p_big++;
             uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, ref, mask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands, own, nown);
             if (rid != NONE) { c->p_rid = rid; c->p_j = j; c->p_dir = 0; return; }
         }
@@ -243,6 +249,7 @@ static void propose(chain_t *c, dict_t *dict, const uint64_t *reads, const uint8
             st->probes++;
             uint32_t bin = dict_lookup(&dict[l], key);
             if (bin == NONE) continue;
+            if (dict[l].start[bin + 1] - dict[l].start[bin] > LARGEBIN && dict[l].nlive[bin] > 0) c->p_big++;
             uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, rev, revmask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands, own, nown);
             if (rid != NONE) { c->p_rid = rid; c->p_j = j; c->p_dir = 1; return; }
         }
@@ -290,6 +297,7 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
         for (int b = 2 * j; b < 2 * L; b++) revmask[(size_t)j * W + (b >> 6)] |= (uint64_t)1 << (b & 63);
     }
     uint8_t *claimed = calloc((size_t)N + 1, 1);
+#define CLAIM(r) do { uint32_t r_ = (r); claimed[r_] = 1; dict[0].nlive[dict[0].binof[r_]]--; dict[1].nlive[dict[1].binof[r_]]--; } while (0)
     uint32_t *bid = malloc(4 * ((size_t)N + 1));
     for (uint32_t i = 0; i < N; i++) bid[i] = NONE;
     chain_t *ch = calloc(K, sizeof(chain_t));
@@ -301,7 +309,7 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
         uint32_t cur = firstread;
         if (N == 0 || claimed[cur]) x->active = 0;
         else {
-            claimed[cur] = 1; out->unmatched++; x->active = 1; x->cur = cur; x->prev = cur; x->prev_unmatched = 1;
+            CLAIM(cur); out->unmatched++; x->active = 1; x->cur = cur; x->prev = cur; x->prev_unmatched = 1;
             cons_reset(x, reads + (size_t)cur * W, L); nactive++;
         }
         firstread += N / K;
@@ -315,7 +323,7 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
             if (!x->active) continue;
             memcpy(x->count0, x->count, sizeof(int32_t) * 4 * L); memcpy(x->cons0, x->cons, L);
             x->nsteps = 0; x->need_reseed = 0;
-            int spos = x->sugg_pos;
+            int spos = x->sugg_pos, bigprobes = 0;
             for (uint32_t t = 0; t < nsteps; t++) {
                 propose(x, dict, reads, claimed, p, mask, revmask, out, x->s_rid, x->nsteps);
                 uint32_t key = (t << 20) | c;
@@ -324,6 +332,8 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
                     x->nsteps = (int)t + 1;
                     if (key < bid[x->p_rid]) bid[x->p_rid] = key;
                     cons_update(x, reads + (size_t)x->p_rid * W, L, x->p_dir, x->p_j);
+                    bigprobes += x->p_big;
+                    if (bigprobes >= SCAN_BUDGET) break;              /* schedule rule: the budget of probes into large bins */
                     continue;
                 }
                 /* no candidate: continue from the chain's look-ahead seeds, highest id first, skipping what got claimed meanwhile
@@ -340,6 +350,8 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
                 x->nsteps = (int)t + 1;
                 if (key < bid[sid]) bid[sid] = key;
                 cons_reset(x, reads + (size_t)sid * W, L);
+                bigprobes += x->p_big;
+                if (bigprobes >= SCAN_BUDGET) break;
             }
             x->p_j = spos;                                        /* scratch: look-ahead position reached by this walk */
         }
@@ -360,7 +372,7 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
             } else x->sugg_pos = x->p_j;
             for (int t = 0; t < v; t++) {
                 uint32_t k = x->s_rid[t];
-                claimed[k] = 1; x->cur = k;
+                CLAIM(k); x->cur = k;
                 if (x->s_kind[t]) {                               /* a new seed (reorder.cpp:678-687) */
                     if (x->prev_unmatched) vpush(&x->s_order, x->prev);
                     out->unmatched++; x->prev_unmatched = 1; x->prev = k;
@@ -385,7 +397,7 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
             x->nsugg = 0; x->sugg_pos = 0;
             if (!found) { x->active = 0; nactive--; x->need_reseed = 0; continue; }
             uint32_t cur = (uint32_t)remainingpos; remainingpos--;
-            claimed[cur] = 1; out->unmatched++;
+            CLAIM(cur); out->unmatched++;
             x->cur = cur; cons_reset(x, reads + (size_t)cur * W, L);
             x->prev_unmatched = 1; x->prev = cur;
             x->need_reseed = 2;                                   /* got a seed: entitled to look-ahead seeds below */
