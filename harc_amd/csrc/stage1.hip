@@ -40,6 +40,7 @@ struct S1Args {
     unsigned long long *stats;       // [0] unmatched [1] conflicts [2] active chains [3] probes [4] candidates
     const uint16_t *probe_tab;       // the probes of one chain step in priority order: shift | dir<<8 | dict<<9
     int nprobe;
+    int budget;                      // HARC_SCAN_BUDGET (experiments may override it: HARC_AMD_BUDGET)
     int nbatch, batch_end[12];       // probe batches: [0,batch_end[0]), [batch_end[0],batch_end[1]) ... each at most 64 wide
     uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups, w sequential-equivalent candidates
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
@@ -255,7 +256,7 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
     if (i == n - 1) *nbins = binidx[i] + head[i];
 }
 #define HARC_LARGEBIN 16u    // stage-I bins with more reads than this are compacted between super-rounds (k_compact_bins)
-#define HARC_SCAN_BUDGET 32  // schedule: a walk ends after the step in which the probes it made into such bins (still holding unclaimed reads) reach this number
+#define HARC_SCAN_BUDGET 16  // schedule: a walk ends after the step in which the probes it made into such bins (still holding unclaimed reads) reach this number
 // one thread per bin: claim an empty slot by CAS on the (start,count) word; keys are unique so no key compare is needed
 __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, const uint32_t *nbins_p, uint32_t n,
                                HashSlot *slots, uint64_t cap, int bucketed, uint32_t bigthresh,
@@ -787,12 +788,23 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
                     // candidates that pass the Hamming test.  Above it the unclaimed reads are counted exactly, as the lane-serial scan would.
                     const bool fast = o_cnt <= (uint32_t)s.maxsearch;
                     int seen = 0, besthit = 64; uint32_t pos = o_cnt;
+                    // software pipeline: the ids and rows of the NEXT 64 entries are requested before the current ones are tested, so that a
+                    // bin of many chunks streams instead of paying one HBM round trip per chunk
+                    uint32_t rid_n = 0, mrd_n[NW];
+#pragma unroll
+                    for (int k = 0; k < NW; k++) mrd_n[k] = 0;
+                    if ((uint32_t)lane < pos) { const uint32_t a0 = pos - 1 - (uint32_t)lane; rid_n = oids[ids0 + a0]; load_read32<W>(s.mirror, m0 + a0, mrd_n); }
                     while (pos > 0 && seen < s.maxsearch && grp) {
                         const bool valid = (uint32_t)lane < pos; dbg_iter++;
-                        const uint32_t at = pos - 1 - (uint32_t)lane;
-                        uint32_t rid = 0; bool clm = true, own = false, cand = false, checked = !fast;
+                        const uint32_t rid = rid_n;
+#pragma unroll
+                        for (int k = 0; k < NW; k++) mrd[k] = mrd_n[k];
+                        {
+                            const uint32_t npos = pos > 64 ? pos - 64 : 0;
+                            if ((uint32_t)lane < npos) { const uint32_t a1 = npos - 1 - (uint32_t)lane; rid_n = oids[ids0 + a1]; load_read32<W>(s.mirror, m0 + a1, mrd_n); }
+                        }
+                        bool clm = true, own = false, cand = false, checked = !fast;
                         unsigned long long um = 0;
-                        if (valid) rid = oids[ids0 + at];
                         if (fast) cand = valid;
                         else {
                             if (valid) clm = ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
@@ -801,8 +813,7 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
                             um = __ballot(un);
                             cand = un && (seen + __popcll(um & ((1ULL << lane) - 1ULL)) < s.maxsearch);
                         }
-                        if (cand) load_read32<W>(s.mirror, m0 + at, mrd);          // mrd is free: the small winner is already in LDS
-                        unsigned long long gm = grp;
+                        unsigned long long gm = grp; dbg_surv += (uint32_t)__popcll(grp);
                         while (gm) {                                               // the probes of this bin, highest priority first
                             const int g = __ffsll((long long)gm) - 1;
                             gm &= gm - 1;
@@ -872,7 +883,7 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
             __builtin_amdgcn_wave_barrier();
             cons_reset_lds<W>(st, rdl, L, lane);
             nst++;
-            if (COOP && bigprobes >= HARC_SCAN_BUDGET) break;
+            if (COOP && bigprobes >= s.budget) break;
             continue;
         }
         if (lane == 0) {
@@ -884,11 +895,11 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
         __builtin_amdgcn_wave_barrier();
         cons_update_lds<W>(st, rdl, L, fdir, fj, lane);
         nst++;
-        if (COOP && bigprobes >= HARC_SCAN_BUDGET) break;
+        if (COOP && bigprobes >= s.budget) break;
     }
     if (nst > 0) cons_store<W>(st, B1, L, lane);
     np = wave_sum_u32(np); nc = wave_sum_u32(nc); ncu = wave_sum_u32(ncu);
-    if (lane == 0 && s.dbg) { atomicAdd(&s.dbg[0], (unsigned long long)dbg_bins); atomicAdd(&s.dbg[1], (unsigned long long)dbg_iter); atomicAdd(&s.dbg[2], (unsigned long long)dbg_miss); atomicAdd(&s.dbg[3], (unsigned long long)dbg_surv); atomicAdd(&s.dbg[4], (unsigned long long)nst); atomicAdd(&s.dbg[5], (unsigned long long)dbg_batches); }
+    if (lane == 0 && s.dbg) { atomicAdd(&s.dbg[0], (unsigned long long)dbg_bins); atomicAdd(&s.dbg[1], (unsigned long long)dbg_iter); atomicAdd(&s.dbg[2], (unsigned long long)dbg_miss); atomicAdd(&s.dbg[3], (unsigned long long)dbg_surv); atomicAdd(&s.dbg[4], (unsigned long long)nst); atomicAdd(&s.dbg[5], (unsigned long long)dbg_batches); atomicMax(&s.dbg[6], (unsigned long long)dbg_iter); atomicMax(&s.dbg[7], (unsigned long long)dbg_surv); atomicMax(&s.dbg[8], (unsigned long long)dbg_bins); }
     if (lane == 0) {
         cst.x += np; cst.y += nc; cst.z += nuse; cst.w += ncu; s.cstat[c] = cst;
         h.mode = 0;
@@ -1315,6 +1326,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     uint16_t *d_tab = nullptr; RC_TRY(dalloc(c, &d_tab, tab.size() + 1));
     HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream));
     a.probe_tab = d_tab; a.nprobe = (int)tab.size();
+    a.budget = getenv("HARC_AMD_BUDGET") ? atoi(getenv("HARC_AMD_BUDGET")) : HARC_SCAN_BUDGET;   // not part of the C-ABI: the oracle knows the default only
     a.nbatch = 0;                                                // adaptive batches (k_steps) unless a fixed schedule is forced
     if (const char *e = getenv("HARC_AMD_BATCHES")) {             // tuning knob, e.g. "32,64"; the last size repeats
         int sizes[12], k = 0, last = 64; const char *q = e;
@@ -1419,7 +1431,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         unsigned long long d[16];
         HIP_TRY(hipMemcpy(d, dbg_ptr, sizeof d, hipMemcpyDeviceToHost));
         const double stp = (double)(d[4] ? d[4] : 1);
-        fprintf(stderr, "[k_steps] steps walked %llu (of them kept %u): per step batches %.2f, cooperative bin scans %.2f, their 64-entry chunks %.2f, sketch survivors %.2f; steps without a hit %.3f\n", d[4], N, d[5] / stp, d[0] / stp, d[1] / stp, d[3] / stp, d[2] / stp);
+        fprintf(stderr, "[k_steps] steps walked %llu (of them kept %u): per step batches %.2f, cooperative bin scans %.2f, their 64-entry chunks %.2f, chunk x probe tests %.2f; steps without a hit %.3f\n", d[4], N, d[5] / stp, d[0] / stp, d[1] / stp, d[3] / stp, d[2] / stp);
+        fprintf(stderr, "[k_steps] worst walk of the run: %llu chunks, %llu chunk x probe tests, %llu bin scans\n", d[6], d[7], d[8]);
     }
     hipHostFree(h_stats);
 

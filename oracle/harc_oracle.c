@@ -39,7 +39,7 @@
 #define MAXSTEPS 64
 #define NSUGG 4           /* look-ahead seeds handed to a chain at every reseed */
 #define LARGEBIN 16u      /* HARC_LARGEBIN of harc_amd/csrc/stage1.hip */
-#define SCAN_BUDGET 32     /* HARC_SCAN_BUDGET: a walk ends after the step in which its probes into bins of more than LARGEBIN reads (not yet exhausted) reach this number */
+#define SCAN_BUDGET 16     /* HARC_SCAN_BUDGET: a walk ends after the step in which its probes into bins of more than LARGEBIN reads (not yet exhausted) reach this number */
 
 /* ------------------------------------------------------------------ parameters (harc:52-60) */
 typedef struct {
