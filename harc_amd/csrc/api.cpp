@@ -41,6 +41,11 @@ static size_t pool_in_use(const harc_amd_ctx *c)
 int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes)
 {
     *p = nullptr;
+    if (const char *e = getenv("HARC_AMD_FAIL_ALLOC")) {           // tests: the n-th pool allocation of the process fails (error paths must leave the context usable)
+        static long long countdown = -1;
+        if (countdown < 0) countdown = atoll(e);
+        if (countdown > 0 && --countdown == 0) { harc_set_error("pool allocation refused (HARC_AMD_FAIL_ALLOC)"); return HARC_AMD_ENOMEM; }
+    }
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes == 0) bytes = 256;
     for (;;) {

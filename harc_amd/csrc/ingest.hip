@@ -125,13 +125,14 @@ extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uin
     }
     if (nbytes == 0) { if (n_records_out) *n_records_out = 0; out_buf(c, HARC_AMD_IN_ORDER_N, 0).clear(); return HARC_AMD_OK; }
     const harc_mark_t mk = harc_pool_mark(c);
+    struct Rel { harc_amd_ctx *c; harc_mark_t mk; ~Rel() { harc_pool_release(c, mk); } } rel{ c, mk };       // scratch goes on every way out
     const uint64_t *nls = nullptr; uint64_t total_lines = 0;
     RC_TRY(build_line_index(c, d_txt, nbytes, &nls, &total_lines));
     // a truncated last record still counts as a read when its sequence line is there: the getline loop handles line 2 before it meets
     // the end of the file (preprocess.cpp:90-111); only `readnum` (case 3, :118) misses it
     const uint64_t nfull = total_lines / 4;
     const uint64_t nrec64 = nfull + ((total_lines % 4) >= 2 ? 1 : 0);
-    if (nrec64 > 4294967290ull) { harc_set_error("Too many reads. HARC supports at most 4294967290 reads"); harc_pool_release(c, mk); return HARC_AMD_EINVAL; }   // preprocess.cpp:122-126
+    if (nrec64 > 4294967290ull) { harc_set_error("Too many reads. HARC supports at most 4294967290 reads"); return HARC_AMD_EINVAL; }   // preprocess.cpp:122-126
     const uint32_t nrec = (uint32_t)nrec64;
     uint32_t *isN = nullptr, *isC = nullptr, *rkN = nullptr, *rkC = nullptr; unsigned int *d_err = nullptr;
     RC_TRY(dalloc(c, &isN, (size_t)nrec + 1)); RC_TRY(dalloc(c, &isC, (size_t)nrec + 1)); RC_TRY(dalloc(c, &rkN, (size_t)nrec + 1)); RC_TRY(dalloc(c, &rkC, (size_t)nrec + 1));
@@ -147,7 +148,7 @@ extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uin
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (err) {
         printf("Read length not fixed. Found reads whose length is not %d\n", L);
-        harc_set_error("read length not fixed (%u records differ from %d)", err, L); harc_pool_release(c, mk); return HARC_AMD_EINVAL;
+        harc_set_error("read length not fixed (%u records differ from %d)", err, L); return HARC_AMD_EINVAL;
     }
     // the packed stores outlive the scratch: raw allocations (as harc_amd_set_reads_*)
     RC_TRY(harc_in_reserve(c, &c->own_reads, ((size_t)nC * c->W + 1) * 8));
@@ -165,7 +166,6 @@ extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uin
     RC_TRY(harc_d2h(c, ob, orderN, (size_t)nN * 4));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (n_records_out) *n_records_out = nfull;                    // what preprocess.cpp:134 prints: complete records
-    harc_pool_release(c, mk);
     return HARC_AMD_OK;
 }
 
@@ -224,6 +224,7 @@ static int emit_lines(harc_amd_ctx *c, const char *d_txt, const uint64_t *nls, c
     std::vector<uint8_t> host;
     for (uint64_t at = 0; at < n; at += CH) {
         const harc_mark_t mk = harc_pool_mark(c);
+        struct Rel { harc_amd_ctx *c; harc_mark_t mk; ~Rel() { harc_pool_release(c, mk); } } rel{ c, mk };
         const uint32_t m = (uint32_t)(n - at < CH ? n - at : CH);
         uint32_t *len = nullptr; uint64_t *off = nullptr;
         RC_TRY(dalloc(c, &len, (size_t)m + 1)); RC_TRY(dalloc(c, &off, (size_t)m + 1));
@@ -234,12 +235,11 @@ static int emit_lines(harc_amd_ctx *c, const char *d_txt, const uint64_t *nls, c
         HIP_TRY(hipMemcpyAsync(&total, off + m, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (err) { harc_set_error("-q without -p needs quality lines of exactly readlen characters (%u differ)", err); harc_pool_release(c, mk); return HARC_AMD_EINVAL; }
+        if (err) { harc_set_error("-q without -p needs quality lines of exactly readlen characters (%u differ)", err); return HARC_AMD_EINVAL; }
         char *out = nullptr; RC_TRY(dalloc(c, &out, (size_t)total + 16));
         hipLaunchKernelGGL(k_q_copy, dim3((m + 3) / 4), dim3(256), 0, c->stream, d_txt, nls, rec + at, (const uint64_t *)off, m, k, out);
         RC_TRY(harc_d2h(c, host, out, (size_t)total));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        harc_pool_release(c, mk);
         if (total && fwrite(host.data(), 1, (size_t)total, fo) != (size_t)total) { harc_set_error("short write"); return HARC_AMD_EIO; }
     }
     return HARC_AMD_OK;

@@ -182,7 +182,7 @@ __global__ void k_gather_reads(const uint64_t *reads, const uint32_t *idx, uint3
 int s1_partition_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint64_t *d_out, unsigned long long *d_counts)
 {
     HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nb * 8, c->stream));
-    if (!n) return HARC_AMD_OK;
+    if (!n) { HIP_TRY(hipStreamSynchronize(c->stream)); return HARC_AMD_OK; }
     const harc_mark_t mk = harc_pool_mark(c);
     uint32_t *b = nullptr, *i0 = nullptr, *i1 = nullptr; uint64_t *k0 = nullptr, *k1 = nullptr;
     RC_TRY(dalloc(c, &b, n)); RC_TRY(dalloc(c, &i0, n)); RC_TRY(dalloc(c, &i1, n)); RC_TRY(dalloc(c, &k0, n)); RC_TRY(dalloc(c, &k1, n));
@@ -1232,6 +1232,41 @@ static uint32_t auto_chains(uint32_t N, int reads_per_chain)
     return k;
 }
 
+// Everything stage1_run_w owns besides pool memory: released on every way out.  The launches of the dominant kernel are timed with a
+// fixed ring of event pairs (params.profile = 1), not with two new events per launch.
+struct S1Resources {
+    static constexpr int RING = 64;
+    hipEvent_t e[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t ring[RING][2];
+    int ring_used = 0; uint64_t ring_next = 0; double ms = 0;
+    unsigned long long *h_stats = nullptr;
+    S1Resources() { for (int i = 0; i < RING; i++) ring[i][0] = ring[i][1] = nullptr; }
+    ~S1Resources()
+    {
+        for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x);
+        for (int i = 0; i < ring_used; i++) { (void)hipEventDestroy(ring[i][0]); (void)hipEventDestroy(ring[i][1]); }
+        if (h_stats) (void)hipHostFree(h_stats);
+    }
+    int init()
+    {
+        for (auto &x : e) HIP_TRY(hipEventCreate(&x));
+        HIP_TRY(hipHostMalloc((void **)&h_stats, ST_N * 8));
+        return HARC_AMD_OK;
+    }
+    // the pair for the next launch; its previous use (RING launches ago) is read first
+    int next_pair(hipEvent_t **pair)
+    {
+        const int k = (int)(ring_next % RING);
+        if (k >= ring_used) { HIP_TRY(hipEventCreate(&ring[k][0])); HIP_TRY(hipEventCreate(&ring[k][1])); ring_used = k + 1; }
+        else RC_TRY(collect(k));
+        ring_next++;
+        *pair = ring[k];
+        return HARC_AMD_OK;
+    }
+    int collect(int k) { float x = 0; HIP_TRY(hipEventSynchronize(ring[k][1])); HIP_TRY(hipEventElapsedTime(&x, ring[k][0], ring[k][1])); ms += x; return HARC_AMD_OK; }
+    int collect_all() { const uint64_t n = ring_next < (uint64_t)RING ? ring_next : (uint64_t)RING; for (uint64_t i = 0; i < n; i++) RC_TRY(collect((int)i)); ring_next = 0; return HARC_AMD_OK; }
+};
+
 template <int W> static int stage1_run_w(harc_amd_ctx *c)
 {
     const harc_amd_params &P = c->P;
@@ -1245,8 +1280,10 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // few chains -> every launch is a chain of dependent HBM round trips: fetch whole buckets; many chains -> request-rate bound: single slots
     bool quad = K <= 16384;
     if (const char *e = getenv("HARC_AMD_QUAD")) quad = atoi(e) != 0;
-    hipEvent_t e0, e1, e2;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+    S1Resources R;
+    RC_TRY(R.init());
+    hipEvent_t &e0 = R.e[0], &e1 = R.e[1], &e2 = R.e[2];
+    unsigned long long *const h_stats = R.h_stats;
     HIP_TRY(hipEventRecord(e0, c->stream));
 
     // ---- pool layout: [stage-I results, worst case][dictionaries][index scratch -> released][chain state] ; all but the results
@@ -1354,18 +1391,16 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge);
     // ---- rounds
     const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe);
-    unsigned long long *h_stats = nullptr;
-    HIP_TRY(hipHostMalloc((void **)&h_stats, ST_N * 8));
-    std::vector<hipEvent_t> ev;
     const bool prof = P.profile != 0;
     uint64_t rounds = 0, launches = 0;
     const int batch = getenv("HARC_AMD_BATCHSYNC") ? atoi(getenv("HARC_AMD_BATCHSYNC")) : 8;
     for (;;) {
         for (int r = 0; r < batch; r++) {
-            if (prof) { hipEvent_t a0, a1; HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1)); ev.push_back(a0); ev.push_back(a1); HIP_TRY(hipEventRecord(a0, c->stream)); }
+            hipEvent_t *pair = nullptr;
+            if (prof) { RC_TRY(R.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }
             if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             else hipLaunchKernelGGL((k_steps<W, false, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
-            if (prof) HIP_TRY(hipEventRecord(ev.back(), c->stream));
+            if (prof) HIP_TRY(hipEventRecord(pair[1], c->stream));
             // the steps that have to scan a large bin (none without such bins: the launch is skipped)
             if (nlarge) hipLaunchKernelGGL((k_steps<W, true, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
@@ -1381,7 +1416,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         HIP_TRY(hipGetLastError());
         if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] round %llu: %llu chains alive\n", (unsigned long long)rounds, h_stats[ST_ACTIVE]);
         if (h_stats[ST_ACTIVE] == 0) break;
-        if (rounds > (uint64_t)N * 2 + 1024) { harc_set_error("stage I did not converge after %llu rounds", (unsigned long long)rounds); return HARC_AMD_ENODEVICE; }
+        if (rounds > (uint64_t)N * 2 + 1024) { harc_set_error("stage I did not converge after %llu rounds", (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
     }
     HIP_TRY(hipEventRecord(e2, c->stream));
 
@@ -1396,7 +1431,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     HIP_TRY(hipMemcpyAsync(&M, bmain + K, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&S, bsing + K, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((unsigned long long)M + S != nlog) { harc_set_error("stage I bookkeeping: M=%u S=%u N=%u", M, S, N); return HARC_AMD_ENODEVICE; }
+    if ((unsigned long long)M + S != nlog) { harc_set_error("stage I bookkeeping: M=%u S=%u N=%u", M, S, N); return HARC_AMD_EINTERNAL; }
     c->M = M; c->S = S;
     unsigned long long *d_bad = a.stats + ST_N - 1;               // last statistics word: records that nobody wrote
     if (nlog) hipLaunchKernelGGL(k_s1_scatter, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, c->stream, a.log, nlog, K, bmain, bsing,
@@ -1404,18 +1439,15 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (h_stats[ST_N - 1]) { harc_set_error("stage I bookkeeping: %llu reads were never emitted", h_stats[ST_N - 1]); return HARC_AMD_ENODEVICE; }
+    if (h_stats[ST_N - 1]) { harc_set_error("stage I bookkeeping: %llu reads were never emitted", h_stats[ST_N - 1]); return HARC_AMD_EINTERNAL; }
 
     c->C.n_main = M; c->C.n_singleton = S; c->C.unmatched = h_stats[ST_UNMATCHED]; c->C.conflicts = h_stats[ST_CONFLICTS];
     c->C.probes = h_stats[ST_PROBES]; c->C.candidates = h_stats[ST_CANDS]; c->C.useful_probes = h_stats[ST_USEFUL]; c->C.candidates_seq = h_stats[ST_CANDS_SEQ]; c->C.rounds = rounds; c->C.propose_launches = launches;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1)); c->C.index_ms = ms;
     HIP_TRY(hipEventElapsedTime(&ms, e1, e2)); c->C.chain_ms = ms;
-    double pms = 0;
-    for (size_t i = 0; i + 1 < ev.size(); i += 2) { float x = 0; HIP_TRY(hipEventElapsedTime(&x, ev[i], ev[i + 1])); pms += x; }
-    c->C.propose_ms = pms;
-    for (hipEvent_t e : ev) hipEventDestroy(e);
-    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    RC_TRY(R.collect_all());
+    c->C.propose_ms = R.ms;
 #ifdef HARC_TIMING
     {
         unsigned long long d[16];
@@ -1434,7 +1466,6 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         fprintf(stderr, "[k_steps] steps walked %llu (of them kept %u): per step batches %.2f, cooperative bin scans %.2f, their 64-entry chunks %.2f, chunk x probe tests %.2f; steps without a hit %.3f\n", d[4], N, d[5] / stp, d[0] / stp, d[1] / stp, d[3] / stp, d[2] / stp);
         fprintf(stderr, "[k_steps] worst walk of the run: %llu chunks, %llu chunk x probe tests, %llu bin scans\n", d[6], d[7], d[8]);
     }
-    hipHostFree(h_stats);
 
     harc_pool_release(c, mark_results);                          // stage II starts right above the results
     c->have_s1 = true;

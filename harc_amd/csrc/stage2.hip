@@ -767,7 +767,7 @@ int stage2_run(harc_amd_ctx *c)
                 }
                 HIP_TRY(hipMemcpyAsync(&nev, a.nevents, 4, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
-                if (nev > a.maxevents) { harc_set_error("stage II: event count changed between two identical passes (%u > %u)", nev, a.maxevents); return HARC_AMD_ENODEVICE; }
+                if (nev > a.maxevents) { harc_set_error("stage II: event count changed between two identical passes (%u > %u)", nev, a.maxevents); return HARC_AMD_EINTERNAL; }
             }
             if (nev) {                                                        // exact sliding-window semantics as a fixed point (k_realign_big)
                 unsigned int *d_changed = nullptr; RC_TRY(dalloc(c, &d_changed, 4));
@@ -778,7 +778,7 @@ int stage2_run(harc_amd_ctx *c)
                     HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));
                     if (!chg) break;
-                    if (pass > (uint64_t)T + 16) { harc_set_error("stage II: the window passes over the large bins did not settle"); return HARC_AMD_ENODEVICE; }
+                    if (pass > (uint64_t)T + 16) { harc_set_error("stage II: the window passes over the large bins did not settle"); return HARC_AMD_EINTERNAL; }
                 }
             }
         }
@@ -850,7 +850,7 @@ int stage2_run(harc_amd_ctx *c)
         unsigned int merr = 0;
         HIP_TRY(hipMemcpyAsync(&merr, d_merr, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (merr) { harc_set_error("stage II: %u order entries outside the shard", merr); return HARC_AMD_ENODEVICE; }
+        if (merr) { harc_set_error("stage II: %u order entries outside the shard", merr); return HARC_AMD_EINTERNAL; }
     }
 
     // ---- shard boundaries in final-list / column / noise coordinates

@@ -40,6 +40,7 @@ extern "C" {
 #define HARC_AMD_EIO (-3)         /* file contract violated (missing / short file) */
 #define HARC_AMD_ESTATE (-4)      /* call order violated (e.g. encode before reorder and without stage-I inputs) */
 #define HARC_AMD_ENOMEM (-5)
+#define HARC_AMD_EINTERNAL (-6)    /* an invariant of the library failed (bookkeeping mismatch, a schedule that does not settle): a bug, not an input problem */
 
 /* Runtime equivalent of src/config.h (harc:52-63).  Fill with harc_amd_default_params, then override. */
 typedef struct harc_amd_params {

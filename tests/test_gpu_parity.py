@@ -659,3 +659,35 @@ def test_reads_per_chain_is_the_auto_chain_count(tmp_path):
         h.close()
     assert outs[0] == outs[1] and outs[0][0] == n // 64
     assert outs[2] == outs[3] and outs[2][0] == gen.auto_chains(n) == n // 1024
+
+
+def test_a_failed_run_leaves_the_context_usable(monkeypatch, tmp_path):
+    """error-path hygiene: an allocation that fails in the middle of harc_amd_reorder (HARC_AMD_FAIL_ALLOC refuses the n-th pool
+    allocation) is reported as HARC_AMD_ENOMEM, and the same context then gives the bytes of a fresh one"""
+    import subprocess, sys, textwrap
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import harc_amd
+        from tests import gen
+        txt = gen.reads_text(5, 30000, 100, 200000, err=0.005)
+        clean = b"".join(l + b"\\n" for l in txt.split() if b"N" not in l); nn = b"".join(l + b"\\n" for l in txt.split() if b"N" in l)
+        def run(h):
+            h.reorder(); h.encode()
+            return [h.stream("S2_SEQ", e) + h.stream("S2_NOISE", e) for e in range(2)] + [h.stream("S2_ORDER")]
+        h = harc_amd.HarcAmd(harc_amd.default_params(100, num_thr=2, num_chains=16))
+        h.set_reads_ascii(clean, len(clean) // 101, 101); h.set_nreads_ascii(nn, len(nn) // 101, 101)
+        try:
+            run(h)
+            print("NOFAIL")
+        except harc_amd.HarcAmdError as e:
+            print("FAILED", e.code)
+        a = run(h)                                            # the countdown is spent: this run goes through, on the same context
+        g = harc_amd.HarcAmd(harc_amd.default_params(100, num_thr=2, num_chains=16))
+        g.set_reads_ascii(clean, len(clean) // 101, 101); g.set_nreads_ascii(nn, len(nn) // 101, 101)
+        print("SAME" if run(g) == a else "DIFFERENT")
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    for n in (12, 40):
+        out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, HARC_AMD_FAIL_ALLOC=str(n)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert out.returncode == 0 and "FAILED -5" in out.stdout and "SAME" in out.stdout, out.stdout[-2000:]
