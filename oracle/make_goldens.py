@@ -56,6 +56,59 @@ def gen_reads(seed, n, L, genome_len, err=0.0, rc=True, repeat=0, dup=0, n_frac=
     return reads
 
 
+def gen_repfam(seed, n, L, genome_len, ncopy, div, npolya, nstr, err):
+    """a genome with a diverged repeat family (ncopy copies of one 300-bp element, every copy with `div` of its bases substituted),
+    poly-A runs and (CA)n runs of 150 bp: dictionary bins of tens of reads, most of which fail the Hamming test"""
+    rs = np.random.RandomState(seed)
+    g = rs.randint(0, 4, size=genome_len)
+    rep = rs.randint(0, 4, size=300)
+    slots = rs.permutation(genome_len // 400)[:ncopy] * 400
+    for p in slots:
+        cp = rep.copy()
+        mut = rs.random_sample(300) < div
+        cp[mut] = (cp[mut] + rs.randint(1, 4, size=int(mut.sum()))) % 4
+        g[p:p + 300] = cp
+    for p in rs.randint(0, genome_len - 400, size=npolya):
+        g[p:p + 150] = 0
+    for p in rs.randint(0, genome_len - 400, size=nstr):
+        g[p:p + 150] = np.tile([1, 0], 75)
+    genome = "".join("ACGT"[x] for x in g)
+    reads = []
+    for i in range(n):
+        p = rs.randint(0, genome_len - L)
+        r = list(genome[p:p + L])
+        for j in range(L):
+            if rs.random_sample() < err:
+                r[j] = "N" if rs.random_sample() < 0.25 else "ACGT"[("ACGT".index(r[j]) + rs.randint(1, 4)) % 4]
+        r = "".join(r)
+        reads.append(revcomp(r) if (i & 1) else r)
+    return reads
+
+
+def gen_noRC(seed, n, L, genome_len, width, errors=True):
+    """the reference's own simulator (util/gen_fastq_noRC, built into oracle/_ref by build_ref.sh) on a small FASTA written here:
+    std::mt19937 with its default seed, read = ref[pos, pos+L) for a 32-bit pos below ref_len - L, -e: one base in a hundred replaced,
+    a quarter of those by N (gen_fastq_noRC.cpp:90-131).  Its FASTA reader takes the last line twice when the file ends with a newline
+    (the feof loop of :19-32): the genome the reads come from is 'width' characters longer than the file says -- kept, it is what a user
+    of the tool gets."""
+    rs = np.random.RandomState(seed)
+    genome = "".join("ACGT"[x] for x in rs.randint(0, 4, size=genome_len))
+    wd = tempfile.mkdtemp(prefix="harc_gen_")
+    try:
+        fa, fq = os.path.join(wd, "g.fa"), os.path.join(wd, "out.fastq")
+        with open(fa, "w") as f:
+            f.write(">chrT synthetic\n")
+            for i in range(0, genome_len, width):
+                f.write(genome[i:i + width] + "\n")
+        run([os.path.join(REF, "gen_fastq_noRC"), str(n), str(L), fa, fq] + (["-e"] if errors else []), wd)
+        lines = open(fq).read().split("\n")
+        reads = [lines[4 * i + 1] for i in range(n)]
+        assert all(len(r) == L for r in reads) and lines[0] == "@T.0" and lines[3] == "H" * L
+        return reads
+    finally:
+        shutil.rmtree(wd)
+
+
 CASES = {
     # name: dict(kwargs for gen_reads)
     "L100_clean_5k": dict(seed=1, n=5000, L=100, genome_len=25000),
@@ -72,6 +125,12 @@ CASES = {
     "L100_three": dict(seed=12, n=3, L=100, genome_len=120),
     # stage-II dictionary bins above maxsearch (2500 N reads sharing their first 50 bases): the sliding window of encoder.cpp:293
     "L100_bigbin2_5k": dict(custom="bigbin_stage2", seed=77, L=100),
+    # the reference's own generator (BASELINE.json configs[0] is "util/gen_fastq_noRC on chrom22"), with -e
+    "L100_gen_noRC_e_3k": dict(custom="gen_noRC", seed=31, n=3000, L=100, genome_len=20030, width=70),
+    # repeat families: diverged copies of a 300-bp element, poly-A and (CA)n runs -> stage-I bins of more than 16 reads (the bin-ordered
+    # mirror, the COOP kernel and the scan budget of the GPU build all sit on this path)
+    "L100_repfam_5k": dict(custom="repfam", seed=41, n=5000, L=100, genome_len=40000, ncopy=40, div=0.10, npolya=8, nstr=4, err=0.004),
+    "L101_repfam_4k": dict(custom="repfam", seed=42, n=4000, L=101, genome_len=30000, ncopy=30, div=0.13, npolya=6, nstr=4, err=0.006),
 }
 
 
@@ -100,6 +159,10 @@ def make_case(name, kw):
         sys.path.insert(0, os.path.dirname(HERE))
         from tests import gen as tgen
         reads = tgen.reads_text_bigbin_stage2(kw["seed"]).decode().split()
+    elif kw.get("custom") == "gen_noRC":
+        reads = gen_noRC(kw["seed"], kw["n"], L, kw["genome_len"], kw["width"])
+    elif kw.get("custom") == "repfam":
+        reads = gen_repfam(**{k: v for k, v in kw.items() if k != "custom"})
     else:
         reads = gen_reads(**kw)
     wd = tempfile.mkdtemp(prefix="harc_gold_")
