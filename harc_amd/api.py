@@ -15,7 +15,7 @@ class Params(C.Structure):
     """harc_amd_params == src/config.h macros (harc:52-63)"""
     _fields_ = [("readlen", C.c_int32), ("num_thr", C.c_int32), ("num_chains", C.c_int32), ("maxmatch", C.c_int32),
                 ("thresh", C.c_int32), ("thresh_s", C.c_int32), ("maxsearch", C.c_int32), ("dict_start", C.c_int32 * 2),
-                ("dict_end", C.c_int32 * 2), ("device", C.c_int32), ("profile", C.c_int32), ("num_steps", C.c_int32), ("reads_per_chain", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("dict_end", C.c_int32 * 2), ("device", C.c_int32), ("profile", C.c_int32), ("num_steps", C.c_int32), ("reads_per_chain", C.c_int32), ("decode_memory_gb", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class Counters(C.Structure):
@@ -165,10 +165,11 @@ def merge_shards(basedir, world):
     _check(lib().harc_amd_merge_shard_files(os.fsencode(basedir), world))
 
 
-def decoder(basedir, num_thr_e, device=0, preserve_order=False):
+def decoder(basedir, num_thr_e, device=0, preserve_order=False, memory_gb=0):
     """== `decoder.out <basedir> <num_thr> <num_thr_e>` (src/decoder.cpp:44-172): output/output.dna;
     preserve_order: the -p chain unpack_order + decoder_preserve + merge_N (harc:183-185)"""
     p = default_params(100, device=device)
+    p.decode_memory_gb = memory_gb
     f = lib().harc_amd_decoder_preserve_files if preserve_order else lib().harc_amd_decoder_files
     _check(f(C.byref(p), os.fsencode(basedir), num_thr_e))
 

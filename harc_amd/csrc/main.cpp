@@ -4,6 +4,7 @@
 //   harc_amd_stage compress <basedir> <readlen> [num_thr] [num_chains]     == both, stage I -> II handed over in HBM
 //   harc_amd_stage pack_order <basedir> <readlen>                          == src/pack_order.out <basedir> (harc:112)
 //   harc_amd_stage decoder <basedir> <readlen ignored> <num_thr_e>         == src/decoder.out <basedir> <num_thr> <num_thr_e> (harc:188)
+//   harc_amd_stage decoder_preserve <basedir> <ignored> <num_thr_e> [memory_gb]   == unpack_order + decoder_preserve + merge_N (harc:174-185, -m = MAX_BIN_SIZE)
 //   harc_amd_stage compressfq <basedir> <readlen> <fastq> [num_thr] [num_chains] [num_steps] [preserve_order] [preserve_quality]
 //                                                                          == preprocess + reorder + encoder (+ reorder_quality), FASTQ parsed on the GPU
 //   harc_amd_stage preprocess <basedir> <readlen> <fastq>                  == src/preprocess.out <fastq> <basedir> .. <readlen> (harc:50)
@@ -51,7 +52,7 @@ int main(int argc, char **argv)
         P.reads_per_chain = 1024;                                     // a bucket shard is fragmented already (multi-GPU)
         rc = harc_amd_compress_fastq_shard_files(&P, argv[4], argv[2], po, pq, world, rank, argv[12]);
     }
-    else if (!strcmp(argv[1], "decoder_preserve")) rc = harc_amd_decoder_preserve_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1);
+    else if (!strcmp(argv[1], "decoder_preserve")) { if (argc > 5) P.decode_memory_gb = atoi(argv[5]); rc = harc_amd_decoder_preserve_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1); }   // [memory]: -m of harc:174
     else if (!strcmp(argv[1], "decoder")) rc = harc_amd_decoder_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1);
     else if (!strcmp(argv[1], "reorder")) rc = harc_amd_reorder_files(&P, argv[2]);
     else if (!strcmp(argv[1], "encoder")) rc = harc_amd_encoder_files(&P, argv[2]);

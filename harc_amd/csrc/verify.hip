@@ -400,7 +400,9 @@ __global__ void k_unpack_order(const uint32_t *packed, uint32_t ngroups, int num
     if (sh + numbits > 32) v |= (uint64_t)w[wi + 1] << 32;
     out[gid] = (uint32_t)((v >> sh) & (numbits == 32 ? 0xFFFFFFFFull : ((1ull << numbits) - 1)));
 }
-__global__ void k_permute_lines(const char *src, const uint32_t *order, uint32_t n, int L, char *dst, uint32_t ndst, unsigned int *err)
+// line i of src goes to line order[i] - lo of dst when lo <= order[i] < hi (one bin of restore_order, decoder_preserve.cpp:246-290);
+// order[i] >= ndst is an inconsistent archive
+__global__ void k_permute_lines(const char *src, const uint32_t *order, uint32_t n, int L, char *dst, uint32_t lo, uint32_t hi, uint32_t ndst, unsigned int *err)
 {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t LL = (uint64_t)L + 1;
@@ -408,7 +410,8 @@ __global__ void k_permute_lines(const char *src, const uint32_t *order, uint32_t
     const uint32_t i = (uint32_t)(gid / LL);
     const uint32_t o = order[i];
     if (o >= ndst) { if (gid % LL == 0) atomicAdd(err, 1u); return; }
-    dst[(uint64_t)o * LL + gid % LL] = src[gid];
+    if (o < lo || o >= hi) return;
+    dst[(uint64_t)(o - lo) * LL + gid % LL] = src[gid];
 }
 __global__ void k_mark_N(const uint32_t *orderN, uint32_t nN, uint32_t total, uint32_t *flag, unsigned int *err)
 {
@@ -417,13 +420,15 @@ __global__ void k_mark_N(const uint32_t *orderN, uint32_t nN, uint32_t total, ui
     if (orderN[m] >= total) { atomicAdd(err, 1u); return; }
     flag[orderN[m]] = 1u;
 }
-__global__ void k_merge_lines(const char *clean, const char *withN, const uint32_t *flag, const uint32_t *rankN, uint32_t total, int L, char *out)
+// output lines [p0, p0 + n): line p is the next read with N (flag) or the next clean read; cl / nl hold the clean reads from index clo on and
+// the N reads from index nlo on (merge_N.cpp:37-57, one bin of it)
+__global__ void k_merge_lines(const char *clean, const char *withN, const uint32_t *flag, const uint32_t *rankN, uint32_t p0, uint32_t n, uint32_t clo, uint32_t nlo, int L, char *out)
 {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t LL = (uint64_t)L + 1;
-    if (gid >= (uint64_t)total * LL) return;
-    const uint32_t p = (uint32_t)(gid / LL); const uint64_t j = gid % LL;
-    out[gid] = flag[p] ? withN[(uint64_t)rankN[p] * LL + j] : clean[(uint64_t)(p - rankN[p]) * LL + j];
+    if (gid >= (uint64_t)n * LL) return;
+    const uint32_t p = p0 + (uint32_t)(gid / LL); const uint64_t j = gid % LL;
+    out[gid] = flag[p] ? withN[(uint64_t)(rankN[p] - nlo) * LL + j] : clean[(uint64_t)(p - rankN[p] - clo) * LL + j];
 }
 
 extern "C" int harc_amd_decoder_preserve_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e)
@@ -450,100 +455,144 @@ extern "C" int harc_amd_decoder_preserve_files(const harc_amd_params *params, co
     if (nC && (numbits < 1 || numbits > 32 || pord.size() != 8 + (size_t)ng * numbits * 4 || ptail.size() != (size_t)ntail * 4)) { harc_set_error("read_order.bin is not a pack_order file"); return HARC_AMD_EIO; }
     const uint32_t nN = (uint32_t)(ordN.size() / 4);
     if (ordNpe.size() != ordN.size()) { harc_set_error("read_order_N_pe.bin and read_order_N.bin disagree"); return HARC_AMD_EIO; }
-    const uint32_t total = nC + nN;
-    uint32_t *d_order = nullptr, *d_ordNpe = nullptr, *d_ordN = nullptr; unsigned int *d_err = nullptr;
-    char *cl = nullptr, *nlines = nullptr;
+    const uint64_t total64 = (uint64_t)nC + nN;
+    if (total64 > 4294967290ull) { harc_set_error("more than 4294967290 reads"); return HARC_AMD_EINVAL; }
+    const uint32_t total = (uint32_t)total64;
+    uint32_t *d_order = nullptr, *d_ordNpe = nullptr, *d_ordN = nullptr, *flag = nullptr, *rankN = nullptr; unsigned int *d_err = nullptr;
     RC_TRY(dalloc(c, &d_order, (size_t)nC + 32)); RC_TRY(dalloc(c, &d_ordNpe, (size_t)nN + 1)); RC_TRY(dalloc(c, &d_ordN, (size_t)nN + 1)); RC_TRY(dalloc(c, &d_err, 4));
-    RC_TRY(dalloc(c, &cl, (size_t)nC * LL + 16)); RC_TRY(dalloc(c, &nlines, (size_t)nN * LL + 16));
+    RC_TRY(dalloc(c, &flag, (size_t)total + 1)); RC_TRY(dalloc(c, &rankN, (size_t)total + 1));
     HIP_TRY(hipMemsetAsync(d_err, 0, 16, c->stream));
     if (ng) {
+        const harc_mark_t mk = harc_pool_mark(c);
         uint8_t *d_p = nullptr; RC_TRY(up(c, pord.data() + 8, (size_t)ng * numbits * 4, &d_p));
         hipLaunchKernelGGL(k_unpack_order, G256((uint64_t)ng * 32), (const uint32_t *)d_p, ng, numbits, d_order);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        harc_pool_release(c, mk);
     }
     if (ntail) HIP_TRY(hipMemcpyAsync(d_order + (size_t)ng * 32, ptail.data(), (size_t)ntail * 4, hipMemcpyHostToDevice, c->stream));
     if (nN) { HIP_TRY(hipMemcpyAsync(d_ordNpe, ordNpe.data(), (size_t)nN * 4, hipMemcpyHostToDevice, c->stream)); HIP_TRY(hipMemcpyAsync(d_ordN, ordN.data(), (size_t)nN * 4, hipMemcpyHostToDevice, c->stream)); }
-    // ---- decode every shard into the two line arrays (stream order)
-    uint64_t cA = 0, cN = 0;
-    for (int e = 0; e < num_thr_e; e++) {
-        const std::string sfx = "." + std::to_string(e);
-        std::vector<uint8_t> seq, seqt, pos, noise, npz, rev, revt;
-        if (!slurp_file(od + "read_seq.txt" + sfx, seq) || !slurp_file(od + "read_seq.txt" + sfx + ".tail", seqt) || !slurp_file(od + "read_pos.txt" + sfx, pos) ||
-            !slurp_file(od + "read_noise.txt" + sfx, noise) || !slurp_file(od + "read_noisepos.txt" + sfx, npz) ||
-            !slurp_file(od + "read_rev.txt" + sfx, rev) || !slurp_file(od + "read_rev.txt" + sfx + ".tail", revt)) { harc_set_error("shard %d: stream files missing", e); return HARC_AMD_EIO; }
-        if (pos.empty()) continue;
-        if (pos.size() > 0xFFFFFFFFull || 8 * rev.size() + revt.size() != pos.size()) { harc_set_error("shard %d: rev stream does not match pos stream", e); return HARC_AMD_EIO; }
-        const harc_mark_t mk = harc_pool_mark(c);
-        const uint32_t n = (uint32_t)pos.size();
-        uint8_t *d_seq, *d_seqt, *d_pos, *d_noise, *d_np, *d_rev, *d_revt, *seqb; uint64_t *p64, *possum, *nlpos; uint32_t *fl, *rk, *isN, *rkN; char *tmp, *outA, *outN;
-        RC_TRY(up(c, seq.data(), seq.size(), &d_seq)); RC_TRY(up(c, seqt.data(), seqt.size(), &d_seqt)); RC_TRY(up(c, pos.data(), pos.size(), &d_pos));
-        RC_TRY(up(c, noise.data(), noise.size(), &d_noise)); RC_TRY(up(c, npz.data(), npz.size(), &d_np)); RC_TRY(up(c, rev.data(), rev.size(), &d_rev)); RC_TRY(up(c, revt.data(), revt.size(), &d_revt));
-        const uint64_t seqlen = 4 * (uint64_t)seq.size() + seqt.size();
-        const size_t nnoise = noise.size();
-        RC_TRY(dalloc(c, &seqb, (size_t)seqlen + 16)); RC_TRY(dalloc(c, &p64, (size_t)n + 1)); RC_TRY(dalloc(c, &possum, (size_t)n + 1)); RC_TRY(dalloc(c, &nlpos, (size_t)n + 1));
-        RC_TRY(dalloc(c, &fl, nnoise + 1)); RC_TRY(dalloc(c, &rk, nnoise + 1)); RC_TRY(dalloc(c, &isN, (size_t)n + 1)); RC_TRY(dalloc(c, &rkN, (size_t)n + 1));
-        RC_TRY(dalloc(c, &tmp, (size_t)n * LL + 16)); RC_TRY(dalloc(c, &outA, (size_t)n * LL + 16)); RC_TRY(dalloc(c, &outN, (size_t)n * LL + 16));
-        if (seqlen) hipLaunchKernelGGL(k_unpack_seq, G256(seqlen), d_seq, (uint64_t)seq.size(), d_seqt, (uint64_t)seqt.size(), seqb);
-        hipLaunchKernelGGL(k_pos_to_u64, G256(n), d_pos, n, p64);
-        RC_TRY(prim_incl_scan_u64(c, p64, possum, n));
-        if (nnoise) {
-            hipLaunchKernelGGL(k_nl_flags, G256(nnoise), d_noise, (uint64_t)nnoise, fl);
-            RC_TRY(prim_excl_scan_u32(c, fl, rk, nnoise));
-            hipLaunchKernelGGL(k_nl_positions, G256(nnoise), d_noise, rk, (uint64_t)nnoise, nlpos);
-        }
-        HIP_TRY(hipMemsetAsync(isN, 0, ((size_t)n + 1) * 4, c->stream));
-        hipLaunchKernelGGL(k_decode_text, G256(n), seqb, seqlen, possum, d_noise, d_np, nlpos, d_rev, (uint64_t)rev.size(), d_revt, n, L, tmp, isN, d_err);
-        RC_TRY(prim_excl_scan_u32(c, isN, rkN, (size_t)n + 1));
-        hipLaunchKernelGGL(k_split_lines, G256((uint64_t)n * LL), tmp, isN, rkN, n, L, outA, outN);
-        uint32_t nNs = 0;
-        HIP_TRY(hipMemcpyAsync(&nNs, rkN + n, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        const uint32_t nAs = n - nNs;
-        if (cA + nAs > nC || cN + nNs > nN) { harc_set_error("streams hold more reads than the order files"); return HARC_AMD_EIO; }
-        if (nAs) HIP_TRY(hipMemcpyAsync(cl + cA * LL, outA, (size_t)nAs * LL, hipMemcpyDeviceToDevice, c->stream));
-        if (nNs) HIP_TRY(hipMemcpyAsync(nlines + cN * LL, outN, (size_t)nNs * LL, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        cA += nAs; cN += nNs;
-        harc_pool_release(c, mk);
-    }
-    {   // singletons, then the N reads that were not aligned
-        std::vector<uint8_t> sg, sgt, nt;
-        if (!slurp_file(od + "read_singleton.txt", sg) || !slurp_file(od + "read_singleton.txt.tail", sgt)) { harc_set_error("singleton files missing"); return HARC_AMD_EIO; }
-        slurp_file(od + "input_N.dna", nt);
-        const uint64_t nb = 4 * (uint64_t)sg.size() + sgt.size();
-        const uint32_t ns = (uint32_t)(nb / L), nu = (uint32_t)(nt.size() / LL);
-        if (cA + ns != nC || cN + nu != nN) { harc_set_error("read counts do not add up: clean %llu+%u vs %u, N %llu+%u vs %u", (unsigned long long)cA, ns, nC, (unsigned long long)cN, nu, nN); return HARC_AMD_EIO; }
-        if (ns) {
-            uint8_t *d_sg, *d_sgt, *codes;
-            RC_TRY(up(c, sg.data(), sg.size(), &d_sg)); RC_TRY(up(c, sgt.data(), sgt.size(), &d_sgt)); RC_TRY(dalloc(c, &codes, (size_t)nb + 16));
-            hipLaunchKernelGGL(k_unpack_seq, G256(nb), d_sg, (uint64_t)sg.size(), d_sgt, (uint64_t)sgt.size(), codes);
-            hipLaunchKernelGGL(k_codes_to_lines, G256((uint64_t)ns * LL), codes, ns, L, cl + cA * LL);
-        }
-        if (nu) HIP_TRY(hipMemcpyAsync(nlines + cN * LL, nt.data(), (size_t)nu * LL, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    // ---- restore_order (decoder_preserve.cpp:246-290) + merge_N (merge_N.cpp:37-57)
-    char *clp = nullptr, *nlp = nullptr, *outl = nullptr; uint32_t *flag = nullptr, *rankN = nullptr;
-    RC_TRY(dalloc(c, &clp, (size_t)nC * LL + 16)); RC_TRY(dalloc(c, &nlp, (size_t)nN * LL + 16)); RC_TRY(dalloc(c, &outl, (size_t)total * LL + 16));
-    RC_TRY(dalloc(c, &flag, (size_t)total + 1)); RC_TRY(dalloc(c, &rankN, (size_t)total + 1));
+    // which output lines are reads with N (merge_N.cpp:37-57), and how many of those come before each line
     HIP_TRY(hipMemsetAsync(flag, 0, ((size_t)total + 1) * 4, c->stream));
-    if (nC) hipLaunchKernelGGL(k_permute_lines, G256((uint64_t)nC * LL), cl, d_order, nC, L, clp, nC, d_err);
-    if (nN) {
-        hipLaunchKernelGGL(k_permute_lines, G256((uint64_t)nN * LL), nlines, d_ordNpe, nN, L, nlp, nN, d_err);
-        hipLaunchKernelGGL(k_mark_N, G256(nN), d_ordN, nN, total, flag, d_err);
-    }
+    if (nN) hipLaunchKernelGGL(k_mark_N, G256(nN), d_ordN, nN, total, flag, d_err);
     RC_TRY(prim_excl_scan_u32(c, flag, rankN, (size_t)total + 1));
-    if (total) hipLaunchKernelGGL(k_merge_lines, G256((uint64_t)total * LL), clp, nlp, flag, rankN, total, L, outl);
-    std::vector<uint8_t> host((size_t)total * LL);
-    unsigned int err = 0;
-    if (!host.empty()) HIP_TRY(hipMemcpyAsync(host.data(), outl, host.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (err) { harc_set_error("decoder -p: %u inconsistent order / stream entries", err); return HARC_AMD_EIO; }
+    pord.clear(); pord.shrink_to_fit();
+
+    // ---- bins of output lines.  The reference restores the order through host memory in bins of MAX_BIN_SIZE * 2e8 / 7 reads (-m,
+    // decoder_preserve.cpp:249-253), reading the decoded reads of every bin back from a temporary file; here a bin is what fits in HBM next
+    // to the scratch of one shard's decode (and no more than -m asks for), and every bin decodes the streams again and keeps the lines that
+    // fall into it -- decoding is cheap, no temporary file, host memory bounded by one output chunk.
+    uint64_t bin_lines;
+    {
+        const int mgb = P.decode_memory_gb > 3 ? P.decode_memory_gb : (P.decode_memory_gb == 0 ? 7 : 3);     // harc:225 default 7; decoder_preserve.cpp:249-252
+        bin_lines = (uint64_t)mgb * 200000000ull / 7ull;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            fr += c->pool_total;
+            const uint64_t cap = (uint64_t)(0.25 * (double)fr / (double)(3 * LL));     // clean + N + merged lines of the bin: a quarter of what is free
+            if (cap && bin_lines > cap) bin_lines = cap;
+        }
+        if (const char *e = getenv("HARC_AMD_BIN_READS")) bin_lines = strtoull(e, nullptr, 10);      // tests: tiny bins
+        if (bin_lines < 1) bin_lines = 1;
+    }
     FILE *fo = fopen((od + "output.dna").c_str(), "wb");
     if (!fo) { harc_set_error("cannot create %soutput.dna", od.c_str()); return HARC_AMD_EIO; }
-    const bool okw = host.empty() || fwrite(host.data(), 1, host.size(), fo) == host.size();
-    fclose(fo);
-    if (!okw) { harc_set_error("short write on output.dna"); return HARC_AMD_EIO; }
+    struct FClose { FILE *f; ~FClose() { if (f) fclose(f); } } fcl{ fo };
+    std::vector<uint8_t> sg, sgt, nt;                             // singletons and unaligned N reads: read once
+    if (!slurp_file(od + "read_singleton.txt", sg) || !slurp_file(od + "read_singleton.txt.tail", sgt)) { harc_set_error("singleton files missing"); return HARC_AMD_EIO; }
+    slurp_file(od + "input_N.dna", nt);
+    const harc_mark_t mark_bins = harc_pool_mark(c);
+    for (uint64_t p0 = 0; p0 < total || (total == 0 && p0 == 0); p0 += bin_lines) {
+        harc_pool_release(c, mark_bins);
+        const uint32_t pn = (uint32_t)(total - p0 < bin_lines ? total - p0 : bin_lines);
+        uint32_t r0 = 0, r1 = 0;
+        HIP_TRY(hipMemcpyAsync(&r0, rankN + p0, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&r1, rankN + p0 + pn, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint32_t nlo = r0, nhi = r1, clo = (uint32_t)p0 - r0, chi = (uint32_t)(p0 + pn) - r1;     // the clean reads and the N reads of this bin
+        char *clp = nullptr, *nlp = nullptr;
+        RC_TRY(dalloc(c, &clp, (size_t)(chi - clo) * LL + 16)); RC_TRY(dalloc(c, &nlp, (size_t)(nhi - nlo) * LL + 16));
+        // ---- decode every shard (stream order) and keep the lines of this bin: restore_order (decoder_preserve.cpp:246-290) and
+        //      restore_order_N (:212-244)
+        uint64_t cA = 0, cN = 0;
+        for (int e = 0; e < num_thr_e; e++) {
+            const std::string sfx = "." + std::to_string(e);
+            std::vector<uint8_t> seq, seqt, pos, noise, npz, rev, revt;
+            if (!slurp_file(od + "read_seq.txt" + sfx, seq) || !slurp_file(od + "read_seq.txt" + sfx + ".tail", seqt) || !slurp_file(od + "read_pos.txt" + sfx, pos) ||
+                !slurp_file(od + "read_noise.txt" + sfx, noise) || !slurp_file(od + "read_noisepos.txt" + sfx, npz) ||
+                !slurp_file(od + "read_rev.txt" + sfx, rev) || !slurp_file(od + "read_rev.txt" + sfx + ".tail", revt)) { harc_set_error("shard %d: stream files missing", e); return HARC_AMD_EIO; }
+            if (pos.empty()) continue;
+            if (pos.size() > 0xFFFFFFFFull || 8 * rev.size() + revt.size() != pos.size()) { harc_set_error("shard %d: rev stream does not match pos stream", e); return HARC_AMD_EIO; }
+            const harc_mark_t mk = harc_pool_mark(c);
+            const uint32_t n = (uint32_t)pos.size();
+            uint8_t *d_seq, *d_seqt, *d_pos, *d_noise, *d_np, *d_rev, *d_revt, *seqb; uint64_t *p64, *possum, *nlpos; uint32_t *fl, *rk, *isN, *rkN; char *tmp, *outA, *outN;
+            RC_TRY(up(c, seq.data(), seq.size(), &d_seq)); RC_TRY(up(c, seqt.data(), seqt.size(), &d_seqt)); RC_TRY(up(c, pos.data(), pos.size(), &d_pos));
+            RC_TRY(up(c, noise.data(), noise.size(), &d_noise)); RC_TRY(up(c, npz.data(), npz.size(), &d_np)); RC_TRY(up(c, rev.data(), rev.size(), &d_rev)); RC_TRY(up(c, revt.data(), revt.size(), &d_revt));
+            const uint64_t seqlen = 4 * (uint64_t)seq.size() + seqt.size();
+            const size_t nnoise = noise.size();
+            RC_TRY(dalloc(c, &seqb, (size_t)seqlen + 16)); RC_TRY(dalloc(c, &p64, (size_t)n + 1)); RC_TRY(dalloc(c, &possum, (size_t)n + 1)); RC_TRY(dalloc(c, &nlpos, (size_t)n + 1));
+            RC_TRY(dalloc(c, &fl, nnoise + 1)); RC_TRY(dalloc(c, &rk, nnoise + 1)); RC_TRY(dalloc(c, &isN, (size_t)n + 1)); RC_TRY(dalloc(c, &rkN, (size_t)n + 1));
+            RC_TRY(dalloc(c, &tmp, (size_t)n * LL + 16)); RC_TRY(dalloc(c, &outA, (size_t)n * LL + 16)); RC_TRY(dalloc(c, &outN, (size_t)n * LL + 16));
+            if (seqlen) hipLaunchKernelGGL(k_unpack_seq, G256(seqlen), d_seq, (uint64_t)seq.size(), d_seqt, (uint64_t)seqt.size(), seqb);
+            hipLaunchKernelGGL(k_pos_to_u64, G256(n), d_pos, n, p64);
+            RC_TRY(prim_incl_scan_u64(c, p64, possum, n));
+            if (nnoise) {
+                hipLaunchKernelGGL(k_nl_flags, G256(nnoise), d_noise, (uint64_t)nnoise, fl);
+                RC_TRY(prim_excl_scan_u32(c, fl, rk, nnoise));
+                hipLaunchKernelGGL(k_nl_positions, G256(nnoise), d_noise, rk, (uint64_t)nnoise, nlpos);
+            }
+            HIP_TRY(hipMemsetAsync(isN, 0, ((size_t)n + 1) * 4, c->stream));
+            hipLaunchKernelGGL(k_decode_text, G256(n), seqb, seqlen, possum, d_noise, d_np, nlpos, d_rev, (uint64_t)rev.size(), d_revt, n, L, tmp, isN, d_err);
+            RC_TRY(prim_excl_scan_u32(c, isN, rkN, (size_t)n + 1));
+            hipLaunchKernelGGL(k_split_lines, G256((uint64_t)n * LL), tmp, isN, rkN, n, L, outA, outN);
+            uint32_t nNs = 0;
+            HIP_TRY(hipMemcpyAsync(&nNs, rkN + n, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const uint32_t nAs = n - nNs;
+            if (cA + nAs > nC || cN + nNs > nN) { harc_set_error("streams hold more reads than the order files"); return HARC_AMD_EIO; }
+            if (nAs) hipLaunchKernelGGL(k_permute_lines, G256((uint64_t)nAs * LL), outA, d_order + cA, nAs, L, clp, clo, chi, nC, d_err);
+            if (nNs) hipLaunchKernelGGL(k_permute_lines, G256((uint64_t)nNs * LL), outN, d_ordNpe + cN, nNs, L, nlp, nlo, nhi, nN, d_err);
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            cA += nAs; cN += nNs;
+            harc_pool_release(c, mk);
+        }
+        {   // singletons, then the N reads that were not aligned (decoder_preserve.cpp:160-197)
+            const harc_mark_t mk = harc_pool_mark(c);
+            const uint64_t nb = 4 * (uint64_t)sg.size() + sgt.size();
+            const uint32_t ns = (uint32_t)(nb / L), nu = (uint32_t)(nt.size() / LL);
+            if (cA + ns != nC || cN + nu != nN) { harc_set_error("read counts do not add up: clean %llu+%u vs %u, N %llu+%u vs %u", (unsigned long long)cA, ns, nC, (unsigned long long)cN, nu, nN); return HARC_AMD_EIO; }
+            if (ns) {
+                uint8_t *d_sg, *d_sgt, *codes; char *sl;
+                RC_TRY(up(c, sg.data(), sg.size(), &d_sg)); RC_TRY(up(c, sgt.data(), sgt.size(), &d_sgt)); RC_TRY(dalloc(c, &codes, (size_t)nb + 16)); RC_TRY(dalloc(c, &sl, (size_t)ns * LL + 16));
+                hipLaunchKernelGGL(k_unpack_seq, G256(nb), d_sg, (uint64_t)sg.size(), d_sgt, (uint64_t)sgt.size(), codes);
+                hipLaunchKernelGGL(k_codes_to_lines, G256((uint64_t)ns * LL), codes, ns, L, sl);
+                hipLaunchKernelGGL(k_permute_lines, G256((uint64_t)ns * LL), sl, d_order + cA, ns, L, clp, clo, chi, nC, d_err);
+            }
+            if (nu) {
+                uint8_t *d_nt; RC_TRY(up(c, nt.data(), (size_t)nu * LL, &d_nt));
+                hipLaunchKernelGGL(k_permute_lines, G256((uint64_t)nu * LL), (const char *)d_nt, d_ordNpe + cN, nu, L, nlp, nlo, nhi, nN, d_err);
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            harc_pool_release(c, mk);
+        }
+        // ---- merge_N for the lines of the bin, written in pieces of at most 256 MiB
+        unsigned int err = 0;
+        HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (err) { harc_set_error("decoder -p: %u inconsistent order / stream entries", err); return HARC_AMD_EIO; }
+        const uint32_t piece = (uint32_t)(((size_t)256 << 20) / LL);
+        char *outl = nullptr; RC_TRY(dalloc(c, &outl, (size_t)piece * LL + 16));
+        std::vector<uint8_t> host;
+        for (uint32_t q = 0; q < pn; q += piece) {
+            const uint32_t m = pn - q < piece ? pn - q : piece;
+            hipLaunchKernelGGL(k_merge_lines, G256((uint64_t)m * LL), clp, nlp, flag, rankN, (uint32_t)p0 + q, m, clo, nlo, L, outl);
+            host.resize((size_t)m * LL);
+            HIP_TRY(hipMemcpyAsync(host.data(), outl, host.size(), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (fwrite(host.data(), 1, host.size(), fo) != host.size()) { harc_set_error("short write on output.dna"); return HARC_AMD_EIO; }
+        }
+        if (total == 0) break;
+    }
     printf("Decoding done\n");
     return HARC_AMD_OK;
 }

@@ -61,7 +61,9 @@ typedef struct harc_amd_params {
                                  of S when num_chains = 1; for num_chains > 1 the pair (K,S) defines the schedule */
     int32_t reads_per_chain;  /* auto mode (num_chains = 0): one chain per this many reads, capped at 65536 chains; 0 = 2048.  Inputs that are
                                  already fragmented (one minimizer bucket of a multi-GPU shard) lose nothing with 1024 and run faster. */
-    int32_t reserved[2];
+    int32_t decode_memory_gb; /* -m of `./harc -d -p` (harc:225, MAX_BIN_SIZE of decoder_preserve.cpp:249-253): the original order is restored in bins of
+                                 decode_memory_gb * 2e8 / 7 reads (0 = the driver's default 7; <= 3 counts as 3), and never more than fits in HBM */
+    int32_t reserved[1];
 } harc_amd_params;
 
 /* Counters: the three numbers the reference prints (reorder.cpp:701, encoder.cpp:506-508) + kernel-side statistics. */
@@ -222,8 +224,9 @@ int harc_amd_preprocess_files(const char *fastq, const char *basedir, int32_t re
 int harc_amd_decoder_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e);
 /* == `unpack_order.out` + `decoder_preserve.out` + `merge_N.out` (harc:183-185, -p): needs read_order.bin(+.tail) as written by
    pack_order, read_order_N_pe.bin and read_order_N.bin; writes output/output.dna = the reads in their original FASTQ order.
-   Everything is held in HBM at once (about 3 x (readlen+1) bytes per read, ~900 M reads of 100 bp on one MI355X; the reference bins
-   through host memory instead, decoder_preserve.cpp:249-253); larger archives fail with HARC_AMD_ENOMEM */
+   The order is restored in bins of output lines (params.decode_memory_gb, the reference's -m; capped by what fits in HBM): every bin
+   decodes the streams again and keeps its own lines, so neither HBM nor host memory grows with the archive (the reference bins
+   through host memory and a temporary file, decoder_preserve.cpp:246-290) */
 int harc_amd_decoder_preserve_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e);
 /* One rank of a multi-GPU `./harc -c -g <world>`: reads its slice of the FASTQ file (cut at record boundaries near rank/world of the
    file), joins the communicator named by comm_spec -- "rccl:<file>" (rank 0 writes the ncclUniqueId there, the others wait for it) or

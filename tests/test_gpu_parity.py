@@ -691,3 +691,35 @@ def test_a_failed_run_leaves_the_context_usable(monkeypatch, tmp_path):
     for n in (12, 40):
         out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, HARC_AMD_FAIL_ALLOC=str(n)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert out.returncode == 0 and "FAILED -5" in out.stdout and "SAME" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("case,E,bins", [("L100_err_5k", 2, 777), ("L100_repfam_5k", 3, 64), ("L150_err_3k", 2, 1000), ("L100_allN_20", 1, 3), ("L100_gen_noRC_e_3k", 1, 1)])
+def test_preserve_order_decoder_in_small_bins(case, E, bins, tmp_path, monkeypatch):
+    """-d -p with the order restored in bins of a few output lines (the reference's -m / MAX_BIN_SIZE path, decoder_preserve.cpp:246-290;
+    HARC_AMD_BIN_READS forces the bin size): every bin decodes the streams again and keeps its own lines.  Same bytes as the input file
+    and as the REAL reference's unpack_order + decoder_preserve + merge_N on the same archive."""
+    import shutil, subprocess
+    import harc_amd
+    g = ol.load_golden(case)
+    L = _L(g)
+    reads = g["reads.txt"].split()
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(_fastq(reads, L))
+    a, b = tmp_path / "a", tmp_path / "b"
+    os.makedirs(a / "output")
+    harc_amd.compress_fastq(str(fq), str(a), L, num_thr=E, num_chains=3, num_steps=16)
+    if len(ol.read_dir(str(a))["read_order.bin"]) == 0:
+        (a / "output" / "read_order.bin").write_bytes(b"")      # all reads have N: pack_order.cpp:36 is undefined on an empty order
+        (a / "output" / "read_order.bin.tail").write_bytes(b"")
+    else:
+        harc_amd.pack_order(str(a), L)
+    shutil.copytree(a, b)
+    monkeypatch.setenv("HARC_AMD_BIN_READS", str(bins))
+    harc_amd.decoder(str(a), E, preserve_order=True, memory_gb=1)
+    assert (a / "output" / "output.dna").read_bytes() == g["reads.txt"]
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    dp = os.path.join(ref, "decoder_preserve_L%d_e%d.out" % (L, E))
+    if os.path.exists(dp) and len(ol.read_dir(str(b))["read_order.bin"]) > 0:
+        for exe in ("unpack_order.out", os.path.basename(dp), "merge_N.out"):
+            subprocess.run([os.path.join(ref, exe), str(b)], check=True, stdout=subprocess.DEVNULL)
+        assert (b / "output" / "output.dna").read_bytes() == g["reads.txt"]
