@@ -110,29 +110,48 @@ static int build_line_index(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes,
     return HARC_AMD_OK;
 }
 
-// FASTQ text already in device memory -> the context's clean reads (2-bit) and N reads (3-bit); the original indices of the N reads
-// (read_order_N.bin, u32 each) are returned through harc_amd_get_stream(HARC_AMD_IN_ORDER_N)
-extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes, uint64_t *n_records_out)
+// FASTQ text in device memory -> the context's clean reads (2-bit) and N reads (3-bit), a chunk of whole records at a time: a file
+// larger than HBM is ingested in pieces (harc_amd_compress_fastq_files_ex), the packed stores grow as the pieces arrive.
+struct IngestState {
+    uint64_t nC = 0, nN = 0, nrec = 0, nfull = 0;                 // clean reads, reads with N, reads, complete records so far
+    std::vector<uint32_t> orderN;                                 // read_order_N.bin: record number of every read with N (preprocess.cpp:102)
+};
+static int ingest_begin(harc_amd_ctx *c, IngestState &st)
 {
-    if (!c || (nbytes && !d_txt)) return HARC_AMD_EINVAL;
-    HIP_TRY(hipSetDevice(c->P.device));
+    st = IngestState();
+    // same effect as harc_amd_set_reads_* on an empty set: previous inputs and results go
+    RC_TRY(harc_amd_set_reads_packed_device(c, nullptr, 0));
+    RC_TRY(harc_amd_set_nreads_ascii_device(c, nullptr, 0, (uint32_t)c->P.readlen));
+    return HARC_AMD_OK;
+}
+// grows *b to `need` bytes keeping its first `keep` bytes
+static int in_grow(harc_amd_ctx *c, harc_amd_ctx::InBuf *b, size_t need, size_t keep)
+{
+    if (b->p && b->cap >= need) return HARC_AMD_OK;
+    harc_amd_ctx::InBuf nb;
+    RC_TRY(harc_in_reserve(c, &nb, need + (keep ? need / 4 : 0)));
+    if (keep) HIP_TRY(hipMemcpyAsync(nb.p, b->p, keep, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (b->p) harc_raw_free(c, b->p);
+    *b = nb;
+    return HARC_AMD_OK;
+}
+// one chunk of whole 4-line records (the last chunk of the file may end inside a record).  expect_*: the caller's estimate of the final
+// counts (0 = unknown), so that the stores are sized once
+static int ingest_append(harc_amd_ctx *c, IngestState &st, const char *d_txt, uint64_t nbytes, bool last, uint64_t expect_clean, uint64_t expect_N)
+{
+    if (nbytes == 0) return HARC_AMD_OK;
     const int L = c->P.readlen;
-    // drop previous inputs / results
-    {
-        // same effect as harc_amd_set_reads_* on an empty set
-        RC_TRY(harc_amd_set_reads_packed_device(c, nullptr, 0));
-        RC_TRY(harc_amd_set_nreads_ascii_device(c, nullptr, 0, (uint32_t)L));
-    }
-    if (nbytes == 0) { if (n_records_out) *n_records_out = 0; out_buf(c, HARC_AMD_IN_ORDER_N, 0).clear(); return HARC_AMD_OK; }
     const harc_mark_t mk = harc_pool_mark(c);
     struct Rel { harc_amd_ctx *c; harc_mark_t mk; ~Rel() { harc_pool_release(c, mk); } } rel{ c, mk };       // scratch goes on every way out
     const uint64_t *nls = nullptr; uint64_t total_lines = 0;
     RC_TRY(build_line_index(c, d_txt, nbytes, &nls, &total_lines));
+    if (!last && (total_lines % 4)) { harc_set_error("FASTQ: a piece of the file does not hold whole 4-line records (%llu lines)", (unsigned long long)total_lines); return HARC_AMD_EINVAL; }
     // a truncated last record still counts as a read when its sequence line is there: the getline loop handles line 2 before it meets
     // the end of the file (preprocess.cpp:90-111); only `readnum` (case 3, :118) misses it
     const uint64_t nfull = total_lines / 4;
     const uint64_t nrec64 = nfull + ((total_lines % 4) >= 2 ? 1 : 0);
-    if (nrec64 > 4294967290ull) { harc_set_error("Too many reads. HARC supports at most 4294967290 reads"); return HARC_AMD_EINVAL; }   // preprocess.cpp:122-126
+    if (st.nrec + nrec64 > 4294967290ull) { harc_set_error("Too many reads. HARC supports at most 4294967290 reads"); return HARC_AMD_EINVAL; }   // preprocess.cpp:122-126
     const uint32_t nrec = (uint32_t)nrec64;
     uint32_t *isN = nullptr, *isC = nullptr, *rkN = nullptr, *rkC = nullptr; unsigned int *d_err = nullptr;
     RC_TRY(dalloc(c, &isN, (size_t)nrec + 1)); RC_TRY(dalloc(c, &isC, (size_t)nrec + 1)); RC_TRY(dalloc(c, &rkN, (size_t)nrec + 1)); RC_TRY(dalloc(c, &rkC, (size_t)nrec + 1));
@@ -150,22 +169,46 @@ extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uin
         printf("Read length not fixed. Found reads whose length is not %d\n", L);
         harc_set_error("read length not fixed (%u records differ from %d)", err, L); return HARC_AMD_EINVAL;
     }
-    // the packed stores outlive the scratch: raw allocations (as harc_amd_set_reads_*)
-    RC_TRY(harc_in_reserve(c, &c->own_reads, ((size_t)nC * c->W + 1) * 8));
-    RC_TRY(harc_in_reserve(c, &c->own_nreads3, ((size_t)nN * c->W3 + 1) * 8));
-    c->N_own = nC; c->NN_own = nN;
-    harc_reset_shard(c);
-    c->nrec_own = nrec64;
+    // the packed stores outlive the scratch: raw allocations (as harc_amd_set_reads_*), grown when a piece does not fit
+    const uint64_t wantC = std::max<uint64_t>(st.nC + nC, expect_clean), wantN = std::max<uint64_t>(st.nN + nN, expect_N);
+    RC_TRY(in_grow(c, &c->own_reads, ((size_t)wantC * c->W + 1) * 8, (size_t)st.nC * c->W * 8));
+    RC_TRY(in_grow(c, &c->own_nreads3, ((size_t)wantN * c->W3 + 1) * 8, (size_t)st.nN * c->W3 * 8));
     uint32_t *orderN = nullptr; RC_TRY(dalloc(c, &orderN, (size_t)nN + 1));
     if (nrec) {
-        hipLaunchKernelGGL(k_ingest_pack2, G256((uint64_t)nrec * c->W), d_txt, nls, isC, rkC, nrec, L, c->W, c->d_reads);
-        hipLaunchKernelGGL(k_ingest_pack3, G256((uint64_t)nrec * c->W3), d_txt, nls, isN, rkN, nrec, L, c->W3, c->d_nreads3, orderN);
+        hipLaunchKernelGGL(k_ingest_pack2, G256((uint64_t)nrec * c->W), d_txt, nls, isC, rkC, nrec, L, c->W, (uint64_t *)c->own_reads.p + (size_t)st.nC * c->W);
+        hipLaunchKernelGGL(k_ingest_pack3, G256((uint64_t)nrec * c->W3), d_txt, nls, isN, rkN, nrec, L, c->W3, (uint64_t *)c->own_nreads3.p + (size_t)st.nN * c->W3, orderN);
     }
     HIP_TRY(hipGetLastError());
-    std::vector<uint8_t> &ob = out_buf(c, HARC_AMD_IN_ORDER_N, 0);
-    RC_TRY(harc_d2h(c, ob, orderN, (size_t)nN * 4));
+    const size_t at = st.orderN.size();
+    st.orderN.resize(at + nN);
+    if (nN) HIP_TRY(hipMemcpyAsync(st.orderN.data() + at, orderN, (size_t)nN * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (n_records_out) *n_records_out = nfull;                    // what preprocess.cpp:134 prints: complete records
+    for (size_t i = at; i < st.orderN.size(); i++) st.orderN[i] += (uint32_t)st.nrec;       // records of the earlier pieces come first
+    st.nC += nC; st.nN += nN; st.nrec += nrec64; st.nfull += nfull;
+    return HARC_AMD_OK;
+}
+static int ingest_finish(harc_amd_ctx *c, IngestState &st)
+{
+    c->N_own = (uint32_t)st.nC; c->NN_own = (uint32_t)st.nN;
+    harc_reset_shard(c);
+    c->nrec_own = st.nrec;
+    std::vector<uint8_t> &ob = out_buf(c, HARC_AMD_IN_ORDER_N, 0);
+    ob.resize(st.orderN.size() * 4);
+    if (!st.orderN.empty()) memcpy(ob.data(), st.orderN.data(), ob.size());
+    return HARC_AMD_OK;
+}
+
+// the whole FASTQ text at once; the original indices of the N reads (read_order_N.bin, u32 each) are returned through
+// harc_amd_get_stream(HARC_AMD_IN_ORDER_N)
+extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes, uint64_t *n_records_out)
+{
+    if (!c || (nbytes && !d_txt)) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    IngestState st;
+    RC_TRY(ingest_begin(c, st));
+    RC_TRY(ingest_append(c, st, d_txt, nbytes, true, 0, 0));
+    RC_TRY(ingest_finish(c, st));
+    if (n_records_out) *n_records_out = st.nfull;                 // what preprocess.cpp:134 prints: complete records
     return HARC_AMD_OK;
 }
 
@@ -242,6 +285,23 @@ static int emit_lines(harc_amd_ctx *c, const char *d_txt, const uint64_t *nls, c
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (total && fwrite(host.data(), 1, (size_t)total, fo) != (size_t)total) { harc_set_error("short write"); return HARC_AMD_EIO; }
     }
+    return HARC_AMD_OK;
+}
+
+// -q -p (preprocess.cpp:64-69): quality values and ids in file order; one piece of whole records at a time, appended to the open files
+static int emit_q_fileorder(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes, FILE *fq, FILE *fi)
+{
+    if (nbytes == 0) return HARC_AMD_OK;
+    const harc_mark_t mk = harc_pool_mark(c);
+    struct Rel { harc_amd_ctx *c; harc_mark_t mk; ~Rel() { harc_pool_release(c, mk); } } rel{ c, mk };
+    const uint64_t *nls = nullptr; uint64_t total_lines = 0;
+    RC_TRY(build_line_index(c, d_txt, nbytes, &nls, &total_lines));
+    const uint32_t nrec = (uint32_t)(total_lines / 4);
+    const uint32_t nid = nrec + (total_lines % 4 ? 1u : 0u);       // the id line of a truncated last record is still written (case 0 of the getline loop)
+    uint32_t *rec = nullptr; RC_TRY(dalloc(c, &rec, (size_t)nid + 1));
+    hipLaunchKernelGGL(k_q_iota, G256((size_t)nid + 1), rec, nid + 1);
+    RC_TRY(emit_lines(c, d_txt, nls, rec, nrec, 3, -1, fq));
+    RC_TRY(emit_lines(c, d_txt, nls, rec, nid, 0, -1, fi));
     return HARC_AMD_OK;
 }
 
@@ -373,52 +433,6 @@ static int write_shard_family(harc_amd_ctx *c, const std::string &od, int first_
     return HARC_AMD_OK;
 }
 
-// FASTQ file -> every stage-II file under <basedir>/output (+ read_order_N.bin, numreads.bin): harc:50-69 without input_clean.dna
-extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order, int32_t preserve_quality)
-{
-    if (!params || !fastq || !basedir) return HARC_AMD_EINVAL;
-    harc_amd_ctx *c = nullptr;
-    RC_TRY(harc_amd_create(params, &c));
-    struct Guard { harc_amd_ctx *c; ~Guard() { harc_amd_destroy(c); } } guard{ c };
-    FILE *f = fopen(fastq, "rb");
-    if (!f) { harc_set_error("cannot open %s", fastq); return HARC_AMD_EIO; }
-    struct FClose { FILE *f; ~FClose() { fclose(f); } } fcl{ f };
-    fseeko(f, 0, SEEK_END); const uint64_t fsz = (uint64_t)ftello(f);
-    char *d_txt = nullptr;
-    RC_TRY(load_file_range(c, f, fastq, 0, fsz, &d_txt));
-    uint64_t nrec = 0;
-    int rc = harc_amd_set_fastq_device(c, d_txt, fsz, &nrec);
-    if (!preserve_quality || rc != HARC_AMD_OK) { harc_raw_free(c, d_txt); d_txt = nullptr; }
-    if (rc != HARC_AMD_OK) return rc;
-    printf("Read length: %d\nTotal number of reads: %llu\nTotal number of reads without N: %llu\nPreprocessing Done!\n", params->readlen,
-           (unsigned long long)nrec, (unsigned long long)c->N);                                           // preprocess.cpp:133-136
-    const std::string od = std::string(basedir) + "/output/";
-    RC_TRY(spit_stream_to(c, HARC_AMD_IN_ORDER_N, 0, od + "read_order_N.bin"));
-    { const uint32_t n32 = c->N; RC_TRY(spit_file(od + "numreads.bin", &n32, 4)); }
-    RC_TRY(harc_amd_reorder(c));
-    RC_TRY(harc_amd_encode(c));
-    harc_amd_counters C; harc_amd_get_counters(c, &C);
-    printf("Reordering done, %llu were unmatched\n", (unsigned long long)C.unmatched);
-    printf("Encoding done:\n%llu singleton reads were aligned\n%llu reads with N were aligned\n", (unsigned long long)C.aligned_singletons, (unsigned long long)C.aligned_N);
-    RC_TRY(write_shard_family(c, od, 0));
-    static const struct { int id; const char *name; } whole[] = {
-        { HARC_AMD_S2_ORDER, "read_order.bin" }, { HARC_AMD_S2_ORDER_N_PE, "read_order_N_pe.bin" }, { HARC_AMD_S2_INPUT_N, "input_N.dna" },
-        { HARC_AMD_S2_META, "read_meta.txt" }, { HARC_AMD_S2_SINGLETON, "read_singleton.txt" }, { HARC_AMD_S2_SINGLETON_TAIL, "read_singleton.txt.tail" } };
-    for (auto &fd : whole) RC_TRY(spit_stream_to(c, fd.id, 0, od + fd.name));
-    if (preserve_quality) {
-        if (!preserve_order) printf("Reordering quality values and ids\n");                                 // harc:122
-        rc = emit_quality_and_ids(c, d_txt, fsz, preserve_order != 0, od, "output.quality", "output.id");
-        harc_raw_free(c, d_txt);
-        if (rc != HARC_AMD_OK) return rc;
-    }
-    return HARC_AMD_OK;
-}
-extern "C" int harc_amd_compress_fastq_files(const harc_amd_params *params, const char *fastq, const char *basedir)
-{
-    return harc_amd_compress_fastq_files_ex(params, fastq, basedir, 0, 0);
-}
-
-// ------------------------------------------------------------------------------------------------ one rank of a multi-GPU run
 // first byte >= pos at which a FASTQ record starts: a line that begins with '@' whose second successor begins with '+'.  (A quality
 // line may begin with '@' too, but then the line two further on is a sequence line, which never begins with '+'.)
 static int record_start_at_or_after(FILE *f, uint64_t pos, uint64_t fsz, uint64_t *out)
@@ -438,6 +452,91 @@ static int record_start_at_or_after(FILE *f, uint64_t pos, uint64_t fsz, uint64_
         if (lo + n >= fsz) { *out = fsz; return HARC_AMD_OK; }   // no further record
     }
 }
+// The records of bytes [lo, end) of the file, a piece at a time: every piece goes to HBM, is indexed, classified and packed, then makes room
+// for the next -- the file never has to fit next to the dictionaries.  With fq / fi (-q -p) the quality and id lines of every piece
+// are written out in file order on the way.
+static int ingest_file_range(harc_amd_ctx *c, FILE *f, const char *name, uint64_t lo, uint64_t end, uint64_t fsz, IngestState &st, FILE *fq, FILE *fi)
+{
+    uint64_t piece = (uint64_t)1 << 30;
+    if (const char *e = getenv("HARC_AMD_INGEST_CHUNK")) { piece = strtoull(e, nullptr, 10); if (piece < 16) piece = 16; }    // tests: pieces of a few records
+    RC_TRY(ingest_begin(c, st));
+    const uint64_t start = lo;
+    while (lo < end) {
+        uint64_t hi = end;
+        if (end - lo > piece) { RC_TRY(record_start_at_or_after(f, lo + piece, fsz, &hi)); if (hi > end) hi = end; if (hi <= lo) hi = end; }
+        char *d_txt = nullptr;
+        RC_TRY(load_file_range(c, f, name, lo, hi, &d_txt));
+        struct Free { harc_amd_ctx *c; char *p; ~Free() { harc_raw_free(c, p); } } fr{ c, d_txt };
+        // the first piece tells how many reads the whole range will hold, give or take: the stores are sized once
+        uint64_t expC = 0, expN = 0;
+        if (lo > start) { const double scale = 1.03 * (double)(end - start) / (double)(lo - start); expC = (uint64_t)(scale * (double)st.nC); expN = (uint64_t)(scale * (double)st.nN); }
+        RC_TRY(ingest_append(c, st, d_txt, hi - lo, hi == fsz, expC, expN));
+        if (fq) RC_TRY(emit_q_fileorder(c, d_txt, hi - lo, fq, fi));
+        lo = hi;
+    }
+    return ingest_finish(c, st);
+}
+
+// FASTQ file -> every stage-II file under <basedir>/output (+ read_order_N.bin, numreads.bin): harc:50-69 without input_clean.dna
+extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order, int32_t preserve_quality)
+{
+    if (!params || !fastq || !basedir) return HARC_AMD_EINVAL;
+    harc_amd_ctx *c = nullptr;
+    RC_TRY(harc_amd_create(params, &c));
+    struct Guard { harc_amd_ctx *c; ~Guard() { harc_amd_destroy(c); } } guard{ c };
+    FILE *f = fopen(fastq, "rb");
+    if (!f) { harc_set_error("cannot open %s", fastq); return HARC_AMD_EIO; }
+    struct FClose { FILE *f; ~FClose() { fclose(f); } } fcl{ f };
+    fseeko(f, 0, SEEK_END); const uint64_t fsz = (uint64_t)ftello(f);
+    const std::string od = std::string(basedir) + "/output/";
+    char *d_txt = nullptr;                                        // -q without -p: the whole text stays in HBM until the orders are known
+    struct FreeTxt { harc_amd_ctx *c; char **p; ~FreeTxt() { if (*p) harc_raw_free(c, *p); } } freetxt{ c, &d_txt };
+    IngestState st;
+    if (preserve_quality && !preserve_order) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)fsz > 0.45 * (double)fr) {
+            harc_set_error("-q without -p keeps the FASTQ text (%llu bytes) in HBM until the reads are reordered and it does not fit; use -p, or split the file", (unsigned long long)fsz);
+            return HARC_AMD_ENOMEM;
+        }
+        RC_TRY(load_file_range(c, f, fastq, 0, fsz, &d_txt));
+        RC_TRY(ingest_begin(c, st));
+        RC_TRY(ingest_append(c, st, d_txt, fsz, true, 0, 0));
+        RC_TRY(ingest_finish(c, st));
+    } else {
+        FILE *fq = nullptr, *fi = nullptr;
+        struct Closer { FILE **a, **b; ~Closer() { if (*a) fclose(*a); if (*b) fclose(*b); } } closer{ &fq, &fi };
+        if (preserve_quality) {
+            fq = fopen((od + "output.quality").c_str(), "wb"); fi = fopen((od + "output.id").c_str(), "wb");
+            if (!fq || !fi) { harc_set_error("cannot create %soutput.quality / output.id", od.c_str()); return HARC_AMD_EIO; }
+        }
+        RC_TRY(ingest_file_range(c, f, fastq, 0, fsz, fsz, st, fq, fi));
+    }
+    printf("Read length: %d\nTotal number of reads: %llu\nTotal number of reads without N: %llu\nPreprocessing Done!\n", params->readlen,
+           (unsigned long long)st.nfull, (unsigned long long)c->N);                                       // preprocess.cpp:133-136
+    RC_TRY(spit_stream_to(c, HARC_AMD_IN_ORDER_N, 0, od + "read_order_N.bin"));
+    { const uint32_t n32 = c->N; RC_TRY(spit_file(od + "numreads.bin", &n32, 4)); }
+    RC_TRY(harc_amd_reorder(c));
+    RC_TRY(harc_amd_encode(c));
+    harc_amd_counters C; harc_amd_get_counters(c, &C);
+    printf("Reordering done, %llu were unmatched\n", (unsigned long long)C.unmatched);
+    printf("Encoding done:\n%llu singleton reads were aligned\n%llu reads with N were aligned\n", (unsigned long long)C.aligned_singletons, (unsigned long long)C.aligned_N);
+    RC_TRY(write_shard_family(c, od, 0));
+    static const struct { int id; const char *name; } whole[] = {
+        { HARC_AMD_S2_ORDER, "read_order.bin" }, { HARC_AMD_S2_ORDER_N_PE, "read_order_N_pe.bin" }, { HARC_AMD_S2_INPUT_N, "input_N.dna" },
+        { HARC_AMD_S2_META, "read_meta.txt" }, { HARC_AMD_S2_SINGLETON, "read_singleton.txt" }, { HARC_AMD_S2_SINGLETON_TAIL, "read_singleton.txt.tail" } };
+    for (auto &fd : whole) RC_TRY(spit_stream_to(c, fd.id, 0, od + fd.name));
+    if (preserve_quality && !preserve_order) {
+        printf("Reordering quality values and ids\n");                                                      // harc:122
+        RC_TRY(emit_quality_and_ids(c, d_txt, fsz, false, od, "output.quality", "output.id"));
+    }
+    return HARC_AMD_OK;
+}
+extern "C" int harc_amd_compress_fastq_files(const harc_amd_params *params, const char *fastq, const char *basedir)
+{
+    return harc_amd_compress_fastq_files_ex(params, fastq, basedir, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ one rank of a multi-GPU run
 static int rendezvous(harc_amd_ctx *c, const char *spec, int world, int rank)
 {
     if (!spec) { harc_set_error("comm_spec missing"); return HARC_AMD_EINVAL; }
@@ -477,21 +576,21 @@ extern "C" int harc_amd_compress_fastq_shard_files(const harc_amd_params *params
     uint64_t lo = 0, hi = fsz;
     RC_TRY(record_start_at_or_after(f, fsz / (uint64_t)world * (uint64_t)rank, fsz, &lo));
     if (rank + 1 < world) RC_TRY(record_start_at_or_after(f, fsz / (uint64_t)world * (uint64_t)(rank + 1), fsz, &hi));
-    char *d_txt = nullptr;
-    RC_TRY(load_file_range(c, f, fastq, lo, hi, &d_txt));
-    uint64_t nrec_full = 0;
-    int rc = harc_amd_set_fastq_device(c, d_txt, hi - lo, &nrec_full);
-    if (!preserve_quality || rc != HARC_AMD_OK) { harc_raw_free(c, d_txt); d_txt = nullptr; }
-    if (rc != HARC_AMD_OK) return rc;
     const std::string od = std::string(basedir) + "/output/", sd = od + ".shard/", r = "." + std::to_string(rank);
     (void)mkdir(sd.c_str(), 0777);                                // every rank tries; the first one wins
-    const uint64_t n_clean_own = c->N_own;
-    std::vector<uint32_t> orderN;                                 // read_order_N.bin of this slice, local record numbers
-    { const void *p; size_t n; RC_TRY(harc_amd_get_stream(c, HARC_AMD_IN_ORDER_N, 0, &p, &n)); orderN.assign((const uint32_t *)p, (const uint32_t *)p + n / 4); }
-    if (preserve_quality) {                                       // file order (preprocess.cpp:64-69): the slices are concatenated by the merge
-        RC_TRY(emit_quality_and_ids(c, d_txt, hi - lo, true, sd, ("quality" + r).c_str(), ("id" + r).c_str()));
-        harc_raw_free(c, d_txt); d_txt = nullptr;
+    IngestState st;
+    {
+        FILE *fq = nullptr, *fi = nullptr;
+        struct Closer { FILE **a, **b; ~Closer() { if (*a) fclose(*a); if (*b) fclose(*b); } } closer{ &fq, &fi };
+        if (preserve_quality) {                                   // file order (preprocess.cpp:64-69): the slices are concatenated by the merge
+            fq = fopen((sd + "quality" + r).c_str(), "wb"); fi = fopen((sd + "id" + r).c_str(), "wb");
+            if (!fq || !fi) { harc_set_error("cannot create the quality / id parts under %s", sd.c_str()); return HARC_AMD_EIO; }
+        }
+        RC_TRY(ingest_file_range(c, f, fastq, lo, hi, fsz, st, fq, fi));
     }
+    const uint64_t nrec_full = st.nfull;
+    const uint64_t n_clean_own = c->N_own;
+    std::vector<uint32_t> orderN = st.orderN;                     // read_order_N.bin of this slice, local record numbers
     RC_TRY(rendezvous(c, comm_spec, world, rank));
     uint64_t info[8];
     RC_TRY(harc_amd_shard_exchange(c, info));

@@ -723,3 +723,35 @@ def test_preserve_order_decoder_in_small_bins(case, E, bins, tmp_path, monkeypat
         for exe in ("unpack_order.out", os.path.basename(dp), "merge_N.out"):
             subprocess.run([os.path.join(ref, exe), str(b)], check=True, stdout=subprocess.DEVNULL)
         assert (b / "output" / "output.dna").read_bytes() == g["reads.txt"]
+
+
+@pytest.mark.parametrize("case,piece", [("L100_err_5k", 3000), ("L150_err_3k", 700), ("L100_repfam_5k", 100000), ("L100_three", 16)])
+def test_fastq_ingest_in_pieces_is_the_same(case, piece, tmp_path, monkeypatch):
+    """a FASTQ larger than HBM is ingested a piece of whole records at a time (HARC_AMD_INGEST_CHUNK forces pieces of a few records here;
+    quality lines that begin with '@' sit at the cuts): same files as the one-piece ingest, -q -p files in file order, truncated last
+    record handled as the reference's getline loop does (preprocess.cpp:90-111)"""
+    import numpy as np
+    import harc_amd
+    g = ol.load_golden(case)
+    L = _L(g)
+    reads = g["reads.txt"].split()
+    rs = np.random.RandomState(4)
+    quals = [bytes([64] + [50 + int(x) for x in rs.randint(0, 20, L - 1)]) for _ in reads]
+    ids = [b"@r%d %s" % (i, b"x" * int(rs.randint(0, 30))) for i in range(len(reads))]
+    body = b"".join(b"%s\n%s\n+\n%s\n" % t for t in zip(ids, reads, quals))
+    body += b"@last\n" + reads[0]                                  # a truncated last record: its read counts, it has no quality line
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(body)
+    outs = []
+    for d, env in (("whole", None), ("pieces", str(piece))):
+        base = tmp_path / d
+        os.makedirs(base / "output")
+        if env:
+            monkeypatch.setenv("HARC_AMD_INGEST_CHUNK", env)
+        harc_amd.compress_fastq(str(fq), str(base), L, num_thr=2, num_chains=4, num_steps=16, preserve_order=True, preserve_quality=True)
+        outs.append(ol.read_dir(str(base)))
+    assert outs[0].keys() == outs[1].keys()
+    for k in outs[0]:
+        assert outs[0][k] == outs[1][k], k
+    assert outs[1]["output.quality"].split(b"\n")[:-1] == quals and outs[1]["output.id"].split(b"\n")[:-1] == ids + [b"@last"]
+    assert np.frombuffer(outs[1]["numreads.bin"], dtype=np.uint32)[0] == sum(1 for r in reads + [reads[0]] if b"N" not in r)
