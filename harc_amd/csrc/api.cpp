@@ -168,11 +168,12 @@ extern "C" void harc_amd_destroy(harc_amd_ctx *c)
     delete c;
 }
 
-static void drop_results(harc_amd_ctx *c)
+void harc_drop_results(harc_amd_ctx *c)
 {
     harc_pool_release(c, 0);                                     // every per-run buffer lives in the pool
     c->d_order = nullptr; c->d_flag = c->d_pos = c->d_rc = nullptr; c->d_order_s = nullptr; c->d_oreads = nullptr; c->d_sreads = nullptr;
     c->have_s1 = c->have_s2 = c->s1_from_files = false; c->M = c->S = 0;
+    c->d_s2_order = c->d_s2_orderN = nullptr; c->n_s2_order = c->n_s2_orderN = 0;
     // results go; what came with the inputs (HARC_AMD_IN_ORDER_N, owned bytes) stays until the inputs are replaced
     for (auto it = c->out.begin(); it != c->out.end();) { if (it->first.first < HARC_AMD_IN_ORDER_N) it = c->out.erase(it); else ++it; }
     harc_host_reset(c);
@@ -206,7 +207,7 @@ extern "C" int harc_amd_set_reads_ascii_device(harc_amd_ctx *c, const char *d_as
 {
     if (!c || (n && !d_ascii) || stride < (uint32_t)c->P.readlen) return HARC_AMD_EINVAL;
     HIP_TRY(hipSetDevice(c->P.device));
-    drop_results(c);
+    harc_drop_results(c);
     c->out.erase(std::make_pair((int)HARC_AMD_IN_ORDER_N, 0));
     RC_TRY(harc_in_reserve(c, &c->own_reads, ((size_t)n * c->W + 1) * 8));
     c->N_own = n; c->nrec_own = (uint64_t)n + c->NN_own;
@@ -230,7 +231,7 @@ extern "C" int harc_amd_set_reads_packed_device(harc_amd_ctx *c, const uint64_t 
 {
     if (!c || (n && !d_packed)) return HARC_AMD_EINVAL;
     HIP_TRY(hipSetDevice(c->P.device));
-    drop_results(c);
+    harc_drop_results(c);
     c->out.erase(std::make_pair((int)HARC_AMD_IN_ORDER_N, 0));
     RC_TRY(harc_in_reserve(c, &c->own_reads, ((size_t)n * c->W + 1) * 8));
     c->N_own = n; c->nrec_own = (uint64_t)n + c->NN_own;
@@ -269,7 +270,7 @@ extern "C" int harc_amd_set_stage1_streams(harc_amd_ctx *c, const char *temp_dna
 {
     if (!c || (M && (!temp_dna || !flag || !pos || !order || !rc)) || (S && (!temp_dna_s || !order_s))) return HARC_AMD_EINVAL;
     HIP_TRY(hipSetDevice(c->P.device));
-    drop_results(c);
+    harc_drop_results(c);
     const int L = c->P.readlen;
     c->M = M; c->S = S;
     RC_TRY(dalloc(c, &c->d_order, (size_t)M + 1)); RC_TRY(dalloc(c, &c->d_flag, (size_t)M + 1)); RC_TRY(dalloc(c, &c->d_pos, (size_t)M + 1));
@@ -326,7 +327,7 @@ extern "C" int harc_amd_reorder(harc_amd_ctx *c)
     if (!c) return HARC_AMD_EINVAL;
     if (!c->d_reads) { harc_set_error("harc_amd_reorder: no reads set"); return HARC_AMD_ESTATE; }
     HIP_TRY(hipSetDevice(c->P.device));
-    drop_results(c);
+    harc_drop_results(c);
     const double t0 = now_ms();
     RC_TRY(stage1_run(c));
     c->C.total_ms = now_ms() - t0;
@@ -395,6 +396,16 @@ extern "C" int harc_amd_get_stream(harc_amd_ctx *c, int32_t id, int32_t shard, c
                 break; }
             }
             HIP_TRY(hipStreamSynchronize(c->stream));
+            it = c->out.find(key);
+        } else if ((id == HARC_AMD_S2_ORDER || id == HARC_AMD_S2_ORDER_N_PE) && shard == 0 && c->have_s2 && c->d_s2_order) {
+            // the order streams of stage II wait in HBM until they are wanted
+            const uint32_t *d = id == HARC_AMD_S2_ORDER ? c->d_s2_order : c->d_s2_orderN;
+            const size_t n = id == HARC_AMD_S2_ORDER ? c->n_s2_order : c->n_s2_orderN;
+            uint8_t *hp = nullptr;
+            RC_TRY(harc_host_alloc(c, (void **)&hp, n));
+            if (n) HIP_TRY(hipMemcpyAsync(hp, d, n, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            out_slice(c, id, shard, hp, n);
             it = c->out.find(key);
         } else { harc_set_error("stream %d shard %d not available", id, shard); return HARC_AMD_ESTATE; }
     }

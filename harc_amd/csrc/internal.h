@@ -117,6 +117,8 @@ struct harc_amd_ctx {
     uint64_t *d_sreads = nullptr;          // S x W singleton reads (= temp.dna.singleton), only when set from files
     bool s1_from_files = false;
     bool have_s2 = false;
+    // read_order.bin / read_order_N_pe.bin of stage II stay in HBM until somebody asks for them (they are only archived with -p)
+    uint32_t *d_s2_order = nullptr, *d_s2_orderN = nullptr; size_t n_s2_order = 0, n_s2_orderN = 0;
 
     // (stream id, shard) -> bytes: either a slice of the pinned host arena (ptr/len) or an owned vector
     struct OutBuf { const uint8_t *ptr = nullptr; size_t len = 0; std::vector<uint8_t> own; };
@@ -143,7 +145,8 @@ struct HarcComm {
     virtual const char *name() const = 0;
 };
 int harc_in_reserve(harc_amd_ctx *c, harc_amd_ctx::InBuf *b, size_t bytes);   // raw allocation reused across runs
-void harc_reset_shard(harc_amd_ctx *c);                                       // stages read the context's own inputs again
+void harc_reset_shard(harc_amd_ctx *c);
+void harc_drop_results(harc_amd_ctx *c);                                       // results of the last run go; inputs (and what came with them) stay                                       // stages read the context's own inputs again
 
 // ---- device memory helpers (api.cpp)
 int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes);

@@ -112,11 +112,7 @@ extern "C" int harc_amd_shard_exchange(harc_amd_ctx *c, uint64_t *info)
     const int world = cm->world, rank = cm->rank;
     const int W = c->W, W3 = c->W3;
     // results of an earlier run go (as every harc_amd_set_* does); the stages will read the shard from here on
-    harc_pool_release(c, 0);
-    c->d_order = nullptr; c->d_flag = c->d_pos = c->d_rc = nullptr; c->d_order_s = nullptr; c->d_oreads = nullptr; c->d_sreads = nullptr;
-    c->have_s1 = c->have_s2 = c->s1_from_files = false; c->M = c->S = 0;
-    for (auto it = c->out.begin(); it != c->out.end();) { if (it->first.first < HARC_AMD_IN_ORDER_N) it = c->out.erase(it); else ++it; }
-    harc_host_reset(c);
+    harc_drop_results(c);
     harc_reset_shard(c);
     const uint32_t N = c->N_own, NN = c->NN_own;
     const uint64_t *own2 = (const uint64_t *)c->own_reads.p, *own3 = (const uint64_t *)c->own_nreads3.p;

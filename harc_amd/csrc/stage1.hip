@@ -656,11 +656,12 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
             // first batch: twice the priority index of the chain's previous hit (high coverage -> hits at small shifts -> narrow first
             // batch), at most FIRSTMAX probes; every later batch is a full wave.  With many chains the kernel runs at the random-access
             // ceiling of the memory system (tools/micro/gups.hip: 26 G 32-byte requests/s beyond 16 GiB), so speculative probes cost
-            // throughput: FIRSTMAX = 32 there (+8 %); with few chains a round trip costs more than the probes.
+            // throughput: the first two batches are FIRSTMAX = 32 wide there (+8 % and +3 %); with few chains a round trip costs more
+            // than the probes.
             // s.nbatch > 0 (HARC_AMD_BATCHES) overrides with a fixed schedule.
             int bend;
             if (s.nbatch > 0) bend = s.batch_end[bi < s.nbatch ? bi : s.nbatch - 1];
-            else { int w0 = bi == 0 ? ((2 * lastp + 16 + 15) & ~15) : 64; if (w0 > (bi == 0 ? FIRSTMAX : 64)) w0 = bi == 0 ? FIRSTMAX : 64; bend = base + w0; }
+            else { int w0 = bi == 0 ? ((2 * lastp + 16 + 15) & ~15) : 64; const int wmax = bi <= 1 ? FIRSTMAX : 64; if (w0 > wmax) w0 = wmax; bend = base + w0; }
             if (bend > s.nprobe) bend = s.nprobe;
             if (bend <= base) bend = s.nprobe;
             const int p = base + lane; dbg_batches++;
@@ -1129,19 +1130,26 @@ __global__ void k_chain_counts(const ChainHdr *hdr, const uint4 *cstat, const ui
     }
 }
 // per-chain streams concatenated in chain order (reorder.cpp:778-821)
+// Two passes: the record of read i goes, as ONE 8-byte store, to its place in chain-major order (a random 32-byte sector per read instead
+// of four: the scatter runs at the random-access ceiling of the memory system); a streaming pass then splits the records into the four
+// files of reorder.cpp:722-830.
 __global__ void k_s1_scatter(const LogRec *log, unsigned long long nlog, uint32_t K, const uint32_t *base_main, const uint32_t *base_sing,
-                             uint32_t *order, uint8_t *flag, uint8_t *pos, uint8_t *rc, uint32_t *order_s, unsigned long long *bad)
+                             uint2 *rec, uint32_t *order_s, unsigned long long *bad)
 {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nlog) return;
     const LogRec r = log[i];
     if (r.chain >= K || r.rid != (uint32_t)i) { atomicAdd(bad, 1ULL); return; }      // a read nobody emitted (the log starts as 0xFF)
     if (r.meta & (1u << 10)) order_s[base_sing[r.chain] + r.seq] = r.rid;
-    else {
-        const uint32_t at = base_main[r.chain] + r.seq;
-        order[at] = r.rid; pos[at] = (uint8_t)(r.meta & 0xFF);
-        flag[at] = (r.meta >> 8) & 1 ? '1' : '0'; rc[at] = (r.meta >> 9) & 1 ? 'r' : 'd';
-    }
+    else rec[base_main[r.chain] + r.seq] = make_uint2(r.rid, r.meta);
+}
+__global__ void k_s1_split(const uint2 *rec, uint32_t m, uint32_t *order, uint8_t *flag, uint8_t *pos, uint8_t *rc)
+{
+    const uint32_t at = blockIdx.x * blockDim.x + threadIdx.x;
+    if (at >= m) return;
+    const uint2 r = rec[at];
+    order[at] = r.x; pos[at] = (uint8_t)(r.y & 0xFF);
+    flag[at] = (r.y >> 8) & 1 ? '1' : '0'; rc[at] = (r.y >> 9) & 1 ? 'r' : 'd';
 }
 // temp.dna in HBM: read `order[i]`, reverse-complemented where rc[i]=='r' (reorder.cpp:743-752)
 template <int W> __global__ void k_orient(const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, int L, uint64_t *out)
@@ -1434,8 +1442,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if ((unsigned long long)M + S != nlog) { harc_set_error("stage I bookkeeping: M=%u S=%u N=%u", M, S, N); return HARC_AMD_EINTERNAL; }
     c->M = M; c->S = S;
     unsigned long long *d_bad = a.stats + ST_N - 1;               // last statistics word: records that nobody wrote
-    if (nlog) hipLaunchKernelGGL(k_s1_scatter, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, c->stream, a.log, nlog, K, bmain, bsing,
-                                 c->d_order, c->d_flag, c->d_pos, c->d_rc, c->d_order_s, d_bad);
+    uint2 *d_rec = nullptr; RC_TRY(dalloc(c, &d_rec, (size_t)M + 1));
+    if (nlog) hipLaunchKernelGGL(k_s1_scatter, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, c->stream, a.log, nlog, K, bmain, bsing, d_rec, c->d_order_s, d_bad);
+    if (M) hipLaunchKernelGGL(k_s1_split, dim3((M + 255) / 256), dim3(256), 0, c->stream, (const uint2 *)d_rec, M, c->d_order, c->d_flag, c->d_pos, c->d_rc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

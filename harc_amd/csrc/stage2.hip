@@ -647,6 +647,10 @@ int stage2_run(harc_amd_ctx *c)
     // drop earlier stage-II outputs
     for (auto it = c->out.begin(); it != c->out.end();) { if (it->first.first >= HARC_AMD_S2_SEQ) it = c->out.erase(it); else ++it; }
 
+    // the two order streams outlive the scratch: worst-case sized, copied to the host only when asked for (harc_amd_get_stream)
+    uint32_t *order_out = nullptr, *orderN_out = nullptr;
+    RC_TRY(dalloc(c, &order_out, (size_t)M + S + 1)); RC_TRY(dalloc(c, &orderN_out, (size_t)NN + 1));
+    c->d_s2_order = c->d_s2_orderN = nullptr; c->n_s2_order = c->n_s2_orderN = 0;
     const harc_mark_t mark_s2 = harc_pool_mark(c);
     S2Args a; memset(&a, 0, sizeof a);
     a.L = L; a.W = W; a.W3 = W3; a.thresh_s = P.thresh_s; a.maxsearch = P.maxsearch;
@@ -832,10 +836,10 @@ int stage2_run(harc_amd_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint32_t n_N_aligned = F - n_nonN;
 
-    uint8_t *noise = nullptr, *noisepos = nullptr, *posb = nullptr, *rcb = nullptr; uint32_t *order_out = nullptr, *orderN_out = nullptr;
+    uint8_t *noise = nullptr, *noisepos = nullptr, *posb = nullptr, *rcb = nullptr;
     uint8_t *sing_bases = nullptr; char *ntext = nullptr;
     RC_TRY(dalloc(c, &noise, (size_t)nmtot + F + 1)); RC_TRY(dalloc(c, &noisepos, (size_t)nmtot + 1)); RC_TRY(dalloc(c, &posb, (size_t)F + 1)); RC_TRY(dalloc(c, &rcb, (size_t)F + 8));
-    RC_TRY(dalloc(c, &order_out, (size_t)n_nonN + US + 1)); RC_TRY(dalloc(c, &orderN_out, (size_t)n_N_aligned + UN + 1));
+    if ((size_t)n_nonN + US > (size_t)M + S || (size_t)n_N_aligned + UN > (size_t)NN) { harc_set_error("stage II bookkeeping: %u + %u clean, %u + %u N order entries", n_nonN, US, n_N_aligned, UN); return HARC_AMD_EINTERNAL; }
     RC_TRY(dalloc(c, &sing_bases, (size_t)US * L + 8)); RC_TRY(dalloc(c, &ntext, (size_t)UN * (L + 1) + 1));
     if (F) launch_noise<true>(c, a, f, cons2, F, nullptr, nullptr, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out);
     if (T) hipLaunchKernelGGL(k_left_emit, G256(T), a, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned, sing_bases, ntext);
@@ -886,18 +890,15 @@ int stage2_run(harc_amd_ctx *c)
     if (sing_nb) hipLaunchKernelGGL(k_pack2_bytes, G256(sing_nb), sing_bases, sing_nb, packed + sing_off);
     if (sing_tl) hipLaunchKernelGGL(k_bases_to_ascii, G256(sing_tl), sing_bases + 4 * sing_nb, sing_tl, packed + sing_off + sing_nb);
     HIP_TRY(hipGetLastError());
-    uint8_t *h_packed = nullptr, *h_noise = nullptr, *h_noisepos = nullptr, *h_pos = nullptr, *h_order = nullptr, *h_orderN = nullptr, *h_ntext = nullptr, *h_meta = nullptr;
+    uint8_t *h_packed = nullptr, *h_noise = nullptr, *h_noisepos = nullptr, *h_pos = nullptr, *h_ntext = nullptr, *h_meta = nullptr;
     const size_t n_order = ((size_t)n_nonN + US) * 4, n_orderN = ((size_t)n_N_aligned + UN) * 4, n_ntext = (size_t)UN * (L + 1);
     RC_TRY(harc_host_alloc(c, (void **)&h_packed, (size_t)poff)); RC_TRY(harc_host_alloc(c, (void **)&h_noise, (size_t)nmtot + F));
     RC_TRY(harc_host_alloc(c, (void **)&h_noisepos, (size_t)nmtot)); RC_TRY(harc_host_alloc(c, (void **)&h_pos, F));
-    RC_TRY(harc_host_alloc(c, (void **)&h_order, n_order)); RC_TRY(harc_host_alloc(c, (void **)&h_orderN, n_orderN));
     RC_TRY(harc_host_alloc(c, (void **)&h_ntext, n_ntext)); RC_TRY(harc_host_alloc(c, (void **)&h_meta, 32));
     if (poff) HIP_TRY(hipMemcpyAsync(h_packed, packed, (size_t)poff, hipMemcpyDeviceToHost, c->stream));
     if (nmtot + F) HIP_TRY(hipMemcpyAsync(h_noise, noise, (size_t)nmtot + F, hipMemcpyDeviceToHost, c->stream));
     if (nmtot) HIP_TRY(hipMemcpyAsync(h_noisepos, noisepos, (size_t)nmtot, hipMemcpyDeviceToHost, c->stream));
     if (F) HIP_TRY(hipMemcpyAsync(h_pos, posb, F, hipMemcpyDeviceToHost, c->stream));
-    if (n_order) HIP_TRY(hipMemcpyAsync(h_order, order_out, n_order, hipMemcpyDeviceToHost, c->stream));
-    if (n_orderN) HIP_TRY(hipMemcpyAsync(h_orderN, orderN_out, n_orderN, hipMemcpyDeviceToHost, c->stream));
     if (n_ntext) HIP_TRY(hipMemcpyAsync(h_ntext, ntext, n_ntext, hipMemcpyDeviceToHost, c->stream));
     for (uint32_t e = 0; e < E; e++) {
         const uint32_t f0 = sh_f[e], f1 = sh_f[e + 1];
@@ -908,7 +909,7 @@ int stage2_run(harc_amd_ctx *c)
         out_slice(c, HARC_AMD_S2_NOISEPOS, e, h_noisepos + sh_nm[e], sh_nm[e + 1] - sh_nm[e]);
     }
     out_slice(c, HARC_AMD_S2_SINGLETON, 0, h_packed + sing_off, sing_nb); out_slice(c, HARC_AMD_S2_SINGLETON_TAIL, 0, h_packed + sing_off + sing_nb, sing_tl);
-    out_slice(c, HARC_AMD_S2_ORDER, 0, h_order, n_order); out_slice(c, HARC_AMD_S2_ORDER_N_PE, 0, h_orderN, n_orderN);
+    c->d_s2_order = order_out; c->n_s2_order = n_order; c->d_s2_orderN = orderN_out; c->n_s2_orderN = n_orderN;
     out_slice(c, HARC_AMD_S2_INPUT_N, 0, h_ntext, n_ntext);
     { const int ml = snprintf((char *)h_meta, 32, "%d\n", L); out_slice(c, HARC_AMD_S2_META, 0, h_meta, (size_t)ml); }
     unsigned long long big = 0;
@@ -924,6 +925,7 @@ int stage2_run(harc_amd_ctx *c)
 
 int pack_order_run(harc_amd_ctx *c)
 {
+    { const void *p0 = nullptr; size_t n0 = 0; if (c->d_s2_order) RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_ORDER, 0, &p0, &n0)); }   // the order stream waits in HBM until wanted
     auto it = c->out.find(std::make_pair((int)HARC_AMD_S2_ORDER, 0));
     if (it == c->out.end()) { harc_set_error("pack_order: no read_order.bin"); return HARC_AMD_ESTATE; }
     const uint8_t *in_p = it->second.ptr ? it->second.ptr : it->second.own.data();
