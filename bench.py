@@ -347,6 +347,14 @@ def main():
             roofline["traffic"] = round((tr["fetch_kb_per_launch"] + tr["write_kb_per_launch"]) * 1024.0, 1)
             roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / max(1.0, roofline["alg_bytes_per_launch"]), 2)
             roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this command, profiles/k_steps_traffic.json (" + tr.get("profile", "") + ")"
+            # the roofline that binds this kernel: random 32-byte sector requests per second (tools/micro/gups.hip) against the L2 misses
+            # of the PMC pass per launch, over the launch time measured live
+            ceil = json.load(open(os.path.join(ROOT, "profiles", "random_access_ceiling.json")))
+            if tr.get("tcc_miss") and avg_ms > 0:
+                req = tr["tcc_miss"] / (avg_ms * 1e-3) / 1e9
+                roofline["random_access"] = {"achieved": round(req, 2), "peak": ceil["G_requests_per_s"]["32B"], "unit": "G sector requests/s (L2 misses; 32-byte slot-pair and read fetches)",
+                                             "frac": round(req / ceil["G_requests_per_s"]["32B"], 3), "l2_misses_per_launch": tr["tcc_miss"],
+                                             "peak_source": "tools/micro/gups.hip, profiles/r02/gups.txt: independent random 32-B loads over 64 GiB"}
     except Exception:
         pass
     out = {
