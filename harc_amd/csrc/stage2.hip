@@ -371,7 +371,11 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args
 // and never below the sequential value (a read that looks visible with too-late claims above it is visible in the sequential run as
 // well), and a state that no event changes any more IS the sequential one.  So: one wave per event, all events at once, 64
 // candidates per round trip, repeated until a pass changes nothing -- as many passes as the deepest bin has windows of maxsearch.
-__global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, unsigned int *changed)
+// estart[e]: the reads of the bin at positions >= estart[e] (the highest ids) were claimed before event e's tuple in an earlier pass;
+// claims only move to earlier tuples, so they stay claimed for e and the next pass starts below them (a bin of n identical reads would
+// otherwise cost every one of its events n loads per pass).  (One wave per BIN walking its events in tuple order settles a deep bin in
+// one pass, but serialises the hundreds of thousands of probes a low-complexity bin attracts: tried, 100x slower.)
+__global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed)
 {
     __shared__ unsigned long long swin[4][HARC_MAXW3];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -397,7 +401,8 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uns
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint32_t seen = 0, pos = cnt; bool ch = false;               // wave-uniform
+    uint32_t top = estart[e]; if (top > cnt) top = cnt;
+    uint32_t seen = 0, pos = top; bool ch = false, leading = true;   // wave-uniform
     while (pos > 0 && seen < (uint32_t)s.maxsearch) {             // highest id first
         const bool valid = (uint32_t)lane < pos;
         uint32_t rid = 0; unsigned long long b = 0; bool un = false;
@@ -407,6 +412,10 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uns
             un = b >= tp;                                          // not claimed before this probe (claimed BY this probe in an earlier pass counts as visible)
         }
         const unsigned long long um = __ballot(un);
+        if (leading) {                                             // the claimed reads on top stay claimed for this event
+            if (um == 0) top -= (uint32_t)__popcll(__ballot(valid));
+            else { top -= (uint32_t)(__ffsll((long long)um) - 1); leading = false; }
+        }
         const uint32_t rank = (uint32_t)__popcll(um & ((1ULL << lane) - 1ULL));
         if (un && seen + rank < (uint32_t)s.maxsearch && b > tp) {
             const uint64_t *r = s.cand3 + (size_t)rid * W3;
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uns
         seen += (uint32_t)__popcll(um);
         pos -= pos > 64 ? 64 : pos;
     }
-    if (__ballot(ch) && lane == 0) atomicOr(changed, 1u);
+    if (lane == 0) { estart[e] = top; if (ch) atomicOr(changed, 1u); }
 }
 
 __global__ void k_acc_flags(const unsigned long long *best, uint32_t T, uint32_t *flag)
@@ -774,10 +783,12 @@ int stage2_run(harc_amd_ctx *c)
                 if (nev > a.maxevents) { harc_set_error("stage II: event count changed between two identical passes (%u > %u)", nev, a.maxevents); return HARC_AMD_EINTERNAL; }
             }
             if (nev) {                                                        // exact sliding-window semantics as a fixed point (k_realign_big)
-                unsigned int *d_changed = nullptr; RC_TRY(dalloc(c, &d_changed, 4));
+                unsigned int *d_changed = nullptr; uint32_t *estart = nullptr;
+                RC_TRY(dalloc(c, &d_changed, 4)); RC_TRY(dalloc(c, &estart, (size_t)nev + 1));
+                HIP_TRY(hipMemsetAsync(estart, 0xFF, ((size_t)nev + 1) * 4, c->stream));
                 for (uint64_t pass = 0;; pass++) {
                     HIP_TRY(hipMemsetAsync(d_changed, 0, 16, c->stream));
-                    hipLaunchKernelGGL(k_realign_big, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, d_changed);
+                    hipLaunchKernelGGL(k_realign_big, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed);
                     unsigned int chg = 0;
                     HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));
