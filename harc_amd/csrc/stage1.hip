@@ -436,10 +436,11 @@ template <int W> struct StepsLds {
     static constexpr int ROW = 3 * NW + 1;
     static constexpr int MROW = (NW + 3) & ~3;                   // mask rows are 16-byte aligned
 };
+#define HARC_WGCMD_BYTES 768           // >= sizeof(WgCmd), checked where the struct is defined
 static inline size_t steps_lds_bytes(int W, int maxmatch, int nprobe)
 {
     const int NW = 2 * W, ROW = 3 * NW + 1, MROW = (NW + 3) & ~3;
-    return ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)2 * nprobe + 8) * 4;
+    return ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)2 * nprobe + 8) * 4 + HARC_WGCMD_BYTES + 16;
 }
 // Hamming distance between a candidate read (registers) and the consensus shifted by the lane's own amount: `row` = ref or rref window
 // row in LDS, bitoff = 32 NW +- 2j, mrow = mask row of (direction, shift) (reorder.cpp:543,608 with mask[j] / revmask[j] of :706-718)
@@ -534,6 +535,95 @@ template <int W> __device__ __forceinline__ void cons_rows(const ConsState<W> &s
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- the COOP kernel gives a whole workgroup to one chain: wave 0 walks the chain (the same code as the main kernel), waves 1..3
+//      wait for scan commands and share the scans of the large bins -- 256 candidates per round trip.  (One wave did up to ~600
+//      chunk iterations in the heaviest walk of a super-round while the chip idled.)
+struct WgCmd {
+    int op;                          // 1 = scan, 0 = leave
+    int l, t, fast;
+    uint32_t ids0, m0, cnt;
+    unsigned long long grp;          // the probes (lanes of wave 0) that look into this bin
+    uint32_t found;                  // the read of the best probe that found one
+    uint32_t nc;                     // candidates tested by the helpers (statistics)
+    unsigned long long hit[2][4];
+    uint32_t uncount[4];
+    uint8_t mj[64], mdir[64];        // shift and direction of every probe
+    uint32_t own[64];                // reads the chain took earlier in this super-round
+};
+struct WgResult { int besthit, fj, fdir; uint32_t iters, tests, nc; };
+static_assert(sizeof(WgCmd) <= HARC_WGCMD_BYTES, "HARC_WGCMD_BYTES too small");
+// every wave of the workgroup: scan the bin of the command; same order, same maxsearch window as a lane-serial scan (reorder.cpp:540-552)
+template <int W> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int role, int lane, const uint32_t *const *ids, const uint64_t *mirror, const unsigned long long *claimed,
+                                                            const uint32_t *rowF, const uint32_t *s_mask, uint32_t *rdl, int maxsearch, int maxmatch, int thresh)
+{
+    constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
+    WgResult r; r.besthit = 64; r.fj = 0; r.fdir = 0; r.iters = 0; r.tests = 0; r.nc = 0;
+    const uint32_t *oids = ids[cmd->l];
+    const uint32_t ids0 = cmd->ids0, m0 = cmd->m0;
+    const int t = cmd->t; const bool fast = cmd->fast != 0;
+    unsigned long long grp = cmd->grp;
+    int seen = 0, par = 0; uint32_t pos = cmd->cnt;
+    uint32_t mrd[NW];
+    while (pos > 0 && seen < maxsearch && grp) {
+        const uint32_t off = 64u * (uint32_t)role + (uint32_t)lane;
+        const bool valid = off < pos; r.iters++;
+        const uint32_t at = pos - 1 - off;
+        uint32_t rid = 0; bool clm = true, own = false, cand = false, checked = !fast; int total = 0;
+        if (valid) rid = oids[ids0 + at];
+        if (fast) cand = valid;
+        else {                                                     // exact window: claim state of all 256 entries, ranks across the waves
+            if (valid) clm = ((claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
+            if (valid && !clm) for (int k = 0; k < t; k++) own |= (cmd->own[k] == rid);
+            const bool un = valid && !clm && !own;
+            const unsigned long long um = __ballot(un);
+            if (lane == 0) cmd->uncount[role] = (uint32_t)__popcll(um);
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < 4; w++) { const int x = (int)cmd->uncount[w]; if (w < role) base += x; total += x; }
+            cand = un && (seen + base + __popcll(um & ((1ULL << lane) - 1ULL)) < maxsearch);
+        }
+        if (cand) load_read32<W>(mirror, m0 + at, mrd);
+        unsigned long long gm = grp; r.tests += (uint32_t)__popcll(grp);
+        while (gm) {                                               // the probes of this bin, highest priority first
+            const int g = __ffsll((long long)gm) - 1;
+            gm &= gm - 1;
+            const int g_j = cmd->mj[g], g_dir = cmd->mdir[g];
+            const uint32_t *const omrow = s_mask + (size_t)(g_dir * maxmatch + g_j) * MROW;
+            const int obit = g_dir * ROW * 32 + 32 * NW + (g_dir ? -2 * g_j : 2 * g_j);
+            bool ok = false;
+            if (cand) { r.nc++; ok = ham_window<W>(rowF, obit, omrow, mrd) <= thresh; }      // statistics: fast mode does not tell claimed entries apart
+            if (ok && !checked) {
+                clm = ((claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
+                if (!clm) for (int k = 0; k < t; k++) own |= (cmd->own[k] == rid);
+                checked = true;
+            }
+            ok = ok && !clm && !own;
+            const unsigned long long pm = __ballot(ok);
+            if (lane == 0) cmd->hit[par][role] = pm;
+            __syncthreads();
+            unsigned long long hw[4];
+            for (int w = 0; w < 4; w++) hw[w] = cmd->hit[par][w];
+            par ^= 1;
+            if (hw[0] | hw[1] | hw[2] | hw[3]) {
+                const int winw = hw[0] ? 0 : hw[1] ? 1 : hw[2] ? 2 : 3;       // the highest ids are in wave 0
+                const int wl = __ffsll((long long)hw[winw]) - 1;
+                if (role == winw && lane == wl) {
+#pragma unroll
+                    for (int k = 0; k < NW; k++) rdl[k] = mrd[k];
+                    cmd->found = rid;
+                }
+                r.fj = g_j; r.fdir = g_dir; r.besthit = g;
+                grp &= (1ULL << g) - 1ULL;                         // this probe is settled, the ones behind it are beaten; the ones before it go on
+                break;
+            }
+        }
+        if (!fast) seen += total;
+        pos -= pos > 256 ? 256 : pos;
+        __syncthreads();                                           // the exchange buffers are free again; the winner's words are in place
+    }
+    return r;
+}
+
 template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 2 : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1))) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
@@ -545,8 +635,15 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
     uint32_t *const s_rdl = s_rows + 4 * 2 * ROW;
     uint32_t *const s_tmp = s_rdl + 4 * MROW;
     uint2 *const s_pinfo = reinterpret_cast<uint2 *>(s_tmp + 4 * 8 * NW);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    WgCmd *const cmd = reinterpret_cast<WgCmd *>(reinterpret_cast<char *>(s_pinfo + s.nprobe) + 8 - ((size_t)(s_pinfo + s.nprobe) & 7));
+    // main kernel: 4 chains per workgroup, one wave each.  COOP: one chain per workgroup, wave 0 walks it (role 0), waves 1..3 help with the scans
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, wv = COOP ? 0 : role;
     const int L = s.L;
+    if (COOP) {                                                   // uniform for the workgroup: nothing to do for this chain
+        if (blockIdx.x >= s.K) return;
+        const uint32_t fl = s.hdr[blockIdx.x].flags;
+        if (!(fl & CH_ACTIVE) || !(fl & CH_COOP)) return;
+    }
     {   // the whole workgroup, before any wave leaves: mask[j] keeps the low 2(L-j) bits, revmask[j] the bits >= 2j below 2L (reorder.cpp:706-718)
         for (int i = threadIdx.x; i < 2 * s.maxmatch * MROW; i += 256) {
             const int k = i % MROW, r = i / MROW, dir = r / s.maxmatch, j = r % s.maxmatch;
@@ -569,8 +666,21 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
         for (int i = threadIdx.x; i < 4 * 8 * NW; i += 256) s_tmp[i] = 0u;
         __syncthreads();
     }
+    if (COOP && role != 0) {                                      // helpers: wait for a scan, take part, until the walk is over
+        const uint32_t *const idp[2] = { s.ids[0], s.ids[1] };
+        uint32_t hnc = 0;
+        for (;;) {
+            __syncthreads();
+            if (cmd->op == 0) break;
+            const WgResult r = wg_scan<W>(cmd, role, lane, idp, s.mirror, s.claimed, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh);
+            hnc += r.nc;
+        }
+        hnc = wave_sum_u32(hnc);
+        if (lane == 0 && hnc) { atomicAdd(&s.cstat[blockIdx.x].y, hnc); atomicAdd(&s.cstat[blockIdx.x].w, hnc); }
+        return;
+    }
     uint32_t ownreg = HARC_NONE;                                 // lane t: the read this chain took at step t of this super-round
-    const uint32_t c = blockIdx.x * 4 + wv;
+    const uint32_t c = COOP ? blockIdx.x : blockIdx.x * 4 + wv;
     if (c >= s.K) return;
     ChainHdr h = s.hdr[c];
     uint4 cst = s.cstat[c];
@@ -782,68 +892,20 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
                     unsigned long long grp = __ballot(big && l == o_l && b_slot == o_slot) & bigm;     // the probes into this bin, bl among them
                     bigm &= ~grp;
                     dbg_bins++;
-                    const uint32_t *oids = s.ids[o_l];
                     const uint2 lt = s.largetab[o_sst];
-                    const uint32_t ids0 = lt.x, m0 = lt.y;
                     // while the bin fits the maxsearch window (reorder.cpp:540) the window never closes: the claim bit is only asked of the
                     // candidates that pass the Hamming test.  Above it the unclaimed reads are counted exactly, as the lane-serial scan would.
-                    const bool fast = o_cnt <= (uint32_t)s.maxsearch;
-                    int seen = 0, besthit = 64; uint32_t pos = o_cnt;
-                    // software pipeline: the ids and rows of the NEXT 64 entries are requested before the current ones are tested, so that a
-                    // bin of many chunks streams instead of paying one HBM round trip per chunk
-                    uint32_t rid_n = 0, mrd_n[NW];
-#pragma unroll
-                    for (int k = 0; k < NW; k++) mrd_n[k] = 0;
-                    if ((uint32_t)lane < pos) { const uint32_t a0 = pos - 1 - (uint32_t)lane; rid_n = oids[ids0 + a0]; load_read32<W>(s.mirror, m0 + a0, mrd_n); }
-                    while (pos > 0 && seen < s.maxsearch && grp) {
-                        const bool valid = (uint32_t)lane < pos; dbg_iter++;
-                        const uint32_t rid = rid_n;
-#pragma unroll
-                        for (int k = 0; k < NW; k++) mrd[k] = mrd_n[k];
-                        {
-                            const uint32_t npos = pos > 64 ? pos - 64 : 0;
-                            if ((uint32_t)lane < npos) { const uint32_t a1 = npos - 1 - (uint32_t)lane; rid_n = oids[ids0 + a1]; load_read32<W>(s.mirror, m0 + a1, mrd_n); }
-                        }
-                        bool clm = true, own = false, cand = false, checked = !fast;
-                        unsigned long long um = 0;
-                        if (fast) cand = valid;
-                        else {
-                            if (valid) clm = ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
-                            if (valid && !clm) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
-                            const bool un = valid && !clm && !own;
-                            um = __ballot(un);
-                            cand = un && (seen + __popcll(um & ((1ULL << lane) - 1ULL)) < s.maxsearch);
-                        }
-                        unsigned long long gm = grp; dbg_surv += (uint32_t)__popcll(grp);
-                        while (gm) {                                               // the probes of this bin, highest priority first
-                            const int g = __ffsll((long long)gm) - 1;
-                            gm &= gm - 1;
-                            const int g_j = __builtin_amdgcn_readlane(j, g), g_dir = __builtin_amdgcn_readlane(dir, g);
-                            const uint32_t *const omrow = s_mask + (size_t)(g_dir * s.maxmatch + g_j) * MROW;
-                            const int obit = g_dir * ROW * 32 + 32 * NW + (g_dir ? -2 * g_j : 2 * g_j);
-                            bool ok = false;
-                            if (cand) { nc++; ncu++; ok = ham_window<W>(rowF, obit, omrow, mrd) <= s.thresh; }   // statistics: fast mode does not tell claimed entries apart
-                            if (ok && !checked) {
-                                clm = ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
-                                if (!clm) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
-                                checked = true;
-                            }
-                            ok = ok && !clm && !own;
-                            const unsigned long long pm = __ballot(ok);
-                            if (pm) {
-                                const int wl = __ffsll((long long)pm) - 1;
-                                found = (uint32_t)__builtin_amdgcn_readlane((int)rid, wl); fj = g_j; fdir = g_dir; besthit = g;
-                                if (lane == wl) {
-#pragma unroll
-                                    for (int k = 0; k < NW; k++) rdl[k] = mrd[k];
-                                }
-                                grp &= (1ULL << g) - 1ULL;                         // this probe is settled, the ones behind it are beaten; the ones before it go on
-                                break;
-                            }
-                        }
-                        if (!fast) seen += __popcll(um);
-                        pos -= pos > 64 ? 64 : pos;
+                    cmd->mj[lane] = (uint8_t)j; cmd->mdir[lane] = (uint8_t)dir; cmd->own[lane] = ownreg;
+                    if (lane == 0) {
+                        cmd->op = 1; cmd->l = o_l; cmd->t = t; cmd->fast = o_cnt <= (uint32_t)s.maxsearch ? 1 : 0;
+                        cmd->ids0 = lt.x; cmd->m0 = lt.y; cmd->cnt = o_cnt; cmd->grp = grp; cmd->found = HARC_NONE;
                     }
+                    __syncthreads();                                           // the helpers start
+                    const uint32_t *const idp[2] = { s.ids[0], s.ids[1] };
+                    const WgResult wr = wg_scan<W>(cmd, 0, lane, idp, s.mirror, s.claimed, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh);
+                    dbg_iter += wr.iters; dbg_surv += wr.tests; nc += wr.nc; ncu += wr.nc;
+                    const int besthit = wr.besthit;
+                    if (besthit < 64) { found = cmd->found; fj = wr.fj; fdir = wr.fdir; }
                     if (besthit < 64) { winlane = besthit; bigm &= (1ULL << besthit) - 1ULL; }
                 }
                 if (COOP) bigprobes += __popcll(__ballot(big) & (winlane < 64 ? ((2ULL << winlane) - 1ULL) : ~0ULL));   // the probes up to and including the winning one
@@ -898,11 +960,13 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
         nst++;
         if (COOP && bigprobes >= s.budget) break;
     }
+    if (COOP) { if (lane == 0) cmd->op = 0; __syncthreads(); }      // the walk is over: the helpers leave
     if (nst > 0) cons_store<W>(st, B1, L, lane);
     np = wave_sum_u32(np); nc = wave_sum_u32(nc); ncu = wave_sum_u32(ncu);
     if (lane == 0 && s.dbg) { atomicAdd(&s.dbg[0], (unsigned long long)dbg_bins); atomicAdd(&s.dbg[1], (unsigned long long)dbg_iter); atomicAdd(&s.dbg[2], (unsigned long long)dbg_miss); atomicAdd(&s.dbg[3], (unsigned long long)dbg_surv); atomicAdd(&s.dbg[4], (unsigned long long)nst); atomicAdd(&s.dbg[5], (unsigned long long)dbg_batches); atomicMax(&s.dbg[6], (unsigned long long)dbg_iter); atomicMax(&s.dbg[7], (unsigned long long)dbg_surv); atomicMax(&s.dbg[8], (unsigned long long)dbg_bins); }
     if (lane == 0) {
-        cst.x += np; cst.y += nc; cst.z += nuse; cst.w += ncu; s.cstat[c] = cst;
+        if (COOP) { atomicAdd(&s.cstat[c].x, np); atomicAdd(&s.cstat[c].y, nc); atomicAdd(&s.cstat[c].z, nuse); atomicAdd(&s.cstat[c].w, ncu); }   // the helpers add to it too
+        else { cst.x += np; cst.y += nc; cst.z += nuse; cst.w += ncu; s.cstat[c] = cst; }
         h.mode = 0;
         h.nsteps = (h.nsteps & 0xFFFF0000u) | (uint32_t)(T0 + nst);
         h.pad0 = ((uint32_t)lastp & 0xFFFFu) | ((uint32_t)spos << 16);
@@ -1410,7 +1474,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             else hipLaunchKernelGGL((k_steps<W, false, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             if (prof) HIP_TRY(hipEventRecord(pair[1], c->stream));
             // the steps that have to scan a large bin (none without such bins: the launch is skipped)
-            if (nlarge) hipLaunchKernelGGL((k_steps<W, true, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
+            if (nlarge) hipLaunchKernelGGL((k_steps<W, true, true>), dim3(K), dim3(256), lds_bytes, c->stream, a);
             if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
             else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve<32>), dim3((K + 7) / 8), dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((k_resolve<64>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
