@@ -698,7 +698,9 @@ int stage2_run(harc_amd_ctx *c)
     uint32_t *bloom[2] = { nullptr, nullptr }; int bloom_shift[2] = { 63, 63 };
     if (T) {
         RC_TRY(harc_dict_alloc(c, &dict[0], T, 0)); RC_TRY(harc_dict_alloc(c, &dict[1], T, dict[0].cap));
-        dict[0].bigthresh = dict[1].bigthresh = (uint32_t)P.maxsearch;
+        // probes into bins of more than 32 candidates are recorded and scanned by a wave each (k_realign_big: 64 candidates per round trip)
+        // instead of lane-serially inside k_realign_propose; above maxsearch that pass is also where the sliding window is exact
+        dict[0].bigthresh = dict[1].bigthresh = (uint32_t)P.maxsearch < 32u ? (uint32_t)P.maxsearch : 32u;
         dict[0].bucketed = dict[1].bucketed = true;
         int lb = 16; while (lb < 36 && (1ULL << lb) < 16ULL * T) lb++;           // 16 bits per key: ~6 % of absent keys pass
         for (int l = 0; l < 2; l++) {
