@@ -1,0 +1,20 @@
+#!/bin/bash
+# The round's profile artefacts (run through gpurun; copy gpurun_out/<tag>/ into profiles/<round>/):
+#   default bench line (configs[2]) with all legs; rocprofv3 kernel stats and PMC passes of the same command for c3 and c2; bench lines of
+#   the other workloads
+R=${1:-r02final}
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+cd "$ROOT"; mkdir -p gpurun_out/$R
+python bench.py --steps 20 --warmup 5 > gpurun_out/$R/bench_c3.json 2> gpurun_out/$R/bench_c3.err
+bash tools/kstats.sh c3 $R 3 > /dev/null 2>&1
+bash tools/pmc.sh $R c3 2 > gpurun_out/$R/pmc_c3.log 2>&1
+python bench.py --workload c2 --steps 20 --warmup 5 > gpurun_out/$R/bench_c2.json 2> /dev/null
+bash tools/kstats.sh c2 $R 5 > /dev/null 2>&1
+bash tools/pmc.sh $R c2 3 > /dev/null 2>&1
+for w in c1 c3s c4s c2r c2d; do python bench.py --workload $w --steps 5 --warmup 1 --no-cpu > gpurun_out/$R/bench_$w.json 2> /dev/null; done
+python bench.py --workload c2 --steps 5 --warmup 1 --force-dist > gpurun_out/$R/bench_c2_forcedist.json 2> /dev/null
+for f in gpurun_out/$R/bench_*.json; do python - "$f" <<PY
+import json,sys
+d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], d['value'], d['ms_per_step'], d['phases_ms_last_step'], d['roundtrip']['ok'], d['roofline'].get('random_access', {}).get('frac'))
+PY
+done
