@@ -242,6 +242,33 @@ __global__ void k_bloom_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, i
     const uint64_t b = mix64(keys[i] ^ 0x9E3779B97F4A7C15ULL) >> shift;
     atomicOr(&bloom[b >> 5], 1u << (b & 31));
 }
+// Combined bitmap of both dictionaries and both orientations, one 4-bit entry per hash position (plane l: a key of dictionary l hashes
+// here; plane 2 + l: the reverse complement of such a key does), two entries of ONE 32-bit word per key.  When both windows have the same
+// width, the four probes of encoder.cpp:262-410 at a window start look up four k-mers of the consensus -- and over all window starts
+// each k-mer of the consensus is looked up four times.  With this bitmap it is hashed and looked up once.
+__device__ __forceinline__ uint64_t rc_key3(uint64_t key, int n)
+{
+    uint64_t r = 0;
+    for (int i = 0; i < n; i++) r |= (uint64_t)(6 - (int)((key >> (3 * (n - 1 - i))) & 7)) << (3 * i);   // A0 <-> T6, G2 <-> C4 (N 1 -> 5: matches nothing)
+    return r;
+}
+__device__ __forceinline__ void bloom4_pos(uint64_t key, int shift, uint64_t *word, int *sh0, int *sh1)
+{
+    const uint64_t h = mix64(key ^ 0x9E3779B97F4A7C15ULL);
+    const uint64_t b = h >> shift;
+    *word = b >> 3; *sh0 = 4 * (int)(b & 7); *sh1 = 4 * (int)(h & 7);
+}
+__global__ void k_bloom4_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, int shift, int l, int nb)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    uint64_t w; int a, b;
+    bloom4_pos(k, shift, &w, &a, &b);
+    atomicOr(&bloom[w], ((1u << l) << a) | ((1u << l) << b));
+    bloom4_pos(rc_key3(k, nb), shift, &w, &a, &b);
+    atomicOr(&bloom[w], ((4u << l) << a) | ((4u << l) << b));
+}
 // candidates in the reads' 2-bit code + N mask (3-bit code A0 N1 G2 C4 T6: code = c3 >> 1, N = c3 & 1); one thread per (read, word)
 __global__ void k_cand2_from3(const uint64_t *cand3, uint32_t T, int L, int W, int W3, uint64_t *cand2, uint64_t *candN)
 {
@@ -274,6 +301,96 @@ template <int W> __device__ __forceinline__ void cons_words(const uint64_t *cons
 // read has a base, and 1 + popcount(window code) where it has an N (N = 001 against A 000, G 010, C 100, T 110).
 #define RSTRIP 8
 #define RTILE (256 * RSTRIP)
+// one probe that passed the bitmap: window start x, direction, dictionary, key
+template <int W> __device__ __forceinline__ void realign_probe(const S2Args &s, uint64_t x, int dir, int l, uint64_t key)
+{
+    uint32_t st = 0, cnt = 0;
+    if (!dict_lookup_b(s.slots[l], s.cap[l], key, &st, &cnt)) return;
+    const int L = s.L;
+    const unsigned long long tp = (x << 2) | ((uint64_t)dir << 1) | (uint64_t)l;
+    if (cnt & SLOT_BIG) {                                     // > maxsearch reads: the visible window slides as reads get claimed
+        const unsigned int at = atomicAdd(s.nevents, 1u);     // (encoder.cpp:293) -> exact sequential pass k_realign_big
+        if (at < s.maxevents) s.events[at] = make_uint4((uint32_t)tp, (uint32_t)(tp >> 32), st, cnt & SLOT_CNT_MASK);
+        return;
+    }
+    uint64_t wv[W];                                           // window words, forward or reverse complement
+    {
+        uint64_t cw[W];
+        cons_words<W>(s.cons2, x, cw);
+#pragma unroll
+        for (int w = 0; w < W; w++) cw[w] &= lowmask_word(2 * L, w);
+        if (dir) rc_words<W>(cw, L, wv);
+        else {
+#pragma unroll
+            for (int w = 0; w < W; w++) wv[w] = cw[w];
+        }
+    }
+    const bool emb = (cnt & SLOT_EMB) != 0;
+    cnt &= SLOT_CNT_MASK;                                     // <= maxsearch: the whole bin is always visible
+    for (uint32_t t = 0; t < cnt; t++) {
+        const uint32_t rid = emb ? st : s.ids[l][st + cnt - 1 - t];
+        const uint64_t *a2 = s.cand2 + (size_t)rid * W, *n2 = s.candN + (size_t)rid * W;
+        int hd = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            const uint64_t av = a2[w], nv = n2[w];
+            hd += __popcll((av ^ wv[w]) & ~nv) + __popcll(nv & 0x5555555555555555ULL) + __popcll(wv[w] & nv);
+        }
+        if (hd <= s.thresh_s) atomicMin(&s.best[rid], tp);
+    }
+}
+// Both windows of the same width n (every read length >= 50): one thread per 8 consecutive k-mer starts c, ONE rolled key, one
+// bitmap word per k-mer (k_bloom4_set).  Plane l says the k-mer is window l of the forward read starting at x = c - ds[l]; plane 2 + l
+// that it is the reverse complement of window l of the read starting at x = c - (L - 1 - de[l]).  The claim order of the reference
+// (window start, direction, dictionary) is carried by the tuple and atomicMin, so it does not matter which thread finds a probe.
+template <int W> __global__ __launch_bounds__(256) void k_realign_propose1(S2Args s)
+{
+    __shared__ uint32_t tile32[(RTILE + 64 + 8) / 4];
+    uint8_t *tile = reinterpret_cast<uint8_t *>(tile32);
+    const uint64_t X0 = (uint64_t)blockIdx.x * RTILE;
+    const int L = s.L, n = s.de[0] - s.ds[0] + 1;
+    const int ntile = RTILE + n + 1;
+    for (int d = threadIdx.x; d < (ntile + 3) / 4; d += 256) {
+        const uint64_t g = X0 + 4ull * d;
+        uint32_t v = 0;
+        if (g + 4 <= s.total) v = *reinterpret_cast<const uint32_t *>(s.cons + g);
+        else for (int k = 0; k < 4; k++) if (g + k < s.total) v |= (uint32_t)s.cons[g + k] << (8 * k);
+        tile32[d] = v;
+    }
+    __syncthreads();
+    const int t0 = threadIdx.x * RSTRIP;
+    if (X0 + t0 >= s.total) return;
+    uint64_t key = 0;
+    for (int b = 0; b < n; b++) key |= (uint64_t)idx_to_c3(tile[t0 + b] & 3) << (3 * b);
+    const uint32_t *bloom = s.bloom[0]; const int shift = s.bloom_shift[0];
+    // the 8 bitmap words first (independent loads), then the rare hits
+    uint32_t hit = 0; uint64_t k = key;
+#pragma unroll
+    for (int c = 0; c < RSTRIP; c++) {
+        uint64_t w; int a, b;
+        bloom4_pos(k, shift, &w, &a, &b);
+        const uint32_t v = bloom[w];
+        hit |= ((v >> a) & (v >> b) & 15u) << (4 * c);
+        k = (k >> 3) | ((uint64_t)idx_to_c3(tile[t0 + c + n] & 3) << (3 * (n - 1)));
+    }
+    if (!hit) return;
+    for (int c = 0; c < RSTRIP; c++) {
+        const uint32_t m = (hit >> (4 * c)) & 15u;
+        if (m) {
+            const uint64_t cpos = X0 + t0 + c;
+            for (int p = 0; p < 4; p++) {
+                if (!((m >> p) & 1u)) continue;
+                const int dir = p >> 1, l = p & 1;
+                const uint64_t off = dir ? (uint64_t)(L - 1 - s.de[l]) : (uint64_t)s.ds[l];
+                if (cpos < off) continue;
+                const uint64_t x = cpos - off;
+                if (x >= s.total || !(s.cons[x] & 4)) continue;                  // no read may start there (k_consensus)
+                realign_probe<W>(s, x, dir, l, dir ? rc_key3(key, n) : key);
+            }
+        }
+        key = (key >> 3) | ((uint64_t)idx_to_c3(tile[t0 + c + n] & 3) << (3 * (n - 1)));
+    }
+}
 template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args s)
 {
     __shared__ uint32_t tile32[(RTILE + 256 + 8) / 4];
@@ -316,43 +433,8 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args
                 const uint64_t b = mix64(keys[k] ^ 0x9E3779B97F4A7C15ULL) >> s.bloom_shift[l];
                 pass[k] = (s.bloom[l][b >> 5] >> (b & 31)) & 1u;
             }
-            if (pass[0] | pass[1] | pass[2] | pass[3]) {
-                uint64_t cw[W], rv[W];
-                bool havew = false;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (!pass[k]) continue;
-                    const int dir = k >> 1, l = k & 1;
-                    uint32_t st = 0, cnt = 0;
-                    if (!dict_lookup_b(s.slots[l], s.cap[l], keys[k], &st, &cnt)) continue;
-                    const unsigned long long tp = (x << 2) | ((uint64_t)dir << 1) | (uint64_t)l;
-                    if (cnt & SLOT_BIG) {                                     // > maxsearch reads: the visible window slides as reads get claimed
-                        const unsigned int at = atomicAdd(s.nevents, 1u);     // (encoder.cpp:293) -> exact sequential pass k_realign_big
-                        if (at < s.maxevents) s.events[at] = make_uint4((uint32_t)tp, (uint32_t)(tp >> 32), st, cnt & SLOT_CNT_MASK);
-                        continue;
-                    }
-                    if (!havew) {                                             // window words, forward and reverse complement
-                        cons_words<W>(s.cons2, x, cw);
-#pragma unroll
-                        for (int w = 0; w < W; w++) cw[w] &= lowmask_word(2 * L, w);
-                        rc_words<W>(cw, L, rv);
-                        havew = true;
-                    }
-                    const bool emb = (cnt & SLOT_EMB) != 0;
-                    cnt &= SLOT_CNT_MASK;                                     // <= maxsearch: the whole bin is always visible
-                    for (uint32_t t = 0; t < cnt; t++) {
-                        const uint32_t rid = emb ? st : s.ids[l][st + cnt - 1 - t];
-                        const uint64_t *a2 = s.cand2 + (size_t)rid * W, *n2 = s.candN + (size_t)rid * W;
-                        int hd = 0;
-#pragma unroll
-                        for (int w = 0; w < W; w++) {
-                            const uint64_t av = a2[w], nv = n2[w], wv = dir ? rv[w] : cw[w];
-                            hd += __popcll((av ^ wv) & ~nv) + __popcll(nv & 0x5555555555555555ULL) + __popcll(wv & nv);
-                        }
-                        if (hd <= s.thresh_s) atomicMin(&s.best[rid], tp);
-                    }
-                }
-            }
+            for (int k = 0; k < 4; k++) if (pass[k]) realign_probe<W>(s, x, k >> 1, k & 1, keys[k]);
         }
         // roll the keys to window x+1
         kf0 = (kf0 >> 3) | ((uint64_t)idx_to_c3(tile[tx + 1 + s.de[0]] & 3) << (3 * (n0 - 1)));
@@ -696,14 +778,22 @@ int stage2_run(harc_amd_ctx *c)
     unsigned long long *d_big = nullptr; RC_TRY(dalloc(c, &d_big, 1));
     HIP_TRY(hipMemsetAsync(d_big, 0, 8, c->stream));
     uint32_t *bloom[2] = { nullptr, nullptr }; int bloom_shift[2] = { 63, 63 };
+    // windows of equal width (read lengths >= 50, encoder.cpp:132-145): one combined bitmap, one lookup per consensus k-mer (k_realign_propose1)
+    const bool bloom4 = a.kbits[0] == a.kbits[1] && !getenv("HARC_AMD_BLOOM1");
+    int bloom_per_key = 16;
+    if (const char *e = getenv("HARC_AMD_BLOOMBITS")) { bloom_per_key = atoi(e); if (bloom_per_key < 1) bloom_per_key = 1; }
     if (T) {
         RC_TRY(harc_dict_alloc(c, &dict[0], T, 0)); RC_TRY(harc_dict_alloc(c, &dict[1], T, dict[0].cap));
         // probes into bins of more than 32 candidates are recorded and scanned by a wave each (k_realign_big: 64 candidates per round trip)
         // instead of lane-serially inside k_realign_propose; above maxsearch that pass is also where the sliding window is exact
         dict[0].bigthresh = dict[1].bigthresh = (uint32_t)P.maxsearch < 32u ? (uint32_t)P.maxsearch : 32u;
         dict[0].bucketed = dict[1].bucketed = true;
-        int lb = 16; while (lb < 36 && (1ULL << lb) < 16ULL * T) lb++;           // 16 bits per key: ~6 % of absent keys pass
-        for (int l = 0; l < 2; l++) {
+        int lb = 16; while (lb < 36 && (1ULL << lb) < (unsigned long long)bloom_per_key * T) lb++;
+        if (bloom4) {   // 4-bit entries, 16 per key and two of them set: ~1.5 % of absent k-mers pass per plane
+            RC_TRY(dalloc(c, &bloom[0], ((size_t)1 << (lb - 3)) + 1));
+            HIP_TRY(hipMemsetAsync(bloom[0], 0, ((size_t)1 << (lb - 3)) * 4, c->stream));
+            bloom[1] = bloom[0]; bloom_shift[0] = bloom_shift[1] = 64 - lb;
+        } else for (int l = 0; l < 2; l++) {                                    // one bit per key and dictionary: ~6 % pass
             RC_TRY(dalloc(c, &bloom[l], ((size_t)1 << (lb - 5)) + 1));
             HIP_TRY(hipMemsetAsync(bloom[l], 0, ((size_t)1 << (lb - 5)) * 4, c->stream));
             bloom_shift[l] = 64 - lb;
@@ -713,7 +803,8 @@ int stage2_run(harc_amd_ctx *c)
         RC_TRY(dalloc(c, &k0, T)); RC_TRY(dalloc(c, &i0, T));
         for (int l = 0; l < 2; l++) {
             hipLaunchKernelGGL(k_key3, G256(T), cand3, T, W3, 3 * a.ds[l], a.kbits[l], k0, i0);
-            hipLaunchKernelGGL(k_bloom_set, G256(T), (const uint64_t *)k0, T, bloom[l], bloom_shift[l]);
+            if (bloom4) hipLaunchKernelGGL(k_bloom4_set, G256(T), (const uint64_t *)k0, T, bloom[0], bloom_shift[0], l, a.kbits[l] / 3);
+            else hipLaunchKernelGGL(k_bloom_set, G256(T), (const uint64_t *)k0, T, bloom[l], bloom_shift[l]);
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, T, (unsigned)a.kbits[l]));
             hipLaunchKernelGGL(k_count_big_bins, G256(dict[l].cap), dict[l].slots, dict[l].cap, (uint32_t)P.maxsearch, d_big);
         }
@@ -762,7 +853,8 @@ int stage2_run(harc_amd_ctx *c)
         if (T) {
             const dim3 rg((unsigned)((total + RTILE - 1) / RTILE));
             switch (W) {
-#define REALIGN_CASE(WW) case WW: hipLaunchKernelGGL((k_realign_propose<WW>), rg, dim3(256), 0, c->stream, a); break;
+#define REALIGN_CASE(WW) case WW: if (bloom4) hipLaunchKernelGGL((k_realign_propose1<WW>), rg, dim3(256), 0, c->stream, a); \
+                                 else hipLaunchKernelGGL((k_realign_propose<WW>), rg, dim3(256), 0, c->stream, a); break;
                 REALIGN_CASE(1) REALIGN_CASE(2) REALIGN_CASE(3) REALIGN_CASE(4) REALIGN_CASE(5) REALIGN_CASE(6) REALIGN_CASE(7) REALIGN_CASE(8)
 #undef REALIGN_CASE
             }
@@ -776,7 +868,8 @@ int stage2_run(harc_amd_ctx *c)
                 RC_TRY(dalloc(c, &a.events, (size_t)a.maxevents));
                 HIP_TRY(hipMemsetAsync(a.nevents, 0, 16, c->stream));
                 switch (W) {
-#define REALIGN_CASE(WW) case WW: hipLaunchKernelGGL((k_realign_propose<WW>), rg, dim3(256), 0, c->stream, a); break;
+#define REALIGN_CASE(WW) case WW: if (bloom4) hipLaunchKernelGGL((k_realign_propose1<WW>), rg, dim3(256), 0, c->stream, a); \
+                                 else hipLaunchKernelGGL((k_realign_propose<WW>), rg, dim3(256), 0, c->stream, a); break;
                     REALIGN_CASE(1) REALIGN_CASE(2) REALIGN_CASE(3) REALIGN_CASE(4) REALIGN_CASE(5) REALIGN_CASE(6) REALIGN_CASE(7) REALIGN_CASE(8)
 #undef REALIGN_CASE
                 }
