@@ -343,12 +343,28 @@ template <int W> __device__ __forceinline__ void realign_probe(const S2Args &s, 
 // bitmap word per k-mer (k_bloom4_set).  Plane l says the k-mer is window l of the forward read starting at x = c - ds[l]; plane 2 + l
 // that it is the reverse complement of window l of the read starting at x = c - (L - 1 - de[l]).  The claim order of the reference
 // (window start, direction, dictionary) is carried by the tuple and atomicMin, so it does not matter which thread finds a probe.
+#define RQCAP 4096
+template <int W> __device__ __forceinline__ void realign_hit1(const S2Args &s, const uint8_t *tile, uint64_t X0, int tc, int p, int n)
+{
+    const int dir = p >> 1, l = p & 1;
+    const uint64_t cpos = X0 + tc;
+    const uint64_t off = dir ? (uint64_t)(s.L - 1 - s.de[l]) : (uint64_t)s.ds[l];
+    if (cpos < off) return;
+    const uint64_t x = cpos - off;
+    if (x >= s.total || !(s.cons[x] & 4)) return;                  // no read may start there (k_consensus)
+    uint64_t key = 0;
+    if (dir) for (int b = 0; b < n; b++) key |= (uint64_t)idx_to_c3(3 - (tile[tc + n - 1 - b] & 3)) << (3 * b);
+    else for (int b = 0; b < n; b++) key |= (uint64_t)idx_to_c3(tile[tc + b] & 3) << (3 * b);
+    realign_probe<W>(s, x, dir, l, key);
+}
 template <int W> __global__ __launch_bounds__(256) void k_realign_propose1(S2Args s)
 {
     __shared__ uint32_t tile32[(RTILE + 64 + 8) / 4];
+    __shared__ uint16_t queue[RQCAP];
+    __shared__ unsigned int qn;
     uint8_t *tile = reinterpret_cast<uint8_t *>(tile32);
     const uint64_t X0 = (uint64_t)blockIdx.x * RTILE;
-    const int L = s.L, n = s.de[0] - s.ds[0] + 1;
+    const int n = s.de[0] - s.ds[0] + 1;
     const int ntile = RTILE + n + 1;
     for (int d = threadIdx.x; d < (ntile + 3) / 4; d += 256) {
         const uint64_t g = X0 + 4ull * d;
@@ -357,40 +373,38 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose1(S2Arg
         else for (int k = 0; k < 4; k++) if (g + k < s.total) v |= (uint32_t)s.cons[g + k] << (8 * k);
         tile32[d] = v;
     }
+    if (threadIdx.x == 0) qn = 0;
     __syncthreads();
     const int t0 = threadIdx.x * RSTRIP;
-    if (X0 + t0 >= s.total) return;
-    uint64_t key = 0;
-    for (int b = 0; b < n; b++) key |= (uint64_t)idx_to_c3(tile[t0 + b] & 3) << (3 * b);
+    uint64_t k = 0;
+    for (int b = 0; b < n; b++) k |= (uint64_t)idx_to_c3(tile[t0 + b] & 3) << (3 * b);
     const uint32_t *bloom = s.bloom[0]; const int shift = s.bloom_shift[0];
-    // the 8 bitmap words first (independent loads), then the rare hits
-    uint32_t hit = 0; uint64_t k = key;
+    // the 8 bitmap words (independent loads)
+    uint32_t hit = 0;
 #pragma unroll
-    for (int c = 0; c < RSTRIP; c++) {
+    for (int c = 0; c < RSTRIP && X0 + t0 + c < s.total; c++) {
         uint64_t w; int a, b;
         bloom4_pos(k, shift, &w, &a, &b);
         const uint32_t v = bloom[w];
         hit |= ((v >> a) & (v >> b) & 15u) << (4 * c);
         k = (k >> 3) | ((uint64_t)idx_to_c3(tile[t0 + c + n] & 3) << (3 * (n - 1)));
     }
-    if (!hit) return;
+    // the rare hits go through a queue in LDS and are worked off one per lane (inline, a wave would wait for its unluckiest lane's
+    // chain of dependent loads while the other 63 idle)
     for (int c = 0; c < RSTRIP; c++) {
-        const uint32_t m = (hit >> (4 * c)) & 15u;
-        if (m) {
-            const uint64_t cpos = X0 + t0 + c;
-            for (int p = 0; p < 4; p++) {
-                if (!((m >> p) & 1u)) continue;
-                const int dir = p >> 1, l = p & 1;
-                const uint64_t off = dir ? (uint64_t)(L - 1 - s.de[l]) : (uint64_t)s.ds[l];
-                if (cpos < off) continue;
-                const uint64_t x = cpos - off;
-                if (x >= s.total || !(s.cons[x] & 4)) continue;                  // no read may start there (k_consensus)
-                realign_probe<W>(s, x, dir, l, dir ? rc_key3(key, n) : key);
-            }
+        uint32_t m = (hit >> (4 * c)) & 15u;
+        while (m) {
+            const int p = __builtin_ctz(m); m &= m - 1;
+            const unsigned int at = atomicAdd(&qn, 1u);
+            if (at < RQCAP) queue[at] = (uint16_t)((t0 + c) | (p << 12));
+            else realign_hit1<W>(s, tile, X0, t0 + c, p, n);
         }
-        key = (key >> 3) | ((uint64_t)idx_to_c3(tile[t0 + c + n] & 3) << (3 * (n - 1)));
     }
+    __syncthreads();
+    const unsigned int nq = qn < RQCAP ? qn : RQCAP;
+    for (unsigned int i = threadIdx.x; i < nq; i += 256) { const uint16_t e = queue[i]; realign_hit1<W>(s, tile, X0, e & 0xFFF, e >> 12, n); }
 }
+
 template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args s)
 {
     __shared__ uint32_t tile32[(RTILE + 256 + 8) / 4];
