@@ -20,6 +20,17 @@ __device__ __forceinline__ uint64_t bucket_slot(uint64_t key, uint64_t cap)
     return (uint64_t)__umulhi(h, (uint32_t)nb) << 2;
 }
 
+// word and two-bit mask of a key in the one-word-per-key bitmap in front of a stage-I dictionary (k_steps: most probes of a step find
+// nothing; they end in this bitmap, which is small enough to be served on-die, instead of in the table).  A hash of its own: keys that
+// share the table's 32-bit hash must not share this one
+__device__ __forceinline__ void bloom_pos(uint64_t key, uint32_t nwords, uint32_t *word, uint32_t *mask)
+{
+    uint32_t g = ((uint32_t)key * 0xC2B2AE35u) ^ __builtin_rotateleft32((uint32_t)(key >> 32) * 0x27D4EB2Fu, 15);
+    g ^= g >> 15; g *= 0x165667B1u;
+    *word = __umulhi(g, nwords);
+    *mask = (1u << (g & 31)) | (1u << ((g >> 5) & 31));
+}
+
 // a[idx] for a small register array and a lane-varying idx; out-of-range -> 0
 template <int W> __device__ __forceinline__ uint64_t sel0(const uint64_t (&a)[W], int idx)
 {

@@ -20,6 +20,8 @@ struct S1Args {
     HashSlot *slots[2];
     uint64_t cap[2];
     const uint32_t *ids[2];
+    int firstmax[2];                 // widths of the first two probe batches of a step when many chains are in flight
+    const uint32_t *bloom[2]; uint32_t bloom_words;   // bitmap over the keys of each dictionary (bloom_pos), 0 words = none
     const uint2 *largetab;           // bins of more than HARC_LARGEBIN reads (SLOT_BIG; their slot's `start` indexes this table): x = first index into ids[], y = first row of `mirror`
     uint64_t *mirror;                // the reads of those bins once more, W words per entry, in bin order: their scan is one coalesced stream
     unsigned long long *claimed;     // bitmap, bit rid&63 of word rid>>6
@@ -288,6 +290,15 @@ __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, cons
         if (bucketed && (sl & 3) == 3) atomicOr(&slots[sl - 3].count, SLOT_OVF);
         if (++sl == cap) sl = 0;
     }
+}
+
+__global__ void k_s1_bloom_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, uint32_t nwords)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w, m;
+    bloom_pos(keys[i], nwords, &w, &m);
+    if ((bloom[w] & m) != m) atomicOr(&bloom[w], m);
 }
 
 // ------------------------------------------------------------------------------------------------ chain kernels
@@ -627,7 +638,6 @@ template <int W> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int rol
 template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 2 : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1))) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
-    constexpr int FIRSTMAX = QUAD ? 64 : 32;
     extern __shared__ uint32_t lds[];
     // [mask rows: (dir, shift) -> NW dwords][window rows: 4 waves x {ref, rref}][accepted read: 4 waves][column bytes: 4 waves x 2 x 16 NW][probes]
     uint32_t *const s_mask = lds;
@@ -764,14 +774,15 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
         int base = 0;
         for (int bi = 0; base < s.nprobe; bi++) {
             // first batch: twice the priority index of the chain's previous hit (high coverage -> hits at small shifts -> narrow first
-            // batch), at most FIRSTMAX probes; every later batch is a full wave.  With many chains the kernel runs at the random-access
+            // batch), at most firstmax probes; every later batch is a full wave.  With many chains the kernel runs close to the random-access
             // ceiling of the memory system (tools/micro/gups.hip: 26 G 32-byte requests/s beyond 16 GiB), so speculative probes cost
-            // throughput: the first two batches are FIRSTMAX = 32 wide there (+8 % and +3 %); with few chains a round trip costs more
-            // than the probes.
+            // throughput: without the bitmap in front of the tables the best width of the first two batches was 32; with it a
+            // speculative probe is an on-die bitmap lookup and 48 is better (configs[2]: chains 768 -> 728 ms).  With few chains a round
+            // trip costs more than the probes (QUAD: 64).
             // s.nbatch > 0 (HARC_AMD_BATCHES) overrides with a fixed schedule.
             int bend;
             if (s.nbatch > 0) bend = s.batch_end[bi < s.nbatch ? bi : s.nbatch - 1];
-            else { int w0 = bi == 0 ? ((2 * lastp + 16 + 15) & ~15) : 64; const int wmax = bi <= 1 ? FIRSTMAX : 64; if (w0 > wmax) w0 = wmax; bend = base + w0; }
+            else { int w0 = bi == 0 ? ((2 * lastp + 16 + 15) & ~15) : 64; const int wmax = QUAD ? 64 : (bi == 0 ? s.firstmax[0] : bi == 1 ? s.firstmax[1] : 64); if (w0 > wmax) w0 = wmax; bend = base + w0; }
             if (bend > s.nprobe) bend = s.nprobe;
             if (bend <= base) bend = s.nprobe;
             const int p = base + lane; dbg_batches++;
@@ -799,7 +810,12 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
                 uint64_t sl = bucket_slot(key, cap);
                 int state = 0, qhit = 0;                                  // 1 = the key is not in the table, 2 = key found
                 uint32_t sst = 0, cw = 0;
-                for (;;) {
+                if (s.bloom_words) {                                      // most keys of a step are in neither: they stop at the bitmap
+                    uint32_t bw, bm;
+                    bloom_pos(key, s.bloom_words, &bw, &bm);
+                    if (((l ? s.bloom[1] : s.bloom[0])[bw] & bm) != bm) state = 1;
+                }
+                if (state == 0) for (;;) {
                     constexpr int NQ = QUAD ? 4 : 2;
                     uint32_t w0 = 0;
 #pragma unroll
@@ -1365,6 +1381,10 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const harc_mark_t mark_results = harc_pool_mark(c);
     // ---- dictionaries (constructdictionary, reorder.cpp:277-394)
     DictDev dict[2];
+    // a bitmap of bloom_bits bits per read in front of each table, two bits set per key (HARC_AMD_S1BLOOM=0: none)
+    uint32_t *d_bloom[2] = { nullptr, nullptr }; uint32_t bloom_words = 0;
+    int bloom_bits = 16;
+    if (const char *e = getenv("HARC_AMD_S1BLOOM")) { bloom_bits = atoi(e); if (bloom_bits < 0) bloom_bits = 0; if (bloom_bits > 64) bloom_bits = 64; }
     unsigned long long *d_large = nullptr; unsigned int *d_nlarge = nullptr;
     const uint32_t maxlarge = 2 * (N / HARC_LARGEBIN) + 16;
     if (N) {
@@ -1374,12 +1394,19 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         HIP_TRY(hipMemsetAsync(d_nlarge, 0, 16, c->stream));
         for (int l = 0; l < 2; l++) { dict[l].large_list = d_large; dict[l].large_n = d_nlarge; dict[l].large_max = maxlarge; dict[l].large_tag = (uint32_t)l; }
         dict[0].bigthresh = dict[1].bigthresh = HARC_LARGEBIN;     // SLOT_BIG: the bin gets a row of largetab and its reads in `mirror`
+        if (bloom_bits) {
+            uint64_t nw = ((uint64_t)N * (uint64_t)bloom_bits + 31) / 32 + 1;
+            if (nw > 0xFFFFFFFFull) nw = 0xFFFFFFFFull;
+            bloom_words = (uint32_t)nw;
+            for (int l = 0; l < 2; l++) { RC_TRY(dalloc(c, &d_bloom[l], (size_t)bloom_words)); HIP_TRY(hipMemsetAsync(d_bloom[l], 0, (size_t)bloom_words * 4, c->stream)); }
+        }
         const harc_mark_t mk = harc_pool_mark(c);
         uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
         RC_TRY(dalloc(c, &k0, N)); RC_TRY(dalloc(c, &i0, N));
         for (int l = 0; l < 2; l++) {
             const int kbits = 2 * (P.dict_end[l] - P.dict_start[l] + 1);
             hipLaunchKernelGGL((k_keygen<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[l], kbits, k0, i0);
+            if (bloom_words) hipLaunchKernelGGL(k_s1_bloom_set, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, d_bloom[l], bloom_words);
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, N, (unsigned)kbits));
         }
         harc_pool_release(c, mk);
@@ -1419,6 +1446,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     for (int l = 0; l < 2; l++) { a.ds[l] = P.dict_start[l]; a.de[l] = P.dict_end[l]; a.kbits[l] = 2 * (P.dict_end[l] - P.dict_start[l] + 1); }
     a.N = N; a.K = K; a.reads = c->d_reads;
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
+    a.bloom[0] = d_bloom[0]; a.bloom[1] = d_bloom[1]; a.bloom_words = bloom_words;
     a.largetab = d_largetab; a.mirror = d_mirror;
     const size_t nwords = (size_t)N / 64 + 2;
     const uint32_t nblk = (K + 255) / 256;
@@ -1437,6 +1465,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     a.probe_tab = d_tab; a.nprobe = (int)tab.size();
     a.budget = getenv("HARC_AMD_BUDGET") ? atoi(getenv("HARC_AMD_BUDGET")) : HARC_SCAN_BUDGET;   // not part of the C-ABI: the oracle knows the default only
     a.nbatch = 0;                                                // adaptive batches (k_steps) unless a fixed schedule is forced
+    a.firstmax[0] = a.firstmax[1] = 48;
+    if (const char *e = getenv("HARC_AMD_FIRSTMAX")) { int x = 32, y = 32; if (sscanf(e, "%d,%d", &x, &y) >= 1) { a.firstmax[0] = x < 1 ? 1 : x > 64 ? 64 : x; a.firstmax[1] = y < 1 ? 1 : y > 64 ? 64 : y; } }
     if (const char *e = getenv("HARC_AMD_BATCHES")) {             // tuning knob, e.g. "32,64"; the last size repeats
         int sizes[12], k = 0, last = 64; const char *q = e;
         while (*q && k < 12) { int v = atoi(q); if (v < 1) v = 1; if (v > 64) v = 64; sizes[k++] = last = v; while (*q && *q != ',') q++; if (*q == ',') q++; }
