@@ -20,14 +20,27 @@ __device__ __forceinline__ uint64_t bucket_slot(uint64_t key, uint64_t cap)
     return (uint64_t)__umulhi(h, (uint32_t)nb) << 2;
 }
 
-// word and two-bit mask of a key in the one-word-per-key bitmap in front of a stage-I dictionary (k_steps: most probes of a step find
-// nothing; they end in this bitmap, which is small enough to be served on-die, instead of in the table).  A hash of its own: keys that
-// share the table's 32-bit hash must not share this one
-__device__ __forceinline__ void bloom_pos(uint64_t key, uint32_t nwords, uint32_t *word, uint32_t *mask)
+// Word and two-bit mask of a key in the bitmap in front of a stage-I dictionary (k_steps: most probes of a step find nothing; they end
+// in this bitmap instead of in the table).  Word and bits come from a hash of the whole key (one of its own: keys that share the
+// table's 32-bit hash must not share this one).  The 64-byte LINE: nwin = 0 -- hashed from the key as well.  nwin > 0 (bitmaps larger
+// than the Infinity Cache) -- chosen by the minimizer of the k-mer, the smallest m-mer inside it (bases re-coded so that C < T < A < G):
+// the probes of one step are k-mers of the consensus at consecutive shifts, a dozen consecutive k-mers share their minimizer, so the 48
+// probes of a batch fall into ~8 lines instead of 48 -- and what bounds the kernel there is the number of requests that miss L2, not
+// bytes (tools/micro/gups.hip; PMC: 64 M -> 12 M misses per launch at configs[2]).
+__device__ __forceinline__ void bloom_pos(uint64_t key, uint32_t nlines, int nwin, uint32_t mmask, uint32_t *word, uint32_t *mask)
 {
     uint32_t g = ((uint32_t)key * 0xC2B2AE35u) ^ __builtin_rotateleft32((uint32_t)(key >> 32) * 0x27D4EB2Fu, 15);
     g ^= g >> 15; g *= 0x165667B1u;
-    *word = __umulhi(g, nwords);
+    uint32_t hl;
+    if (nwin > 0) {
+        const uint32_t lo = (uint32_t)key ^ 0xAAAAAAAAu, hi = (uint32_t)(key >> 32) ^ 0xAAAAAAAAu;
+        uint32_t best = 0xFFFFFFFFu;
+        const int n1 = nwin < 16 ? nwin : 16;
+        for (int i = 0; i < n1; i++) { const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, 2 * i) & mmask; best = x < best ? x : best; }
+        for (int i = 16; i < nwin; i++) { const uint32_t x = (hi >> (2 * i - 32)) & mmask; best = x < best ? x : best; }
+        hl = best * 0x9E3779B1u; hl ^= hl >> 15; hl *= 0x85EBCA77u; hl ^= hl >> 13;
+    } else { hl = g ^ (g >> 16); hl *= 0x9E3779B1u; }
+    *word = (__umulhi(hl, nlines) << 4) | ((g >> 10) & 15u);
     *mask = (1u << (g & 31)) | (1u << ((g >> 5) & 31));
 }
 

@@ -21,7 +21,7 @@ struct S1Args {
     uint64_t cap[2];
     const uint32_t *ids[2];
     int firstmax[2];                 // widths of the first two probe batches of a step when many chains are in flight
-    const uint32_t *bloom[2]; uint32_t bloom_words;   // bitmap over the keys of each dictionary (bloom_pos), 0 words = none
+    const uint32_t *bloom[2]; uint32_t bloom_lines; int bloom_nwin[2]; uint32_t bloom_mmask;   // bitmap over the keys of each dictionary (bloom_pos), 0 lines = none
     const uint2 *largetab;           // bins of more than HARC_LARGEBIN reads (SLOT_BIG; their slot's `start` indexes this table): x = first index into ids[], y = first row of `mirror`
     uint64_t *mirror;                // the reads of those bins once more, W words per entry, in bin order: their scan is one coalesced stream
     unsigned long long *claimed;     // bitmap, bit rid&63 of word rid>>6
@@ -41,6 +41,7 @@ struct S1Args {
     long long *cursor;               // reorder.cpp `remainingpos`, one for all chains
     unsigned long long *stats;       // [0] unmatched [1] conflicts [2] active chains [3] probes [4] candidates
     const uint16_t *probe_tab;       // the probes of one chain step in priority order: shift | dir<<8 | dict<<9
+    const uint32_t *lds_tab;         // mask rows + probe descriptors as k_steps wants them in LDS (k_steps_tables)
     int nprobe;
     int budget;                      // HARC_SCAN_BUDGET (experiments may override it: HARC_AMD_BUDGET)
     int nbatch, batch_end[12];       // probe batches: [0,batch_end[0]), [batch_end[0],batch_end[1]) ... each at most 64 wide
@@ -292,12 +293,12 @@ __global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, cons
     }
 }
 
-__global__ void k_s1_bloom_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, uint32_t nwords)
+__global__ void k_s1_bloom_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, uint32_t nlines, int nwin, uint32_t mmask)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t w, m;
-    bloom_pos(keys[i], nwords, &w, &m);
+    bloom_pos(keys[i], nlines, nwin, mmask, &w, &m);
     if ((bloom[w] & m) != m) atomicOr(&bloom[w], m);
 }
 
@@ -635,6 +636,32 @@ template <int W> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int rol
     return r;
 }
 
+// What every workgroup of k_steps needs in LDS and used to compute for itself at every launch (with integer divisions: a fifth of the
+// kernel's vector instructions): out[0 .. 2 maxmatch MROW) = the mask rows -- mask[j] keeps the low 2(L-j) bits, revmask[j] the bits >= 2j
+// below 2L (reorder.cpp:706-718); then one uint2 per probe p of a step (reorder.cpp:517-649 order): x = bit offset of its key window inside
+// the wave's two rows | dir << 13 | dict << 14 | shift << 16;  y = bit offset of its Hamming window | dword offset of its mask row << 16
+template <int W> __global__ void k_steps_tables(S1Args s, uint32_t *out)
+{
+    constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
+    const int L = s.L, nm = 2 * s.maxmatch * MROW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
+        const int k = i % MROW, r = i / MROW, dir = r / s.maxmatch, j = r % s.maxmatch;
+        const int lo = dir ? 2 * j : 0, hi = dir ? 2 * L : 2 * (L - j);      // bits [lo, hi)
+        const int a = lo - 32 * k, b = hi - 32 * k;
+        const uint32_t mh = b >= 32 ? 0xFFFFFFFFu : (b <= 0 ? 0u : ((1u << b) - 1u)), ml = a >= 32 ? 0xFFFFFFFFu : (a <= 0 ? 0u : ((1u << a) - 1u));
+        out[i] = k < NW ? (mh & ~ml) : 0u;
+    }
+    uint2 *const pinfo = reinterpret_cast<uint2 *>(out + nm);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < s.nprobe; i += gridDim.x * blockDim.x) {
+        const uint32_t e = s.probe_tab[i];
+        const int j = (int)(e & 0xFF), dir = (int)((e >> 8) & 1), l = (int)((e >> 9) & 1);
+        const int koff = dir * ROW * 32 + 32 * NW + (dir ? 2 * (s.ds[l] - j) : 2 * (s.ds[l] + j));
+        const int hoff = dir * ROW * 32 + 32 * NW + (dir ? -2 * j : 2 * j);      // the consensus is shifted by 2j bits (reorder.cpp:647-648)
+        pinfo[i] = make_uint2((uint32_t)koff | ((uint32_t)dir << 13) | ((uint32_t)l << 14) | ((uint32_t)j << 16),
+                              (uint32_t)hoff | ((uint32_t)((dir * s.maxmatch + j) * MROW) << 16));
+    }
+}
+
 template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 2 : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1))) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
@@ -654,24 +681,11 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
         const uint32_t fl = s.hdr[blockIdx.x].flags;
         if (!(fl & CH_ACTIVE) || !(fl & CH_COOP)) return;
     }
-    {   // the whole workgroup, before any wave leaves: mask[j] keeps the low 2(L-j) bits, revmask[j] the bits >= 2j below 2L (reorder.cpp:706-718)
-        for (int i = threadIdx.x; i < 2 * s.maxmatch * MROW; i += 256) {
-            const int k = i % MROW, r = i / MROW, dir = r / s.maxmatch, j = r % s.maxmatch;
-            const int lo = dir ? 2 * j : 0, hi = dir ? 2 * L : 2 * (L - j);      // bits [lo, hi)
-            const int a = lo - 32 * k, b = hi - 32 * k;
-            const uint32_t mh = b >= 32 ? 0xFFFFFFFFu : (b <= 0 ? 0u : ((1u << b) - 1u)), ml = a >= 32 ? 0xFFFFFFFFu : (a <= 0 ? 0u : ((1u << a) - 1u));
-            s_mask[i] = k < NW ? (mh & ~ml) : 0u;
-        }
-        // probe p of a step (reorder.cpp:517-649 order): x = bit offset of its key window inside the wave's two rows | dir << 13 | dict << 14
-        // | shift << 16;  y = bit offset of its Hamming window | dword offset of its mask row << 16
-        for (int i = threadIdx.x; i < s.nprobe; i += 256) {
-            const uint32_t e = s.probe_tab[i];
-            const int j = (int)(e & 0xFF), dir = (int)((e >> 8) & 1), l = (int)((e >> 9) & 1);
-            const int koff = dir * ROW * 32 + 32 * NW + (dir ? 2 * (s.ds[l] - j) : 2 * (s.ds[l] + j));
-            const int hoff = dir * ROW * 32 + 32 * NW + (dir ? -2 * j : 2 * j);      // the consensus is shifted by 2j bits (reorder.cpp:647-648)
-            s_pinfo[i] = make_uint2((uint32_t)koff | ((uint32_t)dir << 13) | ((uint32_t)l << 14) | ((uint32_t)j << 16),
-                                    (uint32_t)hoff | ((uint32_t)((dir * s.maxmatch + j) * MROW) << 16));
-        }
+    {   // the whole workgroup, before any wave leaves: mask rows and probe descriptors (k_steps_tables) -> LDS
+        const int nm = 2 * s.maxmatch * MROW;
+        for (int i = threadIdx.x; i < nm; i += 256) s_mask[i] = s.lds_tab[i];
+        const uint2 *const pt = reinterpret_cast<const uint2 *>(s.lds_tab + nm);
+        for (int i = threadIdx.x; i < s.nprobe; i += 256) s_pinfo[i] = pt[i];
         for (int i = threadIdx.x; i < 4 * 2 * ROW; i += 256) s_rows[i] = 0u;
         for (int i = threadIdx.x; i < 4 * 8 * NW; i += 256) s_tmp[i] = 0u;
         __syncthreads();
@@ -777,7 +791,8 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
             // batch), at most firstmax probes; every later batch is a full wave.  With many chains the kernel runs close to the random-access
             // ceiling of the memory system (tools/micro/gups.hip: 26 G 32-byte requests/s beyond 16 GiB), so speculative probes cost
             // throughput: without the bitmap in front of the tables the best width of the first two batches was 32; with it a
-            // speculative probe is an on-die bitmap lookup and 48 is better (configs[2]: chains 768 -> 728 ms).  With few chains a round
+            // speculative probe is a 4-byte bitmap lookup and 48 is better (configs[2]: chains 768 -> 728 ms); once the bitmap's lines go by
+            // minimizer (bloom_pos) the speculative probes share the lines of the useful ones: 64 (-> 660 ms).  With few chains a round
             // trip costs more than the probes (QUAD: 64).
             // s.nbatch > 0 (HARC_AMD_BATCHES) overrides with a fixed schedule.
             int bend;
@@ -810,9 +825,9 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
                 uint64_t sl = bucket_slot(key, cap);
                 int state = 0, qhit = 0;                                  // 1 = the key is not in the table, 2 = key found
                 uint32_t sst = 0, cw = 0;
-                if (s.bloom_words) {                                      // most keys of a step are in neither: they stop at the bitmap
+                if (s.bloom_lines) {                                      // most keys of a step are in neither: they stop at the bitmap
                     uint32_t bw, bm;
-                    bloom_pos(key, s.bloom_words, &bw, &bm);
+                    bloom_pos(key, s.bloom_lines, l ? s.bloom_nwin[1] : s.bloom_nwin[0], s.bloom_mmask, &bw, &bm);
                     if (((l ? s.bloom[1] : s.bloom[0])[bw] & bm) != bm) state = 1;
                 }
                 if (state == 0) for (;;) {
@@ -1382,8 +1397,13 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // ---- dictionaries (constructdictionary, reorder.cpp:277-394)
     DictDev dict[2];
     // a bitmap of bloom_bits bits per read in front of each table, two bits set per key (HARC_AMD_S1BLOOM=0: none)
-    uint32_t *d_bloom[2] = { nullptr, nullptr }; uint32_t bloom_words = 0;
-    int bloom_bits = 16;
+    uint32_t *d_bloom[2] = { nullptr, nullptr }; uint32_t bloom_lines = 0; int bloom_nwin[2] = { 0, 0 };
+    // lines by minimizer (bloom_pos) once a bitmap is larger than half the Infinity Cache; m = minimizer length in bases
+    int bloom_bits = 16, bloom_m = (P.dict_end[0] - P.dict_start[0] + 1) / 2; size_t bloom_mz_bytes = (size_t)128 << 20;
+    if (bloom_m > 16) bloom_m = 16;
+    if (const char *e = getenv("HARC_AMD_S1BLOOM_M")) { bloom_m = atoi(e); if (bloom_m < 0) bloom_m = 0; if (bloom_m > 16) bloom_m = 16; }
+    if (const char *e = getenv("HARC_AMD_S1BLOOM_MZMB")) bloom_mz_bytes = (size_t)strtoull(e, nullptr, 10) << 20;
+    const uint32_t bloom_mmask = bloom_m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * bloom_m)) - 1u);
     if (const char *e = getenv("HARC_AMD_S1BLOOM")) { bloom_bits = atoi(e); if (bloom_bits < 0) bloom_bits = 0; if (bloom_bits > 64) bloom_bits = 64; }
     unsigned long long *d_large = nullptr; unsigned int *d_nlarge = nullptr;
     const uint32_t maxlarge = 2 * (N / HARC_LARGEBIN) + 16;
@@ -1395,10 +1415,14 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         for (int l = 0; l < 2; l++) { dict[l].large_list = d_large; dict[l].large_n = d_nlarge; dict[l].large_max = maxlarge; dict[l].large_tag = (uint32_t)l; }
         dict[0].bigthresh = dict[1].bigthresh = HARC_LARGEBIN;     // SLOT_BIG: the bin gets a row of largetab and its reads in `mirror`
         if (bloom_bits) {
-            uint64_t nw = ((uint64_t)N * (uint64_t)bloom_bits + 31) / 32 + 1;
-            if (nw > 0xFFFFFFFFull) nw = 0xFFFFFFFFull;
-            bloom_words = (uint32_t)nw;
-            for (int l = 0; l < 2; l++) { RC_TRY(dalloc(c, &d_bloom[l], (size_t)bloom_words)); HIP_TRY(hipMemsetAsync(d_bloom[l], 0, (size_t)bloom_words * 4, c->stream)); }
+            uint64_t nl = ((uint64_t)N * (uint64_t)bloom_bits + 511) / 512 + 1;       // lines of 64 bytes
+            if (nl > 0x0FFFFFFFull) nl = 0x0FFFFFFFull;
+            bloom_lines = (uint32_t)nl;
+            for (int l = 0; l < 2; l++) {
+                RC_TRY(dalloc(c, &d_bloom[l], (size_t)bloom_lines * 16)); HIP_TRY(hipMemsetAsync(d_bloom[l], 0, (size_t)bloom_lines * 64, c->stream));
+                const int nb = P.dict_end[l] - P.dict_start[l] + 1;                   // bases per key
+                bloom_nwin[l] = (bloom_m > 0 && nb > bloom_m && (size_t)bloom_lines * 64 >= bloom_mz_bytes) ? nb - bloom_m + 1 : 0;
+            }
         }
         const harc_mark_t mk = harc_pool_mark(c);
         uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
@@ -1406,7 +1430,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         for (int l = 0; l < 2; l++) {
             const int kbits = 2 * (P.dict_end[l] - P.dict_start[l] + 1);
             hipLaunchKernelGGL((k_keygen<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[l], kbits, k0, i0);
-            if (bloom_words) hipLaunchKernelGGL(k_s1_bloom_set, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, d_bloom[l], bloom_words);
+            if (bloom_lines) hipLaunchKernelGGL(k_s1_bloom_set, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, d_bloom[l], bloom_lines, bloom_nwin[l], bloom_mmask);
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, N, (unsigned)kbits));
         }
         harc_pool_release(c, mk);
@@ -1446,7 +1470,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     for (int l = 0; l < 2; l++) { a.ds[l] = P.dict_start[l]; a.de[l] = P.dict_end[l]; a.kbits[l] = 2 * (P.dict_end[l] - P.dict_start[l] + 1); }
     a.N = N; a.K = K; a.reads = c->d_reads;
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
-    a.bloom[0] = d_bloom[0]; a.bloom[1] = d_bloom[1]; a.bloom_words = bloom_words;
+    a.bloom[0] = d_bloom[0]; a.bloom[1] = d_bloom[1]; a.bloom_lines = bloom_lines; a.bloom_nwin[0] = bloom_nwin[0]; a.bloom_nwin[1] = bloom_nwin[1]; a.bloom_mmask = bloom_mmask;
     a.largetab = d_largetab; a.mirror = d_mirror;
     const size_t nwords = (size_t)N / 64 + 2;
     const uint32_t nblk = (K + 255) / 256;
@@ -1463,9 +1487,16 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     uint16_t *d_tab = nullptr; RC_TRY(dalloc(c, &d_tab, tab.size() + 1));
     HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream));
     a.probe_tab = d_tab; a.nprobe = (int)tab.size();
+    {
+        uint32_t *lt = nullptr;
+        const size_t nm = (size_t)2 * P.maxmatch * StepsLds<W>::MROW;
+        RC_TRY(dalloc(c, &lt, nm + 2 * tab.size() + 2));
+        hipLaunchKernelGGL((k_steps_tables<W>), dim3(4), dim3(256), 0, c->stream, a, lt);
+        a.lds_tab = lt;
+    }
     a.budget = getenv("HARC_AMD_BUDGET") ? atoi(getenv("HARC_AMD_BUDGET")) : HARC_SCAN_BUDGET;   // not part of the C-ABI: the oracle knows the default only
     a.nbatch = 0;                                                // adaptive batches (k_steps) unless a fixed schedule is forced
-    a.firstmax[0] = a.firstmax[1] = 48;
+    a.firstmax[0] = a.firstmax[1] = (bloom_nwin[0] > 0 && bloom_nwin[1] > 0) ? 64 : 48;     // lines by minimizer: speculative probes share their lines
     if (const char *e = getenv("HARC_AMD_FIRSTMAX")) { int x = 32, y = 32; if (sscanf(e, "%d,%d", &x, &y) >= 1) { a.firstmax[0] = x < 1 ? 1 : x > 64 ? 64 : x; a.firstmax[1] = y < 1 ? 1 : y > 64 ? 64 : y; } }
     if (const char *e = getenv("HARC_AMD_BATCHES")) {             // tuning knob, e.g. "32,64"; the last size repeats
         int sizes[12], k = 0, last = 64; const char *q = e;
