@@ -471,7 +471,11 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args
 // claims only move to earlier tuples, so they stay claimed for e and the next pass starts below them (a bin of n identical reads would
 // otherwise cost every one of its events n loads per pass).  (One wave per BIN walking its events in tuple order settles a deep bin in
 // one pass, but serialises the hundreds of thousands of probes a low-complexity bin attracts: tried, 100x slower.)
-__global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed)
+// binver[l][start of the bin in ids[l]]: bumped whenever the claim of one of the bin's reads moves (both bins of the read: it sits in one
+// bin of either dictionary).  What an event does is a function of the claims of its bin's reads, so an event whose bin has the version
+// it had when the event last looked is skipped: after the first passes only the events of the bins that are still settling -- the
+// deepest ones -- are scanned again (a 50 M-read repeat-rich set: 18 passes over ALL events before).
+__global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, uint32_t *binver0, uint32_t *binver1, uint32_t *lastver)
 {
     __shared__ unsigned long long swin[4][HARC_MAXW3];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -482,6 +486,9 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uin
     const unsigned long long tp = (unsigned long long)ev.x | ((unsigned long long)ev.y << 32);
     const uint64_t x = tp >> 2; const int dir = (int)((tp >> 1) & 1), l = (int)(tp & 1);
     const uint32_t st = ev.z, cnt = ev.w;
+    uint32_t *const myver = (l ? binver1 : binver0) + st;
+    const uint32_t ver = __hip_atomic_load(myver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // before anything of the bin is read
+    if (ver == lastver[e]) return;
     // 3-bit window words (forward or reverse complement), lanes 0..W3-1 build one word each
     if (lane < W3) {
         const uint8_t *win = s.cons + x;
@@ -517,12 +524,22 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uin
             const uint64_t *r = s.cand3 + (size_t)rid * W3;
             int hd = 0;
             for (int w = 0; w < W3; w++) { hd += __popcll(swin[wv][w] ^ r[w]); if (hd > s.thresh_s) break; }
-            if (hd <= s.thresh_s && atomicMin(&s.best[rid], tp) > tp) ch = true;      // every passing candidate of the window is taken (encoder.cpp:296-317)
+            if (hd <= s.thresh_s && atomicMin(&s.best[rid], tp) > tp) {               // every passing candidate of the window is taken (encoder.cpp:296-317)
+                ch = true;
+                // the read's bin in the other dictionary sees a new claim too
+                const int ol = 1 - l, off = 3 * s.ds[ol], wi = off >> 6, sh = off & 63;
+                uint64_t okey = r[wi] >> sh;
+                if (sh && wi + 1 < W3) okey |= r[wi + 1] << (64 - sh);
+                if (s.kbits[ol] < 64) okey &= ((uint64_t)1 << s.kbits[ol]) - 1;
+                uint32_t ost = 0, ocnt = 0;
+                if (dict_lookup_b(s.slots[ol], s.cap[ol], okey, &ost, &ocnt) && !(ocnt & SLOT_EMB)) atomicAdd((ol ? binver1 : binver0) + ost, 1u);
+            }
         }
         seen += (uint32_t)__popcll(um);
         pos -= pos > 64 ? 64 : pos;
     }
-    if (lane == 0) { estart[e] = top; if (ch) atomicOr(changed, 1u); }
+    ch = __ballot(ch) != 0;
+    if (lane == 0) { estart[e] = top; lastver[e] = ver; if (ch) { atomicAdd(myver, 1u); atomicOr(changed, 1u); } }
 }
 
 __global__ void k_acc_flags(const unsigned long long *best, uint32_t T, uint32_t *flag)
@@ -892,12 +909,14 @@ int stage2_run(harc_amd_ctx *c)
                 if (nev > a.maxevents) { harc_set_error("stage II: event count changed between two identical passes (%u > %u)", nev, a.maxevents); return HARC_AMD_EINTERNAL; }
             }
             if (nev) {                                                        // exact sliding-window semantics as a fixed point (k_realign_big)
-                unsigned int *d_changed = nullptr; uint32_t *estart = nullptr;
-                RC_TRY(dalloc(c, &d_changed, 4)); RC_TRY(dalloc(c, &estart, (size_t)nev + 1));
+                unsigned int *d_changed = nullptr; uint32_t *estart = nullptr, *binver[2] = { nullptr, nullptr }, *lastver = nullptr;
+                RC_TRY(dalloc(c, &d_changed, 4)); RC_TRY(dalloc(c, &estart, (size_t)nev + 1)); RC_TRY(dalloc(c, &lastver, (size_t)nev + 1));
                 HIP_TRY(hipMemsetAsync(estart, 0xFF, ((size_t)nev + 1) * 4, c->stream));
+                HIP_TRY(hipMemsetAsync(lastver, 0xFF, ((size_t)nev + 1) * 4, c->stream));
+                for (int l = 0; l < 2; l++) { RC_TRY(dalloc(c, &binver[l], (size_t)T + 1)); HIP_TRY(hipMemsetAsync(binver[l], 0, ((size_t)T + 1) * 4, c->stream)); }
                 for (uint64_t pass = 0;; pass++) {
                     HIP_TRY(hipMemsetAsync(d_changed, 0, 16, c->stream));
-                    hipLaunchKernelGGL(k_realign_big, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed);
+                    hipLaunchKernelGGL(k_realign_big, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binver[0], binver[1], lastver);
                     unsigned int chg = 0;
                     HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -84,6 +84,33 @@ def reads_text_bigbin_stage2(seed, n_clean=3000, n_dupN=2500, L=100, genome_len=
     return out.tobytes()
 
 
+def reads_text_bigbin_stage2_mixed(seed, n_clean=4000, n_dupN=3000, L=100, genome_len=6000, copies=3, fail_frac=0.6, nsub=32):
+    """as reads_text_bigbin_stage2, but the shared 100-base window occurs `copies` times in the genome (several probes per bin, in
+    tuple order) and a random fail_frac of the N reads carry nsub substitutions in their second half: they sit in the same two bins
+    but fail the Hamming test, so they stay unclaimed inside every probe's maxsearch window and push it on unevenly"""
+    rs = np.random.RandomState(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rs.randint(0, 4, size=genome_len)]
+    win = genome[200:200 + L].copy()
+    for k in range(1, copies):
+        at = 200 + k * (genome_len - 400) // copies
+        genome[at:at + L] = win
+    starts = rs.randint(0, genome_len - L, size=n_clean)
+    clean = genome[starts[:, None] + np.arange(L)[None, :]].copy()
+    dup = np.tile(win, (n_dupN, 1)).copy()
+    bad = rs.rand(n_dupN) < fail_frac
+    for i in np.nonzero(bad)[0]:
+        cols = rs.choice(np.arange(50, L), size=nsub, replace=False)
+        dup[i, cols] = acgt[(np.searchsorted(acgt, dup[i, cols]) + 1 + rs.randint(0, 3, size=nsub)) % 4]
+    dup[np.arange(n_dupN), rs.randint(50, L, size=n_dupN)] = ord("N")
+    allr = np.concatenate([clean, dup])
+    rs.shuffle(allr)
+    out = np.empty((allr.shape[0], L + 1), dtype=np.uint8)
+    out[:, :L] = allr
+    out[:, L] = 10
+    return out.tobytes()
+
+
 def auto_chains(n_clean, reads_per_chain=2048):
     """auto_chains() of harc_amd/csrc/stage1.hip: K when harc_amd_params.num_chains = 0"""
     k = n_clean // reads_per_chain

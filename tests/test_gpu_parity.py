@@ -233,6 +233,22 @@ def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, maxev, ndup, 
     assert len(s2["read_order_N_pe.bin"]) // 4 == ndup and len(s2["input_N.dna"]) < (ndup - 1000) * 101
 
 
+@pytest.mark.parametrize("K,S,E,seed,fail", [(1, 16, 1, 5, 0.6), (4, 16, 2, 6, 0.5), (1, 16, 1, 7, 0.8), (2, 8, 1, 8, 0.3)])
+def test_stage2_big_bins_partial_claims_exact(K, S, E, seed, fail, oracle, tmp_path):
+    """bins above maxsearch whose reads only partly pass the Hamming test, probed from several places of the consensus: what a probe
+    sees depends on which reads the probes before it took AND on the ones nobody takes (they fill the window).  The passes of
+    k_realign_big must go on while ANY lane of any probe still moves a claim -- same bytes as the sequential oracle."""
+    import harc_amd
+    txt = gen.reads_text_bigbin_stage2_mixed(seed, fail_frac=fail)
+    (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, K, E, tmp_path / "o", S)
+    base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.compress(base, 100, num_thr=E, num_chains=K, num_steps=S)
+    assert_same(ol.read_dir(base), s2, ol.stage2_files(E), "stage II, partly matching bins above maxsearch vs oracle")
+    nleft = len(s2["input_N.dna"]) // 101
+    assert 200 < nleft < 3000 - 200                              # some were taken, some never are
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_decoder_matches_reference_decoder(case, tmp_path):
     """harc_amd_decoder_files == decoder.out: output.dna byte-identical to the REAL reference decoder's on the reference's streams"""
