@@ -53,6 +53,18 @@ def make_reads(rs, L):
     if ndup:
         r = np.concatenate([r, np.tile(r[rs.randint(0, n)], (ndup, 1))])
         rs.shuffle(r)
+    nbig = int(rs.choice([0, 0, 0, 1300, 2600]))                  # stage-II bins above maxsearch, only partly matching (k_realign_big)
+    if nbig:
+        src = r[rs.randint(0, r.shape[0])].copy()
+        src[src == ord("N")] = ord("A")
+        dupn = np.tile(src, (nbig, 1))
+        h = L // 2
+        for i in np.nonzero(rs.random_sample(nbig) < float(rs.choice([0.0, 0.4, 0.8])))[0]:
+            cols = h + rs.choice(L - h, size=min(L - h, 32 * L // 100 + 1), replace=False)
+            dupn[i, cols] = ACGT[rs.randint(0, 4, size=len(cols))]
+        dupn[np.arange(nbig), h + rs.randint(0, L - h, size=nbig)] = ord("N")
+        r = np.concatenate([r, dupn])
+        rs.shuffle(r)
     out = np.empty((r.shape[0], L + 1), dtype=np.uint8)
     out[:, :L] = r
     out[:, L] = 10
