@@ -35,9 +35,19 @@ __device__ __forceinline__ void bloom_pos(uint64_t key, uint32_t nlines, int nwi
     if (nwin > 0) {
         const uint32_t lo = (uint32_t)key ^ 0xAAAAAAAAu, hi = (uint32_t)(key >> 32) ^ 0xAAAAAAAAu;
         uint32_t best = 0xFFFFFFFFu;
-        const int n1 = nwin < 16 ? nwin : 16;
-        for (int i = 0; i < n1; i++) { const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, 2 * i) & mmask; best = x < best ? x : best; }
-        for (int i = 16; i < nwin; i++) { const uint32_t x = (hi >> (2 * i - 32)) & mmask; best = x < best ? x : best; }
+        if (nwin == 17 && mmask == 0xFFFFFFFFu) {                    // 32-base keys, 16-base minimizers (reads of 100 bases and more): unrolled, no masks
+            best = lo < hi ? lo : hi;
+#pragma unroll
+            for (int i = 1; i < 16; i += 3) {
+                const uint32_t a = __builtin_amdgcn_alignbit(hi, lo, 2 * i), b = __builtin_amdgcn_alignbit(hi, lo, 2 * i + 2), c = __builtin_amdgcn_alignbit(hi, lo, 2 * i + 4);
+                const uint32_t m = a < b ? a : b, n = c < best ? c : best;
+                best = m < n ? m : n;
+            }
+        } else {
+            const int n1 = nwin < 16 ? nwin : 16;
+            for (int i = 0; i < n1; i++) { const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, 2 * i) & mmask; best = x < best ? x : best; }
+            for (int i = 16; i < nwin; i++) { const uint32_t x = (hi >> (2 * i - 32)) & mmask; best = x < best ? x : best; }
+        }
         hl = best * 0x9E3779B1u; hl ^= hl >> 15; hl *= 0x85EBCA77u; hl ^= hl >> 13;
     } else { hl = g ^ (g >> 16); hl *= 0x9E3779B1u; }
     *word = (__umulhi(hl, nlines) << 4) | ((g >> 10) & 15u);
