@@ -9,28 +9,37 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
     return x;
 }
 
-// first slot of the 64-byte bucket (4 slots of 16 bytes) a key of a bucketed table hashes to.  32-bit arithmetic: the chain kernel is
-// bound by instruction issue, and a 64 x 64 -> 128 multiply chain per probe was a tenth of its instructions
-__device__ __forceinline__ uint64_t bucket_slot(uint64_t key, uint64_t cap)
+// The dictionaries store and compare SCRAMBLED keys: a bijection of the 64-bit key space (three Feistel rounds of 32-bit
+// multiply-xorshift -- the chain kernel is bound by instruction issue, 64 x 64 -> 128 multiplies are a tenth of its instructions) whose
+// high word picks the bucket monotonically.  Sorting the reads by scrambled key groups equal k-mers just as sorting by key does, and
+// leaves the bins in BUCKET order: the table is then written front to back without a single atomic (harc_dict_build).
+__device__ __forceinline__ uint64_t key_scramble(uint64_t key)
+{
+    uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32), y;
+    y = a * 0x9E3779B1u; b ^= y ^ (y >> 15);
+    y = b * 0x85EBCA77u; a ^= y ^ (y >> 13);
+    y = a * 0xC2B2AE3Du; b ^= y ^ (y >> 16);
+    return ((uint64_t)b << 32) | a;
+}
+// first slot of the 64-byte bucket (4 slots of 16 bytes) a scrambled key belongs to; non-decreasing in h
+__device__ __forceinline__ uint64_t bucket_slot(uint64_t h, uint64_t cap)
 {
     const uint64_t nb = cap >> 2;
-    if (nb >> 32) return __umul64hi(mix64(key), nb) << 2;        // more than 2^34 slots (256 GB): not on one GPU; kept exact
-    uint32_t h = ((uint32_t)key * 0x9E3779B1u) ^ __builtin_rotateleft32((uint32_t)(key >> 32) * 0x85EBCA77u, 16);
-    h ^= h >> 16; h *= 0x2C1B3C6Du;
-    return (uint64_t)__umulhi(h, (uint32_t)nb) << 2;
+    if (nb >> 32) return __umul64hi(h, nb) << 2;                  // more than 2^34 slots (256 GB): not on one GPU; kept exact
+    return (uint64_t)__umulhi((uint32_t)(h >> 32), (uint32_t)nb) << 2;
 }
 
 // Word and two-bit mask of a key in the bitmap in front of a stage-I dictionary (k_steps: most probes of a step find nothing; they end
-// in this bitmap instead of in the table).  Word and bits come from a hash of the whole key (one of its own: keys that share the
-// table's 32-bit hash must not share this one).  The 64-byte LINE: nwin = 0 -- hashed from the key as well.  nwin > 0 (bitmaps larger
+// in this bitmap instead of in the table).  Word and bits come from the low word of the scrambled key (the bucket comes from the high
+// word: keys that share a bucket do not share these).  The 64-byte LINE: nwin = 0 -- hashed from the key as well.  nwin > 0 (bitmaps larger
 // than the Infinity Cache) -- chosen by the minimizer of the k-mer, the smallest m-mer inside it (bases re-coded so that C < T < A < G):
 // the probes of one step are k-mers of the consensus at consecutive shifts, a dozen consecutive k-mers share their minimizer, so the 48
 // probes of a batch fall into ~8 lines instead of 48 -- and what bounds the kernel there is the number of requests that miss L2, not
 // bytes (tools/micro/gups.hip; PMC: 64 M -> 12 M misses per launch at configs[2]).
-__device__ __forceinline__ void bloom_pos(uint64_t key, uint32_t nlines, int nwin, uint32_t mmask, uint32_t *word, uint32_t *mask)
+__device__ __forceinline__ void bloom_pos(uint64_t key, uint64_t hkey, uint32_t nlines, int nwin, uint32_t mmask, uint32_t *word, uint32_t *mask)
 {
-    uint32_t g = ((uint32_t)key * 0xC2B2AE35u) ^ __builtin_rotateleft32((uint32_t)(key >> 32) * 0x27D4EB2Fu, 15);
-    g ^= g >> 15; g *= 0x165667B1u;
+    uint32_t g = (uint32_t)hkey * 0x165667B1u;                   // hkey = key_scramble(key): its low word does not decide the bucket
+    g ^= g >> 15;
     uint32_t hl;
     if (nwin > 0) {
         const uint32_t lo = (uint32_t)key ^ 0xAAAAAAAAu, hi = (uint32_t)(key >> 32) ^ 0xAAAAAAAAu;
@@ -169,19 +178,4 @@ template <int NT> __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32
     for (int k = 0; k < NT / 64; k++) { uint32_t x = sm[k]; if (k < wv) base += x; tot += x; }
     *total = tot;
     return base + ex;
-}
-
-
-// exact key -> (start,count) lookup in the open-addressing table built by harc_dict_build; count 0 = absent
-__device__ __forceinline__ bool dict_lookup(const HashSlot *tab, uint64_t cap, uint64_t key, uint32_t *start, uint32_t *count, uint32_t *nprobe)
-{
-    if (!cap) return false;
-    uint64_t sl = __umul64hi(mix64(key), cap);                   // classic linear probing (tables built with bucketed = false)
-    for (;;) {
-        const uint4 raw = *reinterpret_cast<const uint4 *>(&tab[sl]);
-        (*nprobe)++;
-        if (raw.w == 0) return false;
-        if (((uint64_t)raw.x | ((uint64_t)raw.y << 32)) == key) { *start = raw.z; *count = raw.w; return true; }
-        if (++sl == cap) sl = 0;
-    }
 }

@@ -77,7 +77,6 @@ struct DictDev {
     uint32_t *ids = nullptr;   // read ids sorted by (key, id)
     uint32_t *d_nbins = nullptr;
     uint32_t nbins = 0;
-    bool bucketed = false;     // probing goes bucket by bucket (64 B = 4 slots); a full bucket without SLOT_OVF ends an unsuccessful search
     unsigned long long *large_list = nullptr; unsigned int *large_n = nullptr; uint32_t large_max = 0, large_tag = 0;   // stage I: bins worth compacting, listed at insert time
     uint32_t bigthresh = 0;    // > 0: bins with more entries get SLOT_BIG     // probing starts at a 64-B bucket of 4 slots (fetched whole by a latency-bound k_steps) instead of at the hashed slot
 };
@@ -166,6 +165,7 @@ int prim_excl_scan_u32_to_u64(harc_amd_ctx *c, const uint32_t *in, uint64_t *out
 int prim_excl_scan_u8_to_u64(harc_amd_ctx *c, const uint8_t *in, uint64_t *out, size_t n);
 int prim_incl_scan_u64(harc_amd_ctx *c, const uint64_t *in, uint64_t *out, size_t n);
 int prim_incl_max_u32(harc_amd_ctx *c, const uint32_t *in, uint32_t *out, size_t n);
+int prim_incl_max_u64(harc_amd_ctx *c, const uint64_t *in, uint64_t *out, size_t n);
 
 // ---- stages
 int s1_pack_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t stride, uint64_t *d_out);               // 2-bit

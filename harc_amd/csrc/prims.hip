@@ -70,3 +70,10 @@ int prim_incl_max_u32(harc_amd_ctx *c, const uint32_t *in, uint32_t *out, size_t
     PRIM_CALL(rocprim::inclusive_scan(tmp, bytes, in, out, n, rocprim::maximum<uint32_t>(), c->stream));
     return HARC_AMD_OK;
 }
+
+int prim_incl_max_u64(harc_amd_ctx *c, const uint64_t *in, uint64_t *out, size_t n)
+{
+    if (n == 0) return HARC_AMD_OK;
+    PRIM_CALL(rocprim::inclusive_scan(tmp, bytes, in, out, n, rocprim::maximum<uint64_t>(), c->stream));
+    return HARC_AMD_OK;
+}

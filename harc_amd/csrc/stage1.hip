@@ -260,36 +260,60 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
 }
 #define HARC_LARGEBIN 16u    // stage-I bins with more reads than this are compacted between super-rounds (k_compact_bins)
 #define HARC_SCAN_BUDGET 16  // schedule: a walk ends after the step in which the probes it made into such bins (still holding unclaimed reads) reach this number
-// one thread per bin: claim an empty slot by CAS on the (start,count) word; keys are unique so no key compare is needed
-__global__ void k_table_insert(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, const uint32_t *nbins_p, uint32_t n,
-                               HashSlot *slots, uint64_t cap, int bucketed, uint32_t bigthresh,
-                               unsigned long long *large_list, unsigned int *large_n, uint32_t large_max, uint32_t large_tag)
+// The table is probed bucket by bucket (64 B = 4 slots); a search that finds a full bucket WITHOUT the overflow flag can stop.
+// The reads arrive sorted by scrambled key, so the bins arrive in bucket order (bucket_slot is monotone): the slot of bin i is
+// max(4 * bucket_i, slot_{i-1} + 1) -- the linear-probing invariant -- i.e. an inclusive max-scan of (4 * bucket_i - i), plus i.
+// No atomics, and the stores walk the table front to back.  (A CAS insert ran at the random read-modify-write rate: 37 ms for 350 M bins.)
+__global__ void k_scramble_keys(uint64_t *keys, uint32_t n)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nbins = *nbins_p;
-    if (b >= nbins) return;
-    const uint32_t st = binstart[b];
-    const uint32_t en = (b + 1 < nbins) ? binstart[b + 1] : n;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = key_scramble(keys[i]);
+}
+__global__ void k_place_keys(const uint64_t *skeys, const uint32_t *binstart, uint32_t nbins, uint64_t cap, uint64_t *v)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nbins) v[i] = bucket_slot(skeys[binstart[i]], cap) + (uint64_t)nbins - (uint64_t)i;     // 4 b_i - i, biased by nbins to stay unsigned
+}
+// pass 0: the bins whose slot lies inside the table, plain 16-byte stores.  pass 1 (after pass 0 has finished): the overflow flags -- a key
+// that sits beyond its home bucket has left every bucket in between -- and the few bins at the very end whose slot falls past the
+// table: they wrap around like a probe would.  Single-read bins (the common case) carry the read id in `start`: one dependent load
+// less on every hit.
+__global__ void k_table_place(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, uint32_t nbins, uint32_t n, const uint64_t *q,
+                              HashSlot *slots, uint64_t cap, uint32_t bigthresh,
+                              unsigned long long *large_list, unsigned int *large_n, uint32_t large_max, uint32_t large_tag, uint32_t *nbins_p, int pass)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbins) return;
+    uint64_t sl = q[i] - (uint64_t)nbins + (uint64_t)i;                            // max-scan value + i
+    const uint32_t st = binstart[i];
     const uint64_t key = skeys[st];
-    // single-read bins (the common case) carry the read id in `start`: one dependent load less on every hit
+    if (pass == 1) {
+        const uint64_t home = bucket_slot(key, cap) >> 2, last = (sl < cap ? sl : cap - 1) >> 2;
+        for (uint64_t b = home; b < last; b++) atomicOr(&slots[4 * b].count, SLOT_OVF);
+        if (sl < cap) return;
+    } else if (sl >= cap) return;
+    const uint32_t en = (i + 1 < nbins) ? binstart[i + 1] : n;
     const uint32_t cnt = en - st;
-    if (cnt > SLOT_CNT_MASK) { atomicAdd(const_cast<uint32_t *>(nbins_p) + 1, 1u); return; }     // does not fit the count field: the build fails loudly
+    if (cnt > SLOT_CNT_MASK) { atomicAdd(nbins_p + 1, 1u); return; }               // does not fit the count field: the build fails loudly
     const unsigned long long meta = cnt == 1 ? ((unsigned long long)sids[st] | ((unsigned long long)(1u | SLOT_EMB) << 32))
                                              : ((unsigned long long)st | ((unsigned long long)((cnt & SLOT_CNT_MASK) | ((bigthresh && cnt > bigthresh) ? SLOT_BIG : 0u)) << 32));
-    uint64_t sl = bucketed ? bucket_slot(key, cap) : __umul64hi(mix64(key), cap);   // bucketed: start at a 64-B bucket of 4 slots
-    for (;;) {
-        unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
-        if (atomicCAS(mp, 0ULL, meta) == 0ULL) {
-            slots[sl].key = key;
-            if (large_list && cnt > HARC_LARGEBIN) {              // remembered for k_compact_bins: (slot index, dictionary)
-                const unsigned int at = atomicAdd(large_n, 1u);
-                if (at < large_max) large_list[at] = ((unsigned long long)sl << 1) | large_tag;
-            }
-            return;
+    if (pass == 1) {
+        sl = 0;
+        for (;;) {
+            unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
+            if (atomicCAS(mp, 0ULL, meta) == 0ULL) break;
+            if ((sl & 3) == 3) atomicOr(&slots[sl - 3].count, SLOT_OVF);
+            if (++sl == cap) sl = 0;
         }
-        // leaving a bucket whose four slots are all taken: flag it, so that a search that finds a full bucket WITHOUT the flag can stop
-        if (bucketed && (sl & 3) == 3) atomicOr(&slots[sl - 3].count, SLOT_OVF);
-        if (++sl == cap) sl = 0;
+        slots[sl].key = key;
+        atomicOr(&slots[cap - 4].count, SLOT_OVF);                                // it left the last bucket
+    } else {
+        uint4 w; w.x = (uint32_t)key; w.y = (uint32_t)(key >> 32); w.z = (uint32_t)meta; w.w = (uint32_t)(meta >> 32);
+        *reinterpret_cast<uint4 *>(&slots[sl]) = w;
+    }
+    if (large_list && cnt > HARC_LARGEBIN) {                                      // remembered for k_compact_bins: (slot index, dictionary)
+        const unsigned int at = atomicAdd(large_n, 1u);
+        if (at < large_max) large_list[at] = ((unsigned long long)sl << 1) | large_tag;
     }
 }
 
@@ -298,7 +322,7 @@ __global__ void k_s1_bloom_set(const uint64_t *keys, uint32_t n, uint32_t *bloom
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t w, m;
-    bloom_pos(keys[i], nlines, nwin, mmask, &w, &m);
+    bloom_pos(keys[i], key_scramble(keys[i]), nlines, nwin, mmask, &w, &m);
     if ((bloom[w] & m) != m) atomicOr(&bloom[w], m);
 }
 
@@ -822,12 +846,13 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
                 // (many chains) two slots at a time -- the second pair is the same 64-B sector.  A full bucket ends the
                 // search unless its overflow flag says that keys went on to the next one.
                 // phase 1: every lane finishes its slot search (the dependent bucket fetches of all lanes overlap) ...
-                uint64_t sl = bucket_slot(key, cap);
+                const uint64_t hk = key_scramble(key);                    // what the table stores and compares
+                uint64_t sl = bucket_slot(hk, cap);
                 int state = 0, qhit = 0;                                  // 1 = the key is not in the table, 2 = key found
                 uint32_t sst = 0, cw = 0;
                 if (s.bloom_lines) {                                      // most keys of a step are in neither: they stop at the bitmap
                     uint32_t bw, bm;
-                    bloom_pos(key, s.bloom_lines, l ? s.bloom_nwin[1] : s.bloom_nwin[0], s.bloom_mmask, &bw, &bm);
+                    bloom_pos(key, hk, s.bloom_lines, s.bloom_nwin[0], s.bloom_mmask, &bw, &bm);      // both dictionaries have keys of the same width when nwin > 0
                     if (((l ? s.bloom[1] : s.bloom[0])[bw] & bm) != bm) state = 1;
                 }
                 if (state == 0) for (;;) {
@@ -845,7 +870,7 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
                                 if (state == 0) {
                                     np++;
                                     if (rawq[q].w == 0) state = 1;
-                                    else if (rawq[q].x == (uint32_t)key && rawq[q].y == (uint32_t)(key >> 32)) { state = 2; qhit = hp * NQ + q; sst = rawq[q].z; cw = rawq[q].w; }
+                                    else if (rawq[q].x == (uint32_t)hk && rawq[q].y == (uint32_t)(hk >> 32)) { state = 2; qhit = hp * NQ + q; sst = rawq[q].z; cw = rawq[q].w; }
                                 }
                             }
                         }
@@ -1281,19 +1306,32 @@ int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n, uint64_t cap_like)
 }
 int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, uint32_t n, unsigned kbits)
 {
+    (void)kbits;                                                  // the scrambled keys use all 64 bits
     if (n == 0) return HARC_AMD_OK;
     const harc_mark_t mk = harc_pool_mark(c);
     uint64_t *k1 = nullptr; uint32_t *h0 = nullptr, *b0 = nullptr, *bs = nullptr;
     RC_TRY(dalloc(c, &k1, n)); RC_TRY(dalloc(c, &h0, n)); RC_TRY(dalloc(c, &b0, n)); RC_TRY(dalloc(c, &bs, n));
     const unsigned g = (n + 255) / 256;
     HIP_TRY(hipMemsetAsync(d->d_nbins, 0, 8, c->stream));
-    RC_TRY(prim_sort_pairs_u64_u32(c, keys, k1, ids, d->ids, n, kbits));        // stable: ids ascending inside a bin (reorder.cpp:372-384)
+    hipLaunchKernelGGL(k_scramble_keys, dim3(g), dim3(256), 0, c->stream, keys, n);
+    RC_TRY(prim_sort_pairs_u64_u32(c, keys, k1, ids, d->ids, n, 64));           // stable: ids ascending inside a bin (reorder.cpp:372-384)
     hipLaunchKernelGGL(k_mark_heads, dim3(g), dim3(256), 0, c->stream, k1, n, h0);
     RC_TRY(prim_excl_scan_u32(c, h0, b0, n));
     hipLaunchKernelGGL(k_bin_starts, dim3(g), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins);
     HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
-    hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, c->stream, k1, d->ids, bs, d->d_nbins, n, d->slots, d->cap, d->bucketed ? 1 : 0, d->bigthresh,
-                       d->large_list, d->large_n, d->large_max, d->large_tag);
+    uint32_t nbins = 0;
+    HIP_TRY(hipMemcpyAsync(&nbins, d->d_nbins, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        uint64_t *v = keys, *q = nullptr;                          // the unsorted keys are not needed any more
+        RC_TRY(dalloc(c, &q, (size_t)nbins + 1));
+        const unsigned gb = (nbins + 255) / 256;
+        hipLaunchKernelGGL(k_place_keys, dim3(gb), dim3(256), 0, c->stream, (const uint64_t *)k1, (const uint32_t *)bs, nbins, d->cap, v);
+        RC_TRY(prim_incl_max_u64(c, v, q, nbins));
+        for (int pass = 0; pass < 2; pass++)
+            hipLaunchKernelGGL(k_table_place, dim3(gb), dim3(256), 0, c->stream, (const uint64_t *)k1, (const uint32_t *)d->ids, (const uint32_t *)bs, nbins, n, (const uint64_t *)q,
+                               d->slots, d->cap, d->bigthresh, d->large_list, d->large_n, d->large_max, d->large_tag, d->d_nbins, pass);
+    }
     HIP_TRY(hipGetLastError());
     uint32_t nb2[2] = { 0, 0 };
     HIP_TRY(hipMemcpyAsync(nb2, d->d_nbins, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1409,7 +1447,6 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const uint32_t maxlarge = 2 * (N / HARC_LARGEBIN) + 16;
     if (N) {
         RC_TRY(harc_dict_alloc(c, &dict[0], N, 0)); RC_TRY(harc_dict_alloc(c, &dict[1], N, dict[0].cap));
-        dict[0].bucketed = dict[1].bucketed = true;
         RC_TRY(dalloc(c, &d_large, maxlarge)); RC_TRY(dalloc(c, &d_nlarge, 4));
         HIP_TRY(hipMemsetAsync(d_nlarge, 0, 16, c->stream));
         for (int l = 0; l < 2; l++) { dict[l].large_list = d_large; dict[l].large_n = d_nlarge; dict[l].large_max = maxlarge; dict[l].large_tag = (uint32_t)l; }
@@ -1421,7 +1458,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             for (int l = 0; l < 2; l++) {
                 RC_TRY(dalloc(c, &d_bloom[l], (size_t)bloom_lines * 16)); HIP_TRY(hipMemsetAsync(d_bloom[l], 0, (size_t)bloom_lines * 64, c->stream));
                 const int nb = P.dict_end[l] - P.dict_start[l] + 1;                   // bases per key
-                bloom_nwin[l] = (bloom_m > 0 && nb > bloom_m && (size_t)bloom_lines * 64 >= bloom_mz_bytes) ? nb - bloom_m + 1 : 0;
+                const bool same = P.dict_end[0] - P.dict_start[0] == P.dict_end[1] - P.dict_start[1];     // k_steps takes one window count for both
+                bloom_nwin[l] = (same && bloom_m > 0 && nb > bloom_m && (size_t)bloom_lines * 64 >= bloom_mz_bytes) ? nb - bloom_m + 1 : 0;
             }
         }
         const harc_mark_t mk = harc_pool_mark(c);

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void k_consensus(S2Args s, const uint32_t *cid
 // exact key -> (start,count) lookup in a bucketed table (64 B = 4 slots, overflow flag in slot 0: see k_table_insert); two slots at a time
 __device__ __forceinline__ bool dict_lookup_b(const HashSlot *tab, uint64_t cap, uint64_t key, uint32_t *start, uint32_t *count)
 {
+    key = key_scramble(key);                                      // what the table stores (harc_dict_build)
     uint64_t sl = bucket_slot(key, cap);
     for (;;) {
         const uint4 r0 = *reinterpret_cast<const uint4 *>(&tab[sl]), r1 = *reinterpret_cast<const uint4 *>(&tab[sl + 1]);
@@ -818,7 +819,6 @@ int stage2_run(harc_amd_ctx *c)
         // probes into bins of more than 32 candidates are recorded and scanned by a wave each (k_realign_big: 64 candidates per round trip)
         // instead of lane-serially inside k_realign_propose; above maxsearch that pass is also where the sliding window is exact
         dict[0].bigthresh = dict[1].bigthresh = (uint32_t)P.maxsearch < 32u ? (uint32_t)P.maxsearch : 32u;
-        dict[0].bucketed = dict[1].bucketed = true;
         int lb = 16; while (lb < 36 && (1ULL << lb) < (unsigned long long)bloom_per_key * T) lb++;
         if (bloom4) {   // 4-bit entries, 16 per key and two of them set: ~1.5 % of absent k-mers pass per plane
             RC_TRY(dalloc(c, &bloom[0], ((size_t)1 << (lb - 3)) + 1));
