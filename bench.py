@@ -356,6 +356,14 @@ def main():
                 roofline["random_access"] = {"achieved": round(req, 2), "peak": ceil["G_requests_per_s"]["32B"], "unit": "G sector requests/s (L2 misses; 32-byte slot-pair and read fetches)",
                                              "frac": round(req / ceil["G_requests_per_s"]["32B"], 3), "l2_misses_per_launch": tr["tcc_miss"],
                                              "peak_source": "tools/micro/gups.hip, profiles/r02/gups.txt: independent random 32-B loads over 64 GiB"}
+            # ... and, once the bitmap in front of the tables keeps most probes away from them, instruction issue: vector instructions of
+            # the PMC pass x 4 cycles (one wave64 instruction on a 16-lane SIMD) over the SIMD cycles of the launch measured live
+            if tr.get("sq_insts_valu") and avg_ms > 0:
+                simd_cycles = 256 * 4 * 2.4e9 * avg_ms * 1e-3
+                roofline["issue"] = {"valu_insts_per_launch": tr["sq_insts_valu"], "salu_insts_per_launch": tr.get("sq_insts_salu"),
+                                     "valu_busy_frac": round(tr["sq_insts_valu"] * 4.0 / simd_cycles, 3),
+                                     "wave_cycles_waiting_frac": round(tr["sq_wait_any"] / max(1.0, tr["sq_wave_cycles"]), 3),
+                                     "note": "1024 SIMDs at 2.4 GHz peak clock (the launch runs at ~2.2 GHz: SQ_BUSY_CYCLES), full-rate instructions only: a lower bound of the busy fraction"}
     except Exception:
         pass
     out = {

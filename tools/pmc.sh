@@ -30,12 +30,13 @@ for line in open(sys.argv[1]):
     if "k_steps<" not in line: continue
     m = re.search(r"(\S+)\s+launches=(\d+)\s+avg_per_launch=([0-9.]+)", line)
     if m: vals[m.group(1)] = (int(m.group(2)), float(m.group(3)))
-out = {sys.argv[2]: {"profile": "profiles/pmc_%s_%s_summary.txt" % (sys.argv[2], sys.argv[3]),
+out = {sys.argv[2]: {"profile": "profiles/%s/pmc_%s_summary.txt" % (sys.argv[3], sys.argv[2]),
        "fetch_kb_per_launch": vals.get("FETCH_SIZE", (0, 0.0))[1], "write_kb_per_launch": vals.get("WRITE_SIZE", (0, 0.0))[1],
        "launches": vals.get("FETCH_SIZE", (0, 0.0))[0],
        "tcc_hit": vals.get("TCC_HIT_sum", (0, 0.0))[1], "tcc_miss": vals.get("TCC_MISS_sum", (0, 0.0))[1],
        "sq_wave_cycles": vals.get("SQ_WAVE_CYCLES", (0, 0.0))[1], "sq_wait_any": vals.get("SQ_WAIT_ANY", (0, 0.0))[1],
-       "sq_active_inst_any": vals.get("SQ_ACTIVE_INST_ANY", (0, 0.0))[1], "sq_waves": vals.get("SQ_WAVES", (0, 0.0))[1]}}
+       "sq_active_inst_any": vals.get("SQ_ACTIVE_INST_ANY", (0, 0.0))[1], "sq_waves": vals.get("SQ_WAVES", (0, 0.0))[1],
+       "sq_insts_valu": vals.get("SQ_INSTS_VALU", (0, 0.0))[1], "sq_insts_salu": vals.get("SQ_INSTS_SALU", (0, 0.0))[1], "sq_busy_cycles": vals.get("SQ_BUSY_CYCLES", (0, 0.0))[1]}}
 print(json.dumps(out, indent=1))
 PY
 grep -E "k_steps<|k_resolve|k_reseed" gpurun_out/$R/pmc_${W}_summary.txt
