@@ -34,6 +34,7 @@ struct S2Args {
     const HashSlot *slots[2]; uint64_t cap[2]; const uint32_t *ids[2];
     unsigned long long *best;          // T
     const uint32_t *bloom[2]; int bloom_shift[2];   // one-hash bitmap over the keys of each dictionary (16 bits per key): most windows match nothing
+    int bloom_lbits, bloom_nwin;                    // combined bitmap (k_bloom4_set): log2 of its 64-byte lines; minimizer windows per key (0: lines hashed from the key)
     const uint64_t *cons2;             // consensus, 2-bit code A0 G1 C2 T3, 32 columns per word (k_pack_cons2)
     const uint64_t *cand2, *candN;     // T x W: the candidates in the same 2-bit code (N -> 0) and their N masks (both bits of the field set)
     uint4 *events;                     // probes that hit a bin larger than maxsearch: {tuple lo, tuple hi, dict, slot index lo} (+ slot hi in w>>?)
@@ -151,41 +152,75 @@ __global__ void k_contig_info(S2Args s, unsigned long long *cinfo)
 }
 
 // buildcontig (encoder.cpp:619-652): column x <- first strict maximum over A,C,G,T of the reads covering it.
-// One thread per strip of 8 columns (one binary search per strip).  Byte written: base | 4 when a realignment window may
-// start at x (fits in its contig, encoder.cpp:252, and the contig is not the last of its shard).
+// A workgroup owns a tile of 2048 columns, a thread a strip of 8.  The reads are sorted by their first column, so the ones that touch
+// the tile are one contiguous range: they go through LDS in pieces of CCHUNK (one coalesced pass over the reads instead of every strip
+// fetching its ~13 reads through L2: 10x the bytes), and a strip finds its own reads in a piece by binary search over their
+// tile-relative starts.  Byte written: base | 4 when a realignment window may start at x (fits in its contig, encoder.cpp:252, and the
+// contig is not the last of its shard).
 #define CSTRIP 8
-__global__ __launch_bounds__(256) void k_consensus(S2Args s, const uint32_t *cid, const unsigned long long *cinfo, int want_windows)
+#define CTILE (256 * CSTRIP)
+#define CCHUNK 512
+// first and last read that touch tile t (a binary search per tile here, not two dependent ones at the top of every workgroup)
+__global__ void k_consensus_tiles(S2Args s, uint32_t ntiles, uint32_t *tlo, uint32_t *thi)
 {
-    const uint64_t x0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * CSTRIP;
-    if (x0 >= s.total) return;
-    const int L = s.L;
-    const uint64_t xl = (x0 + CSTRIP - 1 < s.total ? x0 + CSTRIP - 1 : s.total - 1);        // last column of the strip
-    const long long ihi = ub_le(s.gstart, (long long)s.M, xl);                                // last read starting at or before it
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint64_t X0 = (uint64_t)t * CTILE, X1 = X0 + CTILE < s.total ? X0 + CTILE : s.total;
+    thi[t] = (uint32_t)ub_le(s.gstart, (long long)s.M, X1 - 1);             // last read starting inside or before the tile (every column is covered: >= 0)
+    tlo[t] = X0 >= (uint64_t)s.L ? (uint32_t)(ub_le(s.gstart, (long long)s.M, X0 - (uint64_t)s.L) + 1) : 0u;   // first read that reaches column X0
+}
+__global__ __launch_bounds__(256) void k_consensus(S2Args s, const uint32_t *cid, const unsigned long long *cinfo, int want_windows, const uint32_t *tlo, const uint32_t *thi)
+{
+    extern __shared__ uint64_t cl_words[];                        // [CCHUNK][W] read words, then CCHUNK tile-relative starts
+    int *const cl_g = reinterpret_cast<int *>(cl_words + (size_t)CCHUNK * s.W);
+    const uint64_t X0 = (uint64_t)blockIdx.x * CTILE;
+    const int L = s.L, W = s.W;
+    const long long ilo = tlo[blockIdx.x], ihi = thi[blockIdx.x];
+    const int x0r = (int)threadIdx.x * CSTRIP;                   // tile-relative first column of the strip
+    const uint64_t x0 = X0 + (uint64_t)x0r;
+    const bool mine = x0 < s.total;
+    const int xlr = (x0 + CSTRIP - 1 < s.total ? x0r + CSTRIP - 1 : (int)(s.total - 1 - X0));   // last column of the strip
     uint32_t cnt[CSTRIP][4];
 #pragma unroll
     for (int c = 0; c < CSTRIP; c++) { cnt[c][0] = cnt[c][1] = cnt[c][2] = cnt[c][3] = 0; }
-    // every read overlapping the strip is visited once and feeds all the columns it covers (its 2-bit words are loaded once)
-    for (long long ii = ihi; ii >= 0; ii--) {
-        const uint64_t g = s.gstart[ii];
-        if (g + (uint64_t)L <= x0) break;                         // sorted by gstart: nothing further left reaches the strip
-        const uint64_t *r = s.oreads + (size_t)ii * s.W;
-        const long long o0 = (long long)x0 - (long long)g;        // offset of column x0 inside the read (may be negative)
-        const int j0 = o0 < 0 ? 0 : (int)o0;
-        const int w0 = j0 >> 5;
-        const uint64_t wa = r[w0], wb = (w0 + 1 < s.W) ? r[w0 + 1] : 0;
+    long long ilast = ilo - 1;                                    // last read starting at or before x0
+    for (long long base = ilo; base <= ihi; base += CCHUNK) {
+        const int nch = (int)(ihi + 1 - base < CCHUNK ? ihi + 1 - base : CCHUNK);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nch * W; k += 256) cl_words[k] = s.oreads[(size_t)base * W + k];
+        for (int k = threadIdx.x; k < nch; k += 256) cl_g[k] = (int)((long long)s.gstart[base + k] - (long long)X0);
+        __syncthreads();
+        if (!mine) continue;
+        // reads of the piece that cover a column of the strip: start in (x0r - L, xlr]
+        int lo = -1, hi = nch;                                    // cl_g[lo] <= x0r - L < cl_g[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cl_g[mid] <= x0r - L) lo = mid; else hi = mid; }
+        const int first = hi;
+        lo = first - 1; hi = nch;                                 // cl_g[lo] <= xlr < cl_g[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cl_g[mid] <= xlr) lo = mid; else hi = mid; }
+        const int last = lo;
+        for (int k = first; k <= last; k++) {
+            const int g = cl_g[k];
+            if (g <= x0r) ilast = base + k;
+            const uint64_t *r = cl_words + (size_t)k * W;
+            const int o0 = x0r - g;                               // offset of column x0 inside the read (may be negative)
+            const int j0 = o0 < 0 ? 0 : o0;
+            const int w0 = j0 >> 5;
+            const uint64_t wa = r[w0], wb = (w0 + 1 < W) ? r[w0 + 1] : 0;
 #pragma unroll
-        for (int c = 0; c < CSTRIP; c++) {
-            const long long o = o0 + c;
-            if (o >= 0 && o < L && x0 + c <= xl) {
-                const int j = (int)o, wj = j >> 5;
-                const uint64_t word = wj == w0 ? wa : wb;
-                const int v = pc_to_idx((int)((word >> (2 * (j & 31))) & 3));
-                cnt[c][0] += (v == 0); cnt[c][1] += (v == 1); cnt[c][2] += (v == 2); cnt[c][3] += (v == 3);
+            for (int c = 0; c < CSTRIP; c++) {
+                const int o = o0 + c;
+                if (o >= 0 && o < L && x0r + c <= xlr) {
+                    const int wj = o >> 5;
+                    const uint64_t word = wj == w0 ? wa : wb;
+                    const int v = pc_to_idx((int)((word >> (2 * (o & 31))) & 3));
+                    cnt[c][0] += (v == 0); cnt[c][1] += (v == 1); cnt[c][2] += (v == 2); cnt[c][3] += (v == 3);
+                }
             }
         }
     }
+    if (!mine) return;
     uint32_t kprev = HARC_NONE; unsigned long long cend = 0; bool lastc = true;
-    long long i = ub_le(s.gstart, (long long)s.M, x0);
+    long long i = ilast;
     uint8_t outb[CSTRIP];
 #pragma unroll
     for (int c = 0; c < CSTRIP; c++) {
@@ -253,21 +288,41 @@ __device__ __forceinline__ uint64_t rc_key3(uint64_t key, int n)
     for (int i = 0; i < n; i++) r |= (uint64_t)(6 - (int)((key >> (3 * (n - 1 - i))) & 7)) << (3 * i);   // A0 <-> T6, G2 <-> C4 (N 1 -> 5: matches nothing)
     return r;
 }
-__device__ __forceinline__ void bloom4_pos(uint64_t key, int shift, uint64_t *word, int *sh0, int *sh1)
+// The 64-byte line of a key: by its minimizer (the 15-mer inside it with the smallest hash) when nwin > 0 -- consecutive k-mers of the
+// consensus share it, and k_realign_propose1 looks up 3.6 G consecutive k-mers at configs[2] -- else hashed from the key.  (A 10-mer
+// minimizer compared as it is: every value occurs hundreds of times in a genome, the lines of a 26x data set were saturated.)  Word and
+// the two 4-bit entries inside the line come from a hash of the whole key.
+#define BLOOM4_M 15
+__device__ __forceinline__ uint32_t bloom4_mmer(uint64_t key)
 {
-    const uint64_t h = mix64(key ^ 0x9E3779B97F4A7C15ULL);
-    const uint64_t b = h >> shift;
-    *word = b >> 3; *sh0 = 4 * (int)(b & 7); *sh1 = 4 * (int)(h & 7);
+    uint32_t h = ((uint32_t)key * 0x9E3779B1u) ^ (((uint32_t)(key >> 32) & 0x1FFFu) * 0x85EBCA77u);      // the low 45 bits: 15 bases
+    return h ^ (h >> 15);
 }
-__global__ void k_bloom4_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, int shift, int l, int nb)
+__device__ __forceinline__ uint32_t bloom4_minimizer(uint64_t key, int nwin)
+{
+    uint32_t best = 0xFFFFFFFFu;
+    for (int i = 0; i < nwin; i++) { const uint32_t x = bloom4_mmer(key >> (3 * i)); best = x < best ? x : best; }
+    return best;
+}
+__device__ __forceinline__ void bloom4_pos(uint64_t key, uint32_t minz, int nwin, int lbits, uint32_t *word, int *sh0, int *sh1)
+{
+    uint32_t kh = ((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) * 0x85EBCA77u);
+    kh ^= kh >> 15; kh *= 0xC2B2AE3Du; kh ^= kh >> 13;
+    uint32_t lh = nwin > 0 ? minz * 0x9E3779B1u : kh * 0x165667B1u;
+    lh ^= lh >> 15; lh *= 0x85EBCA77u; lh ^= lh >> 13;
+    *word = ((lh >> (32 - lbits)) << 4) | ((kh >> 6) & 15u);
+    *sh0 = 4 * (int)(kh & 7u); *sh1 = 4 * (int)((kh >> 3) & 7u);
+}
+__global__ void k_bloom4_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, int lbits, int nwin, int l, int nb)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = keys[i];
-    uint64_t w; int a, b;
-    bloom4_pos(k, shift, &w, &a, &b);
+    uint32_t w; int a, b;
+    bloom4_pos(k, bloom4_minimizer(k, nwin), nwin, lbits, &w, &a, &b);
     atomicOr(&bloom[w], ((1u << l) << a) | ((1u << l) << b));
-    bloom4_pos(rc_key3(k, nb), shift, &w, &a, &b);
+    const uint64_t r = rc_key3(k, nb);
+    bloom4_pos(r, bloom4_minimizer(r, nwin), nwin, lbits, &w, &a, &b);
     atomicOr(&bloom[w], ((4u << l) << a) | ((4u << l) << b));
 }
 // candidates in the reads' 2-bit code + N mask (3-bit code A0 N1 G2 C4 T6: code = c3 >> 1, N = c3 & 1); one thread per (read, word)
@@ -358,7 +413,7 @@ template <int W> __device__ __forceinline__ void realign_hit1(const S2Args &s, c
     else for (int b = 0; b < n; b++) key |= (uint64_t)idx_to_c3(tile[tc + b] & 3) << (3 * b);
     realign_probe<W>(s, x, dir, l, key);
 }
-template <int W> __global__ __launch_bounds__(256) void k_realign_propose1(S2Args s)
+template <int W, int NWIN> __global__ __launch_bounds__(256) void k_realign_propose1(S2Args s)
 {
     __shared__ uint32_t tile32[(RTILE + 64 + 8) / 4];
     __shared__ uint16_t queue[RQCAP];
@@ -366,7 +421,7 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose1(S2Arg
     uint8_t *tile = reinterpret_cast<uint8_t *>(tile32);
     const uint64_t X0 = (uint64_t)blockIdx.x * RTILE;
     const int n = s.de[0] - s.ds[0] + 1;
-    const int ntile = RTILE + n + 1;
+    const int ntile = RTILE + n + NWIN + 1;
     for (int d = threadIdx.x; d < (ntile + 3) / 4; d += 256) {
         const uint64_t g = X0 + 4ull * d;
         uint32_t v = 0;
@@ -379,16 +434,29 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose1(S2Arg
     const int t0 = threadIdx.x * RSTRIP;
     uint64_t k = 0;
     for (int b = 0; b < n; b++) k |= (uint64_t)idx_to_c3(tile[t0 + b] & 3) << (3 * b);
-    const uint32_t *bloom = s.bloom[0]; const int shift = s.bloom_shift[0];
+    const uint32_t *bloom = s.bloom[0]; const int lbits = s.bloom_lbits;
+    // the keys of the strip; with minimizers also the m-mers at the NWIN - 1 positions behind it (the m-mer at p is the low end of key p)
+    constexpr int NK = RSTRIP + (NWIN > 0 ? NWIN - 1 : 0);
+    uint64_t keys[RSTRIP]; uint32_t mm[NK];
+#pragma unroll
+    for (int c = 0; c < NK; c++) {
+        if (c < RSTRIP) keys[c] = k;
+        mm[c] = bloom4_mmer(k);
+        k = (k >> 3) | ((uint64_t)idx_to_c3(tile[t0 + c + n] & 3) << (3 * (n - 1)));
+    }
     // the 8 bitmap words (independent loads)
     uint32_t hit = 0;
 #pragma unroll
-    for (int c = 0; c < RSTRIP && X0 + t0 + c < s.total; c++) {
-        uint64_t w; int a, b;
-        bloom4_pos(k, shift, &w, &a, &b);
-        const uint32_t v = bloom[w];
-        hit |= ((v >> a) & (v >> b) & 15u) << (4 * c);
-        k = (k >> 3) | ((uint64_t)idx_to_c3(tile[t0 + c + n] & 3) << (3 * (n - 1)));
+    for (int c = 0; c < RSTRIP; c++) {
+        if (X0 + t0 + c < s.total) {
+            uint32_t mz = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < NWIN; i++) mz = mm[c + i] < mz ? mm[c + i] : mz;
+            uint32_t w; int a, b;
+            bloom4_pos(keys[c], mz, NWIN, lbits, &w, &a, &b);
+            const uint32_t v = bloom[w];
+            hit |= ((v >> a) & (v >> b) & 15u) << (4 * c);
+        }
     }
     // the rare hits go through a queue in LDS and are worked off one per lane (inline, a wave would wait for its unluckiest lane's
     // chain of dependent loads while the other 63 idle)
@@ -824,6 +892,8 @@ int stage2_run(harc_amd_ctx *c)
             RC_TRY(dalloc(c, &bloom[0], ((size_t)1 << (lb - 3)) + 1));
             HIP_TRY(hipMemsetAsync(bloom[0], 0, ((size_t)1 << (lb - 3)) * 4, c->stream));
             bloom[1] = bloom[0]; bloom_shift[0] = bloom_shift[1] = 64 - lb;
+            a.bloom_lbits = lb - 7;                                            // 128 entries to a 64-byte line
+            a.bloom_nwin = (a.kbits[0] / 3 == 21 && !getenv("HARC_AMD_BLOOM4_HASHED")) ? 21 - BLOOM4_M + 1 : 0;    // lines by minimizer (read lengths above 50)
         } else for (int l = 0; l < 2; l++) {                                    // one bit per key and dictionary: ~6 % pass
             RC_TRY(dalloc(c, &bloom[l], ((size_t)1 << (lb - 5)) + 1));
             HIP_TRY(hipMemsetAsync(bloom[l], 0, ((size_t)1 << (lb - 5)) * 4, c->stream));
@@ -834,7 +904,7 @@ int stage2_run(harc_amd_ctx *c)
         RC_TRY(dalloc(c, &k0, T)); RC_TRY(dalloc(c, &i0, T));
         for (int l = 0; l < 2; l++) {
             hipLaunchKernelGGL(k_key3, G256(T), cand3, T, W3, 3 * a.ds[l], a.kbits[l], k0, i0);
-            if (bloom4) hipLaunchKernelGGL(k_bloom4_set, G256(T), (const uint64_t *)k0, T, bloom[0], bloom_shift[0], l, a.kbits[l] / 3);
+            if (bloom4) hipLaunchKernelGGL(k_bloom4_set, G256(T), (const uint64_t *)k0, T, bloom[0], a.bloom_lbits, a.bloom_nwin, l, a.kbits[l] / 3);
             else hipLaunchKernelGGL(k_bloom_set, G256(T), (const uint64_t *)k0, T, bloom[l], bloom_shift[l]);
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, T, (unsigned)a.kbits[l]));
             hipLaunchKernelGGL(k_count_big_bins, G256(dict[l].cap), dict[l].slots, dict[l].cap, (uint32_t)P.maxsearch, d_big);
@@ -879,12 +949,17 @@ int stage2_run(harc_amd_ctx *c)
     if (total) {
         unsigned long long *cinfo = nullptr; RC_TRY(dalloc(c, &cinfo, (size_t)nC + 1));
         hipLaunchKernelGGL(k_contig_info, G256(nC), a, cinfo);
-        hipLaunchKernelGGL(k_consensus, G256((total + CSTRIP - 1) / CSTRIP), a, (const uint32_t *)u1, (const unsigned long long *)cinfo, T ? 1 : 0);
+        const uint32_t ntiles = (uint32_t)((total + CTILE - 1) / CTILE);
+        uint32_t *tlo = nullptr, *thi = nullptr; RC_TRY(dalloc(c, &tlo, (size_t)ntiles + 1)); RC_TRY(dalloc(c, &thi, (size_t)ntiles + 1));
+        hipLaunchKernelGGL(k_consensus_tiles, G256(ntiles), a, ntiles, tlo, thi);
+        hipLaunchKernelGGL(k_consensus, dim3(ntiles), dim3(256), (size_t)CCHUNK * (W * 8 + 4), c->stream, a, (const uint32_t *)u1, (const unsigned long long *)cinfo, T ? 1 : 0,
+                           (const uint32_t *)tlo, (const uint32_t *)thi);
         hipLaunchKernelGGL(k_pack_cons2, G256(ncw), (const uint8_t *)a.cons, total, ncw, cons2);
         if (T) {
             const dim3 rg((unsigned)((total + RTILE - 1) / RTILE));
             switch (W) {
-#define REALIGN_CASE(WW) case WW: if (bloom4) hipLaunchKernelGGL((k_realign_propose1<WW>), rg, dim3(256), 0, c->stream, a); \
+#define REALIGN_CASE(WW) case WW: if (bloom4 && a.bloom_nwin) hipLaunchKernelGGL((k_realign_propose1<WW, 21 - BLOOM4_M + 1>), rg, dim3(256), 0, c->stream, a); \
+                                 else if (bloom4) hipLaunchKernelGGL((k_realign_propose1<WW, 0>), rg, dim3(256), 0, c->stream, a); \
                                  else hipLaunchKernelGGL((k_realign_propose<WW>), rg, dim3(256), 0, c->stream, a); break;
                 REALIGN_CASE(1) REALIGN_CASE(2) REALIGN_CASE(3) REALIGN_CASE(4) REALIGN_CASE(5) REALIGN_CASE(6) REALIGN_CASE(7) REALIGN_CASE(8)
 #undef REALIGN_CASE
@@ -899,7 +974,8 @@ int stage2_run(harc_amd_ctx *c)
                 RC_TRY(dalloc(c, &a.events, (size_t)a.maxevents));
                 HIP_TRY(hipMemsetAsync(a.nevents, 0, 16, c->stream));
                 switch (W) {
-#define REALIGN_CASE(WW) case WW: if (bloom4) hipLaunchKernelGGL((k_realign_propose1<WW>), rg, dim3(256), 0, c->stream, a); \
+#define REALIGN_CASE(WW) case WW: if (bloom4 && a.bloom_nwin) hipLaunchKernelGGL((k_realign_propose1<WW, 21 - BLOOM4_M + 1>), rg, dim3(256), 0, c->stream, a); \
+                                 else if (bloom4) hipLaunchKernelGGL((k_realign_propose1<WW, 0>), rg, dim3(256), 0, c->stream, a); \
                                  else hipLaunchKernelGGL((k_realign_propose<WW>), rg, dim3(256), 0, c->stream, a); break;
                     REALIGN_CASE(1) REALIGN_CASE(2) REALIGN_CASE(3) REALIGN_CASE(4) REALIGN_CASE(5) REALIGN_CASE(6) REALIGN_CASE(7) REALIGN_CASE(8)
 #undef REALIGN_CASE
