@@ -20,6 +20,7 @@ struct S1Args {
     HashSlot *slots[2];
     uint64_t cap[2];
     const uint32_t *ids[2];
+    int w0mul, w0add;                // first batch of a step: w0mul * (priority index of the chain's previous hit) + w0add probes, rounded up to 16
     int firstmax[2];                 // widths of the first two probe batches of a step when many chains are in flight
     const uint32_t *bloom[2]; uint32_t bloom_lines; int bloom_nwin[2]; uint32_t bloom_mmask;   // bitmap over the keys of each dictionary (bloom_pos), 0 lines = none
     const uint2 *largetab;           // bins of more than HARC_LARGEBIN reads (SLOT_BIG; their slot's `start` indexes this table): x = first index into ids[], y = first row of `mirror`
@@ -801,7 +802,7 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
     uint32_t dbg_bins = 0, dbg_iter = 0, dbg_miss = 0, dbg_surv = 0, dbg_batches = 0;   // coop scans / their 64-entry chunks / steps without a hit / (unused) / batches
     uint32_t np = 0, nc = 0, nuse = 0, ncu = 0;                   // ncu: candidates a strictly sequential scan (reorder.cpp:517-649) would have tested too
     int nst = 0; bool needseed = false, defer = false;
-    int lastp = (int)(h.pad0 & 0xFFFF);                          // priority index of this chain's previous hit
+    int lastp = (int)(h.pad0 & 0xFFFF);                          // 16 x running mean (weight 1/4) of the priority index of this chain's hits
     int spos = (int)((h.nsteps >> 16) & 0xFF); const int nsugg = (int)(h.nsteps >> 24);   // look-ahead seeds: next to try / held
     int bigprobes = 0;                                           // COOP: probes into large live bins made by this walk so far
     for (int t = T0; t < s.S; t++) {
@@ -811,17 +812,16 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
         // every extra batch is a serial round trip to HBM.
         int base = 0;
         for (int bi = 0; base < s.nprobe; bi++) {
-            // first batch: twice the priority index of the chain's previous hit (high coverage -> hits at small shifts -> narrow first
-            // batch), at most firstmax probes; every later batch is a full wave.  With many chains the kernel runs close to the random-access
-            // ceiling of the memory system (tools/micro/gups.hip: 26 G 32-byte requests/s beyond 16 GiB), so speculative probes cost
-            // throughput: without the bitmap in front of the tables the best width of the first two batches was 32; with it a
-            // speculative probe is a 4-byte bitmap lookup and 48 is better (configs[2]: chains 768 -> 728 ms); once the bitmap's lines go by
-            // minimizer (bloom_pos) the speculative probes share the lines of the useful ones: 64 (-> 660 ms).  With few chains a round
-            // trip costs more than the probes (QUAD: 64).
+            // first batch: twice the running mean of the priority index of the chain's hits + 16 (high coverage -> hits at small shifts ->
+            // narrow first batch; the mean, not the last hit: where reads start is Poisson, the last hit says little about the next),
+            // at most firstmax probes; every later batch is a full wave.  A probe behind the winner is speculation: without the bitmap in
+            // front of the tables it cost a table fetch at the random-access ceiling and 32 was the best cap; with the bitmap it costs a
+            // 4-byte lookup (48: configs[2] chains 768 -> 728 ms); with the bitmap's lines chosen by minimizer it shares the lines of the
+            // useful probes (64).  With few chains a round trip costs more than the probes (QUAD: 64).
             // s.nbatch > 0 (HARC_AMD_BATCHES) overrides with a fixed schedule.
             int bend;
             if (s.nbatch > 0) bend = s.batch_end[bi < s.nbatch ? bi : s.nbatch - 1];
-            else { int w0 = bi == 0 ? ((2 * lastp + 16 + 15) & ~15) : 64; const int wmax = QUAD ? 64 : (bi == 0 ? s.firstmax[0] : bi == 1 ? s.firstmax[1] : 64); if (w0 > wmax) w0 = wmax; bend = base + w0; }
+            else { int w0 = bi == 0 ? ((s.w0mul * (lastp >> 4) + s.w0add + 15) & ~15) : 64; const int wmax = QUAD ? 64 : (bi == 0 ? s.firstmax[0] : bi == 1 ? s.firstmax[1] : 64); if (w0 > wmax) w0 = wmax; bend = base + w0; }
             if (bend > s.nprobe) bend = s.nprobe;
             if (bend <= base) bend = s.nprobe;
             const int p = base + lane; dbg_batches++;
@@ -969,7 +969,7 @@ template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 
             if (lane <= winlane) ncu += ncb;                              // lanes behind the winner were speculation (winlane = 64: no hit, all count)
             if (found != HARC_NONE) {
                 nuse += (uint32_t)(base + winlane + 1);
-                lastp = base + winlane;
+                lastp += 4 * (base + winlane) - (lastp >> 2);
                 break;
             }
             base = bend;
@@ -1536,7 +1536,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     a.nbatch = 0;                                                // adaptive batches (k_steps) unless a fixed schedule is forced
     a.firstmax[0] = a.firstmax[1] = (bloom_nwin[0] > 0 && bloom_nwin[1] > 0) ? 64 : 48;     // lines by minimizer: speculative probes share their lines
     if (const char *e = getenv("HARC_AMD_FIRSTMAX")) { int x = 32, y = 32; if (sscanf(e, "%d,%d", &x, &y) >= 1) { a.firstmax[0] = x < 1 ? 1 : x > 64 ? 64 : x; a.firstmax[1] = y < 1 ? 1 : y > 64 ? 64 : y; } }
-    if (const char *e = getenv("HARC_AMD_BATCHES")) {             // tuning knob, e.g. "32,64"; the last size repeats
+    a.w0mul = 2; a.w0add = 16;
+    if (const char *e = getenv("HARC_AMD_W0")) sscanf(e, "%d,%d", &a.w0mul, &a.w0add);
+    if (const char *e = getenv("HARC_AMD_BATCHES")) {                            // tuning knob, e.g. "32,64"; the last size repeats
         int sizes[12], k = 0, last = 64; const char *q = e;
         while (*q && k < 12) { int v = atoi(q); if (v < 1) v = 1; if (v > 64) v = 64; sizes[k++] = last = v; while (*q && *q != ',') q++; if (*q == ',') q++; }
         for (; k < 12; k++) sizes[k] = last;

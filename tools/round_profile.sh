@@ -18,3 +18,11 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], d['value'], d['ms_per_step'], d['phases_ms_last_step'], d['roundtrip']['ok'], d['roofline'].get('random_access', {}).get('frac'))
 PY
 done
+# the two full-size configurations (one GPU): configs[3] and configs[4] at 1/16
+python bench.py --workload c4 --steps 2 --warmup 1 --no-cpu > gpurun_out/$R/bench_c4_full.json 2> /dev/null
+python bench.py --workload c5s --steps 2 --warmup 1 --no-cpu > gpurun_out/$R/bench_c5s_full.json 2> /dev/null
+for f in gpurun_out/$R/bench_c4_full.json gpurun_out/$R/bench_c5s_full.json; do python - "$f" <<PY
+import json,sys
+d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], d['value'], d['ms_per_step'], d['phases_ms_last_step'], d['roundtrip']['ok'])
+PY
+done
