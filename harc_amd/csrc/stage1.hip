@@ -460,8 +460,11 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
 //  (3) lane 0 records the step and bids for the read with atomicMin(step<<20 | chain); the counts are updated in registers.
 // The kernel is bound by instruction issue at large K (PMC: 85 % of the SIMD issue slots, profiles/r02) and by dependent HBM round
 // trips at small K: both want few instructions per step.
+// Waves per SIMD of the main kernel (launch bound -> register budget).  5 (96 VGPRs, 9 dwords of scratch) unless the launch is at least
+// eight full rounds of waves long (DENSE: K >= 49152 chains): there one more wave hides more latency than its spills cost (80 VGPRs;
+// configs[2] -3.4 %, 150-bp reads -5.5 %), while at 24 k chains the same build was 9 % slower.  Reads of more than 128 bases: one less.
 #ifndef HARC_STEPS_WAVES
-#define HARC_STEPS_WAVES 5       // many chains: 5 waves / SIMD (96 VGPRs, 16 dwords of scratch): +5 % over 4 waves, 6 waves spill too much; reads of more than 128 bases: 4
+#define HARC_STEPS_WAVES 5
 #endif
 #ifndef HARC_STEPS_WAVES_Q
 #define HARC_STEPS_WAVES_Q 3     // few chains (whole-bucket fetch): never more than ~3 waves / SIMD anyway
@@ -687,7 +690,7 @@ template <int W> __global__ void k_steps_tables(S1Args s, uint32_t *out)
     }
 }
 
-template <int W, bool QUAD, bool COOP> __global__ __launch_bounds__(256, COOP ? 2 : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1))) void k_steps(S1Args s)
+template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_bounds__(256, COOP ? 2 : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? 1 : 0))) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
     extern __shared__ uint32_t lds[];
@@ -1565,6 +1568,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // ---- rounds
     const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe);
     const bool prof = P.profile != 0;
+    const bool dense = getenv("HARC_AMD_DENSE") ? atoi(getenv("HARC_AMD_DENSE")) != 0 : K >= 49152;     // see HARC_STEPS_WAVES
     uint64_t rounds = 0, launches = 0;
     const int batch = getenv("HARC_AMD_BATCHSYNC") ? atoi(getenv("HARC_AMD_BATCHSYNC")) : 8;
     for (;;) {
@@ -1572,6 +1576,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             hipEvent_t *pair = nullptr;
             if (prof) { RC_TRY(R.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }
             if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
+            else if (dense) hipLaunchKernelGGL((k_steps<W, false, false, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             else hipLaunchKernelGGL((k_steps<W, false, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             if (prof) HIP_TRY(hipEventRecord(pair[1], c->stream));
             // the steps that have to scan a large bin (none without such bins: the launch is skipped)
