@@ -213,6 +213,27 @@ def test_low_complexity_big_bins_match_oracle(n, glen, K, S, E, err, oracle, tmp
     assert sorted(ol.read_dir(base)["output.dna"].split()) == sorted(txt.split())
 
 
+@pytest.mark.parametrize("env", [{"HARC_AMD_QUAD": "0"}, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1"},
+                                 {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_S1BLOOM_MZMB": "0"}, {"HARC_AMD_S1BLOOM_MZMB": "0"},
+                                 {"HARC_AMD_S1BLOOM": "0"}, {"HARC_AMD_BLOOM4_HASHED": "1"}, {"HARC_AMD_BLOOM1": "1"}, {"HARC_AMD_CAPMULT": "2"}])
+def test_kernel_variants_same_bytes(env, oracle, tmp_path, monkeypatch):
+    """the variants the library picks by problem size (two-slot vs whole-bucket fetches, 5 vs 6 waves per SIMD, bitmap lines hashed vs by
+    minimizer, with / without the bitmaps, stage-II bitmap kinds, a fuller table) are execution details: forced on a small repeat-rich
+    input, every stage-I and stage-II file is the oracle's"""
+    import harc_amd
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    txt = gen.reads_text_lowcomplexity(99, 20000, 100, 50000, err=0.004)
+    (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
+    K, S, E = 24, 16, 3
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, K, E, tmp_path / "o", S)
+    base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.reorder(base, 100, num_chains=K, num_steps=S)
+    assert_same(ol.read_dir(base), s1, ol.STAGE1_FILES, "stage I vs oracle under %r" % env)
+    harc_amd.encoder(base, 100, num_thr=E)
+    assert_same(ol.read_dir(base), s2, ol.stage2_files(E), "stage II vs oracle under %r" % env)
+
+
 @pytest.mark.parametrize("K,S,E,maxev,ndup", [(1, 16, 1, 0, 2500), (8, 16, 3, 0, 2500), (4, 16, 2, 7, 2500), (3, 16, 1, 0, 5200)])
 def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, maxev, ndup, oracle, tmp_path, monkeypatch):
     """ndup N reads sharing their first 50 bases: both stage-II dictionaries hold a bin of ndup > maxsearch.  The reference's
