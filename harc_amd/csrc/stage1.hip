@@ -731,6 +731,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
         if (lane == 0 && hnc) { atomicAdd(&s.cstat[blockIdx.x].y, hnc); atomicAdd(&s.cstat[blockIdx.x].w, hnc); }
         return;
     }
+    const long long dbg_t0 = (COOP && s.dbg) ? wall_clock64() : 0;
     uint32_t ownreg = HARC_NONE;                                 // lane t: the read this chain took at step t of this super-round
     const uint32_t c = COOP ? blockIdx.x : blockIdx.x * 4 + wv;
     if (c >= s.K) return;
@@ -1022,6 +1023,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
     if (COOP) { if (lane == 0) cmd->op = 0; __syncthreads(); }      // the walk is over: the helpers leave
     if (nst > 0) cons_store<W>(st, B1, L, lane);
     np = wave_sum_u32(np); nc = wave_sum_u32(nc); ncu = wave_sum_u32(ncu);
+    if (COOP && lane == 0 && s.dbg) { const unsigned long long dt = (unsigned long long)(wall_clock64() - dbg_t0); atomicAdd(&s.dbg[9], 1ULL); atomicAdd(&s.dbg[10], dt); atomicMax(&s.dbg[11], dt); atomicAdd(&s.dbg[12], (unsigned long long)(nst)); }
     if (lane == 0 && s.dbg) { atomicAdd(&s.dbg[0], (unsigned long long)dbg_bins); atomicAdd(&s.dbg[1], (unsigned long long)dbg_iter); atomicAdd(&s.dbg[2], (unsigned long long)dbg_miss); atomicAdd(&s.dbg[3], (unsigned long long)dbg_surv); atomicAdd(&s.dbg[4], (unsigned long long)nst); atomicAdd(&s.dbg[5], (unsigned long long)dbg_batches); atomicMax(&s.dbg[6], (unsigned long long)dbg_iter); atomicMax(&s.dbg[7], (unsigned long long)dbg_surv); atomicMax(&s.dbg[8], (unsigned long long)dbg_bins); }
     if (lane == 0) {
         if (COOP) { atomicAdd(&s.cstat[c].x, np); atomicAdd(&s.cstat[c].y, nc); atomicAdd(&s.cstat[c].z, nuse); atomicAdd(&s.cstat[c].w, ncu); }   // the helpers add to it too
@@ -1644,6 +1646,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         const double stp = (double)(d[4] ? d[4] : 1);
         fprintf(stderr, "[k_steps] steps walked %llu (of them kept %u): per step batches %.2f, cooperative bin scans %.2f, their 64-entry chunks %.2f, chunk x probe tests %.2f; steps without a hit %.3f\n", d[4], N, d[5] / stp, d[0] / stp, d[1] / stp, d[3] / stp, d[2] / stp);
         fprintf(stderr, "[k_steps] worst walk of the run: %llu chunks, %llu chunk x probe tests, %llu bin scans\n", d[6], d[7], d[8]);
+        if (d[9]) fprintf(stderr, "[k_steps] cooperative walks: %llu (%.1f per super-round), %.2f steps each, mean %.1f us, longest %.1f us (100 MHz wall clock)\n",
+                          d[9], (double)d[9] / (double)(rounds ? rounds : 1), (double)d[12] / (double)d[9], (double)d[10] / (double)d[9] / 100.0, (double)d[11] / 100.0);
     }
 
     harc_pool_release(c, mark_results);                          // stage II starts right above the results
