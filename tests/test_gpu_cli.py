@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("flags,E", [([], 8), (["-t", "3", "-k", "1"], 3), (["-p", "-t", "2"], 2)])
-def test_harc_c_roundtrip(flags, E, oracle, tmp_path):
+@pytest.mark.parametrize("flags,E,packer", [([], 8, "auto"), (["-t", "3", "-k", "1"], 3, "none"), (["-p", "-t", "2"], 2, "xz")])
+def test_harc_c_roundtrip(flags, E, packer, oracle, tmp_path, monkeypatch):
+    monkeypatch.setenv("HARC_AMD_STAGE3", packer)                # stage III (harc:102-109): auto == xz in this image (no bsc / 7z)
     L = 100
     txt = gen.reads_text(99, 20000, L, 150000, err=0.01)
     reads = txt.split()
@@ -30,6 +31,10 @@ def test_harc_c_roundtrip(flags, E, oracle, tmp_path):
     out.mkdir(parents=True)
     with tarfile.open(arc) as tf:
         tf.extractall(out)
+    xzs = [f for f in os.listdir(out) if f.endswith(".xz")]
+    assert bool(xzs) == (packer != "none")
+    for f in xzs:
+        subprocess.check_call(["xz", "-d", str(out / f)])
     for s in ["read_noise", "read_noisepos", "read_pos", "read_seq", "read_rev"]:
         with tarfile.open(out / (s + ".tar")) as tf:
             tf.extractall(out)

@@ -152,7 +152,7 @@ def test_harc_g_roundtrip_on_one_gpu(world, flags, E, tmp_path):
     ids = [b"@run.%d/%d" % (i, 1 + i % 2) for i in range(len(reads))]
     fq = tmp_path / "s.fastq"
     fq.write_bytes(_fastq(reads, quals, ids))
-    env = dict(os.environ, HARC_AMD_XPORT="mailbox", HARC_AMD_SHARE_DEVICE="0", HARC_AMD_MAILBOX_TIMEOUT="120")
+    env = dict(os.environ, HARC_AMD_XPORT="mailbox", HARC_AMD_SHARE_DEVICE="0", HARC_AMD_MAILBOX_TIMEOUT="120", HARC_AMD_STAGE3="none")   # raw tars: the test opens read_pos.tar
     r = subprocess.run([os.path.join(ROOT, "harc"), "-c", str(fq), "-g", str(world)] + flags, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "Total number of reads: %d" % len(reads) in r.stdout and "were unmatched" in r.stdout
