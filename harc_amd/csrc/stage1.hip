@@ -466,6 +466,9 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
 #ifndef HARC_STEPS_WAVES
 #define HARC_STEPS_WAVES 5
 #endif
+#ifndef HARC_COOP_WAVES
+#define HARC_COOP_WAVES 2       // COOP kernel: workgroups of 4 waves, this many waves per SIMD = workgroups per CU
+#endif
 #ifndef HARC_STEPS_WAVES_Q
 #define HARC_STEPS_WAVES_Q 3     // few chains (whole-bucket fetch): never more than ~3 waves / SIMD anyway
 #endif
@@ -690,7 +693,7 @@ template <int W> __global__ void k_steps_tables(S1Args s, uint32_t *out)
     }
 }
 
-template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_bounds__(256, COOP ? 2 : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? 1 : 0))) void k_steps(S1Args s)
+template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_bounds__(256, COOP ? HARC_COOP_WAVES : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? 1 : 0))) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
     extern __shared__ uint32_t lds[];

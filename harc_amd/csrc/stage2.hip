@@ -12,6 +12,7 @@
 //   packbits     :512-616  -> k_pack2_bytes / k_pack1_bytes
 // Shard e of num_thr owns reordered reads [e*q, (e+1)*q) (:171-180); its streams are slices of the global arrays.
 #include "devutil.h"
+#include <time.h>
 #include <algorithm>
 #include <stdlib.h>
 
@@ -544,12 +545,53 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args
 // bin of either dictionary).  What an event does is a function of the claims of its bin's reads, so an event whose bin has the version
 // it had when the event last looked is skipped: after the first passes only the events of the bins that are still settling -- the
 // deepest ones -- are scanned again (a 50 M-read repeat-rich set: 18 passes over ALL events before).
-__global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, uint32_t *binver0, uint32_t *binver1, uint32_t *lastver)
+// Which events run in a pass is free (any order of event executions keeps c above the sequential value, see above); only the END needs
+// passes over all events that change nothing.  Running all events in every pass costs (depth of the deepest bin) x (all events):
+// a poly-A bin of 17 000 reads attracts half a million probes, the first 17 of which -- in tuple order -- take 1000 reads each while
+// all the others rescan the same window seventeen times to lose every bid (50 M-read repeat-rich set: 17 passes x 23 ms).  So the
+// events are ranked by tuple inside their bin (two stable radix sorts) and the passes go over rank ranges [0,64), [64,256), ... x4, each
+// repeated until it is quiet: the early events of every bin settle first, at the price of a few dozen events per bin and pass, and the
+// later ones then run once against a settled bin.  perm = events in (bin, tuple) order, rank = position inside the bin.
+#define EV_DONE 0xFFFFFFFEu     // lastver of an event that never needs to look again (bins within maxsearch: the window never closes)
+__global__ void k_ev_key_tuple(const uint4 *ev, uint32_t nev, uint64_t *key, uint32_t *idx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nev) return;
+    const uint4 e = ev[i];
+    key[i] = (uint64_t)e.x | ((uint64_t)e.y << 32); idx[i] = i;
+}
+__global__ void k_ev_key_bin(const uint4 *ev, const uint32_t *idx, uint32_t nev, uint64_t *key)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nev) return;
+    const uint4 e = ev[idx[i]];
+    key[i] = ((uint64_t)(e.x & 1u) << 32) | e.z;                  // (dictionary, first id index of the bin)
+}
+__global__ void k_ev_heads(const uint64_t *key, uint32_t nev, uint32_t *head)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nev) return;
+    head[i] = (i > 0 && key[i] != key[i - 1]) ? i : 0u;          // max-scan -> first position of the bin's events
+}
+__global__ void k_ev_rank(uint32_t *seg, uint32_t nev, unsigned int *maxrank)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r = 0;
+    if (i < nev) { r = i - seg[i]; seg[i] = r; }
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(r, o, 64); r = x > r ? x : r; }
+    if ((threadIdx.x & 63) == 0 && r) atomicMax(maxrank, r);
+}
+__global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, uint32_t *binver0, uint32_t *binver1, uint32_t *lastver,
+                                                     const uint32_t *perm, const uint32_t *rank, uint32_t rlo, uint32_t rhi)
 {
     __shared__ unsigned long long swin[4][HARC_MAXW3];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t e = blockIdx.x * 4 + wv;
-    if (e >= nev) return;
+    const uint32_t ei = blockIdx.x * 4 + wv;
+    if (ei >= nev) return;
+    uint32_t e = ei;
+    if (perm) { const uint32_t r = rank[ei]; if (r < rlo || r >= rhi) return; e = perm[ei]; }
+    const uint32_t lv = lastver[e];
+    if (lv == EV_DONE) return;
     const int L = s.L, W3 = s.W3;
     const uint4 ev = s.events[e];
     const unsigned long long tp = (unsigned long long)ev.x | ((unsigned long long)ev.y << 32);
@@ -557,7 +599,8 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uin
     const uint32_t st = ev.z, cnt = ev.w;
     uint32_t *const myver = (l ? binver1 : binver0) + st;
     const uint32_t ver = __hip_atomic_load(myver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // before anything of the bin is read
-    if (ver == lastver[e]) return;
+    if (ver == lv) return;
+    if (estart[e] == 0) { if (lane == 0) lastver[e] = EV_DONE; return; }      // every read of the bin was claimed before this event: claims only move to earlier tuples
     // 3-bit window words (forward or reverse complement), lanes 0..W3-1 build one word each
     if (lane < W3) {
         const uint8_t *win = s.cons + x;
@@ -608,7 +651,7 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uin
         pos -= pos > 64 ? 64 : pos;
     }
     ch = __ballot(ch) != 0;
-    if (lane == 0) { estart[e] = top; lastver[e] = ver; if (ch) { atomicAdd(myver, 1u); atomicOr(changed, 1u); } }
+    if (lane == 0) { estart[e] = top; lastver[e] = cnt <= (uint32_t)s.maxsearch ? EV_DONE : ver; if (ch) { atomicAdd(myver, 1u); atomicOr(changed, 1u); } }
 }
 
 __global__ void k_acc_flags(const unsigned long long *best, uint32_t T, uint32_t *flag)
@@ -990,14 +1033,41 @@ int stage2_run(harc_amd_ctx *c)
                 HIP_TRY(hipMemsetAsync(estart, 0xFF, ((size_t)nev + 1) * 4, c->stream));
                 HIP_TRY(hipMemsetAsync(lastver, 0xFF, ((size_t)nev + 1) * 4, c->stream));
                 for (int l = 0; l < 2; l++) { RC_TRY(dalloc(c, &binver[l], (size_t)T + 1)); HIP_TRY(hipMemsetAsync(binver[l], 0, ((size_t)T + 1) * 4, c->stream)); }
-                for (uint64_t pass = 0;; pass++) {
+                const bool trace = getenv("HARC_AMD_TRACE") != nullptr;
+                struct timespec tw0; clock_gettime(CLOCK_MONOTONIC, &tw0);
+                // events in (bin, tuple) order and their rank inside the bin (k_realign_big's header)
+                uint32_t *perm = nullptr, *rank = nullptr; unsigned int maxrank = 0;
+                if (!getenv("HARC_AMD_S2_FLATPASSES")) {
+                    RC_TRY(dalloc(c, &perm, (size_t)nev + 1)); RC_TRY(dalloc(c, &rank, (size_t)nev + 1));
+                    uint64_t *k0 = nullptr, *k1 = nullptr; uint32_t *i0 = nullptr, *i1 = nullptr, *hd = nullptr;
+                    RC_TRY(dalloc(c, &k0, (size_t)nev + 1)); RC_TRY(dalloc(c, &k1, (size_t)nev + 1)); RC_TRY(dalloc(c, &i0, (size_t)nev + 1)); RC_TRY(dalloc(c, &i1, (size_t)nev + 1)); RC_TRY(dalloc(c, &hd, (size_t)nev + 1));
+                    unsigned tbits = 2; while (tbits < 64 && (total >> (tbits - 2)) != 0) tbits++;
+                    hipLaunchKernelGGL(k_ev_key_tuple, G256(nev), (const uint4 *)a.events, nev, k0, i0);
+                    RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i0, i1, nev, tbits));
+                    hipLaunchKernelGGL(k_ev_key_bin, G256(nev), (const uint4 *)a.events, (const uint32_t *)i1, nev, k0);
+                    RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i1, perm, nev, 33));            // stable: tuple order inside a bin
+                    hipLaunchKernelGGL(k_ev_heads, G256(nev), (const uint64_t *)k1, nev, hd);
+                    RC_TRY(prim_incl_max_u32(c, hd, rank, nev));
                     HIP_TRY(hipMemsetAsync(d_changed, 0, 16, c->stream));
-                    hipLaunchKernelGGL(k_realign_big, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binver[0], binver[1], lastver);
+                    hipLaunchKernelGGL(k_ev_rank, G256(nev), rank, nev, d_changed + 1);
+                    HIP_TRY(hipMemcpyAsync(&maxrank, d_changed + 1, 4, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                }
+                uint64_t npass = 0; uint32_t rlo = 0, rhi = 64;
+                if (const char *e = getenv("HARC_AMD_S2_RANK0")) { const int v = atoi(e); rhi = v < 1 ? 1u : (uint32_t)v; }       // tests: narrow ranges on small inputs
+                for (bool ranges = perm != nullptr;;) {
+                    HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream));
+                    hipLaunchKernelGGL(k_realign_big, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binver[0], binver[1], lastver,
+                                       (const uint32_t *)(ranges ? perm : nullptr), (const uint32_t *)rank, rlo, rhi);
                     unsigned int chg = 0;
                     HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));
-                    if (!chg) break;
-                    if (pass > (uint64_t)T + 16) { harc_set_error("stage II: the window passes over the large bins did not settle"); return HARC_AMD_EINTERNAL; }
+                    if (trace) { struct timespec tw; clock_gettime(CLOCK_MONOTONIC, &tw); fprintf(stderr, "[stage II] window pass %llu over %u events, ranks [%u, %u)%s: %s, %.2f ms since the first\n", (unsigned long long)npass, nev, ranges ? rlo : 0u, ranges ? rhi : maxrank + 1, ranges ? "" : " (all)", chg ? "claims moved" : "quiet", (tw.tv_sec - tw0.tv_sec) * 1e3 + (tw.tv_nsec - tw0.tv_nsec) * 1e-6); }
+                    if (++npass > (uint64_t)T + 256) { harc_set_error("stage II: the window passes over the large bins did not settle"); return HARC_AMD_EINTERNAL; }
+                    if (chg) continue;                                                    // the same events again, until they are quiet
+                    if (!ranges) break;                                                   // a pass over ALL events changed nothing: the fixed point
+                    if (rhi > maxrank) ranges = false;                                    // every range has settled: now the passes over everything
+                    else { rlo = rhi; rhi = rhi > 0x20000000u ? 0xFFFFFFFFu : rhi * 4; }
                 }
             }
         }

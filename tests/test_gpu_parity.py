@@ -234,15 +234,17 @@ def test_kernel_variants_same_bytes(env, oracle, tmp_path, monkeypatch):
     assert_same(ol.read_dir(base), s2, ol.stage2_files(E), "stage II vs oracle under %r" % env)
 
 
-@pytest.mark.parametrize("K,S,E,maxev,ndup", [(1, 16, 1, 0, 2500), (8, 16, 3, 0, 2500), (4, 16, 2, 7, 2500), (3, 16, 1, 0, 5200)])
-def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, maxev, ndup, oracle, tmp_path, monkeypatch):
+@pytest.mark.parametrize("K,S,E,maxev,ndup,sched", [(1, 16, 1, 0, 2500, ""), (8, 16, 3, 0, 2500, "rank0=1"), (4, 16, 2, 7, 2500, ""), (3, 16, 1, 0, 5200, ""), (3, 16, 1, 0, 5200, "flat"), (3, 16, 1, 0, 5200, "rank0=2")])
+def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, maxev, ndup, sched, oracle, tmp_path, monkeypatch):
     """ndup N reads sharing their first 50 bases: both stage-II dictionaries hold a bin of ndup > maxsearch.  The reference's
     window slides over the still-unclaimed ids (encoder.cpp:293,321-336); the GPU settles those probes as a fixed point over all of them
     at once (k_realign_big) -- same bytes as the sequential oracle.  maxev: a deliberately tiny event buffer, so that the pass has to be
-    repeated with the size it asks for; ndup = 5200: five windows deep."""
+    repeated with the size it asks for; ndup = 5200: five windows deep.  sched: the passes go over rank ranges of the events inside their
+    bin (first range 64 wide; forced to 1 or 2 here so that a small input walks through many ranges) or, "flat", over all events every time."""
     import harc_amd
     if maxev:
         monkeypatch.setenv("HARC_AMD_MAXEVENTS", str(maxev))
+    _set_sched(monkeypatch, sched)
     txt = gen.reads_text_bigbin_stage2(77, n_dupN=ndup)
     (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
     inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, K, E, tmp_path / "o", S)
@@ -254,12 +256,21 @@ def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, maxev, ndup, 
     assert len(s2["read_order_N_pe.bin"]) // 4 == ndup and len(s2["input_N.dna"]) < (ndup - 1000) * 101
 
 
-@pytest.mark.parametrize("K,S,E,seed,fail", [(1, 16, 1, 5, 0.6), (4, 16, 2, 6, 0.5), (1, 16, 1, 7, 0.8), (2, 8, 1, 8, 0.3)])
-def test_stage2_big_bins_partial_claims_exact(K, S, E, seed, fail, oracle, tmp_path):
+def _set_sched(monkeypatch, sched):
+    if sched == "flat":
+        monkeypatch.setenv("HARC_AMD_S2_FLATPASSES", "1")
+    elif sched.startswith("rank0="):
+        monkeypatch.setenv("HARC_AMD_S2_RANK0", sched[6:])
+
+
+@pytest.mark.parametrize("K,S,E,seed,fail,sched", [(1, 16, 1, 5, 0.6, ""), (4, 16, 2, 6, 0.5, "rank0=3"), (1, 16, 1, 7, 0.8, "flat"), (2, 8, 1, 8, 0.3, "rank0=1"), (1, 16, 1, 9, 0.5, "rank0=2")])
+def test_stage2_big_bins_partial_claims_exact(K, S, E, seed, fail, sched, oracle, tmp_path, monkeypatch):
     """bins above maxsearch whose reads only partly pass the Hamming test, probed from several places of the consensus: what a probe
     sees depends on which reads the probes before it took AND on the ones nobody takes (they fill the window).  The passes of
-    k_realign_big must go on while ANY lane of any probe still moves a claim -- same bytes as the sequential oracle."""
+    k_realign_big must go on while ANY lane of any probe still moves a claim -- same bytes as the sequential oracle, whatever the
+    order the passes take the probes in (sched, see above)."""
     import harc_amd
+    _set_sched(monkeypatch, sched)
     txt = gen.reads_text_bigbin_stage2_mixed(seed, fail_frac=fail)
     (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
     inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, K, E, tmp_path / "o", S)
