@@ -735,6 +735,10 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
         return;
     }
     const long long dbg_t0 = (COOP && s.dbg) ? wall_clock64() : 0;
+    // trace (HARC_AMD_TRACE): wall time of a cooperative walk by phase (setup, consensus rows, probes + small bins, large-bin scans, bid + update,
+    // tail), and time and number of its scans by live entries of the bin (<= 64, 256, 1024, more)
+    long long dbg_tl = dbg_t0; unsigned long long dbg_ph[6] = { 0, 0, 0, 0, 0, 0 }, dbg_kt[4] = { 0, 0, 0, 0 }, dbg_kn[4] = { 0, 0, 0, 0 };
+#define PH(k) do { if (COOP && s.dbg) { const long long tn_ = wall_clock64(); dbg_ph[k] += (unsigned long long)(tn_ - dbg_tl); dbg_tl = tn_; } } while (0)
     uint32_t ownreg = HARC_NONE;                                 // lane t: the read this chain took at step t of this super-round
     const uint32_t c = COOP ? blockIdx.x : blockIdx.x * 4 + wv;
     if (c >= s.K) return;
@@ -812,8 +816,10 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
     int lastp = (int)(h.pad0 & 0xFFFF);                          // 16 x running mean (weight 1/4) of the priority index of this chain's hits
     int spos = (int)((h.nsteps >> 16) & 0xFF); const int nsugg = (int)(h.nsteps >> 24);   // look-ahead seeds: next to try / held
     int bigprobes = 0;                                           // COOP: probes into large live bins made by this walk so far
+    PH(0);
     for (int t = T0; t < s.S; t++) {
         cons_rows<W>(st, L, lane, coltmp, rowF, rowR);            // consensus and its reverse complement -> the wave's window rows
+        PH(1);
         uint32_t found = HARC_NONE; int fj = 0, fdir = 0;
         // Probes are issued in priority order in batches: every probe behind the first hit of a batch is speculative traffic,
         // every extra batch is a serial round trip to HBM.
@@ -943,6 +949,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
             //      (CH_COOP); k_steps<W, QUAD, COOP = true> then goes on with the walk, the whole wave scanning the bins: 64 candidates per round trip from the bin-ordered copy of
             //      their reads (k_large_fill), in the same order and with the same maxsearch window as a lane-serial scan, and the probes
             //      of the step that look into the SAME bin (every shift of a poly-A consensus has the same key) share one pass over it.
+            PH(2);
             {
                 unsigned long long bigm = __ballot(big);
                 if (winlane < 64) bigm &= (1ULL << winlane) - 1ULL;
@@ -955,6 +962,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
                     unsigned long long grp = __ballot(big && l == o_l && b_slot == o_slot) & bigm;     // the probes into this bin, bl among them
                     bigm &= ~grp;
                     dbg_bins++;
+                    const int dbg_kind = o_cnt <= 64 ? 0 : o_cnt <= 256 ? 1 : o_cnt <= 1024 ? 2 : 3;
+                    const long long dbg_s0 = s.dbg ? wall_clock64() : 0;
                     const uint2 lt = s.largetab[o_sst];
                     // while the bin fits the maxsearch window (reorder.cpp:540) the window never closes: the claim bit is only asked of the
                     // candidates that pass the Hamming test.  Above it the unclaimed reads are counted exactly, as the lane-serial scan would.
@@ -970,9 +979,11 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
                     const int besthit = wr.besthit;
                     if (besthit < 64) { found = cmd->found; fj = wr.fj; fdir = wr.fdir; }
                     if (besthit < 64) { winlane = besthit; bigm &= (1ULL << besthit) - 1ULL; }
+                    if (s.dbg) { dbg_kt[dbg_kind] += (unsigned long long)(wall_clock64() - dbg_s0); dbg_kn[dbg_kind]++; }
                 }
                 if (COOP) bigprobes += __popcll(__ballot(big) & (winlane < 64 ? ((2ULL << winlane) - 1ULL) : ~0ULL));   // the probes up to and including the winning one
             }
+            PH(3);
             if (lane <= winlane) ncu += ncb;                              // lanes behind the winner were speculation (winlane = 64: no hit, all count)
             if (found != HARC_NONE) {
                 nuse += (uint32_t)(base + winlane + 1);
@@ -1021,11 +1032,21 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
         __builtin_amdgcn_wave_barrier();
         cons_update_lds<W>(st, rdl, L, fdir, fj, lane);
         nst++;
+        PH(4);
         if (COOP && bigprobes >= s.budget) break;
     }
+    PH(4);
     if (COOP) { if (lane == 0) cmd->op = 0; __syncthreads(); }      // the walk is over: the helpers leave
     if (nst > 0) cons_store<W>(st, B1, L, lane);
     np = wave_sum_u32(np); nc = wave_sum_u32(nc); ncu = wave_sum_u32(ncu);
+    PH(5);
+#undef PH
+    if (COOP && lane == 0 && s.dbg) {
+        for (int k = 0; k < 6; k++) atomicAdd(&s.dbg[16 + k], dbg_ph[k]);
+        for (int k = 0; k < 4; k++) { atomicAdd(&s.dbg[36 + k], dbg_kn[k]); atomicAdd(&s.dbg[40 + k], dbg_kt[k]); }
+        const unsigned long long dt0 = (unsigned long long)(wall_clock64() - dbg_t0);
+        atomicAdd(&s.dbg[24 + (dt0 / 2500 < 11 ? dt0 / 2500 : 11)], 1ULL);
+    }
     if (COOP && lane == 0 && s.dbg) { const unsigned long long dt = (unsigned long long)(wall_clock64() - dbg_t0); atomicAdd(&s.dbg[9], 1ULL); atomicAdd(&s.dbg[10], dt); atomicMax(&s.dbg[11], dt); atomicAdd(&s.dbg[12], (unsigned long long)(nst)); }
     if (lane == 0 && s.dbg) { atomicAdd(&s.dbg[0], (unsigned long long)dbg_bins); atomicAdd(&s.dbg[1], (unsigned long long)dbg_iter); atomicAdd(&s.dbg[2], (unsigned long long)dbg_miss); atomicAdd(&s.dbg[3], (unsigned long long)dbg_surv); atomicAdd(&s.dbg[4], (unsigned long long)nst); atomicAdd(&s.dbg[5], (unsigned long long)dbg_batches); atomicMax(&s.dbg[6], (unsigned long long)dbg_iter); atomicMax(&s.dbg[7], (unsigned long long)dbg_surv); atomicMax(&s.dbg[8], (unsigned long long)dbg_bins); }
     if (lane == 0) {
@@ -1526,7 +1547,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &a.log, (size_t)N + 1));
     RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N));
     RC_TRY(dalloc(c, &a.cstat, K)); HIP_TRY(hipMemsetAsync(a.cstat, 0, (size_t)K * 16, c->stream));
-    RC_TRY(dalloc(c, &a.dbg, 16)); HIP_TRY(hipMemsetAsync(a.dbg, 0, 16 * 8, c->stream));
+    RC_TRY(dalloc(c, &a.dbg, 48)); HIP_TRY(hipMemsetAsync(a.dbg, 0, 48 * 8, c->stream));
     unsigned long long *const dbg_ptr = a.dbg;
     if (!getenv("HARC_AMD_TRACE")) a.dbg = nullptr;
     std::vector<uint16_t> tab = make_probe_table(P);
@@ -1644,13 +1665,22 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     }
 #endif
     if (a.dbg) {
-        unsigned long long d[16];
+        unsigned long long d[48];
         HIP_TRY(hipMemcpy(d, dbg_ptr, sizeof d, hipMemcpyDeviceToHost));
         const double stp = (double)(d[4] ? d[4] : 1);
         fprintf(stderr, "[k_steps] steps walked %llu (of them kept %u): per step batches %.2f, cooperative bin scans %.2f, their 64-entry chunks %.2f, chunk x probe tests %.2f; steps without a hit %.3f\n", d[4], N, d[5] / stp, d[0] / stp, d[1] / stp, d[3] / stp, d[2] / stp);
         fprintf(stderr, "[k_steps] worst walk of the run: %llu chunks, %llu chunk x probe tests, %llu bin scans\n", d[6], d[7], d[8]);
         if (d[9]) fprintf(stderr, "[k_steps] cooperative walks: %llu (%.1f per super-round), %.2f steps each, mean %.1f us, longest %.1f us (100 MHz wall clock)\n",
                           d[9], (double)d[9] / (double)(rounds ? rounds : 1), (double)d[12] / (double)d[9], (double)d[10] / (double)d[9] / 100.0, (double)d[11] / 100.0);
+        if (d[9]) {
+            fprintf(stderr, "[k_steps] cooperative walks, mean us by phase: setup %.1f, consensus rows %.1f, probes + small bins %.1f, large-bin scans %.1f, bid + update %.1f, tail %.1f\n",
+                    d[16] / (double)d[9] / 100.0, d[17] / (double)d[9] / 100.0, d[18] / (double)d[9] / 100.0, d[19] / (double)d[9] / 100.0, d[20] / (double)d[9] / 100.0, d[21] / (double)d[9] / 100.0);
+            fprintf(stderr, "[k_steps] large-bin scans by live entries of the bin: <= 64: %llu (%.2f us each), <= 256: %llu (%.2f), <= 1024: %llu (%.2f), more: %llu (%.2f)\n",
+                    d[36], d[40] / (double)(d[36] ? d[36] : 1) / 100.0, d[37], d[41] / (double)(d[37] ? d[37] : 1) / 100.0, d[38], d[42] / (double)(d[38] ? d[38] : 1) / 100.0, d[39], d[43] / (double)(d[39] ? d[39] : 1) / 100.0);
+            fprintf(stderr, "[k_steps] cooperative walks by duration (25 us bins, last = longer):");
+            for (int k = 0; k < 12; k++) fprintf(stderr, " %llu", d[24 + k]);
+            fprintf(stderr, "\n");
+        }
     }
 
     harc_pool_release(c, mark_results);                          // stage II starts right above the results
