@@ -737,8 +737,13 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
     const long long dbg_t0 = (COOP && s.dbg) ? wall_clock64() : 0;
     // trace (HARC_AMD_TRACE): wall time of a cooperative walk by phase (setup, consensus rows, probes + small bins, large-bin scans, bid + update,
     // tail), and time and number of its scans by live entries of the bin (<= 64, 256, 1024, more)
+    // (a build with -DHARC_COOP_TRACE only: the accumulators cost the cooperative kernel 30 registers and a wave per SIMD)
+#ifdef HARC_COOP_TRACE
     long long dbg_tl = dbg_t0; unsigned long long dbg_ph[6] = { 0, 0, 0, 0, 0, 0 }, dbg_kt[4] = { 0, 0, 0, 0 }, dbg_kn[4] = { 0, 0, 0, 0 };
 #define PH(k) do { if (COOP && s.dbg) { const long long tn_ = wall_clock64(); dbg_ph[k] += (unsigned long long)(tn_ - dbg_tl); dbg_tl = tn_; } } while (0)
+#else
+#define PH(k) do { } while (0)
+#endif
     uint32_t ownreg = HARC_NONE;                                 // lane t: the read this chain took at step t of this super-round
     const uint32_t c = COOP ? blockIdx.x : blockIdx.x * 4 + wv;
     if (c >= s.K) return;
@@ -962,8 +967,10 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
                     unsigned long long grp = __ballot(big && l == o_l && b_slot == o_slot) & bigm;     // the probes into this bin, bl among them
                     bigm &= ~grp;
                     dbg_bins++;
+#ifdef HARC_COOP_TRACE
                     const int dbg_kind = o_cnt <= 64 ? 0 : o_cnt <= 256 ? 1 : o_cnt <= 1024 ? 2 : 3;
                     const long long dbg_s0 = s.dbg ? wall_clock64() : 0;
+#endif
                     const uint2 lt = s.largetab[o_sst];
                     // while the bin fits the maxsearch window (reorder.cpp:540) the window never closes: the claim bit is only asked of the
                     // candidates that pass the Hamming test.  Above it the unclaimed reads are counted exactly, as the lane-serial scan would.
@@ -979,7 +986,9 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
                     const int besthit = wr.besthit;
                     if (besthit < 64) { found = cmd->found; fj = wr.fj; fdir = wr.fdir; }
                     if (besthit < 64) { winlane = besthit; bigm &= (1ULL << besthit) - 1ULL; }
+#ifdef HARC_COOP_TRACE
                     if (s.dbg) { dbg_kt[dbg_kind] += (unsigned long long)(wall_clock64() - dbg_s0); dbg_kn[dbg_kind]++; }
+#endif
                 }
                 if (COOP) bigprobes += __popcll(__ballot(big) & (winlane < 64 ? ((2ULL << winlane) - 1ULL) : ~0ULL));   // the probes up to and including the winning one
             }
@@ -1041,12 +1050,14 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
     np = wave_sum_u32(np); nc = wave_sum_u32(nc); ncu = wave_sum_u32(ncu);
     PH(5);
 #undef PH
+#ifdef HARC_COOP_TRACE
     if (COOP && lane == 0 && s.dbg) {
         for (int k = 0; k < 6; k++) atomicAdd(&s.dbg[16 + k], dbg_ph[k]);
         for (int k = 0; k < 4; k++) { atomicAdd(&s.dbg[36 + k], dbg_kn[k]); atomicAdd(&s.dbg[40 + k], dbg_kt[k]); }
         const unsigned long long dt0 = (unsigned long long)(wall_clock64() - dbg_t0);
         atomicAdd(&s.dbg[24 + (dt0 / 2500 < 11 ? dt0 / 2500 : 11)], 1ULL);
     }
+#endif
     if (COOP && lane == 0 && s.dbg) { const unsigned long long dt = (unsigned long long)(wall_clock64() - dbg_t0); atomicAdd(&s.dbg[9], 1ULL); atomicAdd(&s.dbg[10], dt); atomicMax(&s.dbg[11], dt); atomicAdd(&s.dbg[12], (unsigned long long)(nst)); }
     if (lane == 0 && s.dbg) { atomicAdd(&s.dbg[0], (unsigned long long)dbg_bins); atomicAdd(&s.dbg[1], (unsigned long long)dbg_iter); atomicAdd(&s.dbg[2], (unsigned long long)dbg_miss); atomicAdd(&s.dbg[3], (unsigned long long)dbg_surv); atomicAdd(&s.dbg[4], (unsigned long long)nst); atomicAdd(&s.dbg[5], (unsigned long long)dbg_batches); atomicMax(&s.dbg[6], (unsigned long long)dbg_iter); atomicMax(&s.dbg[7], (unsigned long long)dbg_surv); atomicMax(&s.dbg[8], (unsigned long long)dbg_bins); }
     if (lane == 0) {
@@ -1672,7 +1683,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         fprintf(stderr, "[k_steps] worst walk of the run: %llu chunks, %llu chunk x probe tests, %llu bin scans\n", d[6], d[7], d[8]);
         if (d[9]) fprintf(stderr, "[k_steps] cooperative walks: %llu (%.1f per super-round), %.2f steps each, mean %.1f us, longest %.1f us (100 MHz wall clock)\n",
                           d[9], (double)d[9] / (double)(rounds ? rounds : 1), (double)d[12] / (double)d[9], (double)d[10] / (double)d[9] / 100.0, (double)d[11] / 100.0);
-        if (d[9]) {
+        if (d[9] && d[16]) {                                         // -DHARC_COOP_TRACE builds
             fprintf(stderr, "[k_steps] cooperative walks, mean us by phase: setup %.1f, consensus rows %.1f, probes + small bins %.1f, large-bin scans %.1f, bid + update %.1f, tail %.1f\n",
                     d[16] / (double)d[9] / 100.0, d[17] / (double)d[9] / 100.0, d[18] / (double)d[9] / 100.0, d[19] / (double)d[9] / 100.0, d[20] / (double)d[9] / 100.0, d[21] / (double)d[9] / 100.0);
             fprintf(stderr, "[k_steps] large-bin scans by live entries of the bin: <= 64: %llu (%.2f us each), <= 256: %llu (%.2f), <= 1024: %llu (%.2f), more: %llu (%.2f)\n",
