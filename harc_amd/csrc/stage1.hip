@@ -479,7 +479,10 @@ template <int W> struct StepsLds {
     static constexpr int ROW = 3 * NW + 1;
     static constexpr int MROW = (NW + 3) & ~3;                   // mask rows are 16-byte aligned
 };
-#define HARC_WGCMD_BYTES 768           // >= sizeof(WgCmd), checked where the struct is defined
+#ifndef HARC_SCAN_CH
+#define HARC_SCAN_CH 1                // chunks of 256 bin entries the cooperative scan fetches per round trip (see wg_scan)
+#endif
+#define HARC_WGCMD_BYTES 1280          // >= sizeof(WgCmd), checked where the struct is defined
 static inline size_t steps_lds_bytes(int W, int maxmatch, int nprobe)
 {
     const int NW = 2 * W, ROW = 3 * NW + 1, MROW = (NW + 3) & ~3;
@@ -588,72 +591,114 @@ struct WgCmd {
     unsigned long long grp;          // the probes (lanes of wave 0) that look into this bin
     uint32_t found;                  // the read of the best probe that found one
     uint32_t nc;                     // candidates tested by the helpers (statistics)
-    unsigned long long hit[2][4];
-    uint32_t uncount[4];
+    unsigned long long hit[2][HARC_SCAN_CH][4];
+    unsigned long long um[2][HARC_SCAN_CH][4];     // which entries of each wave count for the maxsearch window
     uint8_t mj[64], mdir[64];        // shift and direction of every probe
     uint32_t own[64];                // reads the chain took earlier in this super-round
 };
 struct WgResult { int besthit, fj, fdir; uint32_t iters, tests, nc; };
 static_assert(sizeof(WgCmd) <= HARC_WGCMD_BYTES, "HARC_WGCMD_BYTES too small");
-// every wave of the workgroup: scan the bin of the command; same order, same maxsearch window as a lane-serial scan (reorder.cpp:540-552)
-template <int W> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int role, int lane, const uint32_t *const *ids, const uint64_t *mirror, const unsigned long long *claimed,
+// every wave of the workgroup: scan the bin of the command; same order, same maxsearch window as a lane-serial scan (reorder.cpp:540-552).
+// No claim bit is asked for: k_compact_bins runs after the last change of the claim bitmap of a super-round (k_resolve, k_reseed), so every
+// entry of a large bin is unclaimed in the frozen state this kernel walks against; what remains to be excluded are the reads the chain
+// took earlier in this super-round (cmd->own).  One chunk of 256 entries = ONE round trip to HBM (ids and the bin-ordered reads
+// together) and ONE barrier: the waves post their hit masks -- and, above maxsearch, which of their entries count for the window -- in
+// the same exchange (double-buffered); only the chunk in which the window closes needs the exact ranks and a second exchange.
+template <int W> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int role, int lane, const uint32_t *const *ids, const uint64_t *mirror,
                                                             const uint32_t *rowF, const uint32_t *s_mask, uint32_t *rdl, int maxsearch, int maxmatch, int thresh)
 {
-    constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
+    constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW, CH = HARC_SCAN_CH;
     WgResult r; r.besthit = 64; r.fj = 0; r.fdir = 0; r.iters = 0; r.tests = 0; r.nc = 0;
     const uint32_t *oids = ids[cmd->l];
     const uint32_t ids0 = cmd->ids0, m0 = cmd->m0;
     const int t = cmd->t; const bool fast = cmd->fast != 0;
     unsigned long long grp = cmd->grp;
     int seen = 0, par = 0; uint32_t pos = cmd->cnt;
-    uint32_t mrd[NW];
+    uint32_t mrd[CH][NW], rid[CH];
     while (pos > 0 && seen < maxsearch && grp) {
-        const uint32_t off = 64u * (uint32_t)role + (uint32_t)lane;
-        const bool valid = off < pos; r.iters++;
-        const uint32_t at = pos - 1 - off;
-        uint32_t rid = 0; bool clm = true, own = false, cand = false, checked = !fast; int total = 0;
-        if (valid) rid = oids[ids0 + at];
-        if (fast) cand = valid;
-        else {                                                     // exact window: claim state of all 256 entries, ranks across the waves
-            if (valid) clm = ((claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
-            if (valid && !clm) for (int k = 0; k < t; k++) own |= (cmd->own[k] == rid);
-            const bool un = valid && !clm && !own;
-            const unsigned long long um = __ballot(un);
-            if (lane == 0) cmd->uncount[role] = (uint32_t)__popcll(um);
-            __syncthreads();
-            int base = 0;
-            for (int w = 0; w < 4; w++) { const int x = (int)cmd->uncount[w]; if (w < role) base += x; total += x; }
-            cand = un && (seen + base + __popcll(um & ((1ULL << lane) - 1ULL)) < maxsearch);
+        // CH chunks of 256 entries per round trip; entry c * 256 + 64 * role + lane from the top of the bin, so priority = (c, role, lane).
+        // CH = 1: with 2 or 4 (a bin of diverged repeat copies is scanned to the end of the window, four dependent round trips) the kernel
+        // needs 153 / 209 registers instead of 124 and loses a wave or two per SIMD: c3sd chains 419 -> 489 / 703 ms.  A chunk costs ~1.5 us
+        // whatever it waits for: the walking wave is alone on its SIMD lane of the workgroup and bound by instruction latency.
+        bool valid[CH], own[CH], un[CH], cand[CH]; unsigned long long um[CH];
+        r.iters++;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t off = 256u * (uint32_t)c + 64u * (uint32_t)role + (uint32_t)lane;
+            valid[c] = off < pos; rid[c] = 0; own[c] = false;
+            if (valid[c]) { const uint32_t at = pos - 1 - off; rid[c] = oids[ids0 + at]; load_read32<W>(mirror, m0 + at, mrd[c]); }
         }
-        if (cand) load_read32<W>(mirror, m0 + at, mrd);
+        // fast (the bin fits the maxsearch window, which then never closes): the chain's own reads are only looked up for candidates that
+        // pass the Hamming test.  Otherwise they do not count for the window either: looked up for every entry.
+        bool ownknown = !fast;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            if (!fast && valid[c]) for (int k = 0; k < t; k++) own[c] |= (cmd->own[k] == rid[c]);
+            un[c] = valid[c] && !own[c]; cand[c] = un[c];
+            um[c] = __ballot(un[c]);
+        }
+        int total = 0;
         unsigned long long gm = grp; r.tests += (uint32_t)__popcll(grp);
+        bool first = true;
         while (gm) {                                               // the probes of this bin, highest priority first
             const int g = __ffsll((long long)gm) - 1;
             gm &= gm - 1;
             const int g_j = cmd->mj[g], g_dir = cmd->mdir[g];
             const uint32_t *const omrow = s_mask + (size_t)(g_dir * maxmatch + g_j) * MROW;
             const int obit = g_dir * ROW * 32 + 32 * NW + (g_dir ? -2 * g_j : 2 * g_j);
-            bool ok = false;
-            if (cand) { r.nc++; ok = ham_window<W>(rowF, obit, omrow, mrd) <= thresh; }      // statistics: fast mode does not tell claimed entries apart
-            if (ok && !checked) {
-                clm = ((claimed[rid >> 6] >> (rid & 63)) & 1ULL) != 0;
-                if (!clm) for (int k = 0; k < t; k++) own |= (cmd->own[k] == rid);
-                checked = true;
+            bool ok[CH]; bool anyok = false;
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                ok[c] = false;
+                if (cand[c]) { r.nc++; ok[c] = ham_window<W>(rowF, obit, omrow, mrd[c]) <= thresh; }
+                anyok |= ok[c];
             }
-            ok = ok && !clm && !own;
-            const unsigned long long pm = __ballot(ok);
-            if (lane == 0) cmd->hit[par][role] = pm;
+            if (anyok && !ownknown) {
+#pragma unroll
+                for (int c = 0; c < CH; c++) if (ok[c]) for (int k = 0; k < t; k++) own[c] |= (cmd->own[k] == rid[c]);
+                ownknown = true;
+            }
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                ok[c] = ok[c] && !own[c];
+                const unsigned long long pm = __ballot(ok[c]);
+                if (lane == 0) { cmd->hit[par][c][role] = pm; if (first && !fast) cmd->um[par][c][role] = um[c]; }
+            }
             __syncthreads();
-            unsigned long long hw[4];
-            for (int w = 0; w < 4; w++) hw[w] = cmd->hit[par][w];
+            if (first && !fast) {
+                int before[CH];                                    // entries that count, ahead of this wave's entries of chunk c
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    before[c] = total;
+                    for (int w = 0; w < 4; w++) { const int x = __popcll(cmd->um[par][c][w]); if (w < role) before[c] += x; total += x; }
+                }
+                if (seen + total > maxsearch) {                    // the window closes inside these chunks: exact ranks, once more
+                    par ^= 1;
+#pragma unroll
+                    for (int c = 0; c < CH; c++) {
+                        cand[c] = un[c] && (seen + before[c] + __popcll(um[c] & ((1ULL << lane) - 1ULL)) < maxsearch);
+                        ok[c] = ok[c] && cand[c];
+                        const unsigned long long pm = __ballot(ok[c]);
+                        if (lane == 0) cmd->hit[par][c][role] = pm;
+                    }
+                    __syncthreads();
+                }
+            }
+            int winc = -1, winw = 0; unsigned long long winm = 0;
+#pragma unroll
+            for (int c = CH - 1; c >= 0; c--)
+                for (int w = 3; w >= 0; w--) { const unsigned long long h = cmd->hit[par][c][w]; if (h) { winc = c; winw = w; winm = h; } }
+            first = false;
             par ^= 1;
-            if (hw[0] | hw[1] | hw[2] | hw[3]) {
-                const int winw = hw[0] ? 0 : hw[1] ? 1 : hw[2] ? 2 : 3;       // the highest ids are in wave 0
-                const int wl = __ffsll((long long)hw[winw]) - 1;
+            if (winc >= 0) {                                       // the highest id: first chunk, first wave, first lane
+                const int wl = __ffsll((long long)winm) - 1;
                 if (role == winw && lane == wl) {
 #pragma unroll
-                    for (int k = 0; k < NW; k++) rdl[k] = mrd[k];
-                    cmd->found = rid;
+                    for (int c = 0; c < CH; c++) if (c == winc) {
+#pragma unroll
+                        for (int k = 0; k < NW; k++) rdl[k] = mrd[c][k];
+                        cmd->found = rid[c];
+                    }
                 }
                 r.fj = g_j; r.fdir = g_dir; r.besthit = g;
                 grp &= (1ULL << g) - 1ULL;                         // this probe is settled, the ones behind it are beaten; the ones before it go on
@@ -661,9 +706,9 @@ template <int W> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int rol
             }
         }
         if (!fast) seen += total;
-        pos -= pos > 256 ? 256 : pos;
-        __syncthreads();                                           // the exchange buffers are free again; the winner's words are in place
+        pos -= pos > 256u * CH ? 256u * CH : pos;
     }
+    __syncthreads();                                               // the winner's words are in place; the command block is free for the next scan
     return r;
 }
 
@@ -727,7 +772,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
         for (;;) {
             __syncthreads();
             if (cmd->op == 0) break;
-            const WgResult r = wg_scan<W>(cmd, role, lane, idp, s.mirror, s.claimed, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh);
+            const WgResult r = wg_scan<W>(cmd, role, lane, idp, s.mirror, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh);
             hnc += r.nc;
         }
         hnc = wave_sum_u32(hnc);
@@ -845,7 +890,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
             const int p = base + lane; dbg_batches++;
             uint32_t mine = HARC_NONE; int j = 0, dir = 0, l = 0;
             uint32_t ncb = 0;                                             // candidates this lane tests in this batch
-            bool big = false; uint32_t b_sst = 0, b_cnt = 0; uint64_t b_slot = 0;   // a bin too large for one lane: scanned by the whole wave below
+            bool big = false; uint32_t b_cnt = 0; uint64_t b_slot = 0;   // a bin too large for one lane: scanned by the whole wave below
+            uint2 b_lt = make_uint2(0, 0);                               // COOP: its row of largetab, fetched by the lane that found it (all bins of the batch in ONE round trip)
             uint32_t mrd[NW];
 #pragma unroll
             for (int k = 0; k < NW; k++) mrd[k] = 0;
@@ -902,7 +948,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
                     const uint32_t cntb = cw & SLOT_CNT_MASK;
                     const bool emb = (cw & SLOT_EMB) != 0;                // single-read bin: `start` IS the read id
                     // bins of more than HARC_LARGEBIN reads (at build time) are scanned by the whole wave, and only by the COOP kernel
-                    if (cw & SLOT_BIG) { big = true; b_sst = sst; b_cnt = cw & (SLOT_CNT_MASK | SLOT_OVF | SLOT_BIG); b_slot = sl + qhit; }
+                    if (cw & SLOT_BIG) { big = true; b_cnt = cw & (SLOT_CNT_MASK | SLOT_OVF | SLOT_BIG); b_slot = sl + qhit; if (COOP) b_lt = s.largetab[sst]; }
                     else {
                         const uint32_t *const ids = l ? s.ids[1] : s.ids[0];
                         const uint32_t *const mrow = s_mask + (pi.y >> 16);
@@ -961,7 +1007,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
                 if (!COOP) { if (bigm) { defer = true; break; } }
                 else while (bigm) {
                     const int bl = __ffsll((long long)bigm) - 1;
-                    const uint32_t o_sst = (uint32_t)__builtin_amdgcn_readlane((int)b_sst, bl), o_raw = (uint32_t)__builtin_amdgcn_readlane((int)b_cnt, bl), o_cnt = o_raw & SLOT_CNT_MASK;
+                    const uint32_t o_raw = (uint32_t)__builtin_amdgcn_readlane((int)b_cnt, bl), o_cnt = o_raw & SLOT_CNT_MASK;
                     const int o_l = __builtin_amdgcn_readlane(l, bl);
                     const uint64_t o_slot = shfl_u64(b_slot, bl);
                     unsigned long long grp = __ballot(big && l == o_l && b_slot == o_slot) & bigm;     // the probes into this bin, bl among them
@@ -971,7 +1017,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
                     const int dbg_kind = o_cnt <= 64 ? 0 : o_cnt <= 256 ? 1 : o_cnt <= 1024 ? 2 : 3;
                     const long long dbg_s0 = s.dbg ? wall_clock64() : 0;
 #endif
-                    const uint2 lt = s.largetab[o_sst];
+                    const uint2 lt = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)b_lt.x, bl), (uint32_t)__builtin_amdgcn_readlane((int)b_lt.y, bl));
                     // while the bin fits the maxsearch window (reorder.cpp:540) the window never closes: the claim bit is only asked of the
                     // candidates that pass the Hamming test.  Above it the unclaimed reads are counted exactly, as the lane-serial scan would.
                     cmd->mj[lane] = (uint8_t)j; cmd->mdir[lane] = (uint8_t)dir; cmd->own[lane] = ownreg;
@@ -981,7 +1027,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
                     }
                     __syncthreads();                                           // the helpers start
                     const uint32_t *const idp[2] = { s.ids[0], s.ids[1] };
-                    const WgResult wr = wg_scan<W>(cmd, 0, lane, idp, s.mirror, s.claimed, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh);
+                    const WgResult wr = wg_scan<W>(cmd, 0, lane, idp, s.mirror, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh);
                     dbg_iter += wr.iters; dbg_surv += wr.tests; nc += wr.nc; ncu += wr.nc;
                     const int besthit = wr.besthit;
                     if (besthit < 64) { found = cmd->found; fj = wr.fj; fdir = wr.fdir; }
