@@ -14,6 +14,7 @@
 #define HARC_MAXW 8      // ceil(2*255/64) words of a 2-bit read
 #define HARC_MAXW3 12    // ceil(3*255/64) words of a 3-bit read
 #define HARC_MAXK (1u << 20)
+#define HARC_LOOK_CHUNKS 16   // k_reseed looks for look-ahead seeds in at most this many chunks of 1024 bitmap words below the cursor (oracle: LOOK_CHUNKS)
 #ifndef HARC_NSUGG
 #define HARC_NSUGG 4      // look-ahead seeds handed to a chain at every reseed (oracle: NSUGG)
 #endif

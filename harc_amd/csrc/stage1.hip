@@ -1246,28 +1246,36 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
     // look-ahead: the next assigned * HARC_NSUGG unclaimed ids below the cursor; nothing is claimed, the cursor moves below them
     const uint32_t want = assigned * (uint32_t)s.nsugg_per_seed;
     uint32_t got = 0;
-    long long look = cursor;
+    const long long look = cursor;
     __threadfence();
     __syncthreads();
-    if (want && look >= 0) {                                      // ONE chunk only (the 1024 words ending at the cursor's word): bounded cost
-        const long long cwd = look >> 6, wi = cwd - t;
+    if (look < 0) got = want;                                     // nothing left below the cursor: no look-ahead (got is reset below)
+    // at most HARC_LOOK_CHUNKS chunks of 1024 words below the cursor (bounded cost; the oracle has the same limit).  One chunk was enough
+    // while few chains reseed per super-round; a minimizer-bucket shard of a multi-GPU run leaves a third of its reads unmatched, tens
+    // of thousands of chains ask for seeds every round, and those that got no look-ahead seed walked ONE read per round: 1296 rounds
+    // instead of ~400 on an 8-way shard of configs[2].
+    for (int ch = 0; ch < HARC_LOOK_CHUNKS && got < want; ch++) {
+        const long long cwd = (look >> 6) - 1024LL * ch, wi = cwd - t;
+        if (cwd < 0) break;
         unsigned long long bits = 0;
         if (wi >= 0) {
             bits = ~s.claimed[wi];
-            if (wi == cwd) { const int top = (int)(look & 63); if (top < 63) bits &= (2ULL << top) - 1ULL; }
+            if (ch == 0 && wi == cwd) { const int top = (int)(look & 63); if (top < 63) bits &= (2ULL << top) - 1ULL; }
         }
         uint32_t total; const uint32_t off = block_excl_scan_u32<1024>((uint32_t)__popcll(bits), sm, &total);
-        got = total >= want ? want : total;
+        const uint32_t take = total >= want - got ? want - got : total;
         uint32_t k = 0;
-        while (bits && off + k < want) {
+        while (bits && off + k < take) {
             const int b = 63 - __clzll((long long)bits);
             bits &= ~(1ULL << b);
             const uint32_t id = (uint32_t)(wi * 64 + b);
-            s.seedbuf[R + off + k] = id;
-            if (off + k == got - 1) scursor = (long long)id - 1;     // the cursor goes below the last look-ahead seed handed out:
+            s.seedbuf[R + got + off + k] = id;
+            if (off + k == take - 1) scursor = (long long)id - 1;   // the cursor goes below the last look-ahead seed handed out:
             k++;                                                    // those reads belong to their chains now, later reseeds do not hand them out again
         }
+        got += take;
     }
+    if (look < 0) got = 0;
     __threadfence();
     __syncthreads();
     if (got) cursor = scursor;

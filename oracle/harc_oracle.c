@@ -38,6 +38,7 @@
 #define NONE 0xFFFFFFFFu
 #define MAXSTEPS 64
 #define NSUGG 4           /* look-ahead seeds handed to a chain at every reseed */
+#define LOOK_CHUNKS 16     /* the look-ahead inspects at most this many chunks of 1024 64-bit bitmap words below the cursor (the GPU's k_reseed) */
 #define LARGEBIN 16u      /* HARC_LARGEBIN of harc_amd/csrc/stage1.hip */
 #define SCAN_BUDGET 16     /* HARC_SCAN_BUDGET: a walk ends after the step in which its probes into bins of more than LARGEBIN reads (not yet exhausted) reach this number */
 
@@ -407,8 +408,8 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
            chain until the chain takes it or finds it claimed by a walk (later reseeds do not hand it out again) */
         {
             int64_t look = remainingpos, last_taken = -1;
-            /* the look-ahead only inspects one bitmap chunk of the GPU's k_reseed: the 1024 64-bit words ending at the cursor's word */
-            int64_t lim = remainingpos >= 0 ? ((remainingpos >> 6) - 1023) * 64 : 0;
+            /* the look-ahead only inspects LOOK_CHUNKS bitmap chunks of the GPU's k_reseed: 1024 64-bit words each, ending at the cursor's word */
+            int64_t lim = remainingpos >= 0 ? ((remainingpos >> 6) - (1024 * (int64_t)LOOK_CHUNKS - 1)) * 64 : 0;
             if (lim < 0) lim = 0;
             for (uint32_t c = 0; c < K; c++) {
                 chain_t *x = &ch[c];

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp; cd "$ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rp_x -- python3 tools/repeat_probe.py $1 > /dev/null 2>&1
 f=$(ls gpurun_out/rp_x/*/*kernel_stats.csv | head -1)
 python3 - "$f" <<PY
