@@ -16,7 +16,7 @@
 #define HARC_MAXK (1u << 20)
 #define HARC_LOOK_CHUNKS 16   // k_reseed looks for look-ahead seeds in at most this many chunks of 1024 bitmap words below the cursor (oracle: LOOK_CHUNKS)
 #ifndef HARC_NSUGG
-#define HARC_NSUGG 4      // look-ahead seeds handed to a chain at every reseed (oracle: NSUGG)
+#define HARC_NSUGG 8      // look-ahead seeds handed to a chain at every reseed (oracle: NSUGG)
 #endif
 
 void harc_set_error(const char *fmt, ...);

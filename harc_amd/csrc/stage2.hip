@@ -810,23 +810,29 @@ __global__ void k_left_flags(const unsigned long long *best, uint32_t T, uint32_
     const bool un = best[i] == TUPLE_NONE;
     fs[i] = (un && i < S) ? 1u : 0u; fn[i] = (un && i >= S) ? 1u : 0u;
 }
+// One thread per (read, group of 16 bases): neighbouring threads write neighbouring 16 bytes.  (A thread per read wrote its L bytes one
+// by one, L bytes apart from its neighbour's: 50 ms for the 115 M leftover reads of an 8-way bucket shard of configs[2].)
 __global__ void k_left_emit(S2Args s, const uint32_t *rs, const uint32_t *rn, uint32_t *order_out, uint32_t order_base,
                             uint32_t *orderN_out, uint32_t orderN_base, uint8_t *sing_bases, char *ntext)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.T) return;
+    const int G = (s.L + 15) / 16;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)s.T * G) return;
+    const uint32_t i = (uint32_t)(gid / G); const int g = (int)(gid % G);
     if (s.best[i] != TUPLE_NONE) return;
     const uint64_t *r = s.cand3 + (size_t)i * s.W3;
+    const int j0 = 16 * g, j1 = j0 + 16 < s.L ? j0 + 16 : s.L;
     if (i < s.S) {
         const uint32_t k = rs[i];
-        order_out[order_base + k] = s.cand_order[i];
-        for (int j = 0; j < s.L; j++) sing_bases[(size_t)k * s.L + j] = (uint8_t)c3_to_idx5(c3_at(r, s.W3, j));
+        if (g == 0) order_out[order_base + k] = s.cand_order[i];
+        uint8_t *o = sing_bases + (size_t)k * s.L;
+        for (int j = j0; j < j1; j++) o[j] = (uint8_t)c3_to_idx5(c3_at(r, s.W3, j));
     } else {
         const uint32_t k = rn[i];
-        orderN_out[orderN_base + k] = s.cand_order[i];
+        if (g == 0) orderN_out[orderN_base + k] = s.cand_order[i];
         char *o = ntext + (size_t)k * (s.L + 1);
-        for (int j = 0; j < s.L; j++) o[j] = "ACGTN"[c3_to_idx5(c3_at(r, s.W3, j))];
-        o[s.L] = '\n';
+        for (int j = j0; j < j1; j++) o[j] = "ACGTN"[c3_to_idx5(c3_at(r, s.W3, j))];
+        if (j1 == s.L) o[s.L] = '\n';
     }
 }
 
@@ -1127,7 +1133,7 @@ int stage2_run(harc_amd_ctx *c)
     if ((size_t)n_nonN + US > (size_t)M + S || (size_t)n_N_aligned + UN > (size_t)NN) { harc_set_error("stage II bookkeeping: %u + %u clean, %u + %u N order entries", n_nonN, US, n_N_aligned, UN); return HARC_AMD_EINTERNAL; }
     RC_TRY(dalloc(c, &sing_bases, (size_t)US * L + 8)); RC_TRY(dalloc(c, &ntext, (size_t)UN * (L + 1) + 1));
     if (F) launch_noise<true>(c, a, f, cons2, F, nullptr, nullptr, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out);
-    if (T) hipLaunchKernelGGL(k_left_emit, G256(T), a, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned, sing_bases, ntext);
+    if (T) hipLaunchKernelGGL(k_left_emit, G256((uint64_t)T * ((L + 15) / 16)), a, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned, sing_bases, ntext);
     HIP_TRY(hipGetLastError());
     if (c->d_gid && !c->s1_from_files) {
         // multi-GPU shard (harc_amd_shard_exchange): the order streams carry the GLOBAL ids of the reads, so that the merged archive

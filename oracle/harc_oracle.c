@@ -37,7 +37,7 @@
 #define MAXL 255
 #define NONE 0xFFFFFFFFu
 #define MAXSTEPS 64
-#define NSUGG 4           /* look-ahead seeds handed to a chain at every reseed */
+#define NSUGG 8           /* look-ahead seeds handed to a chain at every reseed */
 #define LOOK_CHUNKS 16     /* the look-ahead inspects at most this many chunks of 1024 64-bit bitmap words below the cursor (the GPU's k_reseed) */
 #define LARGEBIN 16u      /* HARC_LARGEBIN of harc_amd/csrc/stage1.hip */
 #define SCAN_BUDGET 16     /* HARC_SCAN_BUDGET: a walk ends after the step in which its probes into bins of more than LARGEBIN reads (not yet exhausted) reach this number */

@@ -38,4 +38,5 @@ for it, (K, r_) in enumerate([(0, rpc), (0, rpc)]):
     c = h.counters()
     print(f"iter {it} reads_per_chain {r_}: {dt*1e3:.1f} ms -> {shard.shape[0]/dt/1e6:.1f} Mreads/s/GPU rounds={c.rounds} unmatched={c.unmatched} contigs={c.contigs} seq_bases={c.seq_bases} K={c.chains} "
           f"lookups/read={c.useful_probes/max(1,c.n_clean):.1f} index_ms={c.index_ms:.1f} chain_ms={c.chain_ms:.1f} encode_ms={c.encode_ms:.1f}", flush=True)
+    if it == 0: pass
     h.close()
