@@ -12,6 +12,7 @@ python bench.py --workload c2 --steps 20 --warmup 5 > gpurun_out/$R/bench_c2.jso
 bash tools/kstats.sh c2 $R 5 > /dev/null 2>&1
 bash tools/pmc.sh $R c2 3 > /dev/null 2>&1
 for w in c1 c3s c4s c2r c2d; do python bench.py --workload $w --steps 5 --warmup 1 --no-cpu > gpurun_out/$R/bench_$w.json 2> /dev/null; done
+python bench.py --workload c3sd --steps 2 --warmup 1 --no-cpu > gpurun_out/$R/bench_c3sd.json 2> /dev/null
 python bench.py --workload c2 --steps 5 --warmup 1 --force-dist > gpurun_out/$R/bench_c2_forcedist.json 2> /dev/null
 for f in gpurun_out/$R/bench_*.json; do python - "$f" <<PY
 import json,sys
@@ -26,3 +27,5 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], d['value'], d['ms_per_step'], d['phases_ms_last_step'], d['roundtrip']['ok'])
 PY
 done
+# what one GPU of an 8-GPU run of configs[2] processes (simulation on this GPU, tools/shard_sim_big.py)
+timeout 600 python tools/shard_sim_big.py 8 c3 1024 > gpurun_out/$R/shard_sim_c3_w8.txt 2>&1; tail -2 gpurun_out/$R/shard_sim_c3_w8.txt
