@@ -892,9 +892,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
             uint32_t ncb = 0;                                             // candidates this lane tests in this batch
             bool big = false; uint32_t b_cnt = 0; uint64_t b_slot = 0;   // a bin too large for one lane: scanned by the whole wave below
             uint2 b_lt = make_uint2(0, 0);                               // COOP: its row of largetab, fetched by the lane that found it (all bins of the batch in ONE round trip)
-            uint32_t mrd[NW];
-#pragma unroll
-            for (int k = 0; k < NW; k++) mrd[k] = 0;
+            uint32_t mrd[NW];                                             // only the lane that wins has loaded them, and only it reads them
             if (p < bend && cap) {
                 const uint2 pi = s_pinfo[p];
                 j = (int)(pi.x >> 16); dir = (int)((pi.x >> 13) & 1);
