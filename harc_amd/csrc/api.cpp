@@ -151,6 +151,10 @@ extern "C" int harc_amd_create(const harc_amd_params *params, harc_amd_ctx **out
     c->W3 = (3 * params->readlen + 63) / 64;
     memset(&c->C, 0, sizeof c->C);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; harc_set_error("hipStreamCreate failed"); return HARC_AMD_ENODEVICE; }
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) {
+        if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+        (void)hipStreamDestroy(c->stream); delete c; harc_set_error("hipStreamCreate failed"); return HARC_AMD_ENODEVICE;
+    }
     *out = c;
     return HARC_AMD_OK;
 }
@@ -160,11 +164,14 @@ extern "C" void harc_amd_destroy(harc_amd_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->P.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); }
     delete c->comm; c->comm = nullptr;
     for (void *p : c->owned) (void)hipFree(p);
     for (auto &k : c->pool) (void)hipFree(k.base);
     for (auto &k : c->harena) (void)hipHostFree(k.base);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     delete c;
 }
 

@@ -86,6 +86,8 @@ struct harc_amd_ctx {
     harc_amd_params P;
     int W = 0, W3 = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;     // device -> host copies that run beside the kernels of `stream` (stage II: read_seq)
+    hipEvent_t ev_copy = nullptr;
     size_t dev_bytes = 0, dev_peak = 0;    // raw allocations + pool high-water mark
     std::vector<void *> owned;             // raw allocations (inputs, rocPRIM scratch), freed in destroy
     std::map<void *, size_t> sizes;

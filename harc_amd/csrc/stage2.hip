@@ -988,6 +988,9 @@ int stage2_run(harc_amd_ctx *c)
     c->C.contigs = nC; c->C.seq_bases = total;
 
     // ---- consensus + realignment proposals
+    std::vector<uint64_t> sh_col(E + 1, total), seq_off(E, 0), seq_nb(E, 0), seq_tl(E, 0);
+    uint8_t *h_seq = nullptr;
+    struct CopyJoin { hipStream_t s; ~CopyJoin() { (void)hipStreamSynchronize(s); } } copy_join{ c->copy_stream };   // on every way out: nothing of this run is still in flight
     uint8_t *cons = nullptr; RC_TRY(dalloc(c, &cons, (size_t)total + 8));
     a.cons = cons;
     uint64_t *cons2 = nullptr;
@@ -1004,6 +1007,29 @@ int stage2_run(harc_amd_ctx *c)
         hipLaunchKernelGGL(k_consensus, dim3(ntiles), dim3(256), (size_t)CCHUNK * (W * 8 + 4), c->stream, a, (const uint32_t *)u1, (const unsigned long long *)cinfo, T ? 1 : 0,
                            (const uint32_t *)tlo, (const uint32_t *)thi);
         hipLaunchKernelGGL(k_pack_cons2, G256(ncw), (const uint8_t *)a.cons, total, ncw, cons2);
+        {   // read_seq (packbits, encoder.cpp:527-548) is final here -- the realignment below does not touch the consensus -- and the shard
+            // boundaries on the column axis follow from gstart alone: it is packed now and goes to the host on the copy stream while the
+            // realignment, the merge and the noise kernels run (the largest stream: a quarter of a byte per consensus base)
+            for (uint32_t e = 0; e <= E; e++) {
+                const uint64_t st = (uint64_t)e * a.q; const uint32_t i = e == E ? M : (uint32_t)(st > M ? M : st);
+                if (i >= M) { sh_col[e] = total; continue; }
+                HIP_TRY(hipMemcpyAsync(&sh_col[e], gstart + i, 8, hipMemcpyDeviceToHost, c->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            uint64_t soff = 0;
+            for (uint32_t e = 0; e < E; e++) { const uint64_t cc = sh_col[e + 1] - sh_col[e]; seq_nb[e] = cc / 4; seq_tl[e] = cc % 4; seq_off[e] = soff; soff += (seq_nb[e] + seq_tl[e] + 15) & ~15ull; }
+            uint8_t *seqpk = nullptr; RC_TRY(dalloc(c, &seqpk, (size_t)soff + 64));
+            for (uint32_t e = 0; e < E; e++) {
+                const uint64_t c0 = sh_col[e];
+                if (seq_nb[e]) hipLaunchKernelGGL(k_pack2_bytes, G256(seq_nb[e]), cons + c0, seq_nb[e], seqpk + seq_off[e]);
+                if (seq_tl[e]) hipLaunchKernelGGL(k_bases_to_ascii, G256(seq_tl[e]), cons + c0 + 4 * seq_nb[e], seq_tl[e], seqpk + seq_off[e] + seq_nb[e]);
+            }
+            HIP_TRY(hipGetLastError());
+            RC_TRY(harc_host_alloc(c, (void **)&h_seq, (size_t)soff));
+            HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+            if (soff) HIP_TRY(hipMemcpyAsync(h_seq, seqpk, (size_t)soff, hipMemcpyDeviceToHost, c->copy_stream));
+        }
         if (T) {
             const dim3 rg((unsigned)((total + RTILE - 1) / RTILE));
             switch (W) {
@@ -1149,32 +1175,28 @@ int stage2_run(harc_amd_ctx *c)
     }
 
     // ---- shard boundaries in final-list / column / noise coordinates
-    std::vector<uint32_t> sh_i(E + 1), sh_f(E + 1); std::vector<uint64_t> sh_col(E + 1), sh_nm(E + 1);
+    std::vector<uint32_t> sh_i(E + 1), sh_f(E + 1); std::vector<uint64_t> sh_nm(E + 1);
     for (uint32_t e = 0; e <= E; e++) { uint64_t st = (uint64_t)e * a.q; sh_i[e] = (uint32_t)(st > M ? M : st); }
     sh_i[E] = M;
     for (uint32_t e = 0; e <= E; e++) {
-        if (sh_i[e] >= M) { sh_f[e] = F; sh_col[e] = total; sh_nm[e] = nmtot; continue; }
+        if (sh_i[e] >= M) { sh_f[e] = F; sh_nm[e] = nmtot; continue; }
         HIP_TRY(hipMemcpyAsync(&sh_f[e], fidx_orig + sh_i[e], 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&sh_col[e], gstart + sh_i[e], 8, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (uint32_t e = 0; e <= E; e++) if (sh_i[e] < M) HIP_TRY(hipMemcpyAsync(&sh_nm[e], nmoff + sh_f[e], 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
 
     // ---- packbits per shard into ONE device buffer, then a handful of device -> pinned-host copies; per-shard streams are slices
-    std::vector<uint64_t> seq_off(E), seq_nb(E), seq_tl(E), rev_off(E), rev_nb(E), rev_tl(E);
+    std::vector<uint64_t> rev_off(E), rev_nb(E), rev_tl(E);
     uint64_t poff = 0;
     for (uint32_t e = 0; e < E; e++) {
-        const uint64_t cc = sh_col[e + 1] - sh_col[e]; seq_nb[e] = cc / 4; seq_tl[e] = cc % 4; seq_off[e] = poff; poff += (seq_nb[e] + seq_tl[e] + 15) & ~15ull;
         const uint64_t ff = sh_f[e + 1] - sh_f[e]; rev_nb[e] = ff / 8; rev_tl[e] = ff % 8; rev_off[e] = poff; poff += (rev_nb[e] + rev_tl[e] + 15) & ~15ull;
     }
     const uint64_t sing_nb = (uint64_t)US * L / 4, sing_tl = (uint64_t)US * L % 4, sing_off = poff;
     poff += (sing_nb + sing_tl + 15) & ~15ull;
     uint8_t *packed = nullptr; RC_TRY(dalloc(c, &packed, (size_t)poff + 64));
     for (uint32_t e = 0; e < E; e++) {
-        const uint64_t c0 = sh_col[e]; const uint32_t f0 = sh_f[e];
-        if (seq_nb[e]) hipLaunchKernelGGL(k_pack2_bytes, G256(seq_nb[e]), cons + c0, seq_nb[e], packed + seq_off[e]);
-        if (seq_tl[e]) hipLaunchKernelGGL(k_bases_to_ascii, G256(seq_tl[e]), cons + c0 + 4 * seq_nb[e], seq_tl[e], packed + seq_off[e] + seq_nb[e]);
+        const uint32_t f0 = sh_f[e];
         if (rev_nb[e]) hipLaunchKernelGGL(k_pack1_bytes, G256(rev_nb[e]), rcb + f0, rev_nb[e], packed + rev_off[e]);
         if (rev_tl[e]) HIP_TRY(hipMemcpyAsync(packed + rev_off[e] + rev_nb[e], rcb + f0 + 8 * rev_nb[e], rev_tl[e], hipMemcpyDeviceToDevice, c->stream));
     }
@@ -1193,7 +1215,7 @@ int stage2_run(harc_amd_ctx *c)
     if (n_ntext) HIP_TRY(hipMemcpyAsync(h_ntext, ntext, n_ntext, hipMemcpyDeviceToHost, c->stream));
     for (uint32_t e = 0; e < E; e++) {
         const uint32_t f0 = sh_f[e], f1 = sh_f[e + 1];
-        out_slice(c, HARC_AMD_S2_SEQ, e, h_packed + seq_off[e], seq_nb[e]); out_slice(c, HARC_AMD_S2_SEQ_TAIL, e, h_packed + seq_off[e] + seq_nb[e], seq_tl[e]);
+        out_slice(c, HARC_AMD_S2_SEQ, e, h_seq + seq_off[e], seq_nb[e]); out_slice(c, HARC_AMD_S2_SEQ_TAIL, e, h_seq + seq_off[e] + seq_nb[e], seq_tl[e]);
         out_slice(c, HARC_AMD_S2_REV, e, h_packed + rev_off[e], rev_nb[e]); out_slice(c, HARC_AMD_S2_REV_TAIL, e, h_packed + rev_off[e] + rev_nb[e], rev_tl[e]);
         out_slice(c, HARC_AMD_S2_POS, e, h_pos + f0, f1 - f0);
         out_slice(c, HARC_AMD_S2_NOISE, e, h_noise + sh_nm[e] + f0, (sh_nm[e + 1] + f1) - (sh_nm[e] + f0));
@@ -1206,6 +1228,7 @@ int stage2_run(harc_amd_ctx *c)
     unsigned long long big = 0;
     HIP_TRY(hipMemcpyAsync(&big, d_big, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));                // read_seq has arrived
     c->C.bins_over_maxsearch = big;
     c->C.aligned_singletons = (uint64_t)S - US;                   // encoder.cpp:506-508
     c->C.aligned_N = (uint64_t)NN - UN;
