@@ -1196,17 +1196,19 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
 // unclaimed ids below the cursor (not claimed; the cursor moves below them, so they are this chain's until it takes them or finds
 // them taken by a walk), which k_steps uses when the chain is stuck again.
 // The kernel only ranks the chains and finds the ids; every chain applies its own seed at the top of the next k_steps.
-__global__ __launch_bounds__(1024) void k_reseed(S1Args s)
+// NT threads: 1024, or 256 with few chains (the block scans and barriers of sixteen waves were most of the kernel's 11.5 us on a
+// 2048-chain input: a tenth of a super-round).  The look-ahead range is HARC_LOOK_CHUNKS x 1024 words either way.
+template <int NT> __global__ __launch_bounds__(NT) void k_reseed(S1Args s)
 {
     __shared__ uint32_t sm[20];
     __shared__ long long scursor;
     const int t = threadIdx.x;
     // chains per thread, contiguous and a multiple of 8 so that the need bytes are read as 64-bit words (the array is padded with zeros)
-    const uint32_t chunk = (((s.K + 1023) / 1024) + 7) & ~7u;
+    const uint32_t chunk = (((s.K + NT - 1) / NT) + 7) & ~7u;
     const uint32_t c0 = (uint32_t)t * chunk;
     uint32_t mycnt = 0;
     if (c0 < s.K) for (uint32_t c = c0; c < c0 + chunk; c += 8) mycnt += (uint32_t)__popcll(*(const unsigned long long *)(s.need + c));
-    uint32_t R; const uint32_t rbase = block_excl_scan_u32<1024>(mycnt, sm, &R);
+    uint32_t R; const uint32_t rbase = block_excl_scan_u32<NT>(mycnt, sm, &R);
     if (R == 0) return;
     if (mycnt) {                                                  // rank of every chain that wants a seed, ascending chain id
         uint32_t r = rbase;
@@ -1225,7 +1227,7 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
             bits = ~s.claimed[wi];
             if (wi == cwd) { const int top = (int)(cursor & 63); if (top < 63) bits &= (2ULL << top) - 1ULL; }
         }
-        uint32_t total; const uint32_t off = block_excl_scan_u32<1024>((uint32_t)__popcll(bits), sm, &total);
+        uint32_t total; const uint32_t off = block_excl_scan_u32<NT>((uint32_t)__popcll(bits), sm, &total);
         unsigned long long newclaim = 0; uint32_t k = 0;
         while (bits && assigned + off + k < R) {
             const int b = 63 - __clzll((long long)bits);
@@ -1238,7 +1240,7 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
         if (newclaim) s.claimed[wi] |= newclaim;                  // this workgroup is the only writer of the bitmap in this launch
         __syncthreads();
         if (assigned + total >= R) { assigned = R; cursor = scursor; }
-        else { assigned += total; cursor = (cwd - 1023) * 64 - 1; }
+        else { assigned += total; cursor = (cwd - (NT - 1)) * 64 - 1; }
         __syncthreads();
     }
     // look-ahead: the next assigned * HARC_NSUGG unclaimed ids below the cursor; nothing is claimed, the cursor moves below them
@@ -1252,15 +1254,15 @@ __global__ __launch_bounds__(1024) void k_reseed(S1Args s)
     // while few chains reseed per super-round; a minimizer-bucket shard of a multi-GPU run leaves a third of its reads unmatched, tens
     // of thousands of chains ask for seeds every round, and those that got no look-ahead seed walked ONE read per round: 1296 rounds
     // instead of ~400 on an 8-way shard of configs[2].
-    for (int ch = 0; ch < HARC_LOOK_CHUNKS && got < want; ch++) {
-        const long long cwd = (look >> 6) - 1024LL * ch, wi = cwd - t;
+    for (int ch = 0; ch < HARC_LOOK_CHUNKS * (1024 / NT) && got < want; ch++) {
+        const long long cwd = (look >> 6) - (long long)NT * ch, wi = cwd - t;
         if (cwd < 0) break;
         unsigned long long bits = 0;
         if (wi >= 0) {
             bits = ~s.claimed[wi];
             if (ch == 0 && wi == cwd) { const int top = (int)(look & 63); if (top < 63) bits &= (2ULL << top) - 1ULL; }
         }
-        uint32_t total; const uint32_t off = block_excl_scan_u32<1024>((uint32_t)__popcll(bits), sm, &total);
+        uint32_t total; const uint32_t off = block_excl_scan_u32<NT>((uint32_t)__popcll(bits), sm, &total);
         const uint32_t take = total >= want - got ? want - got : total;
         uint32_t k = 0;
         while (bits && off + k < take) {
@@ -1673,7 +1675,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
             else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve<32>), dim3((K + 7) / 8), dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((k_resolve<64>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
-            hipLaunchKernelGGL(k_reseed, dim3(1), dim3(1024), 0, c->stream, a);
+            if (K <= 4096) hipLaunchKernelGGL((k_reseed<256>), dim3(1), dim3(256), 0, c->stream, a);
+            else hipLaunchKernelGGL((k_reseed<1024>), dim3(1), dim3(1024), 0, c->stream, a);
             if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge);
             launches++;
         }
