@@ -40,6 +40,7 @@ struct S1Args {
     int nsugg_per_seed;              // look-ahead seeds per reseed (HARC_NSUGG; 0 disables them: experiments only, the oracle uses the same value)
     LogRec *log;                     // [N] indexed by read id: every read is emitted exactly once, by exactly one chain
     long long *cursor;               // reorder.cpp `remainingpos`, one for all chains
+    unsigned long long *coopcnt;     // [HARC_COOPCNT] walks handed to the cooperative kernel so far (the host picks its workgroup size from them)
     unsigned long long *stats;       // [0] unmatched [1] conflicts [2] active chains [3] probes [4] candidates
     const uint16_t *probe_tab;       // the probes of one chain step in priority order: shift | dir<<8 | dict<<9
     const uint32_t *lds_tab;         // mask rows + probe descriptors as k_steps wants them in LDS (k_steps_tables)
@@ -56,6 +57,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { for (int o = 32; 
 #define TICK(k) do { } while (0)
 #endif
 enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_USEFUL = 5, ST_CANDS_SEQ = 6, ST_N = 8 };
+#define HARC_COOPCNT 64   // counters of the walks handed to the cooperative kernel, spread over as many words (one word serialised 1300 atomics per round: +10 us)
 
 // ------------------------------------------------------------------------------------------------ packing kernels
 // ASCII -> std::bitset<2L> words (reorder.cpp:184-209). One thread per (read, word).
@@ -604,7 +606,7 @@ static_assert(sizeof(WgCmd) <= HARC_WGCMD_BYTES, "HARC_WGCMD_BYTES too small");
 // took earlier in this super-round (cmd->own).  One chunk of 256 entries = ONE round trip to HBM (ids and the bin-ordered reads
 // together) and ONE barrier: the waves post their hit masks -- and, above maxsearch, which of their entries count for the window -- in
 // the same exchange (double-buffered); only the chunk in which the window closes needs the exact ranks and a second exchange.
-template <int W> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int role, int lane, const uint32_t *const *ids, const uint64_t *mirror,
+template <int W, int NWV> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int role, int lane, const uint32_t *const *ids, const uint64_t *mirror,
                                                             const uint32_t *rowF, const uint32_t *s_mask, uint32_t *rdl, int maxsearch, int maxmatch, int thresh)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW, CH = HARC_SCAN_CH;
@@ -624,7 +626,7 @@ template <int W> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int rol
         r.iters++;
 #pragma unroll
         for (int c = 0; c < CH; c++) {
-            const uint32_t off = 256u * (uint32_t)c + 64u * (uint32_t)role + (uint32_t)lane;
+            const uint32_t off = 64u * NWV * (uint32_t)c + 64u * (uint32_t)role + (uint32_t)lane;
             valid[c] = off < pos; rid[c] = 0; own[c] = false;
             if (valid[c]) { const uint32_t at = pos - 1 - off; rid[c] = oids[ids0 + at]; load_read32<W>(mirror, m0 + at, mrd[c]); }
         }
@@ -670,7 +672,7 @@ template <int W> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int rol
 #pragma unroll
                 for (int c = 0; c < CH; c++) {
                     before[c] = total;
-                    for (int w = 0; w < 4; w++) { const int x = __popcll(cmd->um[par][c][w]); if (w < role) before[c] += x; total += x; }
+                    for (int w = 0; w < NWV; w++) { const int x = __popcll(cmd->um[par][c][w]); if (w < role) before[c] += x; total += x; }
                 }
                 if (seen + total > maxsearch) {                    // the window closes inside these chunks: exact ranks, once more
                     par ^= 1;
@@ -687,7 +689,7 @@ template <int W> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int rol
             int winc = -1, winw = 0; unsigned long long winm = 0;
 #pragma unroll
             for (int c = CH - 1; c >= 0; c--)
-                for (int w = 3; w >= 0; w--) { const unsigned long long h = cmd->hit[par][c][w]; if (h) { winc = c; winw = w; winm = h; } }
+                for (int w = NWV - 1; w >= 0; w--) { const unsigned long long h = cmd->hit[par][c][w]; if (h) { winc = c; winw = w; winm = h; } }
             first = false;
             par ^= 1;
             if (winc >= 0) {                                       // the highest id: first chunk, first wave, first lane
@@ -706,7 +708,7 @@ template <int W> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd, int rol
             }
         }
         if (!fast) seen += total;
-        pos -= pos > 256u * CH ? 256u * CH : pos;
+        pos -= pos > 64u * NWV * CH ? 64u * NWV * CH : pos;
     }
     __syncthreads();                                               // the winner's words are in place; the command block is free for the next scan
     return r;
@@ -738,7 +740,10 @@ template <int W> __global__ void k_steps_tables(S1Args s, uint32_t *out)
     }
 }
 
-template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_bounds__(256, COOP ? HARC_COOP_WAVES : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? 1 : 0))) void k_steps(S1Args s)
+// NWV (COOP only): waves per workgroup = the walking wave + NWV - 1 helpers that share its scans (64 NWV candidates per round trip).  Few
+// walks per super-round are bound by the longest one: 4 waves.  More walks than the chip holds workgroups are bound by wave slots, most of
+// which helpers idle in: fewer helpers, more walkers (stage1_run_w picks it from the walks of the last rounds; what is computed is the same).
+template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global__ __launch_bounds__(256, COOP ? HARC_COOP_WAVES : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? 1 : 0))) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
     extern __shared__ uint32_t lds[];
@@ -759,11 +764,11 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
     }
     {   // the whole workgroup, before any wave leaves: mask rows and probe descriptors (k_steps_tables) -> LDS
         const int nm = 2 * s.maxmatch * MROW;
-        for (int i = threadIdx.x; i < nm; i += 256) s_mask[i] = s.lds_tab[i];
+        for (int i = threadIdx.x; i < nm; i += 64 * NWV) s_mask[i] = s.lds_tab[i];
         const uint2 *const pt = reinterpret_cast<const uint2 *>(s.lds_tab + nm);
-        for (int i = threadIdx.x; i < s.nprobe; i += 256) s_pinfo[i] = pt[i];
-        for (int i = threadIdx.x; i < 4 * 2 * ROW; i += 256) s_rows[i] = 0u;
-        for (int i = threadIdx.x; i < 4 * 8 * NW; i += 256) s_tmp[i] = 0u;
+        for (int i = threadIdx.x; i < s.nprobe; i += 64 * NWV) s_pinfo[i] = pt[i];
+        for (int i = threadIdx.x; i < 4 * 2 * ROW; i += 64 * NWV) s_rows[i] = 0u;
+        for (int i = threadIdx.x; i < 4 * 8 * NW; i += 64 * NWV) s_tmp[i] = 0u;
         __syncthreads();
     }
     if (COOP && role != 0) {                                      // helpers: wait for a scan, take part, until the walk is over
@@ -772,7 +777,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
         for (;;) {
             __syncthreads();
             if (cmd->op == 0) break;
-            const WgResult r = wg_scan<W>(cmd, role, lane, idp, s.mirror, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh);
+            const WgResult r = wg_scan<W, NWV>(cmd, role, lane, idp, s.mirror, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh);
             hnc += r.nc;
         }
         hnc = wave_sum_u32(hnc);
@@ -1025,7 +1030,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
                     }
                     __syncthreads();                                           // the helpers start
                     const uint32_t *const idp[2] = { s.ids[0], s.ids[1] };
-                    const WgResult wr = wg_scan<W>(cmd, 0, lane, idp, s.mirror, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh);
+                    const WgResult wr = wg_scan<W, NWV>(cmd, 0, lane, idp, s.mirror, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh);
                     dbg_iter += wr.iters; dbg_surv += wr.tests; nc += wr.nc; ncu += wr.nc;
                     const int besthit = wr.besthit;
                     if (besthit < 64) { found = cmd->found; fj = wr.fj; fdir = wr.fdir; }
@@ -1112,6 +1117,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false> __global__ __launch_b
         h.pad0 = ((uint32_t)lastp & 0xFFFFu) | ((uint32_t)spos << 16);
         h.flags = needseed ? (h.flags | CH_NEEDSEED) : (h.flags & ~CH_NEEDSEED);
         h.flags = defer ? (h.flags | CH_COOP) : (h.flags & ~CH_COOP);
+        if (!COOP && defer) atomicAdd(&s.coopcnt[c & (HARC_COOPCNT - 1)], 1ULL);
         s.hdr[c] = h;
     }
 }
@@ -1485,7 +1491,7 @@ struct S1Resources {
     int init()
     {
         for (auto &x : e) HIP_TRY(hipEventCreate(&x));
-        HIP_TRY(hipHostMalloc((void **)&h_stats, ST_N * 8));
+        HIP_TRY(hipHostMalloc((void **)&h_stats, (ST_N + HARC_COOPCNT) * 8));
         return HARC_AMD_OK;
     }
     // the pair for the next launch; its previous use (RING launches ago) is read first
@@ -1610,7 +1616,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.steps, (size_t)K * 64)); RC_TRY(dalloc(c, &a.need, (size_t)K + 8192 + 1024));
     RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + HARC_NSUGG))); RC_TRY(dalloc(c, &a.needrank, (size_t)K + 16)); RC_TRY(dalloc(c, &a.rmeta, 4)); RC_TRY(dalloc(c, &a.cst2, (size_t)K + 1)); RC_TRY(dalloc(c, &a.sugg, (size_t)K * HARC_NSUGG));
     RC_TRY(dalloc(c, &a.log, (size_t)N + 1));
-    RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N));
+    RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N)); RC_TRY(dalloc(c, &a.coopcnt, HARC_COOPCNT)); HIP_TRY(hipMemsetAsync(a.coopcnt, 0, HARC_COOPCNT * 8, c->stream));
     RC_TRY(dalloc(c, &a.cstat, K)); HIP_TRY(hipMemsetAsync(a.cstat, 0, (size_t)K * 16, c->stream));
     RC_TRY(dalloc(c, &a.dbg, 48)); HIP_TRY(hipMemsetAsync(a.dbg, 0, 48 * 8, c->stream));
     unsigned long long *const dbg_ptr = a.dbg;
@@ -1661,6 +1667,12 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const bool prof = P.profile != 0;
     const bool dense = getenv("HARC_AMD_DENSE") ? atoi(getenv("HARC_AMD_DENSE")) != 0 : K >= 49152;     // see HARC_STEPS_WAVES
     uint64_t rounds = 0, launches = 0;
+    int coop_forced = getenv("HARC_AMD_COOP_WAVES") ? atoi(getenv("HARC_AMD_COOP_WAVES")) : 0;     // tests: 1, 2 or 4 waves per cooperative workgroup
+    if (coop_forced != 1 && coop_forced != 2 && coop_forced != 4) coop_forced = 0;
+    int coop_waves = coop_forced ? coop_forced : 4;
+    unsigned long long coop_seen = 0;
+    double coop_slots = 1024.0;
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, P.device) == hipSuccess && pr.multiProcessorCount > 0) coop_slots = 4.0 * pr.multiProcessorCount; }
     const int batch = getenv("HARC_AMD_BATCHSYNC") ? atoi(getenv("HARC_AMD_BATCHSYNC")) : 8;
     for (;;) {
         for (int r = 0; r < batch; r++) {
@@ -1671,7 +1683,11 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             else hipLaunchKernelGGL((k_steps<W, false, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             if (prof) HIP_TRY(hipEventRecord(pair[1], c->stream));
             // the steps that have to scan a large bin (none without such bins: the launch is skipped)
-            if (nlarge) hipLaunchKernelGGL((k_steps<W, true, true>), dim3(K), dim3(256), lds_bytes, c->stream, a);
+            if (nlarge) {
+                if (coop_waves == 1) hipLaunchKernelGGL((k_steps<W, true, true, false, 1>), dim3(K), dim3(64), lds_bytes, c->stream, a);
+                else if (coop_waves == 2) hipLaunchKernelGGL((k_steps<W, true, true, false, 2>), dim3(K), dim3(128), lds_bytes, c->stream, a);
+                else hipLaunchKernelGGL((k_steps<W, true, true>), dim3(K), dim3(256), lds_bytes, c->stream, a);
+            }
             if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
             else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve<32>), dim3((K + 7) / 8), dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((k_resolve<64>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
@@ -1682,10 +1698,21 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         }
         rounds += batch;
         HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
+        if (nlarge) HIP_TRY(hipMemcpyAsync(h_stats + ST_N, a.coopcnt, HARC_COOPCNT * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
         if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] round %llu: %llu chains alive\n", (unsigned long long)rounds, h_stats[ST_ACTIVE]);
         if (h_stats[ST_ACTIVE] == 0) break;
+        if (nlarge && coop_forced == 0) {
+            // cooperative walks per super-round over the last rounds against the workgroups of four waves the chip holds (4 per CU): well beyond
+            // that the kernel is bound by wave slots, and helpers hold most of them idle
+            unsigned long long tot = 0;
+            for (int k = 0; k < HARC_COOPCNT; k++) tot += h_stats[ST_N + k];
+            const double per_round = (double)(tot - coop_seen) / (double)batch;
+            coop_seen = tot;
+            // measured: 6800 walks per round (c3sd) 417 / 373 / 392 ms with 4 / 2 / 1 waves; 1300 walks (c2d, c2r) 112 / 133 / 194 ms
+            coop_waves = per_round > 3.0 * coop_slots ? 2 : 4;
+        }
         if (rounds > (uint64_t)N * 2 + 1024) { harc_set_error("stage I did not converge after %llu rounds", (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
     }
     HIP_TRY(hipEventRecord(e2, c->stream));
