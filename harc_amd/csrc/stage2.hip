@@ -40,6 +40,7 @@ struct S2Args {
     const uint64_t *cand2, *candN;     // T x W: the candidates in the same 2-bit code (N -> 0) and their N masks (both bits of the field set)
     uint4 *events;                     // probes that hit a bin larger than maxsearch: {tuple lo, tuple hi, dict, slot index lo} (+ slot hi in w>>?)
     unsigned int *nevents; uint32_t maxevents;
+    int trace;                         // HARC_AMD_TRACE: count the events that look in a window pass
 };
 
 // ---------------------------------------------------------------------------------------------- small device helpers
@@ -581,26 +582,38 @@ __global__ void k_ev_rank(uint32_t *seg, uint32_t nev, unsigned int *maxrank)
     for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(r, o, 64); r = x > r ? x : r; }
     if ((threadIdx.x & 63) == 0 && r) atomicMax(maxrank, r);
 }
-__global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, uint32_t *binver0, uint32_t *binver1, uint32_t *lastver,
-                                                     const uint32_t *perm, const uint32_t *rank, uint32_t rlo, uint32_t rhi)
+// Which events have to look again: what an event does is a function of WHICH reads of its bin are claimed before its tuple, so only a
+// claim with an EARLIER tuple on a read of its bin can change it.  binmin[l][first id index of the bin] = (pass stamp, smallest tuple
+// claimed on a read of the bin during that pass), kept with atomicMin on ((~pass) << 40 | tuple): a newer pass always replaces an older
+// entry, inside a pass the smallest tuple stays -- no clearing between passes; two copies by the parity of the pass, so that the claims
+// of the running pass do not replace what the previous one left.  An event that looked (or was validated) in the previous
+// pass and finds no entry of that pass below its own tuple is validated again without touching the bin.  (A version counter per bin made
+// every event of a bin look again whenever ANY claim of the bin moved: once the ranges had settled, 16 more passes of 13 ms over all
+// events of the deep bins while a handful of claims moved between the two dictionaries -- c3sd with another stage-I schedule: 220 ms.)
+#define EV_TBITS 40
+// one event (probe e, at position ei of the pass order), one wave.  validate: an event that looked in the previous pass and finds no earlier
+// claim on its bin since is validated without looking.  Returns whether a claim moved (wave-uniform).
+__device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint32_t e, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
+                                              uint32_t *lastpass, uint32_t pass, uint32_t T1, unsigned long long *swin, bool validate)
 {
-    __shared__ unsigned long long swin[4][HARC_MAXW3];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t ei = blockIdx.x * 4 + wv;
-    if (ei >= nev) return;
-    uint32_t e = ei;
-    if (perm) { const uint32_t r = rank[ei]; if (r < rlo || r >= rhi) return; e = perm[ei]; }
-    const uint32_t lv = lastver[e];
-    if (lv == EV_DONE) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t lp = lastpass[ei];
+    if (lp == EV_DONE) return false;
     const int L = s.L, W3 = s.W3;
     const uint4 ev = s.events[e];
     const unsigned long long tp = (unsigned long long)ev.x | ((unsigned long long)ev.y << 32);
     const uint64_t x = tp >> 2; const int dir = (int)((tp >> 1) & 1), l = (int)(tp & 1);
     const uint32_t st = ev.z, cnt = ev.w;
-    uint32_t *const myver = (l ? binver1 : binver0) + st;
-    const uint32_t ver = __hip_atomic_load(myver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // before anything of the bin is read
-    if (ver == lv) return;
-    if (estart[e] == 0) { if (lane == 0) lastver[e] = EV_DONE; return; }      // every read of the bin was claimed before this event: claims only move to earlier tuples
+    const size_t cur = (size_t)(pass & 1u) * T1, prv = (size_t)((pass - 1u) & 1u) * T1;      // T1 = entries per copy
+    unsigned long long *const mymin = (l ? binmin1 : binmin0) + st;
+    const unsigned long long tmask = (1ULL << EV_TBITS) - 1ULL, stamp = ((unsigned long long)(~pass & 0xFFFFFFu)) << EV_TBITS;
+    if (validate && lp == pass - 1) {                             // looked, or was validated, in the previous pass: anything earlier than this event since?
+        const unsigned long long m = __hip_atomic_load(mymin + prv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool moved = (m >> EV_TBITS) == (unsigned long long)(~(pass - 1) & 0xFFFFFFu) && (m & tmask) < tp;
+        if (!moved) { if (lane == 0) lastpass[ei] = pass; return false; }
+    }
+    if (estart[ei] == 0) { if (lane == 0) lastpass[ei] = EV_DONE; return false; }      // every read of the bin was claimed before this event: claims only move to earlier tuples
+    if (s.trace && lane == 0) atomicAdd(changed + 2, 1u);         // trace only: events that look (one word: it serialises them)
     // 3-bit window words (forward or reverse complement), lanes 0..W3-1 build one word each
     if (lane < W3) {
         const uint8_t *win = s.cons + x;
@@ -612,11 +625,11 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uin
             const int sh = 3 * b - 64 * lane;
             v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
         }
-        swin[wv][lane] = v;
+        swin[lane] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint32_t top = estart[e]; if (top > cnt) top = cnt;
+    uint32_t top = estart[ei]; if (top > cnt) top = cnt;
     uint32_t seen = 0, pos = top; bool ch = false, leading = true;   // wave-uniform
     while (pos > 0 && seen < (uint32_t)s.maxsearch) {             // highest id first
         const bool valid = (uint32_t)lane < pos;
@@ -635,23 +648,77 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uin
         if (un && seen + rank < (uint32_t)s.maxsearch && b > tp) {
             const uint64_t *r = s.cand3 + (size_t)rid * W3;
             int hd = 0;
-            for (int w = 0; w < W3; w++) { hd += __popcll(swin[wv][w] ^ r[w]); if (hd > s.thresh_s) break; }
+            for (int w = 0; w < W3; w++) { hd += __popcll(swin[w] ^ r[w]); if (hd > s.thresh_s) break; }
             if (hd <= s.thresh_s && atomicMin(&s.best[rid], tp) > tp) {               // every passing candidate of the window is taken (encoder.cpp:296-317)
                 ch = true;
-                // the read's bin in the other dictionary sees a new claim too
+                // the read's bin in the other dictionary sees a claim at this tuple too
                 const int ol = 1 - l, off = 3 * s.ds[ol], wi = off >> 6, sh = off & 63;
                 uint64_t okey = r[wi] >> sh;
                 if (sh && wi + 1 < W3) okey |= r[wi + 1] << (64 - sh);
                 if (s.kbits[ol] < 64) okey &= ((uint64_t)1 << s.kbits[ol]) - 1;
                 uint32_t ost = 0, ocnt = 0;
-                if (dict_lookup_b(s.slots[ol], s.cap[ol], okey, &ost, &ocnt) && !(ocnt & SLOT_EMB)) atomicAdd((ol ? binver1 : binver0) + ost, 1u);
+                if (dict_lookup_b(s.slots[ol], s.cap[ol], okey, &ost, &ocnt) && !(ocnt & SLOT_EMB)) atomicMin((ol ? binmin1 : binmin0) + cur + ost, stamp | tp);
             }
         }
         seen += (uint32_t)__popcll(um);
         pos -= pos > 64 ? 64 : pos;
     }
     ch = __ballot(ch) != 0;
-    if (lane == 0) { estart[e] = top; lastver[e] = cnt <= (uint32_t)s.maxsearch ? EV_DONE : ver; if (ch) { atomicAdd(myver, 1u); atomicOr(changed, 1u); } }
+    if (lane == 0) { estart[ei] = top; lastpass[ei] = cnt <= (uint32_t)s.maxsearch ? EV_DONE : pass; if (ch) { atomicMin(mymin + cur, stamp | tp); atomicOr(changed, 1u); } }
+    return ch;
+}
+__global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
+                                                     uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, uint32_t rlo, uint32_t rhi)
+{
+    __shared__ unsigned long long swin[4][HARC_MAXW3];
+    const int wv = threadIdx.x >> 6;
+    const uint32_t ei = blockIdx.x * 4 + wv;                      // estart / lastpass are indexed by the position the wave works at
+    if (ei >= nev) return;
+    uint32_t e = ei;
+    if (perm) { const uint32_t r = rank[ei]; if (r < rlo || r >= rhi) return; e = perm[ei]; }
+    (void)realign_event(s, ei, e, estart, changed, binmin0, binmin1, lastpass, pass, T1, swin[wv], true);
+}
+// The chaser.  All events of a pass look at the state the previous pass left, so a chain of events of one bin each of which acts on what
+// its predecessor just did -- in a deep bin the event next in tuple order inherits the window -- advances ONE link per pass, while every
+// later event of the bin looks again for nothing (c3sd under another stage-I schedule: 22 passes x 340 000 events x 12 ms for 22 claims).
+// After each pass one wave per bin that saw a claim follows the chain in tuple order from the first event behind the smallest tuple
+// claimed, as long as claims keep moving (and a few events beyond).  Which events run when is free (see above): the passes still end
+// with one over everything that changes nothing.
+#define EV_CHASE_QUIET 16
+#define EV_CHASE_MAX 64
+__global__ __launch_bounds__(256) void k_realign_chase(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
+                                                       uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, const uint32_t *seglen, uint32_t rhi)
+{
+    __shared__ unsigned long long swin[4][HARC_MAXW3];
+    const int wv = threadIdx.x >> 6;
+    const uint32_t i0 = blockIdx.x * 4 + wv;
+    if (i0 >= nev || rank[i0] != 0) return;                       // one wave per bin: the first of its events in (bin, tuple) order
+    const uint4 ev0 = s.events[perm[i0]];
+    const int l = (int)(ev0.x & 1u);
+    const unsigned long long m = __hip_atomic_load((l ? binmin1 : binmin0) + (size_t)(pass & 1u) * T1 + ev0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((m >> EV_TBITS) != (unsigned long long)(~pass & 0xFFFFFFu)) return;       // no claim on this bin in the pass that just ran
+    const unsigned long long mt = m & ((1ULL << EV_TBITS) - 1ULL);
+    uint32_t len = seglen[i0]; if (len > rhi) len = rhi;          // only the ranks the passes have reached
+    uint32_t lo = 0, hi = len;                                     // first event of the bin with a tuple above mt
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint4 evm = s.events[perm[i0 + mid]];
+        const unsigned long long tm = (unsigned long long)evm.x | ((unsigned long long)evm.y << 32);
+        if (tm <= mt) lo = mid + 1; else hi = mid;
+    }
+    int quiet = 0;
+    for (uint32_t j = lo, n = 0; j < len && n < EV_CHASE_MAX && quiet < EV_CHASE_QUIET; j++, n++) {
+        const bool ch = realign_event(s, i0 + j, perm[i0 + j], estart, changed, binmin0, binmin1, lastpass, pass, T1, swin[wv], false);
+        quiet = ch ? 0 : quiet + 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+__global__ void k_ev_seglen(const uint32_t *rank, uint32_t nev, uint32_t *seglen)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nev) return;
+    if (i + 1 == nev || rank[i + 1] == 0) seglen[i - rank[i]] = rank[i] + 1;      // written at the bin's first position
 }
 
 __global__ void k_acc_flags(const unsigned long long *best, uint32_t T, uint32_t *flag)
@@ -1060,15 +1127,17 @@ int stage2_run(harc_amd_ctx *c)
                 if (nev > a.maxevents) { harc_set_error("stage II: event count changed between two identical passes (%u > %u)", nev, a.maxevents); return HARC_AMD_EINTERNAL; }
             }
             if (nev) {                                                        // exact sliding-window semantics as a fixed point (k_realign_big)
-                unsigned int *d_changed = nullptr; uint32_t *estart = nullptr, *binver[2] = { nullptr, nullptr }, *lastver = nullptr;
+                unsigned int *d_changed = nullptr; uint32_t *estart = nullptr, *lastver = nullptr; unsigned long long *binmin[2] = { nullptr, nullptr };
+                if (total >> (EV_TBITS - 2)) { harc_set_error("stage II: more than 2^%d consensus columns", EV_TBITS - 2); return HARC_AMD_EINVAL; }
                 RC_TRY(dalloc(c, &d_changed, 4)); RC_TRY(dalloc(c, &estart, (size_t)nev + 1)); RC_TRY(dalloc(c, &lastver, (size_t)nev + 1));
                 HIP_TRY(hipMemsetAsync(estart, 0xFF, ((size_t)nev + 1) * 4, c->stream));
                 HIP_TRY(hipMemsetAsync(lastver, 0xFF, ((size_t)nev + 1) * 4, c->stream));
-                for (int l = 0; l < 2; l++) { RC_TRY(dalloc(c, &binver[l], (size_t)T + 1)); HIP_TRY(hipMemsetAsync(binver[l], 0, ((size_t)T + 1) * 4, c->stream)); }
-                const bool trace = getenv("HARC_AMD_TRACE") != nullptr;
+                for (int l = 0; l < 2; l++) { RC_TRY(dalloc(c, &binmin[l], 2 * ((size_t)T + 1))); HIP_TRY(hipMemsetAsync(binmin[l], 0xFF, 2 * ((size_t)T + 1) * 8, c->stream)); }
+                const bool trace = getenv("HARC_AMD_TRACE") != nullptr, nochase = getenv("HARC_AMD_S2_NOCHASE") != nullptr;
+                a.trace = trace ? 1 : 0;
                 struct timespec tw0; clock_gettime(CLOCK_MONOTONIC, &tw0);
                 // events in (bin, tuple) order and their rank inside the bin (k_realign_big's header)
-                uint32_t *perm = nullptr, *rank = nullptr; unsigned int maxrank = 0;
+                uint32_t *perm = nullptr, *rank = nullptr, *seglen = nullptr; unsigned int maxrank = 0;
                 if (!getenv("HARC_AMD_S2_FLATPASSES")) {
                     RC_TRY(dalloc(c, &perm, (size_t)nev + 1)); RC_TRY(dalloc(c, &rank, (size_t)nev + 1));
                     uint64_t *k0 = nullptr, *k1 = nullptr; uint32_t *i0 = nullptr, *i1 = nullptr, *hd = nullptr;
@@ -1082,19 +1151,26 @@ int stage2_run(harc_amd_ctx *c)
                     RC_TRY(prim_incl_max_u32(c, hd, rank, nev));
                     HIP_TRY(hipMemsetAsync(d_changed, 0, 16, c->stream));
                     hipLaunchKernelGGL(k_ev_rank, G256(nev), rank, nev, d_changed + 1);
+                    RC_TRY(dalloc(c, &seglen, (size_t)nev + 1));
+                    hipLaunchKernelGGL(k_ev_seglen, G256(nev), (const uint32_t *)rank, nev, seglen);
                     HIP_TRY(hipMemcpyAsync(&maxrank, d_changed + 1, 4, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));
                 }
-                uint64_t npass = 0; uint32_t rlo = 0, rhi = 64;
+                uint64_t npass = 0; uint32_t rlo = 0, rhi = 64; int nall = 0;
                 if (const char *e = getenv("HARC_AMD_S2_RANK0")) { const int v = atoi(e); rhi = v < 1 ? 1u : (uint32_t)v; }       // tests: narrow ranges on small inputs
                 for (bool ranges = perm != nullptr;;) {
-                    HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream));
-                    hipLaunchKernelGGL(k_realign_big, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binver[0], binver[1], lastver,
-                                       (const uint32_t *)(ranges ? perm : nullptr), (const uint32_t *)rank, rlo, rhi);
-                    unsigned int chg = 0;
+                    HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 4, c->stream));
+                    hipLaunchKernelGGL(k_realign_big, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
+                                       (const uint32_t *)perm, (const uint32_t *)rank, ranges ? rlo : 0u, ranges ? rhi : 0xFFFFFFFFu);
+                    // the chaser, after the passes over everything from the second one on (the ranges settle by themselves; the chains it is for show
+                    // when the ranges meet); its claims count for the pass (the same stamp)
+                    if (perm && !nochase && !ranges && nall++ > 0) hipLaunchKernelGGL(k_realign_chase, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
+                                                             (const uint32_t *)perm, (const uint32_t *)rank, (const uint32_t *)seglen, ranges ? rhi : 0xFFFFFFFFu);
+                    unsigned int chg = 0, nlook = 0;
                     HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
+                    if (trace) HIP_TRY(hipMemcpyAsync(&nlook, d_changed + 2, 4, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));
-                    if (trace) { struct timespec tw; clock_gettime(CLOCK_MONOTONIC, &tw); fprintf(stderr, "[stage II] window pass %llu over %u events, ranks [%u, %u)%s: %s, %.2f ms since the first\n", (unsigned long long)npass, nev, ranges ? rlo : 0u, ranges ? rhi : maxrank + 1, ranges ? "" : " (all)", chg ? "claims moved" : "quiet", (tw.tv_sec - tw0.tv_sec) * 1e3 + (tw.tv_nsec - tw0.tv_nsec) * 1e-6); }
+                    if (trace) { struct timespec tw; clock_gettime(CLOCK_MONOTONIC, &tw); fprintf(stderr, "[stage II] window pass %llu over %u events (%u looked), ranks [%u, %u)%s: %s, %.2f ms since the first\n", (unsigned long long)npass, nev, nlook, ranges ? rlo : 0u, ranges ? rhi : maxrank + 1, ranges ? "" : " (all)", chg ? "claims moved" : "quiet", (tw.tv_sec - tw0.tv_sec) * 1e3 + (tw.tv_nsec - tw0.tv_nsec) * 1e-6); }
                     if (++npass > (uint64_t)T + 256) { harc_set_error("stage II: the window passes over the large bins did not settle"); return HARC_AMD_EINTERNAL; }
                     if (chg) continue;                                                    // the same events again, until they are quiet
                     if (!ranges) break;                                                   // a pass over ALL events changed nothing: the fixed point

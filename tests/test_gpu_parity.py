@@ -260,11 +260,13 @@ def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, maxev, ndup, 
 def _set_sched(monkeypatch, sched):
     if sched == "flat":
         monkeypatch.setenv("HARC_AMD_S2_FLATPASSES", "1")
+    elif sched == "nochase":
+        monkeypatch.setenv("HARC_AMD_S2_NOCHASE", "1")
     elif sched.startswith("rank0="):
         monkeypatch.setenv("HARC_AMD_S2_RANK0", sched[6:])
 
 
-@pytest.mark.parametrize("K,S,E,seed,fail,sched", [(1, 16, 1, 5, 0.6, ""), (4, 16, 2, 6, 0.5, "rank0=3"), (1, 16, 1, 7, 0.8, "flat"), (2, 8, 1, 8, 0.3, "rank0=1"), (1, 16, 1, 9, 0.5, "rank0=2")])
+@pytest.mark.parametrize("K,S,E,seed,fail,sched", [(1, 16, 1, 5, 0.6, ""), (4, 16, 2, 6, 0.5, "rank0=3"), (1, 16, 1, 7, 0.8, "flat"), (2, 8, 1, 8, 0.3, "rank0=1"), (1, 16, 1, 9, 0.5, "rank0=2"), (1, 16, 1, 9, 0.5, "nochase")])
 def test_stage2_big_bins_partial_claims_exact(K, S, E, seed, fail, sched, oracle, tmp_path, monkeypatch):
     """bins above maxsearch whose reads only partly pass the Hamming test, probed from several places of the consensus: what a probe
     sees depends on which reads the probes before it took AND on the ones nobody takes (they fill the window).  The passes of
