@@ -1161,7 +1161,7 @@ int stage2_run(harc_amd_ctx *c)
                 for (bool ranges = perm != nullptr;;) {
                     HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 4, c->stream));
                     hipLaunchKernelGGL(k_realign_big, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
-                                       (const uint32_t *)perm, (const uint32_t *)rank, ranges ? rlo : 0u, ranges ? rhi : 0xFFFFFFFFu);
+                                       (const uint32_t *)perm, (const uint32_t *)rank, 0u, ranges ? rhi : 0xFFFFFFFFu);     // the ranks below rlo are validated in passing: no event is ever left unlooked-at for a pass
                     // the chaser, after the passes over everything from the second one on (the ranges settle by themselves; the chains it is for show
                     // when the ranges meet); its claims count for the pass (the same stamp)
                     if (perm && !nochase && !ranges && nall++ > 0) hipLaunchKernelGGL(k_realign_chase, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
