@@ -46,6 +46,7 @@ struct S1Args {
     const uint32_t *lds_tab;         // mask rows + probe descriptors as k_steps wants them in LDS (k_steps_tables)
     int nprobe;
     int budget;                      // HARC_SCAN_BUDGET (experiments may override it: HARC_AMD_BUDGET)
+    int stepcap;                     // HARC_STEP_CAP (HARC_AMD_STEPCAP)
     int nbatch, batch_end[12];       // probe batches: [0,batch_end[0]), [batch_end[0],batch_end[1]) ... each at most 64 wide
     uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups, w sequential-equivalent candidates
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
@@ -262,6 +263,8 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
     if (i == n - 1) *nbins = binidx[i] + head[i];
 }
 #define HARC_LARGEBIN 16u    // stage-I bins with more reads than this are compacted between super-rounds (k_compact_bins)
+#define HARC_STEP_CAP 6     // schedule: a STEP that has made this many probes into such bins without a hit is put off -- the walk ends in front of it, and the next
+                             // super-round takes the step up again behind the probes already made (they found nothing against fewer claims; ChainHdr.flags >> 16)
 #define HARC_SCAN_BUDGET 16  // schedule: a walk ends after the step in which the probes it made into such bins (still holding unclaimed reads) reach this number
 // The table is probed bucket by bucket (64 B = 4 slots); a search that finds a full bucket WITHOUT the overflow flag can stop.
 // The reads arrive sorted by scrambled key, so the bins arrive in bucket order (bucket_slot is monotone): the slot of bin i is
@@ -469,7 +472,7 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
 #define HARC_STEPS_WAVES 5
 #endif
 #ifndef HARC_COOP_WAVES
-#define HARC_COOP_WAVES 2       // COOP kernel: workgroups of 4 waves, this many waves per SIMD = workgroups per CU
+#define HARC_COOP_WAVES 4       // COOP kernel: register budget for 4 waves per SIMD (it sat at 127-128 registers; two more cost it a wave)
 #endif
 #ifndef HARC_STEPS_WAVES_Q
 #define HARC_STEPS_WAVES_Q 3     // few chains (whole-bucket fetch): never more than ~3 waves / SIMD anyway
@@ -810,7 +813,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
         }
         if (r < assigned) {
             const uint32_t id = s.seedbuf[r];
-            h.cur = id; h.prev = id; h.flags = (h.flags | CH_PREVUNM) & ~CH_NEEDSEED; h.mode = 2;
+            h.cur = id; h.prev = id; h.flags = ((h.flags | CH_PREVUNM) & ~CH_NEEDSEED) & 0xFFFFu; h.mode = 2;
             const uint32_t first = r * (uint32_t)s.nsugg_per_seed;
             const uint32_t ng = first >= got ? 0u : (got - first < (uint32_t)s.nsugg_per_seed ? got - first : (uint32_t)s.nsugg_per_seed);
             if ((uint32_t)lane < ng) s.sugg[(size_t)c * HARC_NSUGG + lane] = s.seedbuf[R + first + lane];
@@ -871,6 +874,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
     int lastp = (int)(h.pad0 & 0xFFFF);                          // 16 x running mean (weight 1/4) of the priority index of this chain's hits
     int spos = (int)((h.nsteps >> 16) & 0xFF); const int nsugg = (int)(h.nsteps >> 24);   // look-ahead seeds: next to try / held
     int bigprobes = 0;                                           // COOP: probes into large live bins made by this walk so far
+    const int resume = (int)(h.flags >> 16);                     // the first step of this super-round was put off before: where it takes up again
+    bool stalled = false; int resume_next = 0;
     PH(0);
     for (int t = T0; t < s.S; t++) {
         cons_rows<W>(st, L, lane, coltmp, rowF, rowR);            // consensus and its reverse complement -> the wave's window rows
@@ -878,7 +883,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
         uint32_t found = HARC_NONE; int fj = 0, fdir = 0;
         // Probes are issued in priority order in batches: every probe behind the first hit of a batch is speculative traffic,
         // every extra batch is a serial round trip to HBM.
-        int base = 0;
+        int base = (t == 0 && resume > 0) ? resume : 0;          // the probes before `resume` were made in an earlier super-round: nothing then, nothing now
+        int stepbig = 0;                                         // COOP: probes into large live bins made by this STEP so far
         for (int bi = 0; base < s.nprobe; bi++) {
             // first batch: twice the running mean of the priority index of the chain's hits + 16 (high coverage -> hits at small shifts ->
             // narrow first batch; the mean, not the last hit: where reads start is Poisson, the last hit says little about the next),
@@ -1005,10 +1011,19 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
             //      of the step that look into the SAME bin (every shift of a poly-A consensus has the same key) share one pass over it.
             PH(2);
             {
-                unsigned long long bigm = __ballot(big);
+                const unsigned long long bigall = __ballot(big);
+                unsigned long long bigm = bigall;
                 if (winlane < 64) bigm &= (1ULL << winlane) - 1ULL;
                 if (!COOP) { if (bigm) { defer = true; break; } }
-                else while (bigm) {
+                // the probe at which the step reaches HARC_STEP_CAP probes into large live bins: if nothing is found up to and including
+                // it, the step is put off there (what lies behind it is not looked at: the oracle has not either)
+                int caplane = 64;
+                if (COOP) {
+                    const int need = s.stepcap - stepbig;
+                    if (need >= 1 && __popcll(bigall) >= need) { unsigned long long m = bigall; for (int k = 1; k < need; k++) m &= m - 1; caplane = __ffsll((long long)m) - 1; }
+                    if (caplane < 64 && caplane < winlane) bigm &= (2ULL << caplane) - 1ULL;
+                }
+                if (COOP) while (bigm) {
                     const int bl = __ffsll((long long)bigm) - 1;
                     const uint32_t o_raw = (uint32_t)__builtin_amdgcn_readlane((int)b_cnt, bl), o_cnt = o_raw & SLOT_CNT_MASK;
                     const int o_l = __builtin_amdgcn_readlane(l, bl);
@@ -1039,7 +1054,11 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
                     if (s.dbg) { dbg_kt[dbg_kind] += (unsigned long long)(wall_clock64() - dbg_s0); dbg_kn[dbg_kind]++; }
 #endif
                 }
-                if (COOP) bigprobes += __popcll(__ballot(big) & (winlane < 64 ? ((2ULL << winlane) - 1ULL) : ~0ULL));   // the probes up to and including the winning one
+                if (COOP && caplane < 64 && caplane < winlane) {               // nothing up to the cap: the step is put off
+                    stalled = true; resume_next = base + caplane + 1;
+                    break;
+                }
+                if (COOP) { const int nb = __popcll(bigall & (winlane < 64 ? ((2ULL << winlane) - 1ULL) : ~0ULL)); bigprobes += nb; stepbig += nb; }   // the probes up to and including the winning one
             }
             PH(3);
             if (lane <= winlane) ncu += ncb;                              // lanes behind the winner were speculation (winlane = 64: no hit, all count)
@@ -1050,7 +1069,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
             }
             base = bend;
         }
-        if (defer) break;
+        if (defer || stalled) break;
         if (found == HARC_NONE) {
             // no candidate: go on from the chain's look-ahead seeds (highest id first, skipping what was claimed meanwhile) -- the new
             // seed of reorder.cpp:652-668 without waiting for the next k_reseed
@@ -1117,6 +1136,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
         h.pad0 = ((uint32_t)lastp & 0xFFFFu) | ((uint32_t)spos << 16);
         h.flags = needseed ? (h.flags | CH_NEEDSEED) : (h.flags & ~CH_NEEDSEED);
         h.flags = defer ? (h.flags | CH_COOP) : (h.flags & ~CH_COOP);
+        // a step put off (COOP), or one still waiting for its turn in the cooperative kernel (main kernel, nothing walked yet), keeps its place
+        h.flags = (h.flags & 0xFFFFu) | ((COOP ? (stalled ? (uint32_t)resume_next : 0u) : ((defer && nst == 0) ? (uint32_t)resume : 0u)) << 16);
         if (!COOP && defer) atomicAdd(&s.coopcnt[c & (HARC_COOPCNT - 1)], 1ULL);
         s.hdr[c] = h;
     }
@@ -1186,7 +1207,7 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
         else spos = (h.pad0 >> 16) & 0xFF;
         const uint32_t keep = (h.nsteps & 0xFF000000u) | (spos << 16);
         if (cut) {
-            h.mode = v > 0 ? 1u : 0u; h.nsteps = keep | ((uint32_t)v << 8); h.flags &= ~CH_NEEDSEED;
+            h.mode = v > 0 ? 1u : 0u; h.nsteps = keep | ((uint32_t)v << 8); h.flags &= ~CH_NEEDSEED; h.flags &= 0xFFFFu;   // rolled back: a step put off belonged to a state that is gone
         } else {
             if (n > 0) { h.flags ^= CH_PARITY; h.mode = 0; }
             h.nsteps = keep;
@@ -1632,6 +1653,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         hipLaunchKernelGGL((k_steps_tables<W>), dim3(4), dim3(256), 0, c->stream, a, lt);
         a.lds_tab = lt;
     }
+    a.stepcap = getenv("HARC_AMD_STEPCAP") ? atoi(getenv("HARC_AMD_STEPCAP")) : HARC_STEP_CAP;   // experiments: the oracle knows the default only
+    if (a.stepcap < 1) a.stepcap = 1;
     a.budget = getenv("HARC_AMD_BUDGET") ? atoi(getenv("HARC_AMD_BUDGET")) : HARC_SCAN_BUDGET;   // not part of the C-ABI: the oracle knows the default only
     a.nbatch = 0;                                                // adaptive batches (k_steps) unless a fixed schedule is forced
     a.firstmax[0] = a.firstmax[1] = (bloom_nwin[0] > 0 && bloom_nwin[1] > 0) ? 64 : 48;     // lines by minimizer: speculative probes share their lines

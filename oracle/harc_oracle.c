@@ -40,6 +40,8 @@
 #define NSUGG 8           /* look-ahead seeds handed to a chain at every reseed */
 #define LOOK_CHUNKS 16     /* the look-ahead inspects at most this many chunks of 1024 64-bit bitmap words below the cursor (the GPU's k_reseed) */
 #define LARGEBIN 16u      /* HARC_LARGEBIN of harc_amd/csrc/stage1.hip */
+#define STEP_CAP 6        /* HARC_STEP_CAP: a step that has made this many probes into such bins without a hit is put off: the walk ends in front of it and the
+                              next super-round takes the step up again BEHIND the probes already made (they found nothing against fewer claims) */
 #define SCAN_BUDGET 16     /* HARC_SCAN_BUDGET: a walk ends after the step in which its probes into bins of more than LARGEBIN reads (not yet exhausted) reach this number */
 
 /* ------------------------------------------------------------------ parameters (harc:52-60) */
@@ -155,6 +157,7 @@ typedef struct {
     vec32 m_order, m_meta; /* main stream: order; meta = pos | flag<<8 | rc<<9 */
     vec32 s_order;         /* singleton stream */
     uint32_t p_rid; int p_j, p_dir;   /* proposal of the current step */
+    int p_stalled, p_next, resume_p;  /* the step was put off (STEP_CAP) before probe number p_next of its priority order; where the chain's NEXT step takes up again (0: at the start) */
     int p_big;                        /* probes of the step, up to and including the winning one, into bins of more than LARGEBIN reads that still had unclaimed ones */
     /* super-round: up to MAXSTEPS speculative steps against the frozen claim state */
     uint32_t s_rid[MAXSTEPS]; uint8_t s_j[MAXSTEPS], s_dir[MAXSTEPS], s_kind[MAXSTEPS], s_sidx[MAXSTEPS]; int nsteps, need_reseed;
@@ -232,27 +235,34 @@ static void propose(chain_t *c, dict_t *dict, const uint64_t *reads, const uint8
         rev[(2 * k) >> 6] |= (uint64_t)idx_to_pc[3 - c->cons[i]] << ((2 * k) & 63);
     }
     topmask = ((2 * L) & 63) ? ((((uint64_t)1) << ((2 * L) & 63)) - 1) : ~(uint64_t)0;
-    c->p_rid = NONE; c->p_big = 0;
+    c->p_rid = NONE; c->p_big = 0; c->p_stalled = 0;
+    int pidx = 0;                                                 /* number of the probe in the priority order of the step */
     for (int j = 0; j < p->maxmatch; j++) {
         for (int l = 0; l < 2; l++) {                             /* forward, reorder.cpp:520-580 */
             if (p->de[l] + j >= L) continue;
+            if (pidx++ < c->resume_p) continue;                   /* made in an earlier super-round, before the step was put off */
             uint64_t key = extract_bits(ref, W, 2 * p->ds[l], p->kbits[l]);
             st->probes++;
             uint32_t bin = dict_lookup(&dict[l], key);
             if (bin == NONE) continue;
-            if (dict[l].start[bin + 1] - dict[l].start[bin] > LARGEBIN && dict[l].nlive[bin] > 0) c->p_big++;
+            int big = dict[l].start[bin + 1] - dict[l].start[bin] > LARGEBIN && dict[l].nlive[bin] > 0;
+            if (big) c->p_big++;
             uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, ref, mask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands, own, nown);
             if (rid != NONE) { c->p_rid = rid; c->p_j = j; c->p_dir = 0; return; }
+            if (big && c->p_big >= STEP_CAP) { c->p_stalled = 1; c->p_next = pidx; return; }
         }
         for (int l = 0; l < 2; l++) {                             /* reverse, reorder.cpp:585-643 */
             if (p->ds[l] <= j) continue;
+            if (pidx++ < c->resume_p) continue;
             uint64_t key = extract_bits(rev, W, 2 * p->ds[l], p->kbits[l]);
             st->probes++;
             uint32_t bin = dict_lookup(&dict[l], key);
             if (bin == NONE) continue;
-            if (dict[l].start[bin + 1] - dict[l].start[bin] > LARGEBIN && dict[l].nlive[bin] > 0) c->p_big++;
+            int big = dict[l].start[bin + 1] - dict[l].start[bin] > LARGEBIN && dict[l].nlive[bin] > 0;
+            if (big) c->p_big++;
             uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, rev, revmask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands, own, nown);
             if (rid != NONE) { c->p_rid = rid; c->p_j = j; c->p_dir = 1; return; }
+            if (big && c->p_big >= STEP_CAP) { c->p_stalled = 1; c->p_next = pidx; return; }
         }
         /* revref <<= 2; ref >>= 2  (reorder.cpp:647-648), bitset<2L> semantics */
         for (int w = W - 1; w > 0; w--) rev[w] = (rev[w] << 2) | (rev[w - 1] >> 62);
@@ -327,6 +337,8 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
             int spos = x->sugg_pos, bigprobes = 0;
             for (uint32_t t = 0; t < nsteps; t++) {
                 propose(x, dict, reads, claimed, p, mask, revmask, out, x->s_rid, x->nsteps);
+                if (x->p_stalled) { x->resume_p = x->p_next; break; }             /* the step is put off: the walk ends in front of it */
+                x->resume_p = 0;                                   /* the step is made (a read or a new seed): the next one starts at its first probe */
                 uint32_t key = (t << 20) | c;
                 if (x->p_rid != NONE) {
                     x->s_rid[t] = x->p_rid; x->s_j[t] = (uint8_t)x->p_j; x->s_dir[t] = (uint8_t)x->p_dir; x->s_kind[t] = 0; x->s_sidx[t] = 0;
@@ -363,7 +375,7 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
             int v = 0;
             while (v < x->nsteps && bid[x->s_rid[v]] == (((uint32_t)v << 20) | c)) v++;
             if (v < x->nsteps) {                                  /* lost a bid: roll back and replay the kept steps */
-                out->conflicts++; x->need_reseed = 0;
+                out->conflicts++; x->need_reseed = 0; x->resume_p = 0;     /* rolled back: a step put off belonged to a state that is gone */
                 memcpy(x->count, x->count0, sizeof(int32_t) * 4 * L); memcpy(x->cons, x->cons0, L);
                 for (int t = 0; t < v; t++) {
                     if (x->s_kind[t]) cons_reset(x, reads + (size_t)x->s_rid[t] * W, L);
