@@ -1157,6 +1157,7 @@ int stage2_run(harc_amd_ctx *c)
                     HIP_TRY(hipStreamSynchronize(c->stream));
                 }
                 uint64_t npass = 0; uint32_t rlo = 0, rhi = 64; int nall = 0;
+                const uint32_t pipeline_from = getenv("HARC_AMD_S2_PIPE") ? (uint32_t)atoi(getenv("HARC_AMD_S2_PIPE")) : 1024u;
                 if (const char *e = getenv("HARC_AMD_S2_RANK0")) { const int v = atoi(e); rhi = v < 1 ? 1u : (uint32_t)v; }       // tests: narrow ranges on small inputs
                 for (bool ranges = perm != nullptr;;) {
                     HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 4, c->stream));
@@ -1172,8 +1173,12 @@ int stage2_run(harc_amd_ctx *c)
                     HIP_TRY(hipStreamSynchronize(c->stream));
                     if (trace) { struct timespec tw; clock_gettime(CLOCK_MONOTONIC, &tw); fprintf(stderr, "[stage II] window pass %llu over %u events (%u looked), ranks [%u, %u)%s: %s, %.2f ms since the first\n", (unsigned long long)npass, nev, nlook, ranges ? rlo : 0u, ranges ? rhi : maxrank + 1, ranges ? "" : " (all)", chg ? "claims moved" : "quiet", (tw.tv_sec - tw0.tv_sec) * 1e3 + (tw.tv_nsec - tw0.tv_nsec) * 1e-6); }
                     if (++npass > (uint64_t)T + 256) { harc_set_error("stage II: the window passes over the large bins did not settle"); return HARC_AMD_EINTERNAL; }
-                    if (chg) continue;                                                    // the same events again, until they are quiet
-                    if (!ranges) break;                                                   // a pass over ALL events changed nothing: the fixed point
+                    // a range is repeated until quiet only while it is small (its passes cost next to nothing and the early events of a bin decide
+                    // what all later ones see); a large range moves on at once: every later pass validates its events, and those with an
+                    // earlier claim on their bin look again then -- the separate quiet pass per large range was a third of the time
+                    if (chg && (!ranges || rhi <= pipeline_from)) continue;
+                    if (!ranges && !chg) break;                                           // a pass over ALL events changed nothing: the fixed point
+                    if (!ranges) continue;
                     if (rhi > maxrank) ranges = false;                                    // every range has settled: now the passes over everything
                     else { rlo = rhi; rhi = rhi > 0x20000000u ? 0xFFFFFFFFu : rhi * 4; }
                 }
