@@ -75,12 +75,22 @@ struct RcclComm : HarcComm {
     int alltoallv(harc_amd_ctx *c, int narr, const void *const *send, const size_t *const *soff, const size_t *const *sbytes,
                   void *const *recv, const size_t *const *roff, const size_t *const *rbytes) override
     {
+        // One group; every (array, peer) chunk goes as pieces of at most PIECE bytes -- sender and receiver cut the same byte count the same
+        // way, and the pieces of a pair are matched in the order they are posted.  (With two ranks a chunk of configs[2] is 5.6 GB; a
+        // single send of 10 GB to the rank itself, configs[4] at 1/16 on one GPU, never came back.)
+        const size_t PIECE = getenv("HARC_AMD_XCHG_PIECE") ? (size_t)strtoull(getenv("HARC_AMD_XCHG_PIECE"), nullptr, 10) : ((size_t)1 << 30);
         NCCL_TRY(g_rccl.GroupStart());
         for (int a = 0; a < narr; a++)
             for (int p = 0; p < world; p++) {
                 // zero-byte chunks are skipped on both sides: sender and receiver see the same count matrix
-                if (sbytes[a][p]) NCCL_TRY(g_rccl.Send((const char *)send[a] + soff[a][p], sbytes[a][p], ncclUint8, p, comm, c->stream));
-                if (rbytes[a][p]) NCCL_TRY(g_rccl.Recv((char *)recv[a] + roff[a][p], rbytes[a][p], ncclUint8, p, comm, c->stream));
+                for (size_t o = 0; o < sbytes[a][p]; o += PIECE) {
+                    const size_t n = sbytes[a][p] - o < PIECE ? sbytes[a][p] - o : PIECE;
+                    NCCL_TRY(g_rccl.Send((const char *)send[a] + soff[a][p] + o, n, ncclUint8, p, comm, c->stream));
+                }
+                for (size_t o = 0; o < rbytes[a][p]; o += PIECE) {
+                    const size_t n = rbytes[a][p] - o < PIECE ? rbytes[a][p] - o : PIECE;
+                    NCCL_TRY(g_rccl.Recv((char *)recv[a] + roff[a][p] + o, n, ncclUint8, p, comm, c->stream));
+                }
             }
         NCCL_TRY(g_rccl.GroupEnd());
         return HARC_AMD_OK;

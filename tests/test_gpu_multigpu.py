@@ -59,10 +59,15 @@ RCCL_WORKER = textwrap.dedent("""
 """) % ROOT
 
 
-def test_rccl_exchange_world1_in_a_fresh_process(tmp_path):
+@pytest.mark.parametrize("piece", ["", "40000"])
+def test_rccl_exchange_world1_in_a_fresh_process(piece, tmp_path):
+    """piece: the exchange posts every (array, peer) chunk as sends / receives of at most that many bytes (1 GiB by default: a single
+    10 GB send never came back) -- forced small here, so that a chunk is a few dozen pieces"""
     script = tmp_path / "worker.py"
     script.write_text(RCCL_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if piece:
+        env["HARC_AMD_XCHG_PIECE"] = piece
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", "29547", str(script), str(tmp_path / "oracle")], env=env, cwd=ROOT, stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, text=True, timeout=900)
