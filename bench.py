@@ -189,8 +189,8 @@ def stage2_blobs(h, shards):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("HARC_BENCH_WORKLOAD", "c3"))
     ap.add_argument("--chains", type=int, default=0)
     ap.add_argument("--super-steps", type=int, default=0, help="steps per super-round (num_steps, default 16)")
