@@ -668,12 +668,13 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
     return ch;
 }
 __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
-                                                     uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, uint32_t rlo, uint32_t rhi)
+                                                     uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, uint32_t rlo, uint32_t rhi, const uint32_t *order2)
 {
     __shared__ unsigned long long swin[4][HARC_MAXW3];
     const int wv = threadIdx.x >> 6;
-    const uint32_t ei = blockIdx.x * 4 + wv;                      // estart / lastpass are indexed by the position the wave works at
-    if (ei >= nev) return;
+    const uint32_t k = blockIdx.x * 4 + wv;
+    if (k >= nev) return;                                         // nev: the events of the ranges this pass covers (order2) or all of them
+    const uint32_t ei = order2 ? order2[k] : k;                   // estart / lastpass are indexed by the event's position in (bin, tuple) order
     uint32_t e = ei;
     if (perm) { const uint32_t r = rank[ei]; if (r < rlo || r >= rhi) return; e = perm[ei]; }
     (void)realign_event(s, ei, e, estart, changed, binmin0, binmin1, lastpass, pass, T1, swin[wv], true);
@@ -712,6 +713,29 @@ __global__ __launch_bounds__(256) void k_realign_chase(S2Args s, uint32_t nev, u
         quiet = ch ? 0 : quiet + 1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+}
+// the rank range an event belongs to ([0, r0), [r0, 4 r0), [4 r0, 16 r0) ...) as a sort key, and how many events every range holds: the passes
+// over the first ranges then launch a wave per event of THOSE ranges instead of one per event of the whole list (two million workgroups
+// that leave at once cost 0.5 ms per pass, and the first ranges take dozens of passes)
+__global__ void k_ev_range_keys(const uint32_t *rank, uint32_t nev, uint32_t r0, uint64_t *key, uint32_t *pos, unsigned int *hist)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < nev;
+    uint32_t k = 0xFFFFFFFFu;
+    if (in) {
+        const uint32_t r = rank[i];
+        k = 0;
+        for (unsigned long long b = r0; r >= b && k < 31; b *= 4) k++;
+        key[i] = k; pos[i] = i;
+    }
+    unsigned long long todo = __ballot(in);
+    while (todo) {                                                 // one atomic per distinct range per wave
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lk = __shfl(k, leader, 64);
+        const unsigned long long same = __ballot(in && k == lk);
+        if ((threadIdx.x & 63) == leader) atomicAdd(&hist[lk], (unsigned int)__popcll(same));
+        todo &= ~same;
     }
 }
 __global__ void k_ev_seglen(const uint32_t *rank, uint32_t nev, uint32_t *seglen)
@@ -1137,7 +1161,10 @@ int stage2_run(harc_amd_ctx *c)
                 a.trace = trace ? 1 : 0;
                 struct timespec tw0; clock_gettime(CLOCK_MONOTONIC, &tw0);
                 // events in (bin, tuple) order and their rank inside the bin (k_realign_big's header)
-                uint32_t *perm = nullptr, *rank = nullptr, *seglen = nullptr; unsigned int maxrank = 0;
+                uint32_t *perm = nullptr, *rank = nullptr, *seglen = nullptr, *order2 = nullptr; unsigned int maxrank = 0;
+                uint32_t rhi0 = 64, range_end[32];
+                if (const char *e = getenv("HARC_AMD_S2_RANK0")) { const int v = atoi(e); rhi0 = v < 1 ? 1u : (uint32_t)v; }       // tests: narrow ranges on small inputs
+                for (int k = 0; k < 32; k++) range_end[k] = nev;
                 if (!getenv("HARC_AMD_S2_FLATPASSES")) {
                     RC_TRY(dalloc(c, &perm, (size_t)nev + 1)); RC_TRY(dalloc(c, &rank, (size_t)nev + 1));
                     uint64_t *k0 = nullptr, *k1 = nullptr; uint32_t *i0 = nullptr, *i1 = nullptr, *hd = nullptr;
@@ -1153,16 +1180,25 @@ int stage2_run(harc_amd_ctx *c)
                     hipLaunchKernelGGL(k_ev_rank, G256(nev), rank, nev, d_changed + 1);
                     RC_TRY(dalloc(c, &seglen, (size_t)nev + 1));
                     hipLaunchKernelGGL(k_ev_seglen, G256(nev), (const uint32_t *)rank, nev, seglen);
+                    // the events grouped by rank range ((bin, tuple) order kept inside a range), and the size of every range
+                    unsigned int *hist = nullptr; RC_TRY(dalloc(c, &hist, 32)); HIP_TRY(hipMemsetAsync(hist, 0, 32 * 4, c->stream));
+                    RC_TRY(dalloc(c, &order2, (size_t)nev + 1));
+                    hipLaunchKernelGGL(k_ev_range_keys, G256(nev), (const uint32_t *)rank, nev, rhi0, k0, i0, hist);
+                    RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i0, order2, nev, 5));
+                    unsigned int hh[32];
+                    HIP_TRY(hipMemcpyAsync(hh, hist, sizeof hh, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(hipMemcpyAsync(&maxrank, d_changed + 1, 4, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));
+                    range_end[0] = hh[0];
+                    for (int k = 1; k < 32; k++) range_end[k] = range_end[k - 1] + hh[k];
                 }
-                uint64_t npass = 0; uint32_t rlo = 0, rhi = 64; int nall = 0;
+                uint64_t npass = 0; uint32_t rlo = 0, rhi = rhi0; int nall = 0, ridx = 0;
                 const uint32_t pipeline_from = getenv("HARC_AMD_S2_PIPE") ? (uint32_t)atoi(getenv("HARC_AMD_S2_PIPE")) : 1024u;
-                if (const char *e = getenv("HARC_AMD_S2_RANK0")) { const int v = atoi(e); rhi = v < 1 ? 1u : (uint32_t)v; }       // tests: narrow ranges on small inputs
                 for (bool ranges = perm != nullptr;;) {
                     HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 4, c->stream));
-                    hipLaunchKernelGGL(k_realign_big, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
-                                       (const uint32_t *)perm, (const uint32_t *)rank, 0u, ranges ? rhi : 0xFFFFFFFFu);     // the ranks below rlo are validated in passing: no event is ever left unlooked-at for a pass
+                    const uint32_t nact = (ranges && order2) ? range_end[ridx < 31 ? ridx : 31] : nev;      // the events of the ranges reached so far come first in order2
+                    hipLaunchKernelGGL(k_realign_big, dim3((nact + 3) / 4), dim3(256), 0, c->stream, a, nact, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
+                                       (const uint32_t *)perm, (const uint32_t *)rank, 0u, ranges ? rhi : 0xFFFFFFFFu, (const uint32_t *)(ranges ? order2 : nullptr));     // the ranks below rlo are validated in passing: no event is ever left unlooked-at for a pass
                     // the chaser, after the passes over everything from the second one on (the ranges settle by themselves; the chains it is for show
                     // when the ranges meet); its claims count for the pass (the same stamp)
                     if (perm && !nochase && !ranges && nall++ > 0) hipLaunchKernelGGL(k_realign_chase, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
@@ -1180,7 +1216,7 @@ int stage2_run(harc_amd_ctx *c)
                     if (!ranges && !chg) break;                                           // a pass over ALL events changed nothing: the fixed point
                     if (!ranges) continue;
                     if (rhi > maxrank) ranges = false;                                    // every range has settled: now the passes over everything
-                    else { rlo = rhi; rhi = rhi > 0x20000000u ? 0xFFFFFFFFu : rhi * 4; }
+                    else { rlo = rhi; rhi = rhi > 0x20000000u ? 0xFFFFFFFFu : rhi * 4; ridx++; }
                 }
             }
         }
