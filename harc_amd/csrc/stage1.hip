@@ -1316,10 +1316,59 @@ template <int NT> __global__ __launch_bounds__(NT) void k_reseed(S1Args s)
 // only shrinks from the top (hints).  In repeats and low-complexity sequence a bin holds thousands of reads and every scan would wade
 // through the claimed ones again: between super-rounds one wave per large bin packs the unclaimed ids to the front of the bin (order
 // kept) and lowers the count.  What a scan sees -- the unclaimed reads of the bin, highest id first -- does not change.
-template <int W> __global__ __launch_bounds__(64) void k_compact_bins(S1Args s, const unsigned long long *list, uint32_t nlist)
+#define HARC_HUGEBIN 512u    // bins that start with more reads than this are compacted by a workgroup of 1024 threads (k_compact_huge), the others by a wave
+__global__ void k_huge_list(const uint32_t *sz, uint32_t nlarge, uint32_t *huge, unsigned int *nhuge)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nlarge && sz[b] > HARC_HUGEBIN) huge[atomicAdd(nhuge, 1u)] = b;
+}
+// A wave per bin walks a bin of 17 000 reads in 270 dependent passes while the chip idles: the kernel lasted as long as its largest bin
+// (114 us per super-round on c3sd, a tenth of the chain phase).  Sixteen waves per such bin, order kept by a block scan; every thread has
+// its entry in registers before the first one of the pass is overwritten.
+template <int W> __global__ __launch_bounds__(1024) void k_compact_huge(S1Args s, const unsigned long long *list, const uint32_t *huge, uint32_t nhuge)
+{
+    __shared__ uint32_t sm[20];
+    if (blockIdx.x >= nhuge) return;
+    const uint32_t b = huge[blockIdx.x];
+    const int t = threadIdx.x;
+    const unsigned long long e = list[b];
+    const int l = (int)(e & 1); const uint64_t si = e >> 1;
+    HashSlot *slot = &s.slots[l][si];
+    const uint32_t cw = slot->count;
+    if (cw & SLOT_DEAD) return;
+    const uint32_t cnt = cw & SLOT_CNT_MASK;
+    const uint2 lt = s.largetab[b];
+    uint32_t *ids = const_cast<uint32_t *>(s.ids[l]) + lt.x;
+    uint64_t *mir = s.mirror + (size_t)lt.y * W;
+    uint32_t out = 0;
+    for (uint32_t pos = 0; pos < cnt; pos += 1024) {
+        const bool valid = pos + t < cnt;
+        uint32_t rid = 0; bool un = false; uint64_t rw[W];
+        if (valid) {
+            rid = ids[pos + t]; un = !((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL);
+#pragma unroll
+            for (int w = 0; w < W; w++) rw[w] = mir[(size_t)(pos + t) * W + w];
+        }
+        __builtin_amdgcn_s_waitcnt(0);                            // every entry of the pass has arrived ...
+        uint32_t total; const uint32_t off = block_excl_scan_u32<1024>(un ? 1u : 0u, sm, &total);     // ... before anybody passes the barriers in here
+        if (un) {
+            const uint32_t at = out + off;                        // out <= pos: never ahead of the entries of this pass
+            ids[at] = rid;
+#pragma unroll
+            for (int w = 0; w < W; w++) mir[(size_t)at * W + w] = rw[w];
+        }
+        out += total;
+    }
+    if (t == 0 && out < cnt) {
+        if (out == 0) atomicOr(&slot->count, SLOT_DEAD);
+        else slot->count = out | (cw & ~SLOT_CNT_MASK);
+    }
+}
+template <int W> __global__ __launch_bounds__(64) void k_compact_bins(S1Args s, const unsigned long long *list, uint32_t nlist, const uint32_t *sz0)
 {
     const uint32_t b = blockIdx.x;
     if (b >= nlist) return;
+    if (sz0 && sz0[b] > HARC_HUGEBIN) return;                     // k_compact_huge's
     const int lane = threadIdx.x;
     const unsigned long long e = list[b];
     const int l = (int)(e & 1); const uint64_t si = e >> 1;
@@ -1603,11 +1652,17 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     }
     // their reads once more, in bin order (k_large_fill); nothing on ordinary data
     uint2 *d_largetab = nullptr; uint64_t *d_mirror = nullptr;
+    uint32_t *d_sz0 = nullptr, *d_huge = nullptr; unsigned int *d_nhuge = nullptr; uint32_t nhuge = 0;     // the bins k_compact_huge takes
     if (nlarge) {
         uint32_t *sz = nullptr; uint64_t *moff = nullptr;
         RC_TRY(dalloc(c, &d_largetab, nlarge)); RC_TRY(dalloc(c, &sz, (size_t)nlarge + 1)); RC_TRY(dalloc(c, &moff, (size_t)nlarge + 1));
         HIP_TRY(hipMemsetAsync(sz + nlarge, 0, 4, c->stream));
         hipLaunchKernelGGL(k_large_sizes, dim3((nlarge + 255) / 256), dim3(256), 0, c->stream, (const unsigned long long *)d_large, nlarge, dict[0].slots, dict[1].slots, sz);
+        d_sz0 = sz;
+        RC_TRY(dalloc(c, &d_huge, (size_t)nlarge + 1)); RC_TRY(dalloc(c, &d_nhuge, 4));
+        HIP_TRY(hipMemsetAsync(d_nhuge, 0, 16, c->stream));
+        hipLaunchKernelGGL(k_huge_list, dim3((nlarge + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)sz, nlarge, d_huge, d_nhuge);
+        HIP_TRY(hipMemcpyAsync(&nhuge, d_nhuge, 4, hipMemcpyDeviceToHost, c->stream));
         RC_TRY(prim_excl_scan_u32_to_u64(c, sz, moff, (size_t)nlarge + 1));
         uint64_t mtotal = 0;
         HIP_TRY(hipMemcpyAsync(&mtotal, moff + nlarge, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1684,7 +1739,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     HIP_TRY(hipGetLastError());
 
     // SLOT_DEAD of the large bins must say "no unclaimed read" from the first super-round on (the seeds of k_init_chains are claimed)
-    if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge);
+    if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge, (const uint32_t *)d_sz0);
+    if (nhuge) hipLaunchKernelGGL((k_compact_huge<W>), dim3(nhuge), dim3(1024), 0, c->stream, a, (const unsigned long long *)d_large, (const uint32_t *)d_huge, nhuge);
     // ---- rounds
     const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe);
     const bool prof = P.profile != 0;
@@ -1716,7 +1772,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             else hipLaunchKernelGGL((k_resolve<64>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
             if (K <= 4096) hipLaunchKernelGGL((k_reseed<256>), dim3(1), dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((k_reseed<1024>), dim3(1), dim3(1024), 0, c->stream, a);
-            if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge);
+            if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge, (const uint32_t *)d_sz0);
+    if (nhuge) hipLaunchKernelGGL((k_compact_huge<W>), dim3(nhuge), dim3(1024), 0, c->stream, a, (const unsigned long long *)d_large, (const uint32_t *)d_huge, nhuge);
             launches++;
         }
         rounds += batch;
