@@ -1009,6 +1009,7 @@ int stage2_run(harc_amd_ctx *c)
     if (T) hipLaunchKernelGGL(k_cand2_from3, G256((size_t)T * W), (const uint64_t *)cand3, T, L, W, W3, cand2, candN);
     a.cand2 = cand2; a.candN = candN;
     a.maxevents = 1u << 20;                                       // 16 MB of events to start with; the pass is repeated with a larger buffer when it asks for one
+    if (c->s2_events_hint > a.maxevents) a.maxevents = c->s2_events_hint;   // what the context's last run needed, and a quarter more: no second pass on a repeated workload
     if (const char *e = getenv("HARC_AMD_MAXEVENTS")) { a.maxevents = (uint32_t)strtoul(e, nullptr, 10); if (a.maxevents < 1) a.maxevents = 1; }   // tests: force the growth path
     RC_TRY(dalloc(c, &a.events, (size_t)a.maxevents)); RC_TRY(dalloc(c, &a.nevents, 4));
     HIP_TRY(hipMemsetAsync(a.nevents, 0, 16, c->stream));
@@ -1133,6 +1134,7 @@ int stage2_run(harc_amd_ctx *c)
             unsigned int nev = 0;
             HIP_TRY(hipMemcpyAsync(&nev, a.nevents, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+            { const uint64_t want = (uint64_t)nev + nev / 4; c->s2_events_hint = want > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)want; }
             if (nev > a.maxevents) {
                 // more probes into bins above maxsearch than the buffer holds (low-complexity reads against a long consensus): the pass
                 // is repeated with a buffer of the size it asked for (what it did to best[] is idempotent)
