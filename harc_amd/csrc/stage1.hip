@@ -1791,7 +1791,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             const double per_round = (double)(tot - coop_seen) / (double)batch;
             coop_seen = tot;
             // measured: 6800 walks per round (c3sd) 417 / 373 / 392 ms with 4 / 2 / 1 waves; 1300 walks (c2d, c2r) 112 / 133 / 194 ms
-            coop_waves = per_round > 3.0 * coop_slots ? 2 : 4;
+            // (with the step cap: c3sd 343 / 280 / 268 ms with 4 / 2 / 1 waves, c2r 69 / 79 / 106 ms)
+            coop_waves = per_round > 5.0 * coop_slots ? 1 : per_round > 3.0 * coop_slots ? 2 : 4;
         }
         if (rounds > (uint64_t)N * 2 + 1024) { harc_set_error("stage I did not converge after %llu rounds", (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
     }
