@@ -1492,6 +1492,7 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     uint32_t nbins = 0;
     HIP_TRY(hipMemcpyAsync(&nbins, d->d_nbins, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    d->nbins = nbins;
     {
         uint64_t *v = keys, *q = nullptr;                          // the unsorted keys are not needed any more
         RC_TRY(dalloc(c, &q, (size_t)nbins + 1));
@@ -1642,6 +1643,14 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, N, (unsigned)kbits));
         }
         harc_pool_release(c, mk);
+    }
+    // Low coverage: almost every read has its k-mer to itself (distinct k-mers / reads = (1 - e^-x) / x with x reads per genome position:
+    // 0.986 at 2.9x, 0.95 at 11x, 0.77 at 52x).  There chains cost next to nothing in compressed size (configs[0] stand-in: 1.003 of the
+    // reference's -t 8 with twice the chains) and a small input leaves the chip idle: up to 4096 chains of at least 512 reads.  At 52x the
+    // same would cost 21 % (measured), so the rule asks the index.
+    if (N && P.num_chains <= 0 && P.reads_per_chain <= 0 && (double)dict[0].nbins > 0.98 * (double)N) {
+        const uint32_t k2 = N / 512 < 4096 ? N / 512 : 4096;
+        if (k2 > K) { K = k2; c->C.chains = K; if (!getenv("HARC_AMD_QUAD")) quad = K <= 16384; }
     }
     // bins large enough to be worth compacting between super-rounds were listed by k_table_insert (none on ordinary data)
     uint32_t nlarge = 0;

@@ -111,8 +111,21 @@ def reads_text_bigbin_stage2_mixed(seed, n_clean=4000, n_dupN=3000, L=100, genom
     return out.tobytes()
 
 
-def auto_chains(n_clean, reads_per_chain=2048):
-    """auto_chains() of harc_amd/csrc/stage1.hip: K when harc_amd_params.num_chains = 0"""
+def auto_chains(n_clean, reads_per_chain=2048, clean=None):
+    """auto_chains() of harc_amd/csrc/stage1.hip: K when harc_amd_params.num_chains = 0.  clean: the clean reads ([n, L] uint8 array or
+    the lines of input_clean.dna) for the low-coverage rule of stage1_run_w -- more than 98 % distinct first-dictionary k-mers: up to
+    4096 chains of at least 512 reads"""
     k = n_clean // reads_per_chain
     k = max(k, min(2048, n_clean // 1024))
-    return max(1, min(k, 65536))
+    k = max(1, min(k, 65536))
+    if clean is not None and n_clean > 0:
+        if isinstance(clean, (bytes, bytearray)):
+            rows = [l for l in bytes(clean).split(b"\n") if l and b"N" not in l]
+            clean = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), -1)
+        L = clean.shape[1]
+        ds = L // 2 - 32 if L > 100 else L // 2 - L * 32 // 100      # harc:57-58, dict1_start .. dict1_end
+        de = L // 2 - 1
+        nbins = np.unique(np.ascontiguousarray(clean[:, ds:de + 1]), axis=0).shape[0]
+        if nbins > 0.98 * n_clean:
+            k = max(k, min(4096, n_clean // 512))
+    return k

@@ -128,7 +128,7 @@ def test_two_ranks_one_gpu_match_the_cpu_model(world, n, L, err, E, K, S, oracle
         info = res[r]["info"]
         assert info[6] == plan[r]["clean"].shape[0] and info[7] == plan[r]["withN"].shape[0], (r, info)
         assert info[0] == sum(p["clean"].shape[0] for p in plan) and info[2] == n
-        Ko = K if K else gen.auto_chains(plan[r]["clean"].shape[0])
+        Ko = K if K else gen.auto_chains(plan[r]["clean"].shape[0], clean=plan[r]["clean"])
         want = shard_model.oracle_shard(oracle, plan[r], L, E, Ko, S, str(tmp_path / ("o%d" % r)))
         for k, v in res[r]["files"].items():
             assert v == want[k], "rank %d: %s differs from the oracle on the modelled shard" % (r, k)

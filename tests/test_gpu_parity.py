@@ -103,7 +103,7 @@ def test_medium_vs_oracle_and_roundtrip(n, L, glen, err, K, E, S, oracle, tmp_pa
     import harc_amd
     txt = gen.reads_text(1234 + n, n, L, glen, err=err)
     (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
-    Ko = K if K else gen.auto_chains(txt.count(b"\n") - sum(1 for l in txt.split(b"\n") if b"N" in l))   # auto_chains() in stage1.hip
+    Ko = K if K else gen.auto_chains(txt.count(b"\n") - sum(1 for l in txt.split(b"\n") if b"N" in l), clean=txt)   # auto_chains() in stage1.hip
     inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, L, Ko, E, tmp_path / "o", S if S else 16)
     base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
     harc_amd.compress(base, L, num_thr=E, num_chains=K, num_steps=S)
@@ -375,7 +375,7 @@ def test_minimizer_shard_input_matches_oracle(n, world, K, S, oracle, tmp_path):
     txt = b"".join(bytes(r) + b"\n" for r in sel)
     (tmp_path / "o").mkdir(); (tmp_path / "g1").mkdir(); (tmp_path / "g2").mkdir()
     nclean = sel.shape[0]
-    Ko = K if K else gen.auto_chains(nclean)
+    Ko = K if K else gen.auto_chains(nclean, clean=sel)
     inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, Ko, 4, tmp_path / "o", S)
     outs = []
     for d in ("g1", "g2"):
