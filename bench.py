@@ -16,15 +16,142 @@ libharc_amd.so, packed read + u32 global id per read -- then each GPU chains and
 import argparse
 import json
 import os
+import signal
+import socket
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402  (device memory, streams and torch.distributed only)
+torch = None  # imported in main(), AFTER the launcher decision: the process that starts the ranks never touches the GPU
+
+
+# ---------------------------------------------------------------------------------------------- launcher (python bench.py --gpus N)
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as a fresh child
+    (python -m torch.distributed.run --nproc-per-node N bench.py ...), relay rank 0's JSON line and leave with the child's exit
+    code.  Nothing in this process has touched the GPU (torch is not even imported yet), and nothing is re-exec'ed.  The child
+    runs in its own process group; when it outlives --launch-timeout the whole group is killed and the exit code is 124."""
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # RCCL between processes: dmabuf IPC (before any HIP call of a rank)
+    env["HARC_BENCH_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    line = [None]
+
+    def reader():
+        for raw in child.stdout:
+            txt = raw.decode("utf-8", "replace").strip()
+            if txt.startswith("{") and '"metric"' in txt:
+                line[0] = txt
+            elif txt:
+                print(txt, file=sys.stderr)
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    try:
+        rc = child.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {args.gpus} ranks did not finish within {args.launch_timeout} s: ending process {child.pid} and its descendants", file=sys.stderr)
+        # exactly the processes this call started: the launcher child and whatever descends from it (torch.distributed.run puts its workers
+        # into sessions of their own, so the process group alone would miss them)
+        import psutil
+        try:
+            tree = psutil.Process(child.pid).children(recursive=True)
+        except psutil.Error:
+            tree = []
+        child.terminate()                                         # torch.distributed.run ends its workers on SIGTERM
+        try:
+            child.wait(timeout=15)
+        except subprocess.TimeoutExpired:
+            pass
+        for pr in tree:
+            try:
+                pr.kill()
+            except psutil.Error:
+                pass
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+        child.wait()
+        rc = 124
+    th.join(timeout=10)
+    if rc == 0 and line[0] is None:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        rc = 1
+    if line[0] is not None and rc == 0:
+        print(line[0])
+        sys.stdout.flush()
+    sys.exit(rc)
+
+
+class Watchdog:
+    """A rank that waits for a peer inside a collective (ncclGroupEnd, a barrier, the communicator bootstrap) waits forever when the
+    peer died or never came.  Every phase that can block on a peer runs under `with wd.phase(name, seconds)`: a daemon thread ends
+    THIS process with exit code 86 when the phase overruns (the C calls release the GIL), torch.distributed.run then ends the other
+    ranks and the launcher returns non-zero.  Never a re-exec."""
+
+    def __init__(self):
+        self.deadline = None
+        self.name = ""
+        self.lock = threading.Lock()
+        t = threading.Thread(target=self.run, daemon=True)
+        t.start()
+
+    def run(self):
+        while True:
+            time.sleep(1.0)
+            with self.lock:
+                d, nm = self.deadline, self.name
+            if d is not None and time.monotonic() > d:
+                sys.stderr.write(f"bench.py watchdog: rank {os.environ.get('RANK', '0')} stuck in '{nm}': leaving with exit code 86\n")
+                sys.stderr.flush()
+                os._exit(86)
+
+    def phase(self, name, seconds):
+        wd = self
+
+        class P:
+            def __enter__(self_):
+                with wd.lock:
+                    wd.deadline, wd.name = time.monotonic() + seconds, name
+
+            def __exit__(self_, *a):
+                with wd.lock:
+                    wd.deadline = None
+                return False
+        return P()
+
+
+def launch_only(args):
+    """--launch-only (CPU, gloo): what the launcher and the watchdog do, without a GPU -- every rank joins a gloo group, the world size is
+    all-reduced and rank 0 prints a result line; --hang-rank R makes rank R sleep instead of joining the barrier (the watchdog of the
+    others must end the run with a non-zero exit code)."""
+    import torch.distributed as dist
+    wd = Watchdog()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    with wd.phase("init_process_group", args.watchdog):
+        dist.init_process_group("gloo")
+    import torch as th
+    t = th.ones(1, dtype=th.int64)
+    if args.hang_rank == rank:
+        time.sleep(10 * args.watchdog + 60)
+    with wd.phase("all_reduce", args.watchdog):
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "launch-only", "n_gpus": int(t.item()), "world_env": world, "launched": os.environ.get("HARC_BENCH_LAUNCHED") == "1"}))
+        sys.stdout.flush()
+    dist.destroy_process_group()
 
 WORKLOADS = {
     # name: (reads per GPU, read length, genome bp per GPU, error rate, description == BASELINE.json config)
@@ -198,7 +325,24 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (reference baseline, size comparison) and the exact-mode sample")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket exchange even at world size 1 (exercises the N>1 path on one GPU)")
     ap.add_argument("--cpu-sample", type=int, default=0)
+    ap.add_argument("--mg-mode", default="bucket", choices=["bucket"], help="N>1: bucket = minimizer-bucket shard + one all-to-all (north_star)")
+    ap.add_argument("--via-launcher", action="store_true", help="start the ranks through the launcher even for --gpus 1 (checks that the launcher costs nothing)")
+    ap.add_argument("--launch-timeout", type=float, default=3300.0, help="launcher: seconds after which the ranks' process group is killed")
+    ap.add_argument("--watchdog", type=float, default=600.0, help="seconds a rank may sit in one collective phase before it ends itself (exit code 86)")
+    ap.add_argument("--launch-only", action="store_true", help="CPU rehearsal of launcher + watchdog over gloo (tests)")
+    ap.add_argument("--hang-rank", type=int, default=-1, help="with --launch-only: this rank never joins the collective")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.via_launcher):
+        launch_ranks(args, [a for a in sys.argv[1:] if a != "--via-launcher"])      # does not return
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: start the ranks with --nproc-per-node {args.gpus} (or let bench.py do it: no WORLD_SIZE)")
+    if args.launch_only:
+        return launch_only(args)
+    global torch
+    import torch  # noqa: E402  (device memory, streams and torch.distributed only)
+    wd = Watchdog()
 
     # stdout carries the JSON line and nothing else: whatever C libraries print (RCCL's version banner, the library's counters) goes to
     # stderr from here on
@@ -209,6 +353,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() < max(1, world if "LOCAL_RANK" in os.environ else 1):      # counting devices does not initialise the GPU
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPUs are visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libharc_amd has no CPU path")
     torch.cuda.set_device(local)
@@ -220,7 +366,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)        # nccl == RCCL on ROCm
+        with wd.phase("init_process_group", args.watchdog):
+            import datetime
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=max(args.watchdog, 1800.0) + 60))    # nccl == RCCL on ROCm
 
     import harc_amd
     n, L, G, err, desc = WORKLOADS[args.workload]
@@ -268,8 +416,9 @@ def main():
     torch.cuda.empty_cache()                                      # hand torch's cached blocks back: the library allocates with hipMalloc
     if dist is not None:
         from harc_amd import multigpu
-        multigpu.init_comm(h, dist, dev)                          # ncclUniqueId from the library, broadcast over the process group
-        sig_in = list(multigpu.allreduce_signature(dist, tuple(sig_in), dev))    # the whole job's reads, BEFORE any exchange
+        with wd.phase("communicator bootstrap", args.watchdog):
+            multigpu.init_comm(h, dist, dev)                      # ncclUniqueId from the library, broadcast over the process group
+            sig_in = list(multigpu.allreduce_signature(dist, tuple(sig_in), dev))    # the whole job's reads, BEFORE any exchange
     with_pack_order = args.workload == "c5s"
 
     def step():
@@ -287,12 +436,15 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        with wd.phase("warm-up step", args.watchdog):
+            step()
     agg = dict(propose_ms=0.0, launches=0, steps_alg=0, useful=0, cands=0, cands_seq=0, probes=0, rounds=0)
-    barrier()
+    with wd.phase("barrier before the timed region", args.watchdog):
+        barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        with wd.phase("timed step", args.watchdog):
+            step()
         c = h.counters()
         agg["propose_ms"] += c.propose_ms
         agg["launches"] += c.propose_launches
@@ -302,12 +454,14 @@ def main():
         agg["useful"] += c.useful_probes
         agg["rounds"] += c.rounds
         agg["steps_alg"] += c.n_clean
-    barrier()
+    with wd.phase("barrier after the timed region", args.watchdog):
+        barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        with wd.phase("max over ranks", args.watchdog):
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
     c = h.counters()
     # round trip at full size, outside the timed region: decode the streams of the last step on the GPU (decoder.cpp:90-169
     # restated in verify.hip) and compare the multiset signature (count, sum, xor of 64-bit read hashes) with the inputs'.  N GPUs:
@@ -316,10 +470,11 @@ def main():
     dsig = h.decode_signature()
     seq_bases_total, reads_total = int(c.seq_bases), n
     if dist is not None:
-        dsig = multigpu.allreduce_signature(dist, dsig, dev)
-        sb = torch.tensor([int(c.seq_bases)], dtype=torch.int64, device=dev)
-        dist.all_reduce(sb)
-        seq_bases_total, reads_total = int(sb.item()), n * world
+        with wd.phase("round-trip signature", args.watchdog):
+            dsig = multigpu.allreduce_signature(dist, dsig, dev)
+            sb = torch.tensor([int(c.seq_bases)], dtype=torch.int64, device=dev)
+            dist.all_reduce(sb)
+            seq_bases_total, reads_total = int(sb.item()), n * world
     roundtrip = {"ok": bool(tuple(dsig) == tuple(sig_in)), "reads_decoded": int(dsig[0]), "reads_in": int(sig_in[0]),
                  "check": "multiset signature (count, sum, xor of 64-bit read hashes) of the GPU-decoded streams of all ranks == the input reads of all ranks"}
     total_reads = n * world * args.steps
@@ -383,10 +538,24 @@ def main():
                                "rounds": int(c.rounds), "conflicts": int(c.conflicts), "contigs": int(c.contigs),
                                "seq_bases": int(c.seq_bases), "device_bytes_peak": int(c.device_bytes_peak)},
     }
+    if dist is not None:
+        # every N>1 line carries what ONE GPU does with its own batch, unsharded (no exchange, the single-GPU schedule): the N = 1 equivalent
+        # measured in this very run on rank 0, outside the timed region
+        out["per_gpu_value"] = round(value / world, 3)
+        if rank == 0:
+            h.shard_reset()
+            h.reorder(); h.encode()                               # warm-up at the unsharded size (pool growth)
+            t1 = time.perf_counter()
+            h.reorder(); h.encode()
+            d1 = time.perf_counter() - t1
+            c1 = h.counters()
+            out["n1_equivalent"] = {"value": round(n / d1 / 1e6, 3), "unit": "Mreads/s", "what": "rank 0's own batch, unsharded, on one GPU (1024 reads per chain as in the sharded run)",
+                                    "ms_per_step": round(d1 * 1e3, 3), "seq_bases_per_read": round(int(c1.seq_bases) / max(1, n), 3)}
+            out["scaling_vs_n1_equivalent"] = round(value / max(1e-9, out["n1_equivalent"]["value"]), 3)
     h.close()
     del h
     # ---- bounded side legs on rank 0 (outside the timed region): a sample of the same generator at the same coverage and error rate
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and (not args.no_cpu or dist is not None):
         ns = args.cpu_sample or min(n, 3_300_000 if err > 0 or G // max(1, n) < 10 else 1_000_000)
         if spike:
             Gs, sspike = G, spike                                 # repeat-spiked genomes are not scaled: same genome, fewer reads would change the coverage
@@ -422,7 +591,7 @@ def main():
                                    "buckets": nb, "sample": sdesc + ", clean reads only",
                                    "seq_bases_per_read_this_run": round(seq_bases_total / max(1, reads_total), 3)}
             del pk, bk, cl
-        if world == 1:
+        if world == 1 and not args.no_cpu:
             sample_np = sample.cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(sample_np, L, sdesc)
             # exact mode: num_chains = 1 is the reference at -t 1 byte for byte (tests/test_gpu_parity.py); its speed on a bounded sample
@@ -449,8 +618,9 @@ def main():
                                                "ours_bytes": ours, "reference_bytes": theirs, "sample": f"{nz} reads, same coverage, one chain per {rpc_eff:.0f} reads as in the timed workload"}
         del sample
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        with wd.phase("final barrier (rank 0 runs the side legs meanwhile)", max(args.watchdog, 1800.0)):
+            dist.barrier()
+            dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
         real_stdout.write(json.dumps(out) + "\n")                 # the ONE JSON line: the only thing on stdout

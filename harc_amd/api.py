@@ -91,6 +91,7 @@ def lib():
     l.harc_amd_comm_barrier.argtypes = [ctx]
     l.harc_amd_comm_destroy.argtypes = [ctx]
     l.harc_amd_shard_exchange.argtypes = [ctx, C.POINTER(C.c_uint64)]
+    l.harc_amd_shard_reset.argtypes = [ctx]
     l.harc_amd_compress_fastq_shard_files.argtypes = [PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
     l.harc_amd_merge_shard_files.argtypes = [C.c_char_p, C.c_int32]
     _lib = l
@@ -252,6 +253,10 @@ class HarcAmd:
         info = (C.c_uint64 * 8)()
         _check(lib().harc_amd_shard_exchange(self._ctx, info))
         return tuple(int(x) for x in info)
+
+    def shard_reset(self):
+        """the stages read this context's own slice again (no exchange); results of the last run go"""
+        _check(lib().harc_amd_shard_reset(self._ctx))
 
     def reorder(self):
         _check(lib().harc_amd_reorder(self._ctx))

@@ -22,6 +22,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;               // optional: used when a collective times out
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -44,6 +45,7 @@ int rccl_load()
     SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
     SYM(AllGather, "ncclAllGather"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(h, "ncclCommAbort"));
     g_rccl.h = h;
     return HARC_AMD_OK;
 }
@@ -56,11 +58,38 @@ int rccl_load()
         }                                                                                                          \
     } while (0)
 
+// seconds a collective may stay on the stream before the rank gives up on its peers (HARC_AMD_COMM_TIMEOUT; 0 = wait for ever)
+static double comm_timeout_s()
+{
+    double t = 600.0;
+    if (const char *e = getenv("HARC_AMD_COMM_TIMEOUT")) { char *end = nullptr; const double v = strtod(e, &end); if (end != e && v >= 0) t = v; }
+    return t;
+}
+static double mono_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
 struct RcclComm : HarcComm {
     ncclComm_t comm = nullptr;
     uint64_t *d_ag = nullptr; size_t ag_cap = 0;               // small device buffer for the count all-gather
     ~RcclComm() override { if (comm) g_rccl.CommDestroy(comm); if (d_ag) (void)hipFree(d_ag); }
     const char *name() const override { return "rccl"; }
+    // A peer that died (or never came) leaves this rank's stream waiting inside the collective for ever: the stream is polled, and
+    // when the collective has not finished after the timeout the communicator is aborted and the call fails with HARC_AMD_ETIMEOUT.
+    // The context cannot be used for another exchange after that: the caller is expected to end the process.
+    int wait(harc_amd_ctx *c, const char *what) override
+    {
+        const double lim = comm_timeout_s(), t0 = mono_now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) return HARC_AMD_OK;
+            if (q != hipErrorNotReady) { harc_set_error("%s: %s", what, hipGetErrorString(q)); return HARC_AMD_ENODEVICE; }
+            if (lim > 0 && mono_now() - t0 > lim) {
+                harc_set_error("%s: no answer from the peers after %.0f s (rank %d of %d); communicator aborted", what, lim, rank, world);
+                if (g_rccl.CommAbort && comm) { (void)g_rccl.CommAbort(comm); comm = nullptr; }
+                return HARC_AMD_ETIMEOUT;
+            }
+            usleep(mono_now() - t0 < 0.05 ? 50 : 1000);
+        }
+    }
     int allgather_u64(harc_amd_ctx *c, const uint64_t *in, int n, uint64_t *out) override
     {
         const size_t need = (size_t)(world + 1) * n * 8;
@@ -69,8 +98,7 @@ struct RcclComm : HarcComm {
         HIP_TRY(hipMemcpyAsync(d_in, in, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
         NCCL_TRY(g_rccl.AllGather(d_in, d_out, (size_t)n, ncclUint64, comm, c->stream));
         HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)world * n * 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        return HARC_AMD_OK;
+        return wait(c, "all-gather of the counts");
     }
     int alltoallv(harc_amd_ctx *c, int narr, const void *const *send, const size_t *const *soff, const size_t *const *sbytes,
                   void *const *recv, const size_t *const *roff, const size_t *const *rbytes) override
@@ -78,26 +106,37 @@ struct RcclComm : HarcComm {
         // One group; every (array, peer) chunk goes as pieces of at most PIECE bytes -- sender and receiver cut the same byte count the same
         // way, and the pieces of a pair are matched in the order they are posted.  (With two ranks a chunk of configs[2] is 5.6 GB; a
         // single send of 10 GB to the rank itself, configs[4] at 1/16 on one GPU, never came back.)
-        const size_t PIECE = getenv("HARC_AMD_XCHG_PIECE") ? (size_t)strtoull(getenv("HARC_AMD_XCHG_PIECE"), nullptr, 10) : ((size_t)1 << 30);
+        size_t PIECE = (size_t)1 << 30;
+        if (const char *e = getenv("HARC_AMD_XCHG_PIECE")) {                          // every rank must use the same value; nonsense falls back to the default
+            char *end = nullptr; const unsigned long long v = strtoull(e, &end, 10);
+            if (end != e && v >= ((unsigned long long)1 << 20)) PIECE = (size_t)v;
+        }
         NCCL_TRY(g_rccl.GroupStart());
-        for (int a = 0; a < narr; a++)
-            for (int p = 0; p < world; p++) {
+        // an error between GroupStart and GroupEnd must not leave the group open: the first one is remembered, posting stops, the group is closed
+        ncclResult_t first = ncclSuccess; const char *where = "";
+        for (int a = 0; a < narr && first == ncclSuccess; a++)
+            for (int p = 0; p < world && first == ncclSuccess; p++) {
                 // zero-byte chunks are skipped on both sides: sender and receiver see the same count matrix
-                for (size_t o = 0; o < sbytes[a][p]; o += PIECE) {
+                for (size_t o = 0; o < sbytes[a][p] && first == ncclSuccess; o += PIECE) {
                     const size_t n = sbytes[a][p] - o < PIECE ? sbytes[a][p] - o : PIECE;
-                    NCCL_TRY(g_rccl.Send((const char *)send[a] + soff[a][p] + o, n, ncclUint8, p, comm, c->stream));
+                    first = g_rccl.Send((const char *)send[a] + soff[a][p] + o, n, ncclUint8, p, comm, c->stream); where = "ncclSend";
                 }
-                for (size_t o = 0; o < rbytes[a][p]; o += PIECE) {
+                for (size_t o = 0; o < rbytes[a][p] && first == ncclSuccess; o += PIECE) {
                     const size_t n = rbytes[a][p] - o < PIECE ? rbytes[a][p] - o : PIECE;
-                    NCCL_TRY(g_rccl.Recv((char *)recv[a] + roff[a][p] + o, n, ncclUint8, p, comm, c->stream));
+                    first = g_rccl.Recv((char *)recv[a] + roff[a][p] + o, n, ncclUint8, p, comm, c->stream); where = "ncclRecv";
                 }
             }
-        NCCL_TRY(g_rccl.GroupEnd());
-        return HARC_AMD_OK;
+        const ncclResult_t ge = g_rccl.GroupEnd();
+        if (first != ncclSuccess) { harc_set_error("all-to-all: %s -> %s", where, g_rccl.GetErrorString(first)); return HARC_AMD_ENODEVICE; }
+        if (ge != ncclSuccess) { harc_set_error("all-to-all: ncclGroupEnd -> %s", g_rccl.GetErrorString(ge)); return HARC_AMD_ENODEVICE; }
+        return wait(c, "all-to-all of the reads");
     }
 };
 
 // ------------------------------------------------------------------------------------------------ mailbox (tests)
+// Compiled only with -DHARC_AMD_TEST_TRANSPORT (the Makefile's default, TEST_TRANSPORT=1: the one-GPU tests of the sharded path need it);
+// a production build (make TEST_TRANSPORT=0) has RCCL only and harc_amd_comm_init_mailbox answers HARC_AMD_ESTATE.
+#ifdef HARC_AMD_TEST_TRANSPORT
 struct MailboxComm : HarcComm {
     std::string dir;
     uint64_t seq = 0;
@@ -159,7 +198,9 @@ struct MailboxComm : HarcComm {
             }
         return HARC_AMD_OK;
     }
+    int wait(harc_amd_ctx *c, const char *) override { HIP_TRY(hipStreamSynchronize(c->stream)); return HARC_AMD_OK; }
 };
+#endif
 } // namespace
 
 // ------------------------------------------------------------------------------------------------ C-ABI
@@ -192,12 +233,17 @@ extern "C" int harc_amd_comm_init(harc_amd_ctx *c, const uint8_t *id, size_t id_
 extern "C" int harc_amd_comm_init_mailbox(harc_amd_ctx *c, const char *dir, int32_t world, int32_t rank)
 {
     if (!c || !dir || world < 1 || rank < 0 || rank >= world) { harc_set_error("harc_amd_comm_init_mailbox: bad arguments"); return HARC_AMD_EINVAL; }
+#ifndef HARC_AMD_TEST_TRANSPORT
+    harc_set_error("harc_amd_comm_init_mailbox: this library was built without the test transport (make TEST_TRANSPORT=1)");
+    return HARC_AMD_ESTATE;
+#else
     delete c->comm; c->comm = nullptr;
     MailboxComm *m = new MailboxComm();
     m->world = world; m->rank = rank; m->dir = dir;
     if (const char *e = getenv("HARC_AMD_MAILBOX_TIMEOUT")) m->timeout_s = atof(e);
     c->comm = m;
     return HARC_AMD_OK;
+#endif
 }
 
 extern "C" int harc_amd_comm_destroy(harc_amd_ctx *c)

@@ -145,6 +145,8 @@ struct HarcComm {
     // the chunk from peer p lands at recv[a] + roff[a][p] (rbytes[a][p] bytes); enqueued on c->stream
     virtual int alltoallv(harc_amd_ctx *c, int narr, const void *const *send, const size_t *const *soff, const size_t *const *sbytes,
                           void *const *recv, const size_t *const *roff, const size_t *const *rbytes) = 0;
+    // everything enqueued on c->stream so far (the collective included) has finished, or the peers did not answer in time (HARC_AMD_ETIMEOUT)
+    virtual int wait(harc_amd_ctx *c, const char *what) = 0;
     virtual const char *name() const = 0;
 };
 int harc_in_reserve(harc_amd_ctx *c, harc_amd_ctx::InBuf *b, size_t bytes);   // raw allocation reused across runs
@@ -161,6 +163,16 @@ void harc_raw_free(harc_amd_ctx *c, void *p);
 typedef unsigned long long harc_mark_t;
 harc_mark_t harc_pool_mark(harc_amd_ctx *c);
 void harc_pool_release(harc_amd_ctx *c, harc_mark_t m);          // everything allocated after the mark becomes reusable
+// scope guard: what was allocated after the mark goes on EVERY way out of the scope (error returns included) unless keep() was called
+struct PoolScope {
+    harc_amd_ctx *c; harc_mark_t mk; bool armed = true;
+    explicit PoolScope(harc_amd_ctx *c_) : c(c_), mk(harc_pool_mark(c_)) {}
+    PoolScope(const PoolScope &) = delete;
+    PoolScope &operator=(const PoolScope &) = delete;
+    ~PoolScope() { if (armed) harc_pool_release(c, mk); }
+    void keep() { armed = false; }
+    void release_now() { if (armed) { harc_pool_release(c, mk); armed = false; } }
+};
 
 // ---- primitives (prims.hip): thin wrappers over rocPRIM device-wide sort / scan
 int prim_sort_pairs_u64_u32(harc_amd_ctx *c, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit);

@@ -20,6 +20,9 @@
 int main(int argc, char **argv)
 {
     if (argc < 4) { fprintf(stderr, "usage: %s reorder|encoder|compress|pack_order <basedir> <readlen> [num_thr] [num_chains]\n", argv[0]); return 2; }
+    // RCCL between processes needs dmabuf IPC on this driver stack (hipIpcGetMemHandle fails otherwise): set before the first HIP call
+    // of the process, which is inside the library.  An explicit setting of the caller wins.
+    if (!strcmp(argv[1], "compressfq_shard")) setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     if (!strcmp(argv[1], "merge_shards")) {
         const int rcm = harc_amd_merge_shard_files(argv[2], atoi(argv[3]));
         if (rcm != 0) { fprintf(stderr, "harc_amd_stage merge_shards failed (%d): %s\n", rcm, harc_amd_last_error()); return 1; }

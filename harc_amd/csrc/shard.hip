@@ -83,7 +83,7 @@ int shard_partition(harc_amd_ctx *c, const uint64_t *d_words, uint32_t n, int nw
 {
     HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nb * 8, c->stream));
     if (!n) return HARC_AMD_OK;
-    const harc_mark_t mk = harc_pool_mark(c);
+    PoolScope scope(c);                                           // temporaries go on every way out
     uint32_t *b = nullptr, *i0 = nullptr, *i1 = nullptr; uint64_t *k0 = nullptr, *k1 = nullptr;
     RC_TRY(dalloc(c, &b, n)); RC_TRY(dalloc(c, &i0, n)); RC_TRY(dalloc(c, &i1, n)); RC_TRY(dalloc(c, &k0, n)); RC_TRY(dalloc(c, &k1, n));
     const dim3 g((n + 255) / 256), t(256);
@@ -95,7 +95,6 @@ int shard_partition(harc_amd_ctx *c, const uint64_t *d_words, uint32_t n, int nw
     hipLaunchKernelGGL(k_shard_gather, dim3((unsigned)(((uint64_t)n * nw + 255) / 256)), t, 0, c->stream, d_words, (const uint32_t *)i1, n, nw, gid0, d_out, d_gid_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    harc_pool_release(c, mk);
     return HARC_AMD_OK;
 }
 
@@ -126,8 +125,9 @@ extern "C" int harc_amd_shard_exchange(harc_amd_ctx *c, uint64_t *info)
         harc_set_error("Too many reads. HARC supports at most 4294967290 reads"); return HARC_AMD_EINVAL;      // preprocess.cpp:122-126
     }
 
-    // (2) group by destination bucket
-    const harc_mark_t mk = harc_pool_mark(c);
+    // (2) group by destination bucket.  Whatever goes wrong from here on, the send buffers go and the context keeps reading its own
+    // slice (harc_reset_shard above): a failed exchange leaves the context usable
+    PoolScope scope(c);
     uint64_t *s2 = nullptr, *s3 = nullptr; uint32_t *g2 = nullptr, *g3 = nullptr; unsigned long long *d_cnt = nullptr;
     RC_TRY(dalloc(c, &s2, (size_t)N * W + 1)); RC_TRY(dalloc(c, &g2, (size_t)N + 1));
     RC_TRY(dalloc(c, &s3, (size_t)NN * W3 + 1)); RC_TRY(dalloc(c, &g3, (size_t)NN + 1));
@@ -153,9 +153,9 @@ extern "C" int harc_amd_shard_exchange(harc_amd_ctx *c, uint64_t *info)
             so[3][p] = sNN * 4;     sb[3][p] = sn * 4;      ro[3][p] = rNN * 4;     rb[3][p] = rn * 4;
             sN += sc; sNN += sn; rN += rc; rNN += rn;
         }
-        if (sN != N || sNN != NN) { harc_set_error("shard exchange: bucket counts do not add up"); harc_pool_release(c, mk); return HARC_AMD_ENODEVICE; }
+        if (sN != N || sNN != NN) { harc_set_error("shard exchange: bucket counts do not add up"); return HARC_AMD_EINTERNAL; }
     }
-    if (rN > 0xFFFFFFFFull || rNN > 0xFFFFFFFFull) { harc_set_error("shard exchange: a bucket holds more than 2^32 reads"); harc_pool_release(c, mk); return HARC_AMD_EINVAL; }
+    if (rN > 0xFFFFFFFFull || rNN > 0xFFFFFFFFull) { harc_set_error("shard exchange: a bucket holds more than 2^32 reads"); return HARC_AMD_EINVAL; }
     RC_TRY(harc_in_reserve(c, &c->x_reads, ((size_t)rN * W + 1) * 8)); RC_TRY(harc_in_reserve(c, &c->x_gid, ((size_t)rN + 1) * 4));
     RC_TRY(harc_in_reserve(c, &c->x_nreads3, ((size_t)rNN * W3 + 1) * 8)); RC_TRY(harc_in_reserve(c, &c->x_ngid, ((size_t)rNN + 1) * 4));
     // (4) ONE all-to-all(v): packed reads + ids (8W + 4 bytes per clean read, 8 W3 + 4 per read with N)
@@ -164,10 +164,9 @@ extern "C" int harc_amd_shard_exchange(harc_amd_ctx *c, uint64_t *info)
         void *rp[4] = { c->x_reads.p, c->x_gid.p, c->x_nreads3.p, c->x_ngid.p };
         const size_t *sop[4], *sbp[4], *rop[4], *rbp[4];
         for (int a = 0; a < 4; a++) { sop[a] = so[a].data(); sbp[a] = sb[a].data(); rop[a] = ro[a].data(); rbp[a] = rb[a].data(); }
-        RC_TRY(cm->alltoallv(c, 4, sp, sop, sbp, rp, rop, rbp));
+        RC_TRY(cm->alltoallv(c, 4, sp, sop, sbp, rp, rop, rbp));     // returns when the chunks have arrived (or the peers timed out)
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    harc_pool_release(c, mk);
+    scope.release_now();
     c->d_reads = (uint64_t *)c->x_reads.p; c->N = (uint32_t)rN;
     c->d_nreads3 = (uint64_t *)c->x_nreads3.p; c->NN = (uint32_t)rNN;
     c->d_gid = (uint32_t *)c->x_gid.p; c->d_ngid = (uint32_t *)c->x_ngid.p;
@@ -175,5 +174,15 @@ extern "C" int harc_amd_shard_exchange(harc_amd_ctx *c, uint64_t *info)
     c->shard_info[0] = tot[0]; c->shard_info[1] = tot[1]; c->shard_info[2] = tot[2];
     c->shard_info[3] = off[0]; c->shard_info[4] = off[1]; c->shard_info[5] = off[2]; c->shard_info[6] = rN; c->shard_info[7] = rNN;
     if (info) memcpy(info, c->shard_info, sizeof c->shard_info);
+    return HARC_AMD_OK;
+}
+
+// The stages read the context's own inputs again (what harc_amd_set_* installed); results of the last run go.  The communicator stays.
+extern "C" int harc_amd_shard_reset(harc_amd_ctx *c)
+{
+    if (!c) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    harc_drop_results(c);
+    harc_reset_shard(c);
     return HARC_AMD_OK;
 }

@@ -190,7 +190,7 @@ int s1_partition_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, ui
 {
     HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nb * 8, c->stream));
     if (!n) { HIP_TRY(hipStreamSynchronize(c->stream)); return HARC_AMD_OK; }
-    const harc_mark_t mk = harc_pool_mark(c);
+    PoolScope scope(c);
     uint32_t *b = nullptr, *i0 = nullptr, *i1 = nullptr; uint64_t *k0 = nullptr, *k1 = nullptr;
     RC_TRY(dalloc(c, &b, n)); RC_TRY(dalloc(c, &i0, n)); RC_TRY(dalloc(c, &i1, n)); RC_TRY(dalloc(c, &k0, n)); RC_TRY(dalloc(c, &k1, n));
     hipLaunchKernelGGL(k_bucket, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_packed, n, c->P.readlen, c->W, nb, b);
@@ -200,7 +200,6 @@ int s1_partition_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, ui
     hipLaunchKernelGGL(k_gather_reads, dim3((unsigned)(((uint64_t)n * c->W + 255) / 256)), dim3(256), 0, c->stream, d_packed, (const uint32_t *)i1, n, c->W, d_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    harc_pool_release(c, mk);
     return HARC_AMD_OK;
 }
 
@@ -1478,7 +1477,7 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
 {
     (void)kbits;                                                  // the scrambled keys use all 64 bits
     if (n == 0) return HARC_AMD_OK;
-    const harc_mark_t mk = harc_pool_mark(c);
+    PoolScope scope(c);                                           // temporaries go on every way out
     uint64_t *k1 = nullptr; uint32_t *h0 = nullptr, *b0 = nullptr, *bs = nullptr;
     RC_TRY(dalloc(c, &k1, n)); RC_TRY(dalloc(c, &h0, n)); RC_TRY(dalloc(c, &b0, n)); RC_TRY(dalloc(c, &bs, n));
     const unsigned g = (n + 255) / 256;
@@ -1507,7 +1506,7 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     uint32_t nb2[2] = { 0, 0 };
     HIP_TRY(hipMemcpyAsync(nb2, d->d_nbins, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));                                    // temporaries are reused after this point
-    harc_pool_release(c, mk);
+    scope.release_now();
     if (nb2[1]) { harc_set_error("dictionary: %u bins hold more than %u reads with the same k-mer (count field of the slot)", nb2[1], SLOT_CNT_MASK); return HARC_AMD_EINVAL; }
     return HARC_AMD_OK;
 }
@@ -1599,7 +1598,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     HIP_TRY(hipEventRecord(e0, c->stream));
 
     // ---- pool layout: [stage-I results, worst case][dictionaries][index scratch -> released][chain state] ; all but the results
-    //      are released at the end so that stage II starts right above them
+    //      are released at the end so that stage II starts right above them.  An error on the way releases everything (run_scope).
+    PoolScope run_scope(c);
     RC_TRY(dalloc(c, &c->d_order, (size_t)N + 1)); RC_TRY(dalloc(c, &c->d_flag, (size_t)N + 1)); RC_TRY(dalloc(c, &c->d_pos, (size_t)N + 1));
     RC_TRY(dalloc(c, &c->d_rc, (size_t)N + 1)); RC_TRY(dalloc(c, &c->d_order_s, (size_t)N + 1));
     const harc_mark_t mark_results = harc_pool_mark(c);
@@ -1633,7 +1633,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
                 bloom_nwin[l] = (same && bloom_m > 0 && nb > bloom_m && (size_t)bloom_lines * 64 >= bloom_mz_bytes) ? nb - bloom_m + 1 : 0;
             }
         }
-        const harc_mark_t mk = harc_pool_mark(c);
+        PoolScope kscope(c);
         uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
         RC_TRY(dalloc(c, &k0, N)); RC_TRY(dalloc(c, &i0, N));
         for (int l = 0; l < 2; l++) {
@@ -1642,7 +1642,6 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (bloom_lines) hipLaunchKernelGGL(k_s1_bloom_set, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, d_bloom[l], bloom_lines, bloom_nwin[l], bloom_mmask);
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, N, (unsigned)kbits));
         }
-        harc_pool_release(c, mk);
     }
     // Low coverage: almost every read has its k-mer to itself (distinct k-mers / reads = (1 - e^-x) / x with x reads per genome position:
     // 0.986 at 2.9x, 0.95 at 11x, 0.77 at 52x).  There chains cost next to nothing in compressed size (configs[0] stand-in: 1.003 of the
@@ -1657,7 +1656,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (N) {
         HIP_TRY(hipMemcpyAsync(&nlarge, d_nlarge, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (nlarge > maxlarge) { harc_set_error("stage I: %u bins above %u reads, list of %u", nlarge, HARC_LARGEBIN, maxlarge); return HARC_AMD_ENODEVICE; }   // cannot happen: 2 N / HARC_LARGEBIN bound
+        if (nlarge > maxlarge) { harc_set_error("stage I: %u bins above %u reads, list of %u", nlarge, HARC_LARGEBIN, maxlarge); return HARC_AMD_EINTERNAL; }   // cannot happen: 2 N / HARC_LARGEBIN bound
     }
     // their reads once more, in bin order (k_large_fill); nothing on ordinary data
     uint2 *d_largetab = nullptr; uint64_t *d_mirror = nullptr;
@@ -1867,6 +1866,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     }
 
     harc_pool_release(c, mark_results);                          // stage II starts right above the results
+    run_scope.keep();
     c->have_s1 = true;
     return HARC_AMD_OK;
 }

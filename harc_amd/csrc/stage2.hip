@@ -982,7 +982,7 @@ int stage2_run(harc_amd_ctx *c)
     uint32_t *order_out = nullptr, *orderN_out = nullptr;
     RC_TRY(dalloc(c, &order_out, (size_t)M + S + 1)); RC_TRY(dalloc(c, &orderN_out, (size_t)NN + 1));
     c->d_s2_order = c->d_s2_orderN = nullptr; c->n_s2_order = c->n_s2_orderN = 0;
-    const harc_mark_t mark_s2 = harc_pool_mark(c);
+    PoolScope s2_scope(c);                                        // the scratch goes on every way out (the two order streams above stay)
     S2Args a; memset(&a, 0, sizeof a);
     a.L = L; a.W = W; a.W3 = W3; a.thresh_s = P.thresh_s; a.maxsearch = P.maxsearch;
     if (L > 50) { a.ds[0] = 0; a.de[0] = 20; a.ds[1] = 21; a.de[1] = 41; }                     // encoder.cpp:132-145
@@ -1040,7 +1040,7 @@ int stage2_run(harc_amd_ctx *c)
             HIP_TRY(hipMemsetAsync(bloom[l], 0, ((size_t)1 << (lb - 5)) * 4, c->stream));
             bloom_shift[l] = 64 - lb;
         }
-        const harc_mark_t mk = harc_pool_mark(c);
+        PoolScope kscope(c);
         uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
         RC_TRY(dalloc(c, &k0, T)); RC_TRY(dalloc(c, &i0, T));
         for (int l = 0; l < 2; l++) {
@@ -1051,7 +1051,6 @@ int stage2_run(harc_amd_ctx *c)
             hipLaunchKernelGGL(k_count_big_bins, G256(dict[l].cap), dict[l].slots, dict[l].cap, (uint32_t)P.maxsearch, d_big);
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
-        harc_pool_release(c, mk);
     }
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; a.bloom[l] = bloom[l]; a.bloom_shift[l] = bloom_shift[l]; }
 
@@ -1351,13 +1350,14 @@ int stage2_run(harc_amd_ctx *c)
     c->C.bins_over_maxsearch = big;
     c->C.aligned_singletons = (uint64_t)S - US;                   // encoder.cpp:506-508
     c->C.aligned_N = (uint64_t)NN - UN;
-
-    harc_pool_release(c, mark_s2);
     return HARC_AMD_OK;
 }
 
 int pack_order_run(harc_amd_ctx *c)
 {
+    // after harc_amd_shard_exchange the order stream holds GLOBAL ids (< the whole job's clean reads) while `numbits` below is taken from
+    // the shard's own entry count: the packed fields would truncate them.  pack_order belongs to the merged read_order.bin (./harc -g).
+    if (c->d_gid) { harc_set_error("pack_order: the context holds a shard of a multi-GPU run (global ids); pack the merged read_order.bin instead"); return HARC_AMD_ESTATE; }
     { const void *p0 = nullptr; size_t n0 = 0; if (c->d_s2_order) RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_ORDER, 0, &p0, &n0)); }   // the order stream waits in HBM until wanted
     auto it = c->out.find(std::make_pair((int)HARC_AMD_S2_ORDER, 0));
     if (it == c->out.end()) { harc_set_error("pack_order: no read_order.bin"); return HARC_AMD_ESTATE; }
@@ -1368,7 +1368,7 @@ int pack_order_run(harc_amd_ctx *c)
     int numbits = 0; { uint32_t x = n; while (x) { numbits++; x >>= 1; } }        // (int)(log2(n)+1)
     const uint32_t ng = n / 32;
     uint32_t *d_in = nullptr, *d_out = nullptr;
-    const harc_mark_t mk = harc_pool_mark(c);
+    PoolScope scope(c);
     RC_TRY(dalloc(c, &d_in, (size_t)n + 1)); RC_TRY(dalloc(c, &d_out, (size_t)ng * numbits + 1));
     HIP_TRY(hipMemcpyAsync(d_in, in_p, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     if (ng) hipLaunchKernelGGL(k_pack_order, G256((uint64_t)ng * numbits), d_in, ng, numbits, d_out);
@@ -1381,6 +1381,5 @@ int pack_order_run(harc_amd_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     out_slice(c, HARC_AMD_P_ORDER, 0, hp, 8 + body_bytes);
     { std::vector<uint8_t> tailv(in_p + (size_t)ng * 32 * 4, in_p + (size_t)ng * 32 * 4 + (size_t)(n % 32) * 4); out_buf(c, HARC_AMD_P_ORDER_TAIL, 0) = tailv; }
-    harc_pool_release(c, mk);
     return HARC_AMD_OK;
 }

@@ -489,8 +489,21 @@ extern "C" int harc_amd_decoder_preserve_files(const harc_amd_params *params, co
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
             fr += c->pool_total;
-            const uint64_t cap = (uint64_t)(0.25 * (double)fr / (double)(3 * LL));     // clean + N + merged lines of the bin: a quarter of what is free
-            if (cap && bin_lines > cap) bin_lines = cap;
+            // every bin decodes every shard in full: the scratch of the LARGEST shard (three line buffers + streams + scans, ~3 (L+1) + 64
+            // bytes per read of the shard) is needed whatever the bin size, and is taken off before the bin gets its quarter
+            uint64_t nmax = 0;
+            for (int e = 0; e < num_thr_e; e++) {
+                FILE *fp = fopen((od + "read_pos.txt." + std::to_string(e)).c_str(), "rb");
+                if (fp) { if (fseek(fp, 0, SEEK_END) == 0) { const long sz = ftell(fp); if (sz > 0 && (uint64_t)sz > nmax) nmax = (uint64_t)sz; } fclose(fp); }
+            }
+            const double shard_scratch = (double)nmax * (3.0 * (double)LL + 64.0);
+            if (shard_scratch > 0.9 * (double)fr) {
+                harc_set_error("decoder_preserve: the largest shard (%llu reads) needs %.1f GB of decode scratch, %.1f GB are free; compress with more threads (-t) for smaller shards",
+                               (unsigned long long)nmax, shard_scratch / 1e9, (double)fr / 1e9);
+                return HARC_AMD_ENOMEM;
+            }
+            const uint64_t cap = (uint64_t)(0.25 * ((double)fr - shard_scratch) / (double)(3 * LL));     // clean + N + merged lines of the bin: a quarter of what is left
+            if (bin_lines > (cap ? cap : 1)) bin_lines = cap ? cap : 1;
         }
         if (const char *e = getenv("HARC_AMD_BIN_READS")) bin_lines = strtoull(e, nullptr, 10);      // tests: tiny bins
         if (bin_lines < 1) bin_lines = 1;

@@ -40,6 +40,7 @@ extern "C" {
 #define HARC_AMD_EIO (-3)         /* file contract violated (missing / short file) */
 #define HARC_AMD_ESTATE (-4)      /* call order violated (e.g. encode before reorder and without stage-I inputs) */
 #define HARC_AMD_ENOMEM (-5)
+#define HARC_AMD_ETIMEOUT (-7)    /* multi-GPU: the peers did not answer a collective within HARC_AMD_COMM_TIMEOUT seconds (default 600); the communicator is gone */
 #define HARC_AMD_EINTERNAL (-6)    /* an invariant of the library failed (bookkeeping mismatch, a schedule that does not settle): a bug, not an input problem */
 
 /* Runtime equivalent of src/config.h (harc:52-63).  Fill with harc_amd_default_params, then override. */
@@ -185,6 +186,8 @@ int harc_amd_comm_destroy(harc_amd_ctx *ctx);
    function again repeats the exchange.  info (8 u64, may be NULL): [0] clean reads of the whole job [1] reads with N [2] FASTQ
    records [3] this rank's first clean id [4] first N id [5] first record [6] clean reads received [7] N reads received. */
 int harc_amd_shard_exchange(harc_amd_ctx *ctx, uint64_t *info);
+/* The stages read the context's own slice again (as before the first exchange); the results of the last run go, the communicator stays. */
+int harc_amd_shard_reset(harc_amd_ctx *ctx);
 
 /* ---- compute (all on params.device, asynchronous internally, synchronised before return) */
 int harc_amd_reorder(harc_amd_ctx *ctx);      /* index build + chaining: reorder.cpp:277-703 */
