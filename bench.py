@@ -164,6 +164,7 @@ WORKLOADS = {
     "c4": (810_000_000, 101, 3_100_000_000, 0.01, "configs[3] stand-in on ONE GPU: 810M x 101bp, 3.1 Gbp i.i.d. genome (26x), 1% substitutions (1/4 N), odd reads RC"),
     "c4s": (50_000_000, 101, 191_000_000, 0.01, "configs[3] at 1/16 scale: 50M x 101bp, 191 Mbp i.i.d. genome (26x), 1% substitutions (1/4 N)"),
     "c5s": (250_000_000, 150, 194_000_000, 0.01, "configs[4] at 1/16 scale: 250M x 150bp, 194 Mbp i.i.d. genome (193x), 1% substitutions (1/4 N), -p (pack_order inside the step)"),
+    "c5g": (500_000_000, 150, 388_000_000, 0.01, "configs[4]: ONE GPU's share of the 8-GPU run, 500M x 150bp, 388 Mbp i.i.d. genome (193x), 1% substitutions (1/4 N: 31 % of the reads carry an N), -p (pack_order inside the step)"),
     "c3sd": (50_000_000, 100, 443_000_000, 0.005, "50M x 100bp on a 443 Mbp genome with a diverged repeat family: 100000 copies of one 300-bp element (12 % divergence), 3000 poly-A and 3000 (CA)n runs"),
     "c3m": (4_000_000, 100, 35_400_000, 0.0, "configs[2] at 1/88 scale: 4M x 100bp error-free, 35.4 Mbp i.i.d. genome (11.3x)"),
     "mini": (200_000, 100, 400_000, 0.005, "smoke-sized: 200k x 100bp, 0.4 Mbp genome"),
@@ -419,7 +420,7 @@ def main():
         with wd.phase("communicator bootstrap", args.watchdog):
             multigpu.init_comm(h, dist, dev)                      # ncclUniqueId from the library, broadcast over the process group
             sig_in = list(multigpu.allreduce_signature(dist, tuple(sig_in), dev))    # the whole job's reads, BEFORE any exchange
-    with_pack_order = args.workload == "c5s"
+    with_pack_order = args.workload in ("c5s", "c5g")
 
     def step():
         if dist is not None:

@@ -1688,7 +1688,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     a.L = P.readlen; a.maxmatch = P.maxmatch; a.thresh = P.thresh; a.maxsearch = P.maxsearch;
     a.Lp = ((W + 1) / 2) * 64; a.S = nsteps;
     a.nsugg_per_seed = HARC_NSUGG;
+#ifdef HARC_AMD_EXPERIMENTS    // schedule knobs change the archive bytes: never read from the environment by a product build (make EXPERIMENTS=1)
     if (const char *e = getenv("HARC_AMD_NSUGG")) { a.nsugg_per_seed = atoi(e); if (a.nsugg_per_seed < 0) a.nsugg_per_seed = 0; if (a.nsugg_per_seed > HARC_NSUGG) a.nsugg_per_seed = HARC_NSUGG; }
+#endif
     for (int l = 0; l < 2; l++) { a.ds[l] = P.dict_start[l]; a.de[l] = P.dict_end[l]; a.kbits[l] = 2 * (P.dict_end[l] - P.dict_start[l] + 1); }
     a.N = N; a.K = K; a.reads = c->d_reads;
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
@@ -1716,9 +1718,12 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         hipLaunchKernelGGL((k_steps_tables<W>), dim3(4), dim3(256), 0, c->stream, a, lt);
         a.lds_tab = lt;
     }
-    a.stepcap = getenv("HARC_AMD_STEPCAP") ? atoi(getenv("HARC_AMD_STEPCAP")) : HARC_STEP_CAP;   // experiments: the oracle knows the default only
+    a.stepcap = HARC_STEP_CAP; a.budget = HARC_SCAN_BUDGET;      // part of the schedule (the oracle has the same constants): fixed in a product build
+#ifdef HARC_AMD_EXPERIMENTS
+    if (getenv("HARC_AMD_STEPCAP")) a.stepcap = atoi(getenv("HARC_AMD_STEPCAP"));
+    if (getenv("HARC_AMD_BUDGET")) a.budget = atoi(getenv("HARC_AMD_BUDGET"));
+#endif
     if (a.stepcap < 1) a.stepcap = 1;
-    a.budget = getenv("HARC_AMD_BUDGET") ? atoi(getenv("HARC_AMD_BUDGET")) : HARC_SCAN_BUDGET;   // not part of the C-ABI: the oracle knows the default only
     a.nbatch = 0;                                                // adaptive batches (k_steps) unless a fixed schedule is forced
     a.firstmax[0] = a.firstmax[1] = (bloom_nwin[0] > 0 && bloom_nwin[1] > 0) ? 64 : 48;     // lines by minimizer: speculative probes share their lines
     if (const char *e = getenv("HARC_AMD_FIRSTMAX")) { int x = 32, y = 32; if (sscanf(e, "%d,%d", &x, &y) >= 1) { a.firstmax[0] = x < 1 ? 1 : x > 64 ? 64 : x; a.firstmax[1] = y < 1 ? 1 : y > 64 ? 64 : y; } }

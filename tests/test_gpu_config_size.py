@@ -1,0 +1,99 @@
+"""Parity at CONFIG size (run with -m gpu): the HIP path against the CPU oracle, every stage-I and stage-II file byte for byte, on
+BASELINE.json configs[0] (1 M x 100 bp, 35 Mbp genome, 2.9x) and the configs[1] stand-in (3.3 M x 100 bp, 6.3 Mbp genome, 52x, 0.5 %
+errors), with num_chains = 0 -- the library picks K itself, on configs[0] through its low-coverage rule (stage1_run_w: more than 98 %
+distinct first-dictionary k-mers -> up to 4096 chains), which tests/gen.auto_chains restates for the oracle.  At these sizes the code
+paths that small fixtures only reach through environment overrides run by themselves (whole-bucket fetches vs two-slot fetches, the
+bitmaps, thousands of chains, tens of super-rounds).  Plus a bounded run of the parity fuzz (tools/fuzz_parity.py) inside pytest."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests import gen
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _synth_text(n, L, G, err, seed):
+    """reads of bench.py's generator (made on the GPU: numpy needs minutes for 330 M bases with errors) -> bytes, one read per line"""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    bench.torch = torch
+    r = bench.synth_reads(n, L, G, err, seed, torch.device("cuda", 0)).cpu().numpy()
+    out = np.empty((n, L + 1), dtype=np.uint8)
+    out[:, :L] = r
+    out[:, L] = 10
+    return out.tobytes()
+
+
+@pytest.mark.parametrize("name,n,L,G,err,E,expect_lowcov", [("configs0", 1_000_000, 100, 35_000_000, 0.0, 8, True),
+                                                            ("configs1", 3_300_000, 100, 6_300_000, 0.005, 8, False)])
+def test_config_size_matches_oracle(name, n, L, G, err, E, expect_lowcov, oracle, tmp_path):
+    import harc_amd
+    txt = _synth_text(n, L, G, err, 20260 + n % 97)
+    (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
+    bo = ol.stage_dir(tmp_path / "o", {})
+    assert oracle.harc_oracle_preprocess(txt, len(txt), L, bo.encode()) == 0
+    inputs = ol.read_dir(bo)
+    nclean = len(inputs["input_clean.dna"]) // (L + 1)
+    K_plain = gen.auto_chains(nclean)
+    K = gen.auto_chains(nclean, clean=inputs["input_clean.dna"])
+    assert (K > K_plain) == expect_lowcov, (K, K_plain)               # configs[0]: the low-coverage rule must be what decides K
+    assert oracle.harc_oracle_reorder(bo.encode(), L, K, 16, None, None) == 0
+    s1 = ol.read_dir(bo)
+    assert oracle.harc_oracle_encoder(bo.encode(), L, E, None, None) == 0
+    s2 = ol.read_dir(bo)
+    bg = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.reorder(bg, L, num_chains=0)                              # the library's own choice of K
+    g1 = ol.read_dir(bg)
+    bad = [f for f in ol.STAGE1_FILES if g1.get(f) != s1[f]]
+    assert not bad, f"{name}: stage I differs from the oracle (K = {K}): {bad}"
+    harc_amd.encoder(bg, L, num_thr=E)
+    g2 = ol.read_dir(bg)
+    bad = [f for f in ol.stage2_files(E) if g2.get(f) != s2[f]]
+    assert not bad, f"{name}: stage II differs from the oracle: {bad}"
+    harc_amd.decoder(bg, E)
+    dec = np.frombuffer(ol.read_dir(bg)["output.dna"], dtype=np.uint8).reshape(-1, L + 1)
+    src = np.frombuffer(txt, dtype=np.uint8).reshape(-1, L + 1)
+    v = np.dtype((np.void, L + 1))
+    assert np.array_equal(np.sort(np.ascontiguousarray(dec).view(v).ravel()), np.sort(np.ascontiguousarray(src).view(v).ravel())), f"{name}: round trip"
+
+
+@pytest.mark.parametrize("it", range(24))
+def test_parity_fuzz_bounded(it, oracle, tmp_path):
+    """24 iterations of tools/fuzz_parity.py (seed 7): random repeat-rich inputs, random (L, K, S, E), every file against the oracle"""
+    import harc_amd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity as fz
+    rs = np.random.RandomState(7000 + it)
+    L = int(rs.choice([40, 63, 100, 100, 100, 101, 150]))
+    txt = fz.make_reads(rs, L)
+    nreads = len(txt) // (L + 1)
+    K = int(rs.choice([1, 2, 7, 33, 0, nreads // 64 + 1]))
+    S = int(rs.choice([1, 4, 16, 16, 64]))
+    E = int(rs.choice([1, 2, 5]))
+    (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
+    bo = ol.stage_dir(tmp_path / "o", {})
+    assert oracle.harc_oracle_preprocess(txt, len(txt), L, bo.encode()) == 0
+    inputs = ol.read_dir(bo)
+    nclean = len(inputs["input_clean.dna"]) // (L + 1)
+    Ko = K if K else gen.auto_chains(nclean, clean=inputs["input_clean.dna"])
+    assert oracle.harc_oracle_reorder(bo.encode(), L, Ko, S, None, None) == 0
+    s1 = ol.read_dir(bo)
+    assert oracle.harc_oracle_encoder(bo.encode(), L, E, None, None) == 0
+    s2 = ol.read_dir(bo)
+    bg = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.reorder(bg, L, num_chains=K, num_steps=S)
+    g1 = ol.read_dir(bg)
+    bad = [f for f in ol.STAGE1_FILES if g1.get(f) != s1[f]]
+    assert not bad, f"fuzz {it} (L={L} reads={nreads} K={K} S={S} E={E}): stage I {bad}"
+    harc_amd.encoder(bg, L, num_thr=E)
+    g2 = ol.read_dir(bg)
+    bad = [f for f in ol.stage2_files(E) if g2.get(f) != s2[f]]
+    assert not bad, f"fuzz {it} (L={L} reads={nreads} K={K} S={S} E={E}): stage II {bad}"
+    harc_amd.decoder(bg, E)
+    assert sorted(ol.read_dir(bg)["output.dna"].split()) == sorted(txt.split())

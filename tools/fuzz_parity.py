@@ -92,7 +92,7 @@ def main():
             inputs = ol.read_dir(bo)
             nclean = len(inputs["input_clean.dna"]) // (L + 1)
             from tests import gen
-            Ko = K if K else gen.auto_chains(nclean)
+            Ko = K if K else gen.auto_chains(nclean, clean=inputs["input_clean.dna"])
             assert oracle.harc_oracle_reorder(bo.encode(), L, Ko, S, None, None) == 0
             s1 = ol.read_dir(bo)
             assert oracle.harc_oracle_encoder(bo.encode(), L, E, None, None) == 0
