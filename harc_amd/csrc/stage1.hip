@@ -359,7 +359,9 @@ __global__ void k_init_chains(S1Args s)
 template <int W> struct ConsState {
     static constexpr int CT = (W + 1) / 2;
     static constexpr int LP = 64 * CT;
-    uint4 q[CT];      // counts A,C,G,T of the slot (reorder.cpp:467 `count`)
+    uint4 *ql;        // counts A,C,G,T of the slot (reorder.cpp:467 `count`): in LDS, slot p of the wave at ql[p - lane] (the pointer is the lane's own).  In
+                      // registers they were 8 of the 80 the dense build has: the compiler kept them in scratch across every batch (436 MB of scratch
+                      // writes per launch at configs[2]), and a scratch reload waits for every load issued before it (vmcnt counts in order)
     int v[CT];        // consensus base of the slot (first strict maximum)
     int base;
 };
@@ -388,7 +390,7 @@ template <int W> __device__ __forceinline__ void cons_reset(ConsState<W> &st, co
         const int i = lane + 64 * t;
         int b = 0; uint4 q = make_uint4(0, 0, 0, 0);
         if (i < L) { b = oriented_base<W>(rw, L, 0, i); q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3); }
-        st.q[t] = q; st.v[t] = b;
+        st.ql[64 * t] = q; st.v[t] = b;
     }
 }
 // updaterefcount for a match at `shift` with the read oriented by `rev` (reorder.cpp:884-909)
@@ -401,13 +403,13 @@ template <int W> __device__ __forceinline__ void cons_update(ConsState<W> &st, c
         const int p = lane + 64 * t;
         int oldl = p - st.base; if (oldl < 0) oldl += LP;
         int newl = p - nb; if (newl < 0) newl += LP;
-        uint4 q = st.q[t]; int v = 0;
+        uint4 q = st.ql[64 * t]; int v = 0;
         if (newl < L) {
             const int b = oriented_base<W>(rw, L, rev, newl);
             if (oldl < L && oldl >= shift) { q.x += (b == 0); q.y += (b == 1); q.z += (b == 2); q.w += (b == 3); v = argmax4(q); }
             else { q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3); v = b; }
         } else q = make_uint4(0, 0, 0, 0);
-        st.q[t] = q; st.v[t] = v;
+        st.ql[64 * t] = q; st.v[t] = v;
     }
     st.base = nb;
 }
@@ -419,7 +421,7 @@ template <int W> __device__ __forceinline__ void cons_load(ConsState<W> &st, con
         const int i = lane + 64 * t;
         uint4 q = make_uint4(0, 0, 0, 0); int v = 0;
         if (i < L) { q = src[i]; v = argmax4(q); }
-        st.q[t] = q; st.v[t] = v;
+        st.ql[64 * t] = q; st.v[t] = v;
     }
 }
 template <int W> __device__ __forceinline__ void cons_store(const ConsState<W> &st, uint4 *dst, int L, int lane)
@@ -428,7 +430,7 @@ template <int W> __device__ __forceinline__ void cons_store(const ConsState<W> &
 #pragma unroll
     for (int t = 0; t < ConsState<W>::CT; t++) {
         int l = lane + 64 * t - st.base; if (l < 0) l += LP;
-        if (l < L) dst[l] = st.q[t];
+        if (l < L) dst[l] = st.ql[64 * t];
     }
 }
 // consensus -> packed 2-bit words in column order: ballot the two code bits per ring slot, then rotate the ring by `base`
@@ -464,9 +466,10 @@ template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &s
 //  (3) lane 0 records the step and bids for the read with atomicMin(step<<20 | chain); the counts are updated in registers.
 // The kernel is bound by instruction issue at large K (PMC: 85 % of the SIMD issue slots, profiles/r02) and by dependent HBM round
 // trips at small K: both want few instructions per step.
-// Waves per SIMD of the main kernel (launch bound -> register budget).  5 (96 VGPRs, 9 dwords of scratch) unless the launch is at least
-// eight full rounds of waves long (DENSE: K >= 49152 chains): there one more wave hides more latency than its spills cost (80 VGPRs;
-// configs[2] -3.4 %, 150-bp reads -5.5 %), while at 24 k chains the same build was 9 % slower.  Reads of more than 128 bases: one less.
+// Waves per SIMD of the main kernel (launch bound -> register budget).  5 unless the launch is at least eight full rounds of waves long
+// (DENSE: K >= 49152 chains): there two more waves (72 VGPRs, 6 dwords of scratch) fill issue slots that the others leave empty while
+// they wait (round 3, with the column counts in LDS and the chain header in scalar registers: configs[2] 1252 -> 1137 us per launch; an
+// eighth wave spills 31 registers: 1661 us), while at 24 k chains a sixth wave was 9 % slower (round 2).  Reads of more than 128 bases: one less.
 #ifndef HARC_STEPS_WAVES
 #define HARC_STEPS_WAVES 5
 #endif
@@ -490,7 +493,7 @@ template <int W> struct StepsLds {
 static inline size_t steps_lds_bytes(int W, int maxmatch, int nprobe)
 {
     const int NW = 2 * W, ROW = 3 * NW + 1, MROW = (NW + 3) & ~3;
-    return ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)2 * nprobe + 8) * 4 + HARC_WGCMD_BYTES + 16;
+    return (size_t)4 * (64 * ((W + 1) / 2)) * 16 + ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)2 * nprobe + 8) * 4 + HARC_WGCMD_BYTES + 16;
 }
 // Hamming distance between a candidate read (registers) and the consensus shifted by the lane's own amount: `row` = ref or rref window
 // row in LDS, bitoff = 32 NW +- 2j, mrow = mask row of (direction, shift) (reorder.cpp:543,608 with mask[j] / revmask[j] of :706-718)
@@ -528,7 +531,7 @@ template <int W> __device__ __forceinline__ void cons_update_lds(ConsState<W> &s
         const int p = lane + 64 * t;
         int oldl = p - st.base; if (oldl < 0) oldl += LP;
         int newl = p - nb; if (newl < 0) newl += LP;
-        uint4 q = st.q[t]; int v = 0;
+        uint4 q = st.ql[64 * t]; int v = 0;
         if (newl < L) {
             const int sc = rev ? (L - 1 - newl) : newl;
             const int pc = (int)((rdl[sc >> 4] >> (2 * (sc & 15))) & 3u);
@@ -537,7 +540,7 @@ template <int W> __device__ __forceinline__ void cons_update_lds(ConsState<W> &s
             if (oldl < L && oldl >= shift) { q.x += (b == 0); q.y += (b == 1); q.z += (b == 2); q.w += (b == 3); v = argmax4(q); }
             else { q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3); v = b; }
         } else q = make_uint4(0, 0, 0, 0);
-        st.q[t] = q; st.v[t] = v;
+        st.ql[64 * t] = q; st.v[t] = v;
     }
     st.base = nb;
 }
@@ -553,7 +556,7 @@ template <int W> __device__ __forceinline__ void cons_reset_lds(ConsState<W> &st
             b = ((pc & 1) << 1) | (pc >> 1);
             q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3);
         }
-        st.q[t] = q; st.v[t] = b;
+        st.ql[64 * t] = q; st.v[t] = b;
     }
 }
 
@@ -745,12 +748,13 @@ template <int W> __global__ void k_steps_tables(S1Args s, uint32_t *out)
 // NWV (COOP only): waves per workgroup = the walking wave + NWV - 1 helpers that share its scans (64 NWV candidates per round trip).  Few
 // walks per super-round are bound by the longest one: 4 waves.  More walks than the chip holds workgroups are bound by wave slots, most of
 // which helpers idle in: fewer helpers, more walkers (stage1_run_w picks it from the walks of the last rounds; what is computed is the same).
-template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global__ __launch_bounds__(256, COOP ? HARC_COOP_WAVES : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? 1 : 0))) void k_steps(S1Args s)
+template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global__ __launch_bounds__(256, COOP ? HARC_COOP_WAVES : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? 2 : 0))) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
-    extern __shared__ uint32_t lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // [mask rows: (dir, shift) -> NW dwords][window rows: 4 waves x {ref, rref}][accepted read: 4 waves][column bytes: 4 waves x 2 x 16 NW][probes]
-    uint32_t *const s_mask = lds;
+    // [column counts: 4 waves x LP x uint4][mask rows ...]
+    uint32_t *const s_mask = lds + (size_t)4 * ConsState<W>::LP * 4;
     uint32_t *const s_rows = s_mask + (size_t)2 * s.maxmatch * MROW;
     uint32_t *const s_rdl = s_rows + 4 * 2 * ROW;
     uint32_t *const s_tmp = s_rdl + 4 * MROW;
@@ -797,10 +801,22 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
 #define PH(k) do { } while (0)
 #endif
     uint32_t ownreg = HARC_NONE;                                 // lane t: the read this chain took at step t of this super-round
-    const uint32_t c = COOP ? blockIdx.x : blockIdx.x * 4 + wv;
+    // everything about the chain is the same in all lanes of its wave: told to the compiler, so that it lives in scalar registers
+    // (with the counts in LDS: 26 -> 2 spilled vector registers in the 6-wave build)
+    const uint32_t c = COOP ? blockIdx.x : (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
     if (c >= s.K) return;
-    ChainHdr h = s.hdr[c];
+    ChainHdr h;
+    {
+        const uint4 *hp = reinterpret_cast<const uint4 *>(&s.hdr[c]);
+        const uint4 h0 = hp[0], h1 = hp[1];
+        h.cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.x); h.prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.y);
+        h.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.z); h.mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.w);
+        h.n_main = (uint32_t)__builtin_amdgcn_readfirstlane((int)h1.x); h.n_sing = (uint32_t)__builtin_amdgcn_readfirstlane((int)h1.y);
+        h.nsteps = (uint32_t)__builtin_amdgcn_readfirstlane((int)h1.z); h.pad0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)h1.w);
+    }
     uint4 cst = s.cstat[c];
+    cst.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)cst.x); cst.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)cst.y);
+    cst.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)cst.z); cst.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)cst.w);
     if (!(h.flags & CH_ACTIVE)) return;
     if (COOP && !(h.flags & CH_COOP)) return;
     if (!COOP && s.need[c]) {
@@ -829,6 +845,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
     uint4 *B0 = s.cnt + ((size_t)par * s.K + c) * LP;            // state at the start of this super-round (rollback point)
     uint4 *B1 = s.cnt + ((size_t)(par ^ 1u) * s.K + c) * LP;     // state at its end
     ConsState<W> st;
+    st.ql = reinterpret_cast<uint4 *>(lds) + (size_t)wv * ConsState<W>::LP + lane;
     const int T0 = COOP ? (int)(h.nsteps & 0xFF) : 0;           // COOP: the one step the main kernel stopped in front of
     if (COOP) {
         cons_load<W>(st, T0 > 0 ? B1 : B0, L, lane);
