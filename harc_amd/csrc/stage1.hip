@@ -34,6 +34,7 @@ struct S1Args {
     uint32_t *seedbuf;               // [K * (1 + HARC_NSUGG)] seeds, then look-ahead seeds, found by k_reseed, by rank
     uint32_t *needrank;              // [K] rank of a chain among those that want a seed (k_reseed -> the next k_steps, which applies the seed)
     uint32_t *rmeta;                 // [4] k_reseed's result: chains that wanted a seed, seeds found, look-ahead seeds found
+    unsigned int *reseed_g;          // k_reseed_mg: meeting counter, flag, per-workgroup counts (k_resolve zeroes the first two words every round)
     uint2 *cst2;                     // per chain: x seeds taken (= unmatched reads, reorder.cpp:701), y lost bids
     uint32_t *sugg;                  // [K][HARC_NSUGG] look-ahead seeds of every chain, highest id first
     int S;                           // speculative steps per super-round (1..64)
@@ -356,14 +357,20 @@ __global__ void k_init_chains(S1Args s)
 
 // consensus state of one chain, spread over the wave: lane owns ring slots p = lane + 64 t (t < CT); the slot holding
 // consensus column i is p = (i + base) mod LP, so a shift of the chain only moves `base` (reorder.cpp:887-908 without data movement)
-template <int W> struct ConsState {
+template <int W, bool INLDS> struct ConsState {
     static constexpr int CT = (W + 1) / 2;
     static constexpr int LP = 64 * CT;
-    uint4 *ql;        // counts A,C,G,T of the slot (reorder.cpp:467 `count`): in LDS, slot p of the wave at ql[p - lane] (the pointer is the lane's own).  In
-                      // registers they were 8 of the 80 the dense build has: the compiler kept them in scratch across every batch (436 MB of scratch
-                      // writes per launch at configs[2]), and a scratch reload waits for every load issued before it (vmcnt counts in order)
+    // counts A,C,G,T of the slot (reorder.cpp:467 `count`).  INLDS (the dense main kernel, 7 waves per SIMD on 72 registers): in LDS, slot p
+    // of the wave at ql[p - lane] (the pointer is the lane's own) -- in registers they were 8 of the 80 the dense build had, the compiler kept
+    // them in scratch across every batch (436 MB of scratch writes per launch at configs[2]), and a scratch reload waits for every load
+    // issued before it (vmcnt counts in order).  Otherwise (few chains, cooperative walks: latency-bound, registers to spare) in registers:
+    // LDS there cost configs[1] 7 % and the repeat workloads 3-7 %.
+    uint4 qr[INLDS ? 1 : CT];
+    uint4 *ql;
     int v[CT];        // consensus base of the slot (first strict maximum)
     int base;
+    __device__ __forceinline__ uint4 getq(int t) const { if constexpr (INLDS) return ql[64 * t]; else return qr[t]; }
+    __device__ __forceinline__ void setq(int t, const uint4 &q) { if constexpr (INLDS) ql[64 * t] = q; else qr[t] = q; }
 };
 __device__ __forceinline__ int argmax4(const uint4 &q)
 {
@@ -382,61 +389,61 @@ template <int W> __device__ __forceinline__ int oriented_base(const uint64_t (&r
     const int b = ((pc & 1) << 1) | (pc >> 1);                   // packed code A0 G1 C2 T3 -> A0 C1 G2 T3
     return rev ? 3 - b : b;
 }
-template <int W> __device__ __forceinline__ void cons_reset(ConsState<W> &st, const uint64_t (&rw)[W], int L, int lane)
+template <int W, bool I> __device__ __forceinline__ void cons_reset(ConsState<W, I> &st, const uint64_t (&rw)[W], int L, int lane)
 {
     st.base = 0;
 #pragma unroll
-    for (int t = 0; t < ConsState<W>::CT; t++) {
+    for (int t = 0; t < ConsState<W, I>::CT; t++) {
         const int i = lane + 64 * t;
         int b = 0; uint4 q = make_uint4(0, 0, 0, 0);
         if (i < L) { b = oriented_base<W>(rw, L, 0, i); q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3); }
-        st.ql[64 * t] = q; st.v[t] = b;
+        st.setq(t, q); st.v[t] = b;
     }
 }
 // updaterefcount for a match at `shift` with the read oriented by `rev` (reorder.cpp:884-909)
-template <int W> __device__ __forceinline__ void cons_update(ConsState<W> &st, const uint64_t (&rw)[W], int L, int rev, int shift, int lane)
+template <int W, bool I> __device__ __forceinline__ void cons_update(ConsState<W, I> &st, const uint64_t (&rw)[W], int L, int rev, int shift, int lane)
 {
-    constexpr int LP = ConsState<W>::LP;
+    constexpr int LP = ConsState<W, I>::LP;
     int nb = st.base + shift; if (nb >= LP) nb -= LP;
 #pragma unroll
-    for (int t = 0; t < ConsState<W>::CT; t++) {
+    for (int t = 0; t < ConsState<W, I>::CT; t++) {
         const int p = lane + 64 * t;
         int oldl = p - st.base; if (oldl < 0) oldl += LP;
         int newl = p - nb; if (newl < 0) newl += LP;
-        uint4 q = st.ql[64 * t]; int v = 0;
+        uint4 q = st.getq(t); int v = 0;
         if (newl < L) {
             const int b = oriented_base<W>(rw, L, rev, newl);
             if (oldl < L && oldl >= shift) { q.x += (b == 0); q.y += (b == 1); q.z += (b == 2); q.w += (b == 3); v = argmax4(q); }
             else { q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3); v = b; }
         } else q = make_uint4(0, 0, 0, 0);
-        st.ql[64 * t] = q; st.v[t] = v;
+        st.setq(t, q); st.v[t] = v;
     }
     st.base = nb;
 }
-template <int W> __device__ __forceinline__ void cons_load(ConsState<W> &st, const uint4 *src, int L, int lane)
+template <int W, bool I> __device__ __forceinline__ void cons_load(ConsState<W, I> &st, const uint4 *src, int L, int lane)
 {
     st.base = 0;
 #pragma unroll
-    for (int t = 0; t < ConsState<W>::CT; t++) {
+    for (int t = 0; t < ConsState<W, I>::CT; t++) {
         const int i = lane + 64 * t;
         uint4 q = make_uint4(0, 0, 0, 0); int v = 0;
         if (i < L) { q = src[i]; v = argmax4(q); }
-        st.ql[64 * t] = q; st.v[t] = v;
+        st.setq(t, q); st.v[t] = v;
     }
 }
-template <int W> __device__ __forceinline__ void cons_store(const ConsState<W> &st, uint4 *dst, int L, int lane)
+template <int W, bool I> __device__ __forceinline__ void cons_store(const ConsState<W, I> &st, uint4 *dst, int L, int lane)
 {
-    constexpr int LP = ConsState<W>::LP;
+    constexpr int LP = ConsState<W, I>::LP;
 #pragma unroll
-    for (int t = 0; t < ConsState<W>::CT; t++) {
+    for (int t = 0; t < ConsState<W, I>::CT; t++) {
         int l = lane + 64 * t - st.base; if (l < 0) l += LP;
-        if (l < L) dst[l] = st.ql[64 * t];
+        if (l < L) dst[l] = st.getq(t);
     }
 }
 // consensus -> packed 2-bit words in column order: ballot the two code bits per ring slot, then rotate the ring by `base`
-template <int W> __device__ __forceinline__ void cons_pack(const ConsState<W> &st, int L, int lane, uint64_t (&ref)[W])
+template <int W, bool I> __device__ __forceinline__ void cons_pack(const ConsState<W, I> &st, int L, int lane, uint64_t (&ref)[W])
 {
-    constexpr int CT = ConsState<W>::CT, LP = ConsState<W>::LP, RW = 2 * CT;
+    constexpr int CT = ConsState<W, I>::CT, LP = ConsState<W, I>::LP, RW = 2 * CT;
     uint64_t ring[RW];
 #pragma unroll
     for (int t = 0; t < CT; t++) {
@@ -522,16 +529,16 @@ template <int W> __device__ __forceinline__ void load_read32(const uint64_t *rea
     }
 }
 // updaterefcount (reorder.cpp:884-909) with the accepted read's dwords in LDS (rdl): every lane picks the bases of its own columns
-template <int W> __device__ __forceinline__ void cons_update_lds(ConsState<W> &st, const uint32_t *rdl, int L, int rev, int shift, int lane)
+template <int W, bool I> __device__ __forceinline__ void cons_update_lds(ConsState<W, I> &st, const uint32_t *rdl, int L, int rev, int shift, int lane)
 {
-    constexpr int LP = ConsState<W>::LP;
+    constexpr int LP = ConsState<W, I>::LP;
     int nb = st.base + shift; if (nb >= LP) nb -= LP;
 #pragma unroll
-    for (int t = 0; t < ConsState<W>::CT; t++) {
+    for (int t = 0; t < ConsState<W, I>::CT; t++) {
         const int p = lane + 64 * t;
         int oldl = p - st.base; if (oldl < 0) oldl += LP;
         int newl = p - nb; if (newl < 0) newl += LP;
-        uint4 q = st.ql[64 * t]; int v = 0;
+        uint4 q = st.getq(t); int v = 0;
         if (newl < L) {
             const int sc = rev ? (L - 1 - newl) : newl;
             const int pc = (int)((rdl[sc >> 4] >> (2 * (sc & 15))) & 3u);
@@ -540,15 +547,15 @@ template <int W> __device__ __forceinline__ void cons_update_lds(ConsState<W> &s
             if (oldl < L && oldl >= shift) { q.x += (b == 0); q.y += (b == 1); q.z += (b == 2); q.w += (b == 3); v = argmax4(q); }
             else { q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3); v = b; }
         } else q = make_uint4(0, 0, 0, 0);
-        st.ql[64 * t] = q; st.v[t] = v;
+        st.setq(t, q); st.v[t] = v;
     }
     st.base = nb;
 }
-template <int W> __device__ __forceinline__ void cons_reset_lds(ConsState<W> &st, const uint32_t *rdl, int L, int lane)
+template <int W, bool I> __device__ __forceinline__ void cons_reset_lds(ConsState<W, I> &st, const uint32_t *rdl, int L, int lane)
 {
     st.base = 0;
 #pragma unroll
-    for (int t = 0; t < ConsState<W>::CT; t++) {
+    for (int t = 0; t < ConsState<W, I>::CT; t++) {
         const int i = lane + 64 * t;
         int b = 0; uint4 q = make_uint4(0, 0, 0, 0);
         if (i < L) {
@@ -556,16 +563,16 @@ template <int W> __device__ __forceinline__ void cons_reset_lds(ConsState<W> &st
             b = ((pc & 1) << 1) | (pc >> 1);
             q.x = (b == 0); q.y = (b == 1); q.z = (b == 2); q.w = (b == 3);
         }
-        st.ql[64 * t] = q; st.v[t] = b;
+        st.setq(t, q); st.v[t] = b;
     }
 }
 
 // consensus -> the wave's window rows in LDS: rowF = packed consensus (reorder.cpp `ref`), rowR = its reverse complement (`revref`).
 // Every lane drops the 2-bit codes of its ring slots as bytes at their column (and, complemented, at the mirrored column); 2 NW lanes
 // then squeeze 16 bytes into one dword each.  (The ballot + bit-spread formulation cost 380 vector instructions per step.)
-template <int W> __device__ __forceinline__ void cons_rows(const ConsState<W> &st, int L, int lane, uint8_t *tmp, uint32_t *rowF, uint32_t *rowR)
+template <int W, bool I> __device__ __forceinline__ void cons_rows(const ConsState<W, I> &st, int L, int lane, uint8_t *tmp, uint32_t *rowF, uint32_t *rowR)
 {
-    constexpr int CT = ConsState<W>::CT, LP = ConsState<W>::LP, NW = 2 * W;
+    constexpr int CT = ConsState<W, I>::CT, LP = ConsState<W, I>::LP, NW = 2 * W;
 #pragma unroll
     for (int t = 0; t < CT; t++) {
         int l = lane + 64 * t - st.base; if (l < 0) l += LP;
@@ -754,7 +761,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // [mask rows: (dir, shift) -> NW dwords][window rows: 4 waves x {ref, rref}][accepted read: 4 waves][column bytes: 4 waves x 2 x 16 NW][probes]
     // [column counts: 4 waves x LP x uint4][mask rows ...]
-    uint32_t *const s_mask = lds + (size_t)4 * ConsState<W>::LP * 4;
+    uint32_t *const s_mask = lds + (size_t)4 * ConsState<W, DENSE>::LP * 4;
     uint32_t *const s_rows = s_mask + (size_t)2 * s.maxmatch * MROW;
     uint32_t *const s_rdl = s_rows + 4 * 2 * ROW;
     uint32_t *const s_tmp = s_rdl + 4 * MROW;
@@ -840,23 +847,23 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
             return;
         }
     }
-    constexpr int LP = ConsState<W>::LP;
+    constexpr int LP = ConsState<W, DENSE>::LP;
     const uint32_t par = (h.flags & CH_PARITY) ? 1u : 0u;
     uint4 *B0 = s.cnt + ((size_t)par * s.K + c) * LP;            // state at the start of this super-round (rollback point)
     uint4 *B1 = s.cnt + ((size_t)(par ^ 1u) * s.K + c) * LP;     // state at its end
-    ConsState<W> st;
-    st.ql = reinterpret_cast<uint4 *>(lds) + (size_t)wv * ConsState<W>::LP + lane;
+    ConsState<W, DENSE> st;
+    st.ql = reinterpret_cast<uint4 *>(lds) + (size_t)wv * ConsState<W, DENSE>::LP + lane;
     const int T0 = COOP ? (int)(h.nsteps & 0xFF) : 0;           // COOP: the one step the main kernel stopped in front of
     if (COOP) {
-        cons_load<W>(st, T0 > 0 ? B1 : B0, L, lane);
+        cons_load(st, T0 > 0 ? B1 : B0, L, lane);
         if (lane < T0) ownreg = s.steps[(size_t)c * 64 + lane].x;
     } else if (h.mode == 2) {                                    // fresh seed (reorder.cpp:875-883)
         uint64_t rw[W];
 #pragma unroll
         for (int w = 0; w < W; w++) rw[w] = s.reads[(size_t)h.cur * W + w];
-        cons_reset<W>(st, rw, L, lane);
+        cons_reset(st, rw, L, lane);
     } else {
-        cons_load<W>(st, B0, L, lane);
+        cons_load(st, B0, L, lane);
         if (h.mode == 1) {                                       // rolled back last time: replay the steps that were kept
             const int nrep = (int)((h.nsteps >> 8) & 0xFF);
             uint2 sp = make_uint2(0, 0);
@@ -873,12 +880,12 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
 #pragma unroll
                 for (int w = 0; w < W; w++) rw[w] = shfl_u64(mrw[w], t);
                 const uint32_t y = __shfl(sp.y, t, 64);
-                if ((y >> 16) & 1) cons_reset<W>(st, rw, L, lane);          // the step took a look-ahead seed
-                else cons_update<W>(st, rw, L, (int)((y >> 8) & 1), (int)(y & 0xFF), lane);
+                if ((y >> 16) & 1) cons_reset(st, rw, L, lane);          // the step took a look-ahead seed
+                else cons_update(st, rw, L, (int)((y >> 8) & 1), (int)(y & 0xFF), lane);
             }
         }
     }
-    if (!COOP && h.mode != 0) cons_store<W>(st, B0, L, lane);    // B0 now holds the rollback point of this super-round
+    if (!COOP && h.mode != 0) cons_store(st, B0, L, lane);    // B0 now holds the rollback point of this super-round
 
     uint32_t *const rowF = s_rows + (size_t)wv * 2 * ROW, *const rowR = rowF + ROW, *const rdl = s_rdl + (size_t)wv * MROW;
     uint8_t *const coltmp = reinterpret_cast<uint8_t *>(s_tmp + (size_t)wv * 8 * NW);
@@ -894,7 +901,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
     bool stalled = false; int resume_next = 0;
     PH(0);
     for (int t = T0; t < s.S; t++) {
-        cons_rows<W>(st, L, lane, coltmp, rowF, rowR);            // consensus and its reverse complement -> the wave's window rows
+        cons_rows(st, L, lane, coltmp, rowF, rowR);            // consensus and its reverse complement -> the wave's window rows
         PH(1);
         uint32_t found = HARC_NONE; int fj = 0, fdir = 0;
         // Probes are issued in priority order in batches: every probe behind the first hit of a batch is speculative traffic,
@@ -1111,7 +1118,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
             if (lane < NW) { const uint32_t *rp = reinterpret_cast<const uint32_t *>(s.reads + (size_t)sid * W); rdl[lane] = rp[lane]; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            cons_reset_lds<W>(st, rdl, L, lane);
+            cons_reset_lds(st, rdl, L, lane);
             nst++;
             if (COOP && bigprobes >= s.budget) break;
             continue;
@@ -1123,14 +1130,14 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
         if (lane == t) ownreg = found;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        cons_update_lds<W>(st, rdl, L, fdir, fj, lane);
+        cons_update_lds(st, rdl, L, fdir, fj, lane);
         nst++;
         PH(4);
         if (COOP && bigprobes >= s.budget) break;
     }
     PH(4);
     if (COOP) { if (lane == 0) cmd->op = 0; __syncthreads(); }      // the walk is over: the helpers leave
-    if (nst > 0) cons_store<W>(st, B1, L, lane);
+    if (nst > 0) cons_store(st, B1, L, lane);
     np = wave_sum_u32(np); nc = wave_sum_u32(nc); ncu = wave_sum_u32(ncu);
     PH(5);
 #undef PH
@@ -1164,6 +1171,7 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
 {
     constexpr int CPW = 64 / G;                                   // chains per wave
     const int lane = threadIdx.x & 63, sub = lane / G, sl = lane % G, g0 = sub * G;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { s.reseed_g[0] = 0u; s.reseed_g[1] = 0u; }      // the meeting counter and the flag of the k_reseed_mg that follows
     const uint32_t c = (blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + sub;
     ChainHdr h; h.flags = 0; h.nsteps = 0; h.n_main = 0; h.n_sing = 0; h.prev = 0; h.pad0 = 0;
     if (c < s.K) h = s.hdr[c];
@@ -1325,6 +1333,144 @@ template <int NT> __global__ __launch_bounds__(NT) void k_reseed(S1Args s)
     // the chains take their seeds themselves at the top of the next k_steps (rank -> seedbuf)
     if (t == 0) { s.rmeta[0] = R; s.rmeta[1] = assigned; s.rmeta[2] = got; }
     if (t == 0) *s.cursor = cursor < -1 ? -1 : cursor;
+}
+
+// (C) with many chains: the same, by RESEED_G workgroups of RESEED_NT threads (16384 threads: one word of the claim bitmap each per pass,
+// the look-ahead window of HARC_LOOK_CHUNKS x 1024 words in ONE pass).  The single workgroup took 59 us per super-round at configs[2]
+// (21 000 seeds + 170 000 look-ahead ids per round: a dozen dependent iterations of load, block scan, hand out) and 167 us on a
+// minimizer-bucket shard -- a tenth of the chain phase there.  The workgroups meet at a counter in global memory (they are all resident:
+// 64 workgroups on 256 CUs): once after counting (chains that want a seed per workgroup + unclaimed reads per workgroup's words; more
+// passes, one meeting each, only when a million bits below the cursor do not hold enough unclaimed reads), once for the look-ahead; the
+// read id where the seeds end travels through a flag.  What is computed is the single workgroup's result (the oracle's), id for id.
+// g = [0] meeting counter [1] flag: 2 + cursor after the seeds [2..3] unused [4 .. 4+3G) per workgroup: chains wanting a seed, unclaimed
+// reads of the pass, unclaimed reads of the look-ahead window.  k_resolve zeroes g[0..1] before every launch.
+#define RESEED_NT 256
+#define RESEED_G 64
+__device__ __forceinline__ void grid_meet(unsigned int *cnt, unsigned int target)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(cnt, 1u);
+        while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        __threadfence();
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(RESEED_NT) void k_reseed_mg(S1Args s, unsigned int *g)
+{
+    constexpr int NT = RESEED_NT, G = RESEED_G;
+    __shared__ uint32_t sm[20];
+    __shared__ uint32_t spre[3][G + 1];
+    const int t = threadIdx.x, b = blockIdx.x;
+    const uint32_t gid = (uint32_t)b * NT + (uint32_t)t;
+    unsigned int *const gA = g + 4, *const gB = g + 4 + G, *const gC = g + 4 + 2 * G;
+    unsigned int meet = 0;
+    // chains per thread, contiguous and a multiple of 8 so that the need bytes are read as 64-bit words (the array is padded with zeros)
+    const uint32_t chunk = (((s.K + G * NT - 1) / (G * NT)) + 7) & ~7u;
+    const uint32_t c0 = gid * chunk;
+    uint32_t mycnt = 0;
+    if (c0 < s.K) for (uint32_t c = c0; c < c0 + chunk; c += 8) mycnt += (uint32_t)__popcll(*(const unsigned long long *)(s.need + c));
+    uint32_t totA; const uint32_t offA = block_excl_scan_u32<NT>(mycnt, sm, &totA);
+    const long long cursor0 = *s.cursor;
+    long long top = cursor0;                                       // the pass looks at the G * NT words from the word of `top` downwards
+    uint32_t R = 0, assigned = 0;
+    long long look = -1;
+    for (int pass = 0;; pass++) {
+        const long long cwd = top >> 6, wi = cwd - (long long)gid;
+        unsigned long long bits = 0;
+        if (top >= 0 && wi >= 0) {
+            bits = ~s.claimed[wi];
+            if (wi == cwd) { const int tb = (int)(top & 63); if (tb < 63) bits &= (2ULL << tb) - 1ULL; }
+        }
+        uint32_t totB; const uint32_t offB = block_excl_scan_u32<NT>((uint32_t)__popcll(bits), sm, &totB);
+        if (t == 0) {
+            if (pass == 0) __hip_atomic_store(gA + b, totA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gB + b, totB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        grid_meet(g, (unsigned int)G * ++meet);
+        if (t < 64) {                                              // one wave: prefix sums over the workgroups
+            const uint32_t va = (pass == 0 && t < G) ? __hip_atomic_load(gA + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const uint32_t vb = t < G ? __hip_atomic_load(gB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            uint32_t ta, tb2;
+            const uint32_t ea = wave_excl_scan_u32(va, &ta), eb = wave_excl_scan_u32(vb, &tb2);
+            if (t < G) { if (pass == 0) spre[0][t] = ea; spre[1][t] = eb; }
+            if (t == 0) { if (pass == 0) spre[0][G] = ta; spre[1][G] = tb2; }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            R = spre[0][G];
+            if (R == 0) return;                                    // nobody wants a seed (every workgroup sees the same R)
+            if (mycnt) {                                           // rank of every chain that wants a seed, ascending chain id
+                uint32_t r = spre[0][b] + offA;
+                for (uint32_t c = c0; c < c0 + chunk; c += 8) {
+                    unsigned long long w = *(const unsigned long long *)(s.need + c);
+                    while (w) { const int bb = __ffsll((long long)w) - 1; w &= w - 1; s.needrank[c + (uint32_t)(bb >> 3)] = r++; }
+                }
+            }
+        }
+        const uint32_t total = spre[1][G], off = spre[1][b] + offB;
+        unsigned long long newclaim = 0; uint32_t k = 0;
+        while (bits && assigned + off + k < R) {
+            const int bb = 63 - __clzll((long long)bits);
+            bits &= ~(1ULL << bb);
+            const uint32_t id = (uint32_t)(wi * 64 + bb), r = assigned + off + k;
+            k++; newclaim |= 1ULL << bb;
+            s.seedbuf[r] = id;
+            if (r == R - 1) __hip_atomic_store(g + 1, id + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // 2 + (id - 1): where the seeds end
+        }
+        if (newclaim) s.claimed[wi] |= newclaim;                   // every word has one owner
+        if (assigned + total >= R) {                               // the seeds are all found: everybody waits for the place of the last one
+            assigned = R;
+            if (t == 0) { unsigned int f; while ((f = __hip_atomic_load(g + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(1); spre[2][0] = f; }
+            __syncthreads();
+            look = (long long)spre[2][0] - 2;
+            break;
+        }
+        assigned += total;
+        top = (cwd - (long long)G * NT + 1) * 64 - 1;              // below the words of this pass
+        if (top < 0) { look = -1; break; }                         // the bitmap is exhausted: the remaining chains finish
+        __syncthreads();
+    }
+    // look-ahead: the next assigned * HARC_NSUGG unclaimed ids below the cursor, in HARC_LOOK_CHUNKS x 1024 words; nothing is claimed, the cursor moves below them
+    const uint32_t want = assigned * (uint32_t)s.nsugg_per_seed;
+    uint32_t got = 0;
+    long long cursor = look;
+    if (look >= 0 && want > 0) {
+        const long long cwd = look >> 6, wi = cwd - (long long)gid;
+        unsigned long long bits = 0;
+        if (wi >= 0 && gid < (uint32_t)HARC_LOOK_CHUNKS * 1024u) {
+            bits = ~s.claimed[wi];
+            if (wi == cwd) { const int tb = (int)(look & 63); if (tb < 63) bits &= (2ULL << tb) - 1ULL; }
+        }
+        uint32_t totC; const uint32_t offC = block_excl_scan_u32<NT>((uint32_t)__popcll(bits), sm, &totC);
+        if (t == 0) __hip_atomic_store(gC + b, totC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        grid_meet(g, (unsigned int)G * ++meet);
+        if (t < 64) {
+            const uint32_t vc = t < G ? __hip_atomic_load(gC + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            uint32_t tc; const uint32_t ec = wave_excl_scan_u32(vc, &tc);
+            if (t < G) spre[2][t] = ec;
+            if (t == 0) spre[2][G] = tc;
+        }
+        __syncthreads();
+        const uint32_t total = spre[2][G], off = spre[2][b] + offC;
+        const uint32_t take = total >= want ? want : total;
+        uint32_t k = 0;
+        while (bits && off + k < take) {
+            const int bb = 63 - __clzll((long long)bits);
+            bits &= ~(1ULL << bb);
+            const uint32_t id = (uint32_t)(wi * 64 + bb);
+            s.seedbuf[R + off + k] = id;
+            if (off + k == take - 1) *s.cursor = (long long)id - 1;    // the cursor goes below the last look-ahead seed handed out (everybody has read it long ago)
+            k++;
+        }
+        got = take;
+    }
+    // the chains take their seeds themselves at the top of the next k_steps (rank -> seedbuf)
+    if (gid == 0) {
+        s.rmeta[0] = R; s.rmeta[1] = assigned; s.rmeta[2] = got;
+        if (got == 0) *s.cursor = cursor < -1 ? -1 : cursor;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ big bins stay short
@@ -1717,6 +1863,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const uint32_t nblk = (K + 255) / 256;
     RC_TRY(dalloc(c, &a.claimed, nwords)); RC_TRY(dalloc(c, &a.bid, (size_t)N + 1)); RC_TRY(dalloc(c, &a.hdr, K));
     RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.steps, (size_t)K * 64)); RC_TRY(dalloc(c, &a.need, (size_t)K + 8192 + 1024));
+    RC_TRY(dalloc(c, &a.reseed_g, 4 + 3 * RESEED_G)); HIP_TRY(hipMemsetAsync(a.reseed_g, 0, (4 + 3 * RESEED_G) * 4, c->stream));
     RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + HARC_NSUGG))); RC_TRY(dalloc(c, &a.needrank, (size_t)K + 16)); RC_TRY(dalloc(c, &a.rmeta, 4)); RC_TRY(dalloc(c, &a.cst2, (size_t)K + 1)); RC_TRY(dalloc(c, &a.sugg, (size_t)K * HARC_NSUGG));
     RC_TRY(dalloc(c, &a.log, (size_t)N + 1));
     RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N)); RC_TRY(dalloc(c, &a.coopcnt, HARC_COOPCNT)); HIP_TRY(hipMemsetAsync(a.coopcnt, 0, HARC_COOPCNT * 8, c->stream));
@@ -1783,6 +1930,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     double coop_slots = 1024.0;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, P.device) == hipSuccess && pr.multiProcessorCount > 0) coop_slots = 4.0 * pr.multiProcessorCount; }
     const int batch = getenv("HARC_AMD_BATCHSYNC") ? atoi(getenv("HARC_AMD_BATCHSYNC")) : 8;
+    // k_reseed by 64 workgroups once a single one has thousands of seeds to hand out per round (HARC_AMD_RESEED_MG=0/1 forces either; same result)
+    const bool reseed_mg = getenv("HARC_AMD_RESEED_MG") ? atoi(getenv("HARC_AMD_RESEED_MG")) != 0 : K > 4096;
     for (;;) {
         for (int r = 0; r < batch; r++) {
             hipEvent_t *pair = nullptr;
@@ -1800,7 +1949,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
             else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve<32>), dim3((K + 7) / 8), dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((k_resolve<64>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
-            if (K <= 4096) hipLaunchKernelGGL((k_reseed<256>), dim3(1), dim3(256), 0, c->stream, a);
+            if (reseed_mg) hipLaunchKernelGGL(k_reseed_mg, dim3(RESEED_G), dim3(RESEED_NT), 0, c->stream, a, a.reseed_g);
+            else if (K <= 4096) hipLaunchKernelGGL((k_reseed<256>), dim3(1), dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((k_reseed<1024>), dim3(1), dim3(1024), 0, c->stream, a);
             if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge, (const uint32_t *)d_sz0);
     if (nhuge) hipLaunchKernelGGL((k_compact_huge<W>), dim3(nhuge), dim3(1024), 0, c->stream, a, (const unsigned long long *)d_large, (const uint32_t *)d_huge, nhuge);
