@@ -326,7 +326,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (reference baseline, size comparison) and the exact-mode sample")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket exchange even at world size 1 (exercises the N>1 path on one GPU)")
     ap.add_argument("--cpu-sample", type=int, default=0)
-    ap.add_argument("--mg-mode", default="bucket", choices=["bucket"], help="N>1: bucket = minimizer-bucket shard + one all-to-all (north_star)")
+    ap.add_argument("--mg-mode", default="bucket", choices=["bucket", "replicate"],
+                    help="N>1: bucket = minimizer-bucket shard + one all-to-all, independent shards (north_star; larger archives); replicate = design (R): "
+                         "all-gather of the reads, chains partitioned over the GPUs, one all-gather of the walked steps per super-round -- every GPU "
+                         "holds the whole job (pick a workload of which N batches fit one GPU, e.g. c3s) and the archive is byte-identical to one GPU's")
     ap.add_argument("--via-launcher", action="store_true", help="start the ranks through the launcher even for --gpus 1 (checks that the launcher costs nothing)")
     ap.add_argument("--launch-timeout", type=float, default=3300.0, help="launcher: seconds after which the ranks' process group is killed")
     ap.add_argument("--watchdog", type=float, default=600.0, help="seconds a rank may sit in one collective phase before it ends itself (exit code 86)")
@@ -377,7 +380,7 @@ def main():
     # weak scaling: same reads per GPU, genome (and so coverage) per GPU constant; every rank samples the WHOLE genome
     # a minimizer-bucket shard is already fragmented into islands of ~10 overlapping reads: twice as many chains cost +0.3 % (8 GPUs) to
     # +1.2 % (2 GPUs) of consensus bases there and save 38 % of the chain time (tools/shard_sim.py); one GPU keeps one chain per 2048 reads
-    rpc = 1024 if dist is not None else 0
+    rpc = 1024 if (dist is not None and args.mg_mode == "bucket") else 0
     p = harc_amd.default_params(L, num_thr=args.shards, num_chains=args.chains, device=local, profile=1, num_steps=args.super_steps, reads_per_chain=rpc)
     h = harc_amd.HarcAmd(p)
     # inputs, 4 M reads at a time so that config-3/4-sized sets never exist as ASCII: clean reads are packed to 2 bits per base
@@ -422,8 +425,12 @@ def main():
             sig_in = list(multigpu.allreduce_signature(dist, tuple(sig_in), dev))    # the whole job's reads, BEFORE any exchange
     with_pack_order = args.workload in ("c5s", "c5g")
 
+    replicate = dist is not None and args.mg_mode == "replicate"
+
     def step():
-        if dist is not None:
+        if replicate:
+            h.replicate_exchange()                                # design (R): all-gather of the reads; reorder() partitions the chains
+        elif dist is not None:
             h.shard_exchange()                                    # bucket -> ONE all-to-all(v) over xGMI (RCCL inside the library) -> this GPU's shard
         h.reorder()
         h.encode()
@@ -470,7 +477,9 @@ def main():
     # shards -- a read lost, duplicated or altered anywhere between the slice and the streams (the all-to-all included) shows.
     dsig = h.decode_signature()
     seq_bases_total, reads_total = int(c.seq_bases), n
-    if dist is not None:
+    if replicate:
+        reads_total = n * world                                   # every rank decoded the WHOLE job: its signature alone must equal all ranks' inputs
+    elif dist is not None:
         with wd.phase("round-trip signature", args.watchdog):
             dsig = multigpu.allreduce_signature(dist, dsig, dev)
             sb = torch.tensor([int(c.seq_bases)], dtype=torch.int64, device=dev)
@@ -531,7 +540,7 @@ def main():
                    "error_rate": err, "chains_per_gpu": int(c.chains), "reads_per_chain": rpc or 2048, "encoder_shards_per_gpu": args.shards,
                    "schedule": "throughput mode: deterministic K-chain x S-step schedule of DESIGN.md (lossless, == CPU oracle byte for byte; "
                                "bytes differ from the reference's -t 1, which is num_chains = 1: see exact_mode)",
-                   "parallelism": "single GPU" if world == 1 else f"minimizer-bucket shard x{world}, one RCCL all-to-all (8W+4 B per read) inside every step"},
+                   "parallelism": "single GPU" if world == 1 and dist is None else (f"design (R) x{world}: reads all-gathered, index replicated, chains partitioned, one all-gather of the walked steps per super-round; every GPU ends with the single-GPU archive" if replicate else f"minimizer-bucket shard x{world}, one RCCL all-to-all (8W+4 B per read) inside every step")},
         "roofline": roofline,
         "roundtrip": roundtrip,
         "phases_ms_last_step": {"index": round(c.index_ms, 2), "chain": round(c.chain_ms, 2), "encode": round(c.encode_ms, 2)},
@@ -550,7 +559,7 @@ def main():
             h.reorder(); h.encode()
             d1 = time.perf_counter() - t1
             c1 = h.counters()
-            out["n1_equivalent"] = {"value": round(n / d1 / 1e6, 3), "unit": "Mreads/s", "what": "rank 0's own batch, unsharded, on one GPU (1024 reads per chain as in the sharded run)",
+            out["n1_equivalent"] = {"value": round(n / d1 / 1e6, 3), "unit": "Mreads/s", "what": "rank 0's own batch, unsharded, on one GPU (same reads per chain as in the multi-GPU run)",
                                     "ms_per_step": round(d1 * 1e3, 3), "seq_bases_per_read": round(int(c1.seq_bases) / max(1, n), 3)}
             out["scaling_vs_n1_equivalent"] = round(value / max(1e-9, out["n1_equivalent"]["value"]), 3)
     h.close()
@@ -565,7 +574,7 @@ def main():
             Gs, sspike = max(L * 4, int(G * (ns / n))), None
         sample = synth_reads(ns, L, Gs, err, 999, dev, sspike)
         sdesc = f"{ns} reads of the same generator on a {Gs} bp genome (same coverage and error rate)"
-        if world > 1 or args.force_dist:
+        if (world > 1 or args.force_dist) and not replicate:
             # the price of bucket sharding in compressed size: consensus bases of the sample compressed as `world` minimizer
             # buckets, one after the other on this GPU with the sharded run's parameters, over the consensus bases of the same sample unsharded
             nb = max(2, world)

@@ -92,6 +92,7 @@ def lib():
     l.harc_amd_comm_destroy.argtypes = [ctx]
     l.harc_amd_shard_exchange.argtypes = [ctx, C.POINTER(C.c_uint64)]
     l.harc_amd_shard_reset.argtypes = [ctx]
+    l.harc_amd_replicate_exchange.argtypes = [ctx, C.POINTER(C.c_uint64)]
     l.harc_amd_compress_fastq_shard_files.argtypes = [PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
     l.harc_amd_merge_shard_files.argtypes = [C.c_char_p, C.c_int32]
     _lib = l
@@ -252,6 +253,13 @@ class HarcAmd:
         """bucket the context's own reads, ONE all-to-all(v); -> info tuple (see include/harc_amd.h)"""
         info = (C.c_uint64 * 8)()
         _check(lib().harc_amd_shard_exchange(self._ctx, info))
+        return tuple(int(x) for x in info)
+
+    def replicate_exchange(self):
+        """design (R): all-gather every rank's slice; reorder() then partitions the chains over the ranks and every rank ends with the
+        single-GPU result of the whole job; -> info tuple (see include/harc_amd.h)"""
+        info = (C.c_uint64 * 8)()
+        _check(lib().harc_amd_replicate_exchange(self._ctx, info))
         return tuple(int(x) for x in info)
 
     def shard_reset(self):

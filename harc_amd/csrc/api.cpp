@@ -199,6 +199,7 @@ void harc_reset_shard(harc_amd_ctx *c)
     c->d_reads = (uint64_t *)c->own_reads.p; c->N = c->N_own;
     c->d_nreads3 = (uint64_t *)c->own_nreads3.p; c->NN = c->NN_own;
     c->d_gid = c->d_ngid = nullptr;
+    c->replicated = false;
     memset(c->shard_info, 0, sizeof c->shard_info);
     c->C.n_clean = c->N; c->C.n_N = c->NN;
 }

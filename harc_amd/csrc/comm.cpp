@@ -129,7 +129,7 @@ struct RcclComm : HarcComm {
         const ncclResult_t ge = g_rccl.GroupEnd();
         if (first != ncclSuccess) { harc_set_error("all-to-all: %s -> %s", where, g_rccl.GetErrorString(first)); return HARC_AMD_ENODEVICE; }
         if (ge != ncclSuccess) { harc_set_error("all-to-all: ncclGroupEnd -> %s", g_rccl.GetErrorString(ge)); return HARC_AMD_ENODEVICE; }
-        return wait(c, "all-to-all of the reads");
+        return HARC_AMD_OK;                                       // enqueued on c->stream; wait() tells when (and whether) it has finished
     }
 };
 

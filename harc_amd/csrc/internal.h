@@ -110,6 +110,8 @@ struct harc_amd_ctx {
     struct HarcComm *comm = nullptr;
     InBuf x_reads, x_nreads3, x_gid, x_ngid;            // the received shard and the global ids of its reads
     uint32_t *d_gid = nullptr, *d_ngid = nullptr;       // non-null after an exchange: stage II writes global ids into its order streams
+    bool replicated = false;                            // after harc_amd_replicate_exchange: the context holds the reads of the WHOLE job in global id order (x_reads / x_nreads3)
+                                                        // and stage I partitions the CHAINS over the ranks (stage1.hip)
     uint64_t shard_info[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  // [0] clean reads of the whole job [1] N reads [2] records [3] this rank's first clean id [4] first N id [5] first record
     // stage-I result, device
     bool have_s1 = false;
@@ -141,7 +143,7 @@ struct HarcComm {
     virtual ~HarcComm() {}
     // every rank contributes n u64 (host memory); out = world * n values, rank-major
     virtual int allgather_u64(harc_amd_ctx *c, const uint64_t *in, int n, uint64_t *out) = 0;
-    // ONE all-to-all(v) over `narr` device arrays at once: for array a, the chunk for peer p is send[a] + soff[a][p] (sbytes[a][p] bytes),
+    // ONE all-to-all(v) over `narr` device arrays at once (enqueued on c->stream; wait() below tells when it has finished): for array a, the chunk for peer p is send[a] + soff[a][p] (sbytes[a][p] bytes),
     // the chunk from peer p lands at recv[a] + roff[a][p] (rbytes[a][p] bytes); enqueued on c->stream
     virtual int alltoallv(harc_amd_ctx *c, int narr, const void *const *send, const size_t *const *soff, const size_t *const *sbytes,
                           void *const *recv, const size_t *const *roff, const size_t *const *rbytes) = 0;

@@ -164,7 +164,8 @@ extern "C" int harc_amd_shard_exchange(harc_amd_ctx *c, uint64_t *info)
         void *rp[4] = { c->x_reads.p, c->x_gid.p, c->x_nreads3.p, c->x_ngid.p };
         const size_t *sop[4], *sbp[4], *rop[4], *rbp[4];
         for (int a = 0; a < 4; a++) { sop[a] = so[a].data(); sbp[a] = sb[a].data(); rop[a] = ro[a].data(); rbp[a] = rb[a].data(); }
-        RC_TRY(cm->alltoallv(c, 4, sp, sop, sbp, rp, rop, rbp));     // returns when the chunks have arrived (or the peers timed out)
+        RC_TRY(cm->alltoallv(c, 4, sp, sop, sbp, rp, rop, rbp));
+        RC_TRY(cm->wait(c, "all-to-all of the reads"));              // the chunks have arrived (or the peers timed out)
     }
     scope.release_now();
     c->d_reads = (uint64_t *)c->x_reads.p; c->N = (uint32_t)rN;
@@ -184,5 +185,60 @@ extern "C" int harc_amd_shard_reset(harc_amd_ctx *c)
     HIP_TRY(hipSetDevice(c->P.device));
     harc_drop_results(c);
     harc_reset_shard(c);
+    return HARC_AMD_OK;
+}
+
+// Design (R) of the multi-GPU split: REPLICATE the reads, partition the CHAINS.  Every rank holds its slice of the job
+// (as before an exchange); one all-gather puts the reads of the WHOLE job on every GPU, in global id order (rank-major = the order of a
+// concatenated input_clean.dna / input_N.dna).  harc_amd_reorder then builds the full index on every GPU and walks only the chains it
+// owns, with one all-gather of the walked steps per super-round (stage1.hip); what comes out of harc_amd_reorder / harc_amd_encode is, on
+// every rank, byte for byte what ONE GPU produces from the concatenated input -- the archive keeps the single-GPU compression ratio,
+// which the minimizer-bucket shard of harc_amd_shard_exchange does not (2.4-4.4 times the consensus bases).  The price is
+// memory (every GPU holds everything) and the replicated parts (index build, arbitration, stage II).
+// info as harc_amd_shard_exchange: [0..2] the whole job's clean reads / reads with N / records, [3..5] this rank's first, [6..7] = [0..1].
+extern "C" int harc_amd_replicate_exchange(harc_amd_ctx *c, uint64_t *info)
+{
+    if (!c) return HARC_AMD_EINVAL;
+    if (!c->comm) { harc_set_error("harc_amd_replicate_exchange: no communicator (harc_amd_comm_init)"); return HARC_AMD_ESTATE; }
+    HIP_TRY(hipSetDevice(c->P.device));
+    HarcComm *cm = c->comm;
+    const int world = cm->world, rank = cm->rank;
+    const int W = c->W, W3 = c->W3;
+    harc_drop_results(c);
+    harc_reset_shard(c);
+    const uint32_t N = c->N_own, NN = c->NN_own;
+    std::vector<uint64_t> all((size_t)world * 3);
+    { const uint64_t mine[3] = { N, NN, c->nrec_own }; RC_TRY(cm->allgather_u64(c, mine, 3, all.data())); }
+    uint64_t tot[3] = { 0, 0, 0 }, off[3] = { 0, 0, 0 };
+    for (int r = 0; r < world; r++) for (int k = 0; k < 3; k++) { if (r < rank) off[k] += all[(size_t)r * 3 + k]; tot[k] += all[(size_t)r * 3 + k]; }
+    if (tot[0] > 0xFFFFFFFFull || tot[1] > 0xFFFFFFFFull || tot[2] > 4294967290ull) {
+        harc_set_error("Too many reads. HARC supports at most 4294967290 reads"); return HARC_AMD_EINVAL;      // preprocess.cpp:122-126
+    }
+    RC_TRY(harc_in_reserve(c, &c->x_reads, ((size_t)tot[0] * W + 1) * 8));
+    RC_TRY(harc_in_reserve(c, &c->x_nreads3, ((size_t)tot[1] * W3 + 1) * 8));
+    {   // the all-gather as ONE all-to-all(v) in which every peer gets the whole slice: chunks of (8W, 8 W3) bytes per read
+        std::vector<size_t> so[2], sb[2], ro[2], rb[2];
+        for (int a = 0; a < 2; a++) { so[a].assign(world, 0); sb[a].resize(world); ro[a].resize(world); rb[a].resize(world); }
+        uint64_t accN = 0, accNN = 0;
+        for (int p = 0; p < world; p++) {
+            sb[0][p] = (size_t)N * W * 8; sb[1][p] = (size_t)NN * W3 * 8;
+            ro[0][p] = (size_t)accN * W * 8; rb[0][p] = (size_t)all[(size_t)p * 3] * W * 8;
+            ro[1][p] = (size_t)accNN * W3 * 8; rb[1][p] = (size_t)all[(size_t)p * 3 + 1] * W3 * 8;
+            accN += all[(size_t)p * 3]; accNN += all[(size_t)p * 3 + 1];
+        }
+        const void *sp[2] = { c->own_reads.p, c->own_nreads3.p };
+        void *rp[2] = { c->x_reads.p, c->x_nreads3.p };
+        const size_t *sop[2] = { so[0].data(), so[1].data() }, *sbp[2] = { sb[0].data(), sb[1].data() }, *rop[2] = { ro[0].data(), ro[1].data() }, *rbp[2] = { rb[0].data(), rb[1].data() };
+        RC_TRY(cm->alltoallv(c, 2, sp, sop, sbp, rp, rop, rbp));
+        RC_TRY(cm->wait(c, "all-gather of the reads"));
+    }
+    c->d_reads = (uint64_t *)c->x_reads.p; c->N = (uint32_t)tot[0];
+    c->d_nreads3 = (uint64_t *)c->x_nreads3.p; c->NN = (uint32_t)tot[1];
+    c->d_gid = c->d_ngid = nullptr;                              // the ids of the replicated store ARE the global ids
+    c->replicated = true;                                        // world 1 included: the per-round all-gather then runs over one rank (tests)
+    c->C.n_clean = c->N; c->C.n_N = c->NN;
+    c->shard_info[0] = tot[0]; c->shard_info[1] = tot[1]; c->shard_info[2] = tot[2];
+    c->shard_info[3] = off[0]; c->shard_info[4] = off[1]; c->shard_info[5] = off[2]; c->shard_info[6] = tot[0]; c->shard_info[7] = tot[1];
+    if (info) memcpy(info, c->shard_info, sizeof c->shard_info);
     return HARC_AMD_OK;
 }

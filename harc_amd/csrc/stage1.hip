@@ -34,6 +34,7 @@ struct S1Args {
     uint32_t *seedbuf;               // [K * (1 + HARC_NSUGG)] seeds, then look-ahead seeds, found by k_reseed, by rank
     uint32_t *needrank;              // [K] rank of a chain among those that want a seed (k_reseed -> the next k_steps, which applies the seed)
     uint32_t *rmeta;                 // [4] k_reseed's result: chains that wanted a seed, seeds found, look-ahead seeds found
+    uint32_t own_mod, own_rem;       // design (R), chains partitioned over the ranks of a multi-GPU run: this rank walks the chains c with (c >> 2) % own_mod == own_rem (own_mod <= 1: all)
     unsigned int *reseed_g;          // k_reseed_mg: meeting counter, flag, per-workgroup counts (k_resolve zeroes the first two words every round)
     uint2 *cst2;                     // per chain: x seeds taken (= unmatched reads, reorder.cpp:701), y lost bids
     uint32_t *sugg;                  // [K][HARC_NSUGG] look-ahead seeds of every chain, highest id first
@@ -770,6 +771,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
     // main kernel: 4 chains per workgroup, one wave each.  COOP: one chain per workgroup, wave 0 walks it (role 0), waves 1..3 help with the scans
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, wv = COOP ? 0 : role;
     const int L = s.L;
+    // design (R): the four chains of a workgroup of the main kernel belong to ONE rank; the others leave before anything is set up
+    if (s.own_mod > 1 && ((COOP ? (blockIdx.x >> 2) : blockIdx.x) % s.own_mod) != s.own_rem) return;
     if (COOP) {                                                   // uniform for the workgroup: nothing to do for this chain
         if (blockIdx.x >= s.K) return;
         const uint32_t fl = s.hdr[blockIdx.x].flags;
@@ -1163,6 +1166,72 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
         h.flags = (h.flags & 0xFFFFu) | ((COOP ? (stalled ? (uint32_t)resume_next : 0u) : ((defer && nst == 0) ? (uint32_t)resume : 0u)) << 16);
         if (!COOP && defer) atomicAdd(&s.coopcnt[c & (HARC_COOPCNT - 1)], 1ULL);
         s.hdr[c] = h;
+    }
+}
+
+// ---- design (R): replicate the reads and the index, partition the chains (harc_amd_replicate_exchange).  Everything a super-round
+// changes outside the walking wave's own state is either recomputed identically on every rank (k_resolve, k_reseed, the compaction of the
+// large bins: functions of replicated state) or travels with the all-gather of the walked steps: the chain header and the steps of the
+// super-round (k_pack_chains -> all-to-all(v) -> k_unpack_chains, which also places the bids of the other ranks' chains).  The column
+// counts, the statistics and the hints in the table slots stay with the owner.
+__device__ __forceinline__ bool chain_owned(uint32_t c, uint32_t mod, uint32_t rem) { return mod <= 1 || ((c >> 2) % mod) == rem; }
+// the seed a chain takes at the top of k_steps (reorder.cpp:650-688), on the ranks that do NOT walk it: same records, same counters
+__global__ void k_apply_seed(S1Args s)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= s.K || chain_owned(c, s.own_mod, s.own_rem)) return;
+    ChainHdr h = s.hdr[c];
+    if (!(h.flags & CH_ACTIVE) || !s.need[c]) return;
+    const uint32_t r = s.needrank[c], R = s.rmeta[0], assigned = s.rmeta[1], got = s.rmeta[2];
+    if (h.flags & CH_PREVUNM) {                                   // previous seed found nothing: singleton (reorder.cpp:672-684)
+        LogRec rec; rec.chain = c; rec.seq = h.n_sing; rec.rid = h.prev; rec.meta = 1u << 10; s.log[h.prev] = rec;
+        h.n_sing++;
+    }
+    if (r < assigned) {
+        const uint32_t id = s.seedbuf[r];
+        h.cur = id; h.prev = id; h.flags = ((h.flags | CH_PREVUNM) & ~CH_NEEDSEED) & 0xFFFFu; h.mode = 2;
+        const uint32_t first = r * (uint32_t)s.nsugg_per_seed;
+        const uint32_t ng = first >= got ? 0u : (got - first < (uint32_t)s.nsugg_per_seed ? got - first : (uint32_t)s.nsugg_per_seed);
+        for (uint32_t k = 0; k < ng; k++) s.sugg[(size_t)c * HARC_NSUGG + k] = s.seedbuf[R + first + k];
+        h.nsteps = ng << 24;
+        uint2 q = s.cst2[c]; q.x++; s.cst2[c] = q;
+    } else {                                                      // no reads left (reorder.cpp:670-677)
+        h.flags &= ~(CH_ACTIVE | CH_PREVUNM | CH_NEEDSEED);
+        atomicAdd(&s.stats[ST_ACTIVE], ~0ULL);
+    }
+    s.need[c] = 0;
+    s.hdr[c] = h;                                                 // until the owner's header arrives with the all-gather
+}
+// record of a chain: its header (8 dwords) + the S steps of the super-round (2 dwords each).  Slot li of rank p's block = chain
+// ((li >> 2) * own_mod + p) * 4 + (li & 3).  One thread per dword.
+__global__ void k_pack_chains(S1Args s, uint32_t *buf, uint32_t nper)
+{
+    const uint32_t recw = 8u + 2u * (uint32_t)s.S;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)nper * recw) return;
+    const uint32_t li = (uint32_t)(gid / recw), d = (uint32_t)(gid % recw);
+    const uint32_t c = ((li >> 2) * s.own_mod + s.own_rem) * 4u + (li & 3u);
+    uint32_t v = 0;
+    if (c < s.K) v = d < 8u ? reinterpret_cast<const uint32_t *>(&s.hdr[c])[d] : reinterpret_cast<const uint32_t *>(&s.steps[(size_t)c * 64])[d - 8u];
+    buf[gid] = v;
+}
+__global__ void k_unpack_chains(S1Args s, const uint32_t *buf, uint32_t nper)
+{
+    const uint32_t recw = 8u + 2u * (uint32_t)s.S, p = blockIdx.y;
+    if (p == s.own_rem) return;                                   // this rank's own chains are in place
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)nper * recw) return;
+    const uint32_t li = (uint32_t)(gid / recw), d = (uint32_t)(gid % recw);
+    const uint32_t c = ((li >> 2) * s.own_mod + p) * 4u + (li & 3u);
+    if (c >= s.K) return;
+    const uint32_t *rec = buf + ((size_t)p * nper + li) * recw;
+    const uint32_t v = rec[d];
+    if (d < 8u) reinterpret_cast<uint32_t *>(&s.hdr[c])[d] = v;
+    else {
+        reinterpret_cast<uint32_t *>(&s.steps[(size_t)c * 64])[d - 8u] = v;
+        const uint32_t t = (d - 8u) >> 1;
+        // the bid the walking wave made for the read of step t (k_steps), on this rank too: k_resolve arbitrates over all of them
+        if (((d - 8u) & 1u) == 0 && (rec[2] & CH_ACTIVE) && t < (rec[6] & 0xFFu)) atomicMin(&s.bid[v], (t << 20) | c);
     }
 }
 
@@ -1856,6 +1925,10 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
 #endif
     for (int l = 0; l < 2; l++) { a.ds[l] = P.dict_start[l]; a.de[l] = P.dict_end[l]; a.kbits[l] = 2 * (P.dict_end[l] - P.dict_start[l] + 1); }
     a.N = N; a.K = K; a.reads = c->d_reads;
+    // design (R): after harc_amd_replicate_exchange every rank holds all reads and builds the whole index; the chains are dealt to the ranks
+    // four at a time (a workgroup of the main kernel), and every super-round ends with one all-gather of the walked steps
+    HarcComm *const cm = (c->replicated && c->comm) ? c->comm : nullptr;
+    a.own_mod = cm ? (uint32_t)cm->world : 1u; a.own_rem = cm ? (uint32_t)cm->rank : 0u;
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
     a.bloom[0] = d_bloom[0]; a.bloom[1] = d_bloom[1]; a.bloom_lines = bloom_lines; a.bloom_nwin[0] = bloom_nwin[0]; a.bloom_nwin[1] = bloom_nwin[1]; a.bloom_mmask = bloom_mmask;
     a.largetab = d_largetab; a.mirror = d_mirror;
@@ -1919,6 +1992,15 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge, (const uint32_t *)d_sz0);
     if (nhuge) hipLaunchKernelGGL((k_compact_huge<W>), dim3(nhuge), dim3(1024), 0, c->stream, a, (const unsigned long long *)d_large, (const uint32_t *)d_huge, nhuge);
     // ---- rounds
+    uint32_t *x_send = nullptr, *x_recv = nullptr; uint32_t x_nper = 0; size_t x_bytes = 0;
+    std::vector<size_t> x_so, x_sb, x_ro, x_rb;
+    if (cm) {
+        x_nper = ((((K + 3) / 4) + a.own_mod - 1) / a.own_mod) * 4;                 // chains of one rank's block
+        x_bytes = (size_t)x_nper * (8 + 2 * (size_t)nsteps) * 4;
+        RC_TRY(dalloc(c, &x_send, x_bytes / 4 + 4)); RC_TRY(dalloc(c, &x_recv, (x_bytes / 4) * a.own_mod + 4));
+        x_so.assign(a.own_mod, 0); x_sb.assign(a.own_mod, x_bytes); x_ro.resize(a.own_mod); x_rb.assign(a.own_mod, x_bytes);
+        for (uint32_t p = 0; p < a.own_mod; p++) x_ro[p] = (size_t)p * x_bytes;
+    }
     const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe);
     const bool prof = P.profile != 0;
     const bool dense = getenv("HARC_AMD_DENSE") ? atoi(getenv("HARC_AMD_DENSE")) != 0 : K >= 49152;     // see HARC_STEPS_WAVES
@@ -1935,6 +2017,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     for (;;) {
         for (int r = 0; r < batch; r++) {
             hipEvent_t *pair = nullptr;
+            if (cm) hipLaunchKernelGGL(k_apply_seed, dim3(nblk), dim3(256), 0, c->stream, a);          // the seeds of the chains other ranks walk
             if (prof) { RC_TRY(R.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }
             if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             else if (dense) hipLaunchKernelGGL((k_steps<W, false, false, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
@@ -1945,6 +2028,14 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
                 if (coop_waves == 1) hipLaunchKernelGGL((k_steps<W, true, true, false, 1>), dim3(K), dim3(64), lds_bytes, c->stream, a);
                 else if (coop_waves == 2) hipLaunchKernelGGL((k_steps<W, true, true, false, 2>), dim3(K), dim3(128), lds_bytes, c->stream, a);
                 else hipLaunchKernelGGL((k_steps<W, true, true>), dim3(K), dim3(256), lds_bytes, c->stream, a);
+            }
+            if (cm) {   // ONE all-gather per super-round: header + walked steps of every chain, from the rank that walked it
+                const uint64_t tot = (uint64_t)x_nper * (8 + 2 * (uint64_t)nsteps);
+                hipLaunchKernelGGL(k_pack_chains, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, a, x_send, x_nper);
+                const void *sp[1] = { x_send }; void *rp[1] = { x_recv };
+                const size_t *sop[1] = { x_so.data() }, *sbp[1] = { x_sb.data() }, *rop[1] = { x_ro.data() }, *rbp[1] = { x_rb.data() };
+                RC_TRY(cm->alltoallv(c, 1, sp, sop, sbp, rp, rop, rbp));
+                hipLaunchKernelGGL(k_unpack_chains, dim3((unsigned)((tot + 255) / 256), a.own_mod), dim3(256), 0, c->stream, a, (const uint32_t *)x_recv, x_nper);
             }
             if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
             else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve<32>), dim3((K + 7) / 8), dim3(256), 0, c->stream, a);
@@ -1959,6 +2050,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         rounds += batch;
         HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
         if (nlarge) HIP_TRY(hipMemcpyAsync(h_stats + ST_N, a.coopcnt, HARC_COOPCNT * 8, hipMemcpyDeviceToHost, c->stream));
+        if (cm) RC_TRY(cm->wait(c, "all-gather of the walked steps"));      // a peer that died shows as a timeout, not as a hang
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
         if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] round %llu: %llu chains alive\n", (unsigned long long)rounds, h_stats[ST_ACTIVE]);

@@ -186,6 +186,12 @@ int harc_amd_comm_destroy(harc_amd_ctx *ctx);
    function again repeats the exchange.  info (8 u64, may be NULL): [0] clean reads of the whole job [1] reads with N [2] FASTQ
    records [3] this rank's first clean id [4] first N id [5] first record [6] clean reads received [7] N reads received. */
 int harc_amd_shard_exchange(harc_amd_ctx *ctx, uint64_t *info);
+/* Design (R): replicate the reads, partition the CHAINS.  One all-gather puts the reads of the whole job on every GPU in global id order;
+   harc_amd_reorder then builds the whole index on every GPU, walks only the chains this rank owns and all-gathers the walked steps once per
+   super-round; harc_amd_reorder / harc_amd_encode deliver, on EVERY rank, byte for byte what one GPU produces from the concatenated input
+   (reorder.cpp:455-457 has one address space: this is its multi-GPU form that keeps the compression ratio; the bucket shard above trades
+   ratio for memory and speed).  Every GPU must hold the whole job.  info as for harc_amd_shard_exchange. */
+int harc_amd_replicate_exchange(harc_amd_ctx *ctx, uint64_t *info);
 /* The stages read the context's own slice again (as before the first exchange); the results of the last run go, the communicator stays. */
 int harc_amd_shard_reset(harc_amd_ctx *ctx);
 

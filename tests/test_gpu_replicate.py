@@ -1,0 +1,146 @@
+"""Design (R) of the multi-GPU split -- replicate the reads, partition the chains (harc_amd_replicate_exchange): after
+one all-gather every rank holds the whole job, walks only the chains it owns and all-gathers the walked steps once per super-round.  What
+harc_amd_reorder / harc_amd_encode deliver must be, on EVERY rank, byte for byte what ONE GPU delivers on the concatenated input -- which
+in turn is the oracle's (tests/test_gpu_parity.py).  World 2 and 3 share the one GPU of the box over the mailbox transport (RCCL refuses
+two ranks on a device); the RCCL calls themselves run at world size 1 in a fresh process (tests/test_gpu_multigpu.py does that for the
+bucket exchange; here for the replicating one)."""
+import os
+import subprocess
+import sys
+import textwrap
+import threading
+
+import pytest
+
+from tests import gen, shard_model
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STREAMS = [("read_seq.txt", "S2_SEQ"), ("read_pos.txt", "S2_POS"), ("read_noise.txt", "S2_NOISE"), ("read_noisepos.txt", "S2_NOISEPOS"), ("read_rev.txt", "S2_REV")]
+WHOLE = [("read_order.bin", "S2_ORDER"), ("read_order_N_pe.bin", "S2_ORDER_N_PE"), ("read_singleton.txt", "S2_SINGLETON"),
+         ("read_singleton.txt.tail", "S2_SINGLETON_TAIL"), ("input_N.dna", "S2_INPUT_N")]
+S1 = [("temp.dna", "S1_TEMP_DNA"), ("read_order.bin.s1", "S1_ORDER"), ("tempflag.txt", "S1_FLAG"), ("temppos.txt", "S1_POS"), ("read_rev.txt.s1", "S1_REV")]
+
+
+def _collect(h, E):
+    f = {}
+    for e in range(E):
+        for stem, sid in STREAMS:
+            f["%s.%d" % (stem, e)] = h.stream(sid, e)
+        f["read_seq.txt.%d.tail" % e] = h.stream("S2_SEQ_TAIL", e)
+        f["read_rev.txt.%d.tail" % e] = h.stream("S2_REV_TAIL", e)
+    for name, sid in WHOLE:
+        f[name] = h.stream(sid)
+    return f
+
+
+def _one_gpu(arr, L, E, K, S):
+    import harc_amd
+    hasN = (arr == ord("N")).any(1)
+    h = harc_amd.HarcAmd(harc_amd.default_params(L, num_thr=E, num_chains=K, num_steps=S))
+    h.set_reads_ascii(shard_model.lines(arr[~hasN]), int((~hasN).sum()), L + 1)
+    h.set_nreads_ascii(shard_model.lines(arr[hasN]), int(hasN.sum()), L + 1)
+    h.reorder(); h.encode()
+    f, c = _collect(h, E), h.counters()
+    h.close()
+    return f, c
+
+
+def _ranks(world, slices, L, E, K, S, mbox):
+    import harc_amd
+    res, errs = [None] * world, []
+
+    def work(r):
+        try:
+            s = slices[r]
+            hasN = (s == ord("N")).any(1)
+            h = harc_amd.HarcAmd(harc_amd.default_params(L, num_thr=E, num_chains=K, num_steps=S))
+            h.comm_init_mailbox(mbox, world, r)
+            h.set_reads_ascii(shard_model.lines(s[~hasN]), int((~hasN).sum()), L + 1)
+            h.set_nreads_ascii(shard_model.lines(s[hasN]), int(hasN.sum()), L + 1)
+            info = h.replicate_exchange()
+            h.reorder(); h.encode()
+            res[r] = dict(files=_collect(h, E), info=info, counters=h.counters(), sig=h.decode_signature())
+            h.comm_barrier()
+            h.close()
+        except Exception as ex:                                  # noqa: BLE001
+            errs.append((r, repr(ex)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    return res
+
+
+@pytest.mark.parametrize("world,n,L,err,E,K,S,lowc", [(2, 30000, 100, 0.01, 2, 9, 16, False), (3, 24000, 100, 0.02, 1, 0, 16, False), (2, 9000, 150, 0.01, 1, 64, 8, False),
+                                                       (3, 20000, 100, 0.004, 3, 24, 16, True), (2, 5000, 100, 0.0, 1, 1, 16, False)])
+def test_replicated_ranks_equal_one_gpu(world, n, L, err, E, K, S, lowc, tmp_path):
+    """every rank of a design-(R) run == the single-GPU run on the concatenated input, every stage-II file; lowc: repeats and poly-A runs
+    (the cooperative kernel's walks are partitioned too); K = 1: one chain, one owner, the other ranks only follow"""
+    import numpy as np
+    os.environ["HARC_AMD_MAILBOX_TIMEOUT"] = "180"
+    if lowc:
+        txt = gen.reads_text_lowcomplexity(31 + world, n, L, 50000, err=err)
+        arr = np.frombuffer(txt, dtype=np.uint8).reshape(-1, L + 1)[:, :L].copy()
+    else:
+        arr = gen.reads_array(177 + world, n, L, 8 * n, err=err)
+    want, cw = _one_gpu(arr, L, E, K, S)
+    sl = shard_model.slices_of(arr, world)
+    mbox = tmp_path / "mbox"
+    mbox.mkdir()
+    res = _ranks(world, sl, L, E, K, S, str(mbox))
+    nclean = int((~(arr == ord("N")).any(1)).sum())
+    for r in range(world):
+        info = res[r]["info"]
+        assert info[0] == nclean and info[2] == n and info[6] == nclean, (r, info)
+        for k, v in want.items():
+            assert res[r]["files"][k] == v, "rank %d of %d: %s differs from the single-GPU run" % (r, world, k)
+        c = res[r]["counters"]
+        assert (c.unmatched, c.rounds, c.conflicts, c.n_main, c.n_singleton) == (cw.unmatched, cw.rounds, cw.conflicts, cw.n_main, cw.n_singleton)
+        assert res[r]["sig"][0] == n
+
+
+RCCL_WORKER = textwrap.dedent("""
+    import os, sys, numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", device_id=dev)
+    import harc_amd
+    from harc_amd import multigpu
+    from tests import gen, shard_model
+    L, E, K, S = 100, 2, 40, 16
+    arr = gen.reads_array(505, 12000, L, 90000, err=0.01)
+    hasN = (arr == ord("N")).any(1)
+    def run(repl):
+        h = harc_amd.HarcAmd(harc_amd.default_params(L, num_thr=E, num_chains=K, num_steps=S))
+        if repl:
+            assert multigpu.init_comm(h, dist, dev) == (1, 0)
+        h.set_reads_ascii(shard_model.lines(arr[~hasN]), int((~hasN).sum()), L + 1)
+        h.set_nreads_ascii(shard_model.lines(arr[hasN]), int(hasN.sum()), L + 1)
+        if repl:
+            info = h.replicate_exchange()
+            assert info[0] == int((~hasN).sum()) and info[1] == int(hasN.sum()), info
+        h.reorder(); h.encode()
+        out = [h.stream(sid, e) for e in range(E) for sid in ("S2_SEQ", "S2_POS", "S2_NOISE", "S2_NOISEPOS", "S2_REV")] + [h.stream("S2_ORDER"), h.stream("S2_SINGLETON")]
+        if repl:
+            h.comm_barrier()
+        h.close()
+        return out
+    assert run(True) == run(False)
+    dist.destroy_process_group()
+    print("RCCL_OK")
+""") % ROOT
+
+
+def test_replicate_exchange_over_rccl_world1(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29549", str(script)], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-4000:]
