@@ -30,6 +30,14 @@ sys.path.insert(0, ROOT)
 torch = None  # imported in main(), AFTER the launcher decision: the process that starts the ranks never touches the GPU
 
 
+def _need_torch():
+    """tools and tests import this module for its generator: torch comes in on first use"""
+    global torch
+    if torch is None:
+        import torch as _t
+        torch = _t
+
+
 # ---------------------------------------------------------------------------------------------- launcher (python bench.py --gpus N)
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as a fresh child
@@ -174,6 +182,7 @@ WORKLOADS = {
 def synth_chunks(n, L, G, err, seed, dev, spike=None):
     """yields [m, L] uint8 ASCII reads, 4 M at a time: uniform starts on an i.i.d. genome, substitutions (a quarter become N, as
     gen_fastq_noRC.cpp:67-71), odd reads reverse-complemented (gen_fastq.cpp:105-113)."""
+    _need_torch()
     g = torch.Generator(device=dev)
     g.manual_seed(4242 + G)                                      # the genome is the same on every rank
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
@@ -219,6 +228,7 @@ def synth_chunks(n, L, G, err, seed, dev, spike=None):
 
 
 def synth_reads(n, L, G, err, seed, dev, spike=None):
+    _need_torch()
     return torch.cat(list(synth_chunks(n, L, G, err, seed, dev, spike)))
 
 

@@ -561,8 +561,23 @@ static int rendezvous(harc_amd_ctx *c, const char *spec, int world, int rank)
     return harc_amd_comm_init(c, id, sizeof id, world, rank);
 }
 
+static int compress_fastq_rank(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order,
+                               int32_t preserve_quality, int32_t world, int32_t rank, const char *comm_spec, bool replicate);
 extern "C" int harc_amd_compress_fastq_shard_files(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order,
                                                    int32_t preserve_quality, int32_t world, int32_t rank, const char *comm_spec)
+{
+    return compress_fastq_rank(params, fastq, basedir, preserve_order, preserve_quality, world, rank, comm_spec, false);
+}
+// design (R): every rank ingests its slice, the reads are all-gathered, the chains partitioned; every rank ends with the streams of the whole
+// job -- ONE GPU's streams, byte for byte -- and rank 0 writes them (as shard family 0 .. num_thr - 1, like a single-GPU run); what depends on
+// the slice (read_order_N.bin, quality values and ids in file order) is left as rank parts.  harc_amd_merge_shard_files finishes the archive.
+extern "C" int harc_amd_compress_fastq_replicated_files(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order,
+                                                        int32_t preserve_quality, int32_t world, int32_t rank, const char *comm_spec)
+{
+    return compress_fastq_rank(params, fastq, basedir, preserve_order, preserve_quality, world, rank, comm_spec, true);
+}
+static int compress_fastq_rank(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order,
+                               int32_t preserve_quality, int32_t world, int32_t rank, const char *comm_spec, bool replicate)
 {
     if (!params || !fastq || !basedir || world < 1 || rank < 0 || rank >= world) { harc_set_error("compress_fastq_shard: bad arguments"); return HARC_AMD_EINVAL; }
     if (preserve_quality && !preserve_order) { harc_set_error("multi-GPU -q needs -p (quality values and ids stay in file order)"); return HARC_AMD_EINVAL; }
@@ -593,13 +608,23 @@ extern "C" int harc_amd_compress_fastq_shard_files(const harc_amd_params *params
     std::vector<uint32_t> orderN = st.orderN;                     // read_order_N.bin of this slice, local record numbers
     RC_TRY(rendezvous(c, comm_spec, world, rank));
     uint64_t info[8];
-    RC_TRY(harc_amd_shard_exchange(c, info));
+    if (replicate) RC_TRY(harc_amd_replicate_exchange(c, info)); else RC_TRY(harc_amd_shard_exchange(c, info));
     for (auto &x : orderN) x += (uint32_t)info[5];                // records of the lower ranks come first in the file
     RC_TRY(spit_file(sd + "order_N" + r, orderN.data(), orderN.size() * 4));
     RC_TRY(harc_amd_reorder(c));
     RC_TRY(harc_amd_encode(c));
     harc_amd_counters C; harc_amd_get_counters(c, &C);
-    RC_TRY(write_shard_family(c, od, rank * params->num_thr));
+    if (replicate && rank != 0) {                                 // the same streams as rank 0 holds: nothing to write but empty parts
+        static const char *stems[] = { "order_a", "order_u", "orderN_a", "orderN_u", "singleton", "singleton_tail", "input_N" };
+        for (const char *st0 : stems) RC_TRY(spit_file(sd + st0 + r, "", 0));
+        char line[256];
+        const int n = snprintf(line, sizeof line, "%d %llu %llu %llu 0 0 0 %llu %llu\n", params->readlen, (unsigned long long)nrec_full,
+                               (unsigned long long)n_clean_own, (unsigned long long)c->NN_own, (unsigned long long)c->N, (unsigned long long)c->NN);
+        RC_TRY(spit_file(sd + "stats" + r, line, (size_t)n));
+        RC_TRY(harc_amd_comm_barrier(c));
+        return HARC_AMD_OK;
+    }
+    RC_TRY(write_shard_family(c, od, replicate ? 0 : rank * params->num_thr));
     {   // whole-job files: this rank's part, aligned and unaligned halves apart (the merge interleaves them as encoder.cpp:457-503 does)
         const void *po, *pn, *ps, *pt, *pi; size_t no, nn, ns, nt, ni;
         RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_ORDER, 0, &po, &no)); RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_ORDER_N_PE, 0, &pn, &nn));

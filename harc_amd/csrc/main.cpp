@@ -9,7 +9,7 @@
 //                                                                          == preprocess + reorder + encoder (+ reorder_quality), FASTQ parsed on the GPU
 //   harc_amd_stage preprocess <basedir> <readlen> <fastq>                  == src/preprocess.out <fastq> <basedir> .. <readlen> (harc:50)
 //   harc_amd_stage compressfq_shard <basedir> <readlen> <fastq> <num_thr> <num_chains> <num_steps> <preserve_order> <preserve_quality>
-//                                   <world> <rank> <comm_spec> [device]    one rank of `./harc -c -g <world>` (one process per GPU)
+//                                   <world> <rank> <comm_spec> [device] [replicate]    one rank of `./harc -c -g <world>` (one process per GPU)
 //   harc_amd_stage merge_shards <basedir> <world>                          the whole-job files of the archive from the rank parts
 // readlen / num_thr arrive as arguments instead of the compile-time macros of src/config.h (harc:52-63).
 #include <stdio.h>
@@ -53,7 +53,10 @@ int main(int argc, char **argv)
         const int po = !strcmp(argv[8], "True"), pq = !strcmp(argv[9], "True"), world = atoi(argv[10]), rank = atoi(argv[11]);
         P.device = argc > 13 ? atoi(argv[13]) : rank;                 // one process per GPU: rank r drives device r unless told otherwise
         P.reads_per_chain = 1024;                                     // a bucket shard is fragmented already (multi-GPU)
-        rc = harc_amd_compress_fastq_shard_files(&P, argv[4], argv[2], po, pq, world, rank, argv[12]);
+        // [mode] after [device]: "replicate" = design (R) (reads all-gathered, chains partitioned, single-GPU bytes); default: minimizer-bucket shards
+        const bool repl = argc > 14 && !strcmp(argv[14], "replicate");
+        if (repl) { P.reads_per_chain = 0; rc = harc_amd_compress_fastq_replicated_files(&P, argv[4], argv[2], po, pq, world, rank, argv[12]); }
+        else rc = harc_amd_compress_fastq_shard_files(&P, argv[4], argv[2], po, pq, world, rank, argv[12]);
     }
     else if (!strcmp(argv[1], "decoder_preserve")) { if (argc > 5) P.decode_memory_gb = atoi(argv[5]); rc = harc_amd_decoder_preserve_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1); }   // [memory]: -m of harc:174
     else if (!strcmp(argv[1], "decoder")) rc = harc_amd_decoder_files(&P, argv[2], argc > 4 ? atoi(argv[4]) : 1);

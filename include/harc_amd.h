@@ -248,6 +248,11 @@ int harc_amd_compress_fastq_shard_files(const harc_amd_params *params, const cha
    read_order_N_pe.bin, read_order_N.bin, numreads.bin, read_meta.txt, output.quality / output.id) from the parts under .shard/,
    laid out as encoder.cpp:457-503 writes them: aligned reads of all shards first, then the unaligned ones.  Host code. */
 int harc_amd_merge_shard_files(const char *basedir, int32_t world);
+/* One rank of `./harc -c -g N` in design-(R) mode (HARC_AMD_MG_MODE=replicate): as harc_amd_compress_fastq_shard_files, but the reads are
+   all-gathered (harc_amd_replicate_exchange) and the chains partitioned; rank 0 writes the streams of the whole job -- byte for byte those
+   of a single-GPU run, num_thr stream files -- the other ranks only their slice's parts; harc_amd_merge_shard_files finishes the archive. */
+int harc_amd_compress_fastq_replicated_files(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order,
+                                             int32_t preserve_quality, int32_t world, int32_t rank, const char *comm_spec);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,6 @@ def _synth_text(n, L, G, err, seed):
     import torch
     sys.path.insert(0, ROOT)
     import bench
-    bench.torch = torch
     r = bench.synth_reads(n, L, G, err, seed, torch.device("cuda", 0)).cpu().numpy()
     out = np.empty((n, L + 1), dtype=np.uint8)
     out[:, :L] = r

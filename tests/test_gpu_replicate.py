@@ -144,3 +144,51 @@ def test_replicate_exchange_over_rccl_world1(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", "29549", str(script)], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-4000:]
+
+
+def _members(arc, tmp):
+    """every stream file of an archive made with HARC_AMD_STAGE3=none -> {name: bytes}"""
+    import tarfile
+    out = {}
+    d = tmp / ("x_" + arc.stem)
+    d.mkdir()
+    with tarfile.open(arc) as tf:
+        tf.extractall(d)
+    for p in sorted(d.iterdir()):
+        if p.suffix == ".tar":
+            with tarfile.open(p) as tf:
+                for m in tf.getmembers():
+                    if m.isfile():
+                        out[os.path.basename(m.name)] = tf.extractfile(m).read()
+        elif p.is_file():
+            out[p.name] = p.read_bytes()
+    return out
+
+
+@pytest.mark.parametrize("world,flags", [(2, ["-p", "-t", "2"]), (3, ["-t", "1"]), (2, ["-p", "-q", "-t", "2"])])
+def test_harc_g_replicate_archive_equals_single_gpu_archive(world, flags, tmp_path):
+    """HARC_AMD_MG_MODE=replicate ./harc -c -g <world>: the archive holds byte for byte the stream files of ./harc -c on one GPU"""
+    import numpy as np
+    L = 100
+    txt = gen.reads_text(321, 18000, L, 140000, err=0.01)
+    reads = txt.split()
+    rs = np.random.RandomState(11)
+    quals = [bytes([64] + [50 + int(x) for x in rs.randint(0, 20, L - 1)]) for _ in reads]
+    ids = [b"@run.%d/%d" % (i, 1 + i % 2) for i in range(len(reads))]
+    fq = b"".join(b"%s\n%s\n+\n%s\n" % t for t in zip(ids, reads, quals))
+    got = {}
+    for tag, extra_env, extra in (("one", {}, []), ("repl", {"HARC_AMD_MG_MODE": "replicate", "HARC_AMD_XPORT": "mailbox", "HARC_AMD_SHARE_DEVICE": "0", "HARC_AMD_MAILBOX_TIMEOUT": "180"}, ["-g", str(world)])):
+        d = tmp_path / tag
+        d.mkdir()
+        (d / "s.fastq").write_bytes(fq)
+        env = dict(os.environ, HARC_AMD_STAGE3="none", **extra_env)
+        r = subprocess.run([os.path.join(ROOT, "harc"), "-c", str(d / "s.fastq")] + extra + flags, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        assert not (d / "output").exists()
+        got[tag] = _members(d / "s.harc", d)
+        if "-q" in flags:
+            got[tag]["s.quality"] = (d / "s.quality").read_bytes(); got[tag]["s.id"] = (d / "s.id").read_bytes()
+    assert sorted(got["one"]) == sorted(got["repl"]), (sorted(got["one"]), sorted(got["repl"]))
+    for k in got["one"]:
+        assert got["one"][k] == got["repl"][k], "%s differs between the single-GPU archive and the design-(R) archive of %d ranks" % (k, world)
+    assert not any(".shard" in k or ".mbox" in k for k in got["repl"])
