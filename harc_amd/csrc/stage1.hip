@@ -475,9 +475,10 @@ template <int W, bool I> __device__ __forceinline__ void cons_pack(const ConsSta
 // The kernel is bound by instruction issue at large K (PMC: 85 % of the SIMD issue slots, profiles/r02) and by dependent HBM round
 // trips at small K: both want few instructions per step.
 // Waves per SIMD of the main kernel (launch bound -> register budget).  5 unless the launch is at least eight full rounds of waves long
-// (DENSE: K >= 49152 chains): there two more waves (72 VGPRs, 6 dwords of scratch) fill issue slots that the others leave empty while
-// they wait (round 3, with the column counts in LDS and the chain header in scalar registers: configs[2] 1252 -> 1137 us per launch; an
-// eighth wave spills 31 registers: 1661 us), while at 24 k chains a sixth wave was 9 % slower (round 2).  Reads of more than 128 bases: one less.
+// (DENSE: K >= 49152 chains): there three more waves -- all eight a SIMD holds, 64 VGPRs -- fill issue slots that the others leave empty
+// while they wait (round 3: the column counts in LDS and the chain header in scalar registers made a seventh wave pay, configs[2] 1252 ->
+// 1137 us per launch; an eighth then still spilled 31 registers, 1661 us, until the wave-uniform scan of the small bins took the read's
+// words out of the lanes: 1 spilled register, 1110 us), while at 24 k chains a sixth wave was 9 % slower (round 2).  Reads of more than 128 bases: one less.
 #ifndef HARC_STEPS_WAVES
 #define HARC_STEPS_WAVES 5
 #endif
@@ -494,6 +495,9 @@ template <int W> struct StepsLds {
     static constexpr int ROW = 3 * NW + 1;
     static constexpr int MROW = (NW + 3) & ~3;                   // mask rows are 16-byte aligned
 };
+#ifndef HARC_SEQ_SCAN
+#define HARC_SEQ_SCAN 1               // dense k_steps: the small bins of a batch are scanned one after the other by the whole wave (0: every lane its own bin, as the other kernels)
+#endif
 #ifndef HARC_SCAN_CH
 #define HARC_SCAN_CH 1                // chunks of 256 bin entries the cooperative scan fetches per round trip (see wg_scan)
 #endif
@@ -756,7 +760,7 @@ template <int W> __global__ void k_steps_tables(S1Args s, uint32_t *out)
 // NWV (COOP only): waves per workgroup = the walking wave + NWV - 1 helpers that share its scans (64 NWV candidates per round trip).  Few
 // walks per super-round are bound by the longest one: 4 waves.  More walks than the chip holds workgroups are bound by wave slots, most of
 // which helpers idle in: fewer helpers, more walkers (stage1_run_w picks it from the walks of the last rounds; what is computed is the same).
-template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global__ __launch_bounds__(256, COOP ? HARC_COOP_WAVES : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? 2 : 0))) void k_steps(S1Args s)
+template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ = false> __global__ __launch_bounds__(256, COOP ? HARC_COOP_WAVES : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? (SEQ ? 3 : 2) : 0))) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -929,7 +933,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
             uint32_t ncb = 0;                                             // candidates this lane tests in this batch
             bool big = false; uint32_t b_cnt = 0; uint64_t b_slot = 0;   // a bin too large for one lane: scanned by the whole wave below
             uint2 b_lt = make_uint2(0, 0);                               // COOP: its row of largetab, fetched by the lane that found it (all bins of the batch in ONE round trip)
-            uint32_t mrd[NW];                                             // only the lane that wins has loaded them, and only it reads them
+            bool cand = false; uint32_t c_sst = 0, c_cw = 0, c_piy = 0; uint64_t c_slot = 0;     // SEQ (see "ONE AFTER THE OTHER" below): the small bin this lane's probe found
+            uint32_t mrd[NW];                                             // !SEQ: only the lane that wins has loaded them, and only it reads them
             if (p < bend && cap) {
                 const uint2 pi = s_pinfo[p];
                 j = (int)(pi.x >> 16); dir = (int)((pi.x >> 13) & 1);
@@ -978,13 +983,24 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
                     if (state) break;
                     sl += 4; if (sl >= cap) sl = 0;
                 }
-                // ... phase 2: the lanes that found their key scan their bins together
+                // ... phase 2: the lanes that found their key.  HARC_SEQ_SCAN (default): they only say so -- the bins are looked at below, one after the
+                // other in priority order, by the whole wave.  Otherwise (round 2) every such lane scans its bin itself, all at once.
                 if (state == 2 && !(cw & SLOT_DEAD)) {                    // SLOT_DEAD: every read of this bin is already claimed
-                    const uint32_t cntb = cw & SLOT_CNT_MASK;
-                    const bool emb = (cw & SLOT_EMB) != 0;                // single-read bin: `start` IS the read id
                     // bins of more than HARC_LARGEBIN reads (at build time) are scanned by the whole wave, and only by the COOP kernel
                     if (cw & SLOT_BIG) { big = true; b_cnt = cw & (SLOT_CNT_MASK | SLOT_OVF | SLOT_BIG); b_slot = sl + qhit; if (COOP) b_lt = s.largetab[sst]; }
+                    else if constexpr (SEQ) {
+                        cand = true; c_sst = sst; c_cw = cw; c_piy = pi.y; c_slot = sl + qhit;
+                        if (cw & SLOT_EMB) {
+                            // single-read bins (nearly all): claimed reads and the chain's own reads of this super-round are weeded out HERE, by all
+                            // lanes at once -- tested one after the other below, each of the chain's last few reads (they sit at the small shifts,
+                            // in front of the read the step is looking for) would cost a dependent round trip of its own
+                            if ((reinterpret_cast<const uint32_t *>(s.claimed)[sst >> 5] >> (sst & 31u)) & 1u) { cand = false; atomicOr(reinterpret_cast<uint32_t *>(&tab[sl + qhit]) + 3, SLOT_DEAD); }
+                            else for (int k = 0; k < t; k++) if ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == sst) cand = false;
+                        }
+                    }
                     else {
+                        const uint32_t cntb = cw & SLOT_CNT_MASK;
+                        const bool emb = (cw & SLOT_EMB) != 0;                // single-read bin: `start` IS the read id
                         const uint32_t *const ids = l ? s.ids[1] : s.ids[0];
                         const uint32_t *const mrow = s_mask + (pi.y >> 16);
                         const int bitoff = (int)(pi.y & 0xFFFF);
@@ -1015,9 +1031,66 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4> __global
                     }
                 }
             }
-            // ---- the best hit of the lanes that scanned their (small) bins themselves
             int winlane = 64;
+            if constexpr (SEQ) {
+            // ---- the small bins the probes of this batch found, ONE AFTER THE OTHER in priority order (the sequential order of reorder.cpp:517-552),
+            //      every candidate tested by the whole wave: NW lanes fetch one dword of the read each and take their share of the Hamming
+            //      distance, the claim word and the bin's ids are wave-uniform loads, the chain's own reads one compare across the lanes.  A step
+            //      tests one candidate on average (C-bar ~ 1) -- lane-serial scans of every bin at once kept the whole wave busy with the ~85
+            //      vector instructions of a scan for the two or three lanes that had a bin, and cost 8 registers per lane for the read.
             {
+                unsigned long long mc = __ballot(cand);
+                if (!COOP) { const unsigned long long mb = __ballot(big); if (mb) mc &= (mb & (0ULL - mb)) - 1ULL; }      // behind a large bin the main kernel stops anyway
+                const bool exactwin = s.maxsearch < (int)HARC_LARGEBIN;      // else the maxsearch window (reorder.cpp:540) cannot close inside a small bin
+                uint32_t ntest = 0;
+                while (mc) {
+                    const int w = __ffsll((long long)mc) - 1;
+                    mc &= mc - 1ULL;
+                    const uint32_t o_sst = (uint32_t)__builtin_amdgcn_readlane((int)c_sst, w), o_cw = (uint32_t)__builtin_amdgcn_readlane((int)c_cw, w);
+                    const uint32_t o_piy = (uint32_t)__builtin_amdgcn_readlane((int)c_piy, w);
+                    const int o_l = __builtin_amdgcn_readlane(l, w);
+                    const uint32_t cntb = o_cw & SLOT_CNT_MASK;
+                    const bool emb = (o_cw & SLOT_EMB) != 0;                  // single-read bin: `start` IS the read id
+                    const uint32_t *const ids = o_l ? s.ids[1] : s.ids[0];
+                    const int bitoff = (int)(o_piy & 0xFFFF), i0 = bitoff >> 5, sh = bitoff & 31;
+                    const uint32_t *const mrow = s_mask + (o_piy >> 16);
+                    const uint64_t o_slot = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)c_slot, w) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(c_slot >> 32), w) << 32);
+                    uint32_t lead = 0, hit = HARC_NONE, rd = 0; bool alltop = true; int seen = 0;
+                    for (uint32_t i = cntb; i > 0 && seen < s.maxsearch; i--) {
+                        const uint32_t rid = emb ? o_sst : (uint32_t)__builtin_amdgcn_readfirstlane((int)ids[o_sst + i - 1]);
+                        // claim bit and read words are fetched together (one dependent hop instead of two)
+                        const uint32_t cwd = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t *>(s.claimed)[rid >> 5]);
+                        rd = lane < NW ? reinterpret_cast<const uint32_t *>(s.reads)[(size_t)rid * NW + lane] : 0u;
+                        if ((cwd >> (rid & 31u)) & 1u) { if (alltop) lead++; continue; }
+                        alltop = false;
+                        // taken by this chain earlier in this super-round? (not in the frozen bitmap).  Such a read is not a candidate at all
+                        if (__ballot(ownreg == rid && lane < t)) continue;
+                        uint32_t hdp = 0;
+                        if (lane < NW) hdp = (uint32_t)__popc((__builtin_amdgcn_alignbit(rowF[i0 + lane + 1], rowF[i0 + lane], sh) ^ rd) & mrow[lane]);
+                        // NW <= 16 lanes: the sum over a row of 16 (row_shr 8, 4, 2, 1: lane 15 holds it)
+                        hdp += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hdp, 0x118, 0xF, 0xF, true);
+                        hdp += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hdp, 0x114, 0xF, 0xF, true);
+                        hdp += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hdp, 0x112, 0xF, 0xF, true);
+                        hdp += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hdp, 0x111, 0xF, 0xF, true);
+                        const int hd = __builtin_amdgcn_readlane((int)hdp, 15);
+                        ntest++; if (exactwin) seen++;
+                        if (hd <= s.thresh) { hit = rid; break; }
+                    }
+                    // hints only (the claim bitmap stays the truth): claimed reads at the top of a bin are never looked at again
+                    if (lead && lane == 0) {
+                        uint32_t *cp = reinterpret_cast<uint32_t *>(&(o_l ? s.slots[1] : s.slots[0])[o_slot]) + 3;
+                        if (lead == cntb) atomicOr(cp, SLOT_DEAD); else if (!emb) atomicMin(cp, (cntb - lead) | (o_cw & SLOT_OVF));
+                    }
+                    if (hit != HARC_NONE) {
+                        winlane = w; found = hit; fj = __builtin_amdgcn_readlane(j, w); fdir = __builtin_amdgcn_readlane(dir, w);
+                        if (lane < NW) rdl[lane] = rd;                         // the accepted read, for updaterefcount
+                        break;
+                    }
+                }
+                if (lane == 0) { nc += ntest; ncu += ntest; }
+            }
+            } else {
+            // ---- the best hit of the lanes that scanned their (small) bins themselves
                 const unsigned long long msmall = __ballot(mine != HARC_NONE);
                 if (msmall) {
                     winlane = __ffsll((long long)msmall) - 1;
@@ -2004,6 +2077,10 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe);
     const bool prof = P.profile != 0;
     const bool dense = getenv("HARC_AMD_DENSE") ? atoi(getenv("HARC_AMD_DENSE")) != 0 : K >= 49152;     // see HARC_STEPS_WAVES
+    // dense launches over mostly single-read bins (more than 80 % distinct first-dictionary k-mers: below ~40x): the small bins of a batch one after
+    // the other by the whole wave, 8 waves per SIMD; at 190x (configs[4]) every other bin holds several reads, most of them claimed, and
+    // scanning them one after the other costs more round trips than the lanes' own scans cost instructions (measured: 370 against 381 Mreads/s)
+    const bool seq = getenv("HARC_AMD_SEQ") ? atoi(getenv("HARC_AMD_SEQ")) != 0 : (HARC_SEQ_SCAN && N && (double)dict[0].nbins > 0.80 * (double)N);
     uint64_t rounds = 0, launches = 0;
     int coop_forced = getenv("HARC_AMD_COOP_WAVES") ? atoi(getenv("HARC_AMD_COOP_WAVES")) : 0;     // tests: 1, 2 or 4 waves per cooperative workgroup
     if (coop_forced != 1 && coop_forced != 2 && coop_forced != 4) coop_forced = 0;
@@ -2020,6 +2097,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (cm) hipLaunchKernelGGL(k_apply_seed, dim3(nblk), dim3(256), 0, c->stream, a);          // the seeds of the chains other ranks walk
             if (prof) { RC_TRY(R.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }
             if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
+            else if (dense && seq) hipLaunchKernelGGL((k_steps<W, false, false, true, 4, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             else if (dense) hipLaunchKernelGGL((k_steps<W, false, false, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             else hipLaunchKernelGGL((k_steps<W, false, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             if (prof) HIP_TRY(hipEventRecord(pair[1], c->stream));
