@@ -20,8 +20,8 @@ struct S1Args {
     HashSlot *slots[2];
     uint64_t cap[2];
     const uint32_t *ids[2];
-    int w0mul, w0add;                // first batch of a step: w0mul * (priority index of the chain's previous hit) + w0add probes, rounded up to 16
-    int firstmax[2];                 // widths of the first two probe batches of a step when many chains are in flight
+    int firstmax;                    // width cap of the first two probe batches of a step when many chains are in flight (the first batch: twice the running mean of the
+                                     // priority index of the chain's hits + 16 probes, rounded up to 16)
     const uint32_t *bloom[2]; uint32_t bloom_lines; int bloom_nwin[2]; uint32_t bloom_mmask;   // bitmap over the keys of each dictionary (bloom_pos), 0 lines = none
     const uint2 *largetab;           // bins of more than HARC_LARGEBIN reads (SLOT_BIG; their slot's `start` indexes this table): x = first index into ids[], y = first row of `mirror`
     uint64_t *mirror;                // the reads of those bins once more, W words per entry, in bin order: their scan is one coalesced stream
@@ -49,7 +49,6 @@ struct S1Args {
     int nprobe;
     int budget;                      // HARC_SCAN_BUDGET (experiments may override it: HARC_AMD_BUDGET)
     int stepcap;                     // HARC_STEP_CAP (HARC_AMD_STEPCAP)
-    int nbatch, batch_end[12];       // probe batches: [0,batch_end[0]), [batch_end[0],batch_end[1]) ... each at most 64 wide
     uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups, w sequential-equivalent candidates
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
 };
@@ -922,10 +921,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             // front of the tables it cost a table fetch at the random-access ceiling and 32 was the best cap; with the bitmap it costs a
             // 4-byte lookup (48: configs[2] chains 768 -> 728 ms); with the bitmap's lines chosen by minimizer it shares the lines of the
             // useful probes (64).  With few chains a round trip costs more than the probes (QUAD: 64).
-            // s.nbatch > 0 (HARC_AMD_BATCHES) overrides with a fixed schedule.
             int bend;
-            if (s.nbatch > 0) bend = s.batch_end[bi < s.nbatch ? bi : s.nbatch - 1];
-            else { int w0 = bi == 0 ? ((s.w0mul * (lastp >> 4) + s.w0add + 15) & ~15) : 64; const int wmax = QUAD ? 64 : (bi == 0 ? s.firstmax[0] : bi == 1 ? s.firstmax[1] : 64); if (w0 > wmax) w0 = wmax; bend = base + w0; }
+            { int w0 = bi == 0 ? ((2 * (lastp >> 4) + 16 + 15) & ~15) : 64; const int wmax = QUAD ? 64 : (bi <= 1 ? s.firstmax : 64); if (w0 > wmax) w0 = wmax; bend = base + w0; }
             if (bend > s.nprobe) bend = s.nprobe;
             if (bend <= base) bend = s.nprobe;
             const int p = base + lane; dbg_batches++;
@@ -2034,18 +2031,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (getenv("HARC_AMD_BUDGET")) a.budget = atoi(getenv("HARC_AMD_BUDGET"));
 #endif
     if (a.stepcap < 1) a.stepcap = 1;
-    a.nbatch = 0;                                                // adaptive batches (k_steps) unless a fixed schedule is forced
-    a.firstmax[0] = a.firstmax[1] = (bloom_nwin[0] > 0 && bloom_nwin[1] > 0) ? 64 : 48;     // lines by minimizer: speculative probes share their lines
-    if (const char *e = getenv("HARC_AMD_FIRSTMAX")) { int x = 32, y = 32; if (sscanf(e, "%d,%d", &x, &y) >= 1) { a.firstmax[0] = x < 1 ? 1 : x > 64 ? 64 : x; a.firstmax[1] = y < 1 ? 1 : y > 64 ? 64 : y; } }
-    a.w0mul = 2; a.w0add = 16;
-    if (const char *e = getenv("HARC_AMD_W0")) sscanf(e, "%d,%d", &a.w0mul, &a.w0add);
-    if (const char *e = getenv("HARC_AMD_BATCHES")) {                            // tuning knob, e.g. "32,64"; the last size repeats
-        int sizes[12], k = 0, last = 64; const char *q = e;
-        while (*q && k < 12) { int v = atoi(q); if (v < 1) v = 1; if (v > 64) v = 64; sizes[k++] = last = v; while (*q && *q != ',') q++; if (*q == ',') q++; }
-        for (; k < 12; k++) sizes[k] = last;
-        int en = 0;
-        while (en < a.nprobe && a.nbatch < 12) { en += sizes[a.nbatch]; if (en > a.nprobe) en = a.nprobe; a.batch_end[a.nbatch++] = en; }
-    }
+    a.firstmax = (bloom_nwin[0] > 0 && bloom_nwin[1] > 0) ? 64 : 48;     // lines by minimizer: speculative probes share their lines
+    if (const char *e = getenv("HARC_AMD_FIRSTMAX")) { const int x = atoi(e); a.firstmax = x < 1 ? 1 : x > 64 ? 64 : x; }
     HIP_TRY(hipMemsetAsync(a.claimed, 0, nwords * 8, c->stream));
     HIP_TRY(hipMemsetAsync(a.bid, 0xFF, ((size_t)N + 1) * 4, c->stream));
     HIP_TRY(hipMemsetAsync(a.log, 0xFF, ((size_t)N + 1) * sizeof(LogRec), c->stream));
