@@ -280,30 +280,39 @@ __global__ void k_place_keys(const uint64_t *skeys, const uint32_t *binstart, ui
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nbins) v[i] = bucket_slot(skeys[binstart[i]], cap) + (uint64_t)nbins - (uint64_t)i;     // 4 b_i - i, biased by nbins to stay unsigned
 }
-// pass 0: the bins whose slot lies inside the table, plain 16-byte stores.  pass 1 (after pass 0 has finished): the overflow flags -- a key
-// that sits beyond its home bucket has left every bucket in between -- and the few bins at the very end whose slot falls past the
-// table: they wrap around like a probe would.  Single-read bins (the common case) carry the read id in `start`: one dependent load
-// less on every hit.
+// pass 0: the bins whose slot lies inside the table, plain 16-byte stores, overflow flags included (round 2 set them in a second pass over all
+// bins: 2 x 2.6 ms per dictionary at configs[2]).  pass 1 (after pass 0 has finished, over the last 16 384 bins only): the few bins at the very
+// end whose slot falls past the table: they wrap around like a probe would.  Single-read bins (the common case) carry the read id in
+// `start`: one dependent load less on every hit.
 __global__ void k_table_place(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, uint32_t nbins, uint32_t n, const uint64_t *q,
                               HashSlot *slots, uint64_t cap, uint32_t bigthresh,
-                              unsigned long long *large_list, unsigned int *large_n, uint32_t large_max, uint32_t large_tag, uint32_t *nbins_p, int pass)
+                              unsigned long long *large_list, unsigned int *large_n, uint32_t large_max, uint32_t large_tag, uint32_t *nbins_p, int pass, uint32_t first_block)
 {
+    if (blockIdx.x < first_block) return;                                          // pass 1: the bins beyond the end of the table are among the last
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nbins) return;
     uint64_t sl = q[i] - (uint64_t)nbins + (uint64_t)i;                            // max-scan value + i
     const uint32_t st = binstart[i];
     const uint64_t key = skeys[st];
-    if (pass == 1) {
-        const uint64_t home = bucket_slot(key, cap) >> 2, last = (sl < cap ? sl : cap - 1) >> 2;
-        for (uint64_t b = home; b < last; b++) atomicOr(&slots[4 * b].count, SLOT_OVF);
-        if (sl < cap) return;
-    } else if (sl >= cap) return;
+    // pass 0 places the bins whose slot lies inside the table; pass 1 (launched over the last bins only) the few beyond its end
+    if (pass == 0 && sl >= cap && blockIdx.x + 64 < gridDim.x) { atomicAdd(nbins_p + 1, 1u); return; }   // pass 1 would not reach it: the build fails loudly (never seen)
+    if ((pass == 1) != (sl >= cap)) return;
+    // the overflow flag of a bucket lives in its first slot: "a key whose home is this bucket or an earlier one sits beyond it".  Slots and
+    // homes both grow with the bin index, so that is the case exactly when the bucket is full and the bin right behind it has its home
+    // here or earlier -- decided by the thread that writes the first slot, without a second pass over all bins
+    uint32_t ovf = 0;
+    if (pass == 0 && (sl & 3) == 0 && (uint64_t)i + 4 < (uint64_t)nbins) {
+        const uint64_t s3 = q[i + 3] - (uint64_t)nbins + (uint64_t)(i + 3);
+        if (s3 == sl + 3 && (bucket_slot(skeys[binstart[i + 4]], cap) >> 2) <= (sl >> 2)) ovf = SLOT_OVF;
+    }
     const uint32_t en = (i + 1 < nbins) ? binstart[i + 1] : n;
     const uint32_t cnt = en - st;
     if (cnt > SLOT_CNT_MASK) { atomicAdd(nbins_p + 1, 1u); return; }               // does not fit the count field: the build fails loudly
     const unsigned long long meta = cnt == 1 ? ((unsigned long long)sids[st] | ((unsigned long long)(1u | SLOT_EMB) << 32))
                                              : ((unsigned long long)st | ((unsigned long long)((cnt & SLOT_CNT_MASK) | ((bigthresh && cnt > bigthresh) ? SLOT_BIG : 0u)) << 32));
     if (pass == 1) {
+        // a bin beyond the end wraps around like a probe would: it has left its home bucket, every bucket up to the last, and whatever it passes at the start
+        for (uint64_t b = bucket_slot(key, cap) >> 2; b < (cap >> 2); b++) atomicOr(&slots[4 * b].count, SLOT_OVF);
         sl = 0;
         for (;;) {
             unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
@@ -312,9 +321,8 @@ __global__ void k_table_place(const uint64_t *skeys, const uint32_t *sids, const
             if (++sl == cap) sl = 0;
         }
         slots[sl].key = key;
-        atomicOr(&slots[cap - 4].count, SLOT_OVF);                                // it left the last bucket
     } else {
-        uint4 w; w.x = (uint32_t)key; w.y = (uint32_t)(key >> 32); w.z = (uint32_t)meta; w.w = (uint32_t)(meta >> 32);
+        uint4 w; w.x = (uint32_t)key; w.y = (uint32_t)(key >> 32); w.z = (uint32_t)meta; w.w = (uint32_t)(meta >> 32) | ovf;
         *reinterpret_cast<uint4 *>(&slots[sl]) = w;
     }
     if (large_list && cnt > HARC_LARGEBIN) {                                      // remembered for k_compact_bins: (slot index, dictionary)
@@ -1802,14 +1810,14 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
         RC_TRY(prim_incl_max_u64(c, v, q, nbins));
         for (int pass = 0; pass < 2; pass++)
             hipLaunchKernelGGL(k_table_place, dim3(gb), dim3(256), 0, c->stream, (const uint64_t *)k1, (const uint32_t *)d->ids, (const uint32_t *)bs, nbins, n, (const uint64_t *)q,
-                               d->slots, d->cap, d->bigthresh, d->large_list, d->large_n, d->large_max, d->large_tag, d->d_nbins, pass);
+                               d->slots, d->cap, d->bigthresh, d->large_list, d->large_n, d->large_max, d->large_tag, d->d_nbins, pass, pass == 0 ? 0u : (gb > 64 ? gb - 64 : 0u));
     }
     HIP_TRY(hipGetLastError());
     uint32_t nb2[2] = { 0, 0 };
     HIP_TRY(hipMemcpyAsync(nb2, d->d_nbins, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));                                    // temporaries are reused after this point
     scope.release_now();
-    if (nb2[1]) { harc_set_error("dictionary: %u bins hold more than %u reads with the same k-mer (count field of the slot)", nb2[1], SLOT_CNT_MASK); return HARC_AMD_EINVAL; }
+    if (nb2[1]) { harc_set_error("dictionary: %u bins hold more than %u reads with the same k-mer (count field of the slot), or lie more than 16384 bins beyond the end of the table", nb2[1], SLOT_CNT_MASK); return HARC_AMD_EINVAL; }
     return HARC_AMD_OK;
 }
 void harc_dict_free(harc_amd_ctx *c, DictDev *d)
