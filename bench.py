@@ -523,14 +523,14 @@ def main():
         if tr and world == 1:
             roofline["traffic"] = round((tr["fetch_kb_per_launch"] + tr["write_kb_per_launch"]) * 1024.0, 1)
             roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / max(1.0, roofline["alg_bytes_per_launch"]), 2)
-            roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this command, profiles/k_steps_traffic.json (" + tr.get("profile", "") + ")"
+            roofline["traffic_source"] = "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command taken by the builder, profiles/k_steps_traffic.json (" + tr.get("profile", "") + ")"
             # the roofline that binds this kernel: random 32-byte sector requests per second (tools/micro/gups.hip) against the L2 misses
             # of the PMC pass per launch, over the launch time measured live
             ceil = json.load(open(os.path.join(ROOT, "profiles", "random_access_ceiling.json")))
             if tr.get("tcc_miss") and avg_ms > 0:
                 req = tr["tcc_miss"] / (avg_ms * 1e-3) / 1e9
                 roofline["random_access"] = {"achieved": round(req, 2), "peak": ceil["G_requests_per_s"]["32B"], "unit": "G sector requests/s (L2 misses; 32-byte slot-pair and read fetches)",
-                                             "frac": round(req / ceil["G_requests_per_s"]["32B"], 3), "l2_misses_per_launch": tr["tcc_miss"],
+                                             "frac": round(req / ceil["G_requests_per_s"]["32B"], 3), "l2_misses_per_launch": tr["tcc_miss"], "l2_misses_source": "from the builder's separate PMC run (as traffic); the launch time is this run's",
                                              "peak_source": "tools/micro/gups.hip, profiles/r02/gups.txt: independent random 32-B loads over 64 GiB"}
             # ... and, once the bitmap in front of the tables keeps most probes away from them, instruction issue: vector instructions of
             # the PMC pass x 4 cycles (one wave64 instruction on a 16-lane SIMD) over the SIMD cycles of the launch measured live
@@ -539,7 +539,7 @@ def main():
                 roofline["issue"] = {"valu_insts_per_launch": tr["sq_insts_valu"], "salu_insts_per_launch": tr.get("sq_insts_salu"),
                                      "valu_busy_frac": round(tr["sq_insts_valu"] * 4.0 / simd_cycles, 3),
                                      "wave_cycles_waiting_frac": round(tr["sq_wait_any"] / max(1.0, tr["sq_wave_cycles"]), 3),
-                                     "note": "1024 SIMDs at 2.4 GHz peak clock (the launch runs at ~2.2 GHz: SQ_BUSY_CYCLES), full-rate instructions only: a lower bound of the busy fraction"}
+                                     "note": "instruction counts from the builder's separate PMC run (as traffic), the launch time is this run's; 1024 SIMDs at 2.4 GHz peak clock (the launch runs at ~2.1 GHz), 4 cycles per instruction (tools/micro/valu_rate: 2.9-5.3 measured): a lower bound of the busy fraction"}
     except Exception:
         pass
     out = {

@@ -2072,10 +2072,11 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe);
     const bool prof = P.profile != 0;
     const bool dense = getenv("HARC_AMD_DENSE") ? atoi(getenv("HARC_AMD_DENSE")) != 0 : K >= 49152;     // see HARC_STEPS_WAVES
-    // dense launches over mostly single-read bins (more than 80 % distinct first-dictionary k-mers: below ~40x): the small bins of a batch one after
-    // the other by the whole wave, 8 waves per SIMD; at 190x (configs[4]) every other bin holds several reads, most of them claimed, and
-    // scanning them one after the other costs more round trips than the lanes' own scans cost instructions (measured: 370 against 381 Mreads/s)
-    const bool seq = getenv("HARC_AMD_SEQ") ? atoi(getenv("HARC_AMD_SEQ")) != 0 : (HARC_SEQ_SCAN && N && (double)dict[0].nbins > 0.80 * (double)N);
+    // dense launches over mostly single-read bins (more than 88 % distinct first-dictionary k-mers: configs[2] 0.95, configs[3] 0.96): the small bins
+    // of a batch one after the other by the whole wave, 8 waves per SIMD; at 190x (configs[4]: 0.81, a quarter of it k-mers with a sequencing
+    // error) every other true bin holds several reads, most of them claimed, and scanning them one after the other costs more round trips
+    // than the lanes' own scans cost instructions (measured there: 370 against 385 Mreads/s)
+    const bool seq = getenv("HARC_AMD_SEQ") ? atoi(getenv("HARC_AMD_SEQ")) != 0 : (HARC_SEQ_SCAN && N && (double)dict[0].nbins > 0.88 * (double)N);
     uint64_t rounds = 0, launches = 0;
     int coop_forced = getenv("HARC_AMD_COOP_WAVES") ? atoi(getenv("HARC_AMD_COOP_WAVES")) : 0;     // tests: 1, 2 or 4 waves per cooperative workgroup
     if (coop_forced != 1 && coop_forced != 2 && coop_forced != 4) coop_forced = 0;
