@@ -614,6 +614,7 @@ struct WgCmd {
     int op;                          // 1 = scan, 0 = leave
     int l, t, fast;
     uint32_t ids0, m0, cnt;
+    uint32_t rot;                    // the scan starts at the rot-th entry from the top and takes the rot entries above it last (schedule rule: below)
     unsigned long long grp;          // the probes (lanes of wave 0) that look into this bin
     uint32_t found;                  // the read of the best probe that found one
     uint32_t nc;                     // candidates tested by the helpers (statistics)
@@ -639,9 +640,18 @@ template <int W, int NWV> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd
     const uint32_t ids0 = cmd->ids0, m0 = cmd->m0;
     const int t = cmd->t; const bool fast = cmd->fast != 0;
     unsigned long long grp = cmd->grp;
-    int seen = 0, par = 0; uint32_t pos = cmd->cnt;
+    // Schedule rule of round 3 (the oracle's scan_bin has the same): the scan of a large bin starts at entry number rot from the top -- rot =
+    // (chain * 0x9E3779B1 >> 8) mod min(live entries, maxsearch), 0 for chain 0: one chain stays the reference at -t 1 -- goes down to the
+    // end of the bin or of the maxsearch window, and takes the rot entries above its start last.  The chains that sit in one repeat family
+    // all wanted the highest unclaimed id of the same bin; all but one lost the bid and the rest of their walk (c2r: 4.26 M steps walked to
+    // keep 2.91 M).  Two segments: entries [0, cnt - rot) from their top, then [cnt - rot, cnt) from theirs.
+    int seen = 0, par = 0;
+    const uint32_t rot = cmd->rot;
+    uint32_t pos = cmd->cnt - rot, lo = 0; bool second = rot == 0;
     uint32_t mrd[CH][NW], rid[CH];
-    while (pos > 0 && seen < maxsearch && grp) {
+    for (;;) {
+        if (pos == lo) { if (second) break; second = true; pos = cmd->cnt; lo = cmd->cnt - rot; }
+        if (!(seen < maxsearch && grp)) break;
         // CH chunks of 256 entries per round trip; entry c * 256 + 64 * role + lane from the top of the bin, so priority = (c, role, lane).
         // CH = 1: with 2 or 4 (a bin of diverged repeat copies is scanned to the end of the window, four dependent round trips) the kernel
         // needs 153 / 209 registers instead of 124 and loses a wave or two per SIMD: c3sd chains 419 -> 489 / 703 ms.  A chunk costs ~1.5 us
@@ -651,7 +661,7 @@ template <int W, int NWV> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const uint32_t off = 64u * NWV * (uint32_t)c + 64u * (uint32_t)role + (uint32_t)lane;
-            valid[c] = off < pos; rid[c] = 0; own[c] = false;
+            valid[c] = off < pos - lo; rid[c] = 0; own[c] = false;
             if (valid[c]) { const uint32_t at = pos - 1 - off; rid[c] = oids[ids0 + at]; load_read32<W>(mirror, m0 + at, mrd[c]); }
         }
         // fast (the bin fits the maxsearch window, which then never closes): the chain's own reads are only looked up for candidates that
@@ -732,7 +742,7 @@ template <int W, int NWV> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd
             }
         }
         if (!fast) seen += total;
-        pos -= pos > 64u * NWV * CH ? 64u * NWV * CH : pos;
+        pos -= pos - lo > 64u * NWV * CH ? 64u * NWV * CH : pos - lo;
     }
     __syncthreads();                                               // the winner's words are in place; the command block is free for the next scan
     return r;
@@ -1146,6 +1156,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                     if (lane == 0) {
                         cmd->op = 1; cmd->l = o_l; cmd->t = t; cmd->fast = o_cnt <= (uint32_t)s.maxsearch ? 1 : 0;
                         cmd->ids0 = lt.x; cmd->m0 = lt.y; cmd->cnt = o_cnt; cmd->grp = grp; cmd->found = HARC_NONE;
+                        { const uint32_t m = o_cnt < (uint32_t)s.maxsearch ? o_cnt : (uint32_t)s.maxsearch; cmd->rot = m ? ((c * 0x9E3779B1u) >> 8) % m : 0u; }
                     }
                     __syncthreads();                                           // the helpers start
                     const uint32_t *const idp[2] = { s.ids[0], s.ids[1] };

@@ -151,7 +151,7 @@ typedef struct { uint32_t *v; size_t n, cap; } vec32;
 static void vpush(vec32 *a, uint32_t x) { if (a->n == a->cap) { a->cap = a->cap ? a->cap * 2 : 16; a->v = realloc(a->v, 4 * a->cap); } a->v[a->n++] = x; }
 
 typedef struct {
-    int active; uint32_t cur, prev; int prev_unmatched;
+    int active; uint32_t id, cur, prev; int prev_unmatched;   /* id: the chain's number (its seed, its place in the output, its scan start in large bins) */
     int32_t *count;        /* [4][L], rows A C G T (reorder.cpp:467) */
     uint8_t *cons;         /* consensus, idx codes A0 C1 G2 T3 */
     vec32 m_order, m_meta; /* main stream: order; meta = pos | flag<<8 | rc<<9 */
@@ -200,28 +200,45 @@ static void cons_update(chain_t *c, const uint64_t *r, int L, int rev, int shift
     }
 }
 
-/* scan one bin: ids from highest to lowest, only unclaimed ones, at most maxsearch of them (reorder.cpp:540) */
+/* scan one bin: ids from highest to lowest, only unclaimed ones, at most maxsearch of them (reorder.cpp:540).
+ * rot (schedule rule of round 3, bins of more than LARGEBIN reads only; 0 for every other bin and for chain 0, so that one chain is the
+ * reference at -t 1): the scan starts at the rot-th unclaimed entry from the top, goes down, and takes the rot entries above it last.
+ * Chains that sit in the same repeat all wanted the SAME read -- the highest unclaimed id of the bin -- and all but one lost their bid and
+ * the rest of their walk (a third of all walked steps on an exact-repeat family); a start that depends on the chain spreads them over
+ * the bin.  rot = (chain * 0x9E3779B1 >> 8) mod min(unclaimed entries of the bin, maxsearch), in the frozen state of the super-round. */
 static uint32_t scan_bin(dict_t *d, uint32_t bin, const uint64_t *reads, int W, const uint8_t *claimed,
                          const uint64_t *refsh, const uint64_t *mask, int thresh, int maxsearch, uint64_t *cands,
-                         const uint32_t *own, int nown)
+                         const uint32_t *own, int nown, uint32_t rot)
 {
     uint32_t s = d->start[bin], e = d->live_end[bin];
     while (e > s && claimed[d->ids[e - 1]]) e--;
     d->live_end[bin] = e;
     int seen = 0;
-    for (uint32_t i = e; i > s && seen < maxsearch; i--) {
-        uint32_t rid = d->ids[i - 1];
-        if (claimed[rid]) continue;
-        int mine = 0;                                             /* reads this chain already took earlier in the same super-round */
-        for (int k = 0; k < nown; k++) if (own[k] == rid) mine = 1;
-        if (mine) continue;
-        seen++; (*cands)++;
-        const uint64_t *r = reads + (size_t)rid * W;
-        int hd = 0;
-        for (int w = 0; w < W; w++) hd += __builtin_popcountll(refsh[w] ^ (r[w] & mask[w]));
-        if (hd <= thresh) return rid;
+    for (int phase = 0; phase < 2; phase++) {                     /* 0: from the rot-th unclaimed entry down; 1: the rot entries above it */
+        if (phase == 1 && rot == 0) break;
+        uint32_t u = 0;                                           /* unclaimed entries passed so far, from the top */
+        for (uint32_t i = e; i > s && seen < maxsearch; i--) {
+            uint32_t rid = d->ids[i - 1];
+            if (claimed[rid]) continue;
+            const uint32_t ui = u++;
+            if (phase == 0 ? ui < rot : ui >= rot) { if (phase == 1) break; continue; }
+            int mine = 0;                                         /* reads this chain already took earlier in the same super-round */
+            for (int k = 0; k < nown; k++) if (own[k] == rid) mine = 1;
+            if (mine) continue;
+            seen++; (*cands)++;
+            const uint64_t *r = reads + (size_t)rid * W;
+            int hd = 0;
+            for (int w = 0; w < W; w++) hd += __builtin_popcountll(refsh[w] ^ (r[w] & mask[w]));
+            if (hd <= thresh) return rid;
+        }
     }
     return NONE;
+}
+
+static uint32_t scan_rot(uint32_t chain, uint32_t nlive, int maxsearch)
+{
+    const uint32_t m = nlive < (uint32_t)maxsearch ? nlive : (uint32_t)maxsearch;
+    return m ? (uint32_t)((chain * 0x9E3779B1u) >> 8) % m : 0;
 }
 
 static void propose(chain_t *c, dict_t *dict, const uint64_t *reads, const uint8_t *claimed, const params_t *p,
@@ -247,7 +264,7 @@ static void propose(chain_t *c, dict_t *dict, const uint64_t *reads, const uint8
             if (bin == NONE) continue;
             int big = dict[l].start[bin + 1] - dict[l].start[bin] > LARGEBIN && dict[l].nlive[bin] > 0;
             if (big) c->p_big++;
-            uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, ref, mask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands, own, nown);
+            uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, ref, mask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands, own, nown, big ? scan_rot(c->id, dict[l].nlive[bin], p->maxsearch) : 0);
             if (rid != NONE) { c->p_rid = rid; c->p_j = j; c->p_dir = 0; return; }
             if (big && c->p_big >= STEP_CAP) { c->p_stalled = 1; c->p_next = pidx; return; }
         }
@@ -260,7 +277,7 @@ static void propose(chain_t *c, dict_t *dict, const uint64_t *reads, const uint8
             if (bin == NONE) continue;
             int big = dict[l].start[bin + 1] - dict[l].start[bin] > LARGEBIN && dict[l].nlive[bin] > 0;
             if (big) c->p_big++;
-            uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, rev, revmask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands, own, nown);
+            uint32_t rid = scan_bin(&dict[l], bin, reads, W, claimed, rev, revmask + (size_t)j * W, p->thresh, p->maxsearch, &st->cands, own, nown, big ? scan_rot(c->id, dict[l].nlive[bin], p->maxsearch) : 0);
             if (rid != NONE) { c->p_rid = rid; c->p_j = j; c->p_dir = 1; return; }
             if (big && c->p_big >= STEP_CAP) { c->p_stalled = 1; c->p_next = pidx; return; }
         }
@@ -312,6 +329,7 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
     uint32_t *bid = malloc(4 * ((size_t)N + 1));
     for (uint32_t i = 0; i < N; i++) bid[i] = NONE;
     chain_t *ch = calloc(K, sizeof(chain_t));
+    for (uint32_t c = 0; c < (uint32_t)K; c++) ch[c].id = c;
     uint32_t firstread = 0, nactive = 0;
     for (uint32_t c = 0; c < K; c++) {                            /* reorder.cpp:476-497 */
         chain_t *x = &ch[c];
