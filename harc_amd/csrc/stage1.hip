@@ -265,7 +265,7 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
 #define HARC_LARGEBIN 16u    // stage-I bins with more reads than this are compacted between super-rounds (k_compact_bins)
 #define HARC_STEP_CAP 6     // schedule: a STEP that has made this many probes into such bins without a hit is put off -- the walk ends in front of it, and the next
                              // super-round takes the step up again behind the probes already made (they found nothing against fewer claims; ChainHdr.flags >> 16)
-#define HARC_SCAN_BUDGET 16  // schedule: a walk ends after the step in which the probes it made into such bins (still holding unclaimed reads) reach this number
+#define HARC_SCAN_BUDGET 8   // schedule: a walk ends after the step in which the probes it made into such bins (still holding unclaimed reads) reach this number
 // The table is probed bucket by bucket (64 B = 4 slots); a search that finds a full bucket WITHOUT the overflow flag can stop.
 // The reads arrive sorted by scrambled key, so the bins arrive in bucket order (bucket_slot is monotone): the slot of bin i is
 // max(4 * bucket_i, slot_{i-1} + 1) -- the linear-probing invariant -- i.e. an inclusive max-scan of (4 * bucket_i - i), plus i.

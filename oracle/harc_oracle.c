@@ -42,7 +42,7 @@
 #define LARGEBIN 16u      /* HARC_LARGEBIN of harc_amd/csrc/stage1.hip */
 #define STEP_CAP 6        /* HARC_STEP_CAP: a step that has made this many probes into such bins without a hit is put off: the walk ends in front of it and the
                               next super-round takes the step up again BEHIND the probes already made (they found nothing against fewer claims) */
-#define SCAN_BUDGET 16     /* HARC_SCAN_BUDGET: a walk ends after the step in which its probes into bins of more than LARGEBIN reads (not yet exhausted) reach this number */
+#define SCAN_BUDGET 8      /* HARC_SCAN_BUDGET: a walk ends after the step in which its probes into bins of more than LARGEBIN reads (not yet exhausted) reach this number */
 
 /* ------------------------------------------------------------------ parameters (harc:52-60) */
 typedef struct {
