@@ -1869,6 +1869,7 @@ static uint32_t auto_chains(uint32_t N, int reads_per_chain)
 struct S1Resources {
     static constexpr int RING = 64;
     hipEvent_t e[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t eb[2] = { nullptr, nullptr };
     hipEvent_t ring[RING][2];
     int ring_used = 0; uint64_t ring_next = 0; double ms = 0;
     unsigned long long *h_stats = nullptr;
@@ -1876,12 +1877,14 @@ struct S1Resources {
     ~S1Resources()
     {
         for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x);
+        for (hipEvent_t x : eb) if (x) (void)hipEventDestroy(x);
         for (int i = 0; i < ring_used; i++) { (void)hipEventDestroy(ring[i][0]); (void)hipEventDestroy(ring[i][1]); }
         if (h_stats) (void)hipHostFree(h_stats);
     }
     int init()
     {
         for (auto &x : e) HIP_TRY(hipEventCreate(&x));
+        for (auto &x : eb) HIP_TRY(hipEventCreate(&x));
         HIP_TRY(hipHostMalloc((void **)&h_stats, (ST_N + HARC_COOPCNT) * 8));
         return HARC_AMD_OK;
     }
@@ -2082,12 +2085,19 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     }
     const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe);
     const bool prof = P.profile != 0;
-    const bool dense = getenv("HARC_AMD_DENSE") ? atoi(getenv("HARC_AMD_DENSE")) != 0 : K >= 49152;     // see HARC_STEPS_WAVES
+    // dense kernels (7 / 8 waves per SIMD) for every launch that is not QUAD (round 2: from 49 152 chains on; with the counts in LDS they pay from
+    // 16 385 on: 24 k chains of configs[2] at 1/7 scale +5 %, the 21 k chains of c3sd +3.6 %)
+    const bool dense = getenv("HARC_AMD_DENSE") ? atoi(getenv("HARC_AMD_DENSE")) != 0 : K > 16384;     // see HARC_STEPS_WAVES
     // dense launches over mostly single-read bins (more than 88 % distinct first-dictionary k-mers: configs[2] 0.95, configs[3] 0.96): the small bins
     // of a batch one after the other by the whole wave, 8 waves per SIMD; at 190x (configs[4]: 0.81, a quarter of it k-mers with a sequencing
     // error) every other true bin holds several reads, most of them claimed, and scanning them one after the other costs more round trips
     // than the lanes' own scans cost instructions (measured there: 370 against 385 Mreads/s)
-    const bool seq = getenv("HARC_AMD_SEQ") ? atoi(getenv("HARC_AMD_SEQ")) != 0 : (HARC_SEQ_SCAN && N && (double)dict[0].nbins > 0.88 * (double)N);
+    // ... and repeat families put reads of different copies into small bins of several reads as well (c3sd is 18 % slower with the wave-uniform
+    // scan, and no count the index has tells it from configs[2]).  Both variants compute the same thing, so a dense run MEASURES: the first
+    // eight super-rounds with the wave-uniform scan, the next eight without, the faster one from there on (HARC_AMD_SEQ=0/1 forces one).
+    bool seq = getenv("HARC_AMD_SEQ") ? atoi(getenv("HARC_AMD_SEQ")) != 0 : (HARC_SEQ_SCAN && N && (double)dict[0].nbins > 0.88 * (double)N);
+    int seq_probe = (!getenv("HARC_AMD_SEQ") && HARC_SEQ_SCAN && dense && !quad && seq) ? 0 : 2;      // 0 / 1: the batch being timed, 2: decided
+    float seq_ms[2] = { 0, 0 };
     uint64_t rounds = 0, launches = 0;
     int coop_forced = getenv("HARC_AMD_COOP_WAVES") ? atoi(getenv("HARC_AMD_COOP_WAVES")) : 0;     // tests: 1, 2 or 4 waves per cooperative workgroup
     if (coop_forced != 1 && coop_forced != 2 && coop_forced != 4) coop_forced = 0;
@@ -2099,6 +2109,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // k_reseed by 64 workgroups once a single one has thousands of seeds to hand out per round (HARC_AMD_RESEED_MG=0/1 forces either; same result)
     const bool reseed_mg = getenv("HARC_AMD_RESEED_MG") ? atoi(getenv("HARC_AMD_RESEED_MG")) != 0 : K > 4096;
     for (;;) {
+        if (seq_probe < 2) { seq = seq_probe == 0; HIP_TRY(hipEventRecord(R.eb[0], c->stream)); }
         for (int r = 0; r < batch; r++) {
             hipEvent_t *pair = nullptr;
             if (cm) hipLaunchKernelGGL(k_apply_seed, dim3(nblk), dim3(256), 0, c->stream, a);          // the seeds of the chains other ranks walk
@@ -2133,12 +2144,17 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             launches++;
         }
         rounds += batch;
+        if (seq_probe < 2) HIP_TRY(hipEventRecord(R.eb[1], c->stream));
         HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
         if (nlarge) HIP_TRY(hipMemcpyAsync(h_stats + ST_N, a.coopcnt, HARC_COOPCNT * 8, hipMemcpyDeviceToHost, c->stream));
         if (cm) RC_TRY(cm->wait(c, "all-gather of the walked steps"));      // a peer that died shows as a timeout, not as a hang
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
-        if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] round %llu: %llu chains alive\n", (unsigned long long)rounds, h_stats[ST_ACTIVE]);
+        if (seq_probe < 2) {
+            HIP_TRY(hipEventElapsedTime(&seq_ms[seq_probe], R.eb[0], R.eb[1]));
+            if (++seq_probe == 2) seq = seq_ms[0] < seq_ms[1];
+        }
+        if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] round %llu: %llu chains alive%s\n", (unsigned long long)rounds, h_stats[ST_ACTIVE], seq ? " (wave-uniform scan)" : "");
         if (h_stats[ST_ACTIVE] == 0) break;
         if (nlarge && coop_forced == 0) {
             // cooperative walks per super-round over the last rounds against the workgroups of four waves the chip holds (4 per CU): well beyond
