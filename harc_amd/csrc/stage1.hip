@@ -482,7 +482,7 @@ template <int W, bool I> __device__ __forceinline__ void cons_pack(const ConsSta
 // The kernel is bound by instruction issue at large K (PMC: 85 % of the SIMD issue slots, profiles/r02) and by dependent HBM round
 // trips at small K: both want few instructions per step.
 // Waves per SIMD of the main kernel (launch bound -> register budget).  5 unless the launch is at least eight full rounds of waves long
-// (DENSE: K >= 49152 chains): there three more waves -- all eight a SIMD holds, 64 VGPRs -- fill issue slots that the others leave empty
+// (DENSE: more than 16 384 chains, i.e. whenever the launch is not QUAD): there three more waves -- all eight a SIMD holds, 64 VGPRs -- fill issue slots that the others leave empty
 // while they wait (round 3: the column counts in LDS and the chain header in scalar registers made a seventh wave pay, configs[2] 1252 ->
 // 1137 us per launch; an eighth then still spilled 31 registers, 1661 us, until the wave-uniform scan of the small bins took the read's
 // words out of the lanes: 1 spilled register, 1110 us), while at 24 k chains a sixth wave was 9 % slower (round 2).  Reads of more than 128 bases: one less.
