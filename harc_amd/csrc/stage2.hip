@@ -182,9 +182,22 @@ __global__ __launch_bounds__(256) void k_consensus(S2Args s, const uint32_t *cid
     const uint64_t x0 = X0 + (uint64_t)x0r;
     const bool mine = x0 < s.total;
     const int xlr = (x0 + CSTRIP - 1 < s.total ? x0r + CSTRIP - 1 : (int)(s.total - 1 - X0));   // last column of the strip
-    uint32_t cnt[CSTRIP][4];
+    // Column counts: four 32-bit counters per column (rows A C G T, reorder.cpp order of ties) fed from four 8-BIT counters packed into one
+    // register per column (in packed-code order A G C T: the 2-bit code is the byte index, no recoding per base), which are emptied into the
+    // wide ones before any of them can reach 256.  A read adds to all columns of the strip from ONE 16-bit window of its words (round 2:
+    // per base a word select, a shift, a recode and four compare-adds: 22.6 G vector instructions per launch at configs[2], 34 ms).
+    uint32_t cnt[CSTRIP][4], pk[CSTRIP];
 #pragma unroll
-    for (int c = 0; c < CSTRIP; c++) { cnt[c][0] = cnt[c][1] = cnt[c][2] = cnt[c][3] = 0; }
+    for (int c = 0; c < CSTRIP; c++) { cnt[c][0] = cnt[c][1] = cnt[c][2] = cnt[c][3] = 0; pk[c] = 0; }
+    int since = 0;                                                // reads added to pk since it was last emptied
+    auto flush = [&]() {
+#pragma unroll
+        for (int c = 0; c < CSTRIP; c++) {
+            cnt[c][0] += pk[c] & 0xFFu; cnt[c][2] += (pk[c] >> 8) & 0xFFu; cnt[c][1] += (pk[c] >> 16) & 0xFFu; cnt[c][3] += pk[c] >> 24;   // code A0 G1 C2 T3 -> row A0 C1 G2 T3
+            pk[c] = 0;
+        }
+        since = 0;
+    };
     long long ilast = ilo - 1;                                    // last read starting at or before x0
     for (long long base = ilo; base <= ihi; base += CCHUNK) {
         const int nch = (int)(ihi + 1 - base < CCHUNK ? ihi + 1 - base : CCHUNK);
@@ -205,21 +218,22 @@ __global__ __launch_bounds__(256) void k_consensus(S2Args s, const uint32_t *cid
             if (g <= x0r) ilast = base + k;
             const uint64_t *r = cl_words + (size_t)k * W;
             const int o0 = x0r - g;                               // offset of column x0 inside the read (may be negative)
+            // the 2 CSTRIP bits of the read at the strip's columns: bases o0 .. o0 + CSTRIP - 1 (those before the read's start come out of the shift as zeros and are masked)
             const int j0 = o0 < 0 ? 0 : o0;
-            const int w0 = j0 >> 5;
+            const int w0 = j0 >> 5, sh = 2 * (j0 & 31);
             const uint64_t wa = r[w0], wb = (w0 + 1 < W) ? r[w0 + 1] : 0;
+            uint32_t bits = (uint32_t)(sh ? ((wa >> sh) | (wb << (64 - sh))) : wa) & 0xFFFFu;
+            if (o0 < 0) bits <<= 2 * (-o0);                       // column c holds base o0 + c: the read starts inside the strip
+            // columns of the strip the read covers: c >= -o0, o0 + c < L, x0r + c <= xlr
+            const int c_lo = o0 < 0 ? -o0 : 0, c_hi = (L - o0 < xlr - x0r + 1 ? L - o0 : xlr - x0r + 1);      // [c_lo, c_hi)
+            uint32_t vm = c_hi >= CSTRIP ? 0xFFu : ((1u << (c_hi > 0 ? c_hi : 0)) - 1u);
+            vm &= ~((1u << c_lo) - 1u);
 #pragma unroll
-            for (int c = 0; c < CSTRIP; c++) {
-                const int o = o0 + c;
-                if (o >= 0 && o < L && x0r + c <= xlr) {
-                    const int wj = o >> 5;
-                    const uint64_t word = wj == w0 ? wa : wb;
-                    const int v = pc_to_idx((int)((word >> (2 * (o & 31))) & 3));
-                    cnt[c][0] += (v == 0); cnt[c][1] += (v == 1); cnt[c][2] += (v == 2); cnt[c][3] += (v == 3);
-                }
-            }
+            for (int c = 0; c < CSTRIP; c++) pk[c] += ((vm >> c) & 1u) << (8u * ((bits >> (2 * c)) & 3u));
+            if (++since == 255) flush();
         }
     }
+    flush();
     if (!mine) return;
     uint32_t kprev = HARC_NONE; unsigned long long cend = 0; bool lastc = true;
     long long i = ilast;
@@ -294,10 +308,12 @@ __device__ __forceinline__ uint64_t rc_key3(uint64_t key, int n)
 // consensus share it, and k_realign_propose1 looks up 3.6 G consecutive k-mers at configs[2] -- else hashed from the key.  (A 10-mer
 // minimizer compared as it is: every value occurs hundreds of times in a genome, the lines of a 26x data set were saturated.)  Word and
 // the two 4-bit entries inside the line come from a hash of the whole key.
+#ifndef BLOOM4_M
 #define BLOOM4_M 15
+#endif
 __device__ __forceinline__ uint32_t bloom4_mmer(uint64_t key)
 {
-    uint32_t h = ((uint32_t)key * 0x9E3779B1u) ^ (((uint32_t)(key >> 32) & 0x1FFFu) * 0x85EBCA77u);      // the low 45 bits: 15 bases
+    uint32_t h = ((uint32_t)key * 0x9E3779B1u) ^ (((uint32_t)(key >> 32) & ((1u << (3 * BLOOM4_M - 32)) - 1u)) * 0x85EBCA77u);      // the low 3 M bits: M bases
     return h ^ (h >> 15);
 }
 __device__ __forceinline__ uint32_t bloom4_minimizer(uint64_t key, int nwin)
