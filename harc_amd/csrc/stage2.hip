@@ -435,6 +435,7 @@ template <int W, int NWIN> __global__ __launch_bounds__(256) void k_realign_prop
 {
     __shared__ uint32_t tile32[(RTILE + 64 + 8) / 4];
     __shared__ uint16_t queue[RQCAP];
+    __shared__ uint2 lookup[RTILE];                               // per column: word of the bitmap, the two 4-bit fields inside it
     __shared__ unsigned int qn;
     uint8_t *tile = reinterpret_cast<uint8_t *>(tile32);
     const uint64_t X0 = (uint64_t)blockIdx.x * RTILE;
@@ -462,29 +463,34 @@ template <int W, int NWIN> __global__ __launch_bounds__(256) void k_realign_prop
         mm[c] = bloom4_mmer(k);
         k = (k >> 3) | ((uint64_t)idx_to_c3(tile[t0 + c + n] & 3) << (3 * (n - 1)));
     }
-    // the 8 bitmap words (independent loads)
-    uint32_t hit = 0;
+    // where the key of every column of the strip sits in the bitmap ...
 #pragma unroll
     for (int c = 0; c < RSTRIP; c++) {
-        if (X0 + t0 + c < s.total) {
-            uint32_t mz = 0xFFFFFFFFu;
+        uint32_t mz = 0xFFFFFFFFu;
 #pragma unroll
-            for (int i = 0; i < NWIN; i++) mz = mm[c + i] < mz ? mm[c + i] : mz;
-            uint32_t w; int a, b;
-            bloom4_pos(keys[c], mz, NWIN, lbits, &w, &a, &b);
-            const uint32_t v = bloom[w];
-            hit |= ((v >> a) & (v >> b) & 15u) << (4 * c);
-        }
+        for (int i = 0; i < NWIN; i++) mz = mm[c + i] < mz ? mm[c + i] : mz;
+        uint32_t w; int a, b;
+        bloom4_pos(keys[c], mz, NWIN, lbits, &w, &a, &b);
+        lookup[t0 + c] = make_uint2(w, (uint32_t)a | ((uint32_t)b << 8));
     }
-    // the rare hits go through a queue in LDS and are worked off one per lane (inline, a wave would wait for its unluckiest lane's
-    // chain of dependent loads while the other 63 idle)
+    __syncthreads();
+    // ... and the lookups TRANSPOSED: lane i of a wave takes column 64 q + i, so that the ~4 consecutive columns that share a minimizer -- and
+    // with it a 64-byte line of the bitmap -- are neighbouring lanes of ONE load instead of four loads of one lane (a quarter of the requests
+    // to L2: the kernel made 3.9 G of them per launch at configs[2], 1.07 G missing).  The rare hits go through a queue in LDS and are worked
+    // off one per lane (inline, a wave would wait for its unluckiest lane's chain of dependent loads while the other 63 idle)
+#pragma unroll
     for (int c = 0; c < RSTRIP; c++) {
-        uint32_t m = (hit >> (4 * c)) & 15u;
-        while (m) {
-            const int p = __builtin_ctz(m); m &= m - 1;
-            const unsigned int at = atomicAdd(&qn, 1u);
-            if (at < RQCAP) queue[at] = (uint16_t)((t0 + c) | (p << 12));
-            else realign_hit1<W>(s, tile, X0, t0 + c, p, n);
+        const int col = c * 256 + (int)threadIdx.x;
+        if (X0 + col < s.total) {
+            const uint2 lk = lookup[col];
+            const uint32_t v = bloom[lk.x];
+            uint32_t m = (v >> (lk.y & 0xFFu)) & (v >> (lk.y >> 8)) & 15u;
+            while (m) {
+                const int p = __builtin_ctz(m); m &= m - 1;
+                const unsigned int at = atomicAdd(&qn, 1u);
+                if (at < RQCAP) queue[at] = (uint16_t)(col | (p << 12));
+                else realign_hit1<W>(s, tile, X0, col, p, n);
+            }
         }
     }
     __syncthreads();
