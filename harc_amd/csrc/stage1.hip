@@ -35,6 +35,8 @@ struct S1Args {
     uint32_t *needrank;              // [K] rank of a chain among those that want a seed (k_reseed -> the next k_steps, which applies the seed)
     uint32_t *rmeta;                 // [4] k_reseed's result: chains that wanted a seed, seeds found, look-ahead seeds found
     uint32_t own_mod, own_rem;       // design (R), chains partitioned over the ranks of a multi-GPU run: this rank walks the chains c with (c >> 2) % own_mod == own_rem (own_mod <= 1: all)
+    uint32_t reseed_stress;          // tests (HARC_AMD_RESEED_STRESS): the odd workgroups of k_reseed_mg sleep this many times after every meeting; changes nothing but the timing
+    uint32_t reseed_win;             // words of the claim bitmap one pass of k_reseed_mg looks at: RESEED_G * RESEED_NT (tests, HARC_AMD_RESEED_WIN: fewer, so that small inputs take several passes; same seeds)
     unsigned int *reseed_g;          // k_reseed_mg: meeting counter, flag, per-workgroup counts (k_resolve zeroes the first two words every round)
     uint2 *cst2;                     // per chain: x seeds taken (= unmatched reads, reorder.cpp:701), y lost bids
     uint32_t *sugg;                  // [K][HARC_NSUGG] look-ahead seeds of every chain, highest id first
@@ -1324,6 +1326,24 @@ __global__ void k_unpack_chains(S1Args s, const uint32_t *buf, uint32_t nper)
     }
 }
 
+// What every rank of a design-(R) run must agree on after a super-round, folded into a few words (sums of per-element mixes, so the order of
+// the additions does not matter): [0] claim bitmap [1] chain headers [2] chains that asked for a seed [3] cursor [4..6] what k_reseed handed out.
+// The host compares them over the ranks after every batch of super-rounds: replicas that drift apart would otherwise hang in the next
+// all-gather or end with a wrong archive.
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) v += shfl_u64(v, (__lane_id() + o) & 63); return v; }
+__device__ __forceinline__ unsigned long long digest_mix(unsigned long long x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; return x ^ (x >> 33); }
+__global__ void k_replica_digest(S1Args s, unsigned long long nwords, unsigned long long *out)
+{
+    const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long a = 0, b = 0, d = 0;
+    for (unsigned long long i = gid; i < nwords; i += nth) { const unsigned long long w = s.claimed[i]; if (w) a += digest_mix(w ^ (i * 0x9E3779B97F4A7C15ULL)); }
+    for (unsigned long long i = gid; i < (unsigned long long)s.K * 8; i += nth) b += digest_mix((unsigned long long)reinterpret_cast<const uint32_t *>(s.hdr)[i] ^ (i * 0x9E3779B97F4A7C15ULL));
+    for (unsigned long long i = gid; i < s.K; i += nth) if (s.need[i]) d += digest_mix(i + 1);
+    a = wave_sum_u64(a); b = wave_sum_u64(b); d = wave_sum_u64(d);
+    if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&out[0], a); if (b) atomicAdd(&out[1], b); if (d) atomicAdd(&out[2], d); }
+    if (gid == 0) { out[3] = (unsigned long long)*s.cursor; out[4] = s.rmeta[0]; out[5] = s.rmeta[1]; out[6] = s.rmeta[2]; }
+}
+
 // (B) G lanes per chain (G = 16/32/64 >= S), lane t of the group = step t of the super-round
 template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
 {
@@ -1500,10 +1520,13 @@ template <int NT> __global__ __launch_bounds__(NT) void k_reseed(S1Args s)
 // 64 workgroups on 256 CUs): once after counting (chains that want a seed per workgroup + unclaimed reads per workgroup's words; more
 // passes, one meeting each, only when a million bits below the cursor do not hold enough unclaimed reads), once for the look-ahead; the
 // read id where the seeds end travels through a flag.  What is computed is the single workgroup's result (the oracle's), id for id.
-// g = [0] meeting counter [1] flag: 2 + cursor after the seeds [2..3] unused [4 .. 4+3G) per workgroup: chains wanting a seed, unclaimed
-// reads of the pass, unclaimed reads of the look-ahead window.  k_resolve zeroes g[0..1] before every launch.
+// g = [0] meeting counter [1] flag: 2 + cursor after the seeds [2..3] unused [4 .. 4+4G) per workgroup: chains wanting a seed, unclaimed
+// reads of the pass (two sets, even and odd passes), unclaimed reads of the look-ahead window.  k_resolve zeroes g[0..1] before every launch.
 #define RESEED_NT 256
 #define RESEED_G 64
+#ifndef RESEED_ONE_SET
+#define RESEED_ONE_SET 0
+#endif
 __device__ __forceinline__ void grid_meet(unsigned int *cnt, unsigned int target)
 {
     __syncthreads();
@@ -1522,7 +1545,7 @@ __global__ __launch_bounds__(RESEED_NT) void k_reseed_mg(S1Args s, unsigned int 
     __shared__ uint32_t spre[3][G + 1];
     const int t = threadIdx.x, b = blockIdx.x;
     const uint32_t gid = (uint32_t)b * NT + (uint32_t)t;
-    unsigned int *const gA = g + 4, *const gB = g + 4 + G, *const gC = g + 4 + 2 * G;
+    unsigned int *const gA = g + 4, *const gB0 = g + 4 + G, *const gC = g + 4 + 3 * G;
     unsigned int meet = 0;
     // chains per thread, contiguous and a multiple of 8 so that the need bytes are read as 64-bit words (the array is padded with zeros)
     const uint32_t chunk = (((s.K + G * NT - 1) / (G * NT)) + 7) & ~7u;
@@ -1534,19 +1557,24 @@ __global__ __launch_bounds__(RESEED_NT) void k_reseed_mg(S1Args s, unsigned int 
     long long top = cursor0;                                       // the pass looks at the G * NT words from the word of `top` downwards
     uint32_t R = 0, assigned = 0;
     long long look = -1;
-    for (int pass = 0;; pass++) {
+    int pass = 0;
+    for (;; pass++) {
         const long long cwd = top >> 6, wi = cwd - (long long)gid;
         unsigned long long bits = 0;
-        if (top >= 0 && wi >= 0) {
+        if (top >= 0 && wi >= 0 && gid < s.reseed_win) {
             bits = ~s.claimed[wi];
             if (wi == cwd) { const int tb = (int)(top & 63); if (tb < 63) bits &= (2ULL << tb) - 1ULL; }
         }
         uint32_t totB; const uint32_t offB = block_excl_scan_u32<NT>((uint32_t)__popcll(bits), sm, &totB);
+        // two sets of per-workgroup counts, by the parity of the pass: a workgroup that is already counting pass p + 1 must not overwrite what
+        // a slower one still has to read of pass p (it cannot get further ahead than that: the next meeting waits for everybody)
+        unsigned int *const gB = gB0 + (RESEED_ONE_SET ? 0 : (pass & 1)) * G;
         if (t == 0) {
             if (pass == 0) __hip_atomic_store(gA + b, totA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gB + b, totB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         grid_meet(g, (unsigned int)G * ++meet);
+        if (s.reseed_stress && (b & 1)) for (uint32_t i = 0; i < s.reseed_stress; i++) __builtin_amdgcn_s_sleep(127);     // tests: late readers of the counts
         if (t < 64) {                                              // one wave: prefix sums over the workgroups
             const uint32_t va = (pass == 0 && t < G) ? __hip_atomic_load(gA + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             const uint32_t vb = t < G ? __hip_atomic_load(gB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -1586,7 +1614,7 @@ __global__ __launch_bounds__(RESEED_NT) void k_reseed_mg(S1Args s, unsigned int 
             break;
         }
         assigned += total;
-        top = (cwd - (long long)G * NT + 1) * 64 - 1;              // below the words of this pass
+        top = (cwd - (long long)s.reseed_win + 1) * 64 - 1;        // below the words of this pass
         if (top < 0) { look = -1; break; }                         // the bitmap is exhausted: the remaining chains finish
         __syncthreads();
     }
@@ -1626,7 +1654,7 @@ __global__ __launch_bounds__(RESEED_NT) void k_reseed_mg(S1Args s, unsigned int 
     }
     // the chains take their seeds themselves at the top of the next k_steps (rank -> seedbuf)
     if (gid == 0) {
-        s.rmeta[0] = R; s.rmeta[1] = assigned; s.rmeta[2] = got;
+        s.rmeta[0] = R; s.rmeta[1] = assigned; s.rmeta[2] = got; s.rmeta[3] += (uint32_t)pass;     // [3]: passes beyond the first, whole run (trace)
         if (got == 0) *s.cursor = cursor < -1 ? -1 : cursor;
     }
 }
@@ -1885,7 +1913,7 @@ struct S1Resources {
     {
         for (auto &x : e) HIP_TRY(hipEventCreate(&x));
         for (auto &x : eb) HIP_TRY(hipEventCreate(&x));
-        HIP_TRY(hipHostMalloc((void **)&h_stats, (ST_N + HARC_COOPCNT) * 8));
+        HIP_TRY(hipHostMalloc((void **)&h_stats, (ST_N + HARC_COOPCNT + 8) * 8));
         return HARC_AMD_OK;
     }
     // the pair for the next launch; its previous use (RING launches ago) is read first
@@ -2028,7 +2056,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const uint32_t nblk = (K + 255) / 256;
     RC_TRY(dalloc(c, &a.claimed, nwords)); RC_TRY(dalloc(c, &a.bid, (size_t)N + 1)); RC_TRY(dalloc(c, &a.hdr, K));
     RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.steps, (size_t)K * 64)); RC_TRY(dalloc(c, &a.need, (size_t)K + 8192 + 1024));
-    RC_TRY(dalloc(c, &a.reseed_g, 4 + 3 * RESEED_G)); HIP_TRY(hipMemsetAsync(a.reseed_g, 0, (4 + 3 * RESEED_G) * 4, c->stream));
+    RC_TRY(dalloc(c, &a.reseed_g, 4 + 4 * RESEED_G)); HIP_TRY(hipMemsetAsync(a.reseed_g, 0, (4 + 4 * RESEED_G) * 4, c->stream));
     RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + HARC_NSUGG))); RC_TRY(dalloc(c, &a.needrank, (size_t)K + 16)); RC_TRY(dalloc(c, &a.rmeta, 4)); RC_TRY(dalloc(c, &a.cst2, (size_t)K + 1)); RC_TRY(dalloc(c, &a.sugg, (size_t)K * HARC_NSUGG));
     RC_TRY(dalloc(c, &a.log, (size_t)N + 1));
     RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N)); RC_TRY(dalloc(c, &a.coopcnt, HARC_COOPCNT)); HIP_TRY(hipMemsetAsync(a.coopcnt, 0, HARC_COOPCNT * 8, c->stream));
@@ -2074,7 +2102,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge, (const uint32_t *)d_sz0);
     if (nhuge) hipLaunchKernelGGL((k_compact_huge<W>), dim3(nhuge), dim3(1024), 0, c->stream, a, (const unsigned long long *)d_large, (const uint32_t *)d_huge, nhuge);
     // ---- rounds
-    uint32_t *x_send = nullptr, *x_recv = nullptr; uint32_t x_nper = 0; size_t x_bytes = 0;
+    uint32_t *x_send = nullptr, *x_recv = nullptr; uint32_t x_nper = 0; size_t x_bytes = 0; unsigned long long *x_dig = nullptr;
     std::vector<size_t> x_so, x_sb, x_ro, x_rb;
     if (cm) {
         x_nper = ((((K + 3) / 4) + a.own_mod - 1) / a.own_mod) * 4;                 // chains of one rank's block
@@ -2082,6 +2110,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         RC_TRY(dalloc(c, &x_send, x_bytes / 4 + 4)); RC_TRY(dalloc(c, &x_recv, (x_bytes / 4) * a.own_mod + 4));
         x_so.assign(a.own_mod, 0); x_sb.assign(a.own_mod, x_bytes); x_ro.resize(a.own_mod); x_rb.assign(a.own_mod, x_bytes);
         for (uint32_t p = 0; p < a.own_mod; p++) x_ro[p] = (size_t)p * x_bytes;
+        RC_TRY(dalloc(c, &x_dig, 8));
     }
     const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe);
     const bool prof = P.profile != 0;
@@ -2108,6 +2137,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const int batch = getenv("HARC_AMD_BATCHSYNC") ? atoi(getenv("HARC_AMD_BATCHSYNC")) : 8;
     // k_reseed by 64 workgroups once a single one has thousands of seeds to hand out per round (HARC_AMD_RESEED_MG=0/1 forces either; same result)
     const bool reseed_mg = getenv("HARC_AMD_RESEED_MG") ? atoi(getenv("HARC_AMD_RESEED_MG")) != 0 : K > 4096;
+    a.reseed_win = RESEED_G * RESEED_NT;
+    if (const char *e = getenv("HARC_AMD_RESEED_WIN")) { const int x = atoi(e); if (x >= 1 && x <= RESEED_G * RESEED_NT) a.reseed_win = (uint32_t)x; }     // same seeds, more passes
+    if (const char *e = getenv("HARC_AMD_RESEED_STRESS")) { const int x = atoi(e); a.reseed_stress = x < 0 ? 0u : x > 1000 ? 1000u : (uint32_t)x; }     // delays only
     for (;;) {
         if (seq_probe < 2) { seq = seq_probe == 0; HIP_TRY(hipEventRecord(R.eb[0], c->stream)); }
         for (int r = 0; r < batch; r++) {
@@ -2147,14 +2179,36 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         if (seq_probe < 2) HIP_TRY(hipEventRecord(R.eb[1], c->stream));
         HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
         if (nlarge) HIP_TRY(hipMemcpyAsync(h_stats + ST_N, a.coopcnt, HARC_COOPCNT * 8, hipMemcpyDeviceToHost, c->stream));
-        if (cm) RC_TRY(cm->wait(c, "all-gather of the walked steps"));      // a peer that died shows as a timeout, not as a hang
+        if (cm) {
+            HIP_TRY(hipMemsetAsync(x_dig, 0, 8 * 8, c->stream));
+            hipLaunchKernelGGL(k_replica_digest, dim3(1024), dim3(256), 0, c->stream, a, (unsigned long long)nwords, x_dig);
+            HIP_TRY(hipMemcpyAsync(h_stats + ST_N + HARC_COOPCNT, x_dig, 8 * 8, hipMemcpyDeviceToHost, c->stream));
+            RC_TRY(cm->wait(c, "all-gather of the walked steps"));          // a peer that died shows as a timeout, not as a hang
+        }
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
+        if (cm) {   // the replicas must agree (k_replica_digest): a rank that drifted would hang the others in the next all-gather, or worse
+            uint64_t mine[8], all[8 * 64];
+            if (a.own_mod > 64) { harc_set_error("design (R): at most 64 ranks"); return HARC_AMD_EINVAL; }
+            for (int k = 0; k < 7; k++) mine[k] = h_stats[ST_N + HARC_COOPCNT + k];
+            mine[7] = h_stats[ST_ACTIVE];
+            RC_TRY(cm->allgather_u64(c, mine, 8, all));
+            static const char *const what[8] = { "claim bitmap", "chain headers", "chains asking for a seed", "cursor", "seeds wanted", "seeds handed out", "look-ahead seeds", "chains alive" };
+            for (uint32_t p = 0; p < a.own_mod; p++) for (int k = 0; k < 8; k++) if (all[(size_t)p * 8 + k] != all[k]) {
+                harc_set_error("design (R): the replicas of rank 0 and rank %u differ after super-round %llu (%s: %llx / %llx)", p, (unsigned long long)rounds, what[k],
+                               (unsigned long long)all[k], (unsigned long long)all[(size_t)p * 8 + k]);
+                return HARC_AMD_EINTERNAL;
+            }
+        }
         if (seq_probe < 2) {
             HIP_TRY(hipEventElapsedTime(&seq_ms[seq_probe], R.eb[0], R.eb[1]));
             if (++seq_probe == 2) seq = seq_ms[0] < seq_ms[1];
         }
-        if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] round %llu: %llu chains alive%s\n", (unsigned long long)rounds, h_stats[ST_ACTIVE], seq ? " (wave-uniform scan)" : "");
+        if (getenv("HARC_AMD_TRACE")) {
+            uint32_t rm[4] = { 0, 0, 0, 0 };
+            HIP_TRY(hipMemcpy(rm, a.rmeta, 16, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[stage I] round %llu: %llu chains alive%s; extra passes of k_reseed_mg so far %u\n", (unsigned long long)rounds, h_stats[ST_ACTIVE], seq ? " (wave-uniform scan)" : "", rm[3]);
+        }
         if (h_stats[ST_ACTIVE] == 0) break;
         if (nlarge && coop_forced == 0) {
             // cooperative walks per super-round over the last rounds against the workgroups of four waves the chip holds (4 per CU): well beyond
@@ -2182,6 +2236,25 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     HIP_TRY(hipMemcpyAsync(&M, bmain + K, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&S, bsing + K, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (getenv("HARC_AMD_DIAG")) {     // bookkeeping post-mortem: the reads without a record, what the bitmap, the bids and the chain headers say about them
+        std::vector<LogRec> hl(nlog); std::vector<unsigned long long> hc(nwords); std::vector<uint32_t> hb((size_t)N + 1); std::vector<ChainHdr> hh(K);
+        HIP_TRY(hipMemcpy(hl.data(), a.log, nlog * sizeof(LogRec), hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(hc.data(), a.claimed, nwords * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hb.data(), a.bid, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(hh.data(), a.hdr, (size_t)K * sizeof(ChainHdr), hipMemcpyDeviceToHost));
+        unsigned long long nbad = 0, nunclaimed = 0, nact = 0, npend = 0;
+        for (uint32_t k = 0; k < K; k++) { if (hh[k].flags & CH_ACTIVE) nact++; if (hh[k].flags & CH_PREVUNM) npend++; }
+        for (unsigned long long i = 0; i < nlog; i++) {
+            if (hl[i].chain < K && hl[i].rid == (uint32_t)i) continue;
+            const bool cl = (hc[i >> 6] >> (i & 63)) & 1ULL;
+            if (!cl) nunclaimed++;
+            if (nbad++ < 24) {
+                long long own = -1, ownc = -1;
+                for (uint32_t k = 0; k < K; k++) { if (hh[k].prev == (uint32_t)i) own = k; if (hh[k].cur == (uint32_t)i) ownc = k; }
+                fprintf(stderr, "[diag rank %u] read %llu: no record (log chain %x rid %x); claimed %d bid %x; header with prev = it: %lld (flags %x) cur = it: %lld\n", a.own_rem, i, hl[i].chain, hl[i].rid,
+                        (int)cl, hb[i], own, own >= 0 ? hh[own].flags : 0u, ownc);
+            }
+        }
+        fprintf(stderr, "[diag rank %u] %llu reads without a record, %llu of them unclaimed; M %u S %u N %u; chains active %llu, with a pending seed %llu; cursor/rounds %llu\n", a.own_rem, nbad, nunclaimed, M, S, N, nact, npend, (unsigned long long)rounds);
+    }
     if ((unsigned long long)M + S != nlog) { harc_set_error("stage I bookkeeping: M=%u S=%u N=%u", M, S, N); return HARC_AMD_EINTERNAL; }
     c->M = M; c->S = S;
     unsigned long long *d_bad = a.stats + ST_N - 1;               // last statistics word: records that nobody wrote

@@ -103,3 +103,24 @@ def test_parity_fuzz_bounded(it, oracle, tmp_path):
     assert not bad, f"fuzz {it} (L={L} reads={nreads} K={K} S={S} E={E}): stage II {bad}"
     harc_amd.decoder(bg, E)
     assert sorted(ol.read_dir(bg)["output.dna"].split()) == sorted(txt.split())
+
+
+def test_reseed_by_many_workgroups_with_late_readers(monkeypatch):
+    """k_reseed_mg (64 workgroups that meet at a counter) when a launch needs SEVERAL passes over the claim bitmap and half of the workgroups
+    read the per-pass counts late: the same streams as the single workgroup.  HARC_AMD_RESEED_WIN narrows a pass to 2048 words so that 4 M reads
+    take extra passes; HARC_AMD_RESEED_STRESS only delays the odd workgroups.  (With ONE set of per-pass counts a workgroup already counting
+    pass p + 1 overwrote what a delayed one still had to read of pass p: seeds handed out twice or never, `reads were never emitted` -- seen
+    with three ranks sharing a GPU on 100 M reads, where other processes' kernels delay workgroups by themselves.)"""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from tests.test_gpu_replicate import _one_gpu
+    n, K = 4_000_000, 16384
+    arr = bench.synth_reads(n, 100, int(n * 100 / 26), 0.005, 5, torch.device("cuda", 0)).cpu().numpy()
+    monkeypatch.setenv("HARC_AMD_RESEED_MG", "0")
+    want, cw = _one_gpu(arr, 100, 2, K, 16)
+    monkeypatch.setenv("HARC_AMD_RESEED_MG", "1"); monkeypatch.setenv("HARC_AMD_RESEED_WIN", "2048"); monkeypatch.setenv("HARC_AMD_RESEED_STRESS", "5")
+    got, cg = _one_gpu(arr, 100, 2, K, 16)
+    bad = [k for k in want if got[k] != want[k]]
+    assert not bad, bad
+    assert cg.rounds == cw.rounds and cg.n_main == cw.n_main

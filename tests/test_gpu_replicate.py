@@ -76,6 +76,22 @@ def _ranks(world, slices, L, E, K, S, mbox):
     return res
 
 
+def test_replicated_ranks_large_run_kernels(tmp_path, monkeypatch):
+    """three ranks with the kernels of a run of hundreds of millions of reads forced (dense launch, wave-uniform scan, k_reseed by 64 workgroups with
+    narrowed passes and delayed workgroups) == one GPU with the plain ones; the per-batch digest check of the replicas runs on the way"""
+    import numpy as np
+    os.environ["HARC_AMD_MAILBOX_TIMEOUT"] = "180"
+    arr = gen.reads_array(411, 300000, 100, 1200000, err=0.01)
+    want, cw = _one_gpu(arr, 100, 2, 6000, 16)
+    for k, v in {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_RESEED_MG": "1", "HARC_AMD_RESEED_WIN": "256", "HARC_AMD_RESEED_STRESS": "3"}.items():
+        monkeypatch.setenv(k, v)
+    res = _ranks(3, shard_model.slices_of(arr, 3), 100, 2, 6000, 16, str(tmp_path))
+    for r in range(3):
+        bad = [k for k in want if res[r]["files"][k] != want[k]]
+        assert not bad, (r, bad)
+        assert res[r]["counters"].rounds == cw.rounds
+
+
 @pytest.mark.parametrize("world,n,L,err,E,K,S,lowc", [(2, 30000, 100, 0.01, 2, 9, 16, False), (3, 24000, 100, 0.02, 1, 0, 16, False), (2, 9000, 150, 0.01, 1, 64, 8, False),
                                                        (3, 20000, 100, 0.004, 3, 24, 16, True), (2, 5000, 100, 0.0, 1, 1, 16, False)])
 def test_replicated_ranks_equal_one_gpu(world, n, L, err, E, K, S, lowc, tmp_path):
