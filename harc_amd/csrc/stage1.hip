@@ -1525,7 +1525,7 @@ template <int NT> __global__ __launch_bounds__(NT) void k_reseed(S1Args s)
 #define RESEED_NT 256
 #define RESEED_G 64
 #ifndef RESEED_ONE_SET
-#define RESEED_ONE_SET 0
+#define RESEED_ONE_SET 0     // 1 (make variant VFLAGS=-DRESEED_ONE_SET=1): the race of round 3 back in, to see tests/test_gpu_config_size.py's stress test fail
 #endif
 __device__ __forceinline__ void grid_meet(unsigned int *cnt, unsigned int target)
 {
