@@ -5,7 +5,7 @@
 // the super-round-synchronous K-chain x S-step schedule of DESIGN.md: k_steps (one 64-lane wave per chain, the (shift,
 // direction, dictionary) probes of a chain step spread over the lanes, priority = lane order, up to S steps per launch with
 // the consensus counts in registers), k_resolve (smallest (step, chain) bid wins a read), k_reseed (one global descending
-// cursor, reorder.cpp:652-668).  updaterefcount :863-915 -> cons_update inside k_steps.  writetofile :722-830 -> k_s1_scatter (+ k_orient for the in-HBM hand-over to stage II).
+// cursor, reorder.cpp:652-668).  updaterefcount :863-915 -> cons_update inside k_steps.  writetofile :722-830 -> k_pages_out, k_s1_singles (+ k_orient for the in-HBM hand-over to stage II).
 //
 // Integer / HBM-latency bound; no MFMA.  Wave = 64 everywhere.
 #include "devutil.h"
@@ -42,7 +42,14 @@ struct S1Args {
     uint32_t *sugg;                  // [K][HARC_NSUGG] look-ahead seeds of every chain, highest id first
     int S;                           // speculative steps per super-round (1..64)
     int nsugg_per_seed;              // look-ahead seeds per reseed (HARC_NSUGG; 0 disables them: experiments only, the oracle uses the same value)
-    LogRec *log;                     // [N] indexed by read id: every read is emitted exactly once, by exactly one chain
+    uint2 *slog;                     // [N] indexed by read id: {chain, index in the chain's singleton stream} of the reads that end as singletons (0xFF..: not one)
+    // the main stream of a chain, in PAGES of 64 records {read id, pos | flag<<8 | rc<<9}: k_resolve appends the records a chain keeps in a super-round
+    // side by side (up to 2 S records, one or two lines) instead of one 16-byte record per read at log[read id]; pages come from one counter, and
+    // k_pages_out copies page after page to the chain's place in the output, coalesced on both sides
+    uint2 *pg_rec;                   // [pages][64]
+    uint2 *pg_hdr;                   // per page: {chain, number of the page inside the chain}
+    uint32_t *pg_cur;                // per chain: the first page of its newest chunk (pages c * PG_CHUNK .. are chain c's first)
+    unsigned int *pg_count;          // pages handed out (PG_CHUNK at a time)
     long long *cursor;               // reorder.cpp `remainingpos`, one for all chains
     unsigned long long *coopcnt;     // [HARC_COOPCNT] walks handed to the cooperative kernel so far (the host picks its workgroup size from them)
     unsigned long long *stats;       // [0] unmatched [1] conflicts [2] active chains [3] probes [4] candidates
@@ -54,6 +61,7 @@ struct S1Args {
     uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups, w sequential-equivalent candidates
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
 };
+#define PG_CHUNK 8u
 #ifdef HARC_TIMING
 #define TICK(k) do { const long long tn_ = clock64(); tacc[k] += (unsigned long long)(tn_ - tlast); tlast = tn_; } while (0)
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(v, o, 64); v = x > v ? x : v; } return v; }
@@ -363,6 +371,9 @@ __global__ void k_init_chains(S1Args s)
     s.hdr[c] = h;
     s.cst2[c] = make_uint2(act ? 1u : 0u, 0u);
     s.need[c] = 0;
+    s.pg_cur[c] = c * PG_CHUNK;
+    for (uint32_t k = 0; k < PG_CHUNK; k++) s.pg_hdr[(size_t)c * PG_CHUNK + k] = make_uint2(c, k);
+    if (c == 0) *s.pg_count = s.K * PG_CHUNK;
 }
 
 // consensus state of one chain, spread over the wave: lane owns ring slots p = lane + 64 t (t < CT); the slot holding
@@ -856,7 +867,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         // the chain asked for a seed last super-round and k_reseed ranked it: take seed number `rank` (reorder.cpp:650-688), or finish
         const uint32_t r = s.needrank[c], R = s.rmeta[0], assigned = s.rmeta[1], got = s.rmeta[2];
         if (h.flags & CH_PREVUNM) {                               // previous seed found nothing: singleton (reorder.cpp:672-684)
-            if (lane == 0) { LogRec rec; rec.chain = c; rec.seq = h.n_sing; rec.rid = h.prev; rec.meta = 1u << 10; s.log[h.prev] = rec; }
+            if (lane == 0) s.slog[h.prev] = make_uint2(c, h.n_sing);
             h.n_sing++;
         }
         if (r < assigned) {
@@ -1275,7 +1286,7 @@ __global__ void k_apply_seed(S1Args s)
     if (!(h.flags & CH_ACTIVE) || !s.need[c]) return;
     const uint32_t r = s.needrank[c], R = s.rmeta[0], assigned = s.rmeta[1], got = s.rmeta[2];
     if (h.flags & CH_PREVUNM) {                                   // previous seed found nothing: singleton (reorder.cpp:672-684)
-        LogRec rec; rec.chain = c; rec.seq = h.n_sing; rec.rid = h.prev; rec.meta = 1u << 10; s.log[h.prev] = rec;
+        s.slog[h.prev] = make_uint2(c, h.n_sing);
         h.n_sing++;
     }
     if (r < assigned) {
@@ -1364,10 +1375,12 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
     unsigned long long lost = __ballot(sl < n && !mineb);
     if (G < 64) lost = (lost >> g0) & ((1ULL << (G & 63)) - 1ULL);
     const int v = lost ? (__ffsll((long long)lost) - 1) : n;     // steps kept: those before the first lost bid
-    if (mineb) s.bid[sp.x] = HARC_NONE;                          // every bid this chain holds is withdrawn, kept or not
     const bool cut = v < n;
     // what every kept step emits (reorder.cpp:560-578 for a match, :678-687 for a new seed)
     const bool kept = sl < v;
+    // a bid held for a step behind the cut is withdrawn; the read of a kept step is claimed below and nobody bids for a claimed read again, so
+    // its bid stays where it is (one random write less per kept step: most of them)
+    if (mineb && !kept) s.bid[sp.x] = HARC_NONE;
     const bool seedk = kept && ((sp.y >> 16) & 1);
     const uint32_t pkind = __shfl_up((uint32_t)seedk, 1, 64), prid = __shfl_up(sp.x, 1, 64);
     const bool punm = sl == 0 ? ((h.flags & CH_PREVUNM) != 0) : (pkind != 0);      // a seed is pending before this step
@@ -1377,21 +1390,39 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
     uint32_t tm, ts;
     const uint32_t em = wave_excl_scan_u32(nm, &tm), es = wave_excl_scan_u32(ns, &ts);
     const uint32_t em0 = __shfl(em, g0, 64), es0 = __shfl(es, g0, 64);
-    if (kept) {                                                   // the record of a read lives at log[read id]: no shared counter
-        atomicOr(&s.claimed[sp.x >> 6], 1ULL << (sp.x & 63));
-        if (seedk) {
-            if (punm) { LogRec r; r.chain = c; r.seq = h.n_sing + (es - es0); r.rid = pid; r.meta = 1u << 10; s.log[pid] = r; }
-        } else {
-            uint32_t seq = h.n_main + (em - em0);
-            if (punm) { LogRec r; r.chain = c; r.seq = seq++; r.rid = pid; r.meta = (uint32_t)(s.L & 0xFF); s.log[pid] = r; }   // the pending seed opens a contig
-            LogRec r; r.chain = c; r.seq = seq; r.rid = sp.x;
-            r.meta = (sp.y & 0xFF) | (1u << 8) | (((sp.y >> 8) & 1u) << 9);
-            s.log[sp.x] = r;
-        }
-    }
     // group totals and the last kept step
     const int lastl = g0 + (v > 0 ? v - 1 : 0);
     const uint32_t gm = __shfl(em + nm, lastl, 64) - em0, gs = __shfl(es + ns, lastl, 64) - es0;
+    // the pages the chain's gm new main records go to: its newest page holds record (n_main - 1), new ones come from the counter
+    // (pages are handed out PG_CHUNK at a time: one atomic on the shared counter per 512 records of a chain -- one per page was 14 000 atomics on
+    // one address per super-round at configs[2] and doubled this kernel's time)
+    uint32_t pcur = 0, pnew = 0, qcur = 0;
+    if (act && sl == 0 && v > 0 && gm > 0) {
+        pcur = s.pg_cur[c];                                       // first page of the chunk that holds record n_main - 1
+        qcur = ((h.n_main ? h.n_main - 1u : 0u) >> 6) / PG_CHUNK; // number of that chunk inside the chain
+        const uint32_t qlast = ((h.n_main + gm - 1u) >> 6) / PG_CHUNK;      // at most the next one: 2 S <= 128 records a round, 512 a chunk
+        if (qlast != qcur) {
+            pnew = atomicAdd(s.pg_count, (unsigned int)PG_CHUNK);
+            for (uint32_t k = 0; k < PG_CHUNK; k++) s.pg_hdr[pnew + k] = make_uint2(c, qlast * PG_CHUNK + k);
+            s.pg_cur[c] = pnew;
+        }
+    }
+    pcur = __shfl(pcur, g0, 64); pnew = __shfl(pnew, g0, 64); qcur = __shfl(qcur, g0, 64);
+    if (kept) {
+        atomicOr(&s.claimed[sp.x >> 6], 1ULL << (sp.x & 63));
+        if (seedk) {
+            if (punm) s.slog[pid] = make_uint2(c, h.n_sing + (es - es0));
+        } else {
+            uint32_t seq = h.n_main + (em - em0);
+            if (punm) {                                           // the pending seed opens a contig
+                const uint32_t pn = seq >> 6, pg = (pn / PG_CHUNK == qcur ? pcur : pnew) + pn % PG_CHUNK;
+                s.pg_rec[(size_t)pg * 64 + (seq & 63u)] = make_uint2(pid, (uint32_t)(s.L & 0xFF));
+                seq++;
+            }
+            const uint32_t pn = seq >> 6, pg = (pn / PG_CHUNK == qcur ? pcur : pnew) + pn % PG_CHUNK;
+            s.pg_rec[(size_t)pg * 64 + (seq & 63u)] = make_uint2(sp.x, (sp.y & 0xFF) | (1u << 8) | (((sp.y >> 8) & 1u) << 9));
+        }
+    }
     const uint32_t lastrid = __shfl(sp.x, lastl, 64), lastseed = __shfl((uint32_t)seedk, lastl, 64);
     unsigned long long seedmask = __ballot(seedk);
     if (G < 64) seedmask = (seedmask >> g0) & ((1ULL << (G & 63)) - 1ULL);
@@ -1771,21 +1802,32 @@ __global__ void k_chain_counts(const ChainHdr *hdr, const uint4 *cstat, const ui
 // Two passes: the record of read i goes, as ONE 8-byte store, to its place in chain-major order (a random 32-byte sector per read instead
 // of four: the scatter runs at the random-access ceiling of the memory system); a streaming pass then splits the records into the four
 // files of reorder.cpp:722-830.
-__global__ void k_s1_scatter(const LogRec *log, unsigned long long nlog, uint32_t K, const uint32_t *base_main, const uint32_t *base_sing,
-                             uint2 *rec, uint32_t *order_s, unsigned long long *bad)
+__global__ __launch_bounds__(256) void k_s1_singles(const uint2 *slog, unsigned long long nlog, uint32_t K, const uint32_t *base_sing, uint32_t *order_s, unsigned long long *found)
 {
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nlog) return;
-    const LogRec r = log[i];
-    if (r.chain >= K || r.rid != (uint32_t)i) { atomicAdd(bad, 1ULL); return; }      // a read nobody emitted (the log starts as 0xFF)
-    if (r.meta & (1u << 10)) order_s[base_sing[r.chain] + r.seq] = r.rid;
-    else rec[base_main[r.chain] + r.seq] = make_uint2(r.rid, r.meta);
+    __shared__ unsigned int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    unsigned int mine = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < nlog; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint2 r = slog[i];
+        if (r.x < K) { order_s[base_sing[r.x] + r.y] = (uint32_t)i; mine++; }
+    }
+    mine = wave_sum_u32(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd(found, (unsigned long long)cnt);
 }
-__global__ void k_s1_split(const uint2 *rec, uint32_t m, uint32_t *order, uint8_t *flag, uint8_t *pos, uint8_t *rc)
+// one wave per page of the main stream: 64 records -> their place in the chain-major output, split into the stage-I arrays on the way
+__global__ __launch_bounds__(256) void k_pages_out(const uint2 *pg_rec, const uint2 *pg_hdr, uint32_t npages, const uint32_t *n_main, const uint32_t *base_main,
+                                                   uint32_t *order, uint8_t *flag, uint8_t *pos, uint8_t *rc)
 {
-    const uint32_t at = blockIdx.x * blockDim.x + threadIdx.x;
-    if (at >= m) return;
-    const uint2 r = rec[at];
+    const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= npages) return;
+    const uint2 hd = pg_hdr[p];
+    const uint32_t nm = n_main[hd.x], first = hd.y * 64u;
+    if (first + lane >= nm) return;
+    const uint2 r = pg_rec[(size_t)p * 64 + lane];
+    const size_t at = (size_t)base_main[hd.x] + first + lane;
     order[at] = r.x; pos[at] = (uint8_t)(r.y & 0xFF);
     flag[at] = (r.y >> 8) & 1 ? '1' : '0'; rc[at] = (r.y >> 9) & 1 ? 'r' : 'd';
 }
@@ -2058,7 +2100,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.steps, (size_t)K * 64)); RC_TRY(dalloc(c, &a.need, (size_t)K + 8192 + 1024));
     RC_TRY(dalloc(c, &a.reseed_g, 4 + 4 * RESEED_G)); HIP_TRY(hipMemsetAsync(a.reseed_g, 0, (4 + 4 * RESEED_G) * 4, c->stream));
     RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + HARC_NSUGG))); RC_TRY(dalloc(c, &a.needrank, (size_t)K + 16)); RC_TRY(dalloc(c, &a.rmeta, 4)); RC_TRY(dalloc(c, &a.cst2, (size_t)K + 1)); RC_TRY(dalloc(c, &a.sugg, (size_t)K * HARC_NSUGG));
-    RC_TRY(dalloc(c, &a.log, (size_t)N + 1));
+    RC_TRY(dalloc(c, &a.slog, (size_t)N + 1));
+    const size_t pg_max = (size_t)N / 64 + ((size_t)K + 1) * PG_CHUNK;        // full pages + one open chunk per chain
+    RC_TRY(dalloc(c, &a.pg_rec, pg_max * 64)); RC_TRY(dalloc(c, &a.pg_hdr, pg_max)); RC_TRY(dalloc(c, &a.pg_cur, (size_t)K + 1)); RC_TRY(dalloc(c, &a.pg_count, 4));
     RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N)); RC_TRY(dalloc(c, &a.coopcnt, HARC_COOPCNT)); HIP_TRY(hipMemsetAsync(a.coopcnt, 0, HARC_COOPCNT * 8, c->stream));
     RC_TRY(dalloc(c, &a.cstat, K)); HIP_TRY(hipMemsetAsync(a.cstat, 0, (size_t)K * 16, c->stream));
     RC_TRY(dalloc(c, &a.dbg, 48)); HIP_TRY(hipMemsetAsync(a.dbg, 0, 48 * 8, c->stream));
@@ -2085,7 +2129,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (const char *e = getenv("HARC_AMD_FIRSTMAX")) { const int x = atoi(e); a.firstmax = x < 1 ? 1 : x > 64 ? 64 : x; }
     HIP_TRY(hipMemsetAsync(a.claimed, 0, nwords * 8, c->stream));
     HIP_TRY(hipMemsetAsync(a.bid, 0xFF, ((size_t)N + 1) * 4, c->stream));
-    HIP_TRY(hipMemsetAsync(a.log, 0xFF, ((size_t)N + 1) * sizeof(LogRec), c->stream));
+    HIP_TRY(hipMemsetAsync(a.slog, 0xFF, ((size_t)N + 1) * sizeof(uint2), c->stream));
     HIP_TRY(hipMemsetAsync(a.rmeta, 0, 16, c->stream));
     HIP_TRY(hipMemsetAsync(a.stats, 0, ST_N * 8, c->stream));
     HIP_TRY(hipMemsetAsync(a.need, 0, (size_t)K + 8192 + 1024, c->stream));
@@ -2235,36 +2279,33 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     uint32_t M = 0, S = 0; const unsigned long long nlog = N;
     HIP_TRY(hipMemcpyAsync(&M, bmain + K, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&S, bsing + K, 4, hipMemcpyDeviceToHost, c->stream));
+    unsigned int npages = 0;
+    HIP_TRY(hipMemcpyAsync(&npages, a.pg_count, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (getenv("HARC_AMD_DIAG")) {     // bookkeeping post-mortem: the reads without a record, what the bitmap, the bids and the chain headers say about them
-        std::vector<LogRec> hl(nlog); std::vector<unsigned long long> hc(nwords); std::vector<uint32_t> hb((size_t)N + 1); std::vector<ChainHdr> hh(K);
-        HIP_TRY(hipMemcpy(hl.data(), a.log, nlog * sizeof(LogRec), hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(hc.data(), a.claimed, nwords * 8, hipMemcpyDeviceToHost));
+    if (getenv("HARC_AMD_DIAG")) {     // bookkeeping post-mortem: what the bitmap, the bids and the chain headers say at the end
+        std::vector<unsigned long long> hc(nwords); std::vector<uint32_t> hb((size_t)N + 1); std::vector<ChainHdr> hh(K);
+        HIP_TRY(hipMemcpy(hc.data(), a.claimed, nwords * 8, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(hb.data(), a.bid, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(hh.data(), a.hdr, (size_t)K * sizeof(ChainHdr), hipMemcpyDeviceToHost));
-        unsigned long long nbad = 0, nunclaimed = 0, nact = 0, npend = 0;
+        unsigned long long nunclaimed = 0, nact = 0, npend = 0;
         for (uint32_t k = 0; k < K; k++) { if (hh[k].flags & CH_ACTIVE) nact++; if (hh[k].flags & CH_PREVUNM) npend++; }
         for (unsigned long long i = 0; i < nlog; i++) {
-            if (hl[i].chain < K && hl[i].rid == (uint32_t)i) continue;
-            const bool cl = (hc[i >> 6] >> (i & 63)) & 1ULL;
-            if (!cl) nunclaimed++;
-            if (nbad++ < 24) {
-                long long own = -1, ownc = -1;
-                for (uint32_t k = 0; k < K; k++) { if (hh[k].prev == (uint32_t)i) own = k; if (hh[k].cur == (uint32_t)i) ownc = k; }
-                fprintf(stderr, "[diag rank %u] read %llu: no record (log chain %x rid %x); claimed %d bid %x; header with prev = it: %lld (flags %x) cur = it: %lld\n", a.own_rem, i, hl[i].chain, hl[i].rid,
-                        (int)cl, hb[i], own, own >= 0 ? hh[own].flags : 0u, ownc);
-            }
+            if ((hc[i >> 6] >> (i & 63)) & 1ULL) continue;
+            if (nunclaimed++ < 24) fprintf(stderr, "[diag rank %u] read %llu was never claimed; bid %x\n", a.own_rem, i, hb[i]);
         }
-        fprintf(stderr, "[diag rank %u] %llu reads without a record, %llu of them unclaimed; M %u S %u N %u; chains active %llu, with a pending seed %llu; cursor/rounds %llu\n", a.own_rem, nbad, nunclaimed, M, S, N, nact, npend, (unsigned long long)rounds);
+        fprintf(stderr, "[diag rank %u] %llu reads unclaimed; M %u S %u N %u; chains active %llu, with a pending seed %llu; rounds %llu\n", a.own_rem, nunclaimed, M, S, N, nact, npend, (unsigned long long)rounds);
     }
     if ((unsigned long long)M + S != nlog) { harc_set_error("stage I bookkeeping: M=%u S=%u N=%u", M, S, N); return HARC_AMD_EINTERNAL; }
     c->M = M; c->S = S;
-    unsigned long long *d_bad = a.stats + ST_N - 1;               // last statistics word: records that nobody wrote
-    uint2 *d_rec = nullptr; RC_TRY(dalloc(c, &d_rec, (size_t)M + 1));
-    if (nlog) hipLaunchKernelGGL(k_s1_scatter, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, c->stream, a.log, nlog, K, bmain, bsing, d_rec, c->d_order_s, d_bad);
-    if (M) hipLaunchKernelGGL(k_s1_split, dim3((M + 255) / 256), dim3(256), 0, c->stream, (const uint2 *)d_rec, M, c->d_order, c->d_flag, c->d_pos, c->d_rc);
+    // every read has exactly one record: M + S = N above, S singleton entries found below, and the pages handed out are those the counts ask for
+    unsigned long long *d_found = a.stats + ST_N - 1;             // last statistics word: entries of the singleton log
+    if (nlog) hipLaunchKernelGGL(k_s1_singles, dim3((unsigned)(nlog / 256 + 1 < 8192 ? nlog / 256 + 1 : 8192)), dim3(256), 0, c->stream, (const uint2 *)a.slog, nlog, K, bsing, c->d_order_s, d_found);
+    if ((size_t)npages > pg_max) { harc_set_error("stage I bookkeeping: %u pages handed out, %zu reserved", npages, pg_max); return HARC_AMD_EINTERNAL; }
+    if (npages) hipLaunchKernelGGL(k_pages_out, dim3((npages + 3) / 4), dim3(256), 0, c->stream, (const uint2 *)a.pg_rec, (const uint2 *)a.pg_hdr, (uint32_t)npages, (const uint32_t *)nmain, (const uint32_t *)bmain,
+                                   c->d_order, c->d_flag, c->d_pos, c->d_rc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (h_stats[ST_N - 1]) { harc_set_error("stage I bookkeeping: %llu reads were never emitted", h_stats[ST_N - 1]); return HARC_AMD_EINTERNAL; }
+    if (h_stats[ST_N - 1] != S) { harc_set_error("stage I bookkeeping: %llu singleton records for %u singletons", h_stats[ST_N - 1], S); return HARC_AMD_EINTERNAL; }
 
     c->C.n_main = M; c->C.n_singleton = S; c->C.unmatched = h_stats[ST_UNMATCHED]; c->C.conflicts = h_stats[ST_CONFLICTS];
     c->C.probes = h_stats[ST_PROBES]; c->C.candidates = h_stats[ST_CANDS]; c->C.useful_probes = h_stats[ST_USEFUL]; c->C.candidates_seq = h_stats[ST_CANDS_SEQ]; c->C.rounds = rounds; c->C.propose_launches = launches;
