@@ -115,10 +115,19 @@ static int build_line_index(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes,
 struct IngestState {
     uint64_t nC = 0, nN = 0, nrec = 0, nfull = 0;                 // clean reads, reads with N, reads, complete records so far
     std::vector<uint32_t> orderN;                                 // read_order_N.bin: record number of every read with N (preprocess.cpp:102)
+    // -q without -p on a file that does not stay in HBM (emit_quality_and_ids_streamed): the length of every id line, the lines the file holds
+    bool want_idlen = false;
+    std::vector<uint32_t> idlen;
+    uint64_t total_lines = 0;
 };
+__global__ void k_q_idlen(const uint64_t *nls, uint32_t nid, uint32_t *len)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nid) len[r] = (uint32_t)(nls[4ll * r] - (nls[4ll * r - 1] + 1));
+}
 static int ingest_begin(harc_amd_ctx *c, IngestState &st)
 {
-    st = IngestState();
+    { const bool w = st.want_idlen; st = IngestState(); st.want_idlen = w; }
     // same effect as harc_amd_set_reads_* on an empty set: previous inputs and results go
     RC_TRY(harc_amd_set_reads_packed_device(c, nullptr, 0));
     RC_TRY(harc_amd_set_nreads_ascii_device(c, nullptr, 0, (uint32_t)c->P.readlen));
@@ -184,6 +193,16 @@ static int ingest_append(harc_amd_ctx *c, IngestState &st, const char *d_txt, ui
     if (nN) HIP_TRY(hipMemcpyAsync(st.orderN.data() + at, orderN, (size_t)nN * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (size_t i = at; i < st.orderN.size(); i++) st.orderN[i] += (uint32_t)st.nrec;       // records of the earlier pieces come first
+    if (st.want_idlen) {                                          // one id line per complete record, plus the one of a truncated last record
+        const uint32_t nid = (uint32_t)nfull + (total_lines % 4 ? 1u : 0u);
+        uint32_t *dl = nullptr; RC_TRY(dalloc(c, &dl, (size_t)nid + 1));
+        if (nid) hipLaunchKernelGGL(k_q_idlen, G256(nid), nls, nid, dl);
+        const size_t a0 = st.idlen.size();
+        st.idlen.resize(a0 + nid);
+        if (nid) HIP_TRY(hipMemcpyAsync(st.idlen.data() + a0, dl, (size_t)nid * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    st.total_lines += total_lines;
     st.nC += nC; st.nN += nN; st.nrec += nrec64; st.nfull += nfull;
     return HARC_AMD_OK;
 }
@@ -305,42 +324,19 @@ static int emit_q_fileorder(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes,
     return HARC_AMD_OK;
 }
 
-static int emit_quality_and_ids(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes, bool preserve_order, const std::string &od, const char *qname, const char *iname)
+// Which record's quality line / id line becomes output line p (reorder_quality.cpp:47-133, :140-208), from the per-record flags: qrec[nC + nN],
+// irec[nC + nidN].  Pool memory of the caller's bracket.
+static int q_routes(harc_amd_ctx *c, const uint32_t *isN, const uint32_t *isC, uint32_t nrec, uint32_t nid, unsigned int *d_err, uint32_t **qrec_out, uint32_t **irec_out, uint32_t *nidN_out)
 {
-    FILE *fq = fopen((od + qname).c_str(), "wb"), *fi = fopen((od + iname).c_str(), "wb");
-    struct Closer { FILE *a, *b; ~Closer() { if (a) fclose(a); if (b) fclose(b); } } closer{ fq, fi };
-    if (!fq || !fi) { harc_set_error("cannot create %soutput.quality / output.id", od.c_str()); return HARC_AMD_EIO; }
-    if (nbytes == 0) return HARC_AMD_OK;
-    const int L = c->P.readlen;
-    const harc_mark_t mk = harc_pool_mark(c);
-    struct Rel { harc_amd_ctx *c; harc_mark_t mk; ~Rel() { harc_pool_release(c, mk); } } rel{ c, mk };
-    const uint64_t *nls = nullptr; uint64_t total_lines = 0;
-    RC_TRY(build_line_index(c, d_txt, nbytes, &nls, &total_lines));
-    const uint32_t nrec = (uint32_t)(total_lines / 4);
-    const uint32_t nid = nrec + (total_lines % 4 ? 1u : 0u);       // the id line of a truncated last record is still written (case 0 of the getline loop)
-    if (!preserve_order && (total_lines % 4) >= 2) {               // that read has no quality line: reorder_quality.cpp would walk off its arrays
-        harc_set_error("-q without -p: the last FASTQ record is truncated (its read is kept, its quality line is missing)"); return HARC_AMD_EINVAL;
-    }
-    if (preserve_order) {                                          // preprocess.cpp:64-69: both files in file order
-        uint32_t *rec = nullptr; RC_TRY(dalloc(c, &rec, (size_t)nid + 1));
-        hipLaunchKernelGGL(k_q_iota, G256((size_t)nid + 1), rec, nid + 1);
-        RC_TRY(emit_lines(c, d_txt, nls, rec, nrec, 3, -1, fq));
-        RC_TRY(emit_lines(c, d_txt, nls, rec, nid, 0, -1, fi));
-        return HARC_AMD_OK;
-    }
     const void *ho = nullptr, *hn = nullptr; size_t ho_len = 0, hn_len = 0;
     RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_ORDER, 0, &ho, &ho_len)); RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_ORDER_N_PE, 0, &hn, &hn_len));
     const uint32_t nC = c->N, nN = c->NN;
     if (ho_len != (size_t)nC * 4 || hn_len != (size_t)nN * 4) { harc_set_error("-q: order streams do not match the read counts"); return HARC_AMD_ESTATE; }
-    uint32_t *isN, *isC, *rk, *idC, *idN, *cleanrec, *nrecs, *idcrec, *idnrec, *d_ord, *d_ordn, *qrec, *irec; unsigned int *d_err;
-    RC_TRY(dalloc(c, &isN, (size_t)nid + 1)); RC_TRY(dalloc(c, &isC, (size_t)nid + 1)); RC_TRY(dalloc(c, &rk, (size_t)nid + 2));
+    uint32_t *rk, *idC, *idN, *cleanrec, *nrecs, *idcrec, *idnrec, *d_ord, *d_ordn, *qrec, *irec;
+    RC_TRY(dalloc(c, &rk, (size_t)nid + 2));
     RC_TRY(dalloc(c, &idC, (size_t)nid + 1)); RC_TRY(dalloc(c, &idN, (size_t)nid + 1));
     RC_TRY(dalloc(c, &cleanrec, (size_t)nC + 1)); RC_TRY(dalloc(c, &nrecs, (size_t)nN + 1)); RC_TRY(dalloc(c, &idcrec, (size_t)nid + 1)); RC_TRY(dalloc(c, &idnrec, (size_t)nid + 1));
     RC_TRY(dalloc(c, &d_ord, (size_t)nC + 1)); RC_TRY(dalloc(c, &d_ordn, (size_t)nN + 1)); RC_TRY(dalloc(c, &qrec, (size_t)nC + nN + 1)); RC_TRY(dalloc(c, &irec, (size_t)nC + nid + 1));
-    RC_TRY(dalloc(c, &d_err, 4));
-    HIP_TRY(hipMemsetAsync(d_err, 0, 16, c->stream));
-    HIP_TRY(hipMemsetAsync(isN, 0, ((size_t)nid + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(isC, 0, ((size_t)nid + 1) * 4, c->stream));
-    if (nrec) hipLaunchKernelGGL(k_classify, G256(nrec), d_txt, nls, nrec, L, isN, isC, d_err);
     if (nC) HIP_TRY(hipMemcpyAsync(d_ord, ho, ho_len, hipMemcpyHostToDevice, c->stream));
     if (nN) HIP_TRY(hipMemcpyAsync(d_ordn, hn, hn_len, hipMemcpyHostToDevice, c->stream));
     // quality: clean records gathered by read_order.bin, then N records gathered by read_order_N_pe.bin (reorder_quality.cpp:47-133)
@@ -370,8 +366,205 @@ static int emit_quality_and_ids(harc_amd_ctx *c, const char *d_txt, uint64_t nby
     HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (err) { harc_set_error("-q: order files and FASTQ disagree (%u entries)", err); return HARC_AMD_ESTATE; }
+    *qrec_out = qrec; *irec_out = irec; *nidN_out = nidN;
+    return HARC_AMD_OK;
+}
+
+static int emit_quality_and_ids(harc_amd_ctx *c, const char *d_txt, uint64_t nbytes, bool preserve_order, const std::string &od, const char *qname, const char *iname)
+{
+    FILE *fq = fopen((od + qname).c_str(), "wb"), *fi = fopen((od + iname).c_str(), "wb");
+    struct Closer { FILE *a, *b; ~Closer() { if (a) fclose(a); if (b) fclose(b); } } closer{ fq, fi };
+    if (!fq || !fi) { harc_set_error("cannot create %soutput.quality / output.id", od.c_str()); return HARC_AMD_EIO; }
+    if (nbytes == 0) return HARC_AMD_OK;
+    const int L = c->P.readlen;
+    const harc_mark_t mk = harc_pool_mark(c);
+    struct Rel { harc_amd_ctx *c; harc_mark_t mk; ~Rel() { harc_pool_release(c, mk); } } rel{ c, mk };
+    const uint64_t *nls = nullptr; uint64_t total_lines = 0;
+    RC_TRY(build_line_index(c, d_txt, nbytes, &nls, &total_lines));
+    const uint32_t nrec = (uint32_t)(total_lines / 4);
+    const uint32_t nid = nrec + (total_lines % 4 ? 1u : 0u);       // the id line of a truncated last record is still written (case 0 of the getline loop)
+    if (!preserve_order && (total_lines % 4) >= 2) {               // that read has no quality line: reorder_quality.cpp would walk off its arrays
+        harc_set_error("-q without -p: the last FASTQ record is truncated (its read is kept, its quality line is missing)"); return HARC_AMD_EINVAL;
+    }
+    if (preserve_order) {                                          // preprocess.cpp:64-69: both files in file order
+        uint32_t *rec = nullptr; RC_TRY(dalloc(c, &rec, (size_t)nid + 1));
+        hipLaunchKernelGGL(k_q_iota, G256((size_t)nid + 1), rec, nid + 1);
+        RC_TRY(emit_lines(c, d_txt, nls, rec, nrec, 3, -1, fq));
+        RC_TRY(emit_lines(c, d_txt, nls, rec, nid, 0, -1, fi));
+        return HARC_AMD_OK;
+    }
+    uint32_t *isN, *isC; unsigned int *d_err;
+    RC_TRY(dalloc(c, &isN, (size_t)nid + 1)); RC_TRY(dalloc(c, &isC, (size_t)nid + 1)); RC_TRY(dalloc(c, &d_err, 4));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 16, c->stream));
+    HIP_TRY(hipMemsetAsync(isN, 0, ((size_t)nid + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(isC, 0, ((size_t)nid + 1) * 4, c->stream));
+    if (nrec) hipLaunchKernelGGL(k_classify, G256(nrec), d_txt, nls, nrec, L, isN, isC, d_err);
+    uint32_t *qrec = nullptr, *irec = nullptr, nidN = 0;
+    RC_TRY(q_routes(c, isN, isC, nrec, nid, d_err, &qrec, &irec, &nidN));
+    const uint32_t nC = c->N, nN = c->NN;
     RC_TRY(emit_lines(c, d_txt, nls, qrec, (uint64_t)nC + nN, 3, L, fq));
     RC_TRY(emit_lines(c, d_txt, nls, irec, (uint64_t)nC + nidN, 0, -1, fi));
+    return HARC_AMD_OK;
+}
+
+// ---- -q without -p when the FASTQ text does not stay in HBM: the reference permutes quality values and ids in 4-8 bins of host memory, reading
+// the files once per bin (reorder_quality.cpp:61-77).  Here: the routes (which record's line becomes output line p) come from the per-record N
+// flags and the id-line lengths kept by the ingest; the OUTPUT is cut into bins that fit HBM, and for every bin the FASTQ file is streamed
+// through the GPU once more, piece by piece, every line that belongs to the bin copied to its place (quality lines have a fixed stride -- they
+// must be readlen long, reorder_quality.cpp:78-79 -- id lines go by a prefix sum of their lengths).  Quality and id bins share a pass.
+__global__ void k_q_scatter_flag(const uint32_t *idx, uint32_t n, uint32_t lim, uint32_t *flag, unsigned int *err)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = idx[i];
+    if (r >= lim) { atomicAdd(err, 1u); return; }
+    flag[r] = 1u;
+}
+__global__ void k_q_not(const uint32_t *isN, uint32_t n, uint32_t *isC) { const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r < n) isC[r] = isN[r] ? 0u : 1u; }
+__global__ void k_q_invert(const uint32_t *rec, uint32_t n, uint32_t *pos) { const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; if (p < n) pos[rec[p]] = p; }
+__global__ void k_q_outlen(const uint32_t *idlen, const uint32_t *rec, uint32_t n, uint32_t *len) { const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; if (p < n) len[p] = idlen[rec[p]] + 1u; }
+// first p in [lo, n] with off[p] - off[lo] > budget, minus one (at least lo + 1 when lo < n): the end of the bin that starts at lo
+__global__ void k_q_bin_end(const uint64_t *off, uint32_t lo, uint32_t n, uint64_t budget, uint32_t *out)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    const uint64_t base = off[lo];
+    uint32_t a = lo, b = n;                                       // largest p with off[p] - base <= budget
+    while (a < b) { const uint32_t mid = a + (b - a + 1) / 2; if (off[mid] - base <= budget) a = mid; else b = mid - 1; }
+    if (a == lo && lo < n) a = lo + 1;                            // a single line longer than the budget still goes out
+    out[0] = a;
+}
+// one wave per record of the piece: its quality line and its id line, each if its output line lies in the bin being filled
+__global__ __launch_bounds__(256) void k_q_place(const char *txt, const uint64_t *nls, uint32_t nrec, uint32_t nid, uint32_t base, int L,
+                                                 const uint32_t *posQ, uint32_t q0, uint32_t q1, char *outQ,
+                                                 const uint32_t *posI, const uint64_t *offI, uint32_t i0, uint32_t i1, char *outI, unsigned int *err)
+{
+    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r < nrec) {
+        const uint32_t p = posQ[base + r];
+        if (p >= q0 && p < q1) {
+            const uint64_t s = nls[4ll * r + 2] + 1, l = nls[4ll * r + 3] - s;
+            if (l != (uint64_t)L) { if (lane == 0) atomicAdd(err, 1u); }
+            else {
+                char *o = outQ + (size_t)(p - q0) * (size_t)(L + 1);
+                for (uint64_t j = lane; j < l; j += 64) o[j] = txt[s + j];
+                if (lane == 0) o[l] = '\n';
+            }
+        }
+    }
+    if (r < nid) {
+        const uint32_t p = posI[base + r];
+        if (p >= i0 && p < i1) {
+            const uint64_t s = nls[4ll * r - 1] + 1, l = nls[4ll * r] - s;
+            char *o = outI + (offI[p] - offI[i0]);
+            for (uint64_t j = lane; j < l; j += 64) o[j] = txt[s + j];
+            if (lane == 0) o[l] = '\n';
+        }
+    }
+}
+static int load_file_range(harc_amd_ctx *c, FILE *f, const char *name, uint64_t lo, uint64_t hi, char **d_txt);
+static int record_start_at_or_after(FILE *f, uint64_t pos, uint64_t fsz, uint64_t *out);
+static int write_device_range(harc_amd_ctx *c, const char *d, size_t n, FILE *fo)
+{
+    std::vector<uint8_t> host;
+    const size_t CH = (size_t)256 << 20;
+    for (size_t at = 0; at < n; at += CH) {
+        const size_t m = n - at < CH ? n - at : CH;
+        RC_TRY(harc_d2h(c, host, d + at, m));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (fwrite(host.data(), 1, m, fo) != m) { harc_set_error("short write"); return HARC_AMD_EIO; }
+    }
+    return HARC_AMD_OK;
+}
+static int emit_quality_and_ids_streamed(harc_amd_ctx *c, FILE *f, const char *name, uint64_t fsz, const IngestState &st, const std::string &od, const char *qname, const char *iname)
+{
+    FILE *fq = fopen((od + qname).c_str(), "wb"), *fi = fopen((od + iname).c_str(), "wb");
+    struct Closer { FILE *a, *b; ~Closer() { if (a) fclose(a); if (b) fclose(b); } } closer{ fq, fi };
+    if (!fq || !fi) { harc_set_error("cannot create %soutput.quality / output.id", od.c_str()); return HARC_AMD_EIO; }
+    if (fsz == 0) return HARC_AMD_OK;
+    const int L = c->P.readlen;
+    if ((st.total_lines % 4) >= 2) { harc_set_error("-q without -p: the last FASTQ record is truncated (its read is kept, its quality line is missing)"); return HARC_AMD_EINVAL; }
+    const uint32_t nrec = (uint32_t)st.nfull, nid = nrec + (st.total_lines % 4 ? 1u : 0u);
+    if (st.idlen.size() != (size_t)nid) { harc_set_error("-q: %zu id lines recorded, %u expected", st.idlen.size(), nid); return HARC_AMD_EINTERNAL; }
+    PoolScope scope(c);
+    uint32_t *isN, *isC; unsigned int *d_err;
+    RC_TRY(dalloc(c, &isN, (size_t)nid + 1)); RC_TRY(dalloc(c, &isC, (size_t)nid + 1)); RC_TRY(dalloc(c, &d_err, 4));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 16, c->stream));
+    HIP_TRY(hipMemsetAsync(isN, 0, ((size_t)nid + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(isC, 0, ((size_t)nid + 1) * 4, c->stream));
+    {   // the N flags of k_classify, from read_order_N.bin
+        PoolScope tmp(c);
+        const uint32_t nN = (uint32_t)st.orderN.size();
+        uint32_t *d_on = nullptr; RC_TRY(dalloc(c, &d_on, (size_t)nN + 1));
+        if (nN) { HIP_TRY(hipMemcpyAsync(d_on, st.orderN.data(), (size_t)nN * 4, hipMemcpyHostToDevice, c->stream)); hipLaunchKernelGGL(k_q_scatter_flag, G256(nN), d_on, nN, nrec, isN, d_err); }
+        if (nrec) hipLaunchKernelGGL(k_q_not, G256(nrec), isN, nrec, isC);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    uint32_t *qrec = nullptr, *irec = nullptr, nidN = 0;
+    RC_TRY(q_routes(c, isN, isC, nrec, nid, d_err, &qrec, &irec, &nidN));
+    const uint32_t nC = c->N, nN = c->NN, nQ = nC + nN, nI = nC + nidN;
+    uint32_t *posQ, *posI, *d_idlen, *lenI, *d_end; uint64_t *offI;
+    RC_TRY(dalloc(c, &posQ, (size_t)nrec + 1)); RC_TRY(dalloc(c, &posI, (size_t)nid + 1)); RC_TRY(dalloc(c, &d_idlen, (size_t)nid + 1));
+    RC_TRY(dalloc(c, &lenI, (size_t)nI + 1)); RC_TRY(dalloc(c, &offI, (size_t)nI + 1)); RC_TRY(dalloc(c, &d_end, 4));
+    HIP_TRY(hipMemsetAsync(posQ, 0xFF, ((size_t)nrec + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(posI, 0xFF, ((size_t)nid + 1) * 4, c->stream));
+    if (nQ) hipLaunchKernelGGL(k_q_invert, G256(nQ), qrec, nQ, posQ);
+    if (nI) hipLaunchKernelGGL(k_q_invert, G256(nI), irec, nI, posI);
+    if (nid) HIP_TRY(hipMemcpyAsync(d_idlen, st.idlen.data(), (size_t)nid * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(lenI + nI, 0, 4, c->stream));
+    if (nI) hipLaunchKernelGGL(k_q_outlen, G256(nI), d_idlen, irec, nI, lenI);
+    RC_TRY(prim_excl_scan_u32_to_u64(c, lenI, offI, (size_t)nI + 1));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // bytes of output one pass holds, per file
+    size_t budget;
+    {
+        size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot);
+        budget = (size_t)(0.25 * (double)fr);
+        if (budget > ((size_t)32 << 30)) budget = (size_t)32 << 30;
+        if (budget < ((size_t)64 << 20)) budget = (size_t)64 << 20;
+        if (const char *e = getenv("HARC_AMD_Q_BIN")) { const unsigned long long v = strtoull(e, nullptr, 10); if (v >= 1) budget = (size_t)v; }       // tests: bins of a few lines
+    }
+    uint64_t piece = (uint64_t)1 << 30;
+    if (const char *e = getenv("HARC_AMD_INGEST_CHUNK")) { piece = strtoull(e, nullptr, 10); if (piece < 16) piece = 16; }
+    uint32_t q0 = 0, i0 = 0; int passes = 0;
+    while (q0 < nQ || i0 < nI) {
+        PoolScope pass_scope(c);
+        uint64_t perq = budget / (uint64_t)(L + 1); if (perq < 1) perq = 1;
+        const uint32_t q1 = (uint64_t)nQ - q0 > perq ? q0 + (uint32_t)perq : nQ;
+        uint32_t i1 = i0;
+        uint64_t ob[2] = { 0, 0 };
+        if (i0 < nI) {
+            hipLaunchKernelGGL(k_q_bin_end, dim3(1), dim3(1), 0, c->stream, (const uint64_t *)offI, i0, nI, (uint64_t)budget, d_end);
+            HIP_TRY(hipMemcpyAsync(&i1, d_end, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpyAsync(&ob[0], offI + i0, 8, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipMemcpyAsync(&ob[1], offI + i1, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        const size_t bytesQ = (size_t)(q1 - q0) * (size_t)(L + 1), bytesI = (size_t)(ob[1] - ob[0]);
+        char *outQ = nullptr, *outI = nullptr;
+        RC_TRY(dalloc(c, &outQ, bytesQ + 16)); RC_TRY(dalloc(c, &outI, bytesI + 16));
+        uint64_t lo = 0; uint32_t base = 0;
+        while (lo < fsz) {
+            uint64_t hi = fsz;
+            if (fsz - lo > piece) { RC_TRY(record_start_at_or_after(f, lo + piece, fsz, &hi)); if (hi <= lo) hi = fsz; }
+            char *d_txt = nullptr;
+            RC_TRY(load_file_range(c, f, name, lo, hi, &d_txt));
+            struct Free { harc_amd_ctx *c; char *p; ~Free() { harc_raw_free(c, p); } } fr{ c, d_txt };
+            PoolScope piece_scope(c);
+            const uint64_t *nls = nullptr; uint64_t tl = 0;
+            RC_TRY(build_line_index(c, d_txt, hi - lo, &nls, &tl));
+            const uint32_t pr = (uint32_t)(tl / 4), pi = pr + (tl % 4 ? 1u : 0u);
+            if ((uint64_t)base + pi > (uint64_t)nid) { harc_set_error("-q: the FASTQ file changed between the passes"); return HARC_AMD_EIO; }
+            if (pi) hipLaunchKernelGGL(k_q_place, dim3((pi + 3) / 4), dim3(256), 0, c->stream, (const char *)d_txt, nls, pr, pi, base, L, (const uint32_t *)posQ, q0, q1, outQ,
+                                       (const uint32_t *)posI, (const uint64_t *)offI, i0, i1, outI, d_err);
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            base += pr; lo = hi;
+        }
+        unsigned int err = 0;
+        HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (err) { harc_set_error("-q without -p needs quality lines of exactly readlen characters (%u differ)", err); return HARC_AMD_EINVAL; }
+        RC_TRY(write_device_range(c, outQ, bytesQ, fq)); RC_TRY(write_device_range(c, outI, bytesI, fi));
+        q0 = q1; i0 = i1; passes++;
+    }
+    if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[-q] quality values and ids permuted in %d passes over the FASTQ file (%zu bytes of each per pass)\n", passes, budget);
     return HARC_AMD_OK;
 }
 
@@ -492,12 +685,15 @@ extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, c
     char *d_txt = nullptr;                                        // -q without -p: the whole text stays in HBM until the orders are known
     struct FreeTxt { harc_amd_ctx *c; char **p; ~FreeTxt() { if (*p) harc_raw_free(c, *p); } } freetxt{ c, &d_txt };
     IngestState st;
+    // -q without -p: the text stays in HBM until the orders are known when it fits next to everything else; a larger file is ingested in pieces
+    // like any other and streamed again, once per bin of output, when the orders are there (emit_quality_and_ids_streamed)
+    bool stream_q = false;
     if (preserve_quality && !preserve_order) {
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)fsz > 0.45 * (double)fr) {
-            harc_set_error("-q without -p keeps the FASTQ text (%llu bytes) in HBM until the reads are reordered and it does not fit; use -p, or split the file", (unsigned long long)fsz);
-            return HARC_AMD_ENOMEM;
-        }
+        stream_q = (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)fsz > 0.45 * (double)fr);
+        if (const char *e = getenv("HARC_AMD_Q_STREAM")) stream_q = atoi(e) != 0;       // tests: either way on a small file
+    }
+    if (preserve_quality && !preserve_order && !stream_q) {
         RC_TRY(load_file_range(c, f, fastq, 0, fsz, &d_txt));
         RC_TRY(ingest_begin(c, st));
         RC_TRY(ingest_append(c, st, d_txt, fsz, true, 0, 0));
@@ -505,29 +701,40 @@ extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, c
     } else {
         FILE *fq = nullptr, *fi = nullptr;
         struct Closer { FILE **a, **b; ~Closer() { if (*a) fclose(*a); if (*b) fclose(*b); } } closer{ &fq, &fi };
-        if (preserve_quality) {
+        if (preserve_quality && preserve_order) {                  // file order: written while the pieces pass through
             fq = fopen((od + "output.quality").c_str(), "wb"); fi = fopen((od + "output.id").c_str(), "wb");
             if (!fq || !fi) { harc_set_error("cannot create %soutput.quality / output.id", od.c_str()); return HARC_AMD_EIO; }
         }
+        st.want_idlen = stream_q;
         RC_TRY(ingest_file_range(c, f, fastq, 0, fsz, fsz, st, fq, fi));
     }
     printf("Read length: %d\nTotal number of reads: %llu\nTotal number of reads without N: %llu\nPreprocessing Done!\n", params->readlen,
            (unsigned long long)st.nfull, (unsigned long long)c->N);                                       // preprocess.cpp:133-136
+    const bool tlog = getenv("HARC_AMD_TRACE") != nullptr;
+    auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    double tl0 = now();
+    auto lap = [&](const char *what) { if (tlog) { const double t = now(); fprintf(stderr, "[compress_fastq] %s: %.3f s\n", what, t - tl0); tl0 = t; } };
     RC_TRY(spit_stream_to(c, HARC_AMD_IN_ORDER_N, 0, od + "read_order_N.bin"));
     { const uint32_t n32 = c->N; RC_TRY(spit_file(od + "numreads.bin", &n32, 4)); }
     RC_TRY(harc_amd_reorder(c));
+    lap("reorder");
     RC_TRY(harc_amd_encode(c));
+    lap("encode");
     harc_amd_counters C; harc_amd_get_counters(c, &C);
     printf("Reordering done, %llu were unmatched\n", (unsigned long long)C.unmatched);
     printf("Encoding done:\n%llu singleton reads were aligned\n%llu reads with N were aligned\n", (unsigned long long)C.aligned_singletons, (unsigned long long)C.aligned_N);
     RC_TRY(write_shard_family(c, od, 0));
+    lap("stream files");
     static const struct { int id; const char *name; } whole[] = {
         { HARC_AMD_S2_ORDER, "read_order.bin" }, { HARC_AMD_S2_ORDER_N_PE, "read_order_N_pe.bin" }, { HARC_AMD_S2_INPUT_N, "input_N.dna" },
         { HARC_AMD_S2_META, "read_meta.txt" }, { HARC_AMD_S2_SINGLETON, "read_singleton.txt" }, { HARC_AMD_S2_SINGLETON_TAIL, "read_singleton.txt.tail" } };
     for (auto &fd : whole) RC_TRY(spit_stream_to(c, fd.id, 0, od + fd.name));
     if (preserve_quality && !preserve_order) {
         printf("Reordering quality values and ids\n");                                                      // harc:122
-        RC_TRY(emit_quality_and_ids(c, d_txt, fsz, false, od, "output.quality", "output.id"));
+        lap("whole-job files");
+        if (stream_q) RC_TRY(emit_quality_and_ids_streamed(c, f, fastq, fsz, st, od, "output.quality", "output.id"));
+        else RC_TRY(emit_quality_and_ids(c, d_txt, fsz, false, od, "output.quality", "output.id"));
+        lap("quality values and ids");
     }
     return HARC_AMD_OK;
 }

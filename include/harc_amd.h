@@ -223,7 +223,9 @@ int harc_amd_compress_fastq_files(const harc_amd_params *params, const char *fas
 /* the same with the reference's -p / -q switches (preprocess.out's 3rd and 4th argument, harc:50).  preserve_quality: also writes
    output/output.quality and output/output.id -- in file order with preserve_order (preprocess.cpp:64-69), otherwise gathered by the
    post-encoding orders exactly as reorder_quality.out does (reorder_quality.cpp:47-219, quirks included: see oracle/harc_oracle.c
-   harc_oracle_quality).  preserve_order itself changes nothing else here: pack_order stays a separate call (harc:112). */
+   harc_oracle_quality).  preserve_order itself changes nothing else here: pack_order stays a separate call (harc:112).
+   The file may be larger than HBM in every mode: it is ingested a piece at a time; without preserve_order the quality values and ids are
+   then permuted by streaming the file again once per bin of output (reorder_quality.cpp:61-77 bins through host memory). */
 int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order, int32_t preserve_quality);
 /* == `preprocess.out <fastq> <basedir> <preserve_order> <preserve_quality> <readlen>` (src/preprocess.cpp:22-137, harc:50),
    the N split only; host code, feeds the boundary */

@@ -465,12 +465,23 @@ def test_fastq_ingest_truncated_last_record_like_the_reference(tail, tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------ -q
+def _q_stream_env(monkeypatch, stream):
+    """-q without -p as on a FASTQ file larger than HBM: ingested in pieces of a few thousand records, quality values and ids permuted by
+    streaming the file again once per bin of ~4000 output lines (ingest.hip emit_quality_and_ids_streamed)"""
+    if stream:
+        monkeypatch.setenv("HARC_AMD_Q_STREAM", "1"); monkeypatch.setenv("HARC_AMD_INGEST_CHUNK", "700000"); monkeypatch.setenv("HARC_AMD_Q_BIN", "400000")
+    else:
+        monkeypatch.setenv("HARC_AMD_Q_STREAM", "0")
+
+
+@pytest.mark.parametrize("stream", [False, True])
 @pytest.mark.parametrize("case", ol.quality_cases())
-def test_quality_ids_match_reference_golden(case, tmp_path):
+def test_quality_ids_match_reference_golden(case, stream, tmp_path, monkeypatch):
     """K=1, E=1 gives the reference's own orders, so output.quality / output.id must be the REAL reference's bytes (reorder_quality.out
     after preprocess / reorder / encoder at num_thr=1), and with -p the files preprocess.out writes directly"""
     import json
     import harc_amd
+    _q_stream_env(monkeypatch, stream)
     g = ol.load_golden(case)
     L = json.loads(g["meta.json"])["L"]
     for mode, po in (("np", False), ("p", True)):
@@ -485,11 +496,13 @@ def test_quality_ids_match_reference_golden(case, tmp_path):
         assert got["output.id"] == g[mode + "/output.id"], mode
 
 
+@pytest.mark.parametrize("stream", [False, True])
 @pytest.mark.parametrize("K,S,E,trunc", [(7, 16, 3, 0), (64, 8, 2, 1), (3, 4, 8, 0)])
-def test_quality_ids_match_oracle_any_schedule(K, S, E, trunc, oracle, tmp_path):
+def test_quality_ids_match_oracle_any_schedule(K, S, E, trunc, stream, oracle, tmp_path, monkeypatch):
     """other (K, S, E): the gather must follow this run's own orders -- checked against the oracle's restatement fed with the
     GPU's order files; trunc: the FASTQ ends in a partial record (1 = dangling id line, 2 = id + sequence, no newline at the end)"""
     import harc_amd
+    _q_stream_env(monkeypatch, stream)
     L = 100
     reads = gen.reads_text(4242, 30000, L, 200000, err=0.006).split()
     import numpy as np
@@ -524,8 +537,10 @@ def test_quality_ids_match_oracle_any_schedule(K, S, E, trunc, oracle, tmp_path)
     assert sorted(ql) == sorted(r.split(b"\n")[3] for r in recs)
 
 
-def test_quality_wrong_length_rejected(tmp_path):
+@pytest.mark.parametrize("stream", [False, True])
+def test_quality_wrong_length_rejected(stream, tmp_path, monkeypatch):
     import harc_amd
+    _q_stream_env(monkeypatch, stream)
     reads = gen.reads_text(1, 2000, 100, 20000).split()
     fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"H" * (99 if i == 700 else 100)) for i, r in enumerate(reads))
     (tmp_path / "in.fastq").write_bytes(fq)
