@@ -178,6 +178,7 @@ struct PoolScope {
 
 // ---- primitives (prims.hip): thin wrappers over rocPRIM device-wide sort / scan
 int prim_sort_pairs_u64_u32(harc_amd_ctx *c, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit);
+int prim_sort_keys_u64(harc_amd_ctx *c, const uint64_t *kin, uint64_t *kout, size_t n, unsigned end_bit);       // by the low end_bit bits, stable
 int prim_excl_scan_u32(harc_amd_ctx *c, const uint32_t *in, uint32_t *out, size_t n);
 int prim_excl_scan_u32_to_u64(harc_amd_ctx *c, const uint32_t *in, uint64_t *out, size_t n);
 int prim_excl_scan_u8_to_u64(harc_amd_ctx *c, const uint8_t *in, uint64_t *out, size_t n);

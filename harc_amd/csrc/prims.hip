@@ -31,6 +31,15 @@ int prim_sort_pairs_u64_u32(harc_amd_ctx *c, const uint64_t *kin, uint64_t *kout
     return HARC_AMD_OK;
 }
 
+int prim_sort_keys_u64(harc_amd_ctx *c, const uint64_t *kin, uint64_t *kout, size_t n, unsigned end_bit)
+{
+    if (n == 0) return HARC_AMD_OK;
+    if (end_bit > 64) end_bit = 64;
+    if (end_bit < 1) end_bit = 1;
+    PRIM_CALL(rocprim::radix_sort_keys(tmp, bytes, kin, kout, n, 0u, end_bit, c->stream));
+    return HARC_AMD_OK;
+}
+
 int prim_excl_scan_u32(harc_amd_ctx *c, const uint32_t *in, uint32_t *out, size_t n)
 {
     if (n == 0) return HARC_AMD_OK;

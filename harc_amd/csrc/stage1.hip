@@ -341,6 +341,49 @@ __global__ void k_table_place(const uint64_t *skeys, const uint32_t *sids, const
     }
 }
 
+// The same bitmap for a LARGE input, without the random atomics (configs[2]: 350 M of them into 700 MB, 13.6 ms per dictionary at the
+// random-access ceiling): every key becomes (tile of the bitmap, word inside the tile, its two bits) in one u64, the u64s are sorted by tile
+// (two radix passes over the tile bits), and one workgroup per tile ORs its keys into 64 KB of LDS and writes the tile out in one coalesced
+// stream -- every byte of the bitmap is written exactly once, so it needs no clearing either.
+#define BL_TILE_WORDS 16384u     // 64 KB = 1024 lines
+#define BL_PART_BITS 20          // up to 2^20 tiles (64 GB of bitmap)
+__global__ void k_s1_bloom_keys(const uint64_t *keys, uint32_t n, uint32_t nlines, int nwin, uint32_t mmask, uint64_t *pk)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w, m;
+    bloom_pos(keys[i], key_scramble(keys[i]), nlines, nwin, mmask, &w, &m);
+    const uint32_t b0 = (uint32_t)__ffs((int)m) - 1u, b1 = 31u - (uint32_t)__clz((int)m);
+    pk[i] = ((uint64_t)(((w % BL_TILE_WORDS) << 10) | (b0 << 5) | b1) << BL_PART_BITS) | (uint64_t)(w / BL_TILE_WORDS);
+}
+__global__ __launch_bounds__(256) void k_s1_bloom_tile(const uint64_t *pk, uint32_t n, uint64_t nwords, uint32_t *bloom)
+{
+    __shared__ uint32_t tile[BL_TILE_WORDS];
+    __shared__ uint32_t bounds[2];
+    const uint32_t part = blockIdx.x;
+    for (uint32_t j = threadIdx.x; j < BL_TILE_WORDS; j += 256) tile[j] = 0u;
+    if (threadIdx.x < 2) {                                        // first key of this tile and of the next one
+        const uint64_t want = (uint64_t)part + threadIdx.x, pmask = ((uint64_t)1 << BL_PART_BITS) - 1;
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if ((pk[mid] & pmask) < want) lo = mid + 1; else hi = mid; }
+        bounds[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    for (uint32_t i = bounds[0] + threadIdx.x; i < bounds[1]; i += 256) {
+        const uint32_t v = (uint32_t)(pk[i] >> BL_PART_BITS);
+        atomicOr(&tile[v >> 10], (1u << ((v >> 5) & 31u)) | (1u << (v & 31u)));
+    }
+    __syncthreads();
+    const uint64_t base = (uint64_t)part * BL_TILE_WORDS;
+    for (uint32_t j = threadIdx.x; j < BL_TILE_WORDS; j += 256) if (base + j < nwords) bloom[base + j] = tile[j];
+}
+__global__ void k_s1_bloom_diff(const uint32_t *a, const uint32_t *b, uint64_t nwords, unsigned long long *ndiff)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool d = i < nwords && a[i] != b[i];
+    const unsigned long long m = __ballot(d);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(ndiff, (unsigned long long)__popcll(m));
+}
 __global__ void k_s1_bloom_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, uint32_t nlines, int nwin, uint32_t mmask)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2008,6 +2051,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (const char *e = getenv("HARC_AMD_S1BLOOM_MZMB")) bloom_mz_bytes = (size_t)strtoull(e, nullptr, 10) << 20;
     const uint32_t bloom_mmask = bloom_m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * bloom_m)) - 1u);
     if (const char *e = getenv("HARC_AMD_S1BLOOM")) { bloom_bits = atoi(e); if (bloom_bits < 0) bloom_bits = 0; if (bloom_bits > 64) bloom_bits = 64; }
+    bool bloom_tiled = false;
     unsigned long long *d_large = nullptr; unsigned int *d_nlarge = nullptr;
     const uint32_t maxlarge = 2 * (N / HARC_LARGEBIN) + 16;
     if (N) {
@@ -2020,8 +2064,11 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             uint64_t nl = ((uint64_t)N * (uint64_t)bloom_bits + 511) / 512 + 1;       // lines of 64 bytes
             if (nl > 0x0FFFFFFFull) nl = 0x0FFFFFFFull;
             bloom_lines = (uint32_t)nl;
+            // a bitmap beyond the caches is built tile by tile from sorted keys (k_s1_bloom_tile); a small one takes the atomics in L2 (HARC_AMD_S1BLOOM_TILED=0/1 forces either)
+            bloom_tiled = getenv("HARC_AMD_S1BLOOM_TILED") ? atoi(getenv("HARC_AMD_S1BLOOM_TILED")) != 0 : (size_t)bloom_lines * 64 >= ((size_t)64 << 20);
+            if (((uint64_t)bloom_lines * 16 + BL_TILE_WORDS - 1) / BL_TILE_WORDS > ((uint64_t)1 << BL_PART_BITS)) bloom_tiled = false;
             for (int l = 0; l < 2; l++) {
-                RC_TRY(dalloc(c, &d_bloom[l], (size_t)bloom_lines * 16)); HIP_TRY(hipMemsetAsync(d_bloom[l], 0, (size_t)bloom_lines * 64, c->stream));
+                RC_TRY(dalloc(c, &d_bloom[l], (size_t)bloom_lines * 16)); if (!bloom_tiled) HIP_TRY(hipMemsetAsync(d_bloom[l], 0, (size_t)bloom_lines * 64, c->stream));
                 const int nb = P.dict_end[l] - P.dict_start[l] + 1;                   // bases per key
                 const bool same = P.dict_end[0] - P.dict_start[0] == P.dict_end[1] - P.dict_start[1];     // k_steps takes one window count for both
                 bloom_nwin[l] = (same && bloom_m > 0 && nb > bloom_m && (size_t)bloom_lines * 64 >= bloom_mz_bytes) ? nb - bloom_m + 1 : 0;
@@ -2033,7 +2080,27 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         for (int l = 0; l < 2; l++) {
             const int kbits = 2 * (P.dict_end[l] - P.dict_start[l] + 1);
             hipLaunchKernelGGL((k_keygen<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[l], kbits, k0, i0);
-            if (bloom_lines) hipLaunchKernelGGL(k_s1_bloom_set, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, d_bloom[l], bloom_lines, bloom_nwin[l], bloom_mmask);
+            if (bloom_lines && bloom_tiled) {
+                PoolScope bscope(c);
+                uint64_t *pa = nullptr, *pb = nullptr; RC_TRY(dalloc(c, &pa, (size_t)N + 1)); RC_TRY(dalloc(c, &pb, (size_t)N + 1));
+                const uint64_t nwords = (uint64_t)bloom_lines * 16;
+                const uint32_t ntiles = (uint32_t)((nwords + BL_TILE_WORDS - 1) / BL_TILE_WORDS);
+                unsigned tb = 1; while (((uint64_t)1 << tb) < ntiles) tb++;
+                hipLaunchKernelGGL(k_s1_bloom_keys, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, bloom_lines, bloom_nwin[l], bloom_mmask, pa);
+                RC_TRY(prim_sort_keys_u64(c, pa, pb, N, tb));
+                hipLaunchKernelGGL(k_s1_bloom_tile, dim3(ntiles), dim3(256), 0, c->stream, (const uint64_t *)pb, N, nwords, d_bloom[l]);
+                HIP_TRY(hipGetLastError());
+                if (getenv("HARC_AMD_S1BLOOM_VERIFY")) {            // tests: word for word what the atomics build
+                    uint32_t *ref = nullptr; unsigned long long *nd = nullptr, hnd = 0;
+                    RC_TRY(dalloc(c, &ref, (size_t)nwords)); RC_TRY(dalloc(c, &nd, 1));
+                    HIP_TRY(hipMemsetAsync(ref, 0, (size_t)nwords * 4, c->stream)); HIP_TRY(hipMemsetAsync(nd, 0, 8, c->stream));
+                    hipLaunchKernelGGL(k_s1_bloom_set, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, ref, bloom_lines, bloom_nwin[l], bloom_mmask);
+                    hipLaunchKernelGGL(k_s1_bloom_diff, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)ref, (const uint32_t *)d_bloom[l], nwords, nd);
+                    HIP_TRY(hipMemcpyAsync(&hnd, nd, 8, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    if (hnd) { harc_set_error("stage I bitmap built by tiles differs from the one built with atomics in %llu words", hnd); return HARC_AMD_EINTERNAL; }
+                }
+            } else if (bloom_lines) hipLaunchKernelGGL(k_s1_bloom_set, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, d_bloom[l], bloom_lines, bloom_nwin[l], bloom_mmask);
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, N, (unsigned)kbits));
         }
     }
