@@ -280,10 +280,71 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
 // The reads arrive sorted by scrambled key, so the bins arrive in bucket order (bucket_slot is monotone): the slot of bin i is
 // max(4 * bucket_i, slot_{i-1} + 1) -- the linear-probing invariant -- i.e. an inclusive max-scan of (4 * bucket_i - i), plus i.
 // No atomics, and the stores walk the table front to back.  (A CAS insert ran at the random read-modify-write rate: 37 ms for 350 M bins.)
-__global__ void k_scramble_keys(uint64_t *keys, uint32_t n)
+// The sort of the scrambled keys looks at their TOP bits only (40 of 64 for up to 2^28 reads: five radix passes instead of eight -- the sort is
+// a sixth of the index build); two different keys that agree in those bits are rare (n^2 / 2^41 pairs: 55 000 among 350 M keys) and end up
+// side by side, possibly interleaved.  k_mixed_find lists the places where a key follows a DIFFERENT key with the same top bits; k_mixed_fix
+// sorts every such stretch by the whole key (stable: ids stay ascending inside a bin), one thread per stretch, started from its first listed
+// place.  A stretch that would take too long (two large bins that collide), or a list that overflows, raises a flag and the host sorts again on
+// all 64 bits.
+#define MIXED_MAX (1u << 20)
+#define MIXED_BUDGET 200000u
+// (the keys go through the sort ROTATED, their top bits at the bottom: rocprim sorts the low `sbits` bits, begin_bit = 0 -- with begin_bit > 0
+// its small-input path returned a wrong order here; this pass turns them back on the way)
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, unsigned r) { r &= 63u; return r ? (x << r) | (x >> (64u - r)) : x; }
+__global__ void k_mixed_find(const uint64_t *rk, uint32_t n, unsigned sbits, uint64_t *sk, uint32_t *list, unsigned int *meta)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = key_scramble(keys[i]);
+    if (i >= n) return;
+    const int shift = (int)(64u - sbits);
+    const uint64_t b = rotl64(rk[i], 64u - sbits);                // rotate right by sbits
+    sk[i] = b;
+    if (i == 0) return;
+    const uint64_t a = rotl64(rk[i - 1], 64u - sbits);
+    if (a != b && (a >> shift) == (b >> shift)) { const unsigned int at = atomicAdd(&meta[0], 1u); if (at < MIXED_MAX) list[at] = i; else meta[1] = 1u; }
+}
+// which listed place owns its stretch (the first one inside it); the others are struck off before anything moves
+__global__ void k_mixed_own(const uint64_t *sk, int shift, uint32_t *list, unsigned int *meta)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int nl = meta[0] < MIXED_MAX ? meta[0] : MIXED_MAX;
+    if (t >= nl || meta[1]) return;
+    const uint32_t i = list[t];
+    const uint64_t top = sk[i] >> shift;
+    for (uint32_t h = i; h > 0 && (sk[h - 1] >> shift) == top;) {
+        h--;
+        if (h > 0 && sk[h] != sk[h - 1] && (sk[h - 1] >> shift) == top) { list[t] = HARC_NONE; return; }      // an earlier listed place
+        if (i - h > MIXED_BUDGET) { meta[1] = 1u; return; }
+    }
+}
+__global__ void k_mixed_fix(uint64_t *sk, uint32_t *ids, uint32_t n, int shift, const uint32_t *list, unsigned int *meta)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int nl = meta[0] < MIXED_MAX ? meta[0] : MIXED_MAX;
+    if (t >= nl || meta[1]) return;
+    const uint32_t i = list[t];
+    if (i == HARC_NONE) return;
+    const uint64_t top = sk[i] >> shift;
+    uint32_t h = i;
+    while (h > 0 && (sk[h - 1] >> shift) == top) h--;
+    uint32_t e = i + 1;
+    while (e < n && (sk[e] >> shift) == top) { e++; if (e - h > MIXED_BUDGET) { meta[1] = 1u; return; } }
+    uint32_t moves = 0;
+    for (uint32_t x = h + 1; x < e; x++) {                        // insertion sort: linear in the stretch plus its inversions
+        const uint64_t kx = sk[x]; const uint32_t vx = ids[x];
+        uint32_t y = x;
+        while (y > h && sk[y - 1] > kx) { sk[y] = sk[y - 1]; ids[y] = ids[y - 1]; y--; if (++moves > MIXED_BUDGET) { meta[1] = 1u; return; } }
+        if (y != x) { sk[y] = kx; ids[y] = vx; }
+    }
+}
+__global__ void k_scramble_keys(uint64_t *keys, uint32_t n, unsigned rot)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = rotl64(key_scramble(keys[i]), rot);
+}
+__global__ void k_rotate_keys(uint64_t *keys, uint32_t n, unsigned rot)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = rotl64(keys[i], rot);
 }
 __global__ void k_place_keys(const uint64_t *skeys, const uint32_t *binstart, uint32_t nbins, uint64_t cap, uint64_t *v)
 {
@@ -1915,16 +1976,38 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     uint64_t *k1 = nullptr; uint32_t *h0 = nullptr, *b0 = nullptr, *bs = nullptr;
     RC_TRY(dalloc(c, &k1, n)); RC_TRY(dalloc(c, &h0, n)); RC_TRY(dalloc(c, &b0, n)); RC_TRY(dalloc(c, &bs, n));
     const unsigned g = (n + 255) / 256;
-    HIP_TRY(hipMemsetAsync(d->d_nbins, 0, 8, c->stream));
-    hipLaunchKernelGGL(k_scramble_keys, dim3(g), dim3(256), 0, c->stream, keys, n);
-    RC_TRY(prim_sort_pairs_u64_u32(c, keys, k1, ids, d->ids, n, 64));           // stable: ids ascending inside a bin (reorder.cpp:372-384)
-    hipLaunchKernelGGL(k_mark_heads, dim3(g), dim3(256), 0, c->stream, k1, n, h0);
-    RC_TRY(prim_excl_scan_u32(c, h0, b0, n));
-    hipLaunchKernelGGL(k_bin_starts, dim3(g), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins);
-    HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
+    // top bits the sort looks at: log2(n) + 8, in whole radix digits, all 64 from 2^36 keys on (HARC_AMD_SORT_BITS forces a count: tests use 8,
+    // where nearly every stretch is mixed, and 64)
+    unsigned sbits = 64;
+    { unsigned lg = 1; while (((uint64_t)1 << lg) < n) lg++; sbits = ((lg + 8 + 7) / 8) * 8; if (sbits > 64) sbits = 64; }
+    if (const char *e = getenv("HARC_AMD_SORT_BITS")) { const int x = atoi(e); if (x >= 1 && x <= 64) sbits = (unsigned)x; }
+    uint32_t *mixed = nullptr; unsigned int *mmeta = nullptr; uint64_t *k2 = nullptr;
+    RC_TRY(dalloc(c, &mixed, MIXED_MAX)); RC_TRY(dalloc(c, &mmeta, 4));
+    if (sbits < 64) RC_TRY(dalloc(c, &k2, n));
+    hipLaunchKernelGGL(k_scramble_keys, dim3(g), dim3(256), 0, c->stream, keys, n, sbits < 64 ? sbits : 0u);
     uint32_t nbins = 0;
-    HIP_TRY(hipMemcpyAsync(&nbins, d->d_nbins, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (;;) {
+        HIP_TRY(hipMemsetAsync(mmeta, 0, 16, c->stream));
+        HIP_TRY(hipMemsetAsync(d->d_nbins, 0, 8, c->stream));
+        if (sbits < 64) {
+            RC_TRY(prim_sort_pairs_u64_u32(c, keys, k2, ids, d->ids, n, sbits));       // stable: ids ascending inside a bin (reorder.cpp:372-384)
+            hipLaunchKernelGGL(k_mixed_find, dim3(g), dim3(256), 0, c->stream, (const uint64_t *)k2, n, sbits, k1, mixed, mmeta);
+            hipLaunchKernelGGL(k_mixed_own, dim3(MIXED_MAX / 256), dim3(256), 0, c->stream, (const uint64_t *)k1, (int)(64 - sbits), mixed, mmeta);
+            hipLaunchKernelGGL(k_mixed_fix, dim3(MIXED_MAX / 256), dim3(256), 0, c->stream, k1, d->ids, n, (int)(64 - sbits), (const uint32_t *)mixed, mmeta);
+        } else RC_TRY(prim_sort_pairs_u64_u32(c, keys, k1, ids, d->ids, n, 64));
+        hipLaunchKernelGGL(k_mark_heads, dim3(g), dim3(256), 0, c->stream, k1, n, h0);
+        RC_TRY(prim_excl_scan_u32(c, h0, b0, n));
+        hipLaunchKernelGGL(k_bin_starts, dim3(g), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins);
+        unsigned int mm[2] = { 0, 0 };
+        HIP_TRY(hipMemcpyAsync(&nbins, d->d_nbins, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(mm, mmeta, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[index] sort on the top %u bits: %u places where different keys share them%s\n", sbits, mm[0], mm[1] ? " -- too many or too long, sorting on all bits" : "");
+        if (!mm[1] || sbits == 64) break;
+        hipLaunchKernelGGL(k_rotate_keys, dim3(g), dim3(256), 0, c->stream, keys, n, 64u - sbits);      // back to the scrambled keys as they are
+        sbits = 64;
+    }
+    HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
     d->nbins = nbins;
     {
         uint64_t *v = keys, *q = nullptr;                          // the unsorted keys are not needed any more
