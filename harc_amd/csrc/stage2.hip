@@ -311,20 +311,23 @@ __device__ __forceinline__ uint64_t rc_key3(uint64_t key, int n)
 #ifndef BLOOM4_M
 #define BLOOM4_M 15
 #endif
-__device__ __forceinline__ uint32_t bloom4_mmer(uint64_t key)
+// (The bitmap is addressed by the k-mer in a 2-BIT code of its own -- A0 C1 G2 T3, the consensus bytes & 3, base b at bits 2b: the consensus holds
+// no N, so a dictionary key with an N in it can match nothing and is left out, and a 21-mer is 42 bits instead of 63: the m-mer hash is one
+// 32-bit multiplication, the roll from one window to the next a 64-bit shift.  k_realign_propose1 hashes 3.6 G of them at configs[2].)
+__device__ __forceinline__ uint32_t bloom4_mmer(uint64_t fk)
 {
-    uint32_t h = ((uint32_t)key * 0x9E3779B1u) ^ (((uint32_t)(key >> 32) & ((1u << (3 * BLOOM4_M - 32)) - 1u)) * 0x85EBCA77u);      // the low 3 M bits: M bases
+    const uint32_t h = ((uint32_t)fk & ((1u << (2 * BLOOM4_M)) - 1u)) * 0x9E3779B1u;      // the low 2 M bits: M bases
     return h ^ (h >> 15);
 }
-__device__ __forceinline__ uint32_t bloom4_minimizer(uint64_t key, int nwin)
+__device__ __forceinline__ uint32_t bloom4_minimizer(uint64_t fk, int nwin)
 {
     uint32_t best = 0xFFFFFFFFu;
-    for (int i = 0; i < nwin; i++) { const uint32_t x = bloom4_mmer(key >> (3 * i)); best = x < best ? x : best; }
+    for (int i = 0; i < nwin; i++) { const uint32_t x = bloom4_mmer(fk >> (2 * i)); best = x < best ? x : best; }
     return best;
 }
-__device__ __forceinline__ void bloom4_pos(uint64_t key, uint32_t minz, int nwin, int lbits, uint32_t *word, int *sh0, int *sh1)
+__device__ __forceinline__ void bloom4_pos(uint64_t fk, uint32_t minz, int nwin, int lbits, uint32_t *word, int *sh0, int *sh1)
 {
-    uint32_t kh = ((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) * 0x85EBCA77u);
+    uint32_t kh = ((uint32_t)fk * 0x9E3779B1u) ^ ((uint32_t)(fk >> 32) * 0x85EBCA77u);
     kh ^= kh >> 15; kh *= 0xC2B2AE3Du; kh ^= kh >> 13;
     uint32_t lh = nwin > 0 ? minz * 0x9E3779B1u : kh * 0x165667B1u;
     lh ^= lh >> 15; lh *= 0x85EBCA77u; lh ^= lh >> 13;
@@ -336,10 +339,16 @@ __global__ void k_bloom4_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = keys[i];
+    uint64_t f = 0, r = 0;                                        // the k-mer and its reverse complement in the 2-bit code
+    for (int b = 0; b < nb; b++) {
+        const uint32_t c3 = (uint32_t)(k >> (3 * b)) & 7u;
+        if (c3 & 1u) return;                                      // an N: no window of the consensus equals this key
+        const uint64_t idx = ((c3 >> 2) & 1u) | (c3 & 2u);       // A 000 -> 0, C 100 -> 1, G 010 -> 2, T 110 -> 3
+        f |= idx << (2 * b); r |= (3u - idx) << (2 * (nb - 1 - b));
+    }
     uint32_t w; int a, b;
-    bloom4_pos(k, bloom4_minimizer(k, nwin), nwin, lbits, &w, &a, &b);
+    bloom4_pos(f, bloom4_minimizer(f, nwin), nwin, lbits, &w, &a, &b);
     atomicOr(&bloom[w], ((1u << l) << a) | ((1u << l) << b));
-    const uint64_t r = rc_key3(k, nb);
     bloom4_pos(r, bloom4_minimizer(r, nwin), nwin, lbits, &w, &a, &b);
     atomicOr(&bloom[w], ((4u << l) << a) | ((4u << l) << b));
 }
@@ -451,8 +460,8 @@ template <int W, int NWIN> __global__ __launch_bounds__(256) void k_realign_prop
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
     const int t0 = threadIdx.x * RSTRIP;
-    uint64_t k = 0;
-    for (int b = 0; b < n; b++) k |= (uint64_t)idx_to_c3(tile[t0 + b] & 3) << (3 * b);
+    uint64_t k = 0;                                               // the window in the bitmap's 2-bit code (bloom4_mmer)
+    for (int b = 0; b < n; b++) k |= (uint64_t)(tile[t0 + b] & 3) << (2 * b);
     const uint32_t *bloom = s.bloom[0]; const int lbits = s.bloom_lbits;
     // the keys of the strip; with minimizers also the m-mers at the NWIN - 1 positions behind it (the m-mer at p is the low end of key p)
     constexpr int NK = RSTRIP + (NWIN > 0 ? NWIN - 1 : 0);
@@ -461,7 +470,7 @@ template <int W, int NWIN> __global__ __launch_bounds__(256) void k_realign_prop
     for (int c = 0; c < NK; c++) {
         if (c < RSTRIP) keys[c] = k;
         mm[c] = bloom4_mmer(k);
-        k = (k >> 3) | ((uint64_t)idx_to_c3(tile[t0 + c + n] & 3) << (3 * (n - 1)));
+        k = (k >> 2) | ((uint64_t)(tile[t0 + c + n] & 3) << (2 * (n - 1)));
     }
     // where the key of every column of the strip sits in the bitmap ...
 #pragma unroll
