@@ -612,16 +612,30 @@ static int spit_stream_to(harc_amd_ctx *c, int id, int shard, const std::string 
     return spit_file(path, p, n);
 }
 // read_{seq,pos,noise,noisepos,rev}.txt.<first_shard + e> (+ .tail): the per-shard family of encoder.cpp:190-196
+// Stream by stream, the largest first: when HARC_AMD_READY_FD names an open descriptor (./harc passes a pipe), the name of every stream is
+// written to it as soon as all its shard files are closed, and ./harc starts that stream's stage-III coder (harc:102-109) while the next
+// stream is still being written.
+static void announce_stream(const char *stem)
+{
+    const char *e = getenv("HARC_AMD_READY_FD");
+    if (!e) return;
+    const int fd = atoi(e);
+    if (fd < 3) return;
+    const std::string line = std::string(stem) + "\n";
+    (void)!write(fd, line.data(), line.size());
+}
 static int write_shard_family(harc_amd_ctx *c, const std::string &od, int first_shard)
 {
-    static const struct { int id; const char *name; } files[] = {
-        { HARC_AMD_S2_SEQ, "read_seq.txt" }, { HARC_AMD_S2_POS, "read_pos.txt" }, { HARC_AMD_S2_NOISE, "read_noise.txt" },
-        { HARC_AMD_S2_NOISEPOS, "read_noisepos.txt" }, { HARC_AMD_S2_REV, "read_rev.txt" } };
-    for (int e = 0; e < c->P.num_thr; e++) {
-        const std::string sfx = "." + std::to_string(first_shard + e);
-        for (auto &fd : files) RC_TRY(spit_stream_to(c, fd.id, e, od + fd.name + sfx));
-        RC_TRY(spit_stream_to(c, HARC_AMD_S2_SEQ_TAIL, e, od + "read_seq.txt" + sfx + ".tail"));
-        RC_TRY(spit_stream_to(c, HARC_AMD_S2_REV_TAIL, e, od + "read_rev.txt" + sfx + ".tail"));
+    static const struct { int id; const char *name; int tail; } files[] = {
+        { HARC_AMD_S2_SEQ, "read_seq", HARC_AMD_S2_SEQ_TAIL }, { HARC_AMD_S2_POS, "read_pos", -1 }, { HARC_AMD_S2_NOISE, "read_noise", -1 },
+        { HARC_AMD_S2_NOISEPOS, "read_noisepos", -1 }, { HARC_AMD_S2_REV, "read_rev", HARC_AMD_S2_REV_TAIL } };
+    for (auto &fd : files) {
+        for (int e = 0; e < c->P.num_thr; e++) {
+            const std::string path = od + fd.name + ".txt." + std::to_string(first_shard + e);
+            RC_TRY(spit_stream_to(c, fd.id, e, path));
+            if (fd.tail >= 0) RC_TRY(spit_stream_to(c, fd.tail, e, path + ".tail"));
+        }
+        if (first_shard == 0) announce_stream(fd.name);
     }
     return HARC_AMD_OK;
 }

@@ -106,3 +106,48 @@ def test_stage3_failing_job_fails_the_run(tmp_path):
     r = _run(["-c", str(fq)], env)
     assert r.returncode != 0 and "a stage III job failed" in r.stdout
     assert not (tmp_path / "s.harc").exists()
+
+
+def test_stage3_starts_while_the_stage_program_still_writes(tmp_path):
+    """the stage program names a stream on descriptor HARC_AMD_READY_FD when all its shard files are closed (ingest.hip write_shard_family); the
+    driver must start that stream's tar + coder at once: the stand-in announces read_seq, waits, and finds read_seq.tar(.xz) already there
+    before it writes the next stream.  A failing stage program still fails the run with jobs in flight."""
+    fq, env = _setup(tmp_path)
+    stub = tmp_path / "stage_stub.sh"
+    body = STUB.replace("""    for ((e = 0; e < E; e++)); do
+        for s in read_seq read_pos read_noise read_noisepos read_rev; do head -c $((20000 + 977 * e)) /dev/zero | tr '\\0' 'A' > $out/$s.txt.$e; done
+        printf 'AC' > $out/read_seq.txt.$e.tail; printf '1' > $out/read_rev.txt.$e.tail
+    done
+""", """    for s in read_seq read_pos read_noise read_noisepos read_rev; do
+        for ((e = 0; e < E; e++)); do head -c $((20000 + 977 * e)) /dev/zero | tr '\\0' 'A' > $out/$s.txt.$e; done
+        if [ $s = read_seq ]; then for ((e = 0; e < E; e++)); do printf 'AC' > $out/read_seq.txt.$e.tail; done; fi
+        if [ $s = read_rev ]; then for ((e = 0; e < E; e++)); do printf '1' > $out/read_rev.txt.$e.tail; done; fi
+        echo $s >&$HARC_AMD_READY_FD
+        if [ $s = read_seq ]; then
+            for i in $(seq 50); do ls $out/read_seq.tar* > /dev/null 2>&1 && { touch $base/overlap_seen; break; }; sleep 0.1; done
+            [ -n "$STUB_FAIL" ] && exit 7
+        fi
+    done
+""")
+    assert body != STUB
+    stub.write_text(body)
+    for packer in ("xz", "none"):
+        env["HARC_AMD_STAGE3"] = packer
+        r = _run(["-c", str(fq), "-t", "3"], env)
+        assert r.returncode == 0, r.stdout[-2000:]
+        assert (tmp_path / "overlap_seen").exists(), "read_seq was not packed while the stage program was still writing"
+        (tmp_path / "overlap_seen").unlink()
+        with tarfile.open(tmp_path / "s.harc") as tf:
+            names = sorted(os.path.basename(n) for n in tf.getnames() if os.path.basename(n) not in ("", "."))
+        for s in ["read_seq.tar", "read_pos.tar", "read_noise.tar", "read_noisepos.tar", "read_rev.tar"]:
+            assert (s + ".xz" if packer == "xz" else s) in names, names
+        assert ".ready" not in names
+        r = _run(["-d", str(tmp_path / "s.harc")], env)
+        assert r.returncode == 0, r.stdout[-2000:]
+        sums = dict(reversed(l.split(None, 1)) for l in (tmp_path / "s.dna.d").read_text().splitlines())
+        for e in range(3):
+            assert sums[f"./read_seq.txt.{e}"] == hashlib.sha256(b"A" * (20000 + 977 * e)).hexdigest() and f"./read_seq.txt.{e}.tail" in sums
+        (tmp_path / "s.harc").unlink(); (tmp_path / "s.dna.d").unlink()
+    env["STUB_FAIL"] = "1"
+    r = _run(["-c", str(fq), "-t", "3"], env)
+    assert r.returncode != 0 and not (tmp_path / "s.harc").exists() and not (tmp_path / "output").exists()
