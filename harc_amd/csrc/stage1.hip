@@ -62,6 +62,12 @@ struct S1Args {
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
 };
 #define PG_CHUNK 8u
+#ifndef HARC_W0_MUL
+#define HARC_W0_MUL 2
+#endif
+#ifndef HARC_W0_ADD
+#define HARC_W0_ADD 16
+#endif
 #ifdef HARC_TIMING
 #define TICK(k) do { const long long tn_ = clock64(); tacc[k] += (unsigned long long)(tn_ - tlast); tlast = tn_; } while (0)
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(v, o, 64); v = x > v ? x : v; } return v; }
@@ -1057,7 +1063,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             // 4-byte lookup (48: configs[2] chains 768 -> 728 ms); with the bitmap's lines chosen by minimizer it shares the lines of the
             // useful probes (64).  With few chains a round trip costs more than the probes (QUAD: 64).
             int bend;
-            { int w0 = bi == 0 ? ((2 * (lastp >> 4) + 16 + 15) & ~15) : 64; const int wmax = QUAD ? 64 : (bi <= 1 ? s.firstmax : 64); if (w0 > wmax) w0 = wmax; bend = base + w0; }
+            { int w0 = bi == 0 ? ((HARC_W0_MUL * (lastp >> 4) + HARC_W0_ADD + 15) & ~15) : 64; const int wmax = QUAD ? 64 : (bi <= 1 ? s.firstmax : 64); if (w0 > wmax) w0 = wmax; bend = base + w0; }
             if (bend > s.nprobe) bend = s.nprobe;
             if (bend <= base) bend = s.nprobe;
             const int p = base + lane; dbg_batches++;
