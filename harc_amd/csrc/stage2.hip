@@ -662,14 +662,21 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
     __builtin_amdgcn_wave_barrier();
     uint32_t top = estart[ei]; if (top > cnt) top = cnt;
     uint32_t seen = 0, pos = top; bool ch = false, leading = true;   // wave-uniform
+    // Two chunks of 64 in flight: a look is a chain of dependent round trips (ids -> claims -> candidates) per chunk: the ids of chunk k + 2 and
+    // the claims of chunk k + 1 are requested before chunk k is worked on (k_realign_big 2.57 -> 2.40 ms per pass on c3sd; eight chunks in flight
+    // cost the many short looks more than they saved the long ones: 2.9 ms).  A claim read a little earlier may be staler: the fixed point only
+    // needs values that were true at some time, see above.
+    const uint32_t *const idl = s.ids[l] + st;
+    uint32_t pos1 = pos > 64 ? pos - 64 : 0;
+    uint32_t rid = (uint32_t)lane < pos ? idl[pos - 1 - lane] : 0u;
+    uint32_t rid1 = (uint32_t)lane < pos1 ? idl[pos1 - 1 - lane] : 0u;
+    unsigned long long b = (uint32_t)lane < pos ? __hip_atomic_load(&s.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
     while (pos > 0 && seen < (uint32_t)s.maxsearch) {             // highest id first
+        const uint32_t pos2 = pos1 > 64 ? pos1 - 64 : 0;
+        const unsigned long long b1 = (uint32_t)lane < pos1 ? __hip_atomic_load(&s.best[rid1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+        const uint32_t rid2 = (uint32_t)lane < pos2 ? idl[pos2 - 1 - lane] : 0u;
         const bool valid = (uint32_t)lane < pos;
-        uint32_t rid = 0; unsigned long long b = 0; bool un = false;
-        if (valid) {
-            rid = s.ids[l][st + pos - 1 - lane];
-            b = __hip_atomic_load(&s.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            un = b >= tp;                                          // not claimed before this probe (claimed BY this probe in an earlier pass counts as visible)
-        }
+        const bool un = valid && b >= tp;                          // not claimed before this probe (claimed BY this probe in an earlier pass counts as visible)
         const unsigned long long um = __ballot(un);
         if (leading) {                                             // the claimed reads on top stay claimed for this event
             if (um == 0) top -= (uint32_t)__popcll(__ballot(valid));
@@ -692,7 +699,7 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
             }
         }
         seen += (uint32_t)__popcll(um);
-        pos -= pos > 64 ? 64 : pos;
+        pos = pos1; pos1 = pos2; rid = rid1; rid1 = rid2; b = b1;
     }
     ch = __ballot(ch) != 0;
     if (lane == 0) { estart[ei] = top; lastpass[ei] = cnt <= (uint32_t)s.maxsearch ? EV_DONE : pass; if (ch) { atomicMin(mymin + cur, stamp | tp); atomicOr(changed, 1u); } }
