@@ -1661,20 +1661,28 @@ template <int NT> __global__ __launch_bounds__(NT) void k_reseed(S1Args s)
 // 64 workgroups on 256 CUs): once after counting (chains that want a seed per workgroup + unclaimed reads per workgroup's words; more
 // passes, one meeting each, only when a million bits below the cursor do not hold enough unclaimed reads), once for the look-ahead; the
 // read id where the seeds end travels through a flag.  What is computed is the single workgroup's result (the oracle's), id for id.
-// g = [0] meeting counter [1] flag: 2 + cursor after the seeds [2..3] unused [4 .. 4+4G) per workgroup: chains wanting a seed, unclaimed
+// g = [0] meeting counter [1] flag: 2 + cursor after the seeds [2] a wait ran out (sticky) [3] unused [4 .. 4+4G) per workgroup: chains wanting a seed, unclaimed
 // reads of the pass (two sets, even and odd passes), unclaimed reads of the look-ahead window.  k_resolve zeroes g[0..1] before every launch.
 #define RESEED_NT 256
 #define RESEED_G 64
 #ifndef RESEED_ONE_SET
 #define RESEED_ONE_SET 0     // 1 (make variant VFLAGS=-DRESEED_ONE_SET=1): the race of round 3 back in, to see tests/test_gpu_config_size.py's stress test fail
 #endif
+// (every wait is bounded: a meeting that does not happen within ~2^24 polls -- seconds; it takes microseconds -- raises g[2] and lets everybody
+// through, the kernel ends with a meaningless result and the host fails the run at its next look at the flag, instead of a GPU that never
+// comes back: with one set of per-pass counts workgroups could disagree on the last pass and wait for each other for ever)
+#define RESEED_SPIN_LIMIT (1u << 24)
 __device__ __forceinline__ void grid_meet(unsigned int *cnt, unsigned int target)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
         atomicAdd(cnt, 1u);
-        while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > RESEED_SPIN_LIMIT || __hip_atomic_load(cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { __hip_atomic_store(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
         __threadfence();
     }
     __syncthreads();
@@ -1749,7 +1757,14 @@ __global__ __launch_bounds__(RESEED_NT) void k_reseed_mg(S1Args s, unsigned int 
         if (newclaim) s.claimed[wi] |= newclaim;                   // every word has one owner
         if (assigned + total >= R) {                               // the seeds are all found: everybody waits for the place of the last one
             assigned = R;
-            if (t == 0) { unsigned int f; while ((f = __hip_atomic_load(g + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(1); spre[2][0] = f; }
+            if (t == 0) {
+                unsigned int f, spins = 0;
+                while ((f = __hip_atomic_load(g + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > RESEED_SPIN_LIMIT || __hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { __hip_atomic_store(g + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); f = 2u; break; }
+                }
+                spre[2][0] = f;
+            }
             __syncthreads();
             look = (long long)spre[2][0] - 2;
             break;
@@ -2379,6 +2394,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         if (seq_probe < 2) HIP_TRY(hipEventRecord(R.eb[1], c->stream));
         HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
         if (nlarge) HIP_TRY(hipMemcpyAsync(h_stats + ST_N, a.coopcnt, HARC_COOPCNT * 8, hipMemcpyDeviceToHost, c->stream));
+        unsigned int reseed_timeout = 0;
+        if (reseed_mg) HIP_TRY(hipMemcpyAsync(&reseed_timeout, a.reseed_g + 2, 4, hipMemcpyDeviceToHost, c->stream));
         if (cm) {
             HIP_TRY(hipMemsetAsync(x_dig, 0, 8 * 8, c->stream));
             hipLaunchKernelGGL(k_replica_digest, dim3(1024), dim3(256), 0, c->stream, a, (unsigned long long)nwords, x_dig);
@@ -2387,6 +2404,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
+        if (reseed_timeout) { harc_set_error("stage I: the workgroups of k_reseed_mg did not meet (super-round %llu); HARC_AMD_RESEED_MG=0 uses the single workgroup", (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
         if (cm) {   // the replicas must agree (k_replica_digest): a rank that drifted would hang the others in the next all-gather, or worse
             uint64_t mine[8], all[8 * 64];
             if (a.own_mod > 64) { harc_set_error("design (R): at most 64 ranks"); return HARC_AMD_EINVAL; }
