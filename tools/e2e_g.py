@@ -38,7 +38,8 @@ for spec in (sys.argv[3:] or ["bucket", "replicate"]):
     got = np.fromfile(os.path.join(d, "x.dna.d"), dtype=np.uint8)
     ok = got.size == want.size and bool((got.reshape(-1, L + 1) == want).all())
     ok_all &= ok
-    print(f"{spec}: ./harc -c -g {ranks} -p {t1-t0:.1f}s, archive {os.path.getsize(arc)/1e6:.1f} MB (raw streams), ./harc -d -p {t2-t1:.1f}s, "
+    gflag = "" if mode == "single" else f" -g {ranks}"
+    print(f"{spec}: ./harc -c{gflag} -p {t1-t0:.1f}s, archive {os.path.getsize(arc)/1e6:.1f} MB (raw streams), ./harc -d -p {t2-t1:.1f}s, "
           f"{n} reads back in file order: {'ok' if ok else 'FAILED'}", flush=True)
     shutil.rmtree(d, ignore_errors=True)
 shutil.rmtree(root, ignore_errors=True)
