@@ -363,7 +363,7 @@ __global__ void k_place_keys(const uint64_t *skeys, const uint32_t *binstart, ui
 // `start`: one dependent load less on every hit.
 __global__ void k_table_place(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, uint32_t nbins, uint32_t n, const uint64_t *q,
                               HashSlot *slots, uint64_t cap, uint32_t bigthresh,
-                              unsigned long long *large_list, unsigned int *large_n, uint32_t large_max, uint32_t large_tag, uint32_t *nbins_p, int pass, uint32_t first_block)
+                              unsigned long long *large_list, unsigned int *large_n, uint32_t large_max, uint32_t large_tag, uint32_t *nbins_p, int pass, uint32_t first_block, int fill)
 {
     if (blockIdx.x < first_block) return;                                          // pass 1: the bins beyond the end of the table are among the last
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,6 +381,15 @@ __global__ void k_table_place(const uint64_t *skeys, const uint32_t *sids, const
     if (pass == 0 && (sl & 3) == 0 && (uint64_t)i + 4 < (uint64_t)nbins) {
         const uint64_t s3 = q[i + 3] - (uint64_t)nbins + (uint64_t)(i + 3);
         if (s3 == sl + 3 && (bucket_slot(skeys[binstart[i + 4]], cap) >> 2) <= (sl >> 2)) ovf = SLOT_OVF;
+    }
+    // fill: the table has NOT been cleared (22 GB per dictionary at configs[2], 4.5 ms): slots grow with the bin index, so every bin also
+    // writes the empty slots between its predecessor and itself (three on average at load factor 1/4), and the last bin inside the table those
+    // behind it -- every slot is written exactly once.  (The host clears the table instead when bins are few and the gaps long.)
+    if (pass == 0 && fill) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (uint64_t x = i ? (q[i - 1] - (uint64_t)nbins + (uint64_t)(i - 1)) + 1 : 0; x < sl; x++) *reinterpret_cast<uint4 *>(&slots[x]) = z;
+        if (i + 1 == nbins || q[i + 1] - (uint64_t)nbins + (uint64_t)(i + 1) >= cap)
+            for (uint64_t x = sl + 1; x < cap; x++) *reinterpret_cast<uint4 *>(&slots[x]) = z;
     }
     const uint32_t en = (i + 1 < nbins) ? binstart[i + 1] : n;
     const uint32_t cnt = en - st;
@@ -2028,7 +2037,9 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
         hipLaunchKernelGGL(k_rotate_keys, dim3(g), dim3(256), 0, c->stream, keys, n, 64u - sbits);      // back to the scrambled keys as they are
         sbits = 64;
     }
-    HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
+    // the placement clears the table on its way when the gaps between bins are short (fill); a table of few bins is cleared here
+    const int fill = getenv("HARC_AMD_TABLE_FILL") ? atoi(getenv("HARC_AMD_TABLE_FILL")) != 0 : (uint64_t)nbins * 16 >= d->cap;
+    if (!fill) HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
     d->nbins = nbins;
     {
         uint64_t *v = keys, *q = nullptr;                          // the unsorted keys are not needed any more
@@ -2038,7 +2049,7 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
         RC_TRY(prim_incl_max_u64(c, v, q, nbins));
         for (int pass = 0; pass < 2; pass++)
             hipLaunchKernelGGL(k_table_place, dim3(gb), dim3(256), 0, c->stream, (const uint64_t *)k1, (const uint32_t *)d->ids, (const uint32_t *)bs, nbins, n, (const uint64_t *)q,
-                               d->slots, d->cap, d->bigthresh, d->large_list, d->large_n, d->large_max, d->large_tag, d->d_nbins, pass, pass == 0 ? 0u : (gb > 64 ? gb - 64 : 0u));
+                               d->slots, d->cap, d->bigthresh, d->large_list, d->large_n, d->large_max, d->large_tag, d->d_nbins, pass, pass == 0 ? 0u : (gb > 64 ? gb - 64 : 0u), fill);
     }
     HIP_TRY(hipGetLastError());
     uint32_t nb2[2] = { 0, 0 };
