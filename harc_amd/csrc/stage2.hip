@@ -34,6 +34,7 @@ struct S2Args {
     const uint32_t *chead;             // nC: read index of each contig head
     const HashSlot *slots[2]; uint64_t cap[2]; const uint32_t *ids[2];
     unsigned long long *best;          // T
+    unsigned long long *bestbin[2];    // k_realign_big: best[] once more in the order of ids[l] (refreshed before every window pass): a look reads 64 claims in one line instead of 64 lines
     const uint32_t *bloom[2]; int bloom_shift[2];   // one-hash bitmap over the keys of each dictionary (16 bits per key): most windows match nothing
     int bloom_lbits, bloom_nwin;                    // combined bitmap (k_bloom4_set): log2 of its 64-byte lines; minimizer windows per key (0: lines hashed from the key)
     const uint64_t *cons2;             // consensus, 2-bit code A0 G1 C2 T3, 32 columns per word (k_pack_cons2)
@@ -599,6 +600,12 @@ __global__ void k_ev_key_bin(const uint4 *ev, const uint32_t *idx, uint32_t nev,
     const uint4 e = ev[idx[i]];
     key[i] = ((uint64_t)(e.x & 1u) << 32) | e.z;                  // (dictionary, first id index of the bin)
 }
+// the events once more in (bin, tuple) order: a look starts with its event, and through perm[] that was two dependent round trips
+__global__ void k_ev_gather(const uint4 *ev, const uint32_t *perm, uint32_t nev, uint4 *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nev) out[i] = ev[perm[i]];
+}
 __global__ void k_ev_heads(const uint64_t *key, uint32_t nev, uint32_t *head)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -622,6 +629,19 @@ __global__ void k_ev_rank(uint32_t *seg, uint32_t nev, unsigned int *maxrank)
 // every event of a bin look again whenever ANY claim of the bin moved: once the ranges had settled, 16 more passes of 13 ms over all
 // events of the deep bins while a handful of claims moved between the two dictionaries -- c3sd with another stage-I schedule: 220 ms.)
 #define EV_TBITS 40
+// The claims in bin order.  A look used to gather best[ids[l][..]] -- 64 random 8-byte loads per chunk, ~2 G of them per step on a repeat-rich
+// 50 M-read set; a deep bin is looked at by hundreds of thousands of events that all want the same entries.  Before every pass one thread per
+// (dictionary, entry) copies the claim of that entry's read next to its neighbours in the bin, and the looks read claims as they read ids: one
+// line per chunk.  A claim made during a pass goes to best[] (the truth: atomicMin decides) and to the claimed entry of the bin being looked
+// at; the read's entry in the OTHER dictionary's bin, and anything read a little late, is staler than best[] -- values that were true at some
+// time, which is all the fixed point needs (above: stale claims are later claims, they can only keep an event from claiming, and the bin is
+// marked for another look); the pass that ends it changes nothing, so it saw the truth.
+__global__ void k_bestbin_refresh(const unsigned long long *best, const uint32_t *ids0, const uint32_t *ids1, uint32_t T, unsigned long long *bb0, unsigned long long *bb1)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    bb0[i] = best[ids0[i]]; bb1[i] = best[ids1[i]];
+}
 // one event (probe e, at position ei of the pass order), one wave.  validate: an event that looked in the previous pass and finds no earlier
 // claim on its bin since is validated without looking.  Returns whether a claim moved (wave-uniform).
 __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint32_t e, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
@@ -645,14 +665,22 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
     }
     if (estart[ei] == 0) { if (lane == 0) lastpass[ei] = EV_DONE; return false; }      // every read of the bin was claimed before this event: claims only move to earlier tuples
     if (s.trace && lane == 0) atomicAdd(changed + 2, 1u);         // trace only: events that look (one word: it serialises them)
-    // 3-bit window words (forward or reverse complement), lanes 0..W3-1 build one word each
+    // 3-bit window words (forward or reverse complement).  One lane per base fetches its code from the packed consensus (A0 G1 C2 T3 there, twice
+    // that in the 3-bit code; complement = 3 - code) into LDS, then lanes 0..W3-1 put one word together each -- five lanes walking 21 dependent
+    // byte loads each from global memory were the longest wait of a look (c3sd: the five large passes 32 -> 26 ms)
+    uint8_t *const sc3 = reinterpret_cast<uint8_t *>(swin + HARC_MAXW3);
+    for (int b = lane; b < L; b += 64) {
+        const uint64_t g = x + (uint64_t)(dir ? L - 1 - b : b);
+        const uint32_t c2 = (uint32_t)(s.cons2[g >> 5] >> (2 * (g & 31))) & 3u;
+        sc3[b] = (uint8_t)((dir ? 3u - c2 : c2) << 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (lane < W3) {
-        const uint8_t *win = s.cons + x;
         unsigned long long v = 0;
         const int b0 = (64 * lane) / 3, b1 = (64 * lane + 63) / 3;
         for (int b = b0; b <= b1 && b < L; b++) {
-            const int idx = dir ? 3 - (int)(win[L - 1 - b] & 3) : (int)(win[b] & 3);
-            const unsigned long long c3 = (unsigned long long)idx_to_c3(idx);
+            const unsigned long long c3 = (unsigned long long)sc3[b];
             const int sh = 3 * b - 64 * lane;
             v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
         }
@@ -662,19 +690,16 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
     __builtin_amdgcn_wave_barrier();
     uint32_t top = estart[ei]; if (top > cnt) top = cnt;
     uint32_t seen = 0, pos = top; bool ch = false, leading = true;   // wave-uniform
-    // Two chunks of 64 in flight: a look is a chain of dependent round trips (ids -> claims -> candidates) per chunk: the ids of chunk k + 2 and
-    // the claims of chunk k + 1 are requested before chunk k is worked on (k_realign_big 2.57 -> 2.40 ms per pass on c3sd; eight chunks in flight
-    // cost the many short looks more than they saved the long ones: 2.9 ms).  A claim read a little earlier may be staler: the fixed point only
-    // needs values that were true at some time, see above.
+    // claims from the bin-ordered copy (k_bestbin_refresh), the next chunk's requested before this one is worked on (more in flight -- two ahead with
+    // the gathered claims, eight, or four at once with the copy -- cost the many short looks more than they saved the long ones); ids only for
+    // the candidates tested
     const uint32_t *const idl = s.ids[l] + st;
+    unsigned long long *const bbl = s.bestbin[l] + st;
     uint32_t pos1 = pos > 64 ? pos - 64 : 0;
-    uint32_t rid = (uint32_t)lane < pos ? idl[pos - 1 - lane] : 0u;
-    uint32_t rid1 = (uint32_t)lane < pos1 ? idl[pos1 - 1 - lane] : 0u;
-    unsigned long long b = (uint32_t)lane < pos ? __hip_atomic_load(&s.best[rid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+    unsigned long long b = (uint32_t)lane < pos ? __hip_atomic_load(&bbl[pos - 1 - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
     while (pos > 0 && seen < (uint32_t)s.maxsearch) {             // highest id first
         const uint32_t pos2 = pos1 > 64 ? pos1 - 64 : 0;
-        const unsigned long long b1 = (uint32_t)lane < pos1 ? __hip_atomic_load(&s.best[rid1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
-        const uint32_t rid2 = (uint32_t)lane < pos2 ? idl[pos2 - 1 - lane] : 0u;
+        const unsigned long long b1 = (uint32_t)lane < pos1 ? __hip_atomic_load(&bbl[pos1 - 1 - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
         const bool valid = (uint32_t)lane < pos;
         const bool un = valid && b >= tp;                          // not claimed before this probe (claimed BY this probe in an earlier pass counts as visible)
         const unsigned long long um = __ballot(un);
@@ -684,10 +709,12 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
         }
         const uint32_t rank = (uint32_t)__popcll(um & ((1ULL << lane) - 1ULL));
         if (un && seen + rank < (uint32_t)s.maxsearch && b > tp) {
+            const uint32_t rid = idl[pos - 1 - lane];
             const uint64_t *r = s.cand3 + (size_t)rid * W3;
             int hd = 0;
             for (int w = 0; w < W3; w++) { hd += __popcll(swin[w] ^ r[w]); if (hd > s.thresh_s) break; }
             if (hd <= s.thresh_s && atomicMin(&s.best[rid], tp) > tp) {               // every passing candidate of the window is taken (encoder.cpp:296-317)
+                atomicMin(&bbl[pos - 1 - lane], tp);
                 ch = true;
                 // the read's bin in the other dictionary sees a claim at this tuple too
                 const int ol = 1 - l, off = 3 * s.ds[ol], wi = off >> 6, sh = off & 63;
@@ -699,7 +726,7 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
             }
         }
         seen += (uint32_t)__popcll(um);
-        pos = pos1; pos1 = pos2; rid = rid1; rid1 = rid2; b = b1;
+        pos = pos1; pos1 = pos2; b = b1;
     }
     ch = __ballot(ch) != 0;
     if (lane == 0) { estart[ei] = top; lastpass[ei] = cnt <= (uint32_t)s.maxsearch ? EV_DONE : pass; if (ch) { atomicMin(mymin + cur, stamp | tp); atomicOr(changed, 1u); } }
@@ -708,13 +735,13 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
 __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
                                                      uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, uint32_t rlo, uint32_t rhi, const uint32_t *order2)
 {
-    __shared__ unsigned long long swin[4][HARC_MAXW3];
+    __shared__ unsigned long long swin[4][HARC_MAXW3 + 32];            // the window words of a wave's event + 256 bytes for the codes they are made of
     const int wv = threadIdx.x >> 6;
     const uint32_t k = blockIdx.x * 4 + wv;
     if (k >= nev) return;                                         // nev: the events of the ranges this pass covers (order2) or all of them
     const uint32_t ei = order2 ? order2[k] : k;                   // estart / lastpass are indexed by the event's position in (bin, tuple) order
     uint32_t e = ei;
-    if (perm) { const uint32_t r = rank[ei]; if (r < rlo || r >= rhi) return; e = perm[ei]; }
+    if (perm) { const uint32_t r = rank[ei]; if (r < rlo || r >= rhi) return; }      // (with ranges s.events is in (bin, tuple) order already: k_ev_gather)
     (void)realign_event(s, ei, e, estart, changed, binmin0, binmin1, lastpass, pass, T1, swin[wv], true);
 }
 // The chaser.  All events of a pass look at the state the previous pass left, so a chain of events of one bin each of which acts on what
@@ -728,11 +755,11 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uin
 __global__ __launch_bounds__(256) void k_realign_chase(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
                                                        uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, const uint32_t *seglen, uint32_t rhi)
 {
-    __shared__ unsigned long long swin[4][HARC_MAXW3];
+    __shared__ unsigned long long swin[4][HARC_MAXW3 + 32];            // the window words of a wave's event + 256 bytes for the codes they are made of
     const int wv = threadIdx.x >> 6;
     const uint32_t i0 = blockIdx.x * 4 + wv;
     if (i0 >= nev || rank[i0] != 0) return;                       // one wave per bin: the first of its events in (bin, tuple) order
-    const uint4 ev0 = s.events[perm[i0]];
+    const uint4 ev0 = s.events[i0];
     const int l = (int)(ev0.x & 1u);
     const unsigned long long m = __hip_atomic_load((l ? binmin1 : binmin0) + (size_t)(pass & 1u) * T1 + ev0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((m >> EV_TBITS) != (unsigned long long)(~pass & 0xFFFFFFu)) return;       // no claim on this bin in the pass that just ran
@@ -741,13 +768,13 @@ __global__ __launch_bounds__(256) void k_realign_chase(S2Args s, uint32_t nev, u
     uint32_t lo = 0, hi = len;                                     // first event of the bin with a tuple above mt
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        const uint4 evm = s.events[perm[i0 + mid]];
+        const uint4 evm = s.events[i0 + mid];
         const unsigned long long tm = (unsigned long long)evm.x | ((unsigned long long)evm.y << 32);
         if (tm <= mt) lo = mid + 1; else hi = mid;
     }
     int quiet = 0;
     for (uint32_t j = lo, n = 0; j < len && n < EV_CHASE_MAX && quiet < EV_CHASE_QUIET; j++, n++) {
-        const bool ch = realign_event(s, i0 + j, perm[i0 + j], estart, changed, binmin0, binmin1, lastpass, pass, T1, swin[wv], false);
+        const bool ch = realign_event(s, i0 + j, i0 + j, estart, changed, binmin0, binmin1, lastpass, pass, T1, swin[wv], false);
         quiet = ch ? 0 : quiet + 1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1219,6 +1246,11 @@ int stage2_run(harc_amd_ctx *c)
                     hipLaunchKernelGGL(k_ev_rank, G256(nev), rank, nev, d_changed + 1);
                     RC_TRY(dalloc(c, &seglen, (size_t)nev + 1));
                     hipLaunchKernelGGL(k_ev_seglen, G256(nev), (const uint32_t *)rank, nev, seglen);
+                    {
+                        uint4 *evs = nullptr; RC_TRY(dalloc(c, &evs, (size_t)nev + 1));
+                        hipLaunchKernelGGL(k_ev_gather, G256(nev), (const uint4 *)a.events, (const uint32_t *)perm, nev, evs);
+                        a.events = evs;                            // from here on event i is the i-th in (bin, tuple) order (the unordered list is not used again)
+                    }
                     // the events grouped by rank range ((bin, tuple) order kept inside a range), and the size of every range
                     unsigned int *hist = nullptr; RC_TRY(dalloc(c, &hist, 32)); HIP_TRY(hipMemsetAsync(hist, 0, 32 * 4, c->stream));
                     RC_TRY(dalloc(c, &order2, (size_t)nev + 1));
@@ -1233,8 +1265,10 @@ int stage2_run(harc_amd_ctx *c)
                 }
                 uint64_t npass = 0; uint32_t rlo = 0, rhi = rhi0; int nall = 0, ridx = 0;
                 const uint32_t pipeline_from = getenv("HARC_AMD_S2_PIPE") ? (uint32_t)atoi(getenv("HARC_AMD_S2_PIPE")) : 1024u;
+                RC_TRY(dalloc(c, &a.bestbin[0], (size_t)T + 1)); RC_TRY(dalloc(c, &a.bestbin[1], (size_t)T + 1));
                 for (bool ranges = perm != nullptr;;) {
                     HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 4, c->stream));
+                    hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
                     const uint32_t nact = (ranges && order2) ? range_end[ridx < 31 ? ridx : 31] : nev;      // the events of the ranges reached so far come first in order2
                     hipLaunchKernelGGL(k_realign_big, dim3((nact + 3) / 4), dim3(256), 0, c->stream, a, nact, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
                                        (const uint32_t *)perm, (const uint32_t *)rank, 0u, ranges ? rhi : 0xFFFFFFFFu, (const uint32_t *)(ranges ? order2 : nullptr));     // the ranks below rlo are validated in passing: no event is ever left unlooked-at for a pass
