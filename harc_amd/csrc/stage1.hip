@@ -235,6 +235,30 @@ template <int W> __global__ void k_keygen(const uint64_t *reads, uint32_t n, int
     if (nbits < 64) v &= ((uint64_t)1 << nbits) - 1;
     keys[i] = v; ids[i] = i;
 }
+// both dictionaries' keys in ONE pass over the reads (the second pass was 11 GB read again at configs[2]: 2.7 ms)
+template <int W> __global__ void k_keygen2(const uint64_t *reads, uint32_t n, int off0, int nbits0, int off1, int nbits1, uint64_t *keys0, uint64_t *keys1, uint32_t *ids)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t r[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) r[w] = reads[(size_t)i * W + w];
+    {
+        const int wi = off0 >> 6, sh = off0 & 63;
+        const uint64_t lo = sel0<W>(r, wi), hi = sel0<W>(r, wi + 1);
+        uint64_t v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+        if (nbits0 < 64) v &= ((uint64_t)1 << nbits0) - 1;
+        keys0[i] = v;
+    }
+    {
+        const int wi = off1 >> 6, sh = off1 & 63;
+        const uint64_t lo = sel0<W>(r, wi), hi = sel0<W>(r, wi + 1);
+        uint64_t v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+        if (nbits1 < 64) v &= ((uint64_t)1 << nbits1) - 1;
+        keys1[i] = v;
+    }
+    ids[i] = i;
+}
 // Bins of more than HARC_LARGEBIN reads (repeats, low-complexity sequence) get their reads copied once more in bin order, so that the
 // cooperative scan of k_steps streams 64 candidates per round trip instead of gathering them ("LDS-staged reference reads, coalesced
 // Hamming scan" of the north star, for the bins where it pays).  large_list was filled by k_table_insert: (slot index << 1) | dictionary.
@@ -2190,11 +2214,13 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             }
         }
         PoolScope kscope(c);
-        uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
-        RC_TRY(dalloc(c, &k0, N)); RC_TRY(dalloc(c, &i0, N));
+        uint64_t *kboth[2] = { nullptr, nullptr }; uint32_t *i0 = nullptr;
+        RC_TRY(dalloc(c, &kboth[0], N)); RC_TRY(dalloc(c, &kboth[1], N)); RC_TRY(dalloc(c, &i0, N));
+        hipLaunchKernelGGL((k_keygen2<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[0], 2 * (P.dict_end[0] - P.dict_start[0] + 1),
+                           2 * P.dict_start[1], 2 * (P.dict_end[1] - P.dict_start[1] + 1), kboth[0], kboth[1], i0);
         for (int l = 0; l < 2; l++) {
             const int kbits = 2 * (P.dict_end[l] - P.dict_start[l] + 1);
-            hipLaunchKernelGGL((k_keygen<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[l], kbits, k0, i0);
+            uint64_t *const k0 = kboth[l];
             if (bloom_lines && bloom_tiled) {
                 PoolScope bscope(c);
                 uint64_t *pa = nullptr, *pb = nullptr; RC_TRY(dalloc(c, &pa, (size_t)N + 1)); RC_TRY(dalloc(c, &pb, (size_t)N + 1));
