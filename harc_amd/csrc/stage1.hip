@@ -1,6 +1,6 @@
 // stage1.hip -- HARC stage I (hash-based read reordering) for gfx950.
 //
-// Reference: src/reorder.cpp.  constructdictionary :277-394 -> k_keygen + radix sort + k_table_insert (an exact
+// Reference: src/reorder.cpp.  constructdictionary :277-394 -> k_keygen2 + radix sort + k_table_place (an exact
 // open-addressing key->bin table replaces BBHash: the MPHF value never reaches an output byte).  reorder() :434-703 ->
 // the super-round-synchronous K-chain x S-step schedule of DESIGN.md: k_steps (one 64-lane wave per chain, the (shift,
 // direction, dictionary) probes of a chain step spread over the lanes, priority = lane order, up to S steps per launch with
@@ -222,19 +222,6 @@ int s1_partition_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, ui
 
 // ------------------------------------------------------------------------------------------------ index build
 // key_l(read) = bases [ds_l, de_l] of the read (reorder.cpp:295-299)
-template <int W> __global__ void k_keygen(const uint64_t *reads, uint32_t n, int off, int nbits, uint64_t *keys, uint32_t *ids)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t r[W];
-#pragma unroll
-    for (int w = 0; w < W; w++) r[w] = reads[(size_t)i * W + w];
-    const int wi = off >> 6, sh = off & 63;                     // uniform
-    uint64_t lo = sel0<W>(r, wi), hi = sel0<W>(r, wi + 1);
-    uint64_t v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
-    if (nbits < 64) v &= ((uint64_t)1 << nbits) - 1;
-    keys[i] = v; ids[i] = i;
-}
 // both dictionaries' keys in ONE pass over the reads (the second pass was 11 GB read again at configs[2]: 2.7 ms)
 template <int W> __global__ void k_keygen2(const uint64_t *reads, uint32_t n, int off0, int nbits0, int off1, int nbits1, uint64_t *keys0, uint64_t *keys1, uint32_t *ids)
 {

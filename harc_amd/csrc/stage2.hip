@@ -299,12 +299,6 @@ __global__ void k_bloom_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, i
 // here; plane 2 + l: the reverse complement of such a key does), two entries of ONE 32-bit word per key.  When both windows have the same
 // width, the four probes of encoder.cpp:262-410 at a window start look up four k-mers of the consensus -- and over all window starts
 // each k-mer of the consensus is looked up four times.  With this bitmap it is hashed and looked up once.
-__device__ __forceinline__ uint64_t rc_key3(uint64_t key, int n)
-{
-    uint64_t r = 0;
-    for (int i = 0; i < n; i++) r |= (uint64_t)(6 - (int)((key >> (3 * (n - 1 - i))) & 7)) << (3 * i);   // A0 <-> T6, G2 <-> C4 (N 1 -> 5: matches nothing)
-    return r;
-}
 // The 64-byte line of a key: by its minimizer (the 15-mer inside it with the smallest hash) when nwin > 0 -- consecutive k-mers of the
 // consensus share it, and k_realign_propose1 looks up 3.6 G consecutive k-mers at configs[2] -- else hashed from the key.  (A 10-mer
 // minimizer compared as it is: every value occurs hundreds of times in a genome, the lines of a 26x data set were saturated.)  Word and
