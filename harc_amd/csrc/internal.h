@@ -178,6 +178,13 @@ struct PoolScope {
 
 // ---- primitives (prims.hip): thin wrappers over rocPRIM device-wide sort / scan
 int prim_sort_pairs_u64_u32(harc_amd_ctx *c, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit);
+// a bitmap larger than the caches is built from sorted items instead of with random atomics (stage1.hip: harc_bitmap_from_items)
+#define BL_TILE_WORDS 16384u     // 64 KB of bitmap per workgroup = 1024 lines
+#define BL_PART_BITS 20          // up to 2^20 - 1 tiles (64 GB of bitmap)
+#define harc_bitmap_tiles(nwords) ((uint32_t)(((uint64_t)(nwords) + BL_TILE_WORDS - 1) / BL_TILE_WORDS))      // an item with this tile number sets nothing
+// word w of the bitmap, bits b0 and b1 (0..31) of it
+#define harc_bitmap_item(w, b0, b1) (((uint64_t)((((uint32_t)(w) % BL_TILE_WORDS) << 10) | ((uint32_t)(b0) << 5) | (uint32_t)(b1)) << BL_PART_BITS) | (uint64_t)((uint32_t)(w) / BL_TILE_WORDS))
+int harc_bitmap_from_items(harc_amd_ctx *c, const uint64_t *items, uint64_t *tmp, size_t n, uint64_t nwords, uint32_t *bitmap);
 int prim_sort_keys_u64(harc_amd_ctx *c, const uint64_t *kin, uint64_t *kout, size_t n, unsigned end_bit);       // by the low end_bit bits, stable
 int prim_excl_scan_u32(harc_amd_ctx *c, const uint32_t *in, uint32_t *out, size_t n);
 int prim_excl_scan_u32_to_u64(harc_amd_ctx *c, const uint32_t *in, uint64_t *out, size_t n);

@@ -432,8 +432,6 @@ __global__ void k_table_place(const uint64_t *skeys, const uint32_t *sids, const
 // random-access ceiling): every key becomes (tile of the bitmap, word inside the tile, its two bits) in one u64, the u64s are sorted by tile
 // (two radix passes over the tile bits), and one workgroup per tile ORs its keys into 64 KB of LDS and writes the tile out in one coalesced
 // stream -- every byte of the bitmap is written exactly once, so it needs no clearing either.
-#define BL_TILE_WORDS 16384u     // 64 KB = 1024 lines
-#define BL_PART_BITS 20          // up to 2^20 tiles (64 GB of bitmap)
 __global__ void k_s1_bloom_keys(const uint64_t *keys, uint32_t n, uint32_t nlines, int nwin, uint32_t mmask, uint64_t *pk)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -441,7 +439,7 @@ __global__ void k_s1_bloom_keys(const uint64_t *keys, uint32_t n, uint32_t nline
     uint32_t w, m;
     bloom_pos(keys[i], key_scramble(keys[i]), nlines, nwin, mmask, &w, &m);
     const uint32_t b0 = (uint32_t)__ffs((int)m) - 1u, b1 = 31u - (uint32_t)__clz((int)m);
-    pk[i] = ((uint64_t)(((w % BL_TILE_WORDS) << 10) | (b0 << 5) | b1) << BL_PART_BITS) | (uint64_t)(w / BL_TILE_WORDS);
+    pk[i] = harc_bitmap_item(w, b0, b1);
 }
 __global__ __launch_bounds__(256) void k_s1_bloom_tile(const uint64_t *pk, uint32_t n, uint64_t nwords, uint32_t *bloom)
 {
@@ -463,6 +461,20 @@ __global__ __launch_bounds__(256) void k_s1_bloom_tile(const uint64_t *pk, uint3
     __syncthreads();
     const uint64_t base = (uint64_t)part * BL_TILE_WORDS;
     for (uint32_t j = threadIdx.x; j < BL_TILE_WORDS; j += 256) if (base + j < nwords) bloom[base + j] = tile[j];
+}
+// items[n] (harc_bitmap_item: tile, word in the tile, two bit positions; an item whose tile is harc_bitmap_tiles(nwords) sets nothing) -> the
+// bitmap of `nwords` 32-bit words, every word written once (no clearing needed).  `tmp` holds n u64 as well.  Shared with stage II's combined bitmap.
+int harc_bitmap_from_items(harc_amd_ctx *c, const uint64_t *items, uint64_t *tmp, size_t n, uint64_t nwords, uint32_t *bitmap)
+{
+    const uint64_t ntiles64 = (nwords + BL_TILE_WORDS - 1) / BL_TILE_WORDS;
+    if (ntiles64 + 1 >= (1ull << BL_PART_BITS) || n > 0xFFFFFFFFull) { harc_set_error("bitmap of %llu words / %zu items: too large for the tiled build", (unsigned long long)nwords, n); return HARC_AMD_EINVAL; }
+    const uint32_t ntiles = (uint32_t)ntiles64;
+    if (ntiles == 0) return HARC_AMD_OK;
+    unsigned tb = 1; while (((uint64_t)1 << tb) <= ntiles) tb++;  // the tile numbers 0 .. ntiles (the last one: items that set nothing)
+    RC_TRY(prim_sort_keys_u64(c, items, tmp, n, tb));
+    hipLaunchKernelGGL(k_s1_bloom_tile, dim3(ntiles), dim3(256), 0, c->stream, (const uint64_t *)tmp, (uint32_t)n, nwords, bitmap);
+    HIP_TRY(hipGetLastError());
+    return HARC_AMD_OK;
 }
 __global__ void k_s1_bloom_diff(const uint32_t *a, const uint32_t *b, uint64_t nwords, unsigned long long *ndiff)
 {
@@ -2192,7 +2204,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             bloom_lines = (uint32_t)nl;
             // a bitmap beyond the caches is built tile by tile from sorted keys (k_s1_bloom_tile); a small one takes the atomics in L2 (HARC_AMD_S1BLOOM_TILED=0/1 forces either)
             bloom_tiled = getenv("HARC_AMD_S1BLOOM_TILED") ? atoi(getenv("HARC_AMD_S1BLOOM_TILED")) != 0 : (size_t)bloom_lines * 64 >= ((size_t)64 << 20);
-            if (((uint64_t)bloom_lines * 16 + BL_TILE_WORDS - 1) / BL_TILE_WORDS > ((uint64_t)1 << BL_PART_BITS)) bloom_tiled = false;
+            if (((uint64_t)bloom_lines * 16 + BL_TILE_WORDS - 1) / BL_TILE_WORDS + 1 >= ((uint64_t)1 << BL_PART_BITS)) bloom_tiled = false;
             for (int l = 0; l < 2; l++) {
                 RC_TRY(dalloc(c, &d_bloom[l], (size_t)bloom_lines * 16)); if (!bloom_tiled) HIP_TRY(hipMemsetAsync(d_bloom[l], 0, (size_t)bloom_lines * 64, c->stream));
                 const int nb = P.dict_end[l] - P.dict_start[l] + 1;                   // bases per key
@@ -2212,12 +2224,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
                 PoolScope bscope(c);
                 uint64_t *pa = nullptr, *pb = nullptr; RC_TRY(dalloc(c, &pa, (size_t)N + 1)); RC_TRY(dalloc(c, &pb, (size_t)N + 1));
                 const uint64_t nwords = (uint64_t)bloom_lines * 16;
-                const uint32_t ntiles = (uint32_t)((nwords + BL_TILE_WORDS - 1) / BL_TILE_WORDS);
-                unsigned tb = 1; while (((uint64_t)1 << tb) < ntiles) tb++;
                 hipLaunchKernelGGL(k_s1_bloom_keys, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, bloom_lines, bloom_nwin[l], bloom_mmask, pa);
-                RC_TRY(prim_sort_keys_u64(c, pa, pb, N, tb));
-                hipLaunchKernelGGL(k_s1_bloom_tile, dim3(ntiles), dim3(256), 0, c->stream, (const uint64_t *)pb, N, nwords, d_bloom[l]);
-                HIP_TRY(hipGetLastError());
+                RC_TRY(harc_bitmap_from_items(c, pa, pb, N, nwords, d_bloom[l]));
                 if (getenv("HARC_AMD_S1BLOOM_VERIFY")) {            // tests: word for word what the atomics build
                     uint32_t *ref = nullptr; unsigned long long *nd = nullptr, hnd = 0;
                     RC_TRY(dalloc(c, &ref, (size_t)nwords)); RC_TRY(dalloc(c, &nd, 1));

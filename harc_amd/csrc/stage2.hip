@@ -347,6 +347,33 @@ __global__ void k_bloom4_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, 
     bloom4_pos(r, bloom4_minimizer(r, nwin), nwin, lbits, &w, &a, &b);
     atomicOr(&bloom[w], ((4u << l) << a) | ((4u << l) << b));
 }
+// the same two entries per key as (tile, word, bits) items for harc_bitmap_from_items: a combined bitmap beyond the caches (tens of millions of
+// candidates: reads with N on a 150-bp set) is built from sorted items instead of with random atomics; keys with an N become items that set nothing
+__global__ void k_bloom4_items(const uint64_t *keys, uint32_t n, int lbits, int nwin, int l, int nb, uint32_t skip_tile, uint64_t *items)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    uint64_t f = 0, r = 0; bool hasn = false;
+    for (int b = 0; b < nb; b++) {
+        const uint32_t c3 = (uint32_t)(k >> (3 * b)) & 7u;
+        hasn |= (c3 & 1u) != 0;
+        const uint64_t idx = ((c3 >> 2) & 1u) | (c3 & 2u);
+        f |= idx << (2 * b); r |= (3u - idx) << (2 * (nb - 1 - b));
+    }
+    if (hasn) { items[2 * (size_t)i] = items[2 * (size_t)i + 1] = (uint64_t)skip_tile; return; }
+    uint32_t w; int a, b;
+    bloom4_pos(f, bloom4_minimizer(f, nwin), nwin, lbits, &w, &a, &b);
+    items[2 * (size_t)i] = harc_bitmap_item(w, a + l, b + l);
+    bloom4_pos(r, bloom4_minimizer(r, nwin), nwin, lbits, &w, &a, &b);
+    items[2 * (size_t)i + 1] = harc_bitmap_item(w, a + 2 + l, b + 2 + l);
+}
+__global__ void k_words_differ(const uint32_t *a, const uint32_t *b, uint64_t nwords, unsigned long long *ndiff)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long m = __ballot(i < nwords && a[i] != b[i]);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(ndiff, (unsigned long long)__popcll(m));
+}
 // candidates in the reads' 2-bit code + N mask (3-bit code A0 N1 G2 C4 T6: code = c3 >> 1, N = c3 & 1); one thread per (read, word)
 __global__ void k_cand2_from3(const uint64_t *cand3, uint32_t T, int L, int W, int W3, uint64_t *cand2, uint64_t *candN)
 {
@@ -1080,6 +1107,7 @@ int stage2_run(harc_amd_ctx *c)
     uint32_t *bloom[2] = { nullptr, nullptr }; int bloom_shift[2] = { 63, 63 };
     // windows of equal width (read lengths >= 50, encoder.cpp:132-145): one combined bitmap, one lookup per consensus k-mer (k_realign_propose1)
     const bool bloom4 = a.kbits[0] == a.kbits[1] && !getenv("HARC_AMD_BLOOM1");
+    bool bloom4_tiled = false;
     int bloom_per_key = 16;
     if (const char *e = getenv("HARC_AMD_BLOOMBITS")) { bloom_per_key = atoi(e); if (bloom_per_key < 1) bloom_per_key = 1; }
     if (T) {
@@ -1090,7 +1118,10 @@ int stage2_run(harc_amd_ctx *c)
         int lb = 16; while (lb < 36 && (1ULL << lb) < (unsigned long long)bloom_per_key * T) lb++;
         if (bloom4) {   // 4-bit entries, 16 per key and two of them set: ~1.5 % of absent k-mers pass per plane
             RC_TRY(dalloc(c, &bloom[0], ((size_t)1 << (lb - 3)) + 1));
-            HIP_TRY(hipMemsetAsync(bloom[0], 0, ((size_t)1 << (lb - 3)) * 4, c->stream));
+            // from 64 MB on (16 M candidates) the bitmap is built from sorted items, every word written once (HARC_AMD_S2BLOOM_TILED=0/1 forces either)
+            bloom4_tiled = getenv("HARC_AMD_S2BLOOM_TILED") ? atoi(getenv("HARC_AMD_S2BLOOM_TILED")) != 0 : (((size_t)1 << (lb - 3)) * 4 >= ((size_t)64 << 20));
+            if ((uint64_t)T * 4 > 0xFFFFFFFFull || harc_bitmap_tiles((uint64_t)1 << (lb - 3)) + 1 >= (1u << BL_PART_BITS)) bloom4_tiled = false;
+            if (!bloom4_tiled) HIP_TRY(hipMemsetAsync(bloom[0], 0, ((size_t)1 << (lb - 3)) * 4, c->stream));
             bloom[1] = bloom[0]; bloom_shift[0] = bloom_shift[1] = 64 - lb;
             a.bloom_lbits = lb - 7;                                            // 128 entries to a 64-byte line
             a.bloom_nwin = (a.kbits[0] / 3 == 21 && !getenv("HARC_AMD_BLOOM4_HASHED")) ? 21 - BLOOM4_M + 1 : 0;    // lines by minimizer (read lengths above 50)
@@ -1100,14 +1131,33 @@ int stage2_run(harc_amd_ctx *c)
             bloom_shift[l] = 64 - lb;
         }
         PoolScope kscope(c);
-        uint64_t *k0 = nullptr; uint32_t *i0 = nullptr;
+        uint64_t *k0 = nullptr; uint32_t *i0 = nullptr; uint64_t *items = nullptr, *items_tmp = nullptr;
         RC_TRY(dalloc(c, &k0, T)); RC_TRY(dalloc(c, &i0, T));
+        const uint64_t b4words = (uint64_t)1 << (lb - 3);
+        if (bloom4 && bloom4_tiled) { RC_TRY(dalloc(c, &items, (size_t)T * 4 + 1)); RC_TRY(dalloc(c, &items_tmp, (size_t)T * 4 + 1)); }
         for (int l = 0; l < 2; l++) {
             hipLaunchKernelGGL(k_key3, G256(T), cand3, T, W3, 3 * a.ds[l], a.kbits[l], k0, i0);
-            if (bloom4) hipLaunchKernelGGL(k_bloom4_set, G256(T), (const uint64_t *)k0, T, bloom[0], a.bloom_lbits, a.bloom_nwin, l, a.kbits[l] / 3);
+            if (bloom4 && bloom4_tiled) hipLaunchKernelGGL(k_bloom4_items, G256(T), (const uint64_t *)k0, T, a.bloom_lbits, a.bloom_nwin, l, a.kbits[l] / 3, harc_bitmap_tiles(b4words), items + (size_t)l * 2 * T);
+            else if (bloom4) hipLaunchKernelGGL(k_bloom4_set, G256(T), (const uint64_t *)k0, T, bloom[0], a.bloom_lbits, a.bloom_nwin, l, a.kbits[l] / 3);
             else hipLaunchKernelGGL(k_bloom_set, G256(T), (const uint64_t *)k0, T, bloom[l], bloom_shift[l]);
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, T, (unsigned)a.kbits[l]));
             hipLaunchKernelGGL(k_count_big_bins, G256(dict[l].cap), dict[l].slots, dict[l].cap, (uint32_t)P.maxsearch, d_big);
+        }
+        if (bloom4 && bloom4_tiled) {
+            RC_TRY(harc_bitmap_from_items(c, items, items_tmp, (size_t)T * 4, b4words, bloom[0]));
+            if (getenv("HARC_AMD_S2BLOOM_VERIFY")) {                // tests: word for word what the atomics build
+                uint32_t *ref = nullptr; unsigned long long *nd = nullptr, hnd = 0;
+                RC_TRY(dalloc(c, &ref, (size_t)b4words + 1)); RC_TRY(dalloc(c, &nd, 1));
+                HIP_TRY(hipMemsetAsync(ref, 0, (size_t)b4words * 4, c->stream)); HIP_TRY(hipMemsetAsync(nd, 0, 8, c->stream));
+                for (int l = 0; l < 2; l++) {
+                    hipLaunchKernelGGL(k_key3, G256(T), cand3, T, W3, 3 * a.ds[l], a.kbits[l], k0, i0);
+                    hipLaunchKernelGGL(k_bloom4_set, G256(T), (const uint64_t *)k0, T, ref, a.bloom_lbits, a.bloom_nwin, l, a.kbits[l] / 3);
+                }
+                hipLaunchKernelGGL(k_words_differ, dim3((unsigned)((b4words + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)ref, (const uint32_t *)bloom[0], b4words, nd);
+                HIP_TRY(hipMemcpyAsync(&hnd, nd, 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (hnd) { harc_set_error("stage II bitmap built by tiles differs from the one built with atomics in %llu words", hnd); return HARC_AMD_EINTERNAL; }
+            }
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
     }

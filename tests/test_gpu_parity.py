@@ -215,6 +215,7 @@ def test_low_complexity_big_bins_match_oracle(n, glen, K, S, E, err, oracle, tmp
                                  {"HARC_AMD_RESEED_MG": "1", "HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1"},
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1"}, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "0"},
                                  {"HARC_AMD_TABLE_FILL": "0"}, {"HARC_AMD_TABLE_FILL": "1"}, {"HARC_AMD_SORT_BITS": "8"}, {"HARC_AMD_SORT_BITS": "13"}, {"HARC_AMD_SORT_BITS": "1"}, {"HARC_AMD_SORT_BITS": "64"},
+                                 {"HARC_AMD_S2BLOOM_TILED": "1", "HARC_AMD_S2BLOOM_VERIFY": "1"}, {"HARC_AMD_S2BLOOM_TILED": "1", "HARC_AMD_S2BLOOM_VERIFY": "1", "HARC_AMD_BLOOM4_HASHED": "1"},
                                  {"HARC_AMD_S1BLOOM_TILED": "1", "HARC_AMD_S1BLOOM_VERIFY": "1"},
                                  {"HARC_AMD_S1BLOOM_TILED": "1", "HARC_AMD_S1BLOOM_VERIFY": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1"}])
 def test_kernel_variants_same_bytes(env, oracle, tmp_path, monkeypatch):
