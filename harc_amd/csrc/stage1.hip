@@ -664,10 +664,30 @@ template <int W> struct StepsLds {
 #define HARC_SCAN_CH 1                // chunks of 256 bin entries the cooperative scan fetches per round trip (see wg_scan)
 #endif
 #define HARC_WGCMD_BYTES 1280          // >= sizeof(WgCmd), checked where the struct is defined
+// the reads a chain has taken in the running super-round (they are not in the frozen claim bitmap yet), as a hash table in LDS: 128 slots per wave for
+// at most 64 of them.  The wave-uniform scan weeds them out of its candidates by all lanes at once; walking the wave's register copy with
+// v_readlane (one per read taken so far, every batch) was ~40 of the ~460 vector instructions of a step
+#define HARC_OWN_SLOTS 128
+__device__ __forceinline__ void own_insert(uint32_t *tab, uint32_t id)
+{
+    uint32_t h = (id * 0x9E3779B1u) >> 25;
+    while (tab[h] != HARC_NONE) h = (h + 1u) & (HARC_OWN_SLOTS - 1u);
+    tab[h] = id;
+}
+__device__ __forceinline__ bool own_has(const uint32_t *tab, uint32_t id)
+{
+    uint32_t h = (id * 0x9E3779B1u) >> 25;
+    for (;;) {
+        const uint32_t v = tab[h];
+        if (v == id) return true;
+        if (v == HARC_NONE) return false;
+        h = (h + 1u) & (HARC_OWN_SLOTS - 1u);
+    }
+}
 static inline size_t steps_lds_bytes(int W, int maxmatch, int nprobe)
 {
     const int NW = 2 * W, ROW = 3 * NW + 1, MROW = (NW + 3) & ~3;
-    return (size_t)4 * (64 * ((W + 1) / 2)) * 16 + ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)2 * nprobe + 8) * 4 + HARC_WGCMD_BYTES + 16;
+    return (size_t)4 * (64 * ((W + 1) / 2)) * 16 + ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)4 * HARC_OWN_SLOTS + (size_t)2 * nprobe + 8) * 4 + HARC_WGCMD_BYTES + 16;
 }
 // Hamming distance between a candidate read (registers) and the consensus shifted by the lane's own amount: `row` = ref or rref window
 // row in LDS, bitoff = 32 NW +- 2j, mrow = mask row of (direction, shift) (reorder.cpp:543,608 with mask[j] / revmask[j] of :706-718)
@@ -942,7 +962,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     uint32_t *const s_rows = s_mask + (size_t)2 * s.maxmatch * MROW;
     uint32_t *const s_rdl = s_rows + 4 * 2 * ROW;
     uint32_t *const s_tmp = s_rdl + 4 * MROW;
-    uint2 *const s_pinfo = reinterpret_cast<uint2 *>(s_tmp + 4 * 8 * NW);
+    uint32_t *const s_own = s_tmp + 4 * 8 * NW;
+    uint2 *const s_pinfo = reinterpret_cast<uint2 *>(s_own + 4 * HARC_OWN_SLOTS);
     WgCmd *const cmd = reinterpret_cast<WgCmd *>(reinterpret_cast<char *>(s_pinfo + s.nprobe) + 8 - ((size_t)(s_pinfo + s.nprobe) & 7));
     // main kernel: 4 chains per workgroup, one wave each.  COOP: one chain per workgroup, wave 0 walks it (role 0), waves 1..3 help with the scans
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, wv = COOP ? 0 : role;
@@ -961,6 +982,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         for (int i = threadIdx.x; i < s.nprobe; i += 64 * NWV) s_pinfo[i] = pt[i];
         for (int i = threadIdx.x; i < 4 * 2 * ROW; i += 64 * NWV) s_rows[i] = 0u;
         for (int i = threadIdx.x; i < 4 * 8 * NW; i += 64 * NWV) s_tmp[i] = 0u;
+        for (int i = threadIdx.x; i < 4 * HARC_OWN_SLOTS; i += 64 * NWV) s_own[i] = HARC_NONE;
         __syncthreads();
     }
     if (COOP && role != 0) {                                      // helpers: wait for a scan, take part, until the walk is over
@@ -1068,6 +1090,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
 
     uint32_t *const rowF = s_rows + (size_t)wv * 2 * ROW, *const rowR = rowF + ROW, *const rdl = s_rdl + (size_t)wv * MROW;
     uint8_t *const coltmp = reinterpret_cast<uint8_t *>(s_tmp + (size_t)wv * 8 * NW);
+    uint32_t *const ownt = s_own + (size_t)wv * HARC_OWN_SLOTS;
     const uint64_t kmask0 = s.kbits[0] < 64 ? (((uint64_t)1 << s.kbits[0]) - 1) : ~(uint64_t)0, kmask1 = s.kbits[1] < 64 ? (((uint64_t)1 << s.kbits[1]) - 1) : ~(uint64_t)0;
     const uint64_t cap = s.cap[0];                               // both dictionaries have the same geometry (stage1_run_w)
     uint32_t dbg_bins = 0, dbg_iter = 0, dbg_miss = 0, dbg_surv = 0, dbg_batches = 0;   // coop scans / their 64-entry chunks / steps without a hit / (unused) / batches
@@ -1165,7 +1188,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                             // lanes at once -- tested one after the other below, each of the chain's last few reads (they sit at the small shifts,
                             // in front of the read the step is looking for) would cost a dependent round trip of its own
                             if ((reinterpret_cast<const uint32_t *>(s.claimed)[sst >> 5] >> (sst & 31u)) & 1u) { cand = false; atomicOr(reinterpret_cast<uint32_t *>(&tab[sl + qhit]) + 3, SLOT_DEAD); }
-                            else for (int k = 0; k < t; k++) if ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == sst) cand = false;
+                            else if (own_has(ownt, sst)) cand = false;
                         }
                     }
                     else {
@@ -1362,6 +1385,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                 atomicMin(&s.bid[sid], ((uint32_t)t << 20) | c);
             }
             if (lane == t) ownreg = sid;
+            if constexpr (SEQ) { if (lane == 0) own_insert(ownt, sid); }
             if (lane < NW) { const uint32_t *rp = reinterpret_cast<const uint32_t *>(s.reads + (size_t)sid * W); rdl[lane] = rp[lane]; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1375,6 +1399,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             atomicMin(&s.bid[found], ((uint32_t)t << 20) | c);
         }
         if (lane == t) ownreg = found;
+        if constexpr (SEQ) { if (lane == 0) own_insert(ownt, found); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         cons_update_lds(st, rdl, L, fdir, fj, lane);
