@@ -63,6 +63,7 @@ int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes)
         if (e != hipSuccess && want > bytes) { want = bytes; e = hipMalloc(&base, want); }
         if (e != hipSuccess) { harc_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return HARC_AMD_ENOMEM; }
         if (getenv("HARC_AMD_POISON")) (void)hipMemset(base, 0xA5, want);   // debugging aid: make reads of uninitialised pool memory show
+        if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[pool] chunk %zu: %.2f GB for a request of %.2f GB (pool %.2f GB, in use %.2f GB)\n", c->pool.size(), want / 1e9, bytes / 1e9, (c->pool_total + want) / 1e9, pool_in_use(c) / 1e9);
         c->pool.push_back({ (char *)base, want, 0 });
         c->pool_total += want;
         c->pool_cur = c->pool.size() - 1;

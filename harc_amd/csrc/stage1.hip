@@ -684,10 +684,10 @@ __device__ __forceinline__ bool own_has(const uint32_t *tab, uint32_t id)
         h = (h + 1u) & (HARC_OWN_SLOTS - 1u);
     }
 }
-static inline size_t steps_lds_bytes(int W, int maxmatch, int nprobe)
+static inline size_t steps_lds_bytes(int W, int maxmatch, int nprobe, bool seq = false)
 {
     const int NW = 2 * W, ROW = 3 * NW + 1, MROW = (NW + 3) & ~3;
-    return (size_t)4 * (64 * ((W + 1) / 2)) * 16 + ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)4 * HARC_OWN_SLOTS + (size_t)2 * nprobe + 8) * 4 + HARC_WGCMD_BYTES + 16;
+    return (size_t)4 * (64 * ((W + 1) / 2)) * 16 + ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)(seq ? 4 * HARC_OWN_SLOTS : 0) + (size_t)2 * nprobe + 8) * 4 + HARC_WGCMD_BYTES + 16;
 }
 // Hamming distance between a candidate read (registers) and the consensus shifted by the lane's own amount: `row` = ref or rref window
 // row in LDS, bitoff = 32 NW +- 2j, mrow = mask row of (direction, shift) (reorder.cpp:543,608 with mask[j] / revmask[j] of :706-718)
@@ -963,7 +963,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     uint32_t *const s_rdl = s_rows + 4 * 2 * ROW;
     uint32_t *const s_tmp = s_rdl + 4 * MROW;
     uint32_t *const s_own = s_tmp + 4 * 8 * NW;
-    uint2 *const s_pinfo = reinterpret_cast<uint2 *>(s_own + 4 * HARC_OWN_SLOTS);
+    uint2 *const s_pinfo = reinterpret_cast<uint2 *>(s_own + (SEQ ? 4 * HARC_OWN_SLOTS : 0));      // the table exists in the kernel that asks it only (2 KB more LDS cost the 150-bp kernel a workgroup per CU)
     WgCmd *const cmd = reinterpret_cast<WgCmd *>(reinterpret_cast<char *>(s_pinfo + s.nprobe) + 8 - ((size_t)(s_pinfo + s.nprobe) & 7));
     // main kernel: 4 chains per workgroup, one wave each.  COOP: one chain per workgroup, wave 0 walks it (role 0), waves 1..3 help with the scans
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, wv = COOP ? 0 : role;
@@ -982,7 +982,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         for (int i = threadIdx.x; i < s.nprobe; i += 64 * NWV) s_pinfo[i] = pt[i];
         for (int i = threadIdx.x; i < 4 * 2 * ROW; i += 64 * NWV) s_rows[i] = 0u;
         for (int i = threadIdx.x; i < 4 * 8 * NW; i += 64 * NWV) s_tmp[i] = 0u;
-        for (int i = threadIdx.x; i < 4 * HARC_OWN_SLOTS; i += 64 * NWV) s_own[i] = HARC_NONE;
+        if constexpr (SEQ) for (int i = threadIdx.x; i < 4 * HARC_OWN_SLOTS; i += 64 * NWV) s_own[i] = HARC_NONE;
         __syncthreads();
     }
     if (COOP && role != 0) {                                      // helpers: wait for a scan, take part, until the walk is over
@@ -2204,6 +2204,10 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &c->d_rc, (size_t)N + 1)); RC_TRY(dalloc(c, &c->d_order_s, (size_t)N + 1));
     const harc_mark_t mark_results = harc_pool_mark(c);
     // ---- dictionaries (constructdictionary, reorder.cpp:277-394)
+    const bool itrace = getenv("HARC_AMD_TRACE") != nullptr;
+    auto inow = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    double it0 = inow();
+    auto ilap = [&](const char *what) { if (itrace) { (void)hipStreamSynchronize(c->stream); const double t = inow(); fprintf(stderr, "[index] %s: %.1f ms\n", what, 1e3 * (t - it0)); it0 = t; } };
     DictDev dict[2];
     // a bitmap of bloom_bits bits per read in front of each table, two bits set per key (HARC_AMD_S1BLOOM=0: none)
     uint32_t *d_bloom[2] = { nullptr, nullptr }; uint32_t bloom_lines = 0; int bloom_nwin[2] = { 0, 0 };
@@ -2219,6 +2223,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const uint32_t maxlarge = 2 * (N / HARC_LARGEBIN) + 16;
     if (N) {
         RC_TRY(harc_dict_alloc(c, &dict[0], N, 0)); RC_TRY(harc_dict_alloc(c, &dict[1], N, dict[0].cap));
+        ilap("tables allocated");
         RC_TRY(dalloc(c, &d_large, maxlarge)); RC_TRY(dalloc(c, &d_nlarge, 4));
         HIP_TRY(hipMemsetAsync(d_nlarge, 0, 16, c->stream));
         for (int l = 0; l < 2; l++) { dict[l].large_list = d_large; dict[l].large_n = d_nlarge; dict[l].large_max = maxlarge; dict[l].large_tag = (uint32_t)l; }
@@ -2242,6 +2247,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         RC_TRY(dalloc(c, &kboth[0], N)); RC_TRY(dalloc(c, &kboth[1], N)); RC_TRY(dalloc(c, &i0, N));
         hipLaunchKernelGGL((k_keygen2<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[0], 2 * (P.dict_end[0] - P.dict_start[0] + 1),
                            2 * P.dict_start[1], 2 * (P.dict_end[1] - P.dict_start[1] + 1), kboth[0], kboth[1], i0);
+        ilap("bitmaps allocated, keys made");
         for (int l = 0; l < 2; l++) {
             const int kbits = 2 * (P.dict_end[l] - P.dict_start[l] + 1);
             uint64_t *const k0 = kboth[l];
@@ -2262,7 +2268,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
                     if (hnd) { harc_set_error("stage I bitmap built by tiles differs from the one built with atomics in %llu words", hnd); return HARC_AMD_EINTERNAL; }
                 }
             } else if (bloom_lines) hipLaunchKernelGGL(k_s1_bloom_set, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, d_bloom[l], bloom_lines, bloom_nwin[l], bloom_mmask);
+            ilap("bitmap built");
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, N, (unsigned)kbits));
+            ilap("table built");
         }
     }
     // Low coverage: almost every read has its k-mer to itself (distinct k-mers / reads = (1 - e^-x) / x with x reads per genome position:
@@ -2384,7 +2392,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         for (uint32_t p = 0; p < a.own_mod; p++) x_ro[p] = (size_t)p * x_bytes;
         RC_TRY(dalloc(c, &x_dig, 8));
     }
-    const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe);
+    const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe), lds_bytes_seq = steps_lds_bytes(W, P.maxmatch, a.nprobe, true);
     const bool prof = P.profile != 0;
     // dense kernels (7 / 8 waves per SIMD) for every launch that is not QUAD (round 2: from 49 152 chains on; with the counts in LDS they pay from
     // 16 385 on: 24 k chains of configs[2] at 1/7 scale +5 %, the 21 k chains of c3sd +3.6 %)
@@ -2419,7 +2427,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (cm) hipLaunchKernelGGL(k_apply_seed, dim3(nblk), dim3(256), 0, c->stream, a);          // the seeds of the chains other ranks walk
             if (prof) { RC_TRY(R.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }
             if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
-            else if (dense && seq) hipLaunchKernelGGL((k_steps<W, false, false, true, 4, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
+            else if (dense && seq) hipLaunchKernelGGL((k_steps<W, false, false, true, 4, true>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
             else if (dense) hipLaunchKernelGGL((k_steps<W, false, false, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             else hipLaunchKernelGGL((k_steps<W, false, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             if (prof) HIP_TRY(hipEventRecord(pair[1], c->stream));
