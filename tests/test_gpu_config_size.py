@@ -124,3 +124,27 @@ def test_reseed_by_many_workgroups_with_late_readers(monkeypatch):
     bad = [k for k in want if got[k] != want[k]]
     assert not bad, bad
     assert cg.rounds == cw.rounds and cg.n_main == cw.n_main
+
+
+def test_second_run_of_a_context_allocates_nothing_more():
+    """a context keeps its device pool: the second reorder + encode of the same reads must end with the same high-water mark (no growth, no leak)
+    and the same streams -- what bench.py's steps and tools/shard_sim_big.py rely on when they call a warm-up pass the steady state"""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    import harc_amd
+    from tests.test_gpu_replicate import _collect
+    from tests import shard_model
+    n, L, E = 1_500_000, 100, 3
+    arr = bench.synth_reads(n, L, int(n * 100 / 26), 0.005, 11, torch.device("cuda", 0)).cpu().numpy()
+    hasN = (arr == ord("N")).any(1)
+    h = harc_amd.HarcAmd(harc_amd.default_params(L, num_thr=E, num_chains=0, num_steps=16))
+    h.set_reads_ascii(shard_model.lines(arr[~hasN]), int((~hasN).sum()), L + 1)
+    h.set_nreads_ascii(shard_model.lines(arr[hasN]), int(hasN.sum()), L + 1)
+    peaks, files = [], []
+    for _ in range(3):
+        h.reorder(); h.encode()
+        peaks.append(h.counters().device_bytes_peak); files.append(_collect(h, E))
+    h.close()
+    assert peaks[1] == peaks[0] and peaks[2] == peaks[0], peaks
+    assert files[1] == files[0] and files[2] == files[0]
