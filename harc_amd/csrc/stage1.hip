@@ -62,6 +62,9 @@ struct S1Args {
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
 };
 #define PG_CHUNK 8u
+#ifndef HARC_SEQ_EXTRA_WAVES
+#define HARC_SEQ_EXTRA_WAVES 3     // waves per SIMD of the dense wave-uniform kernel above the base of 5: 8 (64 vector, 80 scalar registers)
+#endif
 #ifndef HARC_W0_MUL
 #define HARC_W0_MUL 2
 #endif
@@ -952,7 +955,7 @@ template <int W> __global__ void k_steps_tables(S1Args s, uint32_t *out)
 // NWV (COOP only): waves per workgroup = the walking wave + NWV - 1 helpers that share its scans (64 NWV candidates per round trip).  Few
 // walks per super-round are bound by the longest one: 4 waves.  More walks than the chip holds workgroups are bound by wave slots, most of
 // which helpers idle in: fewer helpers, more walkers (stage1_run_w picks it from the walks of the last rounds; what is computed is the same).
-template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ = false> __global__ __launch_bounds__(256, COOP ? HARC_COOP_WAVES : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? (SEQ ? 3 : 2) : 0))) void k_steps(S1Args s)
+template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ = false> __global__ __launch_bounds__(256, COOP ? HARC_COOP_WAVES : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? (SEQ ? HARC_SEQ_EXTRA_WAVES : 2) : 0))) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
