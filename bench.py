@@ -56,6 +56,59 @@ def launch_ranks(args, argv):
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
     line = [None]
 
+    def descendants(pid):
+        """the process ids below `pid` (torch.distributed.run puts its workers into sessions of their own, so the process group alone would
+        miss them): psutil when it is there, else a walk over /proc"""
+        try:
+            import psutil
+            try:
+                return [pr.pid for pr in psutil.Process(pid).children(recursive=True)]
+            except psutil.Error:
+                return []
+        except ImportError:
+            kids = {}
+            for d in os.listdir("/proc"):
+                if d.isdigit():
+                    try:
+                        with open(f"/proc/{d}/stat") as f:
+                            kids.setdefault(int(f.read().rsplit(")", 1)[1].split()[1]), []).append(int(d))
+                    except (OSError, ValueError, IndexError):
+                        pass
+            out, todo = [], [pid]
+            while todo:
+                for k in kids.get(todo.pop(), []):
+                    out.append(k); todo.append(k)
+            return out
+
+    def end_tree():
+        """exactly the processes this call started: the launcher child and whatever descends from it.  A fresh kill, never a re-exec."""
+        if child.poll() is not None:
+            return
+        tree = descendants(child.pid)
+        child.terminate()                                         # torch.distributed.run ends its workers on SIGTERM
+        try:
+            child.wait(timeout=15)
+        except subprocess.TimeoutExpired:
+            pass
+        for pid in tree:
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+        child.wait()
+
+    def on_signal(signum, frame):
+        # Ctrl-C, a harness timeout, SIGTERM: the ranks sit in sessions of their own and would run on as orphans on the GPUs
+        print(f"bench.py: signal {signum}: ending process {child.pid} and its descendants", file=sys.stderr)
+        end_tree()
+        sys.exit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, on_signal)
+
     def reader():
         for raw in child.stdout:
             txt = raw.decode("utf-8", "replace").strip()
@@ -66,32 +119,14 @@ def launch_ranks(args, argv):
     th = threading.Thread(target=reader, daemon=True)
     th.start()
     try:
-        rc = child.wait(timeout=args.launch_timeout)
-    except subprocess.TimeoutExpired:
-        print(f"bench.py: the {args.gpus} ranks did not finish within {args.launch_timeout} s: ending process {child.pid} and its descendants", file=sys.stderr)
-        # exactly the processes this call started: the launcher child and whatever descends from it (torch.distributed.run puts its workers
-        # into sessions of their own, so the process group alone would miss them)
-        import psutil
         try:
-            tree = psutil.Process(child.pid).children(recursive=True)
-        except psutil.Error:
-            tree = []
-        child.terminate()                                         # torch.distributed.run ends its workers on SIGTERM
-        try:
-            child.wait(timeout=15)
+            rc = child.wait(timeout=args.launch_timeout)
         except subprocess.TimeoutExpired:
-            pass
-        for pr in tree:
-            try:
-                pr.kill()
-            except psutil.Error:
-                pass
-        try:
-            os.killpg(child.pid, signal.SIGKILL)
-        except (ProcessLookupError, PermissionError):
-            pass
-        child.wait()
-        rc = 124
+            print(f"bench.py: the {args.gpus} ranks did not finish within {args.launch_timeout} s: ending process {child.pid} and its descendants", file=sys.stderr)
+            end_tree()
+            rc = 124
+    finally:
+        end_tree()                                                # any other way out (an exception in this process): the same tree kill
     th.join(timeout=10)
     if rc == 0 and line[0] is None:
         print("bench.py: the ranks finished without a result line", file=sys.stderr)
@@ -236,6 +271,46 @@ def synth_reads(n, L, G, err, seed, dev, spike=None):
 SPIKES = {"c2r": (2000, 0.0, 200, 0), "c2d": (10000, 0.12, 300, 300), "c3sd": (100000, 0.12, 3000, 3000)}
 
 
+def install_synthetic(h, n, L, G, err, seed, dev, spike=None):
+    """the synthetic workload -> the context h, 4 M reads at a time so that config-3/4-sized sets never exist as ASCII: clean reads are
+    packed to 2 bits per base (k_pack2) as they are made, reads with N are kept as text for stage II.  Returns the order-independent
+    signature [count, sum, xor of 64-bit read hashes] of all reads, taken on the way (for the round-trip check after a run)."""
+    _need_torch()
+    Wd = (2 * L + 63) // 64
+    packed = torch.empty((n, Wd), dtype=torch.int64, device=dev)
+    nclean, nparts = 0, []
+    sig = [0, 0, 0]
+
+    def acc(t):
+        c3 = h.reads_signature_device(t.data_ptr(), t.shape[0], L)
+        sig[0] += c3[0]; sig[1] = (sig[1] + c3[1]) % (1 << 64); sig[2] ^= c3[2]
+    for r in synth_chunks(n, L, G, err, seed, dev, spike):
+        hasN = (r == ord("N")).any(1)
+        cl = r[~hasN].contiguous()
+        wn = r[hasN].contiguous()
+        torch.cuda.synchronize()                                  # libharc_amd works on its own stream: its inputs must be complete
+        if cl.shape[0]:
+            h.pack_reads_device(cl.data_ptr(), cl.shape[0], cl.stride(0), packed[nclean:].data_ptr())
+            acc(cl)
+            nclean += cl.shape[0]
+        if wn.shape[0]:
+            acc(wn)
+            nparts.append(wn)
+        del r, hasN, cl, wn
+    withN = torch.cat(nparts) if nparts else torch.empty((0, L), dtype=torch.uint8, device=dev)
+    del nparts
+    packed = packed[:nclean]
+    torch.cuda.synchronize()
+    # this rank's slice of the job is installed ONCE (the library keeps its own copy): on one GPU it is the whole input, on N GPUs the
+    # exchange inside every step starts from it
+    h.set_reads_packed_device(packed.data_ptr(), nclean)
+    h.set_nreads_ascii_device(withN.data_ptr(), withN.shape[0], L)
+    del packed, withN
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                                      # hand torch's cached blocks back: the library allocates with hipMalloc
+    return sig
+
+
 def stage_files(reads_np, d):
     """[n, L] uint8 reads -> the input files of the reference's reorder.out / encoder.out under <d>/output"""
     import numpy as np
@@ -275,8 +350,11 @@ def cpu_baseline(reads_np, L, desc):
     refdir = os.path.join(ROOT, "oracle", "_ref")
     thr = max([t for t in (1, 8, 16, 32, 64) if t <= ncpu and os.path.exists(os.path.join(refdir, f"reorder_L{L}_t{t}.out"))], default=0)
     n_sample = reads_np.shape[0]
+    runs = []
     if thr:
-        dt, _ = run_reference(reads_np, L, thr)
+        for _ in range(3):                                        # one sample moved 0.41 .. 0.52 Mreads/s between runs of the same leg: three, the median
+            runs.append(run_reference(reads_np, L, thr)[0])
+        dt = sorted(runs)[1]
         kind, cores = "reference", thr
     else:
         from tests import oracle_lib as ol
@@ -290,7 +368,8 @@ def cpu_baseline(reads_np, L, desc):
             dt = time.time() - t0
         kind, cores = "port", 1
     return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": kind,
-            "sample": f"{desc}, reorder+encode wall {dt:.1f}s" + (f", ./harc -t {thr} stage programs" if thr else ", scalar C port")}
+            "sample": f"{desc}, reorder+encode wall {dt:.1f}s" + (f" (median of {len(runs)} runs: " + ", ".join(f"{x:.1f}" for x in runs) + f" s), ./harc -t {thr} stage programs" if thr else ", scalar C port"),
+            "runs_s": [round(x, 2) for x in runs]}
 
 
 def xz_size(blobs):
@@ -334,6 +413,8 @@ def main():
     ap.add_argument("--super-steps", type=int, default=0, help="steps per super-round (num_steps, default 16)")
     ap.add_argument("--shards", type=int, default=8, help="num_thr of the reference = encoder shards per GPU (harc:195 default 8)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (reference baseline, size comparison) and the exact-mode sample")
+    ap.add_argument("--no-prime", action="store_true", help="with --warmup 0: do NOT make the untimed pass that allocates the context's device pool and pinned buffers (the first timed step then pays for them: cold-start numbers)")
+    ap.add_argument("--no-side-legs", action="store_true", help="N>1: skip rank 0's GPU side legs after the timed region (n1_equivalent, size_vs_1gpu) -- the peers wait for them in the final barrier")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket exchange even at world size 1 (exercises the N>1 path on one GPU)")
     ap.add_argument("--cpu-sample", type=int, default=0)
     ap.add_argument("--mg-mode", default="bucket", choices=["bucket", "replicate"],
@@ -393,41 +474,8 @@ def main():
     rpc = 1024 if (dist is not None and args.mg_mode == "bucket") else 0
     p = harc_amd.default_params(L, num_thr=args.shards, num_chains=args.chains, device=local, profile=1, num_steps=args.super_steps, reads_per_chain=rpc)
     h = harc_amd.HarcAmd(p)
-    # inputs, 4 M reads at a time so that config-3/4-sized sets never exist as ASCII: clean reads are packed to 2 bits per base
-    # (k_pack2) as they are made, reads with N are kept as text for stage II; the order-independent signature of both is taken on
-    # the way (for the round-trip check after the timed region)
     Wd = (2 * L + 63) // 64
-    packed = torch.empty((n, Wd), dtype=torch.int64, device=dev)
-    nclean, nparts = 0, []
-    sig_in = [0, 0, 0]
-
-    def acc(sig, t):
-        c3 = h.reads_signature_device(t.data_ptr(), t.shape[0], L)
-        sig[0] += c3[0]; sig[1] = (sig[1] + c3[1]) % (1 << 64); sig[2] ^= c3[2]
-    for r in synth_chunks(n, L, G * world, err, 1000 + rank, dev, spike):
-        hasN = (r == ord("N")).any(1)
-        cl = r[~hasN].contiguous()
-        wn = r[hasN].contiguous()
-        torch.cuda.synchronize()                                  # libharc_amd works on its own stream: its inputs must be complete
-        if cl.shape[0]:
-            h.pack_reads_device(cl.data_ptr(), cl.shape[0], cl.stride(0), packed[nclean:].data_ptr())
-            acc(sig_in, cl)
-            nclean += cl.shape[0]
-        if wn.shape[0]:
-            acc(sig_in, wn)
-            nparts.append(wn)
-        del r, hasN, cl, wn
-    withN = torch.cat(nparts) if nparts else torch.empty((0, L), dtype=torch.uint8, device=dev)
-    del nparts
-    packed = packed[:nclean]
-    torch.cuda.synchronize()
-    # this rank's slice of the job is installed ONCE (the library keeps its own copy): on one GPU it is the whole input, on N GPUs the
-    # exchange inside every step starts from it
-    h.set_reads_packed_device(packed.data_ptr(), nclean)
-    h.set_nreads_ascii_device(withN.data_ptr(), withN.shape[0], L)
-    del packed, withN
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()                                      # hand torch's cached blocks back: the library allocates with hipMalloc
+    sig_in = install_synthetic(h, n, L, G * world, err, 1000 + rank, dev, spike)
     if dist is not None:
         from harc_amd import multigpu
         with wd.phase("communicator bootstrap", args.watchdog):
@@ -456,7 +504,7 @@ def main():
     # The first pass of a context allocates its device pool (tens of GB of hipMalloc at configs[2]: 0.1 ... 3 s on this box) and its pinned output
     # buffers; every later pass reuses them (tests/test_gpu_config_size.py::test_second_run_of_a_context_allocates_nothing_more).  With
     # --warmup 0 that allocation would sit inside the first timed step: one untimed priming pass is made then, and the line says so.
-    priming = 1 if args.warmup == 0 else 0
+    priming = 1 if (args.warmup == 0 and not args.no_prime) else 0
     for _ in range(args.warmup + priming):
         with wd.phase("warm-up step", args.watchdog):
             step()
@@ -525,6 +573,9 @@ def main():
     try:                                                          # HBM bytes per launch from the committed PMC passes of the same command
         tr = json.load(open(os.path.join(ROOT, "profiles", "k_steps_traffic.json"))).get(args.workload)
         if tr and world == 1:
+            # the counters were taken by a separate run: they describe THIS kernel only when that run loaded a library built from the same sources
+            roofline["traffic_build_id"] = tr.get("build_id")
+            roofline["traffic_stale"] = tr.get("build_id") != harc_amd.build_id()
             roofline["traffic"] = round((tr["fetch_kb_per_launch"] + tr["write_kb_per_launch"]) * 1024.0, 1)
             roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / max(1.0, roofline["alg_bytes_per_launch"]), 2)
             roofline["traffic_source"] = "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command taken by the builder, profiles/k_steps_traffic.json (" + tr.get("profile", "") + ")"
@@ -548,7 +599,7 @@ def main():
         pass
     out = {
         "metric": "Mreads/s reorder+encode, 100 bp", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "allocation_priming_passes": priming, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "steps": args.steps, "warmup": args.warmup, "warmup_effective": args.warmup + priming, "allocation_priming_passes": priming, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64 (2-bit packed bases, XOR+popcount)", "data": "synthetic",
         "config": {"workload": args.workload, "description": desc, "reads_per_gpu": n, "readlen": L, "genome_bp": G * world,
                    "error_rate": err, "chains_per_gpu": int(c.chains), "reads_per_chain": rpc or 2048, "encoder_shards_per_gpu": args.shards,
@@ -556,6 +607,7 @@ def main():
                                "bytes differ from the reference's -t 1, which is num_chains = 1: see exact_mode)",
                    "parallelism": "single GPU" if world == 1 and dist is None else (f"design (R) x{world}: reads all-gathered, index replicated, chains partitioned, one all-gather of the walked steps per super-round; every GPU ends with the single-GPU archive" if replicate else f"minimizer-bucket shard x{world}, one RCCL all-to-all (8W+4 B per read) inside every step")},
         "roofline": roofline,
+        "build_id": harc_amd.build_id(),
         "roundtrip": roundtrip,
         "phases_ms_last_step": {"index": round(c.index_ms, 2), "chain": round(c.chain_ms, 2), "encode": round(c.encode_ms, 2)},
         "counters_last_step": {"unmatched": int(c.unmatched), "singletons_aligned": int(c.aligned_singletons), "N_aligned": int(c.aligned_N),
@@ -566,7 +618,7 @@ def main():
         # every N>1 line carries what ONE GPU does with its own batch, unsharded (no exchange, the single-GPU schedule): the N = 1 equivalent
         # measured in this very run on rank 0, outside the timed region
         out["per_gpu_value"] = round(value / world, 3)
-        if rank == 0:
+        if rank == 0 and not args.no_side_legs:
             h.shard_reset()
             h.reorder(); h.encode()                               # warm-up at the unsharded size (pool growth)
             t1 = time.perf_counter()
@@ -579,7 +631,7 @@ def main():
     h.close()
     del h
     # ---- bounded side legs on rank 0 (outside the timed region): a sample of the same generator at the same coverage and error rate
-    if rank == 0 and (not args.no_cpu or dist is not None):
+    if rank == 0 and (not args.no_cpu or (dist is not None and not args.no_side_legs)):
         ns = args.cpu_sample or min(n, 3_300_000 if err > 0 or G // max(1, n) < 10 else 1_000_000)
         if spike:
             Gs, sspike = G, spike                                 # repeat-spiked genomes are not scaled: same genome, fewer reads would change the coverage

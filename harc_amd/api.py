@@ -15,7 +15,7 @@ class Params(C.Structure):
     """harc_amd_params == src/config.h macros (harc:52-63)"""
     _fields_ = [("readlen", C.c_int32), ("num_thr", C.c_int32), ("num_chains", C.c_int32), ("maxmatch", C.c_int32),
                 ("thresh", C.c_int32), ("thresh_s", C.c_int32), ("maxsearch", C.c_int32), ("dict_start", C.c_int32 * 2),
-                ("dict_end", C.c_int32 * 2), ("device", C.c_int32), ("profile", C.c_int32), ("num_steps", C.c_int32), ("reads_per_chain", C.c_int32), ("decode_memory_gb", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("dict_end", C.c_int32 * 2), ("device", C.c_int32), ("profile", C.c_int32), ("num_steps", C.c_int32), ("reads_per_chain", C.c_int32), ("decode_memory_gb", C.c_int32), ("stream_digest", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -95,6 +95,8 @@ def lib():
     l.harc_amd_replicate_exchange.argtypes = [ctx, C.POINTER(C.c_uint64)]
     l.harc_amd_compress_fastq_shard_files.argtypes = [PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
     l.harc_amd_merge_shard_files.argtypes = [C.c_char_p, C.c_int32]
+    l.harc_amd_stream_digest.argtypes = [ctx, C.POINTER(C.c_uint64)]
+    l.harc_amd_build_id.restype = C.c_char_p
     _lib = l
     return l
 
@@ -104,12 +106,18 @@ def _check(rc):
         raise HarcAmdError(rc, lib().harc_amd_last_error().decode(errors="replace"))
 
 
-def default_params(readlen, num_thr=8, num_chains=0, device=0, profile=0, num_steps=0, reads_per_chain=0):
+def default_params(readlen, num_thr=8, num_chains=0, device=0, profile=0, num_steps=0, reads_per_chain=0, stream_digest=0):
     p = Params()
     _check(lib().harc_amd_default_params(readlen, C.byref(p)))
     p.num_thr, p.num_chains, p.device, p.profile, p.num_steps = num_thr, num_chains, device, profile, num_steps
     p.reads_per_chain = reads_per_chain
+    p.stream_digest = stream_digest
     return p
+
+
+def build_id():
+    """sha256 of the kernel sources the loaded library was built from"""
+    return lib().harc_amd_build_id().decode()
 
 
 # ---- the reference's stage programs (file contract)
@@ -295,6 +303,12 @@ class HarcAmd:
         ptr, ln = C.c_void_p(), C.c_size_t()
         _check(lib().harc_amd_get_stream(self._ctx, STREAMS[name], shard, C.byref(ptr), C.byref(ln)))
         return C.string_at(ptr, ln.value) if ln.value else b""
+
+    def stream_digest(self):
+        """four 64-bit words over the stage-II streams of the last encode(), folded on the device (params.stream_digest = 1)"""
+        d = (C.c_uint64 * 4)()
+        _check(lib().harc_amd_stream_digest(self._ctx, d))
+        return tuple(int(x) for x in d)
 
     def counters(self):
         c = Counters()

@@ -423,6 +423,16 @@ extern "C" int harc_amd_get_stream(harc_amd_ctx *c, int32_t id, int32_t shard, c
     return HARC_AMD_OK;
 }
 
+extern "C" int harc_amd_stream_digest(harc_amd_ctx *c, uint64_t out[4])
+{
+    if (!c || !out) return HARC_AMD_EINVAL;
+    if (!c->have_s2 || !c->have_digest) { harc_set_error("harc_amd_stream_digest: no digest (params.stream_digest = 1, then harc_amd_encode)"); return HARC_AMD_ESTATE; }
+    for (int k = 0; k < 4; k++) out[k] = c->digest[k];
+    return HARC_AMD_OK;
+}
+#include "build_id.h"
+extern "C" const char *harc_amd_build_id(void) { return HARC_AMD_BUILD_ID; }
+
 extern "C" int harc_amd_get_counters(harc_amd_ctx *c, harc_amd_counters *out)
 {
     if (!c || !out) return HARC_AMD_EINVAL;

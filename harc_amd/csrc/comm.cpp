@@ -70,11 +70,15 @@ static double mono_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &t
 struct RcclComm : HarcComm {
     ncclComm_t comm = nullptr;
     uint64_t *d_ag = nullptr; size_t ag_cap = 0;               // small device buffer for the count all-gather
-    ~RcclComm() override { if (comm) g_rccl.CommDestroy(comm); if (d_ag) (void)hipFree(d_ag); }
+    uint64_t *h_ag = nullptr;                                   // its pinned host twin: the results leave the device only AFTER wait() has seen the collective finish
+    ~RcclComm() override { if (comm) g_rccl.CommDestroy(comm); if (d_ag) (void)hipFree(d_ag); if (h_ag) (void)hipHostFree(h_ag); }
     const char *name() const override { return "rccl"; }
     // A peer that died (or never came) leaves this rank's stream waiting inside the collective for ever: the stream is polled, and
     // when the collective has not finished after the timeout the communicator is aborted and the call fails with HARC_AMD_ETIMEOUT.
     // The context cannot be used for another exchange after that: the caller is expected to end the process.
+    // Nothing that blocks the HOST may be enqueued behind a collective before wait() has returned: a device-to-host copy into pageable
+    // memory is staged by the runtime and holds the calling thread until all earlier work of the stream has finished -- with a dead peer
+    // the thread would sit in hipMemcpyAsync and never reach the poll below.  Results go to pinned memory, or are copied after wait().
     int wait(harc_amd_ctx *c, const char *what) override
     {
         const double lim = comm_timeout_s(), t0 = mono_now();
@@ -93,12 +97,20 @@ struct RcclComm : HarcComm {
     int allgather_u64(harc_amd_ctx *c, const uint64_t *in, int n, uint64_t *out) override
     {
         const size_t need = (size_t)(world + 1) * n * 8;
-        if (need > ag_cap) { if (d_ag) (void)hipFree(d_ag); d_ag = nullptr; HIP_TRY(hipMalloc((void **)&d_ag, need)); ag_cap = need; }
+        if (need > ag_cap) {
+            if (d_ag) (void)hipFree(d_ag);
+            if (h_ag) (void)hipHostFree(h_ag);
+            d_ag = nullptr; h_ag = nullptr; ag_cap = 0;
+            HIP_TRY(hipMalloc((void **)&d_ag, need)); HIP_TRY(hipHostMalloc((void **)&h_ag, need)); ag_cap = need;
+        }
         uint64_t *d_in = d_ag, *d_out = d_ag + n;
-        HIP_TRY(hipMemcpyAsync(d_in, in, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        memcpy(h_ag, in, (size_t)n * 8);                          // pinned on both sides: neither copy blocks the host
+        HIP_TRY(hipMemcpyAsync(d_in, h_ag, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
         NCCL_TRY(g_rccl.AllGather(d_in, d_out, (size_t)n, ncclUint64, comm, c->stream));
-        HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)world * n * 8, hipMemcpyDeviceToHost, c->stream));
-        return wait(c, "all-gather of the counts");
+        HIP_TRY(hipMemcpyAsync(h_ag + n, d_out, (size_t)world * n * 8, hipMemcpyDeviceToHost, c->stream));
+        RC_TRY(wait(c, "all-gather of the counts"));
+        memcpy(out, h_ag + n, (size_t)world * n * 8);
+        return HARC_AMD_OK;
     }
     int alltoallv(harc_amd_ctx *c, int narr, const void *const *send, const size_t *const *soff, const size_t *const *sbytes,
                   void *const *recv, const size_t *const *roff, const size_t *const *rbytes) override

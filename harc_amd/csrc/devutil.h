@@ -3,7 +3,7 @@
 #include "internal.h"
 
 // ------------------------------------------------------------------------------------------------ device helpers
-__device__ __forceinline__ uint64_t mix64(uint64_t x)
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;

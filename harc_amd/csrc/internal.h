@@ -132,6 +132,7 @@ struct harc_amd_ctx {
     struct HostChunk { char *base; size_t size, used; };
     std::vector<HostChunk> harena;
     harc_amd_counters C;
+    uint64_t digest[4] = { 0, 0, 0, 0 }; bool have_digest = false;   // harc_amd_stream_digest: the stage-II streams of the last encode, folded on the device (params.stream_digest)
 
     // scratch for rocPRIM
     void *d_tmp = nullptr; size_t tmp_bytes = 0;

@@ -54,6 +54,8 @@ int main(int argc, char **argv)
         P.device = argc > 13 ? atoi(argv[13]) : rank;                 // one process per GPU: rank r drives device r unless told otherwise
         P.reads_per_chain = 1024;                                     // a bucket shard is fragmented already (multi-GPU)
         // [mode] after [device]: "replicate" = design (R) (reads all-gathered, chains partitioned, single-GPU bytes); default: minimizer-bucket shards
+        // anything else is refused: a typo must not silently give the archive with the larger consensus
+        if (argc > 14 && strcmp(argv[14], "replicate") && strcmp(argv[14], "bucket")) { fprintf(stderr, "compressfq_shard: mode '%s' is neither 'bucket' nor 'replicate'\n", argv[14]); return 2; }
         const bool repl = argc > 14 && !strcmp(argv[14], "replicate");
         if (repl) { P.reads_per_chain = 0; rc = harc_amd_compress_fastq_replicated_files(&P, argv[4], argv[2], po, pq, world, rank, argv[12]); }
         else rc = harc_amd_compress_fastq_shard_files(&P, argv[4], argv[2], po, pq, world, rank, argv[12]);

@@ -203,6 +203,7 @@ extern "C" int harc_amd_replicate_exchange(harc_amd_ctx *c, uint64_t *info)
     HIP_TRY(hipSetDevice(c->P.device));
     HarcComm *cm = c->comm;
     const int world = cm->world, rank = cm->rank;
+    if (world > 64) { harc_set_error("harc_amd_replicate_exchange: design (R) runs on at most 64 ranks (world %d)", world); return HARC_AMD_EINVAL; }     // before anything moves
     const int W = c->W, W3 = c->W3;
     harc_drop_results(c);
     harc_reset_shard(c);

@@ -2164,7 +2164,7 @@ struct S1Resources {
     {
         for (auto &x : e) HIP_TRY(hipEventCreate(&x));
         for (auto &x : eb) HIP_TRY(hipEventCreate(&x));
-        HIP_TRY(hipHostMalloc((void **)&h_stats, (ST_N + HARC_COOPCNT + 8) * 8));
+        HIP_TRY(hipHostMalloc((void **)&h_stats, (ST_N + HARC_COOPCNT + 8 + 1) * 8));      // statistics, cooperative-walk counters, replica digest, k_reseed_mg's timeout flag
         return HARC_AMD_OK;
     }
     // the pair for the next launch; its previous use (RING launches ago) is read first
@@ -2330,6 +2330,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // four at a time (a workgroup of the main kernel), and every super-round ends with one all-gather of the walked steps
     HarcComm *const cm = (c->replicated && c->comm) ? c->comm : nullptr;
     a.own_mod = cm ? (uint32_t)cm->world : 1u; a.own_rem = cm ? (uint32_t)cm->rank : 0u;
+    if (a.own_mod > 64) { harc_set_error("design (R): at most 64 ranks (world %u)", a.own_mod); return HARC_AMD_EINVAL; }     // before any work: the digest compare below holds 64 x 8 words
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; }
     a.bloom[0] = d_bloom[0]; a.bloom[1] = d_bloom[1]; a.bloom_lines = bloom_lines; a.bloom_nwin[0] = bloom_nwin[0]; a.bloom_nwin[1] = bloom_nwin[1]; a.bloom_mmask = bloom_mmask;
     a.largetab = d_largetab; a.mirror = d_mirror;
@@ -2462,8 +2463,11 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         if (seq_probe < 2) HIP_TRY(hipEventRecord(R.eb[1], c->stream));
         HIP_TRY(hipMemcpyAsync(h_stats, a.stats, ST_N * 8, hipMemcpyDeviceToHost, c->stream));
         if (nlarge) HIP_TRY(hipMemcpyAsync(h_stats + ST_N, a.coopcnt, HARC_COOPCNT * 8, hipMemcpyDeviceToHost, c->stream));
-        unsigned int reseed_timeout = 0;
-        if (reseed_mg) HIP_TRY(hipMemcpyAsync(&reseed_timeout, a.reseed_g + 2, 4, hipMemcpyDeviceToHost, c->stream));
+        // (every result of a batch lands in the PINNED block h_stats: a copy into pageable memory would hold this thread inside hipMemcpyAsync
+        // until the stream has drained -- behind a collective whose peer died, for ever -- and cm->wait() below would never get to poll)
+        unsigned int *const h_reseed_timeout = reinterpret_cast<unsigned int *>(h_stats + ST_N + HARC_COOPCNT + 8);
+        *h_reseed_timeout = 0;
+        if (reseed_mg) HIP_TRY(hipMemcpyAsync(h_reseed_timeout, a.reseed_g + 2, 4, hipMemcpyDeviceToHost, c->stream));
         if (cm) {
             HIP_TRY(hipMemsetAsync(x_dig, 0, 8 * 8, c->stream));
             hipLaunchKernelGGL(k_replica_digest, dim3(1024), dim3(256), 0, c->stream, a, (unsigned long long)nwords, x_dig);
@@ -2472,10 +2476,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
-        if (reseed_timeout) { harc_set_error("stage I: the workgroups of k_reseed_mg did not meet (super-round %llu); HARC_AMD_RESEED_MG=0 uses the single workgroup", (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
+        if (*h_reseed_timeout) { harc_set_error("stage I: the workgroups of k_reseed_mg did not meet (super-round %llu); HARC_AMD_RESEED_MG=0 uses the single workgroup", (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
         if (cm) {   // the replicas must agree (k_replica_digest): a rank that drifted would hang the others in the next all-gather, or worse
             uint64_t mine[8], all[8 * 64];
-            if (a.own_mod > 64) { harc_set_error("design (R): at most 64 ranks"); return HARC_AMD_EINVAL; }
             for (int k = 0; k < 7; k++) mine[k] = h_stats[ST_N + HARC_COOPCNT + k];
             mine[7] = h_stats[ST_ACTIVE];
             RC_TRY(cm->allgather_u64(c, mine, 8, all));

@@ -1053,8 +1053,36 @@ __global__ void k_pack_order(const uint32_t *order, uint32_t ngroups, int numbit
     out[gid] = v;
 }
 
+// Digest of a byte range of a stream as it sits in HBM (harc_amd_stream_digest): the sum over its 8-byte words of a 64-bit mix of
+// (word, index of the word, salt) -- position-dependent, so any byte that moves or changes shows, and a sum, so the order of the additions
+// does not matter.  base is 8-byte aligned; the bytes behind `nbytes` in the last word are masked out (the buffers come from the pool
+// uncleared).  Full-size runs are compared through four of these words instead of through gigabytes of host memory.
+__global__ void k_stream_digest(const uint8_t *base, uint64_t nbytes, uint64_t salt, unsigned long long *out)
+{
+    const uint64_t nw = (nbytes + 7) / 8;
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t v = reinterpret_cast<const uint64_t *>(base)[i];
+        const uint64_t left = nbytes - 8 * i;
+        if (left < 8) v &= ((uint64_t)1 << (8 * left)) - 1;
+        acc += mix64(v ^ mix64(i * 0x9E3779B97F4A7C15ULL + salt));
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 #define G256(n) dim3((unsigned)((((uint64_t)(n)) + 255) / 256)), dim3(256), 0, c->stream
+static int digest_range(harc_amd_ctx *c, const void *base, uint64_t nbytes, uint64_t salt, unsigned long long *d_out)
+{
+    if (!nbytes) return HARC_AMD_OK;
+    if ((uintptr_t)base & 7) { harc_set_error("stream digest: a stream does not start on an 8-byte boundary"); return HARC_AMD_EINTERNAL; }
+    const uint64_t nw = (nbytes + 7) / 8;
+    const unsigned nb = (unsigned)(nw / 1024 + 1 < 4096 ? nw / 1024 + 1 : 4096);
+    hipLaunchKernelGGL(k_stream_digest, dim3(nb), dim3(256), 0, c->stream, (const uint8_t *)base, nbytes, salt, d_out);
+    HIP_TRY(hipGetLastError());
+    return HARC_AMD_OK;
+}
 
 int stage2_run(harc_amd_ctx *c)
 {
@@ -1069,6 +1097,12 @@ int stage2_run(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &order_out, (size_t)M + S + 1)); RC_TRY(dalloc(c, &orderN_out, (size_t)NN + 1));
     c->d_s2_order = c->d_s2_orderN = nullptr; c->n_s2_order = c->n_s2_orderN = 0;
     PoolScope s2_scope(c);                                        // the scratch goes on every way out (the two order streams above stay)
+    // harc_amd_params.stream_digest: every stream is folded into four words where it sits in HBM (k_stream_digest), [0] read_seq(+tail) of
+    // all shards, [1] noise + noisepos + pos, [2] rev(+tail) + singleton(+tail) + input_N.dna, [3] the two order streams
+    const bool want_digest = P.stream_digest != 0;
+    unsigned long long *d_digest = nullptr;
+    c->have_digest = false;
+    if (want_digest) { RC_TRY(dalloc(c, &d_digest, 4)); HIP_TRY(hipMemsetAsync(d_digest, 0, 32, c->stream)); }
     S2Args a; memset(&a, 0, sizeof a);
     a.L = L; a.W = W; a.W3 = W3; a.thresh_s = P.thresh_s; a.maxsearch = P.maxsearch;
     if (L > 50) { a.ds[0] = 0; a.de[0] = 20; a.ds[1] = 21; a.de[1] = 41; }                     // encoder.cpp:132-145
@@ -1225,6 +1259,7 @@ int stage2_run(harc_amd_ctx *c)
                 if (seq_tl[e]) hipLaunchKernelGGL(k_bases_to_ascii, G256(seq_tl[e]), cons + c0 + 4 * seq_nb[e], seq_tl[e], seqpk + seq_off[e] + seq_nb[e]);
             }
             HIP_TRY(hipGetLastError());
+            if (want_digest) for (uint32_t e = 0; e < E; e++) RC_TRY(digest_range(c, seqpk + seq_off[e], seq_nb[e] + seq_tl[e], 0x100 + e, d_digest + 0));
             RC_TRY(harc_host_alloc(c, (void **)&h_seq, (size_t)soff));
             HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
             HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
@@ -1447,6 +1482,19 @@ int stage2_run(harc_amd_ctx *c)
     if (nmtot) HIP_TRY(hipMemcpyAsync(h_noisepos, noisepos, (size_t)nmtot, hipMemcpyDeviceToHost, c->stream));
     if (F) HIP_TRY(hipMemcpyAsync(h_pos, posb, F, hipMemcpyDeviceToHost, c->stream));
     if (n_ntext) HIP_TRY(hipMemcpyAsync(h_ntext, ntext, n_ntext, hipMemcpyDeviceToHost, c->stream));
+    if (want_digest) {
+        // the shard cuts of noise / noisepos / pos are positions inside ONE array each: the arrays as a whole, then the cuts themselves
+        RC_TRY(digest_range(c, noise, nmtot + F, 0x200, d_digest + 1)); RC_TRY(digest_range(c, noisepos, nmtot, 0x201, d_digest + 1)); RC_TRY(digest_range(c, posb, F, 0x202, d_digest + 1));
+        for (uint32_t e = 0; e < E; e++) RC_TRY(digest_range(c, packed + rev_off[e], rev_nb[e] + rev_tl[e], 0x300 + e, d_digest + 2));
+        RC_TRY(digest_range(c, packed + sing_off, sing_nb + sing_tl, 0x3F0, d_digest + 2)); RC_TRY(digest_range(c, ntext, n_ntext, 0x3F1, d_digest + 2));
+        RC_TRY(digest_range(c, order_out, n_order, 0x400, d_digest + 3)); RC_TRY(digest_range(c, orderN_out, n_orderN, 0x401, d_digest + 3));
+        unsigned long long *h_dig = nullptr; RC_TRY(harc_host_alloc(c, (void **)&h_dig, 32));
+        HIP_TRY(hipMemcpyAsync(h_dig, d_digest, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 4; k++) c->digest[k] = h_dig[k];
+        for (uint32_t e = 0; e <= E; e++) { c->digest[1] += mix64(0x2F0ull + e + ((uint64_t)sh_f[e] << 20)) + mix64(0x2F8ull + e + (sh_nm[e] << 20)); c->digest[0] += mix64(0x1F0ull + e + (sh_col[e] << 20)); }
+        c->have_digest = true;
+    }
     for (uint32_t e = 0; e < E; e++) {
         const uint32_t f0 = sh_f[e], f1 = sh_f[e + 1];
         out_slice(c, HARC_AMD_S2_SEQ, e, h_seq + seq_off[e], seq_nb[e]); out_slice(c, HARC_AMD_S2_SEQ_TAIL, e, h_seq + seq_off[e] + seq_nb[e], seq_tl[e]);

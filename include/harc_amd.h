@@ -64,7 +64,8 @@ typedef struct harc_amd_params {
                                  already fragmented (one minimizer bucket of a multi-GPU shard) lose nothing with 1024 and run faster. */
     int32_t decode_memory_gb; /* -m of `./harc -d -p` (harc:225, MAX_BIN_SIZE of decoder_preserve.cpp:249-253): the original order is restored in bins of
                                  decode_memory_gb * 2e8 / 7 reads (0 = the driver's default 7; <= 3 counts as 3), and never more than fits in HBM */
-    int32_t reserved[1];
+    int32_t stream_digest;    /* 1: harc_amd_encode also folds every stage-II stream into four 64-bit words where it sits in HBM (harc_amd_stream_digest):
+                                 two runs, two kernel variants or two GPUs are compared at full size without touching gigabytes of host memory */
 } harc_amd_params;
 
 /* Counters: the three numbers the reference prints (reorder.cpp:701, encoder.cpp:506-508) + kernel-side statistics. */
@@ -211,6 +212,14 @@ int harc_amd_get_counters(harc_amd_ctx *ctx, harc_amd_counters *out);
 int harc_amd_decode_signature(harc_amd_ctx *ctx, uint64_t sig[3]);         /* decodes the context's stage-II streams */
 int harc_amd_reads_signature_device(harc_amd_ctx *ctx, const char *d_ascii, uint32_t n_reads, uint32_t stride, uint64_t sig[3]);
 int harc_amd_input_signature(harc_amd_ctx *ctx, uint64_t sig[3]);           /* of the clean + N reads the context currently holds */
+
+/* Digest of the stage-II streams of the last harc_amd_encode (needs params.stream_digest = 1), computed on the device from the very buffers the
+   streams are copied out of: out[0] read_seq.txt.<e>(+.tail) of all shards and their cuts, out[1] read_noise / read_noisepos / read_pos and their
+   cuts, out[2] read_rev.txt.<e>(+.tail), read_singleton.txt(+.tail), input_N.dna, out[3] read_order.bin and read_order_N_pe.bin.  Position-dependent
+   64-bit sums: equal streams give equal words, a changed, moved, lost or added byte changes them (encoder.cpp:190-196,457-503 name the files). */
+int harc_amd_stream_digest(harc_amd_ctx *ctx, uint64_t out[4]);
+/* sha256 (hex) of the kernel sources this library was built from: ties a committed profile (profiles/k_steps_traffic.json) to a build */
+const char *harc_amd_build_id(void);
 
 /* ---- file contract: drop-ins for the reference's stage programs.  basedir as argv[1] of those programs. */
 int harc_amd_reorder_files(const harc_amd_params *params, const char *basedir);

@@ -276,10 +276,63 @@ def make_qcase(name, kw):
     print(name, os.path.getsize(tarpath), "bytes")
 
 
+# Exact mode at CONFIG size (BASELINE.json configs[0] / configs[1]: "bit-exact vs CPU"): the inputs are too large to commit, so the fixture is
+# the generator call (tests/gen.reads_array_big, numpy RandomState: stable across versions), the md5 of the reads it makes, and the md5 + size
+# of EVERY file the reference leaves at -t 1 after reorder.out and after encoder.out.  tests/test_gpu_full_size.py regenerates the reads on the
+# GPU box, checks their md5, runs num_chains = 1 and compares file by file.
+MD5CASES = {
+    "configs0_1M": dict(seed=20260, n=1_000_000, L=100, genome_len=35_000_000, err=0.0),
+    "configs1_3p3M": dict(seed=20261, n=3_300_000, L=100, genome_len=6_300_000, err=0.005),
+}
+
+
+def make_md5case(name, kw):
+    import hashlib
+    sys.path.insert(0, os.path.dirname(HERE))
+    from tests import gen as tgen
+    L = kw["L"]
+    subprocess.check_call([os.path.join(HERE, "build_ref.sh")])
+    subprocess.check_call([os.path.join(HERE, "build_ref.sh"), str(L), "1"])
+    arr = tgen.reads_array_big(**kw)
+    wd = tempfile.mkdtemp(prefix="harc_goldmd5_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        os.makedirs(os.path.join(wd, "output"))
+        n = arr.shape[0]
+        # FASTQ records "@T.<i>\n<read>\n+\n<H x L>\n" without a Python loop over millions of reads
+        fq = os.path.join(wd, "in.fastq")
+        with open(fq, "wb") as f:
+            q = ("+\n" + "H" * L + "\n").encode()
+            for s0 in range(0, n, 100000):
+                blk = arr[s0:s0 + 100000]
+                f.write(b"".join(b"@T.%d\n" % (s0 + i) + blk[i].tobytes() + b"\n" + q for i in range(blk.shape[0])))
+        log = run([os.path.join(REF, "preprocess.out"), fq, wd, "False", "False", str(L)], wd)
+        os.remove(fq)
+        import time
+        t0 = time.time()
+        log += run([os.path.join(REF, f"reorder_L{L}_t1.out"), wd], wd)
+        t1 = time.time()
+        s1 = {k: [hashlib.md5(v).hexdigest(), len(v)] for k, v in snapshot(os.path.join(wd, "output")).items()}
+        t1b = time.time()
+        log += run([os.path.join(REF, f"encoder_L{L}_t1.out"), wd], wd)
+        t2 = time.time()
+        s2 = {k: [hashlib.md5(v).hexdigest(), len(v)] for k, v in snapshot(os.path.join(wd, "output")).items()}
+        meta = dict(name=name, gen=dict(function="tests.gen.reads_array_big", **kw), reads_md5=hashlib.md5(arr.tobytes()).hexdigest(),
+                    reference="reorder.out + encoder.out at num_thr = 1 (oracle/_ref, built by oracle/build_ref.sh from /root/reference)",
+                    reference_seconds=dict(reorder=round(t1 - t0, 1), encoder=round(t2 - t1b, 1)),
+                    stage1=s1, stage2=s2, log=log.splitlines())
+        with open(os.path.join(GOLD, "md5_" + name + ".json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        print(name, meta["reference_seconds"], [l for l in meta["log"] if "unmatched" in l or "aligned" in l])
+    finally:
+        shutil.rmtree(wd)
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + list(QCASES))
+    names = sys.argv[1:] or (list(CASES) + list(QCASES) + list(MD5CASES))
     for n in names:
-        if n in QCASES:
+        if n in MD5CASES:
+            make_md5case(n, MD5CASES[n])
+        elif n in QCASES:
             make_qcase(n, QCASES[n])
         else:
             make_case(n, CASES[n])

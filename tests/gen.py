@@ -29,6 +29,41 @@ def reads_array(seed, n, L, genome_len, err=0.0, rc=True, n_frac=0.25):
     return r
 
 
+def reads_array_big(seed, n, L, genome_len, err=0.0, n_frac=0.25, chunk=250_000):
+    """reads_array's distribution for CONFIG-size inputs (millions of reads), made chunk by chunk so that no (n, L) array of doubles
+    ever exists; its own stream of random numbers (not reads_array's).  Odd reads reverse-complemented."""
+    rs = np.random.RandomState(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rs.randint(0, 4, size=genome_len, dtype=np.uint8)]
+    out = np.empty((n, L), dtype=np.uint8)
+    ar = np.arange(L)
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        starts = rs.randint(0, genome_len - L, size=m)
+        r = genome[starts[:, None] + ar[None, :]]
+        if err > 0:
+            e = rs.random_sample((m, L)) < err
+            ne = int(e.sum())
+            isn = rs.random_sample(ne) < n_frac
+            code = np.searchsorted(acgt, r[e])
+            newb = acgt[(code + rs.randint(1, 4, size=ne)) % 4]
+            newb[isn] = ord("N")
+            r[e] = newb
+        odd = (np.arange(s, s + m) % 2) == 1
+        r[odd] = _COMP[r[odd][:, ::-1]]
+        out[s:s + m] = r
+    return out
+
+
+def lines_of(r):
+    """[n, L] uint8 -> bytes, one read per line"""
+    n, L = r.shape
+    out = np.empty((n, L + 1), dtype=np.uint8)
+    out[:, :L] = r
+    out[:, L] = 10
+    return out.tobytes()
+
+
 def reads_text(*a, **kw):
     """-> bytes: one read per line"""
     r = reads_array(*a, **kw)

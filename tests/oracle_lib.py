@@ -83,3 +83,28 @@ def stage2_files(E=1):
             fs.append(f"{stem}.{e}")
         fs += [f"read_seq.txt.{e}.tail", f"read_rev.txt.{e}.tail"]
     return fs
+
+
+def md5_cases():
+    """exact mode at CONFIG size (oracle/make_goldens.py MD5CASES): generator call + md5 of every file of the reference at -t 1"""
+    return sorted(f[4:-5] for f in os.listdir(GOLDEN_DIR) if f.startswith("md5_") and f.endswith(".json"))
+
+
+def load_md5_case(name):
+    """-> (meta dict, reads as [n, L] uint8) -- the reads are regenerated and checked against the recorded md5"""
+    import hashlib
+    import json
+    from tests import gen
+    with open(os.path.join(GOLDEN_DIR, "md5_" + name + ".json")) as f:
+        meta = json.load(f)
+    kw = {k: v for k, v in meta["gen"].items() if k != "function"}
+    arr = gen.reads_array_big(**kw)
+    got = hashlib.md5(arr.tobytes()).hexdigest()
+    assert got == meta["reads_md5"], f"{name}: the generator gives other reads here ({got}) than where the fixture was made ({meta['reads_md5']})"
+    return meta, arr
+
+
+def md5_mismatches(files, want, names):
+    """names whose bytes in `files` do not have the md5 (and size) recorded in want = {name: [md5, size]}"""
+    import hashlib
+    return [f for f in names if f not in files or [hashlib.md5(files[f]).hexdigest(), len(files[f])] != want[f]]

@@ -102,3 +102,32 @@ def test_quality_full_pipeline_orders_match_reference(oracle, tmp_path):
     assert oracle.harc_oracle_encoder(base.encode(), L, 1, None, None) == 0
     got = ol.read_dir(base)
     assert got["read_order.bin"] == g["np/read_order.bin"] and got["read_order_N_pe.bin"] == g["np/read_order_N_pe.bin"]
+
+
+@pytest.mark.parametrize("case", ol.md5_cases())
+def test_oracle_K1_at_config_size(case, oracle, tmp_path):
+    """P0 at CONFIG size: the oracle at K = 1, E = 1 against the md5 of every file the reference leaves at -t 1 on BASELINE.json configs[0]
+    (1 M x 100 bp, 2.9x) and the configs[1] stand-in (3.3 M x 100 bp, 52x, 0.5 % errors, 12 % N reads) -- 450 000 reseeds on the first,
+    410 000 realigned singleton / N reads on the second (tests/golden/md5_*.json, made by oracle/make_goldens.py)"""
+    from tests import gen
+    meta, arr = ol.load_md5_case(case)
+    L = arr.shape[1]
+    txt = gen.lines_of(arr)
+    del arr
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    import tempfile
+    with tempfile.TemporaryDirectory(dir=shm, prefix="harc_md5_") as td:
+        base = ol.stage_dir(td, {})
+        assert oracle.harc_oracle_preprocess(txt, len(txt), L, base.encode()) == 0
+        del txt
+        um = C.c_uint32(0)
+        assert oracle.harc_oracle_reorder(base.encode(), L, 1, 1, C.byref(um), None) == 0
+        bad = ol.md5_mismatches(ol.read_dir(base), meta["stage1"], ol.STAGE1_FILES + ["input_clean.dna", "input_N.dna", "numreads.bin", "read_order_N.bin"])
+        assert not bad, f"{case}: stage I differs from the reference: {bad}"
+        assert um.value == [int(l.split()[2]) for l in meta["log"] if l.startswith("Reordering done")][0]
+        ms, mn = C.c_uint32(0), C.c_uint32(0)
+        assert oracle.harc_oracle_encoder(base.encode(), L, 1, C.byref(ms), C.byref(mn)) == 0
+        bad = ol.md5_mismatches(ol.read_dir(base), meta["stage2"], ol.stage2_files(1))
+        assert not bad, f"{case}: stage II differs from the reference: {bad}"
+        assert ms.value == [int(l.split()[0]) for l in meta["log"] if "singleton reads were aligned" in l][0]
+        assert mn.value == [int(l.split()[0]) for l in meta["log"] if "reads with N were aligned" in l][0]

@@ -23,14 +23,15 @@ for k in sorted(agg):
 PY
   rm -rf gpurun_out/$R/pmc_$tag
 done
-python3 - gpurun_out/$R/pmc_${W}_summary.txt $W $R > gpurun_out/$R/k_steps_traffic_$W.json <<PY
+BID=$(python3 -c "import sys; sys.path.insert(0, '$ROOT'); import harc_amd; print(harc_amd.build_id())")
+python3 - gpurun_out/$R/pmc_${W}_summary.txt $W $R $BID > gpurun_out/$R/k_steps_traffic_$W.json <<PY
 import sys, json, re
 vals = {}
 for line in open(sys.argv[1]):
     if "k_steps<" not in line: continue
     m = re.search(r"(\S+)\s+launches=(\d+)\s+avg_per_launch=([0-9.]+)", line)
     if m: vals[m.group(1)] = (int(m.group(2)), float(m.group(3)))
-out = {sys.argv[2]: {"profile": "profiles/%s/pmc_%s_summary.txt" % (sys.argv[3], sys.argv[2]),
+out = {sys.argv[2]: {"profile": "profiles/%s/pmc_%s_summary.txt" % (sys.argv[3], sys.argv[2]), "build_id": sys.argv[4],
        "fetch_kb_per_launch": vals.get("FETCH_SIZE", (0, 0.0))[1], "write_kb_per_launch": vals.get("WRITE_SIZE", (0, 0.0))[1],
        "launches": vals.get("FETCH_SIZE", (0, 0.0))[0],
        "tcc_hit": vals.get("TCC_HIT_sum", (0, 0.0))[1], "tcc_miss": vals.get("TCC_MISS_sum", (0, 0.0))[1],
