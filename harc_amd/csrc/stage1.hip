@@ -58,6 +58,7 @@ struct S1Args {
     int nprobe;
     int budget;                      // HARC_SCAN_BUDGET (experiments may override it: HARC_AMD_BUDGET)
     int stepcap;                     // HARC_STEP_CAP (HARC_AMD_STEPCAP)
+    int lazy;                        // 1: steps that agree with the consensus everywhere take the rows from their read and leave the counts to cons_flush (HARC_AMD_LAZY=0: every step applies its counts; same bytes)
     uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups, w sequential-equivalent candidates
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
 };
@@ -690,7 +691,7 @@ __device__ __forceinline__ bool own_has(const uint32_t *tab, uint32_t id)
 static inline size_t steps_lds_bytes(int W, int maxmatch, int nprobe, bool seq = false)
 {
     const int NW = 2 * W, ROW = 3 * NW + 1, MROW = (NW + 3) & ~3;
-    return (size_t)4 * (64 * ((W + 1) / 2)) * 16 + ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)(seq ? 4 * HARC_OWN_SLOTS : 0) + (size_t)2 * nprobe + 8) * 4 + HARC_WGCMD_BYTES + 16;
+    return (size_t)4 * (64 * ((W + 1) / 2)) * 16 + ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)4 * 32 + (size_t)(seq ? 4 * HARC_OWN_SLOTS : 0) + (size_t)2 * nprobe + 8) * 4 + HARC_WGCMD_BYTES + 16;
 }
 // Hamming distance between a candidate read (registers) and the consensus shifted by the lane's own amount: `row` = ref or rref window
 // row in LDS, bitoff = 32 NW +- 2j, mrow = mask row of (direction, shift) (reorder.cpp:543,608 with mask[j] / revmask[j] of :706-718)
@@ -783,6 +784,69 @@ template <int W, bool I> __device__ __forceinline__ void cons_rows(const ConsSta
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// A step whose read agrees with the consensus on EVERY column of the overlap (Hamming distance 0: all steps on error-free data, a third of
+// them at 1 % errors) leaves a consensus that IS the oriented read: the overlap columns keep their majority (the count of the base that already
+// led goes up by one), the columns behind it are the read's (reorder.cpp:884-909).  Such a step takes the window rows straight from the read
+// -- one row is the read as stored, the other its reverse complement, 2 NW lanes make a dword each -- instead of the ~45 vector instructions of
+// cons_rows, and it does NOT touch the column counts: it only notes its shift (cons_flush applies a whole run of such steps at once).
+template <int W> __device__ __forceinline__ void rows_from_read(const uint32_t *rdl, int L, int rev, int lane, uint32_t *rowF, uint32_t *rowR)
+{
+    constexpr int NW = 2 * W;
+    // (the lane number goes through an empty asm: everything below would otherwise be hoisted out of the step loop as a dozen loop-invariant
+    // lane masks and addresses, and the kernel has no register left for them -- they came back as scratch reloads behind s_waitcnt vmcnt(0))
+    int ln = lane; asm volatile("" : "+v"(ln));
+    if (ln < 2 * NW) {
+        const bool copy = ln < NW;
+        const int k = copy ? ln : ln - NW;                        // dword of the row
+        // field i of the reverse complement = 3 - field (L - 1 - i) of the read: the 16 fields of dword k come from the 32-bit window of the
+        // read at bit P = 2 (L - 16 k - 16), field order reversed, complemented; what lies outside the read is zero on both sides
+        const int P = 2 * (L - 16 * k - 16), i0 = P >> 5;
+        const int ia = i0 < 0 ? 0 : (i0 > NW - 1 ? NW - 1 : i0), ib = i0 + 1 < 0 ? 0 : (i0 + 1 > NW - 1 ? NW - 1 : i0 + 1);
+        const uint32_t ra = rdl[copy ? k : ia], rb = rdl[ib];
+        const uint32_t lo = (i0 >= 0 && i0 < NW) ? ra : 0u, hi = (i0 + 1 >= 0 && i0 + 1 < NW) ? rb : 0u;
+        uint32_t w = __brev(__builtin_amdgcn_alignbit(hi, lo, P & 31));
+        w = ((w & 0xAAAAAAAAu) >> 1) | ((w & 0x55555555u) << 1);
+        const int vb = 2 * L - 32 * k;                             // bits of the 2L-bit row that fall into this dword
+        const uint32_t d = copy ? ra : (~w & (vb >= 32 ? 0xFFFFFFFFu : (vb <= 0 ? 0u : ((1u << vb) - 1u))));
+        (copy != (rev != 0) ? rowF : rowR)[NW + k] = d;            // forward match: rowF = read; reverse match: rowF = its reverse complement
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// The column counts after `pend` steps of that kind, whose cumulative shifts are ps[0 .. pend) (ptot = the last): column l of the consensus of
+// now (its base: rowF) was covered by step k exactly when ptot - ps[k] < L - l; where it existed before the run (l + ptot < L: the same ring
+// slot, nothing moved) its old counts stay and the leading base gains one per step, else it starts from the steps that cover it.  Identical
+// to applying cons_update_lds step by step -- the tests force both ways (HARC_AMD_LAZY=0) onto the same bytes.
+template <int W, bool I> __device__ __forceinline__ void cons_flush(ConsState<W, I> &st, const uint16_t *ps, int pend, int ptot, const uint32_t *rowF, int L, int lane)
+{
+    constexpr int LP = ConsState<W, I>::LP, CT = ConsState<W, I>::CT, NW = 2 * W;
+    int nb = 0;
+    if (ptot < L) { nb = st.base + ptot; if (nb >= LP) nb -= LP; }         // beyond that no old column is left and any base will do
+    int ln = lane; asm volatile("" : "+v"(ln));                    // nothing of this is to be hoisted out of the step loop (see rows_from_read)
+    int newl[CT], cnt[CT];
+#pragma unroll
+    for (int t = 0; t < CT; t++) { newl[t] = ln + 64 * t - nb; if (newl[t] < 0) newl[t] += LP; cnt[t] = 0; }
+    for (int k = pend - 1; k >= 0; k--) {                         // the latest steps first: those more than L behind cover nothing
+        const int d = __builtin_amdgcn_readfirstlane(ptot - (int)ps[k]);     // wave-uniform
+        if (d >= L) break;
+#pragma unroll
+        for (int t = 0; t < CT; t++) cnt[t] += (d < L - newl[t]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < CT; t++) {
+        uint4 q = make_uint4(0, 0, 0, 0); int v = 0;
+        if (newl[t] < L) {
+            const int pc = (int)((rowF[NW + (newl[t] >> 4)] >> (2 * (newl[t] & 15))) & 3u);
+            v = ((pc & 1) << 1) | (pc >> 1);                       // packed code A0 G1 C2 T3 -> count row A0 C1 G2 T3
+            if (newl[t] + ptot < L) q = st.getq(t);
+            const uint32_t c = (uint32_t)cnt[t];
+            q.x += v == 0 ? c : 0u; q.y += v == 1 ? c : 0u; q.z += v == 2 ? c : 0u; q.w += v == 3 ? c : 0u;
+        }
+        st.setq(t, q); st.v[t] = v;
+    }
+    st.base = nb;
 }
 
 // ---- the COOP kernel gives a whole workgroup to one chain: wave 0 walks the chain (the same code as the main kernel), waves 1..3
@@ -955,7 +1019,11 @@ template <int W> __global__ void k_steps_tables(S1Args s, uint32_t *out)
 // NWV (COOP only): waves per workgroup = the walking wave + NWV - 1 helpers that share its scans (64 NWV candidates per round trip).  Few
 // walks per super-round are bound by the longest one: 4 waves.  More walks than the chip holds workgroups are bound by wave slots, most of
 // which helpers idle in: fewer helpers, more walkers (stage1_run_w picks it from the walks of the last rounds; what is computed is the same).
-template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ = false> __global__ __launch_bounds__(256, COOP ? HARC_COOP_WAVES : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? (SEQ ? HARC_SEQ_EXTRA_WAVES : 2) : 0))) void k_steps(S1Args s)
+// SPEC (the dense wave-uniform kernel on reads of 100 bases and more, i.e. every headline configuration): 64-bit keys in both dictionaries, bitmap lines
+// by 16-base minimizers over 17 windows, a table of fewer than 2^34 slots, maxsearch above HARC_LARGEBIN, full-width batches -- what the general
+// kernel asks its argument block about at run time is a constant here: no key masks, no 64-bit bucket arithmetic, one minimizer loop, and a
+// dozen scalar registers less to spill (stage1_run_w checks the conditions; same bytes either way, HARC_AMD_SPEC=0 forces the general kernel)
+template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ = false, bool SPEC = false> __global__ __launch_bounds__(256, COOP ? HARC_COOP_WAVES : (QUAD ? HARC_STEPS_WAVES_Q : (W <= 4 ? HARC_STEPS_WAVES : HARC_STEPS_WAVES - 1) + (DENSE ? (SEQ ? HARC_SEQ_EXTRA_WAVES : 2) : 0))) void k_steps(S1Args s)
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -965,7 +1033,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     uint32_t *const s_rows = s_mask + (size_t)2 * s.maxmatch * MROW;
     uint32_t *const s_rdl = s_rows + 4 * 2 * ROW;
     uint32_t *const s_tmp = s_rdl + 4 * MROW;
-    uint32_t *const s_own = s_tmp + 4 * 8 * NW;
+    uint32_t *const s_pend = s_tmp + 4 * 8 * NW;                  // 4 waves x 64 u16: cumulative shifts of the steps whose counts are still to be applied (cons_flush)
+    uint32_t *const s_own = s_pend + 4 * 32;
     uint2 *const s_pinfo = reinterpret_cast<uint2 *>(s_own + (SEQ ? 4 * HARC_OWN_SLOTS : 0));      // the table exists in the kernel that asks it only (2 KB more LDS cost the 150-bp kernel a workgroup per CU)
     WgCmd *const cmd = reinterpret_cast<WgCmd *>(reinterpret_cast<char *>(s_pinfo + s.nprobe) + 8 - ((size_t)(s_pinfo + s.nprobe) & 7));
     // main kernel: 4 chains per workgroup, one wave each.  COOP: one chain per workgroup, wave 0 walks it (role 0), waves 1..3 help with the scans
@@ -1094,7 +1163,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     uint32_t *const rowF = s_rows + (size_t)wv * 2 * ROW, *const rowR = rowF + ROW, *const rdl = s_rdl + (size_t)wv * MROW;
     uint8_t *const coltmp = reinterpret_cast<uint8_t *>(s_tmp + (size_t)wv * 8 * NW);
     uint32_t *const ownt = s_own + (size_t)wv * HARC_OWN_SLOTS;
-    const uint64_t kmask0 = s.kbits[0] < 64 ? (((uint64_t)1 << s.kbits[0]) - 1) : ~(uint64_t)0, kmask1 = s.kbits[1] < 64 ? (((uint64_t)1 << s.kbits[1]) - 1) : ~(uint64_t)0;
+    uint16_t *const pshift = reinterpret_cast<uint16_t *>(s_pend + (size_t)wv * 32);
+    const uint64_t kmask0 = (SPEC || s.kbits[0] >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << s.kbits[0]) - 1), kmask1 = (SPEC || s.kbits[1] >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << s.kbits[1]) - 1);
     const uint64_t cap = s.cap[0];                               // both dictionaries have the same geometry (stage1_run_w)
     uint32_t dbg_bins = 0, dbg_iter = 0, dbg_miss = 0, dbg_surv = 0, dbg_batches = 0;   // coop scans / their 64-entry chunks / steps without a hit / (unused) / batches
     uint32_t np = 0, nc = 0, nuse = 0, ncu = 0;                   // ncu: candidates a strictly sequential scan (reorder.cpp:517-649) would have tested too
@@ -1104,11 +1174,14 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     int bigprobes = 0;                                           // COOP: probes into large live bins made by this walk so far
     const int resume = (int)(h.flags >> 16);                     // the first step of this super-round was put off before: where it takes up again
     bool stalled = false; int resume_next = 0;
+    // steps that agreed with the consensus everywhere (rows_from_read): the rows are current, `pend` of them wait for cons_flush, ptot = their shifts
+    bool rows_ok = false; int pend = 0, ptot = 0;
+    const bool lazy = s.lazy != 0;
     PH(0);
     for (int t = T0; t < s.S; t++) {
-        cons_rows(st, L, lane, coltmp, rowF, rowR);            // consensus and its reverse complement -> the wave's window rows
+        if (!rows_ok) cons_rows(st, L, lane, coltmp, rowF, rowR);   // consensus and its reverse complement -> the wave's window rows
         PH(1);
-        uint32_t found = HARC_NONE; int fj = 0, fdir = 0;
+        uint32_t found = HARC_NONE; int fj = 0, fdir = 0, fhd = -1;   // fhd: Hamming distance of the accepted read where the scan that found it knows it
         // Probes are issued in priority order in batches: every probe behind the first hit of a batch is speculative traffic,
         // every extra batch is a serial round trip to HBM.
         int base = (t == 0 && resume > 0) ? resume : 0;          // the probes before `resume` were made in an earlier super-round: nothing then, nothing now
@@ -1121,11 +1194,11 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             // 4-byte lookup (48: configs[2] chains 768 -> 728 ms); with the bitmap's lines chosen by minimizer it shares the lines of the
             // useful probes (64).  With few chains a round trip costs more than the probes (QUAD: 64).
             int bend;
-            { int w0 = bi == 0 ? ((HARC_W0_MUL * (lastp >> 4) + HARC_W0_ADD + 15) & ~15) : 64; const int wmax = QUAD ? 64 : (bi <= 1 ? s.firstmax : 64); if (w0 > wmax) w0 = wmax; bend = base + w0; }
+            { int w0 = bi == 0 ? ((HARC_W0_MUL * (lastp >> 4) + HARC_W0_ADD + 15) & ~15) : 64; const int wmax = (QUAD || SPEC) ? 64 : (bi <= 1 ? s.firstmax : 64); if (w0 > wmax) w0 = wmax; bend = base + w0; }
             if (bend > s.nprobe) bend = s.nprobe;
             if (bend <= base) bend = s.nprobe;
             const int p = base + lane; dbg_batches++;
-            uint32_t mine = HARC_NONE; int j = 0, dir = 0, l = 0;
+            uint32_t mine = HARC_NONE; int j = 0, dir = 0, l = 0, myhd = 0;
             uint32_t ncb = 0;                                             // candidates this lane tests in this batch
             bool big = false; uint32_t b_cnt = 0; uint64_t b_slot = 0;   // a bin too large for one lane: scanned by the whole wave below
             uint2 b_lt = make_uint2(0, 0);                               // COOP: its row of largetab, fetched by the lane that found it (all bins of the batch in ONE round trip)
@@ -1139,7 +1212,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                 {   // key = kbits bits of the (reverse) consensus at bit 2 (ds +- j)
                     const int i0 = (int)((pi.x & 0x1FFF) >> 5), shb = (int)(pi.x & 31);
                     const uint32_t d0 = rowF[i0], d1 = rowF[i0 + 1], d2 = rowF[i0 + 2];
-                    key = ((uint64_t)__builtin_amdgcn_alignbit(d1, d0, shb) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, shb) << 32)) & (l ? kmask1 : kmask0);
+                    key = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, shb) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, shb) << 32);
+                    if constexpr (!SPEC) key &= (l ? kmask1 : kmask0);
                 }
                 HashSlot *const tab = l ? s.slots[1] : s.slots[0];
                 // The table is bucketed (64 B = 4 slots).  QUAD (few chains, latency-bound): the whole bucket in one round trip; otherwise
@@ -1147,12 +1221,14 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                 // search unless its overflow flag says that keys went on to the next one.
                 // phase 1: every lane finishes its slot search (the dependent bucket fetches of all lanes overlap) ...
                 const uint64_t hk = key_scramble(key);                    // what the table stores and compares
-                uint64_t sl = bucket_slot(hk, cap);
+                uint64_t sl;
+                if constexpr (SPEC) sl = (uint64_t)__umulhi((uint32_t)(hk >> 32), (uint32_t)(cap >> 2)) << 2; else sl = bucket_slot(hk, cap);
                 int state = 0, qhit = 0;                                  // 1 = the key is not in the table, 2 = key found
                 uint32_t sst = 0, cw = 0;
                 if (s.bloom_lines) {                                      // most keys of a step are in neither: they stop at the bitmap
                     uint32_t bw, bm;
-                    bloom_pos(key, hk, s.bloom_lines, s.bloom_nwin[0], s.bloom_mmask, &bw, &bm);      // both dictionaries have keys of the same width when nwin > 0
+                    if constexpr (SPEC) bloom_pos(key, hk, s.bloom_lines, 17, 0xFFFFFFFFu, &bw, &bm);
+                    else bloom_pos(key, hk, s.bloom_lines, s.bloom_nwin[0], s.bloom_mmask, &bw, &bm);      // both dictionaries have keys of the same width when nwin > 0
                     if (((l ? s.bloom[1] : s.bloom[0])[bw] & bm) != bm) state = 1;
                 }
                 if (state == 0) for (;;) {
@@ -1201,7 +1277,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                         const uint32_t *const mrow = s_mask + (pi.y >> 16);
                         const int bitoff = (int)(pi.y & 0xFFFF);
                         // at most HARC_LARGEBIN reads: the maxsearch window (reorder.cpp:540) cannot close unless maxsearch itself is that small
-                        const bool exactwin = s.maxsearch < (int)HARC_LARGEBIN;
+                        const bool exactwin = !SPEC && s.maxsearch < (int)HARC_LARGEBIN;
                         uint32_t lead = 0; bool alltop = true; int seen = 0;
                         for (uint32_t i = cntb; i > 0 && seen < s.maxsearch; i--) {
                             const uint32_t rid = emb ? sst : ids[sst + i - 1];
@@ -1217,7 +1293,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                             if (exactwin || hd <= s.thresh) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
                             if (own) continue;
                             nc++; ncb++; if (exactwin) seen++;
-                            if (hd <= s.thresh) { mine = rid; break; }
+                            if (hd <= s.thresh) { mine = rid; myhd = hd; break; }
                         }
                         // hints only (the claim bitmap stays the truth): claimed reads at the top of a bin are never looked at again
                         if (lead) {
@@ -1237,7 +1313,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             {
                 unsigned long long mc = __ballot(cand);
                 if (!COOP) { const unsigned long long mb = __ballot(big); if (mb) mc &= (mb & (0ULL - mb)) - 1ULL; }      // behind a large bin the main kernel stops anyway
-                const bool exactwin = s.maxsearch < (int)HARC_LARGEBIN;      // else the maxsearch window (reorder.cpp:540) cannot close inside a small bin
+                const bool exactwin = !SPEC && s.maxsearch < (int)HARC_LARGEBIN;      // else the maxsearch window (reorder.cpp:540) cannot close inside a small bin
                 uint32_t ntest = 0;
                 while (mc) {
                     const int w = __ffsll((long long)mc) - 1;
@@ -1251,7 +1327,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                     const int bitoff = (int)(o_piy & 0xFFFF), i0 = bitoff >> 5, sh = bitoff & 31;
                     const uint32_t *const mrow = s_mask + (o_piy >> 16);
                     const uint64_t o_slot = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)c_slot, w) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(c_slot >> 32), w) << 32);
-                    uint32_t lead = 0, hit = HARC_NONE, rd = 0; bool alltop = true; int seen = 0;
+                    uint32_t lead = 0, hit = HARC_NONE, rd = 0; bool alltop = true; int seen = 0, hit_hd = -1;
                     for (uint32_t i = cntb; i > 0 && seen < s.maxsearch; i--) {
                         const uint32_t rid = emb ? o_sst : (uint32_t)__builtin_amdgcn_readfirstlane((int)ids[o_sst + i - 1]);
                         // claim bit and read words are fetched together (one dependent hop instead of two)
@@ -1270,7 +1346,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                         hdp += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hdp, 0x111, 0xF, 0xF, true);
                         const int hd = __builtin_amdgcn_readlane((int)hdp, 15);
                         ntest++; if (exactwin) seen++;
-                        if (hd <= s.thresh) { hit = rid; break; }
+                        if (hd <= s.thresh) { hit = rid; hit_hd = hd; break; }
                     }
                     // hints only (the claim bitmap stays the truth): claimed reads at the top of a bin are never looked at again
                     if (lead && lane == 0) {
@@ -1278,7 +1354,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                         if (lead == cntb) atomicOr(cp, SLOT_DEAD); else if (!emb) atomicMin(cp, (cntb - lead) | (o_cw & SLOT_OVF));
                     }
                     if (hit != HARC_NONE) {
-                        winlane = w; found = hit; fj = __builtin_amdgcn_readlane(j, w); fdir = __builtin_amdgcn_readlane(dir, w);
+                        winlane = w; found = hit; fj = __builtin_amdgcn_readlane(j, w); fdir = __builtin_amdgcn_readlane(dir, w); fhd = hit_hd;
                         if (lane < NW) rdl[lane] = rd;                         // the accepted read, for updaterefcount
                         break;
                     }
@@ -1291,6 +1367,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                 if (msmall) {
                     winlane = __ffsll((long long)msmall) - 1;
                     found = (uint32_t)__builtin_amdgcn_readlane((int)mine, winlane); fj = __builtin_amdgcn_readlane(j, winlane); fdir = __builtin_amdgcn_readlane(dir, winlane);
+                    fhd = __builtin_amdgcn_readlane(myhd, winlane);
                     if (lane == winlane) {
 #pragma unroll
                         for (int k = 0; k < NW; k++) rdl[k] = mrd[k];
@@ -1344,7 +1421,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                     const WgResult wr = wg_scan<W, NWV>(cmd, 0, lane, idp, s.mirror, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh);
                     dbg_iter += wr.iters; dbg_surv += wr.tests; nc += wr.nc; ncu += wr.nc;
                     const int besthit = wr.besthit;
-                    if (besthit < 64) { found = cmd->found; fj = wr.fj; fdir = wr.fdir; }
+                    if (besthit < 64) { found = cmd->found; fj = wr.fj; fdir = wr.fdir; fhd = -1; }     // the helpers' scan does not report the distance
                     if (besthit < 64) { winlane = besthit; bigm &= (1ULL << besthit) - 1ULL; }
 #ifdef HARC_COOP_TRACE
                     if (s.dbg) { dbg_kt[dbg_kind] += (unsigned long long)(wall_clock64() - dbg_s0); dbg_kn[dbg_kind]++; }
@@ -1392,7 +1469,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             if (lane < NW) { const uint32_t *rp = reinterpret_cast<const uint32_t *>(s.reads + (size_t)sid * W); rdl[lane] = rp[lane]; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            cons_reset_lds(st, rdl, L, lane);
+            cons_reset_lds(st, rdl, L, lane);                      // every count is replaced: what was pending is gone with the old consensus
+            rows_ok = false; pend = 0; ptot = 0;
             nst++;
             if (COOP && bigprobes >= s.budget) break;
             continue;
@@ -1405,11 +1483,21 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         if constexpr (SEQ) { if (lane == 0) own_insert(ownt, found); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        cons_update_lds(st, rdl, L, fdir, fj, lane);
+        if (lazy && fhd == 0) {                                    // the read agrees with the consensus on the whole overlap: the new consensus is the read
+            rows_from_read<W>(rdl, L, fdir, lane, rowF, rowR);
+            ptot += fj;
+            if (lane == 0) pshift[pend] = (uint16_t)ptot;
+            pend++; rows_ok = true;
+        } else {
+            if (pend) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); cons_flush(st, pshift, pend, ptot, rowF, L, lane); pend = 0; ptot = 0; }
+            cons_update_lds(st, rdl, L, fdir, fj, lane);
+            rows_ok = false;
+        }
         nst++;
         PH(4);
         if (COOP && bigprobes >= s.budget) break;
     }
+    if (pend) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); cons_flush(st, pshift, pend, ptot, rowF, L, lane); pend = 0; ptot = 0; }
     PH(4);
     if (COOP) { if (lane == 0) cmd->op = 0; __syncthreads(); }      // the walk is over: the helpers leave
     if (nst > 0) cons_store(st, B1, L, lane);
@@ -2365,6 +2453,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (getenv("HARC_AMD_BUDGET")) a.budget = atoi(getenv("HARC_AMD_BUDGET"));
 #endif
     if (a.stepcap < 1) a.stepcap = 1;
+    a.lazy = getenv("HARC_AMD_LAZY") ? (atoi(getenv("HARC_AMD_LAZY")) != 0 ? 1 : 0) : 1;
     a.firstmax = (bloom_nwin[0] > 0 && bloom_nwin[1] > 0) ? 64 : 48;     // lines by minimizer: speculative probes share their lines
     if (const char *e = getenv("HARC_AMD_FIRSTMAX")) { const int x = atoi(e); a.firstmax = x < 1 ? 1 : x > 64 ? 64 : x; }
     HIP_TRY(hipMemsetAsync(a.claimed, 0, nwords * 8, c->stream));
@@ -2409,6 +2498,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // scan, and no count the index has tells it from configs[2]).  Both variants compute the same thing, so a dense run MEASURES: the first
     // eight super-rounds with the wave-uniform scan, the next eight without, the faster one from there on (HARC_AMD_SEQ=0/1 forces one).
     bool seq = getenv("HARC_AMD_SEQ") ? atoi(getenv("HARC_AMD_SEQ")) != 0 : (HARC_SEQ_SCAN && N && (double)dict[0].nbins > 0.88 * (double)N);
+    // the specialised form of the dense wave-uniform kernel (k_steps' SPEC): its constants must be this run's parameters
+    const bool spec = (getenv("HARC_AMD_SPEC") ? atoi(getenv("HARC_AMD_SPEC")) != 0 : true) && W >= 4 && a.kbits[0] == 64 && a.kbits[1] == 64 && bloom_lines > 0 && bloom_nwin[0] == 17 && bloom_nwin[1] == 17 &&
+                      bloom_mmask == 0xFFFFFFFFu && (dict[0].cap >> 34) == 0 && P.maxsearch >= (int)HARC_LARGEBIN && a.firstmax == 64;
     int seq_probe = (!getenv("HARC_AMD_SEQ") && HARC_SEQ_SCAN && dense && !quad && seq) ? 0 : 2;      // 0 / 1: the batch being timed, 2: decided
     float seq_ms[2] = { 0, 0 };
     uint64_t rounds = 0, launches = 0;
@@ -2431,6 +2523,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (cm) hipLaunchKernelGGL(k_apply_seed, dim3(nblk), dim3(256), 0, c->stream, a);          // the seeds of the chains other ranks walk
             if (prof) { RC_TRY(R.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }
             if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
+            else if (dense && seq && spec) hipLaunchKernelGGL((k_steps<W, false, false, true, 4, true, true>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
             else if (dense && seq) hipLaunchKernelGGL((k_steps<W, false, false, true, 4, true>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
             else if (dense) hipLaunchKernelGGL((k_steps<W, false, false, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
             else hipLaunchKernelGGL((k_steps<W, false, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);

@@ -35,6 +35,8 @@ def _synth_text(n, L, G, err, seed):
     # the kernels a 350 M-read run takes, forced at a size the oracle can follow: dense launch with the wave-uniform scan (8 waves per SIMD),
     # k_reseed by 64 workgroups -- with 3.3 M reads its later rounds need more than one pass of a million bitmap bits to find their seeds
     ("configs1", 3_300_000, 100, 6_300_000, 0.005, 8, False, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_RESEED_MG": "1"}),
+    # ... in its specialised form (SPEC: needs the bitmap lines by minimizer, which a 3.3 M-read bitmap gets only when told so)
+    ("configs1", 3_300_000, 100, 6_300_000, 0.005, 8, False, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0"}),
     ("configs0", 1_000_000, 100, 35_000_000, 0.0, 8, True, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_RESEED_MG": "1", "HARC_AMD_S1BLOOM_TILED": "1", "HARC_AMD_S1BLOOM_VERIFY": "1"})])
 def test_config_size_matches_oracle(name, n, L, G, err, E, expect_lowcov, env, oracle, tmp_path, monkeypatch):
     import harc_amd

@@ -58,8 +58,8 @@ def _free():
 def test_configs2_350M_x_100bp(monkeypatch):
     """configs[2]: 350 M x 100 bp error-free on one GPU -- what bench.py times.  Lossless; two runs of one context agree; every execution variant
     a run of this size can take (lane-serial / wave-uniform scan of the small bins, k_reseed by one or by 64 workgroups, bitmap by atomics or
-    by tiles) produces the same digest."""
-    for k in ("HARC_AMD_SEQ", "HARC_AMD_RESEED_MG", "HARC_AMD_S1BLOOM_TILED"):
+    by tiles, column counts applied per step or per run of agreeing steps) produces the same digest."""
+    for k in ("HARC_AMD_SEQ", "HARC_AMD_RESEED_MG", "HARC_AMD_S1BLOOM_TILED", "HARC_AMD_LAZY", "HARC_AMD_SPEC"):
         monkeypatch.delenv(k, raising=False)
     h, sig_in, (n, L, G, err) = _ctx("c3")
     try:
@@ -68,7 +68,7 @@ def test_configs2_350M_x_100bp(monkeypatch):
         assert h.decode_signature() == sig_in, "configs[2]: the decoded streams are not the input reads"
         d1, c1 = _run(h)
         assert d1 == d0 and c1 == c0, "configs[2]: two runs of one context differ"
-        for env in ({"HARC_AMD_SEQ": "0"}, {"HARC_AMD_SEQ": "1"}, {"HARC_AMD_RESEED_MG": "0"}, {"HARC_AMD_S1BLOOM_TILED": "0"}):
+        for env in ({"HARC_AMD_SEQ": "0"}, {"HARC_AMD_SEQ": "1"}, {"HARC_AMD_RESEED_MG": "0"}, {"HARC_AMD_S1BLOOM_TILED": "0"}, {"HARC_AMD_LAZY": "0"}, {"HARC_AMD_SPEC": "0"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             dv, cv = _run(h)

@@ -214,13 +214,17 @@ def test_low_complexity_big_bins_match_oracle(n, glen, K, S, E, err, oracle, tmp
                                  {"HARC_AMD_COOP_WAVES": "1"}, {"HARC_AMD_COOP_WAVES": "2"}, {"HARC_AMD_RESEED_MG": "1"},
                                  {"HARC_AMD_RESEED_MG": "1", "HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1"},
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1"}, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "0"},
+                                 {"HARC_AMD_LAZY": "0"}, {"HARC_AMD_LAZY": "0", "HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1"},
+                                 {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0"},      # the specialised dense kernel (k_steps' SPEC) ...
+                                 {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_SPEC": "0"},      # ... and the general one under the same conditions
+                                 {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_LAZY": "0"},
                                  {"HARC_AMD_TABLE_FILL": "0"}, {"HARC_AMD_TABLE_FILL": "1"}, {"HARC_AMD_SORT_BITS": "8"}, {"HARC_AMD_SORT_BITS": "13"}, {"HARC_AMD_SORT_BITS": "1"}, {"HARC_AMD_SORT_BITS": "64"},
                                  {"HARC_AMD_S2BLOOM_TILED": "1", "HARC_AMD_S2BLOOM_VERIFY": "1"}, {"HARC_AMD_S2BLOOM_TILED": "1", "HARC_AMD_S2BLOOM_VERIFY": "1", "HARC_AMD_BLOOM4_HASHED": "1"},
                                  {"HARC_AMD_S1BLOOM_TILED": "1", "HARC_AMD_S1BLOOM_VERIFY": "1"},
                                  {"HARC_AMD_S1BLOOM_TILED": "1", "HARC_AMD_S1BLOOM_VERIFY": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1"}])
 def test_kernel_variants_same_bytes(env, oracle, tmp_path, monkeypatch):
     """the variants the library picks by problem size (two-slot vs whole-bucket fetches, 5 vs 6 waves per SIMD, bitmap lines hashed vs by
-    minimizer, with / without the bitmaps, the table cleared by a memset or by the placement itself, the index sorted on its top 8 / 13 bits with the mixed stretches fixed up, on 1 bit (stretches too long: falls back to all 64) and on all bits, the stage-I bitmap built tile by tile from sorted keys instead of with atomics (and compared with it word for word), stage-II bitmap kinds, a fuller table, 1 / 2 / 4 waves per cooperative workgroup) are execution details: forced on a small repeat-rich
+    minimizer, with / without the bitmaps, the table cleared by a memset or by the placement itself, the index sorted on its top 8 / 13 bits with the mixed stretches fixed up, on 1 bit (stretches too long: falls back to all 64) and on all bits, the stage-I bitmap built tile by tile from sorted keys instead of with atomics (and compared with it word for word), the column counts applied step by step instead of a run of agreeing steps at once (HARC_AMD_LAZY=0), stage-II bitmap kinds, a fuller table, 1 / 2 / 4 waves per cooperative workgroup) are execution details: forced on a small repeat-rich
     input, every stage-I and stage-II file is the oracle's"""
     import harc_amd
     for k, v in env.items():
