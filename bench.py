@@ -539,7 +539,8 @@ def main():
     # shards -- a read lost, duplicated or altered anywhere between the slice and the streams (the all-to-all included) shows.
     dsig = h.decode_signature()
     seq_bases_total, reads_total = int(c.seq_bases), n
-    if replicate:
+    s2_part = world > 1 and os.environ.get("HARC_AMD_S2_PART", "1") != "0"      # design (R): stage II partitioned over the ranks by encoder shard (the default)
+    if replicate and not s2_part:
         reads_total = n * world                                   # every rank decoded the WHOLE job: its signature alone must equal all ranks' inputs
     elif dist is not None:
         with wd.phase("round-trip signature", args.watchdog):
@@ -605,7 +606,7 @@ def main():
                    "error_rate": err, "chains_per_gpu": int(c.chains), "reads_per_chain": rpc or 2048, "encoder_shards_per_gpu": args.shards,
                    "schedule": "throughput mode: deterministic K-chain x S-step schedule of DESIGN.md (lossless, == CPU oracle byte for byte; "
                                "bytes differ from the reference's -t 1, which is num_chains = 1: see exact_mode)",
-                   "parallelism": "single GPU" if world == 1 and dist is None else (f"design (R) x{world}: reads all-gathered, index replicated, chains partitioned, one all-gather of the walked steps per super-round; every GPU ends with the single-GPU archive" if replicate else f"minimizer-bucket shard x{world}, one RCCL all-to-all (8W+4 B per read) inside every step")},
+                   "parallelism": "single GPU" if world == 1 and dist is None else (f"design (R) x{world}: reads all-gathered, index replicated, chains partitioned, one all-gather of the walked steps per super-round; stage II partitioned by encoder shard with one all-reduce(min) of the claims; the ranks' stream files are the single-GPU archive" if replicate else f"minimizer-bucket shard x{world}, one RCCL all-to-all (8W+4 B per read) inside every step")},
         "roofline": roofline,
         "build_id": harc_amd.build_id(),
         "roundtrip": roundtrip,

@@ -350,7 +350,18 @@ extern "C" int harc_amd_encode(harc_amd_ctx *c)
     if (!c->have_s1) { harc_set_error("harc_amd_encode: no stage-I result (call harc_amd_reorder or harc_amd_set_stage1_streams)"); return HARC_AMD_ESTATE; }
     HIP_TRY(hipSetDevice(c->P.device));
     const double t0 = now_ms();
-    if (!c->s1_from_files) RC_TRY(stage1_make_oriented(c));
+    // design (R) on more than one rank: stage II is partitioned by encoder shard (stage2_run's header); HARC_AMD_S2_PART=0 keeps it replicated --
+    // every rank then ends with ALL streams of the job, as a single GPU does (tests compare the two)
+    c->s2_part = false; c->s2_e0 = 0; c->s2_e1 = 0;
+    uint32_t oi0 = 0, oi1 = 0xFFFFFFFFu;
+    if (c->replicated && c->comm && c->comm->world > 1 && !c->s1_from_files && !(getenv("HARC_AMD_S2_PART") && atoi(getenv("HARC_AMD_S2_PART")) == 0)) {
+        const uint32_t E = (uint32_t)c->P.num_thr, wd = (uint32_t)c->comm->world, rk = (uint32_t)c->comm->rank;
+        c->s2_part = true; c->s2_e0 = (int)((uint64_t)E * rk / wd); c->s2_e1 = (int)((uint64_t)E * (rk + 1) / wd);
+        uint32_t q = 1u + (uint32_t)((c->M - 1u) / E); if (q == 0) q = 1;          // encoder.cpp:171
+        const uint64_t a0 = (uint64_t)c->s2_e0 * q, a1 = (uint64_t)c->s2_e1 * q;
+        oi0 = (uint32_t)(a0 > c->M ? c->M : a0); oi1 = (uint32_t)((uint32_t)c->s2_e1 >= E || a1 > c->M ? c->M : a1);
+    }
+    if (!c->s1_from_files) RC_TRY(stage1_make_oriented(c, oi0, oi1));
     RC_TRY(stage2_run(c));
     c->C.encode_ms = now_ms() - t0;
     c->C.total_ms += c->C.encode_ms;

@@ -28,6 +28,7 @@ struct RcclApi {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 RcclApi g_rccl;
@@ -43,7 +44,7 @@ int rccl_load()
         if (!g_rccl.field) { harc_set_error("librccl: symbol %s missing", name); dlclose(h); return HARC_AMD_ENODEVICE; } } while (0)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
     SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
-    SYM(AllGather, "ncclAllGather"); SYM(GetErrorString, "ncclGetErrorString");
+    SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(h, "ncclCommAbort"));
     g_rccl.h = h;
@@ -110,6 +111,15 @@ struct RcclComm : HarcComm {
         HIP_TRY(hipMemcpyAsync(h_ag + n, d_out, (size_t)world * n * 8, hipMemcpyDeviceToHost, c->stream));
         RC_TRY(wait(c, "all-gather of the counts"));
         memcpy(out, h_ag + n, (size_t)world * n * 8);
+        return HARC_AMD_OK;
+    }
+    int allreduce_min_u64(harc_amd_ctx *c, unsigned long long *d_buf, size_t n) override
+    {
+        // pieces of at most 2^28 elements (2 GB): one ring all-reduce each, in place
+        for (size_t o = 0; o < n; o += (size_t)1 << 28) {
+            const size_t m = n - o < ((size_t)1 << 28) ? n - o : ((size_t)1 << 28);
+            NCCL_TRY(g_rccl.AllReduce(d_buf + o, d_buf + o, m, ncclUint64, ncclMin, comm, c->stream));
+        }
         return HARC_AMD_OK;
     }
     int alltoallv(harc_amd_ctx *c, int narr, const void *const *send, const size_t *const *soff, const size_t *const *sbytes,
@@ -208,6 +218,21 @@ struct MailboxComm : HarcComm {
                 RC_TRY(get(path("xx", s, p, rank, a), h.data(), h.size()));
                 if (rbytes[a][p]) HIP_TRY(hipMemcpy((char *)recv[a] + roff[a][p], h.data(), rbytes[a][p], hipMemcpyHostToDevice));
             }
+        return HARC_AMD_OK;
+    }
+    int allreduce_min_u64(harc_amd_ctx *c, unsigned long long *d_buf, size_t n) override
+    {
+        const uint64_t s = seq++;
+        std::vector<unsigned long long> mine(n), other(n);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (n) HIP_TRY(hipMemcpy(mine.data(), d_buf, n * 8, hipMemcpyDeviceToHost));
+        RC_TRY(put(path("ar", s, rank, 0, 0), mine.data(), n * 8));
+        for (int p = 0; p < world; p++) {
+            if (p == rank) continue;
+            RC_TRY(get(path("ar", s, p, 0, 0), other.data(), n * 8));
+            for (size_t i = 0; i < n; i++) if (other[i] < mine[i]) mine[i] = other[i];
+        }
+        if (n) HIP_TRY(hipMemcpy(d_buf, mine.data(), n * 8, hipMemcpyHostToDevice));
         return HARC_AMD_OK;
     }
     int wait(harc_amd_ctx *c, const char *) override { HIP_TRY(hipStreamSynchronize(c->stream)); return HARC_AMD_OK; }

@@ -624,13 +624,15 @@ static void announce_stream(const char *stem)
     const std::string line = std::string(stem) + "\n";
     (void)!write(fd, line.data(), line.size());
 }
-static int write_shard_family(harc_amd_ctx *c, const std::string &od, int first_shard)
+// the stream files of the context's encoder shards [e_lo, e_hi) (default: all) as read_*.txt.<first_shard + e>
+static int write_shard_family(harc_amd_ctx *c, const std::string &od, int first_shard, int e_lo = 0, int e_hi = -1)
 {
+    if (e_hi < 0) e_hi = c->P.num_thr;
     static const struct { int id; const char *name; int tail; } files[] = {
         { HARC_AMD_S2_SEQ, "read_seq", HARC_AMD_S2_SEQ_TAIL }, { HARC_AMD_S2_POS, "read_pos", -1 }, { HARC_AMD_S2_NOISE, "read_noise", -1 },
         { HARC_AMD_S2_NOISEPOS, "read_noisepos", -1 }, { HARC_AMD_S2_REV, "read_rev", HARC_AMD_S2_REV_TAIL } };
     for (auto &fd : files) {
-        for (int e = 0; e < c->P.num_thr; e++) {
+        for (int e = e_lo; e < e_hi; e++) {
             const std::string path = od + fd.name + ".txt." + std::to_string(first_shard + e);
             RC_TRY(spit_stream_to(c, fd.id, e, path));
             if (fd.tail >= 0) RC_TRY(spit_stream_to(c, fd.tail, e, path + ".tail"));
@@ -835,7 +837,7 @@ static int compress_fastq_rank(const harc_amd_params *params, const char *fastq,
     RC_TRY(harc_amd_reorder(c));
     RC_TRY(harc_amd_encode(c));
     harc_amd_counters C; harc_amd_get_counters(c, &C);
-    if (replicate && rank != 0) {                                 // the same streams as rank 0 holds: nothing to write but empty parts
+    if (replicate && rank != 0 && !c->s2_part) {                  // (HARC_AMD_S2_PART=0) the same streams as rank 0 holds: nothing to write but empty parts
         static const char *stems[] = { "order_a", "order_u", "orderN_a", "orderN_u", "singleton", "singleton_tail", "input_N" };
         for (const char *st0 : stems) RC_TRY(spit_file(sd + st0 + r, "", 0));
         char line[256];
@@ -845,6 +847,12 @@ static int compress_fastq_rank(const harc_amd_params *params, const char *fastq,
         RC_TRY(harc_amd_comm_barrier(c));
         return HARC_AMD_OK;
     }
+    // design (R) with stage II partitioned: every rank writes the stream files of ITS encoder shards under their single-GPU names, and its parts of
+    // the whole-job files (aligned part: its shards; unaligned part: its share of the candidates) -- the merge below is the bucket mode's
+    if (replicate && c->s2_part) {
+        RC_TRY(write_shard_family(c, od, 0, c->s2_e0, c->s2_e1));
+        if (rank != 0) C.unmatched = 0;                           // stage I is the whole job's on every rank: counted once
+    } else
     RC_TRY(write_shard_family(c, od, replicate ? 0 : rank * params->num_thr));
     {   // whole-job files: this rank's part, aligned and unaligned halves apart (the merge interleaves them as encoder.cpp:457-503 does)
         const void *po, *pn, *ps, *pt, *pi; size_t no, nn, ns, nt, ni;

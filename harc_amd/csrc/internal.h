@@ -110,6 +110,7 @@ struct harc_amd_ctx {
     struct HarcComm *comm = nullptr;
     InBuf x_reads, x_nreads3, x_gid, x_ngid;            // the received shard and the global ids of its reads
     uint32_t *d_gid = nullptr, *d_ngid = nullptr;       // non-null after an exchange: stage II writes global ids into its order streams
+    bool s2_part = false; int s2_e0 = 0, s2_e1 = 0;     // stage II partitioned over the ranks of a design-(R) run (harc_amd_encode decides): the encoder shards [s2_e0, s2_e1) are this rank's
     bool replicated = false;                            // after harc_amd_replicate_exchange: the context holds the reads of the WHOLE job in global id order (x_reads / x_nreads3)
                                                         // and stage I partitions the CHAINS over the ranks (stage1.hip)
     uint64_t shard_info[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  // [0] clean reads of the whole job [1] N reads [2] records [3] this rank's first clean id [4] first N id [5] first record
@@ -148,6 +149,9 @@ struct HarcComm {
     // the chunk from peer p lands at recv[a] + roff[a][p] (rbytes[a][p] bytes); enqueued on c->stream
     virtual int alltoallv(harc_amd_ctx *c, int narr, const void *const *send, const size_t *const *soff, const size_t *const *sbytes,
                           void *const *recv, const size_t *const *roff, const size_t *const *rbytes) = 0;
+    // element-wise minimum over the ranks of n u64 in device memory, in place (ncclAllReduce(ncclMin): the singleton / N-read claims of stage II,
+    // one packed (column, direction, dictionary) tuple per candidate); enqueued on c->stream like the all-to-all
+    virtual int allreduce_min_u64(harc_amd_ctx *c, unsigned long long *d_buf, size_t n) = 0;
     // everything enqueued on c->stream so far (the collective included) has finished, or the peers did not answer in time (HARC_AMD_ETIMEOUT)
     virtual int wait(harc_amd_ctx *c, const char *what) = 0;
     virtual const char *name() const = 0;
@@ -206,7 +210,7 @@ int shard_partition(harc_amd_ctx *c, const uint64_t *d_words, uint32_t n, int nw
                     uint64_t *d_out, uint32_t *d_gid_out, unsigned long long *d_counts);
 int shard_map_ids(harc_amd_ctx *c, uint32_t *d_v, uint64_t n, const uint32_t *d_map, uint32_t nmap, unsigned int *d_err);   // v[i] = map[v[i]]
 int stage1_run(harc_amd_ctx *c);
-int stage1_make_oriented(harc_amd_ctx *c);      // d_oreads from d_reads/d_order/d_rc
+int stage1_make_oriented(harc_amd_ctx *c, uint32_t i0 = 0, uint32_t i1 = 0xFFFFFFFFu);      // d_oreads[i0, i1) from d_reads/d_order/d_rc (default: all)
 int s1_orient(harc_amd_ctx *c, const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, uint64_t *out);
 // exact key->bin table over n keys (ids must hold 0..n-1 on entry); allocates d->slots / d->ids / d->d_nbins
 int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n, uint64_t cap_like);   // cap_like != 0: that many slots

@@ -2723,8 +2723,10 @@ int stage1_run(harc_amd_ctx *c)
     }
 }
 
-int stage1_make_oriented(harc_amd_ctx *c)
+int stage1_make_oriented(harc_amd_ctx *c, uint32_t i0, uint32_t i1)
 {
     if (!c->d_oreads) RC_TRY(dalloc(c, &c->d_oreads, (size_t)c->M * c->W + 1));
-    return s1_orient(c, c->d_reads, c->d_order, c->d_rc, c->M, c->d_oreads);
+    if (i1 > c->M) i1 = c->M;
+    if (i0 >= i1) return HARC_AMD_OK;
+    return s1_orient(c, c->d_reads, c->d_order + i0, c->d_rc + i0, i1 - i0, c->d_oreads + (size_t)i0 * c->W);
 }

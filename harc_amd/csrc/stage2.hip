@@ -42,6 +42,10 @@ struct S2Args {
     uint4 *events;                     // probes that hit a bin larger than maxsearch: {tuple lo, tuple hi, dict, slot index lo} (+ slot hi in w>>?)
     unsigned int *nevents; uint32_t maxevents;
     int trace;                         // HARC_AMD_TRACE: count the events that look in a window pass
+    // stage II partitioned over the ranks of a design-(R) run (stage2_run): this rank owns the consensus columns [col0, col1) -- whole encoder shards,
+    // so whole contigs -- and launches its tile kernels from tile `tile_base` on; on one GPU: [0, total), 0
+    uint64_t col0, col1; uint32_t tile_base;
+    const uint64_t *evwin;             // k_realign_big: the 3-bit window words of every event (k_ev_windows), W3 per event
 };
 
 // ---------------------------------------------------------------------------------------------- small device helpers
@@ -168,7 +172,7 @@ __global__ void k_consensus_tiles(S2Args s, uint32_t ntiles, uint32_t *tlo, uint
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
-    const uint64_t X0 = (uint64_t)t * CTILE, X1 = X0 + CTILE < s.total ? X0 + CTILE : s.total;
+    const uint64_t X0 = (uint64_t)(t + s.tile_base) * CTILE, X1 = X0 + CTILE < s.total ? X0 + CTILE : s.total;
     thi[t] = (uint32_t)ub_le(s.gstart, (long long)s.M, X1 - 1);             // last read starting inside or before the tile (every column is covered: >= 0)
     tlo[t] = X0 >= (uint64_t)s.L ? (uint32_t)(ub_le(s.gstart, (long long)s.M, X0 - (uint64_t)s.L) + 1) : 0u;   // first read that reaches column X0
 }
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void k_consensus(S2Args s, const uint32_t *cid
 {
     extern __shared__ uint64_t cl_words[];                        // [CCHUNK][W] read words, then CCHUNK tile-relative starts
     int *const cl_g = reinterpret_cast<int *>(cl_words + (size_t)CCHUNK * s.W);
-    const uint64_t X0 = (uint64_t)blockIdx.x * CTILE;
+    const uint64_t X0 = (uint64_t)(blockIdx.x + s.tile_base) * CTILE;
     const int L = s.L, W = s.W;
     const long long ilo = tlo[blockIdx.x], ihi = thi[blockIdx.x];
     const int x0r = (int)threadIdx.x * CSTRIP;                   // tile-relative first column of the strip
@@ -456,7 +460,7 @@ template <int W> __device__ __forceinline__ void realign_hit1(const S2Args &s, c
     const uint64_t off = dir ? (uint64_t)(s.L - 1 - s.de[l]) : (uint64_t)s.ds[l];
     if (cpos < off) return;
     const uint64_t x = cpos - off;
-    if (x >= s.total || !(s.cons[x] & 4)) return;                  // no read may start there (k_consensus)
+    if (x < s.col0 || x >= s.col1 || !(s.cons[x] & 4)) return;    // another rank's column, or no read may start there (k_consensus)
     uint64_t key = 0;
     if (dir) for (int b = 0; b < n; b++) key |= (uint64_t)idx_to_c3(3 - (tile[tc + n - 1 - b] & 3)) << (3 * b);
     else for (int b = 0; b < n; b++) key |= (uint64_t)idx_to_c3(tile[tc + b] & 3) << (3 * b);
@@ -469,7 +473,7 @@ template <int W, int NWIN> __global__ __launch_bounds__(256) void k_realign_prop
     __shared__ uint2 lookup[RTILE];                               // per column: word of the bitmap, the two 4-bit fields inside it
     __shared__ unsigned int qn;
     uint8_t *tile = reinterpret_cast<uint8_t *>(tile32);
-    const uint64_t X0 = (uint64_t)blockIdx.x * RTILE;
+    const uint64_t X0 = (uint64_t)(blockIdx.x + s.tile_base) * RTILE;
     const int n = s.de[0] - s.ds[0] + 1;
     const int ntile = RTILE + n + NWIN + 1;
     for (int d = threadIdx.x; d < (ntile + 3) / 4; d += 256) {
@@ -533,7 +537,7 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args
 {
     __shared__ uint32_t tile32[(RTILE + 256 + 8) / 4];
     uint8_t *tile = reinterpret_cast<uint8_t *>(tile32);
-    const uint64_t X0 = (uint64_t)blockIdx.x * RTILE;
+    const uint64_t X0 = (uint64_t)(blockIdx.x + s.tile_base) * RTILE;
     const int L = s.L;
     const int ntile = RTILE + L + 1;
     for (int d = threadIdx.x; d < (ntile + 3) / 4; d += 256) {
@@ -561,7 +565,7 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args
         const int tx = t0 + c;
         const uint64_t x = X0 + tx;
         if (x >= s.total) break;
-        if (tile[tx] & 4) {
+        if (x >= s.col0 && x < s.col1 && (tile[tx] & 4)) {
             // the four probes of the window: bitmap first (all four loads in flight together)
             const uint64_t keys[4] = { kf0, kf1, kr0, kr1 };               // order of encoder.cpp: direction, then dictionary
             bool pass[4];
@@ -627,6 +631,43 @@ __global__ void k_ev_gather(const uint4 *ev, const uint32_t *perm, uint32_t nev,
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nev) out[i] = ev[perm[i]];
 }
+// one wave per event: the L columns of its window (forward, or reverse-complemented) as W3 words of the candidates' 3-bit code.  One lane per base
+// fetches its code from the packed consensus (A0 G1 C2 T3 there, twice that in the 3-bit code; complement = 3 - code) into LDS, then lanes
+// 0..W3-1 put one word together each
+__global__ __launch_bounds__(256) void k_ev_windows(S2Args s, const uint4 *ev, uint32_t nev, uint64_t *win)
+{
+    __shared__ uint8_t sc3[4][256];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t e = blockIdx.x * 4 + wv;
+    if (e >= nev) return;
+    const uint4 v = ev[e];
+    const unsigned long long tp = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+    const uint64_t x = tp >> 2; const int dir = (int)((tp >> 1) & 1), L = s.L;
+    for (int b = lane; b < L; b += 64) {
+        const uint64_t g = x + (uint64_t)(dir ? L - 1 - b : b);
+        const uint32_t c2 = (uint32_t)(s.cons2[g >> 5] >> (2 * (g & 31))) & 3u;
+        sc3[wv][b] = (uint8_t)((dir ? 3u - c2 : c2) << 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < s.W3) {
+        unsigned long long w = 0;
+        const int b0 = (64 * lane) / 3, b1 = (64 * lane + 63) / 3;
+        for (int b = b0; b <= b1 && b < L; b++) {
+            const unsigned long long c3 = (unsigned long long)sc3[wv][b];
+            const int sh = 3 * b - 64 * lane;
+            w |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
+        }
+        win[(size_t)e * s.W3 + lane] = w;
+    }
+}
+__global__ void k_ev_gather_win(const uint64_t *win, const uint32_t *perm, uint32_t nev, int W3, uint64_t *out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)nev * W3) return;
+    const uint32_t i = (uint32_t)(t / W3); const int w = (int)(t % W3);
+    out[t] = win[(size_t)perm[i] * W3 + w];
+}
 __global__ void k_ev_heads(const uint64_t *key, uint32_t nev, uint32_t *head)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -671,10 +712,10 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
     const int lane = threadIdx.x & 63;
     const uint32_t lp = lastpass[ei];
     if (lp == EV_DONE) return false;
-    const int L = s.L, W3 = s.W3;
+    const int W3 = s.W3;
     const uint4 ev = s.events[e];
     const unsigned long long tp = (unsigned long long)ev.x | ((unsigned long long)ev.y << 32);
-    const uint64_t x = tp >> 2; const int dir = (int)((tp >> 1) & 1), l = (int)(tp & 1);
+    const int l = (int)(tp & 1);
     const uint32_t st = ev.z, cnt = ev.w;
     const size_t cur = (size_t)(pass & 1u) * T1, prv = (size_t)((pass - 1u) & 1u) * T1;      // T1 = entries per copy
     unsigned long long *const mymin = (l ? binmin1 : binmin0) + st;
@@ -686,27 +727,9 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
     }
     if (estart[ei] == 0) { if (lane == 0) lastpass[ei] = EV_DONE; return false; }      // every read of the bin was claimed before this event: claims only move to earlier tuples
     if (s.trace && lane == 0) atomicAdd(changed + 2, 1u);         // trace only: events that look (one word: it serialises them)
-    // 3-bit window words (forward or reverse complement).  One lane per base fetches its code from the packed consensus (A0 G1 C2 T3 there, twice
-    // that in the 3-bit code; complement = 3 - code) into LDS, then lanes 0..W3-1 put one word together each -- five lanes walking 21 dependent
-    // byte loads each from global memory were the longest wait of a look (c3sd: the five large passes 32 -> 26 ms)
-    uint8_t *const sc3 = reinterpret_cast<uint8_t *>(swin + HARC_MAXW3);
-    for (int b = lane; b < L; b += 64) {
-        const uint64_t g = x + (uint64_t)(dir ? L - 1 - b : b);
-        const uint32_t c2 = (uint32_t)(s.cons2[g >> 5] >> (2 * (g & 31))) & 3u;
-        sc3[b] = (uint8_t)((dir ? 3u - c2 : c2) << 1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < W3) {
-        unsigned long long v = 0;
-        const int b0 = (64 * lane) / 3, b1 = (64 * lane + 63) / 3;
-        for (int b = b0; b <= b1 && b < L; b++) {
-            const unsigned long long c3 = (unsigned long long)sc3[b];
-            const int sh = 3 * b - 64 * lane;
-            v |= sh >= 0 ? (c3 << sh) : (c3 >> (-sh));
-        }
-        swin[lane] = v;
-    }
+    // the 3-bit window words of the event (forward or reverse complement of the consensus at its column): made once per event by k_ev_windows
+    // (every look used to put them together from the packed consensus again; and the events of a multi-GPU run carry them to the other ranks)
+    if (lane < W3) swin[lane] = s.evwin[(size_t)e * W3 + lane];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint32_t top = estart[ei]; if (top > cnt) top = cnt;
@@ -848,34 +871,48 @@ __global__ void k_acc_compact(const unsigned long long *best, const uint32_t *ra
 
 // merge by rank: final index of read i = i + #accepted with column < gstart[i]; of accepted k = k + #reads with gstart <= column
 struct FinalArrays { uint32_t *ref; uint8_t *kind; uint64_t *g; };   // kind 0 original, 1 candidate forward, 2 candidate reverse
-__global__ void k_merge_orig(const uint64_t *gstart, uint32_t M, const uint64_t *tup, uint32_t A, FinalArrays f, uint32_t *fidx_orig)
+// (the reads [i0, i0 + n) and the accepted candidates [a0, a0 + na) of this rank's shards; the final arrays start at final index fbase)
+__global__ void k_merge_orig(const uint64_t *gstart, uint32_t i0, uint32_t n, const uint64_t *tup, uint32_t A, FinalArrays f, uint32_t fbase)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t i = i0 + t;
     const uint64_t g = gstart[i];
     long long lo = -1, hi = A;                                    // #accepted with (tuple>>2) < g
     while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if ((tup[mid] >> 2) < g) lo = mid; else hi = mid; }
-    const uint32_t at = i + (uint32_t)(lo + 1);
+    const uint32_t at = i + (uint32_t)(lo + 1) - fbase;
     f.ref[at] = i; f.kind[at] = 0; f.g[at] = g;
-    fidx_orig[i] = at;
 }
-__global__ void k_merge_acc(const uint64_t *gstart, uint32_t M, const uint64_t *tup, const uint32_t *rid, uint32_t A, FinalArrays f)
+__global__ void k_merge_acc(const uint64_t *gstart, uint32_t M, const uint64_t *tup, const uint32_t *rid, uint32_t a0, uint32_t na, FinalArrays f, uint32_t fbase)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= A) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= na) return;
+    const uint32_t k = a0 + t;
     const uint64_t x = tup[k] >> 2;
     const long long n = ub_le(gstart, (long long)M, x) + 1;       // originals with cumulative pos <= j come first (encoder.cpp:254-268)
-    const uint32_t at = k + (uint32_t)n;
+    const uint32_t at = k + (uint32_t)n - fbase;
     f.ref[at] = rid[k]; f.kind[at] = (tup[k] & 2) ? 2 : 1; f.g[at] = x;
+}
+// final index of the first read of every encoder shard (F where a shard is empty), and the first accepted candidate at or behind its first column
+__global__ void k_shard_bounds(const uint64_t *gstart, uint32_t M, uint32_t q, uint32_t E, const uint64_t *tup, uint32_t A, uint64_t total, uint32_t *sh_f, uint32_t *sh_a, uint64_t *sh_col)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > E) return;
+    const uint64_t st = (uint64_t)e * q;
+    if (e == E || st >= M) { sh_f[e] = M + A; sh_a[e] = A; sh_col[e] = total; return; }
+    const uint64_t g = gstart[st];
+    long long lo = -1, hi = A;
+    while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if ((tup[mid] >> 2) < g) lo = mid; else hi = mid; }
+    sh_f[e] = (uint32_t)st + (uint32_t)(lo + 1); sh_a[e] = (uint32_t)(lo + 1); sh_col[e] = g;
 }
 
 // The noise pass works on packed words: `cons2` is the consensus on the global column axis in the reads' own 2-bit code (A0 G1 C2 T3,
 // 32 columns per word), so a read is compared with W funnel-shifted words and the mismatching columns are the set bits of
 // ((x | x>>1) & 0x55..) with x = read ^ consensus; an N of a candidate read is a mismatch wherever it stands.
-__global__ void k_pack_cons2(const uint8_t *cons, uint64_t total, uint64_t nwords, uint64_t *cons2)
+__global__ void k_pack_cons2(const uint8_t *cons, uint64_t total, uint64_t w0, uint64_t nwords, uint64_t *cons2)
 {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwords) return;
+    const uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // the words [w0, w0 + nwords)
+    if (w >= w0 + nwords) return;
     uint64_t v = 0;
     const uint64_t c0 = w * 32;
     if (c0 + 32 <= total) {
@@ -980,32 +1017,34 @@ template <bool EMIT> static void launch_noise(harc_amd_ctx *c, const S2Args &a, 
 }
 
 // unaligned candidates (encoder.cpp:484-499): singletons -> order + bases; N reads -> order_N + text
-__global__ void k_left_flags(const unsigned long long *best, uint32_t T, uint32_t S, uint32_t *fs, uint32_t *fn)
+// (candidates [t0, t0 + n): this rank's share of the leftovers; fs / fn / rs / rn are indexed from t0)
+__global__ void k_left_flags(const unsigned long long *best, uint32_t t0, uint32_t n, uint32_t S, uint32_t *fs, uint32_t *fn)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t i = t0 + t;
     const bool un = best[i] == TUPLE_NONE;
-    fs[i] = (un && i < S) ? 1u : 0u; fn[i] = (un && i >= S) ? 1u : 0u;
+    fs[t] = (un && i < S) ? 1u : 0u; fn[t] = (un && i >= S) ? 1u : 0u;
 }
 // One thread per (read, group of 16 bases): neighbouring threads write neighbouring 16 bytes.  (A thread per read wrote its L bytes one
 // by one, L bytes apart from its neighbour's: 50 ms for the 115 M leftover reads of an 8-way bucket shard of configs[2].)
-__global__ void k_left_emit(S2Args s, const uint32_t *rs, const uint32_t *rn, uint32_t *order_out, uint32_t order_base,
+__global__ void k_left_emit(S2Args s, uint32_t t0, uint32_t nt, const uint32_t *rs, const uint32_t *rn, uint32_t *order_out, uint32_t order_base,
                             uint32_t *orderN_out, uint32_t orderN_base, uint8_t *sing_bases, char *ntext)
 {
     const int G = (s.L + 15) / 16;
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (uint64_t)s.T * G) return;
-    const uint32_t i = (uint32_t)(gid / G); const int g = (int)(gid % G);
+    if (gid >= (uint64_t)nt * G) return;
+    const uint32_t i = t0 + (uint32_t)(gid / G); const int g = (int)(gid % G);
     if (s.best[i] != TUPLE_NONE) return;
     const uint64_t *r = s.cand3 + (size_t)i * s.W3;
     const int j0 = 16 * g, j1 = j0 + 16 < s.L ? j0 + 16 : s.L;
     if (i < s.S) {
-        const uint32_t k = rs[i];
+        const uint32_t k = rs[i - t0];
         if (g == 0) order_out[order_base + k] = s.cand_order[i];
         uint8_t *o = sing_bases + (size_t)k * s.L;
         for (int j = j0; j < j1; j++) o[j] = (uint8_t)c3_to_idx5(c3_at(r, s.W3, j));
     } else {
-        const uint32_t k = rn[i];
+        const uint32_t k = rn[i - t0];
         if (g == 0) orderN_out[orderN_base + k] = s.cand_order[i];
         char *o = ntext + (size_t)k * (s.L + 1);
         for (int j = j0; j < j1; j++) o[j] = "ACGTN"[c3_to_idx5(c3_at(r, s.W3, j))];
@@ -1084,6 +1123,17 @@ static int digest_range(harc_amd_ctx *c, const void *base, uint64_t nbytes, uint
     return HARC_AMD_OK;
 }
 
+// The host side of stage II.  On one GPU (and on every rank of a bucket-sharded run) the function covers all encoder shards.  In a design-(R)
+// run (harc_amd_replicate_exchange: every rank holds the stage-I result of the WHOLE job) the work is partitioned over the ranks by encoder
+// shard -- contigs never cross a shard start (encoder.cpp:171-180), so a rank's shards are a self-contained piece of the global column axis:
+//   replicated (cheap or global by nature): the candidates and their two dictionaries, the contig structure (prefix sums over all reads), the
+//     sort of the accepted candidates, the window passes over bins above maxsearch (rare; their events travel with their window words);
+//   per rank: consensus, realignment proposals, merge, noise / pos / rev / order streams of ITS shards [e0, e1), and the leftovers (unaligned
+//     singletons and N reads) of ITS share of the candidates [t0, t1);
+//   ONE ncclAllReduce(min) over best[] (one packed (column, direction, dictionary) tuple per candidate): a candidate goes to the
+//     smallest tuple that accepts it wherever the window lies (encoder.cpp:252-410 at num_thr = 1).
+// Every rank ends with the stream files of its shards -- byte for byte the single-GPU ones -- and its parts of the whole-job files, which
+// harc_amd_merge_shard_files lays out (aligned parts in rank order = shard order, then the unaligned parts in candidate order).
 int stage2_run(harc_amd_ctx *c)
 {
     const harc_amd_params &P = c->P;
@@ -1091,18 +1141,10 @@ int stage2_run(harc_amd_ctx *c)
     const uint32_t M = c->M, S = c->S, NN = c->NN, T = S + NN, E = (uint32_t)P.num_thr;
     // drop earlier stage-II outputs
     for (auto it = c->out.begin(); it != c->out.end();) { if (it->first.first >= HARC_AMD_S2_SEQ) it = c->out.erase(it); else ++it; }
+    HarcComm *const cm = (c->s2_part && c->comm && c->replicated) ? c->comm : nullptr;       // partitioned over the ranks (harc_amd_encode decided)
+    const uint32_t e0 = cm ? (uint32_t)c->s2_e0 : 0u, e1 = cm ? (uint32_t)c->s2_e1 : E;
+    const uint32_t t0 = cm ? (uint32_t)((uint64_t)T * (uint32_t)cm->rank / (uint32_t)cm->world) : 0u, t1 = cm ? (uint32_t)((uint64_t)T * ((uint32_t)cm->rank + 1u) / (uint32_t)cm->world) : T;
 
-    // the two order streams outlive the scratch: worst-case sized, copied to the host only when asked for (harc_amd_get_stream)
-    uint32_t *order_out = nullptr, *orderN_out = nullptr;
-    RC_TRY(dalloc(c, &order_out, (size_t)M + S + 1)); RC_TRY(dalloc(c, &orderN_out, (size_t)NN + 1));
-    c->d_s2_order = c->d_s2_orderN = nullptr; c->n_s2_order = c->n_s2_orderN = 0;
-    PoolScope s2_scope(c);                                        // the scratch goes on every way out (the two order streams above stay)
-    // harc_amd_params.stream_digest: every stream is folded into four words where it sits in HBM (k_stream_digest), [0] read_seq(+tail) of
-    // all shards, [1] noise + noisepos + pos, [2] rev(+tail) + singleton(+tail) + input_N.dna, [3] the two order streams
-    const bool want_digest = P.stream_digest != 0;
-    unsigned long long *d_digest = nullptr;
-    c->have_digest = false;
-    if (want_digest) { RC_TRY(dalloc(c, &d_digest, 4)); HIP_TRY(hipMemsetAsync(d_digest, 0, 32, c->stream)); }
     S2Args a; memset(&a, 0, sizeof a);
     a.L = L; a.W = W; a.W3 = W3; a.thresh_s = P.thresh_s; a.maxsearch = P.maxsearch;
     if (L > 50) { a.ds[0] = 0; a.de[0] = 20; a.ds[1] = 21; a.de[1] = 41; }                     // encoder.cpp:132-145
@@ -1112,6 +1154,19 @@ int stage2_run(harc_amd_ctx *c)
     a.q = 1u + (uint32_t)((M - 1u) / E);                          // uint32 arithmetic as encoder.cpp:171
     if (a.q == 0) a.q = 1;
     a.oreads = c->d_oreads; a.flag = c->d_flag; a.pos = c->d_pos; a.rc = c->d_rc; a.order = c->d_order;
+    const uint32_t i0 = (uint32_t)((uint64_t)e0 * a.q > M ? M : (uint64_t)e0 * a.q), i1 = e1 >= E ? M : (uint32_t)((uint64_t)e1 * a.q > M ? M : (uint64_t)e1 * a.q);   // this rank's reordered reads
+
+    // the two order streams outlive the scratch: worst-case sized, copied to the host only when asked for (harc_amd_get_stream)
+    uint32_t *order_out = nullptr, *orderN_out = nullptr;
+    RC_TRY(dalloc(c, &order_out, (size_t)(i1 - i0) + (size_t)S + 1)); RC_TRY(dalloc(c, &orderN_out, (size_t)NN + 1));     // every singleton / N read is in at most one rank's lists
+    c->d_s2_order = c->d_s2_orderN = nullptr; c->n_s2_order = c->n_s2_orderN = 0;
+    PoolScope s2_scope(c);                                        // the scratch goes on every way out (the two order streams above stay)
+    // harc_amd_params.stream_digest: every stream is folded into four words where it sits in HBM (k_stream_digest), [0] read_seq(+tail) of
+    // all shards, [1] noise + noisepos + pos, [2] rev(+tail) + singleton(+tail) + input_N.dna, [3] the two order streams
+    const bool want_digest = P.stream_digest != 0;
+    unsigned long long *d_digest = nullptr;
+    c->have_digest = false;
+    if (want_digest) { RC_TRY(dalloc(c, &d_digest, 4)); HIP_TRY(hipMemsetAsync(d_digest, 0, 32, c->stream)); }
 
     // ---- candidates: singletons then N reads, 3-bit (readsingletons, encoder.cpp:823-872)
     uint64_t *cand3 = nullptr; uint32_t *cand_order = nullptr; unsigned long long *best = nullptr;
@@ -1165,16 +1220,16 @@ int stage2_run(harc_amd_ctx *c)
             bloom_shift[l] = 64 - lb;
         }
         PoolScope kscope(c);
-        uint64_t *k0 = nullptr; uint32_t *i0 = nullptr; uint64_t *items = nullptr, *items_tmp = nullptr;
-        RC_TRY(dalloc(c, &k0, T)); RC_TRY(dalloc(c, &i0, T));
+        uint64_t *k0 = nullptr; uint32_t *i0k = nullptr; uint64_t *items = nullptr, *items_tmp = nullptr;
+        RC_TRY(dalloc(c, &k0, T)); RC_TRY(dalloc(c, &i0k, T));
         const uint64_t b4words = (uint64_t)1 << (lb - 3);
         if (bloom4 && bloom4_tiled) { RC_TRY(dalloc(c, &items, (size_t)T * 4 + 1)); RC_TRY(dalloc(c, &items_tmp, (size_t)T * 4 + 1)); }
         for (int l = 0; l < 2; l++) {
-            hipLaunchKernelGGL(k_key3, G256(T), cand3, T, W3, 3 * a.ds[l], a.kbits[l], k0, i0);
+            hipLaunchKernelGGL(k_key3, G256(T), cand3, T, W3, 3 * a.ds[l], a.kbits[l], k0, i0k);
             if (bloom4 && bloom4_tiled) hipLaunchKernelGGL(k_bloom4_items, G256(T), (const uint64_t *)k0, T, a.bloom_lbits, a.bloom_nwin, l, a.kbits[l] / 3, harc_bitmap_tiles(b4words), items + (size_t)l * 2 * T);
             else if (bloom4) hipLaunchKernelGGL(k_bloom4_set, G256(T), (const uint64_t *)k0, T, bloom[0], a.bloom_lbits, a.bloom_nwin, l, a.kbits[l] / 3);
             else hipLaunchKernelGGL(k_bloom_set, G256(T), (const uint64_t *)k0, T, bloom[l], bloom_shift[l]);
-            RC_TRY(harc_dict_build(c, &dict[l], k0, i0, T, (unsigned)a.kbits[l]));
+            RC_TRY(harc_dict_build(c, &dict[l], k0, i0k, T, (unsigned)a.kbits[l]));
             hipLaunchKernelGGL(k_count_big_bins, G256(dict[l].cap), dict[l].slots, dict[l].cap, (uint32_t)P.maxsearch, d_big);
         }
         if (bloom4 && bloom4_tiled) {
@@ -1184,7 +1239,7 @@ int stage2_run(harc_amd_ctx *c)
                 RC_TRY(dalloc(c, &ref, (size_t)b4words + 1)); RC_TRY(dalloc(c, &nd, 1));
                 HIP_TRY(hipMemsetAsync(ref, 0, (size_t)b4words * 4, c->stream)); HIP_TRY(hipMemsetAsync(nd, 0, 8, c->stream));
                 for (int l = 0; l < 2; l++) {
-                    hipLaunchKernelGGL(k_key3, G256(T), cand3, T, W3, 3 * a.ds[l], a.kbits[l], k0, i0);
+                    hipLaunchKernelGGL(k_key3, G256(T), cand3, T, W3, 3 * a.ds[l], a.kbits[l], k0, i0k);
                     hipLaunchKernelGGL(k_bloom4_set, G256(T), (const uint64_t *)k0, T, ref, a.bloom_lbits, a.bloom_nwin, l, a.kbits[l] / 3);
                 }
                 hipLaunchKernelGGL(k_words_differ, dim3((unsigned)((b4words + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)ref, (const uint32_t *)bloom[0], b4words, nd);
@@ -1197,7 +1252,7 @@ int stage2_run(harc_amd_ctx *c)
     }
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; a.bloom[l] = bloom[l]; a.bloom_shift[l] = bloom_shift[l]; }
 
-    // ---- contig structure on the global column axis
+    // ---- contig structure on the global column axis (all reads, on every rank: prefix sums)
     uint8_t *head = nullptr; uint32_t *u0 = nullptr, *u1 = nullptr; uint64_t *d64 = nullptr, *gstart = nullptr; uint32_t *chead = nullptr;
     RC_TRY(dalloc(c, &head, (size_t)M + 1)); RC_TRY(dalloc(c, &u0, (size_t)M + 1)); RC_TRY(dalloc(c, &u1, (size_t)M + 1));
     RC_TRY(dalloc(c, &d64, (size_t)M + 1)); RC_TRY(dalloc(c, &gstart, (size_t)M + 1));
@@ -1221,8 +1276,17 @@ int stage2_run(harc_amd_ctx *c)
     a.head = head; a.gstart = gstart; a.chead = chead; a.nC = nC; a.total = total;
     c->C.contigs = nC; c->C.seq_bases = total;
 
-    // ---- consensus + realignment proposals
+    // ---- consensus + realignment proposals: the columns of this rank's shards
     std::vector<uint64_t> sh_col(E + 1, total), seq_off(E, 0), seq_nb(E, 0), seq_tl(E, 0);
+    for (uint32_t e = 0; e <= E; e++) {
+        const uint64_t st = (uint64_t)e * a.q; const uint32_t i = e == E ? M : (uint32_t)(st > M ? M : st);
+        if (i >= M) { sh_col[e] = total; continue; }
+        HIP_TRY(hipMemcpyAsync(&sh_col[e], gstart + i, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t col0 = sh_col[e0], col1 = sh_col[e1];
+    a.col0 = col0; a.col1 = col1; a.tile_base = (uint32_t)(col0 / CTILE);
+    if (cm) c->C.seq_bases = col1 - col0;                         // this rank's share (the merge adds the ranks up)
     uint8_t *h_seq = nullptr;
     struct CopyJoin { hipStream_t s; ~CopyJoin() { (void)hipStreamSynchronize(s); } } copy_join{ c->copy_stream };   // on every way out: nothing of this run is still in flight
     uint8_t *cons = nullptr; RC_TRY(dalloc(c, &cons, (size_t)total + 8));
@@ -1232,49 +1296,46 @@ int stage2_run(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &cons2, (size_t)ncw + 2 * W + 4));
     HIP_TRY(hipMemsetAsync(cons2 + ncw, 0, ((size_t)2 * W + 4) * 8, c->stream));
     a.cons2 = cons2;
-    if (total) {
+    unsigned int nev = 0;
+    if (col1 > col0) {
         unsigned long long *cinfo = nullptr; RC_TRY(dalloc(c, &cinfo, (size_t)nC + 1));
         hipLaunchKernelGGL(k_contig_info, G256(nC), a, cinfo);
-        const uint32_t ntiles = (uint32_t)((total + CTILE - 1) / CTILE);
+        const uint32_t ntiles = (uint32_t)((col1 + CTILE - 1) / CTILE) - a.tile_base;      // the tiles that hold a column of [col0, col1)
         uint32_t *tlo = nullptr, *thi = nullptr; RC_TRY(dalloc(c, &tlo, (size_t)ntiles + 1)); RC_TRY(dalloc(c, &thi, (size_t)ntiles + 1));
         hipLaunchKernelGGL(k_consensus_tiles, G256(ntiles), a, ntiles, tlo, thi);
         hipLaunchKernelGGL(k_consensus, dim3(ntiles), dim3(256), (size_t)CCHUNK * (W * 8 + 4), c->stream, a, (const uint32_t *)u1, (const unsigned long long *)cinfo, T ? 1 : 0,
                            (const uint32_t *)tlo, (const uint32_t *)thi);
-        hipLaunchKernelGGL(k_pack_cons2, G256(ncw), (const uint8_t *)a.cons, total, ncw, cons2);
+        { const uint64_t w0 = col0 / 32, w1 = (col1 + 31) / 32; hipLaunchKernelGGL(k_pack_cons2, G256(w1 - w0), (const uint8_t *)a.cons, total, w0, w1 - w0, cons2); }
         {   // read_seq (packbits, encoder.cpp:527-548) is final here -- the realignment below does not touch the consensus -- and the shard
             // boundaries on the column axis follow from gstart alone: it is packed now and goes to the host on the copy stream while the
             // realignment, the merge and the noise kernels run (the largest stream: a quarter of a byte per consensus base)
-            for (uint32_t e = 0; e <= E; e++) {
-                const uint64_t st = (uint64_t)e * a.q; const uint32_t i = e == E ? M : (uint32_t)(st > M ? M : st);
-                if (i >= M) { sh_col[e] = total; continue; }
-                HIP_TRY(hipMemcpyAsync(&sh_col[e], gstart + i, 8, hipMemcpyDeviceToHost, c->stream));
-            }
-            HIP_TRY(hipStreamSynchronize(c->stream));
             uint64_t soff = 0;
-            for (uint32_t e = 0; e < E; e++) { const uint64_t cc = sh_col[e + 1] - sh_col[e]; seq_nb[e] = cc / 4; seq_tl[e] = cc % 4; seq_off[e] = soff; soff += (seq_nb[e] + seq_tl[e] + 15) & ~15ull; }
+            for (uint32_t e = e0; e < e1; e++) { const uint64_t cc = sh_col[e + 1] - sh_col[e]; seq_nb[e] = cc / 4; seq_tl[e] = cc % 4; seq_off[e] = soff; soff += (seq_nb[e] + seq_tl[e] + 15) & ~15ull; }
             uint8_t *seqpk = nullptr; RC_TRY(dalloc(c, &seqpk, (size_t)soff + 64));
-            for (uint32_t e = 0; e < E; e++) {
-                const uint64_t c0 = sh_col[e];
-                if (seq_nb[e]) hipLaunchKernelGGL(k_pack2_bytes, G256(seq_nb[e]), cons + c0, seq_nb[e], seqpk + seq_off[e]);
-                if (seq_tl[e]) hipLaunchKernelGGL(k_bases_to_ascii, G256(seq_tl[e]), cons + c0 + 4 * seq_nb[e], seq_tl[e], seqpk + seq_off[e] + seq_nb[e]);
+            for (uint32_t e = e0; e < e1; e++) {
+                const uint64_t cc0 = sh_col[e];
+                if (seq_nb[e]) hipLaunchKernelGGL(k_pack2_bytes, G256(seq_nb[e]), cons + cc0, seq_nb[e], seqpk + seq_off[e]);
+                if (seq_tl[e]) hipLaunchKernelGGL(k_bases_to_ascii, G256(seq_tl[e]), cons + cc0 + 4 * seq_nb[e], seq_tl[e], seqpk + seq_off[e] + seq_nb[e]);
             }
             HIP_TRY(hipGetLastError());
-            if (want_digest) for (uint32_t e = 0; e < E; e++) RC_TRY(digest_range(c, seqpk + seq_off[e], seq_nb[e] + seq_tl[e], 0x100 + e, d_digest + 0));
+            if (want_digest) for (uint32_t e = e0; e < e1; e++) RC_TRY(digest_range(c, seqpk + seq_off[e], seq_nb[e] + seq_tl[e], 0x100 + e, d_digest + 0));
             RC_TRY(harc_host_alloc(c, (void **)&h_seq, (size_t)soff));
             HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
             HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
             if (soff) HIP_TRY(hipMemcpyAsync(h_seq, seqpk, (size_t)soff, hipMemcpyDeviceToHost, c->copy_stream));
         }
         if (T) {
-            const dim3 rg((unsigned)((total + RTILE - 1) / RTILE));
-            switch (W) {
+            const dim3 rg(ntiles);
+            auto propose = [&]() {
+                switch (W) {
 #define REALIGN_CASE(WW) case WW: if (bloom4 && a.bloom_nwin) hipLaunchKernelGGL((k_realign_propose1<WW, 21 - BLOOM4_M + 1>), rg, dim3(256), 0, c->stream, a); \
                                  else if (bloom4) hipLaunchKernelGGL((k_realign_propose1<WW, 0>), rg, dim3(256), 0, c->stream, a); \
                                  else hipLaunchKernelGGL((k_realign_propose<WW>), rg, dim3(256), 0, c->stream, a); break;
-                REALIGN_CASE(1) REALIGN_CASE(2) REALIGN_CASE(3) REALIGN_CASE(4) REALIGN_CASE(5) REALIGN_CASE(6) REALIGN_CASE(7) REALIGN_CASE(8)
+                    REALIGN_CASE(1) REALIGN_CASE(2) REALIGN_CASE(3) REALIGN_CASE(4) REALIGN_CASE(5) REALIGN_CASE(6) REALIGN_CASE(7) REALIGN_CASE(8)
 #undef REALIGN_CASE
-            }
-            unsigned int nev = 0;
+                }
+            };
+            propose();
             HIP_TRY(hipMemcpyAsync(&nev, a.nevents, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             { const uint64_t want = (uint64_t)nev + nev / 4; c->s2_events_hint = want > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)want; }
@@ -1284,121 +1345,163 @@ int stage2_run(harc_amd_ctx *c)
                 a.maxevents = nev;
                 RC_TRY(dalloc(c, &a.events, (size_t)a.maxevents));
                 HIP_TRY(hipMemsetAsync(a.nevents, 0, 16, c->stream));
-                switch (W) {
-#define REALIGN_CASE(WW) case WW: if (bloom4 && a.bloom_nwin) hipLaunchKernelGGL((k_realign_propose1<WW, 21 - BLOOM4_M + 1>), rg, dim3(256), 0, c->stream, a); \
-                                 else if (bloom4) hipLaunchKernelGGL((k_realign_propose1<WW, 0>), rg, dim3(256), 0, c->stream, a); \
-                                 else hipLaunchKernelGGL((k_realign_propose<WW>), rg, dim3(256), 0, c->stream, a); break;
-                    REALIGN_CASE(1) REALIGN_CASE(2) REALIGN_CASE(3) REALIGN_CASE(4) REALIGN_CASE(5) REALIGN_CASE(6) REALIGN_CASE(7) REALIGN_CASE(8)
-#undef REALIGN_CASE
-                }
+                propose();
                 HIP_TRY(hipMemcpyAsync(&nev, a.nevents, 4, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 if (nev > a.maxevents) { harc_set_error("stage II: event count changed between two identical passes (%u > %u)", nev, a.maxevents); return HARC_AMD_EINTERNAL; }
             }
-            if (nev) {                                                        // exact sliding-window semantics as a fixed point (k_realign_big)
-                unsigned int *d_changed = nullptr; uint32_t *estart = nullptr, *lastver = nullptr; unsigned long long *binmin[2] = { nullptr, nullptr };
-                if (total >> (EV_TBITS - 2)) { harc_set_error("stage II: more than 2^%d consensus columns", EV_TBITS - 2); return HARC_AMD_EINVAL; }
-                RC_TRY(dalloc(c, &d_changed, 4)); RC_TRY(dalloc(c, &estart, (size_t)nev + 1)); RC_TRY(dalloc(c, &lastver, (size_t)nev + 1));
-                HIP_TRY(hipMemsetAsync(estart, 0xFF, ((size_t)nev + 1) * 4, c->stream));
-                HIP_TRY(hipMemsetAsync(lastver, 0xFF, ((size_t)nev + 1) * 4, c->stream));
-                for (int l = 0; l < 2; l++) { RC_TRY(dalloc(c, &binmin[l], 2 * ((size_t)T + 1))); HIP_TRY(hipMemsetAsync(binmin[l], 0xFF, 2 * ((size_t)T + 1) * 8, c->stream)); }
-                const bool trace = getenv("HARC_AMD_TRACE") != nullptr, nochase = getenv("HARC_AMD_S2_NOCHASE") != nullptr;
-                a.trace = trace ? 1 : 0;
-                struct timespec tw0; clock_gettime(CLOCK_MONOTONIC, &tw0);
-                // events in (bin, tuple) order and their rank inside the bin (k_realign_big's header)
-                uint32_t *perm = nullptr, *rank = nullptr, *seglen = nullptr, *order2 = nullptr; unsigned int maxrank = 0;
-                uint32_t rhi0 = 64, range_end[32];
-                if (const char *e = getenv("HARC_AMD_S2_RANK0")) { const int v = atoi(e); rhi0 = v < 1 ? 1u : (uint32_t)v; }       // tests: narrow ranges on small inputs
-                for (int k = 0; k < 32; k++) range_end[k] = nev;
-                if (!getenv("HARC_AMD_S2_FLATPASSES")) {
-                    RC_TRY(dalloc(c, &perm, (size_t)nev + 1)); RC_TRY(dalloc(c, &rank, (size_t)nev + 1));
-                    uint64_t *k0 = nullptr, *k1 = nullptr; uint32_t *i0 = nullptr, *i1 = nullptr, *hd = nullptr;
-                    RC_TRY(dalloc(c, &k0, (size_t)nev + 1)); RC_TRY(dalloc(c, &k1, (size_t)nev + 1)); RC_TRY(dalloc(c, &i0, (size_t)nev + 1)); RC_TRY(dalloc(c, &i1, (size_t)nev + 1)); RC_TRY(dalloc(c, &hd, (size_t)nev + 1));
-                    unsigned tbits = 2; while (tbits < 64 && (total >> (tbits - 2)) != 0) tbits++;
-                    hipLaunchKernelGGL(k_ev_key_tuple, G256(nev), (const uint4 *)a.events, nev, k0, i0);
-                    RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i0, i1, nev, tbits));
-                    hipLaunchKernelGGL(k_ev_key_bin, G256(nev), (const uint4 *)a.events, (const uint32_t *)i1, nev, k0);
-                    RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i1, perm, nev, 33));            // stable: tuple order inside a bin
-                    hipLaunchKernelGGL(k_ev_heads, G256(nev), (const uint64_t *)k1, nev, hd);
-                    RC_TRY(prim_incl_max_u32(c, hd, rank, nev));
-                    HIP_TRY(hipMemsetAsync(d_changed, 0, 16, c->stream));
-                    hipLaunchKernelGGL(k_ev_rank, G256(nev), rank, nev, d_changed + 1);
-                    RC_TRY(dalloc(c, &seglen, (size_t)nev + 1));
-                    hipLaunchKernelGGL(k_ev_seglen, G256(nev), (const uint32_t *)rank, nev, seglen);
-                    {
-                        uint4 *evs = nullptr; RC_TRY(dalloc(c, &evs, (size_t)nev + 1));
-                        hipLaunchKernelGGL(k_ev_gather, G256(nev), (const uint4 *)a.events, (const uint32_t *)perm, nev, evs);
-                        a.events = evs;                            // from here on event i is the i-th in (bin, tuple) order (the unordered list is not used again)
-                    }
-                    // the events grouped by rank range ((bin, tuple) order kept inside a range), and the size of every range
-                    unsigned int *hist = nullptr; RC_TRY(dalloc(c, &hist, 32)); HIP_TRY(hipMemsetAsync(hist, 0, 32 * 4, c->stream));
-                    RC_TRY(dalloc(c, &order2, (size_t)nev + 1));
-                    hipLaunchKernelGGL(k_ev_range_keys, G256(nev), (const uint32_t *)rank, nev, rhi0, k0, i0, hist);
-                    RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i0, order2, nev, 5));
-                    unsigned int hh[32];
-                    HIP_TRY(hipMemcpyAsync(hh, hist, sizeof hh, hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(hipMemcpyAsync(&maxrank, d_changed + 1, 4, hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(hipStreamSynchronize(c->stream));
-                    range_end[0] = hh[0];
-                    for (int k = 1; k < 32; k++) range_end[k] = range_end[k - 1] + hh[k];
-                }
-                uint64_t npass = 0; uint32_t rlo = 0, rhi = rhi0; int nall = 0, ridx = 0;
-                const uint32_t pipeline_from = getenv("HARC_AMD_S2_PIPE") ? (uint32_t)atoi(getenv("HARC_AMD_S2_PIPE")) : 1024u;
-                RC_TRY(dalloc(c, &a.bestbin[0], (size_t)T + 1)); RC_TRY(dalloc(c, &a.bestbin[1], (size_t)T + 1));
-                for (bool ranges = perm != nullptr;;) {
-                    HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 4, c->stream));
-                    hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
-                    const uint32_t nact = (ranges && order2) ? range_end[ridx < 31 ? ridx : 31] : nev;      // the events of the ranges reached so far come first in order2
-                    hipLaunchKernelGGL(k_realign_big, dim3((nact + 3) / 4), dim3(256), 0, c->stream, a, nact, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
-                                       (const uint32_t *)perm, (const uint32_t *)rank, 0u, ranges ? rhi : 0xFFFFFFFFu, (const uint32_t *)(ranges ? order2 : nullptr));     // the ranks below rlo are validated in passing: no event is ever left unlooked-at for a pass
-                    // the chaser, after the passes over everything from the second one on (the ranges settle by themselves; the chains it is for show
-                    // when the ranges meet); its claims count for the pass (the same stamp)
-                    if (perm && !nochase && !ranges && nall++ > 0) hipLaunchKernelGGL(k_realign_chase, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
-                                                             (const uint32_t *)perm, (const uint32_t *)rank, (const uint32_t *)seglen, ranges ? rhi : 0xFFFFFFFFu);
-                    unsigned int chg = 0, nlook = 0;
-                    HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
-                    if (trace) HIP_TRY(hipMemcpyAsync(&nlook, d_changed + 2, 4, hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(hipStreamSynchronize(c->stream));
-                    if (trace) { struct timespec tw; clock_gettime(CLOCK_MONOTONIC, &tw); fprintf(stderr, "[stage II] window pass %llu over %u events (%u looked), ranks [%u, %u)%s: %s, %.2f ms since the first\n", (unsigned long long)npass, nev, nlook, ranges ? rlo : 0u, ranges ? rhi : maxrank + 1, ranges ? "" : " (all)", chg ? "claims moved" : "quiet", (tw.tv_sec - tw0.tv_sec) * 1e3 + (tw.tv_nsec - tw0.tv_nsec) * 1e-6); }
-                    if (++npass > (uint64_t)T + 256) { harc_set_error("stage II: the window passes over the large bins did not settle"); return HARC_AMD_EINTERNAL; }
-                    // a range is repeated until quiet only while it is small (its passes cost next to nothing and the early events of a bin decide
-                    // what all later ones see); a large range moves on at once: every later pass validates its events, and those with an
-                    // earlier claim on their bin look again then -- the separate quiet pass per large range was a third of the time
-                    if (chg && (!ranges || rhi <= pipeline_from)) continue;
-                    if (!ranges && !chg) break;                                           // a pass over ALL events changed nothing: the fixed point
-                    if (!ranges) continue;
-                    if (rhi > maxrank) ranges = false;                                    // every range has settled: now the passes over everything
-                    else { rlo = rhi; rhi = rhi > 0x20000000u ? 0xFFFFFFFFu : rhi * 4; ridx++; }
-                }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    // ---- the window words of the events (k_realign_big reads them instead of the consensus: with the columns partitioned the consensus under an
+    //      event of another rank is not here)
+    uint64_t *evwin = nullptr;
+    if (nev) {
+        RC_TRY(dalloc(c, &evwin, (size_t)nev * W3 + 1));
+        hipLaunchKernelGGL(k_ev_windows, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, (const uint4 *)a.events, nev, evwin);
+    }
+    if (cm && T) {
+        // ---- the claims of all ranks: ONE all-reduce(min) over the packed tuples; then every rank's events (with their windows) to everybody
+        RC_TRY(cm->allreduce_min_u64(c, best, (size_t)T));
+        RC_TRY(cm->wait(c, "all-reduce of the singleton / N-read claims"));
+        std::vector<uint64_t> allnev((size_t)cm->world);
+        { const uint64_t mine = nev; RC_TRY(cm->allgather_u64(c, &mine, 1, allnev.data())); }
+        uint64_t tot = 0; for (uint64_t x : allnev) tot += x;
+        if (tot > 0xFFFFFFFFull) { harc_set_error("stage II: more than 2^32 probes into large bins"); return HARC_AMD_EINVAL; }
+        if (tot) {
+            uint4 *ev_all = nullptr; uint64_t *win_all = nullptr;
+            RC_TRY(dalloc(c, &ev_all, (size_t)tot + 1)); RC_TRY(dalloc(c, &win_all, (size_t)tot * W3 + 1));
+            std::vector<size_t> so[2], sb[2], ro[2], rb[2];
+            for (int k = 0; k < 2; k++) { so[k].assign(cm->world, 0); sb[k].resize(cm->world); ro[k].resize(cm->world); rb[k].resize(cm->world); }
+            uint64_t acc = 0;
+            for (int p = 0; p < cm->world; p++) {
+                sb[0][p] = (size_t)nev * 16; sb[1][p] = (size_t)nev * W3 * 8;
+                ro[0][p] = (size_t)acc * 16; rb[0][p] = (size_t)allnev[p] * 16; ro[1][p] = (size_t)acc * W3 * 8; rb[1][p] = (size_t)allnev[p] * W3 * 8;
+                acc += allnev[p];
             }
+            const void *sp[2] = { a.events, evwin }; void *rp[2] = { ev_all, win_all };
+            const size_t *sop[2] = { so[0].data(), so[1].data() }, *sbp[2] = { sb[0].data(), sb[1].data() }, *rop[2] = { ro[0].data(), ro[1].data() }, *rbp[2] = { rb[0].data(), rb[1].data() };
+            RC_TRY(cm->alltoallv(c, 2, sp, sop, sbp, rp, rop, rbp));
+            RC_TRY(cm->wait(c, "all-gather of the probes into large bins"));
+            a.events = ev_all; evwin = win_all; nev = (unsigned int)tot;
+        } else nev = 0;
+    }
+    a.evwin = evwin;
+    if (nev) {                                                        // exact sliding-window semantics as a fixed point (k_realign_big)
+        unsigned int *d_changed = nullptr; uint32_t *estart = nullptr, *lastver = nullptr; unsigned long long *binmin[2] = { nullptr, nullptr };
+        if (total >> (EV_TBITS - 2)) { harc_set_error("stage II: more than 2^%d consensus columns", EV_TBITS - 2); return HARC_AMD_EINVAL; }
+        RC_TRY(dalloc(c, &d_changed, 4)); RC_TRY(dalloc(c, &estart, (size_t)nev + 1)); RC_TRY(dalloc(c, &lastver, (size_t)nev + 1));
+        HIP_TRY(hipMemsetAsync(estart, 0xFF, ((size_t)nev + 1) * 4, c->stream));
+        HIP_TRY(hipMemsetAsync(lastver, 0xFF, ((size_t)nev + 1) * 4, c->stream));
+        for (int l = 0; l < 2; l++) { RC_TRY(dalloc(c, &binmin[l], 2 * ((size_t)T + 1))); HIP_TRY(hipMemsetAsync(binmin[l], 0xFF, 2 * ((size_t)T + 1) * 8, c->stream)); }
+        const bool trace = getenv("HARC_AMD_TRACE") != nullptr, nochase = getenv("HARC_AMD_S2_NOCHASE") != nullptr;
+        a.trace = trace ? 1 : 0;
+        struct timespec tw0; clock_gettime(CLOCK_MONOTONIC, &tw0);
+        // events in (bin, tuple) order and their rank inside the bin (k_realign_big's header)
+        uint32_t *perm = nullptr, *rank = nullptr, *seglen = nullptr, *order2 = nullptr; unsigned int maxrank = 0;
+        uint32_t rhi0 = 64, range_end[32];
+        if (const char *e = getenv("HARC_AMD_S2_RANK0")) { const int v = atoi(e); rhi0 = v < 1 ? 1u : (uint32_t)v; }       // tests: narrow ranges on small inputs
+        for (int k = 0; k < 32; k++) range_end[k] = nev;
+        if (!getenv("HARC_AMD_S2_FLATPASSES")) {
+            RC_TRY(dalloc(c, &perm, (size_t)nev + 1)); RC_TRY(dalloc(c, &rank, (size_t)nev + 1));
+            uint64_t *k0 = nullptr, *k1 = nullptr; uint32_t *i0e = nullptr, *i1e = nullptr, *hd = nullptr;
+            RC_TRY(dalloc(c, &k0, (size_t)nev + 1)); RC_TRY(dalloc(c, &k1, (size_t)nev + 1)); RC_TRY(dalloc(c, &i0e, (size_t)nev + 1)); RC_TRY(dalloc(c, &i1e, (size_t)nev + 1)); RC_TRY(dalloc(c, &hd, (size_t)nev + 1));
+            unsigned tbits = 2; while (tbits < 64 && (total >> (tbits - 2)) != 0) tbits++;
+            hipLaunchKernelGGL(k_ev_key_tuple, G256(nev), (const uint4 *)a.events, nev, k0, i0e);
+            RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i0e, i1e, nev, tbits));
+            hipLaunchKernelGGL(k_ev_key_bin, G256(nev), (const uint4 *)a.events, (const uint32_t *)i1e, nev, k0);
+            RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i1e, perm, nev, 33));            // stable: tuple order inside a bin
+            hipLaunchKernelGGL(k_ev_heads, G256(nev), (const uint64_t *)k1, nev, hd);
+            RC_TRY(prim_incl_max_u32(c, hd, rank, nev));
+            HIP_TRY(hipMemsetAsync(d_changed, 0, 16, c->stream));
+            hipLaunchKernelGGL(k_ev_rank, G256(nev), rank, nev, d_changed + 1);
+            RC_TRY(dalloc(c, &seglen, (size_t)nev + 1));
+            hipLaunchKernelGGL(k_ev_seglen, G256(nev), (const uint32_t *)rank, nev, seglen);
+            {
+                uint4 *evs = nullptr; uint64_t *wins = nullptr; RC_TRY(dalloc(c, &evs, (size_t)nev + 1)); RC_TRY(dalloc(c, &wins, (size_t)nev * W3 + 1));
+                hipLaunchKernelGGL(k_ev_gather, G256(nev), (const uint4 *)a.events, (const uint32_t *)perm, nev, evs);
+                hipLaunchKernelGGL(k_ev_gather_win, G256((uint64_t)nev * W3), (const uint64_t *)a.evwin, (const uint32_t *)perm, nev, W3, wins);
+                a.events = evs; a.evwin = wins;                    // from here on event i is the i-th in (bin, tuple) order (the unordered list is not used again)
+            }
+            // the events grouped by rank range ((bin, tuple) order kept inside a range), and the size of every range
+            unsigned int *hist = nullptr; RC_TRY(dalloc(c, &hist, 32)); HIP_TRY(hipMemsetAsync(hist, 0, 32 * 4, c->stream));
+            RC_TRY(dalloc(c, &order2, (size_t)nev + 1));
+            hipLaunchKernelGGL(k_ev_range_keys, G256(nev), (const uint32_t *)rank, nev, rhi0, k0, i0e, hist);
+            RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i0e, order2, nev, 5));
+            unsigned int hh[32];
+            HIP_TRY(hipMemcpyAsync(hh, hist, sizeof hh, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(&maxrank, d_changed + 1, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            range_end[0] = hh[0];
+            for (int k = 1; k < 32; k++) range_end[k] = range_end[k - 1] + hh[k];
+        }
+        uint64_t npass = 0; uint32_t rlo = 0, rhi = rhi0; int nall = 0, ridx = 0;
+        const uint32_t pipeline_from = getenv("HARC_AMD_S2_PIPE") ? (uint32_t)atoi(getenv("HARC_AMD_S2_PIPE")) : 1024u;
+        RC_TRY(dalloc(c, &a.bestbin[0], (size_t)T + 1)); RC_TRY(dalloc(c, &a.bestbin[1], (size_t)T + 1));
+        for (bool ranges = perm != nullptr;;) {
+            HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
+            const uint32_t nact = (ranges && order2) ? range_end[ridx < 31 ? ridx : 31] : nev;      // the events of the ranges reached so far come first in order2
+            hipLaunchKernelGGL(k_realign_big, dim3((nact + 3) / 4), dim3(256), 0, c->stream, a, nact, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
+                               (const uint32_t *)perm, (const uint32_t *)rank, 0u, ranges ? rhi : 0xFFFFFFFFu, (const uint32_t *)(ranges ? order2 : nullptr));     // the ranks below rlo are validated in passing: no event is ever left unlooked-at for a pass
+            // the chaser, after the passes over everything from the second one on (the ranges settle by themselves; the chains it is for show
+            // when the ranges meet); its claims count for the pass (the same stamp)
+            if (perm && !nochase && !ranges && nall++ > 0) hipLaunchKernelGGL(k_realign_chase, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
+                                                     (const uint32_t *)perm, (const uint32_t *)rank, (const uint32_t *)seglen, ranges ? rhi : 0xFFFFFFFFu);
+            unsigned int chg = 0, nlook = 0;
+            HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
+            if (trace) HIP_TRY(hipMemcpyAsync(&nlook, d_changed + 2, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (trace) { struct timespec tw; clock_gettime(CLOCK_MONOTONIC, &tw); fprintf(stderr, "[stage II] window pass %llu over %u events (%u looked), ranks [%u, %u)%s: %s, %.2f ms since the first\n", (unsigned long long)npass, nev, nlook, ranges ? rlo : 0u, ranges ? rhi : maxrank + 1, ranges ? "" : " (all)", chg ? "claims moved" : "quiet", (tw.tv_sec - tw0.tv_sec) * 1e3 + (tw.tv_nsec - tw0.tv_nsec) * 1e-6); }
+            if (++npass > (uint64_t)T + 256) { harc_set_error("stage II: the window passes over the large bins did not settle"); return HARC_AMD_EINTERNAL; }
+            // a range is repeated until quiet only while it is small (its passes cost next to nothing and the early events of a bin decide
+            // what all later ones see); a large range moves on at once: every later pass validates its events, and those with an
+            // earlier claim on their bin look again then -- the separate quiet pass per large range was a third of the time
+            if (chg && (!ranges || rhi <= pipeline_from)) continue;
+            if (!ranges && !chg) break;                                           // a pass over ALL events changed nothing: the fixed point
+            if (!ranges) continue;
+            if (rhi > maxrank) ranges = false;                                    // every range has settled: now the passes over everything
+            else { rlo = rhi; rhi = rhi > 0x20000000u ? 0xFFFFFFFFu : rhi * 4; ridx++; }
         }
     }
     HIP_TRY(hipGetLastError());
 
-    // ---- accepted candidates sorted by (tuple, rid descending)
+    // ---- accepted candidates sorted by (tuple, rid descending): all of them, on every rank (a sort of 16-byte pairs)
     uint32_t A = 0;
-    uint32_t *t0 = nullptr, *t1 = nullptr; uint64_t *tup0 = nullptr, *tup = nullptr; uint32_t *rid0 = nullptr, *rid = nullptr;
-    RC_TRY(dalloc(c, &t0, (size_t)T + 1)); RC_TRY(dalloc(c, &t1, (size_t)T + 1));
+    uint32_t *ta = nullptr, *tb = nullptr; uint64_t *tup0 = nullptr, *tup = nullptr; uint32_t *rid0 = nullptr, *rid = nullptr;
+    RC_TRY(dalloc(c, &ta, (size_t)T + 1)); RC_TRY(dalloc(c, &tb, (size_t)T + 1));
     if (T) {
-        HIP_TRY(hipMemsetAsync(t0, 0, ((size_t)T + 1) * 4, c->stream));
-        hipLaunchKernelGGL(k_acc_flags, G256(T), best, T, t0);
-        RC_TRY(prim_excl_scan_u32(c, t0, t1, (size_t)T + 1));
-        HIP_TRY(hipMemcpyAsync(&A, t1 + T, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemsetAsync(ta, 0, ((size_t)T + 1) * 4, c->stream));
+        hipLaunchKernelGGL(k_acc_flags, G256(T), best, T, ta);
+        RC_TRY(prim_excl_scan_u32(c, ta, tb, (size_t)T + 1));
+        HIP_TRY(hipMemcpyAsync(&A, tb + T, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     RC_TRY(dalloc(c, &tup0, (size_t)A + 1)); RC_TRY(dalloc(c, &tup, (size_t)A + 1)); RC_TRY(dalloc(c, &rid0, (size_t)A + 1)); RC_TRY(dalloc(c, &rid, (size_t)A + 1));
     if (A) {
-        hipLaunchKernelGGL(k_acc_compact, G256(T), best, t1, T, A, tup0, rid0);
+        hipLaunchKernelGGL(k_acc_compact, G256(T), best, tb, T, A, tup0, rid0);
         unsigned bits = 2; while (bits < 64 && (total >> (bits - 2)) != 0) bits++;
         RC_TRY(prim_sort_pairs_u64_u32(c, tup0, tup, rid0, rid, A, bits));
     }
 
+    // ---- shard boundaries in final-list coordinates; this rank's piece of the final read list is [fbase, fend)
+    std::vector<uint32_t> sh_f(E + 1), sh_a(E + 1);
+    {
+        uint32_t *d_shf = nullptr, *d_sha = nullptr; uint64_t *d_shc = nullptr;
+        RC_TRY(dalloc(c, &d_shf, (size_t)E + 2)); RC_TRY(dalloc(c, &d_sha, (size_t)E + 2)); RC_TRY(dalloc(c, &d_shc, (size_t)E + 2));
+        hipLaunchKernelGGL(k_shard_bounds, G256(E + 1), (const uint64_t *)gstart, M, a.q, E, (const uint64_t *)tup, A, total, d_shf, d_sha, d_shc);
+        HIP_TRY(hipMemcpyAsync(sh_f.data(), d_shf, ((size_t)E + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(sh_a.data(), d_sha, ((size_t)E + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    const uint32_t fbase = sh_f[e0], fend = sh_f[e1], F = fend - fbase, a0 = sh_a[e0], na = sh_a[e1] - sh_a[e0];
+    if ((uint64_t)(i1 - i0) + na != F) { harc_set_error("stage II bookkeeping: %u reads + %u accepted candidates in a piece of %u", i1 - i0, na, F); return HARC_AMD_EINTERNAL; }
+
     // ---- merge into the final read list
-    const uint32_t F = M + A;
-    FinalArrays f; uint32_t *fidx_orig = nullptr;
-    RC_TRY(dalloc(c, &f.ref, (size_t)F + 1)); RC_TRY(dalloc(c, &f.kind, (size_t)F + 1)); RC_TRY(dalloc(c, &f.g, (size_t)F + 1)); RC_TRY(dalloc(c, &fidx_orig, (size_t)M + 1));
-    if (M) hipLaunchKernelGGL(k_merge_orig, G256(M), gstart, M, tup, A, f, fidx_orig);
-    if (A) hipLaunchKernelGGL(k_merge_acc, G256(A), gstart, M, tup, rid, A, f);
+    FinalArrays f;
+    RC_TRY(dalloc(c, &f.ref, (size_t)F + 1)); RC_TRY(dalloc(c, &f.kind, (size_t)F + 1)); RC_TRY(dalloc(c, &f.g, (size_t)F + 1));
+    if (i1 > i0) hipLaunchKernelGGL(k_merge_orig, G256(i1 - i0), gstart, i0, i1 - i0, tup, A, f, fbase);
+    if (na) hipLaunchKernelGGL(k_merge_acc, G256(na), gstart, M, tup, rid, a0, na, f, fbase);
 
     // ---- noise / pos / order / rc streams
     uint32_t *nm = nullptr, *nonN = nullptr, *nonNrank = nullptr; uint64_t *nmoff = nullptr;
@@ -1410,25 +1513,26 @@ int stage2_run(harc_amd_ctx *c)
     uint64_t nmtot = 0; uint32_t n_nonN = 0;
     HIP_TRY(hipMemcpyAsync(&nmtot, nmoff + F, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&n_nonN, nonNrank + F, 4, hipMemcpyDeviceToHost, c->stream));
-    // leftovers
+    // leftovers: this rank's share of the candidates
+    const uint32_t nt = t1 - t0;
     uint32_t *ls = nullptr, *ln = nullptr, *rs = nullptr, *rn = nullptr;
-    RC_TRY(dalloc(c, &ls, (size_t)T + 1)); RC_TRY(dalloc(c, &ln, (size_t)T + 1)); RC_TRY(dalloc(c, &rs, (size_t)T + 1)); RC_TRY(dalloc(c, &rn, (size_t)T + 1));
-    HIP_TRY(hipMemsetAsync(ls, 0, ((size_t)T + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(ln, 0, ((size_t)T + 1) * 4, c->stream));
-    if (T) hipLaunchKernelGGL(k_left_flags, G256(T), best, T, S, ls, ln);
-    RC_TRY(prim_excl_scan_u32(c, ls, rs, (size_t)T + 1)); RC_TRY(prim_excl_scan_u32(c, ln, rn, (size_t)T + 1));
+    RC_TRY(dalloc(c, &ls, (size_t)nt + 1)); RC_TRY(dalloc(c, &ln, (size_t)nt + 1)); RC_TRY(dalloc(c, &rs, (size_t)nt + 1)); RC_TRY(dalloc(c, &rn, (size_t)nt + 1));
+    HIP_TRY(hipMemsetAsync(ls, 0, ((size_t)nt + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(ln, 0, ((size_t)nt + 1) * 4, c->stream));
+    if (nt) hipLaunchKernelGGL(k_left_flags, G256(nt), best, t0, nt, S, ls, ln);
+    RC_TRY(prim_excl_scan_u32(c, ls, rs, (size_t)nt + 1)); RC_TRY(prim_excl_scan_u32(c, ln, rn, (size_t)nt + 1));
     uint32_t US = 0, UN = 0;
-    HIP_TRY(hipMemcpyAsync(&US, rs + T, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&UN, rn + T, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&US, rs + nt, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&UN, rn + nt, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint32_t n_N_aligned = F - n_nonN;
 
     uint8_t *noise = nullptr, *noisepos = nullptr, *posb = nullptr, *rcb = nullptr;
     uint8_t *sing_bases = nullptr; char *ntext = nullptr;
     RC_TRY(dalloc(c, &noise, (size_t)nmtot + F + 1)); RC_TRY(dalloc(c, &noisepos, (size_t)nmtot + 1)); RC_TRY(dalloc(c, &posb, (size_t)F + 1)); RC_TRY(dalloc(c, &rcb, (size_t)F + 8));
-    if ((size_t)n_nonN + US > (size_t)M + S || (size_t)n_N_aligned + UN > (size_t)NN) { harc_set_error("stage II bookkeeping: %u + %u clean, %u + %u N order entries", n_nonN, US, n_N_aligned, UN); return HARC_AMD_EINTERNAL; }
+    if ((size_t)n_nonN + US > (size_t)(i1 - i0) + (size_t)S || (size_t)n_N_aligned + UN > (size_t)NN) { harc_set_error("stage II bookkeeping: %u + %u clean, %u + %u N order entries", n_nonN, US, n_N_aligned, UN); return HARC_AMD_EINTERNAL; }
     RC_TRY(dalloc(c, &sing_bases, (size_t)US * L + 8)); RC_TRY(dalloc(c, &ntext, (size_t)UN * (L + 1) + 1));
     if (F) launch_noise<true>(c, a, f, cons2, F, nullptr, nullptr, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out);
-    if (T) hipLaunchKernelGGL(k_left_emit, G256((uint64_t)T * ((L + 15) / 16)), a, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned, sing_bases, ntext);
+    if (nt) hipLaunchKernelGGL(k_left_emit, G256((uint64_t)nt * ((L + 15) / 16)), a, t0, nt, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned, sing_bases, ntext);
     HIP_TRY(hipGetLastError());
     if (c->d_gid && !c->s1_from_files) {
         // multi-GPU shard (harc_amd_shard_exchange): the order streams carry the GLOBAL ids of the reads, so that the merged archive
@@ -1443,29 +1547,22 @@ int stage2_run(harc_amd_ctx *c)
         if (merr) { harc_set_error("stage II: %u order entries outside the shard", merr); return HARC_AMD_EINTERNAL; }
     }
 
-    // ---- shard boundaries in final-list / column / noise coordinates
-    std::vector<uint32_t> sh_i(E + 1), sh_f(E + 1); std::vector<uint64_t> sh_nm(E + 1);
-    for (uint32_t e = 0; e <= E; e++) { uint64_t st = (uint64_t)e * a.q; sh_i[e] = (uint32_t)(st > M ? M : st); }
-    sh_i[E] = M;
-    for (uint32_t e = 0; e <= E; e++) {
-        if (sh_i[e] >= M) { sh_f[e] = F; sh_nm[e] = nmtot; continue; }
-        HIP_TRY(hipMemcpyAsync(&sh_f[e], fidx_orig + sh_i[e], 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (uint32_t e = 0; e <= E; e++) if (sh_i[e] < M) HIP_TRY(hipMemcpyAsync(&sh_nm[e], nmoff + sh_f[e], 8, hipMemcpyDeviceToHost, c->stream));
+    // ---- shard boundaries in noise coordinates (relative to this rank's piece)
+    std::vector<uint64_t> sh_nm(E + 1, 0);
+    for (uint32_t e = e0; e <= e1; e++) HIP_TRY(hipMemcpyAsync(&sh_nm[e], nmoff + (sh_f[e] - fbase), 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
 
     // ---- packbits per shard into ONE device buffer, then a handful of device -> pinned-host copies; per-shard streams are slices
-    std::vector<uint64_t> rev_off(E), rev_nb(E), rev_tl(E);
+    std::vector<uint64_t> rev_off(E, 0), rev_nb(E, 0), rev_tl(E, 0);
     uint64_t poff = 0;
-    for (uint32_t e = 0; e < E; e++) {
+    for (uint32_t e = e0; e < e1; e++) {
         const uint64_t ff = sh_f[e + 1] - sh_f[e]; rev_nb[e] = ff / 8; rev_tl[e] = ff % 8; rev_off[e] = poff; poff += (rev_nb[e] + rev_tl[e] + 15) & ~15ull;
     }
     const uint64_t sing_nb = (uint64_t)US * L / 4, sing_tl = (uint64_t)US * L % 4, sing_off = poff;
     poff += (sing_nb + sing_tl + 15) & ~15ull;
     uint8_t *packed = nullptr; RC_TRY(dalloc(c, &packed, (size_t)poff + 64));
-    for (uint32_t e = 0; e < E; e++) {
-        const uint32_t f0 = sh_f[e];
+    for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t f0 = sh_f[e] - fbase;
         if (rev_nb[e]) hipLaunchKernelGGL(k_pack1_bytes, G256(rev_nb[e]), rcb + f0, rev_nb[e], packed + rev_off[e]);
         if (rev_tl[e]) HIP_TRY(hipMemcpyAsync(packed + rev_off[e] + rev_nb[e], rcb + f0 + 8 * rev_nb[e], rev_tl[e], hipMemcpyDeviceToDevice, c->stream));
     }
@@ -1485,18 +1582,22 @@ int stage2_run(harc_amd_ctx *c)
     if (want_digest) {
         // the shard cuts of noise / noisepos / pos are positions inside ONE array each: the arrays as a whole, then the cuts themselves
         RC_TRY(digest_range(c, noise, nmtot + F, 0x200, d_digest + 1)); RC_TRY(digest_range(c, noisepos, nmtot, 0x201, d_digest + 1)); RC_TRY(digest_range(c, posb, F, 0x202, d_digest + 1));
-        for (uint32_t e = 0; e < E; e++) RC_TRY(digest_range(c, packed + rev_off[e], rev_nb[e] + rev_tl[e], 0x300 + e, d_digest + 2));
+        for (uint32_t e = e0; e < e1; e++) RC_TRY(digest_range(c, packed + rev_off[e], rev_nb[e] + rev_tl[e], 0x300 + e, d_digest + 2));
         RC_TRY(digest_range(c, packed + sing_off, sing_nb + sing_tl, 0x3F0, d_digest + 2)); RC_TRY(digest_range(c, ntext, n_ntext, 0x3F1, d_digest + 2));
         RC_TRY(digest_range(c, order_out, n_order, 0x400, d_digest + 3)); RC_TRY(digest_range(c, orderN_out, n_orderN, 0x401, d_digest + 3));
         unsigned long long *h_dig = nullptr; RC_TRY(harc_host_alloc(c, (void **)&h_dig, 32));
         HIP_TRY(hipMemcpyAsync(h_dig, d_digest, 32, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (int k = 0; k < 4; k++) c->digest[k] = h_dig[k];
-        for (uint32_t e = 0; e <= E; e++) { c->digest[1] += mix64(0x2F0ull + e + ((uint64_t)sh_f[e] << 20)) + mix64(0x2F8ull + e + (sh_nm[e] << 20)); c->digest[0] += mix64(0x1F0ull + e + (sh_col[e] << 20)); }
+        for (uint32_t e = e0; e <= e1; e++) { c->digest[1] += mix64(0x2F0ull + e + ((uint64_t)(sh_f[e] - fbase) << 20)) + mix64(0x2F8ull + e + (sh_nm[e] << 20)); c->digest[0] += mix64(0x1F0ull + e + ((sh_col[e] - col0) << 20)); }
         c->have_digest = true;
     }
     for (uint32_t e = 0; e < E; e++) {
-        const uint32_t f0 = sh_f[e], f1 = sh_f[e + 1];
+        if (e < e0 || e >= e1) {                                  // another rank's shard: nothing of it is here
+            for (int id : { HARC_AMD_S2_SEQ, HARC_AMD_S2_SEQ_TAIL, HARC_AMD_S2_REV, HARC_AMD_S2_REV_TAIL, HARC_AMD_S2_POS, HARC_AMD_S2_NOISE, HARC_AMD_S2_NOISEPOS }) out_slice(c, id, e, h_meta, 0);
+            continue;
+        }
+        const uint32_t f0 = sh_f[e] - fbase, f1 = sh_f[e + 1] - fbase;
         out_slice(c, HARC_AMD_S2_SEQ, e, h_seq + seq_off[e], seq_nb[e]); out_slice(c, HARC_AMD_S2_SEQ_TAIL, e, h_seq + seq_off[e] + seq_nb[e], seq_tl[e]);
         out_slice(c, HARC_AMD_S2_REV, e, h_packed + rev_off[e], rev_nb[e]); out_slice(c, HARC_AMD_S2_REV_TAIL, e, h_packed + rev_off[e] + rev_nb[e], rev_tl[e]);
         out_slice(c, HARC_AMD_S2_POS, e, h_pos + f0, f1 - f0);
@@ -1512,8 +1613,10 @@ int stage2_run(harc_amd_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));                // read_seq has arrived
     c->C.bins_over_maxsearch = big;
-    c->C.aligned_singletons = (uint64_t)S - US;                   // encoder.cpp:506-508
-    c->C.aligned_N = (uint64_t)NN - UN;
+    // encoder.cpp:506-508; partitioned: this rank's share of the candidates (the merge adds the ranks up)
+    const uint32_t s_lo = t0 < S ? t0 : S, s_hi = t1 < S ? t1 : S;
+    c->C.aligned_singletons = (uint64_t)(s_hi - s_lo) - US;
+    c->C.aligned_N = (uint64_t)((t1 - t0) - (s_hi - s_lo)) - UN;
     return HARC_AMD_OK;
 }
 
@@ -1521,7 +1624,7 @@ int pack_order_run(harc_amd_ctx *c)
 {
     // after harc_amd_shard_exchange the order stream holds GLOBAL ids (< the whole job's clean reads) while `numbits` below is taken from
     // the shard's own entry count: the packed fields would truncate them.  pack_order belongs to the merged read_order.bin (./harc -g).
-    if (c->d_gid) { harc_set_error("pack_order: the context holds a shard of a multi-GPU run (global ids); pack the merged read_order.bin instead"); return HARC_AMD_ESTATE; }
+    if (c->d_gid || c->s2_part) { harc_set_error("pack_order: the context holds a piece of a multi-GPU run; pack the merged read_order.bin instead"); return HARC_AMD_ESTATE; }
     { const void *p0 = nullptr; size_t n0 = 0; if (c->d_s2_order) RC_TRY(harc_amd_get_stream(c, HARC_AMD_S2_ORDER, 0, &p0, &n0)); }   // the order stream waits in HBM until wanted
     auto it = c->out.find(std::make_pair((int)HARC_AMD_S2_ORDER, 0));
     if (it == c->out.end()) { harc_set_error("pack_order: no read_order.bin"); return HARC_AMD_ESTATE; }

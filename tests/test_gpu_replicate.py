@@ -76,6 +76,38 @@ def _ranks(world, slices, L, E, K, S, mbox):
     return res
 
 
+def _assemble(res, E, L):
+    """the single-GPU streams from the pieces of a run with stage II partitioned over the ranks (what harc_amd_merge_shard_files does with the
+    rank parts): a shard's streams from the rank that owns it, read_order.bin / read_order_N_pe.bin = the aligned parts of all ranks, then the
+    unaligned parts (encoder.cpp:457-503), read_singleton.txt re-packed across the joints, input_N.dna concatenated"""
+    out = {}
+    for e in range(E):
+        for stem in [st for st, _ in STREAMS] + ["read_seq.txt.tail", "read_rev.txt.tail"]:
+            k = "%s.%d" % (stem, e) if not stem.endswith(".tail") else "%s.%d.tail" % (stem[:-5], e)
+            owners = [r for r in res if r["files"]["read_pos.txt.%d" % e] or r is res[-1]]
+            out[k] = owners[0]["files"][k]
+        assert sum(1 for r in res if r["files"]["read_pos.txt.%d" % e]) <= 1, "shard %d written by two ranks" % e
+    a, u, na, nu, bases, ntext = b"", b"", b"", b"", b"", b""
+    for r in res:
+        f = r["files"]
+        sg, tl = f["read_singleton.txt"], f["read_singleton.txt.tail"]
+        US = (4 * len(sg) + len(tl)) // L
+        UN = len(f["input_N.dna"]) // (L + 1)
+        o, on = f["read_order.bin"], f["read_order_N_pe.bin"]
+        a += o[:len(o) - 4 * US]; u += o[len(o) - 4 * US:]
+        na += on[:len(on) - 4 * UN]; nu += on[len(on) - 4 * UN:]
+        bases += b"".join(bytes(b"ACGT"[(b >> (2 * k)) & 3] for k in range(4)) for b in sg) + tl
+        ntext += f["input_N.dna"]
+    out["read_order.bin"] = a + u
+    out["read_order_N_pe.bin"] = na + nu
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    nb = len(bases) // 4
+    out["read_singleton.txt"] = bytes(code[bases[4 * i]] | (code[bases[4 * i + 1]] << 2) | (code[bases[4 * i + 2]] << 4) | (code[bases[4 * i + 3]] << 6) for i in range(nb))
+    out["read_singleton.txt.tail"] = bases[4 * nb:]
+    out["input_N.dna"] = ntext
+    return out
+
+
 def test_replicated_ranks_large_run_kernels(tmp_path, monkeypatch):
     """three ranks with the kernels of a run of hundreds of millions of reads forced (dense launch, wave-uniform scan, k_reseed by 64 workgroups with
     narrowed passes and delayed workgroups) == one GPU with the plain ones; the per-batch digest check of the replicas runs on the way"""
@@ -86,19 +118,26 @@ def test_replicated_ranks_large_run_kernels(tmp_path, monkeypatch):
     for k, v in {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_RESEED_MG": "1", "HARC_AMD_RESEED_WIN": "256", "HARC_AMD_RESEED_STRESS": "3"}.items():
         monkeypatch.setenv(k, v)
     res = _ranks(3, shard_model.slices_of(arr, 3), 100, 2, 6000, 16, str(tmp_path))
+    got = _assemble(res, 2, 100)                                   # stage II partitioned over the three ranks (two shards: one rank has none)
+    bad = [k for k in want if got[k] != want[k]]
+    assert not bad, bad
     for r in range(3):
-        bad = [k for k in want if res[r]["files"][k] != want[k]]
-        assert not bad, (r, bad)
         assert res[r]["counters"].rounds == cw.rounds
 
 
+@pytest.mark.parametrize("part", [True, False])
 @pytest.mark.parametrize("world,n,L,err,E,K,S,lowc", [(2, 30000, 100, 0.01, 2, 9, 16, False), (3, 24000, 100, 0.02, 1, 0, 16, False), (2, 9000, 150, 0.01, 1, 64, 8, False),
-                                                       (3, 20000, 100, 0.004, 3, 24, 16, True), (2, 5000, 100, 0.0, 1, 1, 16, False)])
-def test_replicated_ranks_equal_one_gpu(world, n, L, err, E, K, S, lowc, tmp_path):
-    """every rank of a design-(R) run == the single-GPU run on the concatenated input, every stage-II file; lowc: repeats and poly-A runs
-    (the cooperative kernel's walks are partitioned too); K = 1: one chain, one owner, the other ranks only follow"""
+                                                       (3, 20000, 100, 0.004, 3, 24, 16, True), (2, 5000, 100, 0.0, 1, 1, 16, False), (3, 40000, 100, 0.01, 8, 0, 16, False),
+                                                       (2, 30000, 100, 0.01, 5, 16, 16, True)])
+def test_replicated_ranks_equal_one_gpu(world, n, L, err, E, K, S, lowc, part, tmp_path, monkeypatch):
+    """a design-(R) run == the single-GPU run on the concatenated input, every stage-II file.  part: stage II partitioned over the ranks by
+    encoder shard, ONE all-reduce(min) of the claims (the pieces of the ranks put together as harc_amd_merge_shard_files does); else
+    (HARC_AMD_S2_PART=0) stage II replicated: every rank holds every file.  lowc: repeats and poly-A runs (the cooperative kernel's walks are
+    partitioned too; stage-II bins above maxsearch: their probes travel to every rank with their window words); K = 1: one chain, one owner,
+    the other ranks only follow; E = 1 with three ranks: two ranks without a shard"""
     import numpy as np
     os.environ["HARC_AMD_MAILBOX_TIMEOUT"] = "180"
+    monkeypatch.setenv("HARC_AMD_S2_PART", "1" if part else "0")
     if lowc:
         txt = gen.reads_text_lowcomplexity(31 + world, n, L, 50000, err=err)
         arr = np.frombuffer(txt, dtype=np.uint8).reshape(-1, L + 1)[:, :L].copy()
@@ -110,14 +149,21 @@ def test_replicated_ranks_equal_one_gpu(world, n, L, err, E, K, S, lowc, tmp_pat
     mbox.mkdir()
     res = _ranks(world, sl, L, E, K, S, str(mbox))
     nclean = int((~(arr == ord("N")).any(1)).sum())
+    if part:
+        got = _assemble(res, E, L)
+        for k, v in want.items():
+            assert got[k] == v, "%d ranks, stage II partitioned: %s differs from the single-GPU run" % (world, k)
+        assert sum(res[r]["sig"][0] for r in range(world)) == n           # every read decoded by exactly one rank
+        assert sum(res[r]["counters"].aligned_singletons for r in range(world)) == cw.aligned_singletons and sum(res[r]["counters"].aligned_N for r in range(world)) == cw.aligned_N
     for r in range(world):
         info = res[r]["info"]
         assert info[0] == nclean and info[2] == n and info[6] == nclean, (r, info)
-        for k, v in want.items():
-            assert res[r]["files"][k] == v, "rank %d of %d: %s differs from the single-GPU run" % (r, world, k)
+        if not part:
+            for k, v in want.items():
+                assert res[r]["files"][k] == v, "rank %d of %d: %s differs from the single-GPU run" % (r, world, k)
+            assert res[r]["sig"][0] == n
         c = res[r]["counters"]
         assert (c.unmatched, c.rounds, c.conflicts, c.n_main, c.n_singleton) == (cw.unmatched, cw.rounds, cw.conflicts, cw.n_main, cw.n_singleton)
-        assert res[r]["sig"][0] == n
 
 
 RCCL_WORKER = textwrap.dedent("""
