@@ -354,8 +354,14 @@ extern "C" int harc_amd_encode(harc_amd_ctx *c)
     // every rank then ends with ALL streams of the job, as a single GPU does (tests compare the two)
     c->s2_part = false; c->s2_e0 = 0; c->s2_e1 = 0;
     uint32_t oi0 = 0, oi1 = 0xFFFFFFFFu;
-    if (c->replicated && c->comm && c->comm->world > 1 && !c->s1_from_files && !(getenv("HARC_AMD_S2_PART") && atoi(getenv("HARC_AMD_S2_PART")) == 0)) {
-        const uint32_t E = (uint32_t)c->P.num_thr, wd = (uint32_t)c->comm->world, rk = (uint32_t)c->comm->rank;
+    int simr = 0, simw = 0;
+    // HARC_AMD_S2_SIM=rank/world (profiling only): what ONE rank of a partitioned stage II computes, without peers -- no all-reduce, so the claims of
+    // the other ranks' columns are missing and the streams are NOT an archive; tools/s2_share.py times configs[3]'s share with it
+    if (const char *e = getenv("HARC_AMD_S2_SIM")) { if (sscanf(e, "%d/%d", &simr, &simw) != 2 || simw < 2 || simr < 0 || simr >= simw) simw = 0; }
+    const bool real_part = c->replicated && c->comm && c->comm->world > 1 && !(getenv("HARC_AMD_S2_PART") && atoi(getenv("HARC_AMD_S2_PART")) == 0);
+    if ((real_part || simw) && !c->s1_from_files) {
+        const uint32_t E = (uint32_t)c->P.num_thr, wd = real_part ? (uint32_t)c->comm->world : (uint32_t)simw, rk = real_part ? (uint32_t)c->comm->rank : (uint32_t)simr;
+        c->s2_world = (int)wd; c->s2_rank = (int)rk;
         c->s2_part = true; c->s2_e0 = (int)((uint64_t)E * rk / wd); c->s2_e1 = (int)((uint64_t)E * (rk + 1) / wd);
         uint32_t q = 1u + (uint32_t)((c->M - 1u) / E); if (q == 0) q = 1;          // encoder.cpp:171
         const uint64_t a0 = (uint64_t)c->s2_e0 * q, a1 = (uint64_t)c->s2_e1 * q;

@@ -110,6 +110,7 @@ struct harc_amd_ctx {
     struct HarcComm *comm = nullptr;
     InBuf x_reads, x_nreads3, x_gid, x_ngid;            // the received shard and the global ids of its reads
     uint32_t *d_gid = nullptr, *d_ngid = nullptr;       // non-null after an exchange: stage II writes global ids into its order streams
+    int s2_world = 1, s2_rank = 0;                      // the partition's geometry (the communicator's; or HARC_AMD_S2_SIM=rank/world: one rank's share without peers, profiling only)
     bool s2_part = false; int s2_e0 = 0, s2_e1 = 0;     // stage II partitioned over the ranks of a design-(R) run (harc_amd_encode decides): the encoder shards [s2_e0, s2_e1) are this rank's
     bool replicated = false;                            // after harc_amd_replicate_exchange: the context holds the reads of the WHOLE job in global id order (x_reads / x_nreads3)
                                                         // and stage I partitions the CHAINS over the ranks (stage1.hip)

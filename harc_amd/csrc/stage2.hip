@@ -1141,9 +1141,14 @@ int stage2_run(harc_amd_ctx *c)
     const uint32_t M = c->M, S = c->S, NN = c->NN, T = S + NN, E = (uint32_t)P.num_thr;
     // drop earlier stage-II outputs
     for (auto it = c->out.begin(); it != c->out.end();) { if (it->first.first >= HARC_AMD_S2_SEQ) it = c->out.erase(it); else ++it; }
-    HarcComm *const cm = (c->s2_part && c->comm && c->replicated) ? c->comm : nullptr;       // partitioned over the ranks (harc_amd_encode decided)
-    const uint32_t e0 = cm ? (uint32_t)c->s2_e0 : 0u, e1 = cm ? (uint32_t)c->s2_e1 : E;
-    const uint32_t t0 = cm ? (uint32_t)((uint64_t)T * (uint32_t)cm->rank / (uint32_t)cm->world) : 0u, t1 = cm ? (uint32_t)((uint64_t)T * ((uint32_t)cm->rank + 1u) / (uint32_t)cm->world) : T;
+    const bool part = c->s2_part;                                 // partitioned over the ranks (harc_amd_encode decided)
+    HarcComm *const cm = (part && c->comm && c->replicated && c->comm->world > 1) ? c->comm : nullptr;       // null with HARC_AMD_S2_SIM: one rank's share without peers (profiling)
+    const uint32_t pw = part ? (uint32_t)c->s2_world : 1u, pr = part ? (uint32_t)c->s2_rank : 0u;
+    const uint32_t e0 = part ? (uint32_t)c->s2_e0 : 0u, e1 = part ? (uint32_t)c->s2_e1 : E;
+    const uint32_t t0 = (uint32_t)((uint64_t)T * pr / pw), t1 = (uint32_t)((uint64_t)T * (pr + 1u) / pw);
+    const bool trace2 = getenv("HARC_AMD_TRACE") != nullptr;
+    struct timespec tl0; clock_gettime(CLOCK_MONOTONIC, &tl0);
+    auto lap = [&](const char *what) { if (trace2) { (void)hipStreamSynchronize(c->stream); struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); fprintf(stderr, "[stage II%s] %s: %.1f ms\n", part ? " (partitioned)" : "", what, (t.tv_sec - tl0.tv_sec) * 1e3 + (t.tv_nsec - tl0.tv_nsec) * 1e-6); tl0 = t; } };
 
     S2Args a; memset(&a, 0, sizeof a);
     a.L = L; a.W = W; a.W3 = W3; a.thresh_s = P.thresh_s; a.maxsearch = P.maxsearch;
@@ -1251,6 +1256,7 @@ int stage2_run(harc_amd_ctx *c)
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; a.bloom[l] = bloom[l]; a.bloom_shift[l] = bloom_shift[l]; }
+    lap("candidates and their dictionaries (all candidates, on every rank)");
 
     // ---- contig structure on the global column axis (all reads, on every rank: prefix sums)
     uint8_t *head = nullptr; uint32_t *u0 = nullptr, *u1 = nullptr; uint64_t *d64 = nullptr, *gstart = nullptr; uint32_t *chead = nullptr;
@@ -1285,8 +1291,9 @@ int stage2_run(harc_amd_ctx *c)
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint64_t col0 = sh_col[e0], col1 = sh_col[e1];
+    lap("contig structure (all reads, on every rank)");
     a.col0 = col0; a.col1 = col1; a.tile_base = (uint32_t)(col0 / CTILE);
-    if (cm) c->C.seq_bases = col1 - col0;                         // this rank's share (the merge adds the ranks up)
+    if (part) c->C.seq_bases = col1 - col0;                       // this rank's share (the merge adds the ranks up)
     uint8_t *h_seq = nullptr;
     struct CopyJoin { hipStream_t s; ~CopyJoin() { (void)hipStreamSynchronize(s); } } copy_join{ c->copy_stream };   // on every way out: nothing of this run is still in flight
     uint8_t *cons = nullptr; RC_TRY(dalloc(c, &cons, (size_t)total + 8));
@@ -1353,6 +1360,7 @@ int stage2_run(harc_amd_ctx *c)
         }
     }
     HIP_TRY(hipGetLastError());
+    lap("consensus + read_seq + proposals (this rank's columns)");
     // ---- the window words of the events (k_realign_big reads them instead of the consensus: with the columns partitioned the consensus under an
     //      event of another rank is not here)
     uint64_t *evwin = nullptr;
@@ -1387,6 +1395,7 @@ int stage2_run(harc_amd_ctx *c)
         } else nev = 0;
     }
     a.evwin = evwin;
+    lap("all-reduce of the claims, probes into large bins gathered");
     if (nev) {                                                        // exact sliding-window semantics as a fixed point (k_realign_big)
         unsigned int *d_changed = nullptr; uint32_t *estart = nullptr, *lastver = nullptr; unsigned long long *binmin[2] = { nullptr, nullptr };
         if (total >> (EV_TBITS - 2)) { harc_set_error("stage II: more than 2^%d consensus columns", EV_TBITS - 2); return HARC_AMD_EINVAL; }
@@ -1466,6 +1475,7 @@ int stage2_run(harc_amd_ctx *c)
     }
     HIP_TRY(hipGetLastError());
 
+    lap("window passes over the large bins (all probes, on every rank)");
     // ---- accepted candidates sorted by (tuple, rid descending): all of them, on every rank (a sort of 16-byte pairs)
     uint32_t A = 0;
     uint32_t *ta = nullptr, *tb = nullptr; uint64_t *tup0 = nullptr, *tup = nullptr; uint32_t *rid0 = nullptr, *rid = nullptr;
@@ -1484,6 +1494,7 @@ int stage2_run(harc_amd_ctx *c)
         RC_TRY(prim_sort_pairs_u64_u32(c, tup0, tup, rid0, rid, A, bits));
     }
 
+    lap("accepted candidates sorted (all, on every rank)");
     // ---- shard boundaries in final-list coordinates; this rank's piece of the final read list is [fbase, fend)
     std::vector<uint32_t> sh_f(E + 1), sh_a(E + 1);
     {
@@ -1612,6 +1623,7 @@ int stage2_run(harc_amd_ctx *c)
     HIP_TRY(hipMemcpyAsync(&big, d_big, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));                // read_seq has arrived
+    lap("merge, noise / pos / rev / order streams, leftovers, device -> host (this rank's shards)");
     c->C.bins_over_maxsearch = big;
     // encoder.cpp:506-508; partitioned: this rank's share of the candidates (the merge adds the ranks up)
     const uint32_t s_lo = t0 < S ? t0 : S, s_hi = t1 < S ? t1 : S;
