@@ -1176,7 +1176,9 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     bool stalled = false; int resume_next = 0;
     // steps that agreed with the consensus everywhere (rows_from_read): the rows are current, `pend` of them wait for cons_flush, ptot = their shifts
     bool rows_ok = false; int pend = 0, ptot = 0;
-    const bool lazy = s.lazy != 0;
+    // (compiled into the wave-uniform kernels only: there the run of agreeing steps is the rule -- dense launches over error-free or nearly error-free
+    // reads -- and the code fits; in the other kernels the second path cost registers: the 150-bp dense kernel lost 3.7 % to it)
+    const bool lazy = SEQ && s.lazy != 0;
     PH(0);
     for (int t = T0; t < s.S; t++) {
         if (!rows_ok) cons_rows(st, L, lane, coltmp, rowF, rowR);   // consensus and its reverse complement -> the wave's window rows
@@ -2278,6 +2280,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (N == 0 || K > N) K = 1;                                  // floor(N/K)=0: only chain 0 ever runs (reorder.cpp:484-490)
     c->C.chains = K;
     int nsteps = P.num_steps > 0 ? P.num_steps : 16;
+    // (one chain cannot lose a bid, so its output does not depend on S -- but longer walks do not pay: every candidate is compared with the reads the
+    // walk has taken so far, and 64 steps per launch ran exact mode at 0.22 instead of 0.25 Mreads/s)
     if (nsteps > 64) nsteps = 64;
     // few chains -> every launch is a chain of dependent HBM round trips: fetch whole buckets; many chains -> request-rate bound: single slots
     bool quad = K <= 16384;

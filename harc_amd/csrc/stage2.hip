@@ -965,11 +965,12 @@ template <int W> __device__ __forceinline__ void final_words(const S2Args &s, ui
         for (int w = 0; w < W; w++) nmk[w] = ~t[w] & lowmask_word(2 * s.L, w);
     }
 }
-template <int W, bool EMIT> __global__ void k_noise(S2Args s, FinalArrays f, const uint64_t *cons2, uint32_t F, uint32_t *nm, uint32_t *nonN,
+// (the final-list entries [fb, F): the emitting pass is launched shard by shard, so that a shard's streams leave for the host while the next is written)
+template <int W, bool EMIT> __global__ void k_noise(S2Args s, FinalArrays f, const uint64_t *cons2, uint32_t fb, uint32_t F, uint32_t *nm, uint32_t *nonN,
                                                     const uint64_t *nmoff, const uint32_t *nonNrank,
                                                     uint8_t *noise, uint8_t *noisepos, uint8_t *posb, uint8_t *rcb, uint32_t *order_out, uint32_t *orderN_out)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = fb + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F) return;
     const uint32_t ref = f.ref[i]; const int kind = f.kind[i]; const uint64_t g = f.g[i];
     uint64_t rd[W], nk[W], cw[W], mm[W];
@@ -1007,11 +1008,11 @@ template <int W, bool EMIT> __global__ void k_noise(S2Args s, FinalArrays f, con
     const bool isN = (kind != 0 && ref >= s.S);
     if (isN) orderN_out[i - nonNrank[i]] = ov; else order_out[nonNrank[i]] = ov;
 }
-template <bool EMIT> static void launch_noise(harc_amd_ctx *c, const S2Args &a, const FinalArrays &f, const uint64_t *cons2, uint32_t F, uint32_t *nm, uint32_t *nonN,
+template <bool EMIT> static void launch_noise(harc_amd_ctx *c, const S2Args &a, const FinalArrays &f, const uint64_t *cons2, uint32_t fb, uint32_t F, uint32_t *nm, uint32_t *nonN,
                                               const uint64_t *nmoff, const uint32_t *nonNrank, uint8_t *noise, uint8_t *noisepos, uint8_t *posb, uint8_t *rcb,
                                               uint32_t *order_out, uint32_t *orderN_out)
 {
-#define NOISE_CASE(WW) case WW: hipLaunchKernelGGL((k_noise<WW, EMIT>), dim3((F + 255) / 256), dim3(256), 0, c->stream, a, f, cons2, F, nm, nonN, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out); break;
+#define NOISE_CASE(WW) case WW: hipLaunchKernelGGL((k_noise<WW, EMIT>), dim3((F - fb + 255) / 256), dim3(256), 0, c->stream, a, f, cons2, fb, F, nm, nonN, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out); break;
     switch (a.W) { NOISE_CASE(1) NOISE_CASE(2) NOISE_CASE(3) NOISE_CASE(4) NOISE_CASE(5) NOISE_CASE(6) NOISE_CASE(7) NOISE_CASE(8) }
 #undef NOISE_CASE
 }
@@ -1184,6 +1185,55 @@ int stage2_run(harc_amd_ctx *c)
     if (T) hipLaunchKernelGGL(k_cand_order, G256(T), c->d_order_s, S, T, cand_order);
     HIP_TRY(hipMemsetAsync(best, 0xFF, ((size_t)T + 1) * 8, c->stream));
     a.cand3 = cand3; a.cand_order = cand_order; a.best = best;
+    // ---- contig structure on the global column axis (all reads, on every rank: prefix sums).  Allocation order is the lifetime order (the pool is a
+    //      stack): what the streams need to the end first, then -- in a scope of their own, released after the realignment -- the candidates'
+    //      dictionaries, bitmaps, 2-bit copies, the consensus bytes and the window passes' state; the merge / noise arrays then take their place
+    //      (configs[3]: 185 -> 140 GB peak)
+    uint8_t *head = nullptr; uint32_t *u1 = nullptr; uint64_t *gstart = nullptr; uint32_t *chead = nullptr;
+    RC_TRY(dalloc(c, &head, (size_t)M + 1)); RC_TRY(dalloc(c, &u1, (size_t)M + 1)); RC_TRY(dalloc(c, &gstart, (size_t)M + 1));
+    uint32_t nC = 0; uint64_t total = 0;
+    if (M) {
+        PoolScope cscope(c);
+        uint32_t *u0 = nullptr; uint64_t *d64 = nullptr;
+        RC_TRY(dalloc(c, &u0, (size_t)M + 1)); RC_TRY(dalloc(c, &d64, (size_t)M + 1));
+        hipLaunchKernelGGL(k_heads1, G256(M), c->d_flag, M, a.q, head, u0);
+        RC_TRY(prim_incl_max_u32(c, u0, u1, M));
+        hipLaunchKernelGGL(k_heads2, G256(M), M, head, u1, u0);                  // u0 := head flags as u32
+        RC_TRY(prim_excl_scan_u32(c, u0, u1, M));                                // u1 := contig id
+        hipLaunchKernelGGL(k_col_steps, G256(M), head, c->d_pos, M, L, d64);
+        RC_TRY(prim_incl_scan_u64(c, d64, gstart, M));
+        uint32_t lastcid = 0, lasthead = 0; uint64_t lastg = 0;
+        HIP_TRY(hipMemcpyAsync(&lastcid, u1 + (M - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&lasthead, u0 + (M - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&lastg, gstart + (M - 1), 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        nC = lastcid + lasthead; total = lastg + (uint64_t)L;
+    }
+    RC_TRY(dalloc(c, &chead, (size_t)nC + 1));
+    if (M) hipLaunchKernelGGL(k_contig_heads, G256(M), head, u1, M, chead);
+    a.head = head; a.gstart = gstart; a.chead = chead; a.nC = nC; a.total = total;
+    c->C.contigs = nC; c->C.seq_bases = total;
+    std::vector<uint64_t> sh_col(E + 1, total), seq_off(E, 0), seq_nb(E, 0), seq_tl(E, 0);
+    for (uint32_t e = 0; e <= E; e++) {
+        const uint64_t st = (uint64_t)e * a.q; const uint32_t i = e == E ? M : (uint32_t)(st > M ? M : st);
+        if (i >= M) { sh_col[e] = total; continue; }
+        HIP_TRY(hipMemcpyAsync(&sh_col[e], gstart + i, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t col0 = sh_col[e0], col1 = sh_col[e1];
+    a.col0 = col0; a.col1 = col1; a.tile_base = (uint32_t)(col0 / CTILE);
+    if (part) c->C.seq_bases = col1 - col0;                       // this rank's share (the merge adds the ranks up)
+    lap("contig structure (all reads, on every rank)");
+    // the packed consensus (the noise pass reads it) and the packed read_seq of this rank's shards (on its way to the host beside the realignment)
+    uint64_t *cons2 = nullptr;
+    const uint64_t ncw = (total + 31) / 32;
+    RC_TRY(dalloc(c, &cons2, (size_t)ncw + 2 * W + 4));
+    HIP_TRY(hipMemsetAsync(cons2 + ncw, 0, ((size_t)2 * W + 4) * 8, c->stream));
+    a.cons2 = cons2;
+    uint64_t seq_total = 0;
+    for (uint32_t e = e0; e < e1; e++) { const uint64_t cc = sh_col[e + 1] - sh_col[e]; seq_nb[e] = cc / 4; seq_tl[e] = cc % 4; seq_off[e] = seq_total; seq_total += (seq_nb[e] + seq_tl[e] + 15) & ~15ull; }
+    uint8_t *seqpk = nullptr; RC_TRY(dalloc(c, &seqpk, (size_t)seq_total + 64));
+    PoolScope ascope(c);                                          // ---- from here to the end of the realignment: released before the merge
     uint64_t *cand2 = nullptr, *candN = nullptr;
     RC_TRY(dalloc(c, &cand2, (size_t)T * W + 1)); RC_TRY(dalloc(c, &candN, (size_t)T * W + 1));
     if (T) hipLaunchKernelGGL(k_cand2_from3, G256((size_t)T * W), (const uint64_t *)cand3, T, L, W, W3, cand2, candN);
@@ -1258,51 +1308,11 @@ int stage2_run(harc_amd_ctx *c)
     for (int l = 0; l < 2; l++) { a.slots[l] = dict[l].slots; a.cap[l] = dict[l].cap; a.ids[l] = dict[l].ids; a.bloom[l] = bloom[l]; a.bloom_shift[l] = bloom_shift[l]; }
     lap("candidates and their dictionaries (all candidates, on every rank)");
 
-    // ---- contig structure on the global column axis (all reads, on every rank: prefix sums)
-    uint8_t *head = nullptr; uint32_t *u0 = nullptr, *u1 = nullptr; uint64_t *d64 = nullptr, *gstart = nullptr; uint32_t *chead = nullptr;
-    RC_TRY(dalloc(c, &head, (size_t)M + 1)); RC_TRY(dalloc(c, &u0, (size_t)M + 1)); RC_TRY(dalloc(c, &u1, (size_t)M + 1));
-    RC_TRY(dalloc(c, &d64, (size_t)M + 1)); RC_TRY(dalloc(c, &gstart, (size_t)M + 1));
-    uint32_t nC = 0; uint64_t total = 0;
-    if (M) {
-        hipLaunchKernelGGL(k_heads1, G256(M), c->d_flag, M, a.q, head, u0);
-        RC_TRY(prim_incl_max_u32(c, u0, u1, M));
-        hipLaunchKernelGGL(k_heads2, G256(M), M, head, u1, u0);                  // u0 := head flags as u32
-        RC_TRY(prim_excl_scan_u32(c, u0, u1, M));                                // u1 := contig id
-        hipLaunchKernelGGL(k_col_steps, G256(M), head, c->d_pos, M, L, d64);
-        RC_TRY(prim_incl_scan_u64(c, d64, gstart, M));
-        uint32_t lastcid = 0, lasthead = 0; uint64_t lastg = 0;
-        HIP_TRY(hipMemcpyAsync(&lastcid, u1 + (M - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&lasthead, u0 + (M - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&lastg, gstart + (M - 1), 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        nC = lastcid + lasthead; total = lastg + (uint64_t)L;
-        RC_TRY(dalloc(c, &chead, (size_t)nC + 1));
-        hipLaunchKernelGGL(k_contig_heads, G256(M), head, u1, M, chead);
-    }
-    a.head = head; a.gstart = gstart; a.chead = chead; a.nC = nC; a.total = total;
-    c->C.contigs = nC; c->C.seq_bases = total;
-
     // ---- consensus + realignment proposals: the columns of this rank's shards
-    std::vector<uint64_t> sh_col(E + 1, total), seq_off(E, 0), seq_nb(E, 0), seq_tl(E, 0);
-    for (uint32_t e = 0; e <= E; e++) {
-        const uint64_t st = (uint64_t)e * a.q; const uint32_t i = e == E ? M : (uint32_t)(st > M ? M : st);
-        if (i >= M) { sh_col[e] = total; continue; }
-        HIP_TRY(hipMemcpyAsync(&sh_col[e], gstart + i, 8, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const uint64_t col0 = sh_col[e0], col1 = sh_col[e1];
-    lap("contig structure (all reads, on every rank)");
-    a.col0 = col0; a.col1 = col1; a.tile_base = (uint32_t)(col0 / CTILE);
-    if (part) c->C.seq_bases = col1 - col0;                       // this rank's share (the merge adds the ranks up)
     uint8_t *h_seq = nullptr;
     struct CopyJoin { hipStream_t s; ~CopyJoin() { (void)hipStreamSynchronize(s); } } copy_join{ c->copy_stream };   // on every way out: nothing of this run is still in flight
     uint8_t *cons = nullptr; RC_TRY(dalloc(c, &cons, (size_t)total + 8));
     a.cons = cons;
-    uint64_t *cons2 = nullptr;
-    const uint64_t ncw = (total + 31) / 32;
-    RC_TRY(dalloc(c, &cons2, (size_t)ncw + 2 * W + 4));
-    HIP_TRY(hipMemsetAsync(cons2 + ncw, 0, ((size_t)2 * W + 4) * 8, c->stream));
-    a.cons2 = cons2;
     unsigned int nev = 0;
     if (col1 > col0) {
         unsigned long long *cinfo = nullptr; RC_TRY(dalloc(c, &cinfo, (size_t)nC + 1));
@@ -1316,9 +1326,7 @@ int stage2_run(harc_amd_ctx *c)
         {   // read_seq (packbits, encoder.cpp:527-548) is final here -- the realignment below does not touch the consensus -- and the shard
             // boundaries on the column axis follow from gstart alone: it is packed now and goes to the host on the copy stream while the
             // realignment, the merge and the noise kernels run (the largest stream: a quarter of a byte per consensus base)
-            uint64_t soff = 0;
-            for (uint32_t e = e0; e < e1; e++) { const uint64_t cc = sh_col[e + 1] - sh_col[e]; seq_nb[e] = cc / 4; seq_tl[e] = cc % 4; seq_off[e] = soff; soff += (seq_nb[e] + seq_tl[e] + 15) & ~15ull; }
-            uint8_t *seqpk = nullptr; RC_TRY(dalloc(c, &seqpk, (size_t)soff + 64));
+            const uint64_t soff = seq_total;
             for (uint32_t e = e0; e < e1; e++) {
                 const uint64_t cc0 = sh_col[e];
                 if (seq_nb[e]) hipLaunchKernelGGL(k_pack2_bytes, G256(seq_nb[e]), cons + cc0, seq_nb[e], seqpk + seq_off[e]);
@@ -1476,6 +1484,10 @@ int stage2_run(harc_amd_ctx *c)
     HIP_TRY(hipGetLastError());
 
     lap("window passes over the large bins (all probes, on every rank)");
+    unsigned long long big = 0;
+    HIP_TRY(hipMemcpyAsync(&big, d_big, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                     // nothing of the realignment is still running: its arrays go
+    ascope.release_now();
     // ---- accepted candidates sorted by (tuple, rid descending): all of them, on every rank (a sort of 16-byte pairs)
     uint32_t A = 0;
     uint32_t *ta = nullptr, *tb = nullptr; uint64_t *tup0 = nullptr, *tup = nullptr; uint32_t *rid0 = nullptr, *rid = nullptr;
@@ -1518,7 +1530,7 @@ int stage2_run(harc_amd_ctx *c)
     uint32_t *nm = nullptr, *nonN = nullptr, *nonNrank = nullptr; uint64_t *nmoff = nullptr;
     RC_TRY(dalloc(c, &nm, (size_t)F + 1)); RC_TRY(dalloc(c, &nonN, (size_t)F + 1)); RC_TRY(dalloc(c, &nonNrank, (size_t)F + 1)); RC_TRY(dalloc(c, &nmoff, (size_t)F + 1));
     HIP_TRY(hipMemsetAsync(nm, 0, ((size_t)F + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(nonN, 0, ((size_t)F + 1) * 4, c->stream));
-    if (F) launch_noise<false>(c, a, f, cons2, F, nm, nonN, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (F) launch_noise<false>(c, a, f, cons2, 0u, F, nm, nonN, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     RC_TRY(prim_excl_scan_u32_to_u64(c, nm, nmoff, (size_t)F + 1));
     RC_TRY(prim_excl_scan_u32(c, nonN, nonNrank, (size_t)F + 1));
     uint64_t nmtot = 0; uint32_t n_nonN = 0;
@@ -1542,7 +1554,28 @@ int stage2_run(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &noise, (size_t)nmtot + F + 1)); RC_TRY(dalloc(c, &noisepos, (size_t)nmtot + 1)); RC_TRY(dalloc(c, &posb, (size_t)F + 1)); RC_TRY(dalloc(c, &rcb, (size_t)F + 8));
     if ((size_t)n_nonN + US > (size_t)(i1 - i0) + (size_t)S || (size_t)n_N_aligned + UN > (size_t)NN) { harc_set_error("stage II bookkeeping: %u + %u clean, %u + %u N order entries", n_nonN, US, n_N_aligned, UN); return HARC_AMD_EINTERNAL; }
     RC_TRY(dalloc(c, &sing_bases, (size_t)US * L + 8)); RC_TRY(dalloc(c, &ntext, (size_t)UN * (L + 1) + 1));
-    if (F) launch_noise<true>(c, a, f, cons2, F, nullptr, nullptr, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out);
+    // ---- shard boundaries in noise coordinates (relative to this rank's piece)
+    std::vector<uint64_t> sh_nm(E + 1, 0);
+    for (uint32_t e = e0; e <= e1; e++) HIP_TRY(hipMemcpyAsync(&sh_nm[e], nmoff + (sh_f[e] - fbase), 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // ---- emission, shard by shard: the noise / noisepos / pos bytes of shard e go to the host on the copy stream while shard e + 1 is written,
+    //      and the leftovers and the bit-packing below run beside the copies (configs[3]: 4 GB of these streams, 80 ms of PCIe that used to
+    //      start only when everything had been computed)
+    uint8_t *h_packed = nullptr, *h_noise = nullptr, *h_noisepos = nullptr, *h_pos = nullptr, *h_ntext = nullptr, *h_meta = nullptr;
+    const size_t n_order = ((size_t)n_nonN + US) * 4, n_orderN = ((size_t)n_N_aligned + UN) * 4, n_ntext = (size_t)UN * (L + 1);
+    RC_TRY(harc_host_alloc(c, (void **)&h_noise, (size_t)nmtot + F)); RC_TRY(harc_host_alloc(c, (void **)&h_noisepos, (size_t)nmtot)); RC_TRY(harc_host_alloc(c, (void **)&h_pos, F));
+    RC_TRY(harc_host_alloc(c, (void **)&h_ntext, n_ntext)); RC_TRY(harc_host_alloc(c, (void **)&h_meta, 32));
+    for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t f0 = sh_f[e] - fbase, f1 = sh_f[e + 1] - fbase;
+        if (f1 <= f0) continue;
+        launch_noise<true>(c, a, f, cons2, f0, f1, nullptr, nullptr, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out);
+        HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+        const uint64_t nz0 = sh_nm[e] + f0, nz1 = sh_nm[e + 1] + f1;
+        HIP_TRY(hipMemcpyAsync(h_noise + nz0, noise + nz0, (size_t)(nz1 - nz0), hipMemcpyDeviceToHost, c->copy_stream));
+        if (sh_nm[e + 1] > sh_nm[e]) HIP_TRY(hipMemcpyAsync(h_noisepos + sh_nm[e], noisepos + sh_nm[e], (size_t)(sh_nm[e + 1] - sh_nm[e]), hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipMemcpyAsync(h_pos + f0, posb + f0, (size_t)(f1 - f0), hipMemcpyDeviceToHost, c->copy_stream));
+    }
     if (nt) hipLaunchKernelGGL(k_left_emit, G256((uint64_t)nt * ((L + 15) / 16)), a, t0, nt, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned, sing_bases, ntext);
     HIP_TRY(hipGetLastError());
     if (c->d_gid && !c->s1_from_files) {
@@ -1557,11 +1590,6 @@ int stage2_run(harc_amd_ctx *c)
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (merr) { harc_set_error("stage II: %u order entries outside the shard", merr); return HARC_AMD_EINTERNAL; }
     }
-
-    // ---- shard boundaries in noise coordinates (relative to this rank's piece)
-    std::vector<uint64_t> sh_nm(E + 1, 0);
-    for (uint32_t e = e0; e <= e1; e++) HIP_TRY(hipMemcpyAsync(&sh_nm[e], nmoff + (sh_f[e] - fbase), 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
 
     // ---- packbits per shard into ONE device buffer, then a handful of device -> pinned-host copies; per-shard streams are slices
     std::vector<uint64_t> rev_off(E, 0), rev_nb(E, 0), rev_tl(E, 0);
@@ -1580,16 +1608,12 @@ int stage2_run(harc_amd_ctx *c)
     if (sing_nb) hipLaunchKernelGGL(k_pack2_bytes, G256(sing_nb), sing_bases, sing_nb, packed + sing_off);
     if (sing_tl) hipLaunchKernelGGL(k_bases_to_ascii, G256(sing_tl), sing_bases + 4 * sing_nb, sing_tl, packed + sing_off + sing_nb);
     HIP_TRY(hipGetLastError());
-    uint8_t *h_packed = nullptr, *h_noise = nullptr, *h_noisepos = nullptr, *h_pos = nullptr, *h_ntext = nullptr, *h_meta = nullptr;
-    const size_t n_order = ((size_t)n_nonN + US) * 4, n_orderN = ((size_t)n_N_aligned + UN) * 4, n_ntext = (size_t)UN * (L + 1);
-    RC_TRY(harc_host_alloc(c, (void **)&h_packed, (size_t)poff)); RC_TRY(harc_host_alloc(c, (void **)&h_noise, (size_t)nmtot + F));
-    RC_TRY(harc_host_alloc(c, (void **)&h_noisepos, (size_t)nmtot)); RC_TRY(harc_host_alloc(c, (void **)&h_pos, F));
-    RC_TRY(harc_host_alloc(c, (void **)&h_ntext, n_ntext)); RC_TRY(harc_host_alloc(c, (void **)&h_meta, 32));
-    if (poff) HIP_TRY(hipMemcpyAsync(h_packed, packed, (size_t)poff, hipMemcpyDeviceToHost, c->stream));
-    if (nmtot + F) HIP_TRY(hipMemcpyAsync(h_noise, noise, (size_t)nmtot + F, hipMemcpyDeviceToHost, c->stream));
-    if (nmtot) HIP_TRY(hipMemcpyAsync(h_noisepos, noisepos, (size_t)nmtot, hipMemcpyDeviceToHost, c->stream));
-    if (F) HIP_TRY(hipMemcpyAsync(h_pos, posb, F, hipMemcpyDeviceToHost, c->stream));
-    if (n_ntext) HIP_TRY(hipMemcpyAsync(h_ntext, ntext, n_ntext, hipMemcpyDeviceToHost, c->stream));
+    RC_TRY(harc_host_alloc(c, (void **)&h_packed, (size_t)poff));
+    // these two follow the shard copies on the copy stream (one PCIe link: side by side they would only share it)
+    HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+    if (poff) HIP_TRY(hipMemcpyAsync(h_packed, packed, (size_t)poff, hipMemcpyDeviceToHost, c->copy_stream));
+    if (n_ntext) HIP_TRY(hipMemcpyAsync(h_ntext, ntext, n_ntext, hipMemcpyDeviceToHost, c->copy_stream));
     if (want_digest) {
         // the shard cuts of noise / noisepos / pos are positions inside ONE array each: the arrays as a whole, then the cuts themselves
         RC_TRY(digest_range(c, noise, nmtot + F, 0x200, d_digest + 1)); RC_TRY(digest_range(c, noisepos, nmtot, 0x201, d_digest + 1)); RC_TRY(digest_range(c, posb, F, 0x202, d_digest + 1));
@@ -1619,8 +1643,6 @@ int stage2_run(harc_amd_ctx *c)
     c->d_s2_order = order_out; c->n_s2_order = n_order; c->d_s2_orderN = orderN_out; c->n_s2_orderN = n_orderN;
     out_slice(c, HARC_AMD_S2_INPUT_N, 0, h_ntext, n_ntext);
     { const int ml = snprintf((char *)h_meta, 32, "%d\n", L); out_slice(c, HARC_AMD_S2_META, 0, h_meta, (size_t)ml); }
-    unsigned long long big = 0;
-    HIP_TRY(hipMemcpyAsync(&big, d_big, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));                // read_seq has arrived
     lap("merge, noise / pos / rev / order streams, leftovers, device -> host (this rank's shards)");
