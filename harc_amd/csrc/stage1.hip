@@ -2129,10 +2129,12 @@ int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n, uint64_t cap_like)
     d->cap = 0; d->slots = nullptr; d->ids = nullptr; d->d_nbins = nullptr;
     if (n == 0) return HARC_AMD_OK;
     if (cap_like) d->cap = cap_like;                              // same geometry as a sibling table (k_steps addresses both dictionaries alike)
-    else {   // load factor 1/4 when HBM allows (fewer dependent re-probes: the chain kernel is latency-bound), else 1/3, else 1/2
+    else {   // load factor 1/4 when HBM allows (fewer dependent re-probes: the chain kernel is latency-bound), else 1/3, else 1/2: a table takes at most
+             // 15 % of the device's memory.  Measured at configs[3] (810 M reads, profiles/r04/bench_c4_cap*.json): 4 / 3 / 2 slots per read =
+             // 594 / 591 / 569 Mreads/s at 52 / 39 / 26 GB per table -- there the rule picks 3; configs[2] and configs[4]'s share keep 4
         unsigned long long m = 4;
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) { fr += c->pool_total; while (m > 2 && (double)m * n * sizeof(HashSlot) > 0.2 * (double)fr) m--; }
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) { fr += c->pool_total; while (m > 2 && ((double)m * n * sizeof(HashSlot) > 0.2 * (double)fr || (double)m * n * sizeof(HashSlot) > 0.15 * (double)tot)) m--; }
         if (const char *e = getenv("HARC_AMD_CAPMULT")) m = strtoull(e, nullptr, 10);
         d->cap = (((m < 2 ? 2 : m) * n + 4) + 3) & ~3ull;           // whole 64-B buckets of 4 slots
     }

@@ -385,11 +385,17 @@ __global__ void k_cand2_from3(const uint64_t *cand3, uint32_t T, int L, int W, i
     if (gid >= (uint64_t)T * W) return;
     const uint32_t i = (uint32_t)(gid / W); const int w = (int)(gid % W);
     const uint64_t *r = cand3 + (size_t)i * W3;
+    // the 32 bases of word w are the 96 bits from bit 96 w on: 64 + 32 of them out of two (three) words, every shift below a constant
+    // (a call of c3_at per base was 20 ms for the 220 M candidates of configs[3]); the store holds zeros behind base L, so nothing is cut
+    (void)L;
+    const int wi = (3 * w) >> 1;
+    const uint64_t x0 = r[wi], x1 = wi + 1 < W3 ? r[wi + 1] : 0;
+    uint64_t lo, hi;
+    if (w & 1) { lo = (x0 >> 32) | (x1 << 32); hi = x1 >> 32; } else { lo = x0; hi = x1 & 0xFFFFFFFFull; }
     uint64_t a = 0, n = 0;
+#pragma unroll
     for (int k = 0; k < 32; k++) {
-        const int j = 32 * w + k;
-        if (j >= L) break;
-        const uint64_t c3 = (uint64_t)c3_at(r, W3, j);
+        const uint64_t c3 = (k <= 20 ? (lo >> (3 * k)) : k == 21 ? ((lo >> 63) | (hi << 1)) : (hi >> (3 * k - 64))) & 7;
         a |= (c3 >> 1) << (2 * k);
         n |= ((c3 & 1) * 3) << (2 * k);
     }
@@ -1029,8 +1035,16 @@ __global__ void k_left_flags(const unsigned long long *best, uint32_t t0, uint32
 }
 // One thread per (read, group of 16 bases): neighbouring threads write neighbouring 16 bytes.  (A thread per read wrote its L bytes one
 // by one, L bytes apart from its neighbour's: 50 ms for the 115 M leftover reads of an 8-way bucket shard of configs[2].)
-__global__ void k_left_emit(S2Args s, uint32_t t0, uint32_t nt, const uint32_t *rs, const uint32_t *rn, uint32_t *order_out, uint32_t order_base,
-                            uint32_t *orderN_out, uint32_t orderN_base, uint8_t *sing_bases, char *ntext)
+// their order entries (behind the aligned ones: the bases are known long before -- k_noise's sizes pass decides where the aligned entries end)
+__global__ void k_left_orders(S2Args s, uint32_t t0, uint32_t nt, const uint32_t *rs, const uint32_t *rn, uint32_t *order_out, uint32_t order_base, uint32_t *orderN_out, uint32_t orderN_base)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const uint32_t i = t0 + t;
+    if (s.best[i] != TUPLE_NONE) return;
+    if (i < s.S) order_out[order_base + rs[t]] = s.cand_order[i]; else orderN_out[orderN_base + rn[t]] = s.cand_order[i];
+}
+__global__ void k_left_emit(S2Args s, uint32_t t0, uint32_t nt, const uint32_t *rs, const uint32_t *rn, uint8_t *sing_bases, char *ntext)
 {
     const int G = (s.L + 15) / 16;
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1041,12 +1055,10 @@ __global__ void k_left_emit(S2Args s, uint32_t t0, uint32_t nt, const uint32_t *
     const int j0 = 16 * g, j1 = j0 + 16 < s.L ? j0 + 16 : s.L;
     if (i < s.S) {
         const uint32_t k = rs[i - t0];
-        if (g == 0) order_out[order_base + k] = s.cand_order[i];
         uint8_t *o = sing_bases + (size_t)k * s.L;
         for (int j = j0; j < j1; j++) o[j] = (uint8_t)c3_to_idx5(c3_at(r, s.W3, j));
     } else {
         const uint32_t k = rn[i - t0];
-        if (g == 0) orderN_out[orderN_base + k] = s.cand_order[i];
         char *o = ntext + (size_t)k * (s.L + 1);
         for (int j = j0; j < j1; j++) o[j] = "ACGTN"[c3_to_idx5(c3_at(r, s.W3, j))];
         if (j1 == s.L) o[s.L] = '\n';
@@ -1244,6 +1256,7 @@ int stage2_run(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &a.events, (size_t)a.maxevents)); RC_TRY(dalloc(c, &a.nevents, 4));
     HIP_TRY(hipMemsetAsync(a.nevents, 0, 16, c->stream));
 
+    lap("  candidates: 3-bit store, 2-bit copies");
     // ---- dictionaries over the candidates (encoder.cpp:886-992)
     DictDev dict[2];
     unsigned long long *d_big = nullptr; RC_TRY(dalloc(c, &d_big, 1));
@@ -1284,11 +1297,14 @@ int stage2_run(harc_amd_ctx *c)
             if (bloom4 && bloom4_tiled) hipLaunchKernelGGL(k_bloom4_items, G256(T), (const uint64_t *)k0, T, a.bloom_lbits, a.bloom_nwin, l, a.kbits[l] / 3, harc_bitmap_tiles(b4words), items + (size_t)l * 2 * T);
             else if (bloom4) hipLaunchKernelGGL(k_bloom4_set, G256(T), (const uint64_t *)k0, T, bloom[0], a.bloom_lbits, a.bloom_nwin, l, a.kbits[l] / 3);
             else hipLaunchKernelGGL(k_bloom_set, G256(T), (const uint64_t *)k0, T, bloom[l], bloom_shift[l]);
+            lap("  keys, bitmap items");
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0k, T, (unsigned)a.kbits[l]));
             hipLaunchKernelGGL(k_count_big_bins, G256(dict[l].cap), dict[l].slots, dict[l].cap, (uint32_t)P.maxsearch, d_big);
+            lap("  dictionary built");
         }
         if (bloom4 && bloom4_tiled) {
             RC_TRY(harc_bitmap_from_items(c, items, items_tmp, (size_t)T * 4, b4words, bloom[0]));
+            lap("  combined bitmap from sorted items");
             if (getenv("HARC_AMD_S2BLOOM_VERIFY")) {                // tests: word for word what the atomics build
                 uint32_t *ref = nullptr; unsigned long long *nd = nullptr, hnd = 0;
                 RC_TRY(dalloc(c, &ref, (size_t)b4words + 1)); RC_TRY(dalloc(c, &nd, 1));
@@ -1488,6 +1504,32 @@ int stage2_run(harc_amd_ctx *c)
     HIP_TRY(hipMemcpyAsync(&big, d_big, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));                     // nothing of the realignment is still running: its arrays go
     ascope.release_now();
+    // ---- leftovers (unaligned singletons and N reads, encoder.cpp:484-499): this rank's share of the candidates.  They depend on the claims alone,
+    //      so their bases and text are made NOW and leave for the host beside the merge and the noise passes (configs[3]: 1.4 GB of input_N.dna)
+    const uint32_t nt = t1 - t0;
+    uint32_t *ls = nullptr, *ln = nullptr, *rs = nullptr, *rn = nullptr;
+    RC_TRY(dalloc(c, &ls, (size_t)nt + 1)); RC_TRY(dalloc(c, &ln, (size_t)nt + 1)); RC_TRY(dalloc(c, &rs, (size_t)nt + 1)); RC_TRY(dalloc(c, &rn, (size_t)nt + 1));
+    HIP_TRY(hipMemsetAsync(ls, 0, ((size_t)nt + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(ln, 0, ((size_t)nt + 1) * 4, c->stream));
+    if (nt) hipLaunchKernelGGL(k_left_flags, G256(nt), best, t0, nt, S, ls, ln);
+    RC_TRY(prim_excl_scan_u32(c, ls, rs, (size_t)nt + 1)); RC_TRY(prim_excl_scan_u32(c, ln, rn, (size_t)nt + 1));
+    uint32_t US = 0, UN = 0;
+    HIP_TRY(hipMemcpyAsync(&US, rs + nt, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&UN, rn + nt, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint8_t *sing_bases = nullptr, *spk = nullptr; char *ntext = nullptr;
+    const uint64_t sing_nb = (uint64_t)US * L / 4, sing_tl = (uint64_t)US * L % 4;
+    const size_t n_ntext = (size_t)UN * (L + 1);
+    RC_TRY(dalloc(c, &sing_bases, (size_t)US * L + 8)); RC_TRY(dalloc(c, &ntext, n_ntext + 1)); RC_TRY(dalloc(c, &spk, (size_t)(sing_nb + sing_tl) + 64));
+    uint8_t *h_sing = nullptr, *h_ntext = nullptr;
+    RC_TRY(harc_host_alloc(c, (void **)&h_sing, (size_t)(sing_nb + sing_tl))); RC_TRY(harc_host_alloc(c, (void **)&h_ntext, n_ntext));
+    if (nt) hipLaunchKernelGGL(k_left_emit, G256((uint64_t)nt * ((L + 15) / 16)), a, t0, nt, rs, rn, sing_bases, ntext);
+    if (sing_nb) hipLaunchKernelGGL(k_pack2_bytes, G256(sing_nb), sing_bases, sing_nb, spk);
+    if (sing_tl) hipLaunchKernelGGL(k_bases_to_ascii, G256(sing_tl), sing_bases + 4 * sing_nb, sing_tl, spk + sing_nb);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+    if (sing_nb + sing_tl) HIP_TRY(hipMemcpyAsync(h_sing, spk, (size_t)(sing_nb + sing_tl), hipMemcpyDeviceToHost, c->copy_stream));
+    if (n_ntext) HIP_TRY(hipMemcpyAsync(h_ntext, ntext, n_ntext, hipMemcpyDeviceToHost, c->copy_stream));
     // ---- accepted candidates sorted by (tuple, rid descending): all of them, on every rank (a sort of 16-byte pairs)
     uint32_t A = 0;
     uint32_t *ta = nullptr, *tb = nullptr; uint64_t *tup0 = nullptr, *tup = nullptr; uint32_t *rid0 = nullptr, *rid = nullptr;
@@ -1536,24 +1578,12 @@ int stage2_run(harc_amd_ctx *c)
     uint64_t nmtot = 0; uint32_t n_nonN = 0;
     HIP_TRY(hipMemcpyAsync(&nmtot, nmoff + F, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&n_nonN, nonNrank + F, 4, hipMemcpyDeviceToHost, c->stream));
-    // leftovers: this rank's share of the candidates
-    const uint32_t nt = t1 - t0;
-    uint32_t *ls = nullptr, *ln = nullptr, *rs = nullptr, *rn = nullptr;
-    RC_TRY(dalloc(c, &ls, (size_t)nt + 1)); RC_TRY(dalloc(c, &ln, (size_t)nt + 1)); RC_TRY(dalloc(c, &rs, (size_t)nt + 1)); RC_TRY(dalloc(c, &rn, (size_t)nt + 1));
-    HIP_TRY(hipMemsetAsync(ls, 0, ((size_t)nt + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(ln, 0, ((size_t)nt + 1) * 4, c->stream));
-    if (nt) hipLaunchKernelGGL(k_left_flags, G256(nt), best, t0, nt, S, ls, ln);
-    RC_TRY(prim_excl_scan_u32(c, ls, rs, (size_t)nt + 1)); RC_TRY(prim_excl_scan_u32(c, ln, rn, (size_t)nt + 1));
-    uint32_t US = 0, UN = 0;
-    HIP_TRY(hipMemcpyAsync(&US, rs + nt, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&UN, rn + nt, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint32_t n_N_aligned = F - n_nonN;
 
     uint8_t *noise = nullptr, *noisepos = nullptr, *posb = nullptr, *rcb = nullptr;
-    uint8_t *sing_bases = nullptr; char *ntext = nullptr;
     RC_TRY(dalloc(c, &noise, (size_t)nmtot + F + 1)); RC_TRY(dalloc(c, &noisepos, (size_t)nmtot + 1)); RC_TRY(dalloc(c, &posb, (size_t)F + 1)); RC_TRY(dalloc(c, &rcb, (size_t)F + 8));
     if ((size_t)n_nonN + US > (size_t)(i1 - i0) + (size_t)S || (size_t)n_N_aligned + UN > (size_t)NN) { harc_set_error("stage II bookkeeping: %u + %u clean, %u + %u N order entries", n_nonN, US, n_N_aligned, UN); return HARC_AMD_EINTERNAL; }
-    RC_TRY(dalloc(c, &sing_bases, (size_t)US * L + 8)); RC_TRY(dalloc(c, &ntext, (size_t)UN * (L + 1) + 1));
     // ---- shard boundaries in noise coordinates (relative to this rank's piece)
     std::vector<uint64_t> sh_nm(E + 1, 0);
     for (uint32_t e = e0; e <= e1; e++) HIP_TRY(hipMemcpyAsync(&sh_nm[e], nmoff + (sh_f[e] - fbase), 8, hipMemcpyDeviceToHost, c->stream));
@@ -1561,10 +1591,10 @@ int stage2_run(harc_amd_ctx *c)
     // ---- emission, shard by shard: the noise / noisepos / pos bytes of shard e go to the host on the copy stream while shard e + 1 is written,
     //      and the leftovers and the bit-packing below run beside the copies (configs[3]: 4 GB of these streams, 80 ms of PCIe that used to
     //      start only when everything had been computed)
-    uint8_t *h_packed = nullptr, *h_noise = nullptr, *h_noisepos = nullptr, *h_pos = nullptr, *h_ntext = nullptr, *h_meta = nullptr;
-    const size_t n_order = ((size_t)n_nonN + US) * 4, n_orderN = ((size_t)n_N_aligned + UN) * 4, n_ntext = (size_t)UN * (L + 1);
+    uint8_t *h_packed = nullptr, *h_noise = nullptr, *h_noisepos = nullptr, *h_pos = nullptr, *h_meta = nullptr;
+    const size_t n_order = ((size_t)n_nonN + US) * 4, n_orderN = ((size_t)n_N_aligned + UN) * 4;
     RC_TRY(harc_host_alloc(c, (void **)&h_noise, (size_t)nmtot + F)); RC_TRY(harc_host_alloc(c, (void **)&h_noisepos, (size_t)nmtot)); RC_TRY(harc_host_alloc(c, (void **)&h_pos, F));
-    RC_TRY(harc_host_alloc(c, (void **)&h_ntext, n_ntext)); RC_TRY(harc_host_alloc(c, (void **)&h_meta, 32));
+    RC_TRY(harc_host_alloc(c, (void **)&h_meta, 32));
     for (uint32_t e = e0; e < e1; e++) {
         const uint32_t f0 = sh_f[e] - fbase, f1 = sh_f[e + 1] - fbase;
         if (f1 <= f0) continue;
@@ -1576,7 +1606,7 @@ int stage2_run(harc_amd_ctx *c)
         if (sh_nm[e + 1] > sh_nm[e]) HIP_TRY(hipMemcpyAsync(h_noisepos + sh_nm[e], noisepos + sh_nm[e], (size_t)(sh_nm[e + 1] - sh_nm[e]), hipMemcpyDeviceToHost, c->copy_stream));
         HIP_TRY(hipMemcpyAsync(h_pos + f0, posb + f0, (size_t)(f1 - f0), hipMemcpyDeviceToHost, c->copy_stream));
     }
-    if (nt) hipLaunchKernelGGL(k_left_emit, G256((uint64_t)nt * ((L + 15) / 16)), a, t0, nt, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned, sing_bases, ntext);
+    if (nt) hipLaunchKernelGGL(k_left_orders, G256(nt), a, t0, nt, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned);
     HIP_TRY(hipGetLastError());
     if (c->d_gid && !c->s1_from_files) {
         // multi-GPU shard (harc_amd_shard_exchange): the order streams carry the GLOBAL ids of the reads, so that the merged archive
@@ -1597,28 +1627,23 @@ int stage2_run(harc_amd_ctx *c)
     for (uint32_t e = e0; e < e1; e++) {
         const uint64_t ff = sh_f[e + 1] - sh_f[e]; rev_nb[e] = ff / 8; rev_tl[e] = ff % 8; rev_off[e] = poff; poff += (rev_nb[e] + rev_tl[e] + 15) & ~15ull;
     }
-    const uint64_t sing_nb = (uint64_t)US * L / 4, sing_tl = (uint64_t)US * L % 4, sing_off = poff;
-    poff += (sing_nb + sing_tl + 15) & ~15ull;
     uint8_t *packed = nullptr; RC_TRY(dalloc(c, &packed, (size_t)poff + 64));
     for (uint32_t e = e0; e < e1; e++) {
         const uint32_t f0 = sh_f[e] - fbase;
         if (rev_nb[e]) hipLaunchKernelGGL(k_pack1_bytes, G256(rev_nb[e]), rcb + f0, rev_nb[e], packed + rev_off[e]);
         if (rev_tl[e]) HIP_TRY(hipMemcpyAsync(packed + rev_off[e] + rev_nb[e], rcb + f0 + 8 * rev_nb[e], rev_tl[e], hipMemcpyDeviceToDevice, c->stream));
     }
-    if (sing_nb) hipLaunchKernelGGL(k_pack2_bytes, G256(sing_nb), sing_bases, sing_nb, packed + sing_off);
-    if (sing_tl) hipLaunchKernelGGL(k_bases_to_ascii, G256(sing_tl), sing_bases + 4 * sing_nb, sing_tl, packed + sing_off + sing_nb);
     HIP_TRY(hipGetLastError());
     RC_TRY(harc_host_alloc(c, (void **)&h_packed, (size_t)poff));
-    // these two follow the shard copies on the copy stream (one PCIe link: side by side they would only share it)
+    // it follows the shard copies on the copy stream (one PCIe link: side by side they would only share it)
     HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
     if (poff) HIP_TRY(hipMemcpyAsync(h_packed, packed, (size_t)poff, hipMemcpyDeviceToHost, c->copy_stream));
-    if (n_ntext) HIP_TRY(hipMemcpyAsync(h_ntext, ntext, n_ntext, hipMemcpyDeviceToHost, c->copy_stream));
     if (want_digest) {
         // the shard cuts of noise / noisepos / pos are positions inside ONE array each: the arrays as a whole, then the cuts themselves
         RC_TRY(digest_range(c, noise, nmtot + F, 0x200, d_digest + 1)); RC_TRY(digest_range(c, noisepos, nmtot, 0x201, d_digest + 1)); RC_TRY(digest_range(c, posb, F, 0x202, d_digest + 1));
         for (uint32_t e = e0; e < e1; e++) RC_TRY(digest_range(c, packed + rev_off[e], rev_nb[e] + rev_tl[e], 0x300 + e, d_digest + 2));
-        RC_TRY(digest_range(c, packed + sing_off, sing_nb + sing_tl, 0x3F0, d_digest + 2)); RC_TRY(digest_range(c, ntext, n_ntext, 0x3F1, d_digest + 2));
+        RC_TRY(digest_range(c, spk, sing_nb + sing_tl, 0x3F0, d_digest + 2)); RC_TRY(digest_range(c, ntext, n_ntext, 0x3F1, d_digest + 2));
         RC_TRY(digest_range(c, order_out, n_order, 0x400, d_digest + 3)); RC_TRY(digest_range(c, orderN_out, n_orderN, 0x401, d_digest + 3));
         unsigned long long *h_dig = nullptr; RC_TRY(harc_host_alloc(c, (void **)&h_dig, 32));
         HIP_TRY(hipMemcpyAsync(h_dig, d_digest, 32, hipMemcpyDeviceToHost, c->stream));
@@ -1639,7 +1664,7 @@ int stage2_run(harc_amd_ctx *c)
         out_slice(c, HARC_AMD_S2_NOISE, e, h_noise + sh_nm[e] + f0, (sh_nm[e + 1] + f1) - (sh_nm[e] + f0));
         out_slice(c, HARC_AMD_S2_NOISEPOS, e, h_noisepos + sh_nm[e], sh_nm[e + 1] - sh_nm[e]);
     }
-    out_slice(c, HARC_AMD_S2_SINGLETON, 0, h_packed + sing_off, sing_nb); out_slice(c, HARC_AMD_S2_SINGLETON_TAIL, 0, h_packed + sing_off + sing_nb, sing_tl);
+    out_slice(c, HARC_AMD_S2_SINGLETON, 0, h_sing, sing_nb); out_slice(c, HARC_AMD_S2_SINGLETON_TAIL, 0, h_sing + sing_nb, sing_tl);
     c->d_s2_order = order_out; c->n_s2_order = n_order; c->d_s2_orderN = orderN_out; c->n_s2_orderN = n_orderN;
     out_slice(c, HARC_AMD_S2_INPUT_N, 0, h_ntext, n_ntext);
     { const int ml = snprintf((char *)h_meta, 32, "%d\n", L); out_slice(c, HARC_AMD_S2_META, 0, h_meta, (size_t)ml); }
