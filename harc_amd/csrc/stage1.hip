@@ -376,59 +376,90 @@ __global__ void k_place_keys(const uint64_t *skeys, const uint32_t *binstart, ui
 // bins: 2 x 2.6 ms per dictionary at configs[2]).  pass 1 (after pass 0 has finished, over the last 16 384 bins only): the few bins at the very
 // end whose slot falls past the table: they wrap around like a probe would.  Single-read bins (the common case) carry the read id in
 // `start`: one dependent load less on every hit.
-__global__ void k_table_place(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, uint32_t nbins, uint32_t n, const uint64_t *q,
+#define TP_SPAN 2048u             // table slots a workgroup of the filling placement stages in LDS (32 KB): 256 bins span ~1024 slots at load factor 1/4
+__global__ __launch_bounds__(256) void k_table_place(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, uint32_t nbins, uint32_t n, const uint64_t *q,
                               HashSlot *slots, uint64_t cap, uint32_t bigthresh,
                               unsigned long long *large_list, unsigned int *large_n, uint32_t large_max, uint32_t large_tag, uint32_t *nbins_p, int pass, uint32_t first_block, int fill)
 {
+    __shared__ uint4 tile[TP_SPAN];
     if (blockIdx.x < first_block) return;                                          // pass 1: the bins beyond the end of the table are among the last
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nbins) return;
-    uint64_t sl = q[i] - (uint64_t)nbins + (uint64_t)i;                            // max-scan value + i
-    const uint32_t st = binstart[i];
-    const uint64_t key = skeys[st];
-    // pass 0 places the bins whose slot lies inside the table; pass 1 (launched over the last bins only) the few beyond its end
-    if (pass == 0 && sl >= cap && blockIdx.x + 64 < gridDim.x) { atomicAdd(nbins_p + 1, 1u); return; }   // pass 1 would not reach it: the build fails loudly (never seen)
-    if ((pass == 1) != (sl >= cap)) return;
-    // the overflow flag of a bucket lives in its first slot: "a key whose home is this bucket or an earlier one sits beyond it".  Slots and
-    // homes both grow with the bin index, so that is the case exactly when the bucket is full and the bin right behind it has its home
-    // here or earlier -- decided by the thread that writes the first slot, without a second pass over all bins
-    uint32_t ovf = 0;
-    if (pass == 0 && (sl & 3) == 0 && (uint64_t)i + 4 < (uint64_t)nbins) {
-        const uint64_t s3 = q[i + 3] - (uint64_t)nbins + (uint64_t)(i + 3);
-        if (s3 == sl + 3 && (bucket_slot(skeys[binstart[i + 4]], cap) >> 2) <= (sl >> 2)) ovf = SLOT_OVF;
-    }
-    // fill: the table has NOT been cleared (22 GB per dictionary at configs[2], 4.5 ms): slots grow with the bin index, so every bin also
-    // writes the empty slots between its predecessor and itself (three on average at load factor 1/4), and the last bin inside the table those
-    // behind it -- every slot is written exactly once.  (The host clears the table instead when bins are few and the gaps long.)
-    if (pass == 0 && fill) {
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        for (uint64_t x = i ? (q[i - 1] - (uint64_t)nbins + (uint64_t)(i - 1)) + 1 : 0; x < sl; x++) *reinterpret_cast<uint4 *>(&slots[x]) = z;
-        if (i + 1 == nbins || q[i + 1] - (uint64_t)nbins + (uint64_t)(i + 1) >= cap)
-            for (uint64_t x = sl + 1; x < cap; x++) *reinterpret_cast<uint4 *>(&slots[x]) = z;
-    }
-    const uint32_t en = (i + 1 < nbins) ? binstart[i + 1] : n;
-    const uint32_t cnt = en - st;
-    if (cnt > SLOT_CNT_MASK) { atomicAdd(nbins_p + 1, 1u); return; }               // does not fit the count field: the build fails loudly
-    const unsigned long long meta = cnt == 1 ? ((unsigned long long)sids[st] | ((unsigned long long)(1u | SLOT_EMB) << 32))
-                                             : ((unsigned long long)st | ((unsigned long long)((cnt & SLOT_CNT_MASK) | ((bigthresh && cnt > bigthresh) ? SLOT_BIG : 0u)) << 32));
-    if (pass == 1) {
-        // a bin beyond the end wraps around like a probe would: it has left its home bucket, every bucket up to the last, and whatever it passes at the start
-        for (uint64_t b = bucket_slot(key, cap) >> 2; b < (cap >> 2); b++) atomicOr(&slots[4 * b].count, SLOT_OVF);
-        sl = 0;
-        for (;;) {
-            unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
-            if (atomicCAS(mp, 0ULL, meta) == 0ULL) break;
-            if ((sl & 3) == 3) atomicOr(&slots[sl - 3].count, SLOT_OVF);
-            if (++sl == cap) sl = 0;
+    const bool have = i < nbins;
+    auto slot_of = [&](uint32_t k) -> uint64_t { return q[k] - (uint64_t)nbins + (uint64_t)k; };     // max-scan value + k
+    // fill (pass 0): the table has NOT been cleared (22 GB per dictionary at configs[2]): slots grow with the bin index, so the 256 bins of a
+    // workgroup own one contiguous stretch of the table -- from behind the last slot of the workgroup before to their own last slot, to the end
+    // of the table for the last bins inside it.  The stretch is put together in LDS (zeros, then the bins' slots) and written out as ONE
+    // coalesced stream of 16-byte stores: every slot of the table is written exactly once, at streaming rate (round 3 let every bin write
+    // the gap in front of it with stores of its own: 11 ms per dictionary at configs[2] for 22 GB; now 5).  A stretch longer than the LDS tile
+    // (few bins, long gaps) falls back to that.
+    const uint32_t b0 = blockIdx.x * blockDim.x, b1 = b0 + blockDim.x < nbins ? b0 + blockDim.x : nbins;
+    bool tiled = false; uint64_t lo = 0, hi = 0;
+    if (pass == 0 && fill && b0 < nbins) {
+        lo = b0 ? slot_of(b0 - 1) + 1 : 0;
+        const uint64_t last = slot_of(b1 - 1);
+        if (lo < cap) {
+            hi = (last >= cap || b1 == nbins || slot_of(b1) >= cap) ? cap : last + 1;     // the last bins inside the table clear what lies behind them
+            tiled = hi - lo <= TP_SPAN;
         }
-        slots[sl].key = key;
-    } else {
-        uint4 w; w.x = (uint32_t)key; w.y = (uint32_t)(key >> 32); w.z = (uint32_t)meta; w.w = (uint32_t)(meta >> 32) | ovf;
-        *reinterpret_cast<uint4 *>(&slots[sl]) = w;
     }
-    if (large_list && cnt > HARC_LARGEBIN) {                                      // remembered for k_compact_bins: (slot index, dictionary)
-        const unsigned int at = atomicAdd(large_n, 1u);
-        if (at < large_max) large_list[at] = ((unsigned long long)sl << 1) | large_tag;
+    if (tiled) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t j = threadIdx.x; j < (uint32_t)(hi - lo); j += blockDim.x) tile[j] = z;
+        __syncthreads();
+    }
+    uint64_t sl = have ? slot_of(i) : 0;
+    bool mine = have;
+    // pass 0 places the bins whose slot lies inside the table; pass 1 (launched over the last bins only) the few beyond its end
+    if (mine && pass == 0 && sl >= cap && blockIdx.x + 64 < gridDim.x) { atomicAdd(nbins_p + 1, 1u); mine = false; }   // pass 1 would not reach it: the build fails loudly (never seen)
+    if (mine && (pass == 1) != (sl >= cap)) mine = false;
+    if (mine) {
+        const uint32_t st = binstart[i];
+        const uint64_t key = skeys[st];
+        // the overflow flag of a bucket lives in its first slot: "a key whose home is this bucket or an earlier one sits beyond it".  Slots and
+        // homes both grow with the bin index, so that is the case exactly when the bucket is full and the bin right behind it has its home
+        // here or earlier -- decided by the thread that writes the first slot, without a second pass over all bins
+        uint32_t ovf = 0;
+        if (pass == 0 && (sl & 3) == 0 && (uint64_t)i + 4 < (uint64_t)nbins) {
+            const uint64_t s3 = slot_of(i + 3);
+            if (s3 == sl + 3 && (bucket_slot(skeys[binstart[i + 4]], cap) >> 2) <= (sl >> 2)) ovf = SLOT_OVF;
+        }
+        if (pass == 0 && fill && !tiled) {
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            for (uint64_t x = i ? slot_of(i - 1) + 1 : 0; x < sl; x++) *reinterpret_cast<uint4 *>(&slots[x]) = z;
+            if (i + 1 == nbins || slot_of(i + 1) >= cap)
+                for (uint64_t x = sl + 1; x < cap; x++) *reinterpret_cast<uint4 *>(&slots[x]) = z;
+        }
+        const uint32_t en = (i + 1 < nbins) ? binstart[i + 1] : n;
+        const uint32_t cnt = en - st;
+        if (cnt > SLOT_CNT_MASK) atomicAdd(nbins_p + 1, 1u);                       // does not fit the count field: the build fails loudly
+        else {
+            // Single-read bins (the common case) carry the read id in `start`: one dependent load less on every hit.
+            const unsigned long long meta = cnt == 1 ? ((unsigned long long)sids[st] | ((unsigned long long)(1u | SLOT_EMB) << 32))
+                                                     : ((unsigned long long)st | ((unsigned long long)((cnt & SLOT_CNT_MASK) | ((bigthresh && cnt > bigthresh) ? SLOT_BIG : 0u)) << 32));
+            if (pass == 1) {
+                // a bin beyond the end wraps around like a probe would: it has left its home bucket, every bucket up to the last, and whatever it passes at the start
+                for (uint64_t bb = bucket_slot(key, cap) >> 2; bb < (cap >> 2); bb++) atomicOr(&slots[4 * bb].count, SLOT_OVF);
+                sl = 0;
+                for (;;) {
+                    unsigned long long *mp = reinterpret_cast<unsigned long long *>(&slots[sl]) + 1;
+                    if (atomicCAS(mp, 0ULL, meta) == 0ULL) break;
+                    if ((sl & 3) == 3) atomicOr(&slots[sl - 3].count, SLOT_OVF);
+                    if (++sl == cap) sl = 0;
+                }
+                slots[sl].key = key;
+            } else {
+                uint4 w; w.x = (uint32_t)key; w.y = (uint32_t)(key >> 32); w.z = (uint32_t)meta; w.w = (uint32_t)(meta >> 32) | ovf;
+                if (tiled) tile[sl - lo] = w; else *reinterpret_cast<uint4 *>(&slots[sl]) = w;
+            }
+            if (large_list && cnt > HARC_LARGEBIN) {                              // remembered for k_compact_bins: (slot index, dictionary)
+                const unsigned int at = atomicAdd(large_n, 1u);
+                if (at < large_max) large_list[at] = ((unsigned long long)sl << 1) | large_tag;
+            }
+        }
+    }
+    if (tiled) {
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < (uint32_t)(hi - lo); j += blockDim.x) *reinterpret_cast<uint4 *>(&slots[lo + j]) = tile[j];
     }
 }
 

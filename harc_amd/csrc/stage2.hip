@@ -1595,15 +1595,18 @@ int stage2_run(harc_amd_ctx *c)
     const size_t n_order = ((size_t)n_nonN + US) * 4, n_orderN = ((size_t)n_N_aligned + UN) * 4;
     RC_TRY(harc_host_alloc(c, (void **)&h_noise, (size_t)nmtot + F)); RC_TRY(harc_host_alloc(c, (void **)&h_noisepos, (size_t)nmtot)); RC_TRY(harc_host_alloc(c, (void **)&h_pos, F));
     RC_TRY(harc_host_alloc(c, (void **)&h_meta, 32));
-    for (uint32_t e = e0; e < e1; e++) {
-        const uint32_t f0 = sh_f[e] - fbase, f1 = sh_f[e + 1] - fbase;
+    // (small outputs go in one piece: a launch and three copies per shard cost a 3 M-read input more than they hide)
+    const uint32_t estep = (nmtot + F) >= ((uint64_t)32 << 20) ? 1u : (e1 - e0 ? e1 - e0 : 1u);
+    for (uint32_t e = e0; e < e1; e += estep) {
+        const uint32_t eb = e + estep < e1 ? e + estep : e1;
+        const uint32_t f0 = sh_f[e] - fbase, f1 = sh_f[eb] - fbase;
         if (f1 <= f0) continue;
         launch_noise<true>(c, a, f, cons2, f0, f1, nullptr, nullptr, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out);
         HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
         HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
-        const uint64_t nz0 = sh_nm[e] + f0, nz1 = sh_nm[e + 1] + f1;
+        const uint64_t nz0 = sh_nm[e] + f0, nz1 = sh_nm[eb] + f1;
         HIP_TRY(hipMemcpyAsync(h_noise + nz0, noise + nz0, (size_t)(nz1 - nz0), hipMemcpyDeviceToHost, c->copy_stream));
-        if (sh_nm[e + 1] > sh_nm[e]) HIP_TRY(hipMemcpyAsync(h_noisepos + sh_nm[e], noisepos + sh_nm[e], (size_t)(sh_nm[e + 1] - sh_nm[e]), hipMemcpyDeviceToHost, c->copy_stream));
+        if (sh_nm[eb] > sh_nm[e]) HIP_TRY(hipMemcpyAsync(h_noisepos + sh_nm[e], noisepos + sh_nm[e], (size_t)(sh_nm[eb] - sh_nm[e]), hipMemcpyDeviceToHost, c->copy_stream));
         HIP_TRY(hipMemcpyAsync(h_pos + f0, posb + f0, (size_t)(f1 - f0), hipMemcpyDeviceToHost, c->copy_stream));
     }
     if (nt) hipLaunchKernelGGL(k_left_orders, G256(nt), a, t0, nt, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned);
