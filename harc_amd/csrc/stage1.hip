@@ -58,6 +58,7 @@ struct S1Args {
     int nprobe;
     int budget;                      // HARC_SCAN_BUDGET (experiments may override it: HARC_AMD_BUDGET)
     int stepcap;                     // HARC_STEP_CAP (HARC_AMD_STEPCAP)
+    int weedmin;                     // wave-uniform scan: single-read bins a batch must find before their claim bits are looked up ahead of the tests (HARC_AMD_WEEDMIN)
     int lazy;                        // 1: steps that agree with the consensus everywhere take the rows from their read and leave the counts to cons_flush (HARC_AMD_LAZY=0: every step applies its counts; same bytes)
     uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups, w sequential-equivalent candidates
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
@@ -1066,7 +1067,11 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     uint32_t *const s_tmp = s_rdl + 4 * MROW;
     uint32_t *const s_pend = s_tmp + 4 * 8 * NW;                  // 4 waves x 64 u16: cumulative shifts of the steps whose counts are still to be applied (cons_flush)
     uint32_t *const s_own = s_pend + 4 * 32;
-    uint2 *const s_pinfo = reinterpret_cast<uint2 *>(s_own + (SEQ ? 4 * HARC_OWN_SLOTS : 0));      // the table exists in the kernel that asks it only (2 KB more LDS cost the 150-bp kernel a workgroup per CU)
+    // OWNT: the kernels that keep the reads a walk has taken in the LDS hash table -- the wave-uniform ones, and the whole-bucket kernel of runs with few
+    // chains (there LDS is no limit, and exact mode walks 64 steps per launch: comparing every candidate with up to 63 earlier reads by v_readlane was
+    // what made long walks slower than short ones)
+    constexpr bool OWNT = SEQ || (QUAD && !COOP);
+    uint2 *const s_pinfo = reinterpret_cast<uint2 *>(s_own + (OWNT ? 4 * HARC_OWN_SLOTS : 0));      // the table exists in the kernel that asks it only (2 KB more LDS cost the 150-bp kernel a workgroup per CU)
     WgCmd *const cmd = reinterpret_cast<WgCmd *>(reinterpret_cast<char *>(s_pinfo + s.nprobe) + 8 - ((size_t)(s_pinfo + s.nprobe) & 7));
     // main kernel: 4 chains per workgroup, one wave each.  COOP: one chain per workgroup, wave 0 walks it (role 0), waves 1..3 help with the scans
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, wv = COOP ? 0 : role;
@@ -1085,7 +1090,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         for (int i = threadIdx.x; i < s.nprobe; i += 64 * NWV) s_pinfo[i] = pt[i];
         for (int i = threadIdx.x; i < 4 * 2 * ROW; i += 64 * NWV) s_rows[i] = 0u;
         for (int i = threadIdx.x; i < 4 * 8 * NW; i += 64 * NWV) s_tmp[i] = 0u;
-        if constexpr (SEQ) for (int i = threadIdx.x; i < 4 * HARC_OWN_SLOTS; i += 64 * NWV) s_own[i] = HARC_NONE;
+        if constexpr (SEQ || (QUAD && !COOP)) for (int i = threadIdx.x; i < 4 * HARC_OWN_SLOTS; i += 64 * NWV) s_own[i] = HARC_NONE;
         __syncthreads();
     }
     if (COOP && role != 0) {                                      // helpers: wait for a scan, take part, until the walk is over
@@ -1209,7 +1214,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     bool rows_ok = false; int pend = 0, ptot = 0;
     // (compiled into the wave-uniform kernels only: there the run of agreeing steps is the rule -- dense launches over error-free or nearly error-free
     // reads -- and the code fits; in the other kernels the second path cost registers: the 150-bp dense kernel lost 3.7 % to it)
-    const bool lazy = SEQ && s.lazy != 0;
+    const bool lazy = (SEQ || (QUAD && !COOP)) && s.lazy != 0;
     PH(0);
     for (int t = T0; t < s.S; t++) {
         if (!rows_ok) cons_rows(st, L, lane, coltmp, rowF, rowR);   // consensus and its reverse complement -> the wave's window rows
@@ -1299,7 +1304,10 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                             // single-read bins (nearly all): claimed reads and the chain's own reads of this super-round are weeded out HERE, by all
                             // lanes at once -- tested one after the other below, each of the chain's last few reads (they sit at the small shifts,
                             // in front of the read the step is looking for) would cost a dependent round trip of its own
-                            if ((reinterpret_cast<const uint32_t *>(s.claimed)[sst >> 5] >> (sst & 31u)) & 1u) { cand = false; atomicOr(reinterpret_cast<uint32_t *>(&tab[sl + qhit]) + 3, SLOT_DEAD); }
+                            // -- but the look at the claim bitmap is a round trip to memory of its own, in front of the one that fetches the read: it is
+                            // made only when the batch found at least `weedmin` such bins (one or two are tested faster than they are weeded: the test
+                            // asks for the claim word anyway).  __ballot here counts the lanes that are in this branch.
+                            if (__popcll(__ballot(true)) >= s.weedmin && ((reinterpret_cast<const uint32_t *>(s.claimed)[sst >> 5] >> (sst & 31u)) & 1u)) { cand = false; atomicOr(reinterpret_cast<uint32_t *>(&tab[sl + qhit]) + 3, SLOT_DEAD); }
                             else if (own_has(ownt, sst)) cand = false;
                         }
                     }
@@ -1323,7 +1331,10 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                             // taken by this chain earlier in this super-round? (not in the frozen bitmap).  Such a read is not a candidate at
                             // all (it does not count); asked only when the answer matters
                             bool own = false;
-                            if (exactwin || hd <= s.thresh) for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
+                            if (exactwin || hd <= s.thresh) {
+                                if constexpr (OWNT) own = own_has(ownt, rid);
+                                else for (int k = 0; k < t; k++) own |= ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) == rid);
+                            }
                             if (own) continue;
                             nc++; ncb++; if (exactwin) seen++;
                             if (hd <= s.thresh) { mine = rid; myhd = hd; break; }
@@ -1487,7 +1498,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                 if (idx < nsugg) {
                     id = __hip_atomic_load(&s.sugg[(size_t)c * HARC_NSUGG + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // may have been written by this wave above
                     okc = !((s.claimed[id >> 6] >> (id & 63)) & 1ULL);
-                    for (int k = 0; k < t; k++) okc = okc && ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) != id);
+                    if constexpr (OWNT) okc = okc && !own_has(ownt, id);
+                    else for (int k = 0; k < t; k++) okc = okc && ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) != id);
                 }
                 const unsigned long long sm = __ballot(okc);
                 if (sm) { const int f = __ffsll((long long)sm) - 1; sid = __shfl(id, f, 64); spos += f + 1; } else spos = nsugg;
@@ -1498,7 +1510,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                 atomicMin(&s.bid[sid], ((uint32_t)t << 20) | c);
             }
             if (lane == t) ownreg = sid;
-            if constexpr (SEQ) { if (lane == 0) own_insert(ownt, sid); }
+            if constexpr (OWNT) { if (lane == 0) own_insert(ownt, sid); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
             if (lane < NW) { const uint32_t *rp = reinterpret_cast<const uint32_t *>(s.reads + (size_t)sid * W); rdl[lane] = rp[lane]; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1513,7 +1525,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             atomicMin(&s.bid[found], ((uint32_t)t << 20) | c);
         }
         if (lane == t) ownreg = found;
-        if constexpr (SEQ) { if (lane == 0) own_insert(ownt, found); }
+        if constexpr (OWNT) { if (lane == 0) own_insert(ownt, found); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lazy && fhd == 0) {                                    // the read agrees with the consensus on the whole overlap: the new consensus is the read
@@ -2313,8 +2325,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (N == 0 || K > N) K = 1;                                  // floor(N/K)=0: only chain 0 ever runs (reorder.cpp:484-490)
     c->C.chains = K;
     int nsteps = P.num_steps > 0 ? P.num_steps : 16;
-    // (one chain cannot lose a bid, so its output does not depend on S -- but longer walks do not pay: every candidate is compared with the reads the
-    // walk has taken so far, and 64 steps per launch ran exact mode at 0.22 instead of 0.25 Mreads/s)
+    // one chain cannot lose a bid: its output does not depend on S, and every super-round is three launches for S steps --
+    // exact mode takes the longest walks there are (a launch per 64 reads instead of per 16)
+    if (P.num_steps <= 0 && K == 1) nsteps = 64;
     if (nsteps > 64) nsteps = 64;
     // few chains -> every launch is a chain of dependent HBM round trips: fetch whole buckets; many chains -> request-rate bound: single slots
     bool quad = K <= 16384;
@@ -2490,6 +2503,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (getenv("HARC_AMD_BUDGET")) a.budget = atoi(getenv("HARC_AMD_BUDGET"));
 #endif
     if (a.stepcap < 1) a.stepcap = 1;
+    a.weedmin = getenv("HARC_AMD_WEEDMIN") ? atoi(getenv("HARC_AMD_WEEDMIN")) : 3;
     a.lazy = getenv("HARC_AMD_LAZY") ? (atoi(getenv("HARC_AMD_LAZY")) != 0 ? 1 : 0) : 1;
     a.firstmax = (bloom_nwin[0] > 0 && bloom_nwin[1] > 0) ? 64 : 48;     // lines by minimizer: speculative probes share their lines
     if (const char *e = getenv("HARC_AMD_FIRSTMAX")) { const int x = atoi(e); a.firstmax = x < 1 ? 1 : x > 64 ? 64 : x; }
@@ -2559,7 +2573,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             hipEvent_t *pair = nullptr;
             if (cm) hipLaunchKernelGGL(k_apply_seed, dim3(nblk), dim3(256), 0, c->stream, a);          // the seeds of the chains other ranks walk
             if (prof) { RC_TRY(R.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }
-            if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
+            if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
             else if (dense && seq && spec) hipLaunchKernelGGL((k_steps<W, false, false, true, 4, true, true>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
             else if (dense && seq) hipLaunchKernelGGL((k_steps<W, false, false, true, 4, true>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
             else if (dense) hipLaunchKernelGGL((k_steps<W, false, false, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
