@@ -390,8 +390,8 @@ __global__ __launch_bounds__(256) void k_table_place(const uint64_t *skeys, cons
     // fill (pass 0): the table has NOT been cleared (22 GB per dictionary at configs[2]): slots grow with the bin index, so the 256 bins of a
     // workgroup own one contiguous stretch of the table -- from behind the last slot of the workgroup before to their own last slot, to the end
     // of the table for the last bins inside it.  The stretch is put together in LDS (zeros, then the bins' slots) and written out as ONE
-    // coalesced stream of 16-byte stores: every slot of the table is written exactly once, at streaming rate (round 3 let every bin write
-    // the gap in front of it with stores of its own: 11 ms per dictionary at configs[2] for 22 GB; now 5).  A stretch longer than the LDS tile
+    // coalesced stream of 16-byte stores: every slot of the table is written exactly once (round 3 let every bin write the gap in front of it
+    // with stores of its own: 12.3 ms per dictionary at configs[2] for 22 GB; now 10.5).  A stretch longer than the LDS tile
     // (few bins, long gaps) falls back to that.
     const uint32_t b0 = blockIdx.x * blockDim.x, b1 = b0 + blockDim.x < nbins ? b0 + blockDim.x : nbins;
     bool tiled = false; uint64_t lo = 0, hi = 0;
