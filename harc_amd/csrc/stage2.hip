@@ -1559,56 +1559,67 @@ int stage2_run(harc_amd_ctx *c)
         HIP_TRY(hipMemcpyAsync(sh_a.data(), d_sha, ((size_t)E + 1) * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    const uint32_t fbase = sh_f[e0], fend = sh_f[e1], F = fend - fbase, a0 = sh_a[e0], na = sh_a[e1] - sh_a[e0];
+    const uint32_t fbase = sh_f[e0], fend = sh_f[e1], F = fend - fbase, na = sh_a[e1] - sh_a[e0];
     if ((uint64_t)(i1 - i0) + na != F) { harc_set_error("stage II bookkeeping: %u reads + %u accepted candidates in a piece of %u", i1 - i0, na, F); return HARC_AMD_EINTERNAL; }
 
-    // ---- merge into the final read list
+    // ---- merge into the final read list, noise / pos / order / rc streams: GROUP BY GROUP.  A group is one encoder shard (all of this rank's shards
+    //      when the output is small): its reads and accepted candidates are merged, sized (writecontig's sizes first, encoder.cpp:654-717),
+    //      scanned and emitted, and its noise / noisepos / pos bytes leave on the copy stream while the next group is merged and sized --
+    //      the host only waits for a group's two totals.  (Until round 4 the whole piece was merged, sized and scanned before the first byte
+    //      left: configs[3] has 4 GB of these streams, 80 ms of PCIe, behind 65 ms of kernels.)
     FinalArrays f;
     RC_TRY(dalloc(c, &f.ref, (size_t)F + 1)); RC_TRY(dalloc(c, &f.kind, (size_t)F + 1)); RC_TRY(dalloc(c, &f.g, (size_t)F + 1));
-    if (i1 > i0) hipLaunchKernelGGL(k_merge_orig, G256(i1 - i0), gstart, i0, i1 - i0, tup, A, f, fbase);
-    if (na) hipLaunchKernelGGL(k_merge_acc, G256(na), gstart, M, tup, rid, a0, na, f, fbase);
-
-    // ---- noise / pos / order / rc streams
     uint32_t *nm = nullptr, *nonN = nullptr, *nonNrank = nullptr; uint64_t *nmoff = nullptr;
     RC_TRY(dalloc(c, &nm, (size_t)F + 1)); RC_TRY(dalloc(c, &nonN, (size_t)F + 1)); RC_TRY(dalloc(c, &nonNrank, (size_t)F + 1)); RC_TRY(dalloc(c, &nmoff, (size_t)F + 1));
     HIP_TRY(hipMemsetAsync(nm, 0, ((size_t)F + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(nonN, 0, ((size_t)F + 1) * 4, c->stream));
-    if (F) launch_noise<false>(c, a, f, cons2, 0u, F, nm, nonN, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    RC_TRY(prim_excl_scan_u32_to_u64(c, nm, nmoff, (size_t)F + 1));
-    RC_TRY(prim_excl_scan_u32(c, nonN, nonNrank, (size_t)F + 1));
-    uint64_t nmtot = 0; uint32_t n_nonN = 0;
-    HIP_TRY(hipMemcpyAsync(&nmtot, nmoff + F, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&n_nonN, nonNrank + F, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const uint32_t n_N_aligned = F - n_nonN;
-
-    uint8_t *noise = nullptr, *noisepos = nullptr, *posb = nullptr, *rcb = nullptr;
-    RC_TRY(dalloc(c, &noise, (size_t)nmtot + F + 1)); RC_TRY(dalloc(c, &noisepos, (size_t)nmtot + 1)); RC_TRY(dalloc(c, &posb, (size_t)F + 1)); RC_TRY(dalloc(c, &rcb, (size_t)F + 8));
-    if ((size_t)n_nonN + US > (size_t)(i1 - i0) + (size_t)S || (size_t)n_N_aligned + UN > (size_t)NN) { harc_set_error("stage II bookkeeping: %u + %u clean, %u + %u N order entries", n_nonN, US, n_N_aligned, UN); return HARC_AMD_EINTERNAL; }
-    // ---- shard boundaries in noise coordinates (relative to this rank's piece)
-    std::vector<uint64_t> sh_nm(E + 1, 0);
-    for (uint32_t e = e0; e <= e1; e++) HIP_TRY(hipMemcpyAsync(&sh_nm[e], nmoff + (sh_f[e] - fbase), 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    // ---- emission, shard by shard: the noise / noisepos / pos bytes of shard e go to the host on the copy stream while shard e + 1 is written,
-    //      and the leftovers and the bit-packing below run beside the copies (configs[3]: 4 GB of these streams, 80 ms of PCIe that used to
-    //      start only when everything had been computed)
-    uint8_t *h_packed = nullptr, *h_noise = nullptr, *h_noisepos = nullptr, *h_pos = nullptr, *h_meta = nullptr;
-    const size_t n_order = ((size_t)n_nonN + US) * 4, n_orderN = ((size_t)n_N_aligned + UN) * 4;
-    RC_TRY(harc_host_alloc(c, (void **)&h_noise, (size_t)nmtot + F)); RC_TRY(harc_host_alloc(c, (void **)&h_noisepos, (size_t)nmtot)); RC_TRY(harc_host_alloc(c, (void **)&h_pos, F));
-    RC_TRY(harc_host_alloc(c, (void **)&h_meta, 32));
-    // (small outputs go in one piece: a launch and three copies per shard cost a 3 M-read input more than they hide)
-    const uint32_t estep = (nmtot + F) >= ((uint64_t)32 << 20) ? 1u : (e1 - e0 ? e1 - e0 : 1u);
-    for (uint32_t e = e0; e < e1; e += estep) {
-        const uint32_t eb = e + estep < e1 ? e + estep : e1;
-        const uint32_t f0 = sh_f[e] - fbase, f1 = sh_f[eb] - fbase;
-        if (f1 <= f0) continue;
-        launch_noise<true>(c, a, f, cons2, f0, f1, nullptr, nullptr, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out);
+    uint8_t *posb = nullptr, *rcb = nullptr;
+    RC_TRY(dalloc(c, &posb, (size_t)F + 1)); RC_TRY(dalloc(c, &rcb, (size_t)F + 8));
+    uint8_t *h_packed = nullptr, *h_pos = nullptr, *h_meta = nullptr;
+    RC_TRY(harc_host_alloc(c, (void **)&h_pos, F)); RC_TRY(harc_host_alloc(c, (void **)&h_meta, 32));
+    unsigned long long *h_tot = nullptr; RC_TRY(harc_host_alloc(c, (void **)&h_tot, 16 * ((size_t)E + 2)));      // pinned: a group's totals and shard cuts
+    std::vector<uint64_t> sh_nm(E + 1, 0);                        // noise coordinates of a shard's first read, relative to its GROUP
+    std::vector<uint8_t *> g_noise(E, nullptr), g_noisepos(E, nullptr), gh_noise(E, nullptr), gh_noisepos(E, nullptr);      // per group (indexed by its first shard): device and host buffers
+    std::vector<uint32_t> g_of(E, 0);                             // the first shard of the group a shard belongs to
+    std::vector<uint64_t> gtot(E, 0);                             // noise entries of a group
+    std::vector<uint64_t> s_nz0(E, 0), s_nz1(E, 0), s_np0(E, 0), s_np1(E, 0);      // a shard's noise / noisepos bytes inside its group's buffers
+    uint64_t nmtot = 0; uint32_t n_nonN = 0, n_N_aligned = 0;
+    const uint32_t estep = (uint64_t)F * 3 >= ((uint64_t)32 << 20) ? 1u : (e1 - e0 ? e1 - e0 : 1u);       // small outputs: one group (a launch and copies per shard cost a 3 M-read input more than they hide)
+    for (uint32_t ea = e0; ea < e1; ea += estep) {
+        const uint32_t eb = ea + estep < e1 ? ea + estep : e1;
+        for (uint32_t e = ea; e < eb; e++) g_of[e] = ea;
+        const uint32_t fa = sh_f[ea] - fbase, fb = sh_f[eb] - fbase;
+        if (fb <= fa) continue;
+        const uint32_t ia = (uint32_t)((uint64_t)ea * a.q > M ? M : (uint64_t)ea * a.q), ib = eb >= E ? M : (uint32_t)((uint64_t)eb * a.q > M ? M : (uint64_t)eb * a.q);
+        if (ib > ia) hipLaunchKernelGGL(k_merge_orig, G256(ib - ia), gstart, ia, ib - ia, tup, A, f, fbase);
+        if (sh_a[eb] > sh_a[ea]) hipLaunchKernelGGL(k_merge_acc, G256(sh_a[eb] - sh_a[ea]), gstart, M, tup, rid, sh_a[ea], sh_a[eb] - sh_a[ea], f, fbase);
+        launch_noise<false>(c, a, f, cons2, fa, fb, nm, nonN, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        // exclusive scans over the group (nm[fb] = nonN[fb] = 0 still: the next group writes them after this)
+        RC_TRY(prim_excl_scan_u32_to_u64(c, nm + fa, nmoff + fa, (size_t)(fb - fa) + 1));
+        RC_TRY(prim_excl_scan_u32(c, nonN + fa, nonNrank + fa, (size_t)(fb - fa) + 1));
+        HIP_TRY(hipMemcpyAsync(&h_tot[0], nmoff + fb, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(reinterpret_cast<uint32_t *>(&h_tot[1]), nonNrank + fb, 4, hipMemcpyDeviceToHost, c->stream));
+        for (uint32_t e = ea + 1; e < eb; e++) HIP_TRY(hipMemcpyAsync(&h_tot[2 + (e - ea)], nmoff + (sh_f[e] - fbase), 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));                 // the copies of the groups before go on meanwhile (copy stream)
+        const uint64_t gnm = h_tot[0]; const uint32_t gnon = *reinterpret_cast<uint32_t *>(&h_tot[1]), gF = fb - fa;
+        sh_nm[ea] = 0; for (uint32_t e = ea + 1; e < eb; e++) sh_nm[e] = h_tot[2 + (e - ea)];
+        RC_TRY(dalloc(c, &g_noise[ea], (size_t)gnm + gF + 8)); RC_TRY(dalloc(c, &g_noisepos[ea], (size_t)gnm + 8));
+        RC_TRY(harc_host_alloc(c, (void **)&gh_noise[ea], (size_t)gnm + gF)); RC_TRY(harc_host_alloc(c, (void **)&gh_noisepos[ea], (size_t)gnm));
+        // k_noise indexes noise with nmoff[i] + i and the N-read orders with i - nonNrank[i], i counted from the rank's piece: the bases move by fa
+        launch_noise<true>(c, a, f, cons2, fa, fb, nullptr, nullptr, nmoff, nonNrank, g_noise[ea] - fa, g_noisepos[ea], posb, rcb, order_out + n_nonN, orderN_out + n_N_aligned - fa);
         HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
         HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
-        const uint64_t nz0 = sh_nm[e] + f0, nz1 = sh_nm[eb] + f1;
-        HIP_TRY(hipMemcpyAsync(h_noise + nz0, noise + nz0, (size_t)(nz1 - nz0), hipMemcpyDeviceToHost, c->copy_stream));
-        if (sh_nm[eb] > sh_nm[e]) HIP_TRY(hipMemcpyAsync(h_noisepos + sh_nm[e], noisepos + sh_nm[e], (size_t)(sh_nm[eb] - sh_nm[e]), hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_TRY(hipMemcpyAsync(h_pos + f0, posb + f0, (size_t)(f1 - f0), hipMemcpyDeviceToHost, c->copy_stream));
+        if (gnm + gF) HIP_TRY(hipMemcpyAsync(gh_noise[ea], g_noise[ea], (size_t)gnm + gF, hipMemcpyDeviceToHost, c->copy_stream));
+        if (gnm) HIP_TRY(hipMemcpyAsync(gh_noisepos[ea], g_noisepos[ea], (size_t)gnm, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipMemcpyAsync(h_pos + fa, posb + fa, (size_t)gF, hipMemcpyDeviceToHost, c->copy_stream));
+        nmtot += gnm; n_nonN += gnon; n_N_aligned += gF - gnon;
+        gtot[ea] = gnm;
+        for (uint32_t e = ea; e < eb; e++) {
+            const uint64_t n0 = sh_nm[e], n1 = e + 1 < eb ? sh_nm[e + 1] : gnm;
+            s_np0[e] = n0; s_np1[e] = n1; s_nz0[e] = n0 + (sh_f[e] - sh_f[ea]); s_nz1[e] = n1 + (sh_f[e + 1] - sh_f[ea]);
+        }
     }
+    if ((size_t)n_nonN + US > (size_t)(i1 - i0) + (size_t)S || (size_t)n_N_aligned + UN > (size_t)NN) { harc_set_error("stage II bookkeeping: %u + %u clean, %u + %u N order entries", n_nonN, US, n_N_aligned, UN); return HARC_AMD_EINTERNAL; }
+    const size_t n_order = ((size_t)n_nonN + US) * 4, n_orderN = ((size_t)n_N_aligned + UN) * 4;
     if (nt) hipLaunchKernelGGL(k_left_orders, G256(nt), a, t0, nt, rs, rn, order_out, n_nonN, orderN_out, n_N_aligned);
     HIP_TRY(hipGetLastError());
     if (c->d_gid && !c->s1_from_files) {
@@ -1643,8 +1654,12 @@ int stage2_run(harc_amd_ctx *c)
     HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
     if (poff) HIP_TRY(hipMemcpyAsync(h_packed, packed, (size_t)poff, hipMemcpyDeviceToHost, c->copy_stream));
     if (want_digest) {
-        // the shard cuts of noise / noisepos / pos are positions inside ONE array each: the arrays as a whole, then the cuts themselves
-        RC_TRY(digest_range(c, noise, nmtot + F, 0x200, d_digest + 1)); RC_TRY(digest_range(c, noisepos, nmtot, 0x201, d_digest + 1)); RC_TRY(digest_range(c, posb, F, 0x202, d_digest + 1));
+        // noise / noisepos group by group (a group's buffers start on an 8-byte boundary), pos as a whole; then the shard cuts themselves
+        for (uint32_t e = e0; e < e1; e++) if (g_of[e] == e && g_noise[e]) {
+            uint32_t eb = e; while (eb < e1 && g_of[eb] == e) eb++;
+            RC_TRY(digest_range(c, g_noise[e], gtot[e] + (sh_f[eb] - sh_f[e]), 0x200 + 16 * e, d_digest + 1)); RC_TRY(digest_range(c, g_noisepos[e], gtot[e], 0x201 + 16 * e, d_digest + 1));
+        }
+        RC_TRY(digest_range(c, posb, F, 0x202, d_digest + 1));
         for (uint32_t e = e0; e < e1; e++) RC_TRY(digest_range(c, packed + rev_off[e], rev_nb[e] + rev_tl[e], 0x300 + e, d_digest + 2));
         RC_TRY(digest_range(c, spk, sing_nb + sing_tl, 0x3F0, d_digest + 2)); RC_TRY(digest_range(c, ntext, n_ntext, 0x3F1, d_digest + 2));
         RC_TRY(digest_range(c, order_out, n_order, 0x400, d_digest + 3)); RC_TRY(digest_range(c, orderN_out, n_orderN, 0x401, d_digest + 3));
@@ -1652,7 +1667,7 @@ int stage2_run(harc_amd_ctx *c)
         HIP_TRY(hipMemcpyAsync(h_dig, d_digest, 32, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (int k = 0; k < 4; k++) c->digest[k] = h_dig[k];
-        for (uint32_t e = e0; e <= e1; e++) { c->digest[1] += mix64(0x2F0ull + e + ((uint64_t)(sh_f[e] - fbase) << 20)) + mix64(0x2F8ull + e + (sh_nm[e] << 20)); c->digest[0] += mix64(0x1F0ull + e + ((sh_col[e] - col0) << 20)); }
+        for (uint32_t e = e0; e <= e1; e++) { c->digest[1] += mix64(0x2F0ull + e + ((uint64_t)(sh_f[e] - fbase) << 20)) + (e < e1 ? mix64(0x2F8ull + e + (s_np1[e] << 20)) : 0ull); c->digest[0] += mix64(0x1F0ull + e + ((sh_col[e] - col0) << 20)); }
         c->have_digest = true;
     }
     for (uint32_t e = 0; e < E; e++) {
@@ -1664,8 +1679,9 @@ int stage2_run(harc_amd_ctx *c)
         out_slice(c, HARC_AMD_S2_SEQ, e, h_seq + seq_off[e], seq_nb[e]); out_slice(c, HARC_AMD_S2_SEQ_TAIL, e, h_seq + seq_off[e] + seq_nb[e], seq_tl[e]);
         out_slice(c, HARC_AMD_S2_REV, e, h_packed + rev_off[e], rev_nb[e]); out_slice(c, HARC_AMD_S2_REV_TAIL, e, h_packed + rev_off[e] + rev_nb[e], rev_tl[e]);
         out_slice(c, HARC_AMD_S2_POS, e, h_pos + f0, f1 - f0);
-        out_slice(c, HARC_AMD_S2_NOISE, e, h_noise + sh_nm[e] + f0, (sh_nm[e + 1] + f1) - (sh_nm[e] + f0));
-        out_slice(c, HARC_AMD_S2_NOISEPOS, e, h_noisepos + sh_nm[e], sh_nm[e + 1] - sh_nm[e]);
+        const uint32_t g = g_of[e];
+        out_slice(c, HARC_AMD_S2_NOISE, e, gh_noise[g] ? gh_noise[g] + s_nz0[e] : h_meta, gh_noise[g] ? s_nz1[e] - s_nz0[e] : 0);
+        out_slice(c, HARC_AMD_S2_NOISEPOS, e, gh_noisepos[g] ? gh_noisepos[g] + s_np0[e] : h_meta, gh_noisepos[g] ? s_np1[e] - s_np0[e] : 0);
     }
     out_slice(c, HARC_AMD_S2_SINGLETON, 0, h_sing, sing_nb); out_slice(c, HARC_AMD_S2_SINGLETON_TAIL, 0, h_sing + sing_nb, sing_tl);
     c->d_s2_order = order_out; c->n_s2_order = n_order; c->d_s2_orderN = orderN_out; c->n_s2_orderN = n_orderN;
