@@ -45,7 +45,7 @@ struct ChainHdr {
     uint32_t n_main;    // records emitted to the main stream so far
     uint32_t n_sing;    // records emitted to the singleton stream so far
     uint32_t nsteps;    // byte0: steps walked in the last k_steps launch; byte1: steps to replay; byte2: look-ahead seeds consumed; byte3: look-ahead seeds held
-    uint32_t pad0;      // low 16 bits: 16 x running mean of the priority index of the chain's hits (width of the first probe batch); bits 16-23: look-ahead position reached by the last walk; bits 24, 25: the count matrices of parity 0 / 1 hold u32 counts (else u16: cons_store)
+    uint32_t pad0;      // low 16 bits: 16 x running mean of the priority index of the chain's hits (width of the first probe batch); bits 16-23: look-ahead position reached by the last walk; bits 24-25 / 26-27: the form of the count matrices of parity 0 / 1 (0 = u8, 1 = u16, 2 = u32 counts: cons_store)
 };
 #define CH_ACTIVE 1u
 #define CH_PREVUNM 2u

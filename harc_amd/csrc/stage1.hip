@@ -619,11 +619,12 @@ template <int W, bool I> __device__ __forceinline__ void cons_update(ConsState<W
     }
     st.base = nb;
 }
-// The count matrices of a chain go to HBM between super-rounds (two halves by parity: the rollback point and the state after the walk).  While
-// no count exceeds 65 535 -- always, outside collapsed repeats walked by a single chain -- a column is four u16 (8 bytes) instead of four u32:
-// 52 of the 105 MB a launch of 65 536 chains writes, and as much of what the next one reads.  `wide` (ChainHdr.pad0 bit 24 + parity) says which
-// form a half holds; the wide form is exact for any count, so nothing saturates.
-template <int W, bool I> __device__ __forceinline__ void cons_load(ConsState<W, I> &st, const uint4 *src, int L, int lane, bool wide)
+// The count matrices of a chain go to HBM between super-rounds (two halves by parity: the rollback point and the state after the walk).  A
+// column is four u8 (4 bytes) while no count of the chain exceeds 255 -- the rule on ordinary data: a count is the number of the chain's reads
+// over a column, i.e. about the coverage --, four u16 up to 65 535, four u32 beyond (collapsed repeats walked by a single chain): 26 instead of 105 MB
+// per launch of 65 536 chains written, and as much less read by the next one.  `fmt` (0 / 1 / 2: ChainHdr.pad0 bits 24-25 for parity 0, 26-27
+// for parity 1) says which form a half holds; the widest form is exact for any count, so nothing saturates.
+template <int W, bool I> __device__ __forceinline__ void cons_load(ConsState<W, I> &st, const uint4 *src, int L, int lane, uint32_t fmt)
 {
     st.base = 0;
 #pragma unroll
@@ -631,15 +632,16 @@ template <int W, bool I> __device__ __forceinline__ void cons_load(ConsState<W, 
         const int i = lane + 64 * t;
         uint4 q = make_uint4(0, 0, 0, 0); int v = 0;
         if (i < L) {
-            if (wide) q = src[i];
-            else { const uint2 p = reinterpret_cast<const uint2 *>(src)[i]; q = make_uint4(p.x & 0xFFFFu, p.x >> 16, p.y & 0xFFFFu, p.y >> 16); }
+            if (fmt == 2u) q = src[i];
+            else if (fmt == 1u) { const uint2 p = reinterpret_cast<const uint2 *>(src)[i]; q = make_uint4(p.x & 0xFFFFu, p.x >> 16, p.y & 0xFFFFu, p.y >> 16); }
+            else { const uint32_t p = reinterpret_cast<const uint32_t *>(src)[i]; q = make_uint4(p & 0xFFu, (p >> 8) & 0xFFu, (p >> 16) & 0xFFu, p >> 24); }
             v = argmax4(q);
         }
         st.setq(t, q); st.v[t] = v;
     }
 }
-// returns whether the wide form was written (wave-uniform)
-template <int W, bool I> __device__ __forceinline__ bool cons_store(const ConsState<W, I> &st, uint4 *dst, int L, int lane)
+// returns the form that was written (wave-uniform)
+template <int W, bool I> __device__ __forceinline__ uint32_t cons_store(const ConsState<W, I> &st, uint4 *dst, int L, int lane)
 {
     constexpr int LP = ConsState<W, I>::LP;
     uint32_t mx = 0;
@@ -648,16 +650,18 @@ template <int W, bool I> __device__ __forceinline__ bool cons_store(const ConsSt
         int l = lane + 64 * t - st.base; if (l < 0) l += LP;
         if (l < L) { const uint4 q = st.getq(t); const uint32_t a = q.x > q.y ? q.x : q.y, b = q.z > q.w ? q.z : q.w; const uint32_t m = a > b ? a : b; mx = m > mx ? m : mx; }
     }
-    const bool wide = __ballot(mx > 0xFFFFu) != 0;
+    const uint32_t fmt = __ballot(mx > 0xFFFFu) != 0 ? 2u : (__ballot(mx > 0xFFu) != 0 ? 1u : 0u);
 #pragma unroll
     for (int t = 0; t < ConsState<W, I>::CT; t++) {
         int l = lane + 64 * t - st.base; if (l < 0) l += LP;
         if (l < L) {
             const uint4 q = st.getq(t);
-            if (wide) dst[l] = q; else reinterpret_cast<uint2 *>(dst)[l] = make_uint2(q.x | (q.y << 16), q.z | (q.w << 16));
+            if (fmt == 2u) dst[l] = q;
+            else if (fmt == 1u) reinterpret_cast<uint2 *>(dst)[l] = make_uint2(q.x | (q.y << 16), q.z | (q.w << 16));
+            else reinterpret_cast<uint32_t *>(dst)[l] = q.x | (q.y << 8) | (q.z << 16) | (q.w << 24);
         }
     }
-    return wide;
+    return fmt;
 }
 // consensus -> packed 2-bit words in column order: ballot the two code bits per ring slot, then rotate the ring by `base`
 template <int W, bool I> __device__ __forceinline__ void cons_pack(const ConsState<W, I> &st, int L, int lane, uint64_t (&ref)[W])
@@ -1184,7 +1188,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     st.ql = reinterpret_cast<uint4 *>(lds) + (size_t)wv * ConsState<W, DENSE>::LP + lane;
     const int T0 = COOP ? (int)(h.nsteps & 0xFF) : 0;           // COOP: the one step the main kernel stopped in front of
     if (COOP) {
-        cons_load(st, T0 > 0 ? B1 : B0, L, lane, ((h.pad0 >> (24 + (T0 > 0 ? (par ^ 1u) : par))) & 1u) != 0);
+        cons_load(st, T0 > 0 ? B1 : B0, L, lane, (h.pad0 >> (24 + 2 * (T0 > 0 ? (par ^ 1u) : par))) & 3u);
         if (lane < T0) ownreg = s.steps[(size_t)c * 64 + lane].x;
     } else if (h.mode == 2) {                                    // fresh seed (reorder.cpp:875-883)
         uint64_t rw[W];
@@ -1192,7 +1196,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         for (int w = 0; w < W; w++) rw[w] = s.reads[(size_t)h.cur * W + w];
         cons_reset(st, rw, L, lane);
     } else {
-        cons_load(st, B0, L, lane, ((h.pad0 >> (24 + par)) & 1u) != 0);
+        cons_load(st, B0, L, lane, (h.pad0 >> (24 + 2 * par)) & 3u);
         if (h.mode == 1) {                                       // rolled back last time: replay the steps that were kept
             const int nrep = (int)((h.nsteps >> 8) & 0xFF);
             uint2 sp = make_uint2(0, 0);
@@ -1214,8 +1218,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             }
         }
     }
-    uint32_t widebits = (h.pad0 >> 24) & 3u;                     // which halves of the chain's count matrices hold u32 counts (cons_store)
-    if (!COOP && h.mode != 0) { const bool w0 = cons_store(st, B0, L, lane); widebits = (widebits & ~(1u << par)) | ((w0 ? 1u : 0u) << par); }    // B0 now holds the rollback point of this super-round
+    uint32_t widebits = (h.pad0 >> 24) & 15u;                    // the form of the two halves of the chain's count matrices (cons_store), two bits each
+    if (!COOP && h.mode != 0) { const uint32_t w0 = cons_store(st, B0, L, lane); widebits = (widebits & ~(3u << (2 * par))) | (w0 << (2 * par)); }    // B0 now holds the rollback point of this super-round
 
     uint32_t *const rowF = s_rows + (size_t)wv * 2 * ROW, *const rowR = rowF + ROW, *const rdl = s_rdl + (size_t)wv * MROW;
     uint8_t *const coltmp = reinterpret_cast<uint8_t *>(s_tmp + (size_t)wv * 8 * NW);
@@ -1566,7 +1570,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     if (pend) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); cons_flush(st, pshift, pend, ptot, rowF, L, lane); pend = 0; ptot = 0; }
     PH(4);
     if (COOP) { if (lane == 0) cmd->op = 0; __syncthreads(); }      // the walk is over: the helpers leave
-    if (nst > 0) { const bool w1 = cons_store(st, B1, L, lane); widebits = (widebits & ~(1u << (par ^ 1u))) | ((w1 ? 1u : 0u) << (par ^ 1u)); }
+    if (nst > 0) { const uint32_t w1 = cons_store(st, B1, L, lane); widebits = (widebits & ~(3u << (2 * (par ^ 1u)))) | (w1 << (2 * (par ^ 1u))); }
     np = wave_sum_u32(np); nc = wave_sum_u32(nc); ncu = wave_sum_u32(ncu);
     PH(5);
 #undef PH

@@ -1611,7 +1611,7 @@ int stage2_run(harc_amd_ctx *c)
         if (gnm + gF) HIP_TRY(hipMemcpyAsync(gh_noise[ea], g_noise[ea], (size_t)gnm + gF, hipMemcpyDeviceToHost, c->copy_stream));
         if (gnm) HIP_TRY(hipMemcpyAsync(gh_noisepos[ea], g_noisepos[ea], (size_t)gnm, hipMemcpyDeviceToHost, c->copy_stream));
         HIP_TRY(hipMemcpyAsync(h_pos + fa, posb + fa, (size_t)gF, hipMemcpyDeviceToHost, c->copy_stream));
-        nmtot += gnm; n_nonN += gnon; n_N_aligned += gF - gnon;
+        nmtot += gnm; n_nonN += gnon; n_N_aligned += gF - gnon;     // (nmtot: the trace's total)
         gtot[ea] = gnm;
         for (uint32_t e = ea; e < eb; e++) {
             const uint64_t n0 = sh_nm[e], n1 = e + 1 < eb ? sh_nm[e + 1] : gnm;
@@ -1689,6 +1689,7 @@ int stage2_run(harc_amd_ctx *c)
     { const int ml = snprintf((char *)h_meta, 32, "%d\n", L); out_slice(c, HARC_AMD_S2_META, 0, h_meta, (size_t)ml); }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));                // read_seq has arrived
+    if (trace2) fprintf(stderr, "[stage II] %llu noise entries, %u reads in this rank's piece\n", (unsigned long long)nmtot, F);
     lap("merge, noise / pos / rev / order streams, leftovers, device -> host (this rank's shards)");
     c->C.bins_over_maxsearch = big;
     // encoder.cpp:506-508; partitioned: this rank's share of the candidates (the merge adds the ranks up)
