@@ -52,3 +52,41 @@ def test_launch_timeout_kills_the_group():
 def test_world_size_mismatch_is_refused():
     p, _ = run(["--gpus", "2", "--launch-only"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_sigterm_on_the_launcher_ends_the_ranks():
+    """a harness that gives up on `python bench.py --gpus N` sends SIGTERM to the launcher: the ranks sit in sessions of their own and must not
+    outlive it"""
+    import signal
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-only", "--hang-rank", "0", "--watchdog", "1000", "--launch-timeout", "600"],
+                         env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    def descendants(pid):
+        kids = {}
+        for d in os.listdir("/proc"):
+            if d.isdigit():
+                try:
+                    with open("/proc/%s/stat" % d) as f:
+                        kids.setdefault(int(f.read().rsplit(")", 1)[1].split()[1]), []).append(int(d))
+                except (OSError, ValueError, IndexError):
+                    pass
+        out, todo = [], [pid]
+        while todo:
+            for k in kids.get(todo.pop(), []):
+                out.append(k); todo.append(k)
+        return out
+    deadline = time.time() + 120
+    tree = []
+    while time.time() < deadline:                                    # until the launcher's child and its two ranks exist
+        tree = descendants(p.pid)
+        if len(tree) >= 3:
+            break
+        time.sleep(0.5)
+    assert len(tree) >= 3, tree
+    time.sleep(3)
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=120)
+    assert rc == 128 + signal.SIGTERM, rc
+    time.sleep(1)
+    alive = [k for k in tree if os.path.exists("/proc/%d" % k) and open("/proc/%d/stat" % k).read().rsplit(")", 1)[1].split()[0] != "Z"]
+    assert not alive, alive

@@ -151,3 +151,15 @@ def test_stage3_starts_while_the_stage_program_still_writes(tmp_path):
     env["STUB_FAIL"] = "1"
     r = _run(["-c", str(fq), "-t", "3"], env)
     assert r.returncode != 0 and not (tmp_path / "s.harc").exists() and not (tmp_path / "output").exists()
+
+
+def test_mistyped_multi_gpu_mode_is_refused_before_any_rank_starts(tmp_path):
+    """HARC_AMD_MG_MODE is 'bucket' or 'replicate': anything else (a typo would silently give the archive with the larger consensus) ends the run with
+    a message, before a rank is started and with the output directory gone"""
+    fq, env = _setup(tmp_path)
+    marker = tmp_path / "stage_was_started"
+    (tmp_path / "stage_stub.sh").write_text("#!/bin/bash\ntouch %s\nexit 1\n" % marker)
+    env["HARC_AMD_MG_MODE"] = "replicated"
+    r = _run(["-c", str(fq), "-g", "2"], env)
+    assert r.returncode != 0 and "HARC_AMD_MG_MODE" in r.stdout, r.stdout[-1000:]
+    assert not marker.exists() and not (tmp_path / "output").exists() and not (tmp_path / "s.harc").exists()
