@@ -61,9 +61,12 @@ struct S1Args {
     int weedmin;                     // wave-uniform scan: single-read bins a batch must find before their claim bits are looked up ahead of the tests (HARC_AMD_WEEDMIN)
     int lazy;                        // 1: steps that agree with the consensus everywhere take the rows from their read and leave the counts to cons_flush (HARC_AMD_LAZY=0: every step applies its counts; same bytes)
     uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups, w sequential-equivalent candidates
+    const uint2 *succ;               // runs with one chain or a few (k_succ): per (read, orientation) the first HARC_SUCC_N candidates of the step whose consensus IS that read; null = none
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
 };
 #define PG_CHUNK 8u
+#define HARC_SUCC_N 8              // entries of a successor list: one 64-byte line per (read, orientation)
+#define HARC_SUCC_OPEN 0x80000000u // in every entry's y: the list stops before the probes of the step do (a large bin, or more candidates than entries)
 #ifndef HARC_SEQ_EXTRA_WAVES
 #define HARC_SEQ_EXTRA_WAVES 3     // waves per SIMD of the dense wave-uniform kernel above the base of 5: 8 (64 vector, 80 scalar registers)
 #endif
@@ -1072,6 +1075,127 @@ template <int W> __global__ void k_steps_tables(S1Args s, uint32_t *out)
     }
 }
 
+// ---- Exact mode (ONE chain: the reference at -t 1, byte for byte) and runs with a handful of chains leave the chip idle while a single wave
+//      chases its chain read by read, ~700 dependent instructions, ~30 LDS round trips and three trips to memory per step.  Nearly all of that
+//      answers a question that does not depend on the walk: a step that agreed with the consensus on every column of the overlap (Hamming
+//      distance 0: every step on error-free reads, most of them at a fraction of a percent of errors) leaves a consensus that IS the read just
+//      taken, in the orientation it was taken in (rows_from_read) -- so which reads the NEXT step may take, in the reference's priority order
+//      (reorder.cpp:517-649: shift by shift, dictionary by dictionary, every bin from its highest id down, Hamming distance <= thresh), is a
+//      function of (read, orientation) and of nothing else.  k_succ asks it for every read and both orientations at once, with the same probe
+//      table, bitmaps, tables and mask rows as k_steps: one wave per (read, orientation), HARC_SUCC_N entries {read, shift | dir << 8 |
+//      distance << 9 | probe << 16}.  What the walk then has to add is what does depend on it -- the first entry that is neither claimed nor
+//      taken by the chain in the running super-round: one line of 64 bytes, the claim words, no key, no table, no read (k_steps' FASTP).  A list
+//      that stops early (HARC_SUCC_OPEN: a bin of more than HARC_LARGEBIN reads among the probes -- their scan order is the walk's business --,
+//      or more candidates than entries) sends the walk back to the probes when all its entries are taken.
+template <int W> __global__ __launch_bounds__(256) void k_succ(S1Args s, uint2 *succ, uint32_t n)
+{
+    constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int nm = 2 * s.maxmatch * MROW;
+    uint32_t *const s_mask = lds;
+    uint2 *const s_pinfo = reinterpret_cast<uint2 *>(s_mask + nm);
+    uint32_t *const s_rows = reinterpret_cast<uint32_t *>(s_pinfo + s.nprobe);
+    uint32_t *const s_rdl = s_rows + 4 * 2 * ROW;
+    uint2 *const s_out = reinterpret_cast<uint2 *>(s_rdl + 4 * MROW);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < nm; i += 256) s_mask[i] = s.lds_tab[i];
+    { const uint2 *const pt = reinterpret_cast<const uint2 *>(s.lds_tab + nm); for (int i = threadIdx.x; i < s.nprobe; i += 256) s_pinfo[i] = pt[i]; }
+    for (int i = threadIdx.x; i < 4 * 2 * ROW; i += 256) s_rows[i] = 0u;
+    __syncthreads();
+    const uint64_t g = (uint64_t)blockIdx.x * 4 + wv;
+    if (g >= 2ull * n) return;
+    const uint32_t r = (uint32_t)(g >> 1); const int o = (int)(g & 1);
+    const int L = s.L;
+    uint32_t *const rowF = s_rows + (size_t)wv * 2 * ROW, *const rowR = rowF + ROW, *const rdl = s_rdl + (size_t)wv * MROW;
+    uint2 *const out = s_out + (size_t)wv * HARC_SUCC_N;
+    if (lane < NW) rdl[lane] = reinterpret_cast<const uint32_t *>(s.reads)[(size_t)r * NW + lane];
+    if (lane < HARC_SUCC_N) out[lane] = make_uint2(HARC_NONE, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    rows_from_read<W>(rdl, L, o, lane, rowF, rowR);
+    const uint64_t kmask0 = s.kbits[0] >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << s.kbits[0]) - 1), kmask1 = s.kbits[1] >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << s.kbits[1]) - 1);
+    const uint64_t cap = s.cap[0];
+    uint32_t total = 0; bool open = false;
+    for (int base = 0; base < s.nprobe && total < HARC_SUCC_N && !open; base += 64) {
+        const int p = base + lane;
+        int state = 0, j = 0, dir = 0, l = 0; uint32_t sst = 0, cw = 0; uint2 pi = make_uint2(0, 0);
+        if (p < s.nprobe && cap) {
+            pi = s_pinfo[p];
+            j = (int)(pi.x >> 16); dir = (int)((pi.x >> 13) & 1); l = (int)((pi.x >> 14) & 1);
+            uint64_t key;
+            {
+                const int i0 = (int)((pi.x & 0x1FFF) >> 5), shb = (int)(pi.x & 31);
+                const uint32_t d0 = rowF[i0], d1 = rowF[i0 + 1], d2 = rowF[i0 + 2];
+                key = ((uint64_t)__builtin_amdgcn_alignbit(d1, d0, shb) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, shb) << 32)) & (l ? kmask1 : kmask0);
+            }
+            const HashSlot *const tab = l ? s.slots[1] : s.slots[0];
+            const uint64_t hk = key_scramble(key);
+            uint64_t sl = bucket_slot(hk, cap);
+            if (s.bloom_lines) {
+                uint32_t bw, bm;
+                bloom_pos(key, hk, s.bloom_lines, s.bloom_nwin[0], s.bloom_mmask, &bw, &bm);
+                if (((l ? s.bloom[1] : s.bloom[0])[bw] & bm) != bm) state = 1;
+            }
+            while (state == 0) {                                       // the bucketed search of k_steps: a full bucket ends it unless its overflow flag is set
+                uint32_t w0 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint4 raw = *reinterpret_cast<const uint4 *>(&tab[sl + q]);
+                    if (q == 0) w0 = raw.w;
+                    if (state == 0) {
+                        if (raw.w == 0) state = 1;
+                        else if (raw.x == (uint32_t)hk && raw.y == (uint32_t)(hk >> 32)) { state = 2; sst = raw.z; cw = raw.w; }
+                    }
+                }
+                if (state == 0 && !(w0 & SLOT_OVF)) state = 1;
+                sl += 4; if (sl >= cap) sl = 0;
+            }
+        }
+        const bool big = state == 2 && (cw & SLOT_BIG) != 0;
+        const unsigned long long mb = __ballot(big);
+        const int firstbig = mb ? __ffsll((long long)mb) - 1 : 64;
+        // the candidates of this lane's bin, from the highest id down; the list wants them in (probe, position in the bin) order: count, then place
+        const bool scan = state == 2 && !big && lane < firstbig;
+        const uint32_t cntb = cw & SLOT_CNT_MASK; const bool emb = (cw & SLOT_EMB) != 0;
+        const uint32_t *const ids = l ? s.ids[1] : s.ids[0];
+        const uint32_t *const mrow = s_mask + (pi.y >> 16);
+        const int bitoff = (int)(pi.y & 0xFFFF);
+        uint32_t cnt = 0;
+        if (scan) for (uint32_t i = cntb; i > 0; i--) {
+            const uint32_t rid = emb ? sst : ids[sst + i - 1];
+            if (rid == r) continue;                                    // the read itself: taken by the walk that asks
+            uint32_t mrd[NW];
+            load_read32<W>(s.reads, rid, mrd);
+            if (ham_window<W>(rowF, bitoff, mrow, mrd) <= s.thresh) cnt++;
+        }
+        uint32_t incl = cnt;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += y; }
+        const uint32_t off = total + incl - cnt;
+        if (scan && cnt && off < HARC_SUCC_N) {
+            uint32_t k = 0;
+            for (uint32_t i = cntb; i > 0; i--) {
+                const uint32_t rid = emb ? sst : ids[sst + i - 1];
+                if (rid == r) continue;
+                uint32_t mrd[NW];
+                load_read32<W>(s.reads, rid, mrd);
+                const int hd = ham_window<W>(rowF, bitoff, mrow, mrd);
+                if (hd <= s.thresh) { if (off + k < HARC_SUCC_N) out[off + k] = make_uint2(rid, (uint32_t)j | ((uint32_t)dir << 8) | ((uint32_t)hd << 9) | ((uint32_t)p << 16)); k++; }
+            }
+        }
+        total += (uint32_t)__shfl((int)incl, 63, 64);
+        if (firstbig < 64) open = true;
+    }
+    if (total >= HARC_SUCC_N) open = true;                             // there may be more
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < HARC_SUCC_N) { uint2 e = out[lane]; if (open) e.y |= HARC_SUCC_OPEN; succ[g * HARC_SUCC_N + lane] = e; }
+}
+static inline size_t succ_lds_bytes(int W, int maxmatch, int nprobe)
+{
+    const int NW = 2 * W, ROW = 3 * NW + 1, MROW = (NW + 3) & ~3;
+    return ((size_t)2 * maxmatch * MROW + (size_t)2 * nprobe + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * HARC_SUCC_N * 2) * 4 + 16;
+}
+
 // NWV (COOP only): waves per workgroup = the walking wave + NWV - 1 helpers that share its scans (64 NWV candidates per round trip).  Few
 // walks per super-round are bound by the longest one: 4 waves.  More walks than the chip holds workgroups are bound by wave slots, most of
 // which helpers idle in: fewer helpers, more walkers (stage1_run_w picks it from the walks of the last rounds; what is computed is the same).
@@ -1240,11 +1364,46 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     // (compiled into the wave-uniform kernels only: there the run of agreeing steps is the rule -- dense launches over error-free or nearly error-free
     // reads -- and the code fits; in the other kernels the second path cost registers: the 150-bp dense kernel lost 3.7 % to it)
     const bool lazy = (SEQ || (QUAD && !COOP)) && s.lazy != 0;
+    // FASTP (the kernel of runs with few chains; k_succ): while the consensus IS a read -- `lastrid`, taken in orientation `lastdir`: after a fresh
+    // seed and after every step with Hamming distance 0 -- the step reads its candidates from that read's successor list instead of asking the
+    // tables.  Such a step does not even fetch the read it takes: the window rows are made from it only when something asks for them
+    // (rows_lazy: a step that has to go back to the probes, a step that disagrees with the consensus somewhere, the end of the launch).
+    constexpr bool FASTP = QUAD && !COOP;
+    uint32_t lastrid = HARC_NONE; int lastdir = 0; bool rows_lazy = false;
+    if (FASTP && s.succ && h.mode == 2) lastrid = h.cur;
+    auto rows_materialise = [&]() {
+        if (lane < NW) rdl[lane] = reinterpret_cast<const uint32_t *>(s.reads)[(size_t)lastrid * NW + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        rows_from_read<W>(rdl, L, lastdir, lane, rowF, rowR);
+        rows_ok = true; rows_lazy = false;
+    };
     PH(0);
     for (int t = T0; t < s.S; t++) {
-        if (!rows_ok) cons_rows(st, L, lane, coltmp, rowF, rowR);   // consensus and its reverse complement -> the wave's window rows
-        PH(1);
         uint32_t found = HARC_NONE; int fj = 0, fdir = 0, fhd = -1;   // fhd: Hamming distance of the accepted read where the scan that found it knows it
+        bool viafast = false, nohit = false;
+        if constexpr (FASTP) {
+            if (s.succ && lastrid != HARC_NONE && !(t == 0 && resume > 0)) {
+                uint2 e = make_uint2(HARC_NONE, 0u);
+                if (lane < HARC_SUCC_N) e = s.succ[((size_t)lastrid * 2 + (size_t)lastdir) * HARC_SUCC_N + lane];
+                bool ok = false;
+                if (e.x != HARC_NONE) ok = !((s.claimed[e.x >> 6] >> (e.x & 63)) & 1ULL) && !own_has(ownt, e.x);
+                const unsigned long long m = __ballot(ok);
+                if (m) {
+                    const int f = __ffsll((long long)m) - 1;
+                    found = (uint32_t)__builtin_amdgcn_readlane((int)e.x, f);
+                    const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)e.y, f);
+                    fj = (int)(meta & 0xFFu); fdir = (int)((meta >> 8) & 1u); fhd = (int)((meta >> 9) & 0x7Fu);
+                    const int pp = (int)((meta >> 16) & 0xFFFu);
+                    nuse += (uint32_t)(pp + 1); lastp += 4 * pp - (lastp >> 2);
+                    if (lane == 0) { nc++; ncu++; }
+                    viafast = true;
+                } else if (!((uint32_t)__builtin_amdgcn_readlane((int)e.y, 0) & HARC_SUCC_OPEN)) nohit = true;     // the whole list is taken and nothing lies behind it
+            }
+        }
+        if (!viafast && !nohit) {
+        if (!rows_ok) { if (FASTP && rows_lazy) rows_materialise(); else cons_rows(st, L, lane, coltmp, rowF, rowR); }   // consensus and its reverse complement -> the wave's window rows
+        PH(1);
         // Probes are issued in priority order in batches: every probe behind the first hit of a batch is speculative traffic,
         // every extra batch is a serial round trip to HBM.
         int base = (t == 0 && resume > 0) ? resume : 0;          // the probes before `resume` were made in an earlier super-round: nothing then, nothing now
@@ -1511,6 +1670,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             }
             base = bend;
         }
+        }
         if (defer || stalled) break;
         if (found == HARC_NONE) {
             // no candidate: go on from the chain's look-ahead seeds (highest id first, skipping what was claimed meanwhile) -- the new
@@ -1541,6 +1701,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             __builtin_amdgcn_wave_barrier();
             cons_reset_lds(st, rdl, L, lane);                      // every count is replaced: what was pending is gone with the old consensus
             rows_ok = false; pend = 0; ptot = 0;
+            if (FASTP && s.succ) { lastrid = sid; lastdir = 0; rows_lazy = false; }
             nst++;
             if (COOP && bigprobes >= s.budget) break;
             continue;
@@ -1553,21 +1714,38 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         if constexpr (OWNT) { if (lane == 0) own_insert(ownt, found); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lazy && fhd == 0) {                                    // the read agrees with the consensus on the whole overlap: the new consensus is the read
-            rows_from_read<W>(rdl, L, fdir, lane, rowF, rowR);
+        if (FASTP && viafast && fhd == 0) {                        // (k_succ) ... and nobody has asked for its rows yet
             ptot += fj;
             if (lane == 0) pshift[pend] = (uint16_t)ptot;
-            pend++; rows_ok = true;
+            pend++; rows_ok = false; rows_lazy = true; lastrid = found; lastdir = fdir;
         } else {
-            if (pend) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); cons_flush(st, pshift, pend, ptot, rowF, L, lane); pend = 0; ptot = 0; }
-            cons_update_lds(st, rdl, L, fdir, fj, lane);
-            rows_ok = false;
+            if (FASTP && viafast) {                                // the list's read disagrees with the consensus somewhere: the counts want the rows of the consensus and the read's words after all
+                if (pend && !rows_ok) rows_materialise();
+                if (lane < NW) rdl[lane] = reinterpret_cast<const uint32_t *>(s.reads)[(size_t)found * NW + lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lazy && fhd == 0) {                                // the read agrees with the consensus on the whole overlap: the new consensus is the read
+                rows_from_read<W>(rdl, L, fdir, lane, rowF, rowR);
+                ptot += fj;
+                if (lane == 0) pshift[pend] = (uint16_t)ptot;
+                pend++; rows_ok = true;
+                if (FASTP && s.succ) { lastrid = found; lastdir = fdir; rows_lazy = false; }
+            } else {
+                if (pend) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); cons_flush(st, pshift, pend, ptot, rowF, L, lane); pend = 0; ptot = 0; }
+                cons_update_lds(st, rdl, L, fdir, fj, lane);
+                rows_ok = false;
+                if (FASTP) { lastrid = HARC_NONE; rows_lazy = false; }
+            }
         }
         nst++;
         PH(4);
         if (COOP && bigprobes >= s.budget) break;
     }
-    if (pend) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); cons_flush(st, pshift, pend, ptot, rowF, L, lane); pend = 0; ptot = 0; }
+    if (pend) {
+        if (FASTP && rows_lazy) rows_materialise();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); cons_flush(st, pshift, pend, ptot, rowF, L, lane); pend = 0; ptot = 0;
+    }
     PH(4);
     if (COOP) { if (lane == 0) cmd->op = 0; __syncthreads(); }      // the walk is over: the helpers leave
     if (nst > 0) { const uint32_t w1 = cons_store(st, B1, L, lane); widebits = (widebits & ~(3u << (2 * (par ^ 1u)))) | (w1 << (2 * (par ^ 1u))); }
@@ -2532,6 +2710,24 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     a.lazy = getenv("HARC_AMD_LAZY") ? (atoi(getenv("HARC_AMD_LAZY")) != 0 ? 1 : 0) : 1;
     a.firstmax = (bloom_nwin[0] > 0 && bloom_nwin[1] > 0) ? 64 : 48;     // lines by minimizer: speculative probes share their lines
     if (const char *e = getenv("HARC_AMD_FIRSTMAX")) { const int x = atoi(e); a.firstmax = x < 1 ? 1 : x > 64 ? 64 : x; }
+    // successor lists (k_succ): by default where the walk is ONE wave (exact mode, num_chains = 1) -- there the precomputation, twice the lookups of a
+    // whole run, is done by a chip that has nothing else to do.  HARC_AMD_SUCC=1 asks for them with any number of chains of the few-chains kernel
+    // (tests: the same bytes), =0 never.  They need the lazy counts (a step by list does not fetch its read), every small bin scanned to its end
+    // (maxsearch above HARC_LARGEBIN) and 128 bytes per read.
+    {
+        bool want = getenv("HARC_AMD_SUCC") ? atoi(getenv("HARC_AMD_SUCC")) != 0 : K == 1;
+        const size_t sbytes = (size_t)N * 2 * HARC_SUCC_N * sizeof(uint2);
+        size_t fr = 0, tot = 0;
+        if (want) HIP_TRY(hipMemGetInfo(&fr, &tot));
+        if (want && N && quad && !cm && a.lazy && P.maxsearch >= (int)HARC_LARGEBIN && P.thresh <= 127 && a.nprobe <= 4095 && P.maxmatch <= 255 && sbytes < tot / 8) {
+            uint2 *sp = nullptr;
+            RC_TRY(dalloc(c, &sp, (size_t)N * 2 * HARC_SUCC_N));
+            hipLaunchKernelGGL((k_succ<W>), dim3((unsigned)(((uint64_t)N * 2 + 3) / 4)), dim3(256), succ_lds_bytes(W, P.maxmatch, a.nprobe), c->stream, a, sp, N);
+            HIP_TRY(hipGetLastError());
+            a.succ = sp;
+            if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] successor lists of %u reads x 2 orientations (%.1f MB)\n", N, (double)sbytes / 1e6);
+        }
+    }
     HIP_TRY(hipMemsetAsync(a.claimed, 0, nwords * 8, c->stream));
     HIP_TRY(hipMemsetAsync(a.bid, 0xFF, ((size_t)N + 1) * 4, c->stream));
     HIP_TRY(hipMemsetAsync(a.slog, 0xFF, ((size_t)N + 1) * sizeof(uint2), c->stream));

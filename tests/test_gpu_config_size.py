@@ -72,9 +72,12 @@ def test_config_size_matches_oracle(name, n, L, G, err, E, expect_lowcov, env, o
 
 
 @pytest.mark.parametrize("it", range(24))
-def test_parity_fuzz_bounded(it, oracle, tmp_path):
-    """24 iterations of tools/fuzz_parity.py (seed 7): random repeat-rich inputs, random (L, K, S, E), every file against the oracle"""
+def test_parity_fuzz_bounded(it, oracle, tmp_path, monkeypatch):
+    """24 iterations of tools/fuzz_parity.py (seed 7): random repeat-rich inputs, random (L, K, S, E), every file against the oracle; every other
+    iteration with the steps by successor list (k_succ) whatever the number of chains"""
     import harc_amd
+    if it % 2:
+        monkeypatch.setenv("HARC_AMD_SUCC", "1")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_parity as fz
     rs = np.random.RandomState(7000 + it)

@@ -32,9 +32,13 @@ def assert_same(got, want, files, what):
     assert not errs, what + "\n" + "\n".join(errs)
 
 
+@pytest.mark.parametrize("succ", [None, "0"])
 @pytest.mark.parametrize("case", CASES)
-def test_stage1_K1_matches_reference(case, tmp_path):
+def test_stage1_K1_matches_reference(case, succ, tmp_path, monkeypatch):
+    """exact mode: by default through the successor lists (k_succ), and without them (HARC_AMD_SUCC=0)"""
     import harc_amd
+    if succ is not None:
+        monkeypatch.setenv("HARC_AMD_SUCC", succ)
     g = ol.load_golden(case)
     base = ol.stage_dir(tmp_path, {k: g["stage1/" + k] for k in ["input_clean.dna", "numreads.bin"]})
     harc_amd.reorder(base, _L(g), num_chains=1)
@@ -215,6 +219,7 @@ def test_low_complexity_big_bins_match_oracle(n, glen, K, S, E, err, oracle, tmp
                                  {"HARC_AMD_RESEED_MG": "1", "HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1"},
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1"}, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "0"},
                                  {"HARC_AMD_LAZY": "0"}, {"HARC_AMD_LAZY": "0", "HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1"},
+                                 {"HARC_AMD_SUCC": "1"}, {"HARC_AMD_SUCC": "1", "HARC_AMD_S1BLOOM": "0"}, {"HARC_AMD_SUCC": "1", "HARC_AMD_S1BLOOM_MZMB": "0"},      # steps by successor list (k_succ), with chains that lose bids and are rolled back
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0"},      # the specialised dense kernel (k_steps' SPEC) ...
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_SPEC": "0"},      # ... and the general one under the same conditions
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_LAZY": "0"},
