@@ -42,6 +42,7 @@ struct S1Args {
     uint32_t *sugg;                  // [K][HARC_NSUGG] look-ahead seeds of every chain, highest id first
     int S;                           // speculative steps per super-round (1..64)
     int nsugg_per_seed;              // look-ahead seeds per reseed (HARC_NSUGG; 0 disables them: experiments only, the oracle uses the same value)
+    int nsugg_stride;                // entries per chain in sugg[] and per seed in seedbuf[] (>= nsugg_per_seed)
     uint2 *slog;                     // [N] indexed by read id: {chain, index in the chain's singleton stream} of the reads that end as singletons (0xFF..: not one)
     // the main stream of a chain, in PAGES of 64 records {read id, pos | flag<<8 | rc<<9}: k_resolve appends the records a chain keeps in a super-round
     // side by side (up to 2 S records, one or two lines) instead of one 16-byte record per read at log[read id]; pages come from one counter, and
@@ -1295,7 +1296,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             h.cur = id; h.prev = id; h.flags = ((h.flags | CH_PREVUNM) & ~CH_NEEDSEED) & 0xFFFFu; h.mode = 2;
             const uint32_t first = r * (uint32_t)s.nsugg_per_seed;
             const uint32_t ng = first >= got ? 0u : (got - first < (uint32_t)s.nsugg_per_seed ? got - first : (uint32_t)s.nsugg_per_seed);
-            if ((uint32_t)lane < ng) s.sugg[(size_t)c * HARC_NSUGG + lane] = s.seedbuf[R + first + lane];
+            if ((uint32_t)lane < ng) s.sugg[(size_t)c * s.nsugg_stride + lane] = s.seedbuf[R + first + lane];
             h.nsteps = ng << 24;                                  // nothing walked, nothing to replay, look-ahead position 0
             if (lane == 0) { uint2 q = s.cst2[c]; q.x++; s.cst2[c] = q; s.need[c] = 0; }
         } else {                                                  // no reads left (reorder.cpp:670-677)
@@ -1370,6 +1371,22 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     // (rows_lazy: a step that has to go back to the probes, a step that disagrees with the consensus somewhere, the end of the launch).
     constexpr bool FASTP = QUAD && !COOP;
     uint32_t lastrid = HARC_NONE; int lastdir = 0; bool rows_lazy = false;
+    // ... and one trip to memory per step instead of two: together with the claim words of the list's entries the step asks for the lists of ALL of them
+    // (64 lanes, eight lines); the one of the entry that wins is the next step's list (enext)
+    uint2 enext = make_uint2(HARC_NONE, 0u); bool have_next = false;
+    // with the lists the reads a walk has taken reach the LDS table only when something asks the table (the probes' bin scans, the look-ahead seeds):
+    // a step by list compares its candidate with the wave's register copy (lane t: the read of step t) -- no LDS round trip in such a step
+    const bool ownlate = FASTP && s.succ != nullptr;
+    int own_ins = T0;                                             // steps [T0, own_ins) of this launch are in the table
+    auto own_sync = [&](int upto) {
+        if (lane >= own_ins && lane < upto) {
+            uint32_t hh = (ownreg * 0x9E3779B1u) >> 25;
+            while (atomicCAS(&ownt[hh], HARC_NONE, ownreg) != HARC_NONE) hh = (hh + 1u) & (HARC_OWN_SLOTS - 1u);
+        }
+        own_ins = upto;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     if (FASTP && s.succ && h.mode == 2) lastrid = h.cur;
     auto rows_materialise = [&]() {
         if (lane < NW) rdl[lane] = reinterpret_cast<const uint32_t *>(s.reads)[(size_t)lastrid * NW + lane];
@@ -1385,23 +1402,37 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         if constexpr (FASTP) {
             if (s.succ && lastrid != HARC_NONE && !(t == 0 && resume > 0)) {
                 uint2 e = make_uint2(HARC_NONE, 0u);
-                if (lane < HARC_SUCC_N) e = s.succ[((size_t)lastrid * 2 + (size_t)lastdir) * HARC_SUCC_N + lane];
+                if (have_next) e = enext;
+                else if (lane < HARC_SUCC_N) e = s.succ[((size_t)lastrid * 2 + (size_t)lastdir) * HARC_SUCC_N + lane];
+                have_next = false;
+                static_assert(HARC_SUCC_N == 8, "lane >> 3 = entry, lane & 7 = entry of its list");
+                const uint32_t ck = (uint32_t)__shfl((int)e.x, lane >> 3, 64), cy = (uint32_t)__shfl((int)e.y, lane >> 3, 64);
+                uint2 e2 = make_uint2(HARC_NONE, 0u);
+                if (ck != HARC_NONE) e2 = s.succ[((size_t)ck * 2 + (size_t)((cy >> 8) & 1u)) * HARC_SUCC_N + (lane & 7)];
                 bool ok = false;
-                if (e.x != HARC_NONE) ok = !((s.claimed[e.x >> 6] >> (e.x & 63)) & 1ULL) && !own_has(ownt, e.x);
-                const unsigned long long m = __ballot(ok);
+                if (e.x != HARC_NONE) ok = !((s.claimed[e.x >> 6] >> (e.x & 63)) & 1ULL);
+                unsigned long long m = __ballot(ok);
+                while (m) {                                            // ... and not taken by this walk since the bitmap was frozen (nearly always the first one is not)
+                    const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)e.x, __ffsll((long long)m) - 1);
+                    if (!__ballot(ownreg == x)) break;
+                    m &= m - 1ULL;
+                }
                 if (m) {
                     const int f = __ffsll((long long)m) - 1;
+                    enext.x = (uint32_t)__shfl((int)e2.x, 8 * f + (lane & 7), 64); enext.y = (uint32_t)__shfl((int)e2.y, 8 * f + (lane & 7), 64);
+                    if (lane >= HARC_SUCC_N) enext = make_uint2(HARC_NONE, 0u);
                     found = (uint32_t)__builtin_amdgcn_readlane((int)e.x, f);
                     const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)e.y, f);
                     fj = (int)(meta & 0xFFu); fdir = (int)((meta >> 8) & 1u); fhd = (int)((meta >> 9) & 0x7Fu);
                     const int pp = (int)((meta >> 16) & 0xFFFu);
                     nuse += (uint32_t)(pp + 1); lastp += 4 * pp - (lastp >> 2);
                     if (lane == 0) { nc++; ncu++; }
-                    viafast = true;
+                    viafast = true; have_next = fhd == 0;
                 } else if (!((uint32_t)__builtin_amdgcn_readlane((int)e.y, 0) & HARC_SUCC_OPEN)) nohit = true;     // the whole list is taken and nothing lies behind it
             }
         }
         if (!viafast && !nohit) {
+        if (ownlate && own_ins < t) own_sync(t);
         if (!rows_ok) { if (FASTP && rows_lazy) rows_materialise(); else cons_rows(st, L, lane, coltmp, rowF, rowR); }   // consensus and its reverse complement -> the wave's window rows
         PH(1);
         // Probes are issued in priority order in batches: every probe behind the first hit of a batch is speculative traffic,
@@ -1676,12 +1707,13 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             // no candidate: go on from the chain's look-ahead seeds (highest id first, skipping what was claimed meanwhile) -- the new
             // seed of reorder.cpp:652-668 without waiting for the next k_reseed
             nuse += (uint32_t)s.nprobe; dbg_miss++;
+            if (ownlate && own_ins < t) own_sync(t);
             uint32_t sid = HARC_NONE;
             if (spos < nsugg) {
                 const int idx = spos + lane;
                 uint32_t id = 0; bool okc = false;
                 if (idx < nsugg) {
-                    id = __hip_atomic_load(&s.sugg[(size_t)c * HARC_NSUGG + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // may have been written by this wave above
+                    id = __hip_atomic_load(&s.sugg[(size_t)c * s.nsugg_stride + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // may have been written by this wave above
                     okc = !((s.claimed[id >> 6] >> (id & 63)) & 1ULL);
                     if constexpr (OWNT) okc = okc && !own_has(ownt, id);
                     else for (int k = 0; k < t; k++) okc = okc && ((uint32_t)__builtin_amdgcn_readlane((int)ownreg, k) != id);
@@ -1690,12 +1722,9 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                 if (sm) { const int f = __ffsll((long long)sm) - 1; sid = __shfl(id, f, 64); spos += f + 1; } else spos = nsugg;
             }
             if (sid == HARC_NONE) { needseed = true; break; }
-            if (lane == 0) {
-                s.steps[(size_t)c * 64 + t] = make_uint2(sid, (1u << 16) | ((uint32_t)spos << 24));
-                atomicMin(&s.bid[sid], ((uint32_t)t << 20) | c);
-            }
+            if (lane == 0) s.steps[(size_t)c * 64 + t] = make_uint2(sid, (1u << 16) | ((uint32_t)spos << 24));     // (the bid: after the walk, below)
             if (lane == t) ownreg = sid;
-            if constexpr (OWNT) { if (lane == 0) own_insert(ownt, sid); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
+            if constexpr (OWNT) { if (!ownlate && lane == 0) own_insert(ownt, sid); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
             if (lane < NW) { const uint32_t *rp = reinterpret_cast<const uint32_t *>(s.reads + (size_t)sid * W); rdl[lane] = rp[lane]; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1706,12 +1735,9 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             if (COOP && bigprobes >= s.budget) break;
             continue;
         }
-        if (lane == 0) {
-            s.steps[(size_t)c * 64 + t] = make_uint2(found, (uint32_t)fj | ((uint32_t)fdir << 8));
-            atomicMin(&s.bid[found], ((uint32_t)t << 20) | c);
-        }
+        if (lane == 0) s.steps[(size_t)c * 64 + t] = make_uint2(found, (uint32_t)fj | ((uint32_t)fdir << 8));
         if (lane == t) ownreg = found;
-        if constexpr (OWNT) { if (lane == 0) own_insert(ownt, found); }
+        if constexpr (OWNT) { if (!ownlate && lane == 0) own_insert(ownt, found); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (FASTP && viafast && fhd == 0) {                        // (k_succ) ... and nobody has asked for its rows yet
@@ -1742,6 +1768,9 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         PH(4);
         if (COOP && bigprobes >= s.budget) break;
     }
+    // the bids of the steps walked in this launch, all at once (lane t holds the read of step t): k_resolve is their only reader, and an atomic on a cold
+    // line of bid[] in every step sat in front of the next step's first wait for memory (vmcnt counts loads and atomics alike)
+    if (lane >= T0 && lane < T0 + nst) atomicMin(&s.bid[ownreg], ((uint32_t)lane << 20) | c);
     if (pend) {
         if (FASTP && rows_lazy) rows_materialise();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); cons_flush(st, pshift, pend, ptot, rowF, L, lane); pend = 0; ptot = 0;
@@ -1800,7 +1829,7 @@ __global__ void k_apply_seed(S1Args s)
         h.cur = id; h.prev = id; h.flags = ((h.flags | CH_PREVUNM) & ~CH_NEEDSEED) & 0xFFFFu; h.mode = 2;
         const uint32_t first = r * (uint32_t)s.nsugg_per_seed;
         const uint32_t ng = first >= got ? 0u : (got - first < (uint32_t)s.nsugg_per_seed ? got - first : (uint32_t)s.nsugg_per_seed);
-        for (uint32_t k = 0; k < ng; k++) s.sugg[(size_t)c * HARC_NSUGG + k] = s.seedbuf[R + first + k];
+        for (uint32_t k = 0; k < ng; k++) s.sugg[(size_t)c * s.nsugg_stride + k] = s.seedbuf[R + first + k];
         h.nsteps = ng << 24;
         uint2 q = s.cst2[c]; q.x++; s.cst2[c] = q;
     } else {                                                      // no reads left (reorder.cpp:670-677)
@@ -1862,12 +1891,12 @@ __global__ void k_replica_digest(S1Args s, unsigned long long nwords, unsigned l
 }
 
 // (B) G lanes per chain (G = 16/32/64 >= S), lane t of the group = step t of the super-round
-template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
+template <int G> __device__ __forceinline__ void resolve_body(const S1Args &s, const uint32_t bx)
 {
     constexpr int CPW = 64 / G;                                   // chains per wave
     const int lane = threadIdx.x & 63, sub = lane / G, sl = lane % G, g0 = sub * G;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { s.reseed_g[0] = 0u; s.reseed_g[1] = 0u; }      // the meeting counter and the flag of the k_reseed_mg that follows
-    const uint32_t c = (blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + sub;
+    if (bx == 0 && threadIdx.x == 0) { s.reseed_g[0] = 0u; s.reseed_g[1] = 0u; }      // the meeting counter and the flag of the k_reseed_mg that follows
+    const uint32_t c = (bx * 4 + (threadIdx.x >> 6)) * CPW + sub;
     ChainHdr h; h.flags = 0; h.nsteps = 0; h.n_main = 0; h.n_sing = 0; h.prev = 0; h.pad0 = 0;
     if (c < s.K) h = s.hdr[c];
     const bool act = c < s.K && (h.flags & CH_ACTIVE);
@@ -1956,6 +1985,7 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
         s.need[c] = (!cut && (h.flags & CH_NEEDSEED)) ? 1 : 0;
     }
 }
+template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s) { resolve_body<G>(s, blockIdx.x); }
 
 // (C) one workgroup: new seeds, in chain order, from the single descending cursor over unclaimed reads (reorder.cpp:650-688);
 // when the cursor runs out the remaining chains finish.  Every reseeded chain also gets HARC_NSUGG look-ahead seeds: the next
@@ -1964,7 +1994,7 @@ template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s)
 // The kernel only ranks the chains and finds the ids; every chain applies its own seed at the top of the next k_steps.
 // NT threads: 1024, or 256 with few chains (the block scans and barriers of sixteen waves were most of the kernel's 11.5 us on a
 // 2048-chain input: a tenth of a super-round).  The look-ahead range is HARC_LOOK_CHUNKS x 1024 words either way.
-template <int NT> __global__ __launch_bounds__(NT) void k_reseed(S1Args s)
+template <int NT> __device__ __forceinline__ void reseed_body(const S1Args &s)
 {
     __shared__ uint32_t sm[20];
     __shared__ long long scursor;
@@ -2048,6 +2078,16 @@ template <int NT> __global__ __launch_bounds__(NT) void k_reseed(S1Args s)
     // the chains take their seeds themselves at the top of the next k_steps (rank -> seedbuf)
     if (t == 0) { s.rmeta[0] = R; s.rmeta[1] = assigned; s.rmeta[2] = got; }
     if (t == 0) *s.cursor = cursor < -1 ? -1 : cursor;
+}
+template <int NT> __global__ __launch_bounds__(NT) void k_reseed(S1Args s) { reseed_body<NT>(s); }
+// (B) + (C) in one launch when ONE workgroup of k_resolve holds every chain (exact mode: one chain; a super-round of a single wave's walk is ~60 us, of which
+// the two launches were ten)
+template <int G> __global__ __launch_bounds__(256) void k_resolve_reseed(S1Args s)
+{
+    resolve_body<G>(s, 0u);
+    __threadfence();
+    __syncthreads();
+    reseed_body<256>(s);
 }
 
 // (C) with many chains: the same, by RESEED_G workgroups of RESEED_NT threads (16384 threads: one word of the claim bitmap each per pass,
@@ -2662,6 +2702,10 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     a.L = P.readlen; a.maxmatch = P.maxmatch; a.thresh = P.thresh; a.maxsearch = P.maxsearch;
     a.Lp = ((W + 1) / 2) * 64; a.S = nsteps;
     a.nsugg_per_seed = HARC_NSUGG;
+    // ONE chain (exact mode) takes its seeds from the same descending cursor whatever the look-ahead holds (nobody else claims anything between the
+    // hand-out and the use, and the walk skips what it took itself): 64 look-ahead seeds instead of 8 are the same bytes and a third of the
+    // super-rounds on low-coverage input, where a walk needs a new seed every few reads
+    if (K == 1) a.nsugg_per_seed = 64;
 #ifdef HARC_AMD_EXPERIMENTS    // schedule knobs change the archive bytes: never read from the environment by a product build (make EXPERIMENTS=1)
     if (const char *e = getenv("HARC_AMD_NSUGG")) { a.nsugg_per_seed = atoi(e); if (a.nsugg_per_seed < 0) a.nsugg_per_seed = 0; if (a.nsugg_per_seed > HARC_NSUGG) a.nsugg_per_seed = HARC_NSUGG; }
 #endif
@@ -2680,7 +2724,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &a.claimed, nwords)); RC_TRY(dalloc(c, &a.bid, (size_t)N + 1)); RC_TRY(dalloc(c, &a.hdr, K));
     RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.steps, (size_t)K * 64)); RC_TRY(dalloc(c, &a.need, (size_t)K + 8192 + 1024));
     RC_TRY(dalloc(c, &a.reseed_g, 4 + 4 * RESEED_G)); HIP_TRY(hipMemsetAsync(a.reseed_g, 0, (4 + 4 * RESEED_G) * 4, c->stream));
-    RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + HARC_NSUGG))); RC_TRY(dalloc(c, &a.needrank, (size_t)K + 16)); RC_TRY(dalloc(c, &a.rmeta, 4)); RC_TRY(dalloc(c, &a.cst2, (size_t)K + 1)); RC_TRY(dalloc(c, &a.sugg, (size_t)K * HARC_NSUGG));
+    a.nsugg_stride = a.nsugg_per_seed > HARC_NSUGG ? a.nsugg_per_seed : HARC_NSUGG;
+    RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + a.nsugg_stride))); RC_TRY(dalloc(c, &a.needrank, (size_t)K + 16)); RC_TRY(dalloc(c, &a.rmeta, 4)); RC_TRY(dalloc(c, &a.cst2, (size_t)K + 1)); RC_TRY(dalloc(c, &a.sugg, (size_t)K * a.nsugg_stride));
     RC_TRY(dalloc(c, &a.slog, (size_t)N + 1));
     const size_t pg_max = (size_t)N / 64 + ((size_t)K + 1) * PG_CHUNK;        // full pages + one open chunk per chain
     RC_TRY(dalloc(c, &a.pg_rec, pg_max * 64)); RC_TRY(dalloc(c, &a.pg_hdr, pg_max)); RC_TRY(dalloc(c, &a.pg_cur, (size_t)K + 1)); RC_TRY(dalloc(c, &a.pg_count, 4));
@@ -2785,6 +2830,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     const int batch = getenv("HARC_AMD_BATCHSYNC") ? atoi(getenv("HARC_AMD_BATCHSYNC")) : 8;
     // k_reseed by 64 workgroups once a single one has thousands of seeds to hand out per round (HARC_AMD_RESEED_MG=0/1 forces either; same result)
     const bool reseed_mg = getenv("HARC_AMD_RESEED_MG") ? atoi(getenv("HARC_AMD_RESEED_MG")) != 0 : K > 4096;
+    // one launch for both while a single workgroup of k_resolve holds all chains (HARC_AMD_FUSED_RR=0: two, as with more chains; same result)
+    const bool fused_rr = !reseed_mg && K <= 4u * (64u / (nsteps <= 16 ? 16u : nsteps <= 32 ? 32u : 64u)) && !(getenv("HARC_AMD_FUSED_RR") && atoi(getenv("HARC_AMD_FUSED_RR")) == 0);
     a.reseed_win = RESEED_G * RESEED_NT;
     if (const char *e = getenv("HARC_AMD_RESEED_WIN")) { const int x = atoi(e); if (x >= 1 && x <= RESEED_G * RESEED_NT) a.reseed_win = (uint32_t)x; }     // same seeds, more passes
     if (const char *e = getenv("HARC_AMD_RESEED_STRESS")) { const int x = atoi(e); a.reseed_stress = x < 0 ? 0u : x > 1000 ? 1000u : (uint32_t)x; }     // delays only
@@ -2814,10 +2861,16 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
                 RC_TRY(cm->alltoallv(c, 1, sp, sop, sbp, rp, rop, rbp));
                 hipLaunchKernelGGL(k_unpack_chains, dim3((unsigned)((tot + 255) / 256), a.own_mod), dim3(256), 0, c->stream, a, (const uint32_t *)x_recv, x_nper);
             }
-            if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
+            if (fused_rr) {
+                if (nsteps <= 16) hipLaunchKernelGGL((k_resolve_reseed<16>), dim3(1), dim3(256), 0, c->stream, a);
+                else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve_reseed<32>), dim3(1), dim3(256), 0, c->stream, a);
+                else hipLaunchKernelGGL((k_resolve_reseed<64>), dim3(1), dim3(256), 0, c->stream, a);
+            }
+            else if (nsteps <= 16) hipLaunchKernelGGL((k_resolve<16>), dim3((K + 15) / 16), dim3(256), 0, c->stream, a);
             else if (nsteps <= 32) hipLaunchKernelGGL((k_resolve<32>), dim3((K + 7) / 8), dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((k_resolve<64>), dim3((K + 3) / 4), dim3(256), 0, c->stream, a);
-            if (reseed_mg) hipLaunchKernelGGL(k_reseed_mg, dim3(RESEED_G), dim3(RESEED_NT), 0, c->stream, a, a.reseed_g);
+            if (fused_rr) { }
+            else if (reseed_mg) hipLaunchKernelGGL(k_reseed_mg, dim3(RESEED_G), dim3(RESEED_NT), 0, c->stream, a, a.reseed_g);
             else if (K <= 4096) hipLaunchKernelGGL((k_reseed<256>), dim3(1), dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((k_reseed<1024>), dim3(1), dim3(1024), 0, c->stream, a);
             if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge, (const uint32_t *)d_sz0);

@@ -32,13 +32,13 @@ def assert_same(got, want, files, what):
     assert not errs, what + "\n" + "\n".join(errs)
 
 
-@pytest.mark.parametrize("succ", [None, "0"])
+@pytest.mark.parametrize("env", [{}, {"HARC_AMD_SUCC": "0"}, {"HARC_AMD_FUSED_RR": "0"}])
 @pytest.mark.parametrize("case", CASES)
-def test_stage1_K1_matches_reference(case, succ, tmp_path, monkeypatch):
-    """exact mode: by default through the successor lists (k_succ), and without them (HARC_AMD_SUCC=0)"""
+def test_stage1_K1_matches_reference(case, env, tmp_path, monkeypatch):
+    """exact mode: by default through the successor lists (k_succ) and with k_resolve + k_reseed in one launch; without the lists; with two launches"""
     import harc_amd
-    if succ is not None:
-        monkeypatch.setenv("HARC_AMD_SUCC", succ)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     g = ol.load_golden(case)
     base = ol.stage_dir(tmp_path, {k: g["stage1/" + k] for k in ["input_clean.dna", "numreads.bin"]})
     harc_amd.reorder(base, _L(g), num_chains=1)

@@ -1,0 +1,9 @@
+#!/bin/bash
+R=r04z2
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"; cd "$ROOT"; mkdir -p gpurun_out/$R
+( timeout -k 10 700 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "K1_matches or variants_same or K_chains or low_complexity or medium_vs" ) > gpurun_out/$R/pytest1.log 2>&1; rc=$?
+tail -3 gpurun_out/$R/pytest1.log
+[ $rc -eq 0 ] || exit $rc
+for w in c3 c2 c1; do timeout -k 10 200 python tools/exact_probe.py $w 200000 2>&1 | tail -1; done | tee gpurun_out/$R/exact.txt
+bash tools/ab.sh $R c1 20 "-"
+bash tools/ab.sh $R c2 20 "-"
