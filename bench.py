@@ -678,6 +678,12 @@ def main():
             out["exact_mode"] = {"value": round(ne / dte / 1e6, 4), "unit": "Mreads/s", "num_chains": 1, "num_thr": 1,
                                  "sample": f"{ne} reads, same coverage; streams byte-identical to the reference at -t 1"}
             he.close()
+            # ... and the program it is identical to, on the same sample and this box's host: the reference's reorder + encoder at -t 1
+            if os.path.exists(os.path.join(ROOT, "oracle", "_ref", f"reorder_L{L}_t1.out")):
+                dtr, _ = run_reference(esample.cpu().numpy(), L, 1)
+                out["exact_mode"]["reference_t1"] = {"value": round(ne / dtr / 1e6, 4), "unit": "Mreads/s", "cores": 1, "sample": "the same reads"}
+                out["exact_mode"]["vs_reference_t1"] = round(dtr / dte, 1)
+            del esample
             # compressed size against the reference's default (-t 8), xz -6 of every stage-II stream as the stand-in for bsc / 7z
             refdir = os.path.join(ROOT, "oracle", "_ref")
             nz = min(ns, 1_000_000)

@@ -732,6 +732,11 @@ template <int W> struct StepsLds {
 // at most 64 of them.  The wave-uniform scan weeds them out of its candidates by all lanes at once; walking the wave's register copy with
 // v_readlane (one per read taken so far, every batch) was ~40 of the ~460 vector instructions of a step
 #define HARC_OWN_SLOTS 128
+#ifndef HARC_SEQ_OWNT
+#define HARC_SEQ_OWNT 1               // the wave-uniform kernels keep the table too and their lanes weed the chain's own reads out of the single-read bins.  0 (make variant): no
+                                      // table, the wave-uniform test asks the wave's registers before it fetches anything -- two LDS round trips less per step and 3 % SLOWER
+                                      // (configs[2]: 1023 against 994 us per launch): at eight waves per SIMD the round trips are hidden, the two extra turns of the candidate loop are not
+#endif
 __device__ __forceinline__ void own_insert(uint32_t *tab, uint32_t id)
 {
     uint32_t h = (id * 0x9E3779B1u) >> 25;
@@ -1219,7 +1224,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     // OWNT: the kernels that keep the reads a walk has taken in the LDS hash table -- the wave-uniform ones, and the whole-bucket kernel of runs with few
     // chains (there LDS is no limit, and exact mode walks 64 steps per launch: comparing every candidate with up to 63 earlier reads by v_readlane was
     // what made long walks slower than short ones)
-    constexpr bool OWNT = SEQ || (QUAD && !COOP);
+    constexpr bool OWNT = (SEQ && HARC_SEQ_OWNT) || (QUAD && !COOP);
     uint2 *const s_pinfo = reinterpret_cast<uint2 *>(s_own + (OWNT ? 4 * HARC_OWN_SLOTS : 0));      // the table exists in the kernel that asks it only (2 KB more LDS cost the 150-bp kernel a workgroup per CU)
     WgCmd *const cmd = reinterpret_cast<WgCmd *>(reinterpret_cast<char *>(s_pinfo + s.nprobe) + 8 - ((size_t)(s_pinfo + s.nprobe) & 7));
     // main kernel: 4 chains per workgroup, one wave each.  COOP: one chain per workgroup, wave 0 walks it (role 0), waves 1..3 help with the scans
@@ -1239,7 +1244,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         for (int i = threadIdx.x; i < s.nprobe; i += 64 * NWV) s_pinfo[i] = pt[i];
         for (int i = threadIdx.x; i < 4 * 2 * ROW; i += 64 * NWV) s_rows[i] = 0u;
         for (int i = threadIdx.x; i < 4 * 8 * NW; i += 64 * NWV) s_tmp[i] = 0u;
-        if constexpr (SEQ || (QUAD && !COOP)) for (int i = threadIdx.x; i < 4 * HARC_OWN_SLOTS; i += 64 * NWV) s_own[i] = HARC_NONE;
+        if constexpr (OWNT) for (int i = threadIdx.x; i < 4 * HARC_OWN_SLOTS; i += 64 * NWV) s_own[i] = HARC_NONE;
         __syncthreads();
     }
     if (COOP && role != 0) {                                      // helpers: wait for a scan, take part, until the walk is over
@@ -1523,7 +1528,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                             // made only when the batch found at least `weedmin` such bins (one or two are tested faster than they are weeded: the test
                             // asks for the claim word anyway).  __ballot here counts the lanes that are in this branch.
                             if (__popcll(__ballot(true)) >= s.weedmin && ((reinterpret_cast<const uint32_t *>(s.claimed)[sst >> 5] >> (sst & 31u)) & 1u)) { cand = false; atomicOr(reinterpret_cast<uint32_t *>(&tab[sl + qhit]) + 3, SLOT_DEAD); }
-                            else if (own_has(ownt, sst)) cand = false;
+                            else if (OWNT && own_has(ownt, sst)) cand = false;
                         }
                     }
                     else {
@@ -1589,13 +1594,15 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                     uint32_t lead = 0, hit = HARC_NONE, rd = 0; bool alltop = true; int seen = 0, hit_hd = -1;
                     for (uint32_t i = cntb; i > 0 && seen < s.maxsearch; i--) {
                         const uint32_t rid = emb ? o_sst : (uint32_t)__builtin_amdgcn_readfirstlane((int)ids[o_sst + i - 1]);
+                        // taken by this chain earlier in this super-round? (not in the frozen bitmap: the read the consensus came from sits in the first bins of
+                        // every step).  Such a read is not a candidate at all; asked of the wave's registers BEFORE anything is fetched for it
+                        if (!OWNT && __ballot(ownreg == rid && lane < t)) { alltop = false; continue; }
                         // claim bit and read words are fetched together (one dependent hop instead of two)
                         const uint32_t cwd = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t *>(s.claimed)[rid >> 5]);
                         rd = lane < NW ? reinterpret_cast<const uint32_t *>(s.reads)[(size_t)rid * NW + lane] : 0u;
                         if ((cwd >> (rid & 31u)) & 1u) { if (alltop) lead++; continue; }
                         alltop = false;
-                        // taken by this chain earlier in this super-round? (not in the frozen bitmap).  Such a read is not a candidate at all
-                        if (__ballot(ownreg == rid && lane < t)) continue;
+                        if (OWNT && __ballot(ownreg == rid && lane < t)) continue;     // (with the LDS table the lanes have weeded most of these out already)
                         uint32_t hdp = 0;
                         if (lane < NW) hdp = (uint32_t)__popc((__builtin_amdgcn_alignbit(rowF[i0 + lane + 1], rowF[i0 + lane], sh) ^ rd) & mrow[lane]);
                         // NW <= 16 lanes: the sum over a row of 16 (row_shr 8, 4, 2, 1: lane 15 holds it)
