@@ -2834,7 +2834,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     unsigned long long coop_seen = 0;
     double coop_slots = 1024.0;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, P.device) == hipSuccess && pr.multiProcessorCount > 0) coop_slots = 4.0 * pr.multiProcessorCount; }
-    const int batch = getenv("HARC_AMD_BATCHSYNC") ? atoi(getenv("HARC_AMD_BATCHSYNC")) : 8;
+    // super-rounds between two looks of the host at the counters: 8; 32 where a round is one wave's walk (a look costs as much as two such rounds)
+    const int batch = getenv("HARC_AMD_BATCHSYNC") ? atoi(getenv("HARC_AMD_BATCHSYNC")) : (K <= 4 ? 32 : 8);
     // k_reseed by 64 workgroups once a single one has thousands of seeds to hand out per round (HARC_AMD_RESEED_MG=0/1 forces either; same result)
     const bool reseed_mg = getenv("HARC_AMD_RESEED_MG") ? atoi(getenv("HARC_AMD_RESEED_MG")) != 0 : K > 4096;
     // one launch for both while a single workgroup of k_resolve holds all chains (HARC_AMD_FUSED_RR=0: two, as with more chains; same result)
