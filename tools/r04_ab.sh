@@ -1,0 +1,7 @@
+#!/bin/bash
+R=r04ab
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"; cd "$ROOT"; mkdir -p gpurun_out/$R
+for cfg in "-" "HARC_AMD_BATCHSYNC=8" "HARC_AMD_BATCHSYNC=128"; do
+  [ "$cfg" = "-" ] && cfg=""
+  for w in c3 c1; do env $cfg timeout -k 10 200 python tools/exact_probe.py $w 200000 2>&1 | tail -1; done
+done | tee gpurun_out/$R/exact.txt
