@@ -1392,6 +1392,18 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
+    // ... and a look-ahead seed taken by such a walk does not fetch its read either: the counts become the seed's when something asks for them (seedrid)
+    uint32_t seedrid = HARC_NONE;
+    auto counts_sync = [&]() {
+        if (seedrid == HARC_NONE) return;
+        if (lane < NW) rdl[lane] = reinterpret_cast<const uint32_t *>(s.reads)[(size_t)seedrid * NW + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cons_reset_lds(st, rdl, L, lane);
+        seedrid = HARC_NONE;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     if (FASTP && s.succ && h.mode == 2) lastrid = h.cur;
     auto rows_materialise = [&]() {
         if (lane < NW) rdl[lane] = reinterpret_cast<const uint32_t *>(s.reads)[(size_t)lastrid * NW + lane];
@@ -1438,6 +1450,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         }
         if (!viafast && !nohit) {
         if (ownlate && own_ins < t) own_sync(t);
+        if (ownlate) counts_sync();
         if (!rows_ok) { if (FASTP && rows_lazy) rows_materialise(); else cons_rows(st, L, lane, coltmp, rowF, rowR); }   // consensus and its reverse complement -> the wave's window rows
         PH(1);
         // Probes are issued in priority order in batches: every probe behind the first hit of a batch is speculative traffic,
@@ -1732,12 +1745,14 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             if (lane == 0) s.steps[(size_t)c * 64 + t] = make_uint2(sid, (1u << 16) | ((uint32_t)spos << 24));     // (the bid: after the walk, below)
             if (lane == t) ownreg = sid;
             if constexpr (OWNT) { if (!ownlate && lane == 0) own_insert(ownt, sid); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
-            if (lane < NW) { const uint32_t *rp = reinterpret_cast<const uint32_t *>(s.reads + (size_t)sid * W); rdl[lane] = rp[lane]; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            cons_reset_lds(st, rdl, L, lane);                      // every count is replaced: what was pending is gone with the old consensus
+            if (ownlate) { seedrid = sid; lastrid = sid; lastdir = 0; rows_lazy = true; }      // rows and counts from the read, when somebody wants them
+            else {
+                if (lane < NW) { const uint32_t *rp = reinterpret_cast<const uint32_t *>(s.reads + (size_t)sid * W); rdl[lane] = rp[lane]; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                cons_reset_lds(st, rdl, L, lane);                  // every count is replaced: what was pending is gone with the old consensus
+            }
             rows_ok = false; pend = 0; ptot = 0;
-            if (FASTP && s.succ) { lastrid = sid; lastdir = 0; rows_lazy = false; }
             nst++;
             if (COOP && bigprobes >= s.budget) break;
             continue;
@@ -1753,6 +1768,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             pend++; rows_ok = false; rows_lazy = true; lastrid = found; lastdir = fdir;
         } else {
             if (FASTP && viafast) {                                // the list's read disagrees with the consensus somewhere: the counts want the rows of the consensus and the read's words after all
+                counts_sync();
                 if (pend && !rows_ok) rows_materialise();
                 if (lane < NW) rdl[lane] = reinterpret_cast<const uint32_t *>(s.reads)[(size_t)found * NW + lane];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1778,6 +1794,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     // the bids of the steps walked in this launch, all at once (lane t holds the read of step t): k_resolve is their only reader, and an atomic on a cold
     // line of bid[] in every step sat in front of the next step's first wait for memory (vmcnt counts loads and atomics alike)
     if (lane >= T0 && lane < T0 + nst) atomicMin(&s.bid[ownreg], ((uint32_t)lane << 20) | c);
+    if (ownlate) counts_sync();
     if (pend) {
         if (FASTP && rows_lazy) rows_materialise();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); cons_flush(st, pshift, pend, ptot, rowF, L, lane); pend = 0; ptot = 0;
@@ -2903,28 +2920,13 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
         if (*h_reseed_timeout) { harc_set_error("stage I: the workgroups of k_reseed_mg did not meet (super-round %llu); HARC_AMD_RESEED_MG=0 uses the single workgroup", (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
-        if (cm) {   // the replicas must agree (k_replica_digest): a rank that drifted would hang the others in the next all-gather, or worse
-            uint64_t mine[8], all[8 * 64];
-            for (int k = 0; k < 7; k++) mine[k] = h_stats[ST_N + HARC_COOPCNT + k];
-            mine[7] = h_stats[ST_ACTIVE];
-            RC_TRY(cm->allgather_u64(c, mine, 8, all));
-            static const char *const what[8] = { "claim bitmap", "chain headers", "chains asking for a seed", "cursor", "seeds wanted", "seeds handed out", "look-ahead seeds", "chains alive" };
-            for (uint32_t p = 0; p < a.own_mod; p++) for (int k = 0; k < 8; k++) if (all[(size_t)p * 8 + k] != all[k]) {
-                harc_set_error("design (R): the replicas of rank 0 and rank %u differ after super-round %llu (%s: %llx / %llx)", p, (unsigned long long)rounds, what[k],
-                               (unsigned long long)all[k], (unsigned long long)all[(size_t)p * 8 + k]);
-                return HARC_AMD_EINTERNAL;
-            }
-        }
+        // what this rank would run next, from its own clock and counters: which scan of the small bins (measured over the first two batches) and how
+        // many waves per cooperative workgroup.  Every variant computes the same bytes; design (R) still runs rank 0's choice on all ranks (below), so
+        // that a variant that ever differed would differ between RUNS, where the parity tests see it, and not between the replicas of one run
         if (seq_probe < 2) {
             HIP_TRY(hipEventElapsedTime(&seq_ms[seq_probe], R.eb[0], R.eb[1]));
             if (++seq_probe == 2) seq = seq_ms[0] < seq_ms[1];
         }
-        if (getenv("HARC_AMD_TRACE")) {
-            uint32_t rm[4] = { 0, 0, 0, 0 };
-            HIP_TRY(hipMemcpy(rm, a.rmeta, 16, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[stage I] round %llu: %llu chains alive%s; extra passes of k_reseed_mg so far %u\n", (unsigned long long)rounds, h_stats[ST_ACTIVE], seq ? " (wave-uniform scan)" : "", rm[3]);
-        }
-        if (h_stats[ST_ACTIVE] == 0) break;
         if (nlarge && coop_forced == 0) {
             // cooperative walks per super-round over the last rounds against the workgroups of four waves the chip holds (4 per CU): well beyond
             // that the kernel is bound by wave slots, and helpers hold most of them idle
@@ -2936,6 +2938,27 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             // (with the step cap: c3sd 343 / 280 / 268 ms with 4 / 2 / 1 waves, c2r 69 / 79 / 106 ms)
             coop_waves = per_round > 5.0 * coop_slots ? 1 : per_round > 3.0 * coop_slots ? 2 : 4;
         }
+        if (cm) {   // the replicas must agree (k_replica_digest): a rank that drifted would hang the others in the next all-gather, or worse
+            uint64_t mine[10], all[10 * 64];
+            for (int k = 0; k < 7; k++) mine[k] = h_stats[ST_N + HARC_COOPCNT + k];
+            mine[7] = h_stats[ST_ACTIVE];
+            mine[8] = seq_probe == 2 ? (seq ? 1u : 0u) : 2u; mine[9] = (uint64_t)coop_waves;
+            RC_TRY(cm->allgather_u64(c, mine, 10, all));
+            static const char *const what[8] = { "claim bitmap", "chain headers", "chains asking for a seed", "cursor", "seeds wanted", "seeds handed out", "look-ahead seeds", "chains alive" };
+            for (uint32_t p = 0; p < a.own_mod; p++) for (int k = 0; k < 8; k++) if (all[(size_t)p * 10 + k] != all[k]) {
+                harc_set_error("design (R): the replicas of rank 0 and rank %u differ after super-round %llu (%s: %llx / %llx)", p, (unsigned long long)rounds, what[k],
+                               (unsigned long long)all[k], (unsigned long long)all[(size_t)p * 10 + k]);
+                return HARC_AMD_EINTERNAL;
+            }
+            if (all[8] < 2u) seq = all[8] != 0;                    // rank 0's choices
+            if (coop_forced == 0 && (all[9] == 1u || all[9] == 2u || all[9] == 4u)) coop_waves = (int)all[9];
+        }
+        if (getenv("HARC_AMD_TRACE")) {
+            uint32_t rm[4] = { 0, 0, 0, 0 };
+            HIP_TRY(hipMemcpy(rm, a.rmeta, 16, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[stage I] round %llu: %llu chains alive%s; extra passes of k_reseed_mg so far %u\n", (unsigned long long)rounds, h_stats[ST_ACTIVE], seq ? " (wave-uniform scan)" : "", rm[3]);
+        }
+        if (h_stats[ST_ACTIVE] == 0) break;
         if (rounds > (uint64_t)N * 2 + 1024) { harc_set_error("stage I did not converge after %llu rounds", (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
     }
     HIP_TRY(hipEventRecord(e2, c->stream));
