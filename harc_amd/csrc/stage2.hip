@@ -1065,6 +1065,39 @@ __global__ void k_left_emit(S2Args s, uint32_t t0, uint32_t nt, const uint32_t *
     }
 }
 
+// The same from the LIST of the leftover candidates, singletons first (k_left_list), one wave per read and one lane per base: with a thread group per
+// candidate, 1.4 G threads found out that nine in ten of the 200 M candidates of configs[3] are aligned -- 30 ms for 1.4 GB of text.
+// (A first version kept k_left_emit's groups of 16 bases over the list: at 50 M reads its text differed between two launches on the same inputs, in
+// whole waves and always in the sixth base of every group -- the one iteration in which two lanes per read take the branch for a field that straddles
+// two words -- while the same loop over all candidates, with a tenth of the lanes active, gave the same bytes every time; no overlapping buffers, no
+// concurrent writer, cause not found.  This form has no loop and no branch on the field's position.)
+__global__ void k_left_list(const uint32_t *fs, const uint32_t *fn, const uint32_t *rs, const uint32_t *rn, uint32_t nt, uint32_t US, uint32_t *list)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    if (fs[t]) list[rs[t]] = t;
+    else if (fn[t]) list[US + rn[t]] = t;
+}
+__global__ __launch_bounds__(256) void k_left_emit_w(S2Args s, uint32_t t0, const uint32_t *list, uint32_t nl, uint32_t US, uint8_t *sing_bases, char *ntext)
+{
+    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);      // entry of the list: singletons [0, US), reads with N behind them
+    const int lane = threadIdx.x & 63;
+    if (q >= nl) return;
+    const uint32_t i = t0 + list[q];
+    const uint64_t *r = s.cand3 + (size_t)i * s.W3;
+    const bool single = q < US;
+    uint8_t *const ob = sing_bases + (size_t)q * s.L;
+    char *const ot = ntext + (size_t)(q - US) * (s.L + 1);
+    for (int j = lane; j < s.L; j += 64) {
+        const int off = 3 * j, wi = off >> 6, sh = off & 63;
+        const uint64_t lo = r[wi], hi = wi + 1 < s.W3 ? r[wi + 1] : 0ULL;
+        const int c3 = (int)(((lo >> sh) | (sh ? (hi << (64 - sh)) : 0ULL)) & 7ULL);
+        const int b = c3_to_idx5(c3);
+        if (single) ob[j] = (uint8_t)b; else ot[j] = "ACGTN"[b];
+    }
+    if (!single && lane == 0) ot[s.L] = '\n';
+}
+
 // packbits (encoder.cpp:527-548, :560-578)
 __global__ void k_pack2_bytes(const uint8_t *bases, uint64_t nbytes_out, uint8_t *out)
 {
@@ -1522,7 +1555,13 @@ int stage2_run(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &sing_bases, (size_t)US * L + 8)); RC_TRY(dalloc(c, &ntext, n_ntext + 1)); RC_TRY(dalloc(c, &spk, (size_t)(sing_nb + sing_tl) + 64));
     uint8_t *h_sing = nullptr, *h_ntext = nullptr;
     RC_TRY(harc_host_alloc(c, (void **)&h_sing, (size_t)(sing_nb + sing_tl))); RC_TRY(harc_host_alloc(c, (void **)&h_ntext, n_ntext));
-    if (nt) hipLaunchKernelGGL(k_left_emit, G256((uint64_t)nt * ((L + 15) / 16)), a, t0, nt, rs, rn, sing_bases, ntext);
+    if (getenv("HARC_AMD_LEFT_ALL")) { if (nt) hipLaunchKernelGGL(k_left_emit, G256((uint64_t)nt * ((L + 15) / 16)), a, t0, nt, rs, rn, sing_bases, ntext); }     // tests: over all candidates, as before
+    else if (US + UN) {
+        uint32_t *llist = nullptr;
+        RC_TRY(dalloc(c, &llist, (size_t)US + UN + 1));
+        hipLaunchKernelGGL(k_left_list, G256(nt), (const uint32_t *)ls, (const uint32_t *)ln, (const uint32_t *)rs, (const uint32_t *)rn, nt, US, llist);
+        hipLaunchKernelGGL(k_left_emit_w, dim3((US + UN + 3) / 4), dim3(256), 0, c->stream, a, t0, (const uint32_t *)llist, US + UN, US, sing_bases, ntext);
+    }
     if (sing_nb) hipLaunchKernelGGL(k_pack2_bytes, G256(sing_nb), sing_bases, sing_nb, spk);
     if (sing_tl) hipLaunchKernelGGL(k_bases_to_ascii, G256(sing_tl), sing_bases + 4 * sing_nb, sing_tl, spk + sing_nb);
     HIP_TRY(hipGetLastError());

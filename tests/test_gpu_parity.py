@@ -223,6 +223,7 @@ def test_low_complexity_big_bins_match_oracle(n, glen, K, S, E, err, oracle, tmp
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0"},      # the specialised dense kernel (k_steps' SPEC) ...
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_SPEC": "0"},      # ... and the general one under the same conditions
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_LAZY": "0"},
+                                 {"HARC_AMD_LEFT_ALL": "1"},      # the leftover reads emitted by a pass over all candidates instead of over their list
                                  {"HARC_AMD_TABLE_FILL": "0"}, {"HARC_AMD_TABLE_FILL": "1"}, {"HARC_AMD_SORT_BITS": "8"}, {"HARC_AMD_SORT_BITS": "13"}, {"HARC_AMD_SORT_BITS": "1"}, {"HARC_AMD_SORT_BITS": "64"},
                                  {"HARC_AMD_S2BLOOM_TILED": "1", "HARC_AMD_S2BLOOM_VERIFY": "1"}, {"HARC_AMD_S2BLOOM_TILED": "1", "HARC_AMD_S2BLOOM_VERIFY": "1", "HARC_AMD_BLOOM4_HASHED": "1"},
                                  {"HARC_AMD_S1BLOOM_TILED": "1", "HARC_AMD_S1BLOOM_VERIFY": "1"},
