@@ -878,13 +878,26 @@ __global__ void k_acc_compact(const unsigned long long *best, const uint32_t *ra
 // merge by rank: final index of read i = i + #accepted with column < gstart[i]; of accepted k = k + #reads with gstart <= column
 struct FinalArrays { uint32_t *ref; uint8_t *kind; uint64_t *g; };   // kind 0 original, 1 candidate forward, 2 candidate reverse
 // (the reads [i0, i0 + n) and the accepted candidates [a0, a0 + na) of this rank's shards; the final arrays start at final index fbase)
-__global__ void k_merge_orig(const uint64_t *gstart, uint32_t i0, uint32_t n, const uint64_t *tup, uint32_t A, FinalArrays f, uint32_t fbase)
+// (gstart does not decrease with i, so neither does the count: k_merge_cuts looks it up for the first read of every block of 256 -- and for the last read of
+// the range --, and a read searches between its block's cut and the next one: ~70 accepted candidates at configs[3], a handful of loads from lines
+// its neighbours ask for too, instead of 28 dependent ones through 180 M tuples: encode 327 -> 317 ms there, 88 -> 84 ms at configs[2])
+__global__ void k_merge_cuts(const uint64_t *gstart, uint32_t i0, uint32_t n, const uint64_t *tup, uint32_t A, long long *cut)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, nb = (n + 255u) / 256u;
+    if (b > nb) return;
+    const uint32_t t = b < nb ? b * 256u : n - 1u;
+    const uint64_t g = gstart[i0 + t];
+    long long lo = -1, hi = A;                                    // #accepted with (tuple>>2) < g, minus one
+    while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if ((tup[mid] >> 2) < g) lo = mid; else hi = mid; }
+    cut[b] = lo;
+}
+__global__ void k_merge_orig(const uint64_t *gstart, uint32_t i0, uint32_t n, const uint64_t *tup, uint32_t A, FinalArrays f, uint32_t fbase, const long long *cut)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t i = i0 + t;
     const uint64_t g = gstart[i];
-    long long lo = -1, hi = A;                                    // #accepted with (tuple>>2) < g
+    long long lo = cut[blockIdx.x], hi = cut[blockIdx.x + 1] + 1;  // tup[lo] < g (or lo = -1); tup[hi] >= the next block's first g >= g (or hi = A)
     while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if ((tup[mid] >> 2) < g) lo = mid; else hi = mid; }
     const uint32_t at = i + (uint32_t)(lo + 1) - fbase;
     f.ref[at] = i; f.kind[at] = 0; f.g[at] = g;
@@ -1621,6 +1634,7 @@ int stage2_run(harc_amd_ctx *c)
     std::vector<uint32_t> g_of(E, 0);                             // the first shard of the group a shard belongs to
     std::vector<uint64_t> gtot(E, 0);                             // noise entries of a group
     std::vector<uint64_t> s_nz0(E, 0), s_nz1(E, 0), s_np0(E, 0), s_np1(E, 0);      // a shard's noise / noisepos bytes inside its group's buffers
+    long long *mcut = nullptr; RC_TRY(dalloc(c, &mcut, (size_t)(i1 - i0) / 256 + 4));      // k_merge_cuts: per block of 256 reads of a group
     uint64_t nmtot = 0; uint32_t n_nonN = 0, n_N_aligned = 0;
     const uint32_t estep = (uint64_t)F * 3 >= ((uint64_t)32 << 20) ? 1u : (e1 - e0 ? e1 - e0 : 1u);       // small outputs: one group (a launch and copies per shard cost a 3 M-read input more than they hide)
     for (uint32_t ea = e0; ea < e1; ea += estep) {
@@ -1629,7 +1643,10 @@ int stage2_run(harc_amd_ctx *c)
         const uint32_t fa = sh_f[ea] - fbase, fb = sh_f[eb] - fbase;
         if (fb <= fa) continue;
         const uint32_t ia = (uint32_t)((uint64_t)ea * a.q > M ? M : (uint64_t)ea * a.q), ib = eb >= E ? M : (uint32_t)((uint64_t)eb * a.q > M ? M : (uint64_t)eb * a.q);
-        if (ib > ia) hipLaunchKernelGGL(k_merge_orig, G256(ib - ia), gstart, ia, ib - ia, tup, A, f, fbase);
+        if (ib > ia) {
+            hipLaunchKernelGGL(k_merge_cuts, G256((ib - ia + 255u) / 256u + 1u), gstart, ia, ib - ia, tup, A, mcut);
+            hipLaunchKernelGGL(k_merge_orig, G256(ib - ia), gstart, ia, ib - ia, tup, A, f, fbase, (const long long *)mcut);
+        }
         if (sh_a[eb] > sh_a[ea]) hipLaunchKernelGGL(k_merge_acc, G256(sh_a[eb] - sh_a[ea]), gstart, M, tup, rid, sh_a[ea], sh_a[eb] - sh_a[ea], f, fbase);
         launch_noise<false>(c, a, f, cons2, fa, fb, nm, nonN, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         // exclusive scans over the group (nm[fb] = nonN[fb] = 0 still: the next group writes them after this)
