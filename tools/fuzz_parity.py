@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Parity fuzz on the GPU box: random small inputs rich in what the schedule is sensitive to (exact repeats, diverged repeat families,
 poly-A / (CA)n runs, duplicates, N reads, short and long reads), random (K, S, E); libharc_amd.so through its file contract against the
-CPU oracle, every stage-I and stage-II file byte for byte, then the decoder round trip.   python tools/fuzz_parity.py [iterations] [seed]"""
+CPU oracle, every stage-I and stage-II file byte for byte, then the decoder round trip.   [FUZZ_K=k] [FUZZ_S=s] python tools/fuzz_parity.py [iterations] [seed]"""
 import os
 import sys
 import tempfile
@@ -84,6 +84,8 @@ def main():
         K = int(rs.choice([1, 2, 7, 33, 0, nreads // 64 + 1]))
         S = int(rs.choice([1, 4, 16, 16, 64]))
         E = int(rs.choice([1, 2, 5]))
+        if os.environ.get("FUZZ_K"): K = int(os.environ["FUZZ_K"])          # e.g. FUZZ_K=1 FUZZ_S=64: exact mode only
+        if os.environ.get("FUZZ_S"): S = int(os.environ["FUZZ_S"])
         with tempfile.TemporaryDirectory() as d:
             od, gd = os.path.join(d, "o"), os.path.join(d, "g")
             os.makedirs(od); os.makedirs(gd)
