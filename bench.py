@@ -580,14 +580,17 @@ def main():
             roofline["traffic"] = round((tr["fetch_kb_per_launch"] + tr["write_kb_per_launch"]) * 1024.0, 1)
             roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / max(1.0, roofline["alg_bytes_per_launch"]), 2)
             roofline["traffic_source"] = "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command taken by the builder, profiles/k_steps_traffic.json (" + tr.get("profile", "") + ")"
-            # the roofline that binds this kernel: random 32-byte sector requests per second (tools/micro/gups.hip) against the L2 misses
-            # of the PMC pass per launch, over the launch time measured live
+            # the random-access roofline: L2 misses of the PMC pass per launch over the launch time measured live, against the ceiling for requests
+            # of the same shape -- one small load per random 64-byte sector, 64 GiB, eight waves per SIMD -- measured by two programs in one call
+            # (tools/micro/gups sector, tools/micro/lat2 indep: 48.5 G/s, 64.0 B fetched per miss; profiles/r05/random_access_ceiling.txt)
             ceil = json.load(open(os.path.join(ROOT, "profiles", "random_access_ceiling.json")))
             if tr.get("tcc_miss") and avg_ms > 0:
                 req = tr["tcc_miss"] / (avg_ms * 1e-3) / 1e9
-                roofline["random_access"] = {"achieved": round(req, 2), "peak": ceil["G_requests_per_s"]["32B"], "unit": "G sector requests/s (L2 misses; 32-byte slot-pair and read fetches)",
-                                             "frac": round(req / ceil["G_requests_per_s"]["32B"], 3), "l2_misses_per_launch": tr["tcc_miss"], "l2_misses_source": "from the builder's separate PMC run (as traffic); the launch time is this run's",
-                                             "peak_source": "tools/micro/gups.hip, profiles/r02/gups.txt: independent random 32-B loads over 64 GiB"}
+                peak = ceil["sector"]["G_requests_per_s"]
+                roofline["random_access"] = {"achieved": round(req, 2), "peak": peak, "unit": "G sector requests/s (L2 misses, 64 B fetched each)",
+                                             "frac": round(req / peak, 3), "l2_misses_per_launch": tr["tcc_miss"], "l2_misses_source": "from the builder's separate PMC run (as traffic); the launch time is this run's",
+                                             "request_shape": "one 4/8-byte load per random 64-byte sector (bitmap word, claim word, read dword, slot pair)",
+                                             "peak_source": "tools/micro/gups sector 64 = 47.4-48.7, tools/micro/lat2 indep 64 = 45.4-49.4 G/s in one call (profiles/r05/random_access_ceiling.txt); rounds 2-4 quoted 26.3 = two dwordx4 loads per lane, a wider request than the kernel makes"}
             # ... and, once the bitmap in front of the tables keeps most probes away from them, instruction issue: vector instructions of
             # the PMC pass x 4 cycles (one wave64 instruction on a 16-lane SIMD) over the SIMD cycles of the launch measured live
             if tr.get("sq_insts_valu") and avg_ms > 0:
