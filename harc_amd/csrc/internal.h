@@ -51,6 +51,7 @@ struct ChainHdr {
 #define CH_PREVUNM 2u
 #define CH_PARITY 4u     // which half of cnt[2][K][Lp] holds the state at the start of the super-round
 #define CH_NEEDSEED 8u   // the last walk stopped because a step found no candidate
+#define CH_WIDE 32u      // (between the two launches of k_steps_grp only) the chain's column counts need more than the 16 bits the first form keeps in LDS: the u32 form walks it
 #define CH_COOP 16u      // the walk stopped in front of a step that has to scan a bin of more than HARC_LARGEBIN reads: k_steps<.., COOP = true> makes that step
 
 // One emitted record of stage I (16 B); scattered into stream order by k_s1_scatter

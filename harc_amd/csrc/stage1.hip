@@ -64,6 +64,8 @@ struct S1Args {
     uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups, w sequential-equivalent candidates
     const uint2 *succ;               // runs with one chain or a few (k_succ): per (read, orientation) the first HARC_SUCC_N candidates of the step whose consensus IS that read; null = none
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
+    unsigned int *grp_ticket;        // k_steps_grp: the next chain a group takes when its walk is over (k_resolve sets it back to zero)
+    uint32_t grp_wide_warn, grp_wide_limit;   // k_steps_grp (steps_group.h): largest column count the u16 form reports / walks itself (GRP_WIDE_WARN / GRP_WIDE_LIMIT; tests lower them)
 };
 #define PG_CHUNK 8u
 #define HARC_SUCC_N 8              // entries of a successor list: one 64-byte line per (read, orientation)
@@ -83,7 +85,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { for (int o = 32; 
 #else
 #define TICK(k) do { } while (0)
 #endif
-enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_USEFUL = 5, ST_CANDS_SEQ = 6, ST_N = 8 };
+enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_USEFUL = 5, ST_CANDS_SEQ = 6, ST_WIDE = 7 /* k_steps_grp: some chain's counts passed GRP_WIDE_WARN (sticky) */, ST_N = 10 /* the last word: entries of the singleton log */ };
 #define HARC_COOPCNT 64   // counters of the walks handed to the cooperative kernel, spread over as many words (one word serialised 1300 atomics per round: +10 us)
 
 // ------------------------------------------------------------------------------------------------ packing kernels
@@ -1830,6 +1832,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     }
 }
 
+#include "steps_group.h"       // k_steps_grp: the dense SPEC kernel with two chains per wave (round 5)
+
 // ---- design (R): replicate the reads and the index, partition the chains (harc_amd_replicate_exchange).  Everything a super-round
 // changes outside the walking wave's own state is either recomputed identically on every rank (k_resolve, k_reseed, the compaction of the
 // large bins: functions of replicated state) or travels with the all-gather of the walked steps: the chain header and the steps of the
@@ -1919,7 +1923,7 @@ template <int G> __device__ __forceinline__ void resolve_body(const S1Args &s, c
 {
     constexpr int CPW = 64 / G;                                   // chains per wave
     const int lane = threadIdx.x & 63, sub = lane / G, sl = lane % G, g0 = sub * G;
-    if (bx == 0 && threadIdx.x == 0) { s.reseed_g[0] = 0u; s.reseed_g[1] = 0u; }      // the meeting counter and the flag of the k_reseed_mg that follows
+    if (bx == 0 && threadIdx.x == 0) { s.reseed_g[0] = 0u; s.reseed_g[1] = 0u; s.grp_ticket[0] = 0u; }      // the meeting counter and the flag of the k_reseed_mg that follows
     const uint32_t c = (bx * 4 + (threadIdx.x >> 6)) * CPW + sub;
     ChainHdr h; h.flags = 0; h.nsteps = 0; h.n_main = 0; h.n_sing = 0; h.prev = 0; h.pad0 = 0;
     if (c < s.K) h = s.hdr[c];
@@ -2748,6 +2752,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &a.claimed, nwords)); RC_TRY(dalloc(c, &a.bid, (size_t)N + 1)); RC_TRY(dalloc(c, &a.hdr, K));
     RC_TRY(dalloc(c, &a.cnt, (size_t)2 * K * a.Lp)); RC_TRY(dalloc(c, &a.steps, (size_t)K * 64)); RC_TRY(dalloc(c, &a.need, (size_t)K + 8192 + 1024));
     RC_TRY(dalloc(c, &a.reseed_g, 4 + 4 * RESEED_G)); HIP_TRY(hipMemsetAsync(a.reseed_g, 0, (4 + 4 * RESEED_G) * 4, c->stream));
+    RC_TRY(dalloc(c, &a.grp_ticket, 4)); HIP_TRY(hipMemsetAsync(a.grp_ticket, 0, 16, c->stream));
     a.nsugg_stride = a.nsugg_per_seed > HARC_NSUGG ? a.nsugg_per_seed : HARC_NSUGG;
     RC_TRY(dalloc(c, &a.seedbuf, (size_t)K * (1 + a.nsugg_stride))); RC_TRY(dalloc(c, &a.needrank, (size_t)K + 16)); RC_TRY(dalloc(c, &a.rmeta, 4)); RC_TRY(dalloc(c, &a.cst2, (size_t)K + 1)); RC_TRY(dalloc(c, &a.sugg, (size_t)K * a.nsugg_stride));
     RC_TRY(dalloc(c, &a.slog, (size_t)N + 1));
@@ -2775,7 +2780,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (getenv("HARC_AMD_BUDGET")) a.budget = atoi(getenv("HARC_AMD_BUDGET"));
 #endif
     if (a.stepcap < 1) a.stepcap = 1;
-    a.weedmin = getenv("HARC_AMD_WEEDMIN") ? atoi(getenv("HARC_AMD_WEEDMIN")) : 3;
+    a.weedmin = getenv("HARC_AMD_WEEDMIN") ? atoi(getenv("HARC_AMD_WEEDMIN")) : 3;      // (k_steps_grp never weeds by claim bit unless told to: set below)
     a.lazy = getenv("HARC_AMD_LAZY") ? (atoi(getenv("HARC_AMD_LAZY")) != 0 ? 1 : 0) : 1;
     a.firstmax = (bloom_nwin[0] > 0 && bloom_nwin[1] > 0) ? 64 : 48;     // lines by minimizer: speculative probes share their lines
     if (const char *e = getenv("HARC_AMD_FIRSTMAX")) { const int x = atoi(e); a.firstmax = x < 1 ? 1 : x > 64 ? 64 : x; }
@@ -2842,7 +2847,43 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // the specialised form of the dense wave-uniform kernel (k_steps' SPEC): its constants must be this run's parameters
     const bool spec = (getenv("HARC_AMD_SPEC") ? atoi(getenv("HARC_AMD_SPEC")) != 0 : true) && W >= 4 && a.kbits[0] == 64 && a.kbits[1] == 64 && bloom_lines > 0 && bloom_nwin[0] == 17 && bloom_nwin[1] == 17 &&
                       bloom_mmask == 0xFFFFFFFFu && (dict[0].cap >> 34) == 0 && P.maxsearch >= (int)HARC_LARGEBIN && a.firstmax == 64;
-    int seq_probe = (!getenv("HARC_AMD_SEQ") && HARC_SEQ_SCAN && dense && !quad && seq) ? 0 : 2;      // 0 / 1: the batch being timed, 2: decided
+    // two chains per wave (k_steps_grp, steps_group.h): the dense SPEC conditions, at most 32 steps and look-ahead seeds per group of 32 lanes.
+    // HARC_AMD_GRP=1 asks for it wherever it can run, =0 never (same bytes either way: tests)
+    const bool grp_ok = (W == 4 || W == 5) && dense && !quad && spec && nsteps <= 16 && a.nsugg_per_seed <= 16 && a.nsugg_stride <= 16 && (dict[0].cap >> 32) == 0;
+    bool grp = grp_ok && (getenv("HARC_AMD_GRP") ? atoi(getenv("HARC_AMD_GRP")) != 0 : false);
+    if (getenv("HARC_AMD_GRP") && atoi(getenv("HARC_AMD_GRP")) == 2 && !grp) {      // tests: the kernel asked for must be the kernel that runs
+        harc_set_error("HARC_AMD_GRP=2: k_steps_grp cannot run here (W %d dense %d quad %d spec %d steps %d look-ahead seeds %d)", W, (int)dense, (int)quad, (int)spec, nsteps, a.nsugg_per_seed);
+        return HARC_AMD_EINVAL;
+    }
+    // lanes per chain: 16 (four chains per wave) for reads of up to 128 bases, 32 beyond (HARC_AMD_GRP_G=32 forces two chains per wave)
+    int grp_g = W <= 4 ? 16 : 32;
+    if (const char *e = getenv("HARC_AMD_GRP_G")) { if (atoi(e) == 32) grp_g = 32; }
+    const int grp_u = 2;                                         // probes per lane and batch (measured with 1, 2 and 4: steps_group.h)
+    const size_t lds_bytes_grp = steps_grp_lds_bytes(W, grp_g, true, P.maxmatch, a.nprobe), lds_bytes_grp32 = steps_grp_lds_bytes(W, 32, false, P.maxmatch, a.nprobe);
+    // the u32 form behind it (steps_group.h: chains whose counts outgrow 16 bits): during the first batch of the run, and from the batch on in which
+    // the first form reports a chain beyond GRP_WIDE_WARN; HARC_AMD_GRP_WIDE=1 launches it always (tests)
+    a.grp_wide_warn = GRP_WIDE_WARN; a.grp_wide_limit = GRP_WIDE_LIMIT;
+    if (const char *e = getenv("HARC_AMD_GRP_WIDE_LIMIT")) { const int x = atoi(e); if (x >= 1 && x < (int)GRP_WIDE_LIMIT) { a.grp_wide_limit = (uint32_t)x; a.grp_wide_warn = (uint32_t)x / 2; } }      // tests (with HARC_AMD_GRP_WIDE=1): chains change hands at small counts
+    // workgroups of it the chip holds at once (HARC_AMD_GRP_GRID: that many per compute unit instead of what the occupancy calculator says; a large
+    // number = one workgroup per 8 / 16 chains, no tickets)
+    uint32_t grp_resident = 1u << 30;
+    if (grp) {
+        if constexpr (W == 4 || W == 5) {
+            int per_cu = 0;
+            hipError_t oe = hipSuccess;
+            if (W == 4 && grp_g == 16) { if constexpr (W == 4) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_steps_grp<W, 16, true, 2>, 256, lds_bytes_grp); }
+            else oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_steps_grp<W, 32, true, 2>, 256, lds_bytes_grp);
+            if (oe != hipSuccess || per_cu < 1) per_cu = 4;
+            if (const char *e = getenv("HARC_AMD_GRP_GRID")) { const int x = atoi(e); if (x >= 1) per_cu = x; }
+            hipDeviceProp_t pr;
+            const int ncu = (hipGetDeviceProperties(&pr, P.device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+            grp_resident = (uint32_t)per_cu * (uint32_t)ncu;
+            if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] k_steps_grp: %d lanes per chain, %d probes per lane and batch, %d workgroups per compute unit x %d\n", grp_g, grp_u, per_cu, ncu);
+        }
+    }
+    if (grp && !getenv("HARC_AMD_WEEDMIN")) a.weedmin = 99;     // with several chains per wave the look at the claim bitmap ahead of the tests is one more trip for everybody: 1090 -> 1066 us per wave
+    bool grp_wide_seen = getenv("HARC_AMD_GRP_WIDE") && atoi(getenv("HARC_AMD_GRP_WIDE")) != 0; uint64_t grp_rounds = 0;
+    int seq_probe = (!getenv("HARC_AMD_SEQ") && HARC_SEQ_SCAN && dense && !quad && seq && !grp) ? 0 : 2;      // 0 / 1: the batch being timed, 2: decided
     float seq_ms[2] = { 0, 0 };
     uint64_t rounds = 0, launches = 0;
     int coop_forced = getenv("HARC_AMD_COOP_WAVES") ? atoi(getenv("HARC_AMD_COOP_WAVES")) : 0;     // tests: 1, 2 or 4 waves per cooperative workgroup
@@ -2867,6 +2908,16 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (cm) hipLaunchKernelGGL(k_apply_seed, dim3(nblk), dim3(256), 0, c->stream, a);          // the seeds of the chains other ranks walk
             if (prof) { RC_TRY(R.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }
             if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
+            else if (grp) {
+                if constexpr (W == 4 || W == 5) {
+                    // a persistent grid: as many workgroups as the chip holds at once (its groups take further chains by ticket), fewer when there are fewer chains
+                    const uint32_t cpb = grp_g == 16 ? 16u : 8u, gmax = (K + cpb - 1) / cpb, ggrid = gmax < grp_resident ? gmax : grp_resident;
+                    if (W == 4 && grp_g == 16) { if constexpr (W == 4) hipLaunchKernelGGL((k_steps_grp<W, 16, true, 2>), dim3(ggrid), dim3(256), lds_bytes_grp, c->stream, a); }
+                    else hipLaunchKernelGGL((k_steps_grp<W, 32, true, 2>), dim3(ggrid), dim3(256), lds_bytes_grp, c->stream, a);
+                    if (grp_wide_seen || grp_rounds < (uint64_t)batch) hipLaunchKernelGGL((k_steps_grp<W, 32, false, 1>), dim3((K + 7) / 8), dim3(256), lds_bytes_grp32, c->stream, a);
+                    grp_rounds++;
+                }
+            }
             else if (dense && seq && spec) hipLaunchKernelGGL((k_steps<W, false, false, true, 4, true, true>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
             else if (dense && seq) hipLaunchKernelGGL((k_steps<W, false, false, true, 4, true>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
             else if (dense) hipLaunchKernelGGL((k_steps<W, false, false, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
@@ -2919,6 +2970,10 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
+        if (grp) {
+            if (h_stats[ST_WIDE]) grp_wide_seen = true;
+            if (h_stats[ST_WIDE + 1]) { harc_set_error("stage I: %llu chains with wide counts were left unwalked by k_steps_grp (super-round %llu)", h_stats[ST_WIDE + 1], (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
+        }
         if (*h_reseed_timeout) { harc_set_error("stage I: the workgroups of k_reseed_mg did not meet (super-round %llu); HARC_AMD_RESEED_MG=0 uses the single workgroup", (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
         // what this rank would run next, from its own clock and counters: which scan of the small bins (measured over the first two batches) and how
         // many waves per cooperative workgroup.  Every variant computes the same bytes; design (R) still runs rank 0's choice on all ranks (below), so
@@ -3018,6 +3073,16 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         fprintf(stderr, "[k_steps timing] per step: batches %.2f  max-lane slot iterations %.2f  max-lane scan iterations %.2f  total scan iterations %.2f  lanes probing %.1f\n",
                 d[10] / st, d[8] / st, d[9] / st, d[11] / st, d[12] / st);
     }
+#endif
+#ifdef HARC_GRP_STATS
+    if (a.dbg && grp) {
+        unsigned long long d[24];
+        HIP_TRY(hipMemcpy(d, dbg_ptr, sizeof d, hipMemcpyDeviceToHost));
+        const double w = (double)(d[0] ? d[0] : 1);
+        fprintf(stderr, "[k_steps_grp] us per wave by phase: take %.1f, rows %.1f, keys + bitmap issue %.1f, bitmap wait + table %.1f, candidates %.1f, step end + seeds %.1f, finish %.1f\n", d[16] / w / 100.0, d[17] / w / 100.0, d[18] / w / 100.0, d[19] / w / 100.0, d[20] / w / 100.0, d[21] / w / 100.0, d[22] / w / 100.0);
+        fprintf(stderr, "[k_steps_grp] waves %llu over %llu launches; per wave: slots %.1f, live groups per slot %.2f, slots with a take %.1f, with a finish %.1f, with a hit %.1f, candidate turns %.1f; wave life %.1f us mean, %.1f us longest (100 MHz clock)\n",
+                d[0], (unsigned long long)launches, d[1] / w, (double)d[2] / (double)(d[1] ? d[1] : 1), d[3] / w, d[4] / w, d[6] / w, d[5] / w, d[7] / w / 100.0, d[8] / 100.0);
+    } else
 #endif
     if (a.dbg) {
         unsigned long long d[48];

@@ -37,6 +37,10 @@ def _synth_text(n, L, G, err, seed):
     ("configs1", 3_300_000, 100, 6_300_000, 0.005, 8, False, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_RESEED_MG": "1"}),
     # ... in its specialised form (SPEC: needs the bitmap lines by minimizer, which a 3.3 M-read bitmap gets only when told so)
     ("configs1", 3_300_000, 100, 6_300_000, 0.005, 8, False, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0"}),
+    # ... and with two chains per wave (k_steps_grp; HARC_AMD_GRP=2 fails the run if that kernel cannot be the one that walks)
+    ("configs1", 3_300_000, 100, 6_300_000, 0.005, 8, False, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_GRP": "2"}),
+    ("configs0", 1_000_000, 100, 35_000_000, 0.0, 8, True, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_GRP": "2", "HARC_AMD_RESEED_MG": "1"}),
+    ("configs1", 3_300_000, 100, 6_300_000, 0.005, 8, False, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_GRP": "2", "HARC_AMD_GRP_WIDE": "1", "HARC_AMD_GRP_WIDE_LIMIT": "40"}),      # at 52x half of the chains are beyond 40 in some column
     ("configs0", 1_000_000, 100, 35_000_000, 0.0, 8, True, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_RESEED_MG": "1", "HARC_AMD_S1BLOOM_TILED": "1", "HARC_AMD_S1BLOOM_VERIFY": "1"})])
 def test_config_size_matches_oracle(name, n, L, G, err, E, expect_lowcov, env, oracle, tmp_path, monkeypatch):
     import harc_amd

@@ -223,6 +223,12 @@ def test_low_complexity_big_bins_match_oracle(n, glen, K, S, E, err, oracle, tmp
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0"},      # the specialised dense kernel (k_steps' SPEC) ...
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_SPEC": "0"},      # ... and the general one under the same conditions
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_LAZY": "0"},
+                                 {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_GRP": "2"},      # two chains per wave (k_steps_grp; 2 = fail if it cannot run)
+                                 {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_GRP": "2", "HARC_AMD_LAZY": "0"},
+                                 {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_GRP": "2", "HARC_AMD_RESEED_MG": "1", "HARC_AMD_WEEDMIN": "1"},
+                                 {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_GRP": "2", "HARC_AMD_GRP_G": "32"},      # two chains per wave instead of four
+                                 {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_GRP": "2", "HARC_AMD_GRP_WIDE": "1", "HARC_AMD_GRP_WIDE_LIMIT": "6"},      # chains with a count above 6 change to the u32 form of the kernel
+                                 {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_GRP": "2", "HARC_AMD_GRP_G": "32", "HARC_AMD_GRP_WIDE": "1", "HARC_AMD_GRP_WIDE_LIMIT": "2", "HARC_AMD_LAZY": "0"},
                                  {"HARC_AMD_LEFT_ALL": "1"},      # the leftover reads emitted by a pass over all candidates instead of over their list
                                  {"HARC_AMD_TABLE_FILL": "0"}, {"HARC_AMD_TABLE_FILL": "1"}, {"HARC_AMD_SORT_BITS": "8"}, {"HARC_AMD_SORT_BITS": "13"}, {"HARC_AMD_SORT_BITS": "1"}, {"HARC_AMD_SORT_BITS": "64"},
                                  {"HARC_AMD_S2BLOOM_TILED": "1", "HARC_AMD_S2BLOOM_VERIFY": "1"}, {"HARC_AMD_S2BLOOM_TILED": "1", "HARC_AMD_S2BLOOM_VERIFY": "1", "HARC_AMD_BLOOM4_HASHED": "1"},

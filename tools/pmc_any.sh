@@ -11,7 +11,7 @@ import csv,sys,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k=r["Kernel_Name"][:56]
-    if "k_steps<" not in k: continue
+    if "k_steps" not in k: continue
     agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
 for k in sorted(agg):
     print(sys.argv[2], k, "launches", max(cnt[(k,c)] for c in agg[k]))
