@@ -208,6 +208,8 @@ WORKLOADS = {
     "c4s": (50_000_000, 101, 191_000_000, 0.01, "configs[3] at 1/16 scale: 50M x 101bp, 191 Mbp i.i.d. genome (26x), 1% substitutions (1/4 N)"),
     "c5s": (250_000_000, 150, 194_000_000, 0.01, "configs[4] at 1/16 scale: 250M x 150bp, 194 Mbp i.i.d. genome (193x), 1% substitutions (1/4 N), -p (pack_order inside the step)"),
     "c5g": (500_000_000, 150, 388_000_000, 0.01, "configs[4]: ONE GPU's share of the 8-GPU run, 500M x 150bp, 388 Mbp i.i.d. genome (193x), 1% substitutions (1/4 N: 31 % of the reads carry an N), -p (pack_order inside the step)"),
+    "c3r": (350_000_000, 100, 3_100_000_000, 0.0, "configs[2] with a human-like repeat content: 350M x 100bp error-free on a 3.1 Gbp genome of which 10 % is one diverged family of 300-mers (1 M copies, 12 %), 2 % a family of 6-kb elements (10 000 copies, 5 %), plus 30 000 poly-A and (CA)n runs and 2000 tandem arrays of a 171-mer"),
+    "c4r": (810_000_000, 101, 3_100_000_000, 0.01, "configs[3] with a human-like repeat content (the shape of ERR194146): 810M x 101bp, 1 % errors, on a 3.1 Gbp genome of which 10 % is one diverged family of 300-mers (1 M copies, 12 %), 2 % a family of 6-kb elements (10 000 copies, 5 %), plus 30 000 poly-A and (CA)n runs and 2000 tandem arrays of a 171-mer"),
     "c3sd": (50_000_000, 100, 443_000_000, 0.005, "50M x 100bp on a 443 Mbp genome with a diverged repeat family: 100000 copies of one 300-bp element (12 % divergence), 3000 poly-A and 3000 (CA)n runs"),
     "c3m": (4_000_000, 100, 35_400_000, 0.0, "configs[2] at 1/88 scale: 4M x 100bp error-free, 35.4 Mbp i.i.d. genome (11.3x)"),
     "mini": (200_000, 100, 400_000, 0.005, "smoke-sized: 200k x 100bp, 0.4 Mbp genome"),
@@ -228,7 +230,43 @@ def synth_chunks(n, L, G, err, seed, dev, spike=None):
     for s in range(0, G, 1 << 28):
         m = min(1 << 28, G - s)
         genome[s:s + m] = lut[torch.randint(0, 4, (m,), generator=g, device=dev)]
-    if spike:                                                    # repeats and low-complexity runs: hot dictionary bins
+    if isinstance(spike, dict):
+        # a human-like repeat content (what ERR194146 has and an i.i.d. genome lacks): interspersed families -- `fam`: (copies, element length,
+        # per-copy divergence) each, every copy diverged from its family's element on its own and dropped into a slot of its own --, homopolymer
+        # and dinucleotide runs, and tandem arrays of a short monomer (`sat`: (arrays, monomer length, monomers per array, per-monomer divergence))
+        for ncopy, flen, div in spike.get("fam", []):
+            rep = torch.randint(0, 4, (flen,), generator=g, device=dev, dtype=torch.uint8)
+            slot_bp = flen + 100
+            pos = torch.randperm(G // slot_bp, generator=g, device=dev)[:ncopy] * slot_bp
+            CHK = max(1, (1 << 26) // flen)                        # copies per piece: the index tensor stays below a GiB
+            ar_f = torch.arange(flen, device=dev)
+            for a in range(0, int(pos.shape[0]), CHK):
+                pp = pos[a:a + CHK]
+                cp = rep[None, :].repeat(pp.shape[0], 1)
+                if div > 0:
+                    mut = torch.rand((pp.shape[0], flen), generator=g, device=dev) < div
+                    cp = torch.where(mut, (cp + torch.randint(1, 4, (pp.shape[0], flen), generator=g, device=dev, dtype=torch.uint8)) % 4, cp)
+                genome[(pp[:, None] + ar_f[None, :]).reshape(-1)] = lut[cp.reshape(-1).long()]
+                del cp
+        ar150 = torch.arange(150, device=dev)
+        if spike.get("polya", 0):
+            pa = torch.randint(0, G - 400, (spike["polya"],), generator=g, device=dev)
+            genome[(pa[:, None] + ar150[None, :]).reshape(-1)] = ord("A")
+        if spike.get("ca", 0):
+            pc = torch.randint(0, G - 400, (spike["ca"],), generator=g, device=dev)
+            ca = torch.tensor(list(b"CA" * 75), dtype=torch.uint8, device=dev)
+            genome[(pc[:, None] + ar150[None, :]).reshape(-1)] = ca.repeat(pc.shape[0])
+        if spike.get("sat"):
+            narr, mlen, nmono, sdiv = spike["sat"]
+            mono = torch.randint(0, 4, (mlen,), generator=g, device=dev, dtype=torch.uint8)
+            alen = mlen * nmono
+            ps = torch.randperm(G // (alen + 100), generator=g, device=dev)[:narr] * (alen + 100)
+            cp = mono[None, :].repeat(int(ps.shape[0]) * nmono, 1)
+            mut = torch.rand(cp.shape, generator=g, device=dev) < sdiv
+            cp = torch.where(mut, (cp + torch.randint(1, 4, cp.shape, generator=g, device=dev, dtype=torch.uint8)) % 4, cp)
+            genome[(ps[:, None] + torch.arange(alen, device=dev)[None, :]).reshape(-1)] = lut[cp.reshape(-1).long()]
+            del cp
+    elif spike:                                                  # repeats and low-complexity runs: hot dictionary bins
         ncopy, div, npolya, nstr = spike
         rep = torch.randint(0, 4, (300,), generator=g, device=dev)
         pos = torch.randperm(G // 400, generator=g, device=dev)[:ncopy] * 400     # distinct 400-bp slots: copies never overlap
@@ -268,7 +306,24 @@ def synth_reads(n, L, G, err, seed, dev, spike=None):
 
 
 # workload -> (copies of a 300-bp element, per-copy divergence, poly-A runs, (CA)n runs) put into the genome
-SPIKES = {"c2r": (2000, 0.0, 200, 0), "c2d": (10000, 0.12, 300, 300), "c3sd": (100000, 0.12, 3000, 3000)}
+SPIKES = {"c2r": (2000, 0.0, 200, 0), "c2d": (10000, 0.12, 300, 300), "c3sd": (100000, 0.12, 3000, 3000),
+          # the human-like repeat content of the BASELINE-sized repeat workloads: a tenth of the genome in one diverged family of short elements (an Alu-like
+          # 300-mer, a million copies, 12 % apart from the element), 2 % in a family of long ones (6 kb x 10 000, 5 %), poly-A and (CA)n runs, and tandem
+          # arrays of a 171-base monomer (2000 arrays x 18 monomers, 2 % apart: the centromeric kind of bin that holds tens of thousands of reads)
+          "c4r": {"fam": [(1_000_000, 300, 0.12), (10_000, 6000, 0.05)], "polya": 30_000, "ca": 30_000, "sat": (2000, 171, 18, 0.02)},
+          "c3r": {"fam": [(1_000_000, 300, 0.12), (10_000, 6000, 0.05)], "polya": 30_000, "ca": 30_000, "sat": (2000, 171, 18, 0.02)}}
+
+
+def scale_spike(spike, f):
+    """the repeat content of a genome f times the size (side legs on a sample: same fractions of the genome, same copy-number RATIOS would need the
+    same genome; what is kept is the share of the genome every kind of repeat takes)"""
+    if not isinstance(spike, dict):
+        return spike
+    out = {"fam": [(max(1, int(n * f)), fl, d) for n, fl, d in spike.get("fam", [])], "polya": max(1, int(spike.get("polya", 0) * f)), "ca": max(1, int(spike.get("ca", 0) * f))}
+    if spike.get("sat"):
+        a, m, k, d = spike["sat"]
+        out["sat"] = (max(1, int(a * f)), m, k, d)
+    return out
 
 
 def install_synthetic(h, n, L, G, err, seed, dev, spike=None):
@@ -403,6 +458,37 @@ def stage2_blobs(h, shards):
     return out
 
 
+def run_other_config(harc_amd, name, dev_index, dev, shards, steps=2):
+    """one of the other BASELINE configurations on this GPU: 1 warm-up (pool growth) + `steps` timed reorder + encode (+ pack_order) passes,
+    timed like the main line (reads resident in HBM -> streams in pinned host memory), then the round trip on all reads"""
+    n, L, G, err, desc = WORKLOADS[name]
+    h = harc_amd.HarcAmd(harc_amd.default_params(L, num_thr=shards, device=dev_index, profile=1))
+    try:
+        sig_in = install_synthetic(h, n, L, G, err, 1000, dev, SPIKES.get(name))
+        po = name in ("c5s", "c5g")
+
+        def step():
+            h.reorder(); h.encode()
+            if po:
+                h.pack_order()
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        c = h.counters()
+        dsig = h.decode_signature()
+        return {"value": round(n * steps / dt / 1e6, 3), "unit": "Mreads/s", "steps": steps, "warmup": 1, "ms_per_step": round(dt / steps * 1e3, 2), "description": desc,
+                "phases_ms_last_step": {"index": round(c.index_ms, 2), "chain": round(c.chain_ms, 2), "encode": round(c.encode_ms, 2)},
+                "k_steps_avg_launch_us": round(c.propose_ms / max(1, c.propose_launches) * 1e3, 2), "rounds": int(c.rounds), "chains": int(c.chains),
+                "roundtrip": {"ok": bool(tuple(dsig) == tuple(sig_in)), "reads_decoded": int(dsig[0]), "reads_in": int(sig_in[0])},
+                "device_bytes_peak": int(c.device_bytes_peak)}
+    finally:
+        h.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -417,6 +503,7 @@ def main():
     ap.add_argument("--no-side-legs", action="store_true", help="N>1: skip rank 0's GPU side legs after the timed region (n1_equivalent, size_vs_1gpu) -- the peers wait for them in the final barrier")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket exchange even at world size 1 (exercises the N>1 path on one GPU)")
     ap.add_argument("--cpu-sample", type=int, default=0)
+    ap.add_argument("--no-other-configs", action="store_true", help="default workload on one GPU: skip the side lines for configs[3] (c4) and configs[4]'s share (c5g), 2 timed steps each after the main line's timed region")
     ap.add_argument("--mg-mode", default="bucket", choices=["bucket", "replicate"],
                     help="N>1: bucket = minimizer-bucket shard + one all-to-all, independent shards (north_star; larger archives); replicate = design (R): "
                          "all-gather of the reads, chains partitioned over the GPUs, one all-gather of the walked steps per super-round -- every GPU "
@@ -539,7 +626,8 @@ def main():
     # shards -- a read lost, duplicated or altered anywhere between the slice and the streams (the all-to-all included) shows.
     dsig = h.decode_signature()
     seq_bases_total, reads_total = int(c.seq_bases), n
-    s2_part = world > 1 and os.environ.get("HARC_AMD_S2_PART", "1") != "0"      # design (R): stage II partitioned over the ranks by encoder shard (the default)
+    s2_env = os.environ.get("HARC_AMD_S2_PART", "1")
+    s2_part = (world > 1 and s2_env != "0") or (replicate and s2_env == "2")      # design (R): stage II partitioned over the ranks by encoder shard (the default from two ranks on; 2: also at world 1, so that its collectives run)
     if replicate and not s2_part:
         reads_total = n * world                                   # every rank decoded the WHOLE job: its signature alone must equal all ranks' inputs
     elif dist is not None:
@@ -611,6 +699,7 @@ def main():
                                "bytes differ from the reference's -t 1, which is num_chains = 1: see exact_mode)",
                    "parallelism": "single GPU" if world == 1 and dist is None else (f"design (R) x{world}: reads all-gathered, index replicated, chains partitioned, one all-gather of the walked steps per super-round; stage II partitioned by encoder shard with one all-reduce(min) of the claims; the ranks' stream files are the single-GPU archive" if replicate else f"minimizer-bucket shard x{world}, one RCCL all-to-all (8W+4 B per read) inside every step")},
         "roofline": roofline,
+        "stage2_mode": ("partitioned by encoder shard over the ranks, one all-reduce(min) of the claims" if (replicate and s2_part) else "replicated on every rank" if replicate else "independent per shard" if dist is not None else "single GPU"),
         "build_id": harc_amd.build_id(),
         "roundtrip": roundtrip,
         "phases_ms_last_step": {"index": round(c.index_ms, 2), "chain": round(c.chain_ms, 2), "encode": round(c.encode_ms, 2)},
@@ -637,7 +726,10 @@ def main():
     # ---- bounded side legs on rank 0 (outside the timed region): a sample of the same generator at the same coverage and error rate
     if rank == 0 and (not args.no_cpu or (dist is not None and not args.no_side_legs)):
         ns = args.cpu_sample or min(n, 3_300_000 if err > 0 or G // max(1, n) < 10 else 1_000_000)
-        if spike:
+        if isinstance(spike, dict):                               # the BASELINE-sized repeat workloads: a sample genome with the same SHARES of every kind of repeat
+            ns = args.cpu_sample or 3_300_000
+            Gs = max(L * 4, int(G * (ns / n))); sspike = scale_spike(spike, ns / n)
+        elif spike:
             Gs, sspike = G, spike                                 # repeat-spiked genomes are not scaled: same genome, fewer reads would change the coverage
             ns = n
         else:
@@ -691,7 +783,8 @@ def main():
             refdir = os.path.join(ROOT, "oracle", "_ref")
             nz = min(ns, 1_000_000)
             if os.path.exists(os.path.join(refdir, f"reorder_L{L}_t8.out")):
-                zs = sample[:nz].contiguous() if sspike else synth_reads(nz, L, max(L * 4, int(Gs * (nz / ns))), err, 997, dev, None)
+                if isinstance(spike, dict): zs = synth_reads(nz, L, max(L * 4, int(G * (nz / n))), err, 997, dev, scale_spike(spike, nz / n))
+                else: zs = sample[:nz].contiguous() if sspike else synth_reads(nz, L, max(L * 4, int(Gs * (nz / ns))), err, 997, dev, None)
                 # the sample is run with the workload's reads per chain (a 1 M-read sample at the automatic chain count would be cut into
                 # shorter chains than the 350 M-read workload is): what the workload's schedule costs in compressed size
                 rpc_eff = max(1.0, float(c.n_clean) / max(1, int(c.chains)))
@@ -703,6 +796,22 @@ def main():
                 out["size_vs_reference_t8"] = {"value": round(ours / max(1, theirs), 4), "unit": "xz -6 bytes of all stage-II streams, this build (default schedule) / reference -t 8",
                                                "ours_bytes": ours, "reference_bytes": theirs, "sample": f"{nz} reads, same coverage, one chain per {rpc_eff:.0f} reads as in the timed workload"}
         del sample
+    # ---- the other BASELINE configurations that fit one GPU, on the same line (outside the timed region, after the context of the main
+    #      workload is gone): configs[3] on ONE GPU (c4: 810 M x 101 bp, 1 % errors) and one GPU's share of configs[4] (c5g: 500 M x 150 bp, 31 %
+    #      of the reads with N, pack_order inside the step) -- one warm-up + 2 timed steps each, round trip checked on all reads; bounded in wall time
+    if rank == 0 and world == 1 and dist is None and args.workload == "c3" and not args.no_other_configs and not args.no_cpu:
+        out["other_configs"] = {}
+        t_other = time.perf_counter()
+        for name in ("c4", "c5g"):
+            if time.perf_counter() - t_other > 100.0:            # c4 took long on this box: the line must not
+                out["other_configs"][name] = {"skipped": "wall-time bound of the side lines reached"}
+                continue
+            try:
+                out["other_configs"][name] = run_other_config(harc_amd, name, local, dev, args.shards)
+            except Exception as e:                                # a side line never takes the main line down
+                out["other_configs"][name] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+        out["other_configs"]["wall_s"] = round(time.perf_counter() - t_other, 1)
     if dist is not None:
         with wd.phase("final barrier (rank 0 runs the side legs meanwhile)", max(args.watchdog, 1800.0)):
             dist.barrier()

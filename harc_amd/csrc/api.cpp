@@ -11,12 +11,31 @@ void harc_set_error(const char *fmt, ...)
 }
 extern "C" const char *harc_amd_last_error(void) { return g_err; }
 
+// The empty chunks of the pool behind chunk `from` go back to the device (stack discipline: every chunk behind the one in use is empty).  Their places
+// in the list stay, as chunks of no size, so that marks keep their meaning.  For the case that the device is full of chunks too small for what is
+// asked for now (a first pass over an input whose later buffers are larger than its earlier ones: configs[3] with repeats asked for 16 GB with 119 GB
+// of the pool's 267 GB idle in 8.6-GB chunks).  Returns the bytes handed back.
+static size_t pool_hand_back(harc_amd_ctx *c, size_t from, size_t asked)
+{
+    size_t given = 0;
+    for (size_t i = 0; i < c->pool.size(); i++) {                  // (a chunk below the one in use that holds nothing was too small for what came after it)
+        harc_amd_ctx::PoolChunk &k = c->pool[i];
+        if (i == from || k.size == 0 || k.used != 0) continue;
+        (void)hipFree(k.base); c->pool_total -= k.size; given += k.size; k.base = nullptr; k.size = 0;
+    }
+    if (given) {
+        (void)hipGetLastError();
+        if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[pool] %.2f GB of empty chunks handed back for a request of %.2f GB\n", given / 1e9, asked / 1e9);
+    }
+    return given;
+}
 int harc_raw_alloc(harc_amd_ctx *c, void **p, size_t bytes)
 {
     *p = nullptr;
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess) { harc_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return HARC_AMD_ENOMEM; }
+    if (e != hipSuccess && !c->pool.empty() && pool_hand_back(c, c->pool_cur, bytes)) e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); harc_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return HARC_AMD_ENOMEM; }
     c->owned.push_back(*p);
     c->sizes[*p] = bytes;
     c->dev_bytes += bytes;
@@ -48,6 +67,7 @@ int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes)
     }
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes == 0) bytes = 256;
+    const size_t cur_in = c->pool_cur;                             // stack discipline: every chunk behind this one is empty
     for (;;) {
         if (c->pool_cur < c->pool.size()) {
             harc_amd_ctx::PoolChunk &k = c->pool[c->pool_cur];
@@ -56,12 +76,15 @@ int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes)
         }
         size_t want = bytes;
         const size_t grow = c->pool_total < ((size_t)8 << 30) ? c->pool_total : ((size_t)8 << 30);
-        if (want < grow) want = grow;
+        // small requests share large chunks; a request of more than half a chunk gets one of its own size -- an 8.6-GB chunk per 5-GB buffer left 40 % of
+        // the pool idle behind the buffers (configs[3] with repeats: 267 GB of chunks for 148 GB in use, and the next 16 GB did not exist)
+        if (want < grow / 2) want = grow;
         if (want < ((size_t)64 << 20)) want = (size_t)64 << 20;
         void *base = nullptr;
         hipError_t e = hipMalloc(&base, want);
         if (e != hipSuccess && want > bytes) { want = bytes; e = hipMalloc(&base, want); }
-        if (e != hipSuccess) { harc_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return HARC_AMD_ENOMEM; }
+        if (e != hipSuccess && !c->pool.empty() && pool_hand_back(c, cur_in, bytes)) e = hipMalloc(&base, want);
+        if (e != hipSuccess) { (void)hipGetLastError(); harc_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return HARC_AMD_ENOMEM; }
         if (getenv("HARC_AMD_POISON")) (void)hipMemset(base, 0xA5, want);   // debugging aid: make reads of uninitialised pool memory show
         if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[pool] chunk %zu: %.2f GB for a request of %.2f GB (pool %.2f GB, in use %.2f GB)\n", c->pool.size(), want / 1e9, bytes / 1e9, (c->pool_total + want) / 1e9, pool_in_use(c) / 1e9);
         c->pool.push_back({ (char *)base, want, 0 });
@@ -355,10 +378,16 @@ extern "C" int harc_amd_encode(harc_amd_ctx *c)
     c->s2_part = false; c->s2_e0 = 0; c->s2_e1 = 0;
     uint32_t oi0 = 0, oi1 = 0xFFFFFFFFu;
     int simr = 0, simw = 0;
-    // HARC_AMD_S2_SIM=rank/world (profiling only): what ONE rank of a partitioned stage II computes, without peers -- no all-reduce, so the claims of
-    // the other ranks' columns are missing and the streams are NOT an archive; tools/s2_share.py times configs[3]'s share with it
+#ifdef HARC_AMD_EXPERIMENTS
+    // HARC_AMD_S2_SIM=rank/world (profiling only, `make EXPERIMENTS=1` builds only: the streams it leaves are NOT an archive): what ONE rank of a
+    // partitioned stage II computes, without peers -- no all-reduce, so the claims of the other ranks' columns are missing; tools/s2_share.sh times
+    // configs[3]'s share with it
     if (const char *e = getenv("HARC_AMD_S2_SIM")) { if (sscanf(e, "%d/%d", &simr, &simw) != 2 || simw < 2 || simr < 0 || simr >= simw) simw = 0; }
-    const bool real_part = c->replicated && c->comm && c->comm->world > 1 && !(getenv("HARC_AMD_S2_PART") && atoi(getenv("HARC_AMD_S2_PART")) == 0);
+#endif
+    // HARC_AMD_S2_PART: 1 (default) = partitioned from two ranks on; 0 = replicated; 2 = partitioned even at world 1 (tests: the all-reduce(min) of the
+    // claims and the exchange of the large-bin events then run over RCCL on a one-GPU box; the rank holds every shard, the streams are the single GPU's)
+    const int s2p = getenv("HARC_AMD_S2_PART") ? atoi(getenv("HARC_AMD_S2_PART")) : 1;
+    const bool real_part = c->replicated && c->comm && (c->comm->world > 1 || s2p == 2) && s2p != 0;
     if ((real_part || simw) && !c->s1_from_files) {
         const uint32_t E = (uint32_t)c->P.num_thr, wd = real_part ? (uint32_t)c->comm->world : (uint32_t)simw, rk = real_part ? (uint32_t)c->comm->rank : (uint32_t)simr;
         c->s2_world = (int)wd; c->s2_rank = (int)rk;

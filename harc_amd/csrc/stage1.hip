@@ -755,6 +755,11 @@ __device__ __forceinline__ bool own_has(const uint32_t *tab, uint32_t id)
         h = (h + 1u) & (HARC_OWN_SLOTS - 1u);
     }
 }
+static inline size_t steps_lds_bytes_coop(int W, int maxmatch, int nprobe)
+{
+    const int NW = 2 * W, ROW = 3 * NW + 1, MROW = (NW + 3) & ~3;
+    return ((size_t)2 * maxmatch * MROW + (size_t)((2 * ROW + 3) & ~3) + (size_t)MROW + (size_t)8 * NW + (size_t)32 + (size_t)2 * nprobe + 8) * 4 + HARC_WGCMD_BYTES + 16;
+}
 static inline size_t steps_lds_bytes(int W, int maxmatch, int nprobe, bool seq = false)
 {
     const int NW = 2 * W, ROW = 3 * NW + 1, MROW = (NW + 3) & ~3;
@@ -1217,12 +1222,15 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // [mask rows: (dir, shift) -> NW dwords][window rows: 4 waves x {ref, rref}][accepted read: 4 waves][column bytes: 4 waves x 2 x 16 NW][probes]
     // [column counts: 4 waves x LP x uint4][mask rows ...]
-    uint32_t *const s_mask = lds + (size_t)4 * ConsState<W, DENSE>::LP * 4;
+    // (the cooperative kernel walks ONE chain per workgroup with its counts in registers: no counts area and one set of rows -- 16 KB per workgroup held
+    // its one-wave form at 10 walks per compute unit where the registers allow 16)
+    constexpr int NSL = COOP ? 1 : 4;                             // chains a workgroup walks
+    uint32_t *const s_mask = lds + (COOP ? (size_t)0 : (size_t)4 * ConsState<W, DENSE>::LP * 4);
     uint32_t *const s_rows = s_mask + (size_t)2 * s.maxmatch * MROW;
-    uint32_t *const s_rdl = s_rows + 4 * 2 * ROW;
-    uint32_t *const s_tmp = s_rdl + 4 * MROW;
-    uint32_t *const s_pend = s_tmp + 4 * 8 * NW;                  // 4 waves x 64 u16: cumulative shifts of the steps whose counts are still to be applied (cons_flush)
-    uint32_t *const s_own = s_pend + 4 * 32;
+    uint32_t *const s_rdl = s_rows + ((NSL * 2 * ROW + 3) & ~3);      // (the column bytes behind it are read 16 bytes at a time)
+    uint32_t *const s_tmp = s_rdl + NSL * MROW;
+    uint32_t *const s_pend = s_tmp + NSL * 8 * NW;                // per chain 64 u16: cumulative shifts of the steps whose counts are still to be applied (cons_flush)
+    uint32_t *const s_own = s_pend + NSL * 32;
     // OWNT: the kernels that keep the reads a walk has taken in the LDS hash table -- the wave-uniform ones, and the whole-bucket kernel of runs with few
     // chains (there LDS is no limit, and exact mode walks 64 steps per launch: comparing every candidate with up to 63 earlier reads by v_readlane was
     // what made long walks slower than short ones)
@@ -1244,8 +1252,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         for (int i = threadIdx.x; i < nm; i += 64 * NWV) s_mask[i] = s.lds_tab[i];
         const uint2 *const pt = reinterpret_cast<const uint2 *>(s.lds_tab + nm);
         for (int i = threadIdx.x; i < s.nprobe; i += 64 * NWV) s_pinfo[i] = pt[i];
-        for (int i = threadIdx.x; i < 4 * 2 * ROW; i += 64 * NWV) s_rows[i] = 0u;
-        for (int i = threadIdx.x; i < 4 * 8 * NW; i += 64 * NWV) s_tmp[i] = 0u;
+        for (int i = threadIdx.x; i < NSL * 2 * ROW; i += 64 * NWV) s_rows[i] = 0u;
+        for (int i = threadIdx.x; i < NSL * 8 * NW; i += 64 * NWV) s_tmp[i] = 0u;
         if constexpr (OWNT) for (int i = threadIdx.x; i < 4 * HARC_OWN_SLOTS; i += 64 * NWV) s_own[i] = HARC_NONE;
         __syncthreads();
     }
@@ -2308,8 +2316,23 @@ template <int W> __global__ __launch_bounds__(1024) void k_compact_huge(S1Args s
     const uint2 lt = s.largetab[b];
     uint32_t *ids = const_cast<uint32_t *>(s.ids[l]) + lt.x;
     uint64_t *mir = s.mirror + (size_t)lt.y * W;
-    uint32_t out = 0;
-    for (uint32_t pos = 0; pos < cnt; pos += 1024) {
+    // Only the TOP of the bin is looked at: a scan starts at the highest id and ends with the maxsearch-th unclaimed entry (reorder.cpp:540), so all it
+    // can ever reach is the last stretch of the bin that holds maxsearch unclaimed entries.  That stretch [A, cnt) is found from the top in growing
+    // pieces and compacted in place; what lies below A keeps its claimed entries until the stretch above it has thinned out and the next passes reach
+    // down to it (A = 0: the whole bin, as before).  A bin of 130 000 reads of a diverged repeat family was 127 dependent passes of this workgroup
+    // every super-round -- the kernel lasts as long as its largest bin: 540 us per round, a seventh of the chain phase of configs[2] with repeats.
+    uint32_t A = 0;
+    for (uint32_t T = 4096; T < cnt; T *= 4) {
+        uint32_t u = 0;
+        for (uint32_t pos = cnt - T; pos < cnt; pos += 1024) {
+            if (pos + t < cnt) { const uint32_t rid = ids[pos + t]; u += ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) ? 0u : 1u; }
+        }
+        uint32_t total; (void)block_excl_scan_u32<1024>(u, sm, &total);
+        __syncthreads();
+        if (total >= (uint32_t)s.maxsearch) { A = cnt - T; break; }
+    }
+    uint32_t out = A;
+    for (uint32_t pos = A; pos < cnt; pos += 1024) {
         const bool valid = pos + t < cnt;
         uint32_t rid = 0; bool un = false; uint64_t rw[W];
         if (valid) {
@@ -2831,7 +2854,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         for (uint32_t p = 0; p < a.own_mod; p++) x_ro[p] = (size_t)p * x_bytes;
         RC_TRY(dalloc(c, &x_dig, 8));
     }
-    const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe), lds_bytes_seq = steps_lds_bytes(W, P.maxmatch, a.nprobe, true);
+    const size_t lds_bytes = steps_lds_bytes(W, P.maxmatch, a.nprobe), lds_bytes_seq = steps_lds_bytes(W, P.maxmatch, a.nprobe, true), lds_bytes_coop = steps_lds_bytes_coop(W, P.maxmatch, a.nprobe);
     const bool prof = P.profile != 0;
     // dense kernels (7 / 8 waves per SIMD) for every launch that is not QUAD (round 2: from 49 152 chains on; with the counts in LDS they pay from
     // 16 385 on: 24 k chains of configs[2] at 1/7 scale +5 %, the 21 k chains of c3sd +3.6 %)
@@ -2925,9 +2948,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (prof) HIP_TRY(hipEventRecord(pair[1], c->stream));
             // the steps that have to scan a large bin (none without such bins: the launch is skipped)
             if (nlarge) {
-                if (coop_waves == 1) hipLaunchKernelGGL((k_steps<W, true, true, false, 1>), dim3(K), dim3(64), lds_bytes, c->stream, a);
-                else if (coop_waves == 2) hipLaunchKernelGGL((k_steps<W, true, true, false, 2>), dim3(K), dim3(128), lds_bytes, c->stream, a);
-                else hipLaunchKernelGGL((k_steps<W, true, true>), dim3(K), dim3(256), lds_bytes, c->stream, a);
+                if (coop_waves == 1) hipLaunchKernelGGL((k_steps<W, true, true, false, 1>), dim3(K), dim3(64), lds_bytes_coop, c->stream, a);
+                else if (coop_waves == 2) hipLaunchKernelGGL((k_steps<W, true, true, false, 2>), dim3(K), dim3(128), lds_bytes_coop, c->stream, a);
+                else hipLaunchKernelGGL((k_steps<W, true, true>), dim3(K), dim3(256), lds_bytes_coop, c->stream, a);
             }
             if (cm) {   // ONE all-gather per super-round: header + walked steps of every chain, from the rank that walked it
                 const uint64_t tot = (uint64_t)x_nper * (8 + 2 * (uint64_t)nsteps);

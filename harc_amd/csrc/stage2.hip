@@ -1201,7 +1201,7 @@ int stage2_run(harc_amd_ctx *c)
     // drop earlier stage-II outputs
     for (auto it = c->out.begin(); it != c->out.end();) { if (it->first.first >= HARC_AMD_S2_SEQ) it = c->out.erase(it); else ++it; }
     const bool part = c->s2_part;                                 // partitioned over the ranks (harc_amd_encode decided)
-    HarcComm *const cm = (part && c->comm && c->replicated && c->comm->world > 1) ? c->comm : nullptr;       // null with HARC_AMD_S2_SIM: one rank's share without peers (profiling)
+    HarcComm *const cm = (part && c->comm && c->replicated) ? c->comm : nullptr;       // null with HARC_AMD_S2_SIM (experiment builds): one rank's share without peers (profiling); world 1 with HARC_AMD_S2_PART=2 (tests)
     const uint32_t pw = part ? (uint32_t)c->s2_world : 1u, pr = part ? (uint32_t)c->s2_rank : 0u;
     const uint32_t e0 = part ? (uint32_t)c->s2_e0 : 0u, e1 = part ? (uint32_t)c->s2_e1 : E;
     const uint32_t t0 = (uint32_t)((uint64_t)T * pr / pw), t1 = (uint32_t)((uint64_t)T * (pr + 1u) / pw);

@@ -146,6 +146,22 @@ def reads_text_bigbin_stage2_mixed(seed, n_clean=4000, n_dupN=3000, L=100, genom
     return out.tobytes()
 
 
+def reads_text_hugebin_stage1(seed, n_core=9000, n_norm=6000, L=100, genome_len=40000):
+    """stage-I bins far above maxsearch AND above the 4096 entries k_compact_huge looks at per pass: n_core reads that share bases [15, 55) (the first
+    dictionary's whole window) and are random elsewhere -- one bin of n_core reads none of which overlaps another within the Hamming threshold, thinned
+    from the top as the chains take their seeds from the descending cursor -- shuffled among ordinary reads of a small genome"""
+    rs = np.random.RandomState(seed)
+    core = rs.randint(0, 4, 40)
+    a = rs.randint(0, 4, (n_core, L))
+    a[:, 15:55] = core
+    g = rs.randint(0, 4, genome_len)
+    st = rs.randint(0, genome_len - L, n_norm)
+    b = g[st[:, None] + np.arange(L)[None, :]]
+    allr = np.concatenate([a, b])
+    allr = allr[rs.permutation(allr.shape[0])]
+    return lines_of(np.frombuffer(b"ACGT", dtype=np.uint8)[allr])
+
+
 def auto_chains(n_clean, reads_per_chain=2048, clean=None):
     """auto_chains() of harc_amd/csrc/stage1.hip: K when harc_amd_params.num_chains = 0.  clean: the clean reads ([n, L] uint8 array or
     the lines of input_clean.dna) for the low-coverage rule of stage1_run_w -- more than 98 % distinct first-dictionary k-mers: up to

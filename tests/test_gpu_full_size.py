@@ -95,6 +95,30 @@ def test_configs3_810M_x_101bp_one_gpu():
         _free()
 
 
+@pytest.mark.parametrize("workload", ["c3r", "c4r"])
+def test_human_like_repeats_at_baseline_size(workload, monkeypatch):
+    """configs[2] / configs[3] with the repeat content the real data sets have and an i.i.d. genome lacks (SURVEY.md 8d "add a repeat-spiked variant";
+    bench.py SPIKES: a tenth of the genome in a diverged family of 300-mers, a family of 6-kb elements, poly-A / (CA)n runs, tandem arrays of a 171-mer):
+    bins of thousands of reads, cooperative walks, bins above maxsearch in stage II -- at 350 M / 810 M reads.  Lossless; two runs agree; the two scans of
+    the small bins (HARC_AMD_SEQ=0/1), which a run of this kind chooses between by measuring, give the same digest."""
+    monkeypatch.delenv("HARC_AMD_SEQ", raising=False)
+    h, sig_in, (n, L, G, err) = _ctx(workload)
+    try:
+        d0, c0 = _run(h)
+        assert c0["n_clean"] + c0["n_N"] == n and c0["n_main"] + c0["n_singleton"] == c0["n_clean"]
+        assert h.decode_signature() == sig_in, f"{workload}: the decoded streams are not the input reads"
+        for env in ({"HARC_AMD_SEQ": "0"}, {"HARC_AMD_SEQ": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            dv, cv = _run(h)
+            for k in env:
+                monkeypatch.delenv(k)
+            assert dv == d0 and cv == c0, f"{workload}: variant {env} differs"
+    finally:
+        h.close()
+        _free()
+
+
 def test_configs4_share_500M_x_150bp_pack_order():
     """configs[4]: what ONE of the 8 GPUs gets -- 500 M x 150 bp, 193x, 1 % substitutions (31 % N reads), -p: pack_order inside the run"""
     h, sig_in, (n, L, G, err) = _ctx("c5g")

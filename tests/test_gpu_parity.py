@@ -212,6 +212,21 @@ def test_low_complexity_big_bins_match_oracle(n, glen, K, S, E, err, oracle, tmp
     assert_same(ol.read_dir(base), s2, ol.stage2_files(E), "low-complexity stage II vs oracle")
 
 
+@pytest.mark.parametrize("K,S", [(12, 16), (1, 64), (40, 8)])
+def test_huge_bin_compacted_from_its_top_matches_oracle(K, S, oracle, tmp_path):
+    """a stage-I bin of 9000 reads (k_compact_huge: only the stretch at the top of the bin that a scan can reach -- maxsearch unclaimed entries -- is
+    compacted each super-round, the rest when the passes get down to it): the scans see what the oracle's serial scan over the whole bin sees"""
+    import harc_amd
+    txt = gen.reads_text_hugebin_stage1(2026)
+    (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, K, 2, tmp_path / "o", S)
+    base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.reorder(base, 100, num_chains=K, num_steps=S)
+    assert_same(ol.read_dir(base), s1, ol.STAGE1_FILES, "huge-bin stage I vs oracle")
+    harc_amd.encoder(base, 100, num_thr=2)
+    assert_same(ol.read_dir(base), s2, ol.stage2_files(2), "huge-bin stage II vs oracle")
+
+
 @pytest.mark.parametrize("env", [{"HARC_AMD_QUAD": "0"}, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1"},
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_S1BLOOM_MZMB": "0"}, {"HARC_AMD_S1BLOOM_MZMB": "0"},
                                  {"HARC_AMD_S1BLOOM": "0"}, {"HARC_AMD_BLOOM4_HASHED": "1"}, {"HARC_AMD_BLOOM1": "1"}, {"HARC_AMD_CAPMULT": "2"},

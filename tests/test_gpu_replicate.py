@@ -193,7 +193,19 @@ RCCL_WORKER = textwrap.dedent("""
             h.comm_barrier()
         h.close()
         return out
-    assert run(True) == run(False)
+    one = run(False)
+    assert run(True) == one
+    # ... and stage II PARTITIONED at world 1 (HARC_AMD_S2_PART=2): the all-reduce(min) of the claims and the exchange of the large-bin events go
+    # through RCCL on this one GPU; the rank owns every encoder shard, so the streams are the single GPU's
+    os.environ["HARC_AMD_S2_PART"] = "2"
+    assert run(True) == one
+    txt = gen.reads_text_bigbin_stage2(77, n_dupN=2500)      # bins above maxsearch in stage II: their probes travel with their window words
+    arr = np.frombuffer(txt, dtype=np.uint8).reshape(-1, L + 1)[:, :L].copy()
+    hasN = (arr == ord("N")).any(1)
+    K = 4
+    part = run(True)
+    os.environ["HARC_AMD_S2_PART"] = "0"
+    assert part == run(True) == run(False)
     dist.destroy_process_group()
     print("RCCL_OK")
 """) % ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS an experiments build (make -C harc_amd/csrc clean && make -C harc_amd/csrc EXPERIMENTS=1): a product build does not read HARC_AMD_S2_SIM
 # What ONE rank of an N-rank design-(R) run computes in stage II, measured on one GPU (HARC_AMD_S2_SIM=rank/world: the partition without
 # peers; the claims of the other ranks' columns are missing, so the round trip of this run fails by construction):  tools/s2_share.sh <tag> <workload> <world>
 R=$1; W=$2; N=$3
