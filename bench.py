@@ -101,11 +101,16 @@ def launch_ranks(args, argv):
             pass
         child.wait()
 
+    class _Signalled(BaseException):
+        pass
+
     def on_signal(signum, frame):
-        # Ctrl-C, a harness timeout, SIGTERM: the ranks sit in sessions of their own and would run on as orphans on the GPUs
-        print(f"bench.py: signal {signum}: ending process {child.pid} and its descendants", file=sys.stderr)
-        end_tree()
-        sys.exit(128 + signum)
+        # Ctrl-C, a harness timeout, SIGTERM: the ranks sit in sessions of their own and would run on as orphans on the GPUs.  The handler only
+        # raises: the tree is ended by the try / finally below, OUTSIDE signal context (the main thread may be inside Popen.wait()'s lock when the
+        # signal lands; terminating and waiting for the child from in here could deadlock on it)
+        got[0] = signum
+        raise _Signalled()
+    got = [0]
     for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
         signal.signal(sg, on_signal)
 
@@ -125,8 +130,15 @@ def launch_ranks(args, argv):
             print(f"bench.py: the {args.gpus} ranks did not finish within {args.launch_timeout} s: ending process {child.pid} and its descendants", file=sys.stderr)
             end_tree()
             rc = 124
+        except _Signalled:
+            for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+                signal.signal(sg, signal.SIG_IGN)                 # one tree kill is under way: a second signal changes nothing
+            print(f"bench.py: signal {got[0]}: ending process {child.pid} and its descendants", file=sys.stderr)
+            rc = 128 + got[0]
     finally:
-        end_tree()                                                # any other way out (an exception in this process): the same tree kill
+        end_tree()                                                # every way out (a signal, an exception in this process): the same tree kill, once the wait is over
+    if got[0]:
+        sys.exit(rc)
     th.join(timeout=10)
     if rc == 0 and line[0] is None:
         print("bench.py: the ranks finished without a result line", file=sys.stderr)

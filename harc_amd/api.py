@@ -15,7 +15,7 @@ class Params(C.Structure):
     """harc_amd_params == src/config.h macros (harc:52-63)"""
     _fields_ = [("readlen", C.c_int32), ("num_thr", C.c_int32), ("num_chains", C.c_int32), ("maxmatch", C.c_int32),
                 ("thresh", C.c_int32), ("thresh_s", C.c_int32), ("maxsearch", C.c_int32), ("dict_start", C.c_int32 * 2),
-                ("dict_end", C.c_int32 * 2), ("device", C.c_int32), ("profile", C.c_int32), ("num_steps", C.c_int32), ("reads_per_chain", C.c_int32), ("decode_memory_gb", C.c_int32), ("stream_digest", C.c_int32)]
+                ("dict_end", C.c_int32 * 2), ("device", C.c_int32), ("profile", C.c_int32), ("num_steps", C.c_int32), ("reads_per_chain", C.c_int32), ("decode_memory_gb", C.c_int32), ("stream_digest", C.c_int32), ("table_slots_per_read", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -106,12 +106,13 @@ def _check(rc):
         raise HarcAmdError(rc, lib().harc_amd_last_error().decode(errors="replace"))
 
 
-def default_params(readlen, num_thr=8, num_chains=0, device=0, profile=0, num_steps=0, reads_per_chain=0, stream_digest=0):
+def default_params(readlen, num_thr=8, num_chains=0, device=0, profile=0, num_steps=0, reads_per_chain=0, stream_digest=0, table_slots_per_read=0):
     p = Params()
     _check(lib().harc_amd_default_params(readlen, C.byref(p)))
     p.num_thr, p.num_chains, p.device, p.profile, p.num_steps = num_thr, num_chains, device, profile, num_steps
     p.reads_per_chain = reads_per_chain
     p.stream_digest = stream_digest
+    p.table_slots_per_read = table_slots_per_read      # 0: the library chooses (4, 3 or 2 by free memory); include/harc_amd.h
     return p
 
 

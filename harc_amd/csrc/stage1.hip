@@ -1967,15 +1967,33 @@ template <int G> __device__ __forceinline__ void resolve_body(const S1Args &s, c
     // the pages the chain's gm new main records go to: its newest page holds record (n_main - 1), new ones come from the counter
     // (pages are handed out PG_CHUNK at a time: one atomic on the shared counter per 512 records of a chain -- one per page was 14 000 atomics on
     // one address per super-round at configs[2] and doubled this kernel's time)
-    uint32_t pcur = 0, pnew = 0, qcur = 0;
+    uint32_t pcur = 0, pnew = 0, qcur = 0, qlast = 0;
+    bool wantchunk = false;
     if (act && sl == 0 && v > 0 && gm > 0) {
         pcur = s.pg_cur[c];                                       // first page of the chunk that holds record n_main - 1
         qcur = ((h.n_main ? h.n_main - 1u : 0u) >> 6) / PG_CHUNK; // number of that chunk inside the chain
-        const uint32_t qlast = ((h.n_main + gm - 1u) >> 6) / PG_CHUNK;      // at most the next one: 2 S <= 128 records a round, 512 a chunk
-        if (qlast != qcur) {
-            pnew = atomicAdd(s.pg_count, (unsigned int)PG_CHUNK);
-            for (uint32_t k = 0; k < PG_CHUNK; k++) s.pg_hdr[pnew + k] = make_uint2(c, qlast * PG_CHUNK + k);
-            s.pg_cur[c] = pnew;
+        qlast = ((h.n_main + gm - 1u) >> 6) / PG_CHUNK;           // at most the next one: 2 S <= 128 records a round, 512 a chunk
+        wantchunk = qlast != qcur;
+    }
+    // The chains of a run march in step: they all fill their chunk of 512 records within a few super-rounds of each other, and every 32nd round or so
+    // nearly all 65 536 of them asked the ONE counter for their next chunk in the same launch -- 65 536 atomics on one address, +150 us of this kernel
+    // (profiles/r04/ksteps_profile_c3.txt: k_resolve 61 -> 210 us at rounds 32, 64, 96 ..., fading as the chains drift apart).  The workgroup asks once
+    // for all its chains (which page a chain gets is not visible in the output: k_pages_out goes by pg_hdr).
+    {
+        __shared__ uint32_t sh_cnt, sh_base;
+        if (__syncthreads_or(wantchunk ? 1 : 0)) {
+            if (threadIdx.x == 0) sh_cnt = 0u;
+            __syncthreads();
+            uint32_t myrank = 0;
+            if (wantchunk) myrank = atomicAdd(&sh_cnt, 1u);
+            __syncthreads();
+            if (threadIdx.x == 0) sh_base = atomicAdd(s.pg_count, sh_cnt * (unsigned int)PG_CHUNK);
+            __syncthreads();
+            if (wantchunk) {
+                pnew = sh_base + myrank * PG_CHUNK;
+                for (uint32_t k = 0; k < PG_CHUNK; k++) s.pg_hdr[pnew + k] = make_uint2(c, qlast * PG_CHUNK + k);
+                s.pg_cur[c] = pnew;
+            }
         }
     }
     pcur = __shfl(pcur, g0, 64); pnew = __shfl(pnew, g0, 64); qcur = __shfl(qcur, g0, 64);
@@ -2472,7 +2490,8 @@ int harc_dict_alloc(harc_amd_ctx *c, DictDev *d, uint32_t n, uint64_t cap_like)
         unsigned long long m = 4;
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) { fr += c->pool_total; while (m > 2 && ((double)m * n * sizeof(HashSlot) > 0.2 * (double)fr || (double)m * n * sizeof(HashSlot) > 0.15 * (double)tot)) m--; }
-        if (const char *e = getenv("HARC_AMD_CAPMULT")) m = strtoull(e, nullptr, 10);
+        if (c->P.table_slots_per_read >= 2 && c->P.table_slots_per_read <= 4) m = (unsigned long long)c->P.table_slots_per_read;      // the caller's choice (harc_amd_params)
+        if (const char *e = getenv("HARC_AMD_CAPMULT")) m = strtoull(e, nullptr, 10);      // (tests force a fuller table on small inputs)
         d->cap = (((m < 2 ? 2 : m) * n + 4) + 3) & ~3ull;           // whole 64-B buckets of 4 slots
     }
     RC_TRY(dalloc(c, &d->slots, d->cap)); RC_TRY(dalloc(c, &d->ids, n)); RC_TRY(dalloc(c, &d->d_nbins, 2));

@@ -66,6 +66,10 @@ typedef struct harc_amd_params {
                                  decode_memory_gb * 2e8 / 7 reads (0 = the driver's default 7; <= 3 counts as 3), and never more than fits in HBM */
     int32_t stream_digest;    /* 1: harc_amd_encode also folds every stage-II stream into four 64-bit words where it sits in HBM (harc_amd_stream_digest):
                                  two runs, two kernel variants or two GPUs are compared at full size without touching gigabytes of host memory */
+    int32_t table_slots_per_read; /* 16-byte slots per read in each of the two stage-I dictionaries (the replacement of BooPHF.h's MPHF + startpos, reorder.cpp:277-394):
+                                 4, 3 or 2; 0 = the library chooses -- 4 while one table stays below 15 % of the device's memory and a fifth of what is free, else 3,
+                                 else 2.  A memory / speed choice, not visible in any output byte: configs[3] on one GPU 167 / 149 / 142 GB at 100 / 98.6 / 95.5 %
+                                 of the speed (206 / 184 / 176 bytes per input read) */
 } harc_amd_params;
 
 /* Counters: the three numbers the reference prints (reorder.cpp:701, encoder.cpp:506-508) + kernel-side statistics. */

@@ -26,6 +26,7 @@ def test_default_params_follow_harc_driver(L, d1, d2):
     p = harc_amd.default_params(L)
     assert (p.dict_start[0], p.dict_end[0]) == d1 and (p.dict_start[1], p.dict_end[1]) == d2
     assert p.maxmatch == L // 2 and p.thresh == 4 and p.thresh_s == 24 and p.maxsearch == 1000 and p.num_thr == 8
+    assert p.table_slots_per_read == 0 and harc_amd.default_params(L, table_slots_per_read=2).table_slots_per_read == 2      # 0 = the library chooses by free memory
 
 
 def test_readlen_limits():

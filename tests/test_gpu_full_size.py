@@ -95,6 +95,24 @@ def test_configs3_810M_x_101bp_one_gpu():
         _free()
 
 
+def test_leftover_emission_is_stable_at_50M(monkeypatch):
+    """a first list-based form of the kernel that writes the unaligned singletons / N reads (k_left_emit) differed between two launches on the
+    same inputs at 50 M reads; the form that shipped (k_left_emit_w) and the pass over all candidates it replaced (HARC_AMD_LEFT_ALL=1) are held here to
+    ONE digest, twice each, on 50 M x 101 bp with 1 % errors (c4s: 11 M reads with N, a tenth of them left unaligned)"""
+    monkeypatch.delenv("HARC_AMD_LEFT_ALL", raising=False)
+    h, sig_in, (n, L, G, err) = _ctx("c4s")
+    try:
+        d0, c0 = _run(h)
+        assert h.decode_signature() == sig_in
+        assert _run(h) == (d0, c0)
+        monkeypatch.setenv("HARC_AMD_LEFT_ALL", "1")
+        assert _run(h) == (d0, c0)
+        assert _run(h) == (d0, c0)
+    finally:
+        h.close()
+        _free()
+
+
 @pytest.mark.parametrize("workload", ["c3r", "c4r"])
 def test_human_like_repeats_at_baseline_size(workload, monkeypatch):
     """configs[2] / configs[3] with the repeat content the real data sets have and an i.i.d. genome lacks (SURVEY.md 8d "add a repeat-spiked variant";

@@ -227,6 +227,22 @@ def test_huge_bin_compacted_from_its_top_matches_oracle(K, S, oracle, tmp_path):
     assert_same(ol.read_dir(base), s2, ol.stage2_files(2), "huge-bin stage II vs oracle")
 
 
+def test_table_slots_per_read_is_not_visible_in_the_bytes(oracle, tmp_path):
+    """harc_amd_params.table_slots_per_read = 2 / 3 / 4 (a memory / speed choice of the caller): the same streams"""
+    import harc_amd
+    arr = gen.reads_array(606, 9000, 100, 70000, err=0.01)
+    hasN = (arr == ord("N")).any(1)
+    outs = []
+    for m in (0, 2, 3, 4):
+        h = harc_amd.HarcAmd(harc_amd.default_params(100, num_thr=2, num_chains=12, num_steps=16, table_slots_per_read=m))
+        h.set_reads_ascii(gen.lines_of(arr[~hasN]), int((~hasN).sum()), 101)
+        h.set_nreads_ascii(gen.lines_of(arr[hasN]), int(hasN.sum()), 101)
+        h.reorder(); h.encode()
+        outs.append([h.stream(sid, e) for e in range(2) for sid in ("S2_SEQ", "S2_POS", "S2_NOISE", "S2_NOISEPOS", "S2_REV")] + [h.stream("S2_ORDER"), h.stream("S2_SINGLETON")])
+        h.close()
+    assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0]
+
+
 @pytest.mark.parametrize("env", [{"HARC_AMD_QUAD": "0"}, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1"},
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_S1BLOOM_MZMB": "0"}, {"HARC_AMD_S1BLOOM_MZMB": "0"},
                                  {"HARC_AMD_S1BLOOM": "0"}, {"HARC_AMD_BLOOM4_HASHED": "1"}, {"HARC_AMD_BLOOM1": "1"}, {"HARC_AMD_CAPMULT": "2"},
