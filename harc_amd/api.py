@@ -96,6 +96,7 @@ def lib():
     l.harc_amd_compress_fastq_shard_files.argtypes = [PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
     l.harc_amd_merge_shard_files.argtypes = [C.c_char_p, C.c_int32]
     l.harc_amd_stream_digest.argtypes = [ctx, C.POINTER(C.c_uint64)]
+    l.harc_amd_selftest_launch.argtypes = [ctx, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     l.harc_amd_build_id.restype = C.c_char_p
     _lib = l
     return l
@@ -304,6 +305,12 @@ class HarcAmd:
         ptr, ln = C.c_void_p(), C.c_size_t()
         _check(lib().harc_amd_get_stream(self._ctx, STREAMS[name], shard, C.byref(ptr), C.byref(ln)))
         return C.string_at(ptr, ln.value) if ln.value else b""
+
+    def selftest_launch(self, n):
+        """(visited, sum of indices mod 2^64) of a thread-per-item launch over n items through the library's launch geometry"""
+        v, x = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().harc_amd_selftest_launch(self._ctx, n, C.byref(v), C.byref(x)))
+        return int(v.value), int(x.value)
 
     def stream_digest(self):
         """four 64-bit words over the stage-II streams of the last encode(), folded on the device (params.stream_digest = 1)"""

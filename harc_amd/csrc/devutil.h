@@ -2,6 +2,24 @@
 #pragma once
 #include "internal.h"
 
+// ------------------------------------------------------------------------------------------------ launch geometry
+// A grid is dispatched with its size in WORK-ITEMS per dimension as a 32-bit number: blocks x threads of 2^32 and more is taken modulo 2^32 WITHOUT an error
+// (tools/micro/grid_limit.hip: 39 000 000 x 256 runs 5 445 568 workgroups and reports hipSuccess; an exact multiple of 2^32 is hipErrorInvalidConfiguration,
+// which the next successful call erases).  Found in round 5 at 402 M probes into stage II's large bins; the decoders had it from 42 M reads per shard on.
+// A thread per item: harc_grid256(n) folds the workgroups into rows of at most HARC_GRID_ROW (x 256 threads < 2^32) and the kernel takes its index from
+// harc_gid().  Kernels whose item count is a 32-bit number never get a second row and may keep blockIdx.x * blockDim.x + threadIdx.x.
+#define HARC_GRID_ROW 16777215u
+static inline dim3 harc_grid256(uint64_t n)
+{
+    uint64_t b = (n + 255) / 256;
+    if (b == 0) b = 1;
+    if (b <= HARC_GRID_ROW) return dim3((unsigned)b);
+    return dim3(HARC_GRID_ROW, (unsigned)((b + HARC_GRID_ROW - 1) / HARC_GRID_ROW));
+}
+// a workgroup of 64 threads per item (blockIdx.y * gridDim.x + blockIdx.x in the kernel): rows of 2^25 items x 64 threads = 2^31 work-items
+static inline dim3 wave_grid(uint32_t n) { if (n <= (1u << 25)) return dim3(n ? n : 1u); return dim3(1u << 25, (n + (1u << 25) - 1) >> 25); }
+__device__ __forceinline__ uint64_t harc_gid() { return ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; }
+
 // ------------------------------------------------------------------------------------------------ device helpers
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {

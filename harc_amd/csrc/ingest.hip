@@ -50,7 +50,7 @@ __global__ void k_classify(const char *txt, const uint64_t *nl, uint32_t nrec, i
 // clean reads -> 2-bit words (one thread per (record, word)); N reads -> 3-bit words; original index of N reads (read_order_N.bin)
 __global__ void k_ingest_pack2(const char *txt, const uint64_t *nl, const uint32_t *isClean, const uint32_t *rankC, uint32_t nrec, int L, int W, uint64_t *out)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     if (gid >= (uint64_t)nrec * W) return;
     const uint32_t r = (uint32_t)(gid / W); const int w = (int)(gid % W);
     if (!isClean[r]) return;
@@ -64,7 +64,7 @@ __global__ void k_ingest_pack2(const char *txt, const uint64_t *nl, const uint32
 }
 __global__ void k_ingest_pack3(const char *txt, const uint64_t *nl, const uint32_t *isN, const uint32_t *rankN, uint32_t nrec, int L, int W3, uint64_t *out, uint32_t *orderN)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     if (gid >= (uint64_t)nrec * W3) return;
     const uint32_t r = (uint32_t)(gid / W3); const int w = (int)(gid % W3);
     if (!isN[r]) return;
@@ -81,7 +81,7 @@ __global__ void k_ingest_pack3(const char *txt, const uint64_t *nl, const uint32
     if (w == 0) orderN[rankN[r]] = r;                             // preprocess.cpp:102
 }
 
-#define G256(n) dim3((unsigned)((((uint64_t)(n)) + 255) / 256)), dim3(256), 0, c->stream
+#define G256(n) harc_grid256((uint64_t)(n)), dim3(256), 0, c->stream
 
 // nls[k] = byte position of the newline that ends line k (a last line without one ends at nbytes); nls[-1] = (u64)-1 so that line k
 // starts at nls[k-1]+1 for every k.  Pool memory: the caller brackets it with harc_pool_mark / release.

@@ -1,6 +1,6 @@
 // prims.hip -- device-wide sort / scan building blocks (rocPRIM).  Everything algorithm-specific is hand-written in
 // stage1.hip / stage2.hip; these are the "plain library" pieces (the role std::sort plays at reorder.cpp:305).
-#include "internal.h"
+#include "devutil.h"
 #include <rocprim/rocprim.hpp>
 
 int harc_tmp_reserve(harc_amd_ctx *c, size_t bytes)
@@ -84,5 +84,31 @@ int prim_incl_max_u64(harc_amd_ctx *c, const uint64_t *in, uint64_t *out, size_t
 {
     if (n == 0) return HARC_AMD_OK;
     PRIM_CALL(rocprim::inclusive_scan(tmp, bytes, in, out, n, rocprim::maximum<uint64_t>(), c->stream));
+    return HARC_AMD_OK;
+}
+
+// ---- self-test of the launch geometry (devutil.h: harc_grid256 / harc_gid): n items, a thread each; returns how many were visited and the sum of their
+// indices -- n and n (n - 1) / 2 (mod 2^64) when every item was visited exactly once.  tests/test_gpu_parity.py runs it beyond 2^32 items, where a plain
+// one-dimensional grid is cut short without an error on this platform.
+__global__ void k_selftest_grid(uint64_t n, unsigned long long *out)
+{
+    const uint64_t i = harc_gid();
+    unsigned long long one = i < n ? 1ULL : 0ULL, idx = i < n ? (unsigned long long)i : 0ULL;
+    for (int o = 32; o > 0; o >>= 1) { one += __shfl_xor(one, o, 64); idx += __shfl_xor(idx, o, 64); }
+    if ((threadIdx.x & 63) == 0 && one) { atomicAdd(&out[0], one); atomicAdd(&out[1], idx); }
+}
+extern "C" int harc_amd_selftest_launch(harc_amd_ctx *c, uint64_t n, uint64_t *visited, uint64_t *index_sum)
+{
+    if (!c || !visited || !index_sum) return HARC_AMD_EINVAL;
+    HIP_TRY(hipSetDevice(c->P.device));
+    unsigned long long *d = nullptr, h[2] = { 0, 0 };
+    HIP_TRY(hipMalloc((void **)&d, 16));
+    hipError_t e = hipMemsetAsync(d, 0, 16, c->stream);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_selftest_grid, harc_grid256(n), dim3(256), 0, c->stream, n, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { harc_set_error("harc_amd_selftest_launch: %s", hipGetErrorString(e)); return HARC_AMD_ENODEVICE; }
+    *visited = h[0]; *index_sum = h[1];
     return HARC_AMD_OK;
 }

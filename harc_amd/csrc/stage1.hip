@@ -271,7 +271,7 @@ __global__ void k_large_sizes(const unsigned long long *list, uint32_t nlist, Ha
 template <int W> __global__ __launch_bounds__(64) void k_large_fill(const unsigned long long *list, uint32_t nlist, HashSlot *s0, HashSlot *s1, const uint32_t *ids0, const uint32_t *ids1,
                                                                    const uint64_t *moff, const uint64_t *reads, uint2 *largetab, uint64_t *mirror)
 {
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;      // (rows of at most 2^25 bins: wave_grid)
     if (b >= nlist) return;
     const int lane = threadIdx.x;
     const unsigned long long e = list[b];
@@ -2375,7 +2375,7 @@ template <int W> __global__ __launch_bounds__(1024) void k_compact_huge(S1Args s
 }
 template <int W> __global__ __launch_bounds__(64) void k_compact_bins(S1Args s, const unsigned long long *list, uint32_t nlist, const uint32_t *sz0)
 {
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;      // (rows of at most 2^25 bins: wave_grid)
     if (b >= nlist) return;
     if (sz0 && sz0[b] > HARC_HUGEBIN) return;                     // k_compact_huge's
     const int lane = threadIdx.x;
@@ -2462,20 +2462,29 @@ __global__ __launch_bounds__(256) void k_pages_out(const uint2 *pg_rec, const ui
     flag[at] = (r.y >> 8) & 1 ? '1' : '0'; rc[at] = (r.y >> 9) & 1 ? 'r' : 'd';
 }
 // temp.dna in HBM: read `order[i]`, reverse-complemented where rc[i]=='r' (reorder.cpp:743-752)
+// W lanes per read, one 64-bit word each: the W words of a read are ONE request of W x 8 bytes to one sector (profiles/r05/random_access_ceiling.txt:
+// a random sector fetched by narrow loads of neighbouring lanes runs at 48.5 G requests/s, the same 32 bytes as two dwordx4 loads of ONE lane -- 64
+// distinct lines per instruction -- at 26.3: this kernel was 10.4 ms at configs[2] with a thread per read)
 template <int W> __global__ void k_orient(const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, int L, uint64_t *out)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const uint32_t rid = order[i];
+    constexpr int RPW = 64 / W;                                   // reads per wave
+    const int lane = threadIdx.x & 63, rl = lane / W, w = lane % W;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t i = wave * RPW + (uint32_t)rl;
+    const bool on = rl < RPW && i < m;
+    uint64_t mine = 0; bool rev = false;
+    if (on) {
+        const uint32_t rid = order[i];
+        mine = reads[(size_t)rid * W + w];
+        rev = rc != nullptr && rc[i] == 'r';
+    }
     uint64_t r[W], o[W];
 #pragma unroll
-    for (int w = 0; w < W; w++) r[w] = reads[(size_t)rid * W + w];
-    if (rc == nullptr || rc[i] != 'r') {
-#pragma unroll
-        for (int w = 0; w < W; w++) o[w] = r[w];
-    } else rc_words<W>(r, L, o);
-#pragma unroll
-    for (int w = 0; w < W; w++) out[(size_t)i * W + w] = o[w];
+    for (int k = 0; k < W; k++) r[k] = shfl_u64(mine, rl * W + k);
+    if (!on) return;
+    uint64_t ow = mine;
+    if (rev) { rc_words<W>(r, L, o); ow = sel0<W>(o, w); }
+    out[(size_t)i * W + w] = ow;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -2761,7 +2770,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (mtotal > 0xFFFFFFFFull) { harc_set_error("stage I: more than 2^32 reads in large bins"); return HARC_AMD_EINVAL; }
         RC_TRY(dalloc(c, &d_mirror, (size_t)mtotal * W + 1));
-        hipLaunchKernelGGL((k_large_fill<W>), dim3(nlarge), dim3(64), 0, c->stream, (const unsigned long long *)d_large, nlarge, dict[0].slots, dict[1].slots,
+        hipLaunchKernelGGL((k_large_fill<W>), wave_grid(nlarge), dim3(64), 0, c->stream, (const unsigned long long *)d_large, nlarge, dict[0].slots, dict[1].slots,
                            (const uint32_t *)dict[0].ids, (const uint32_t *)dict[1].ids, (const uint64_t *)moff, (const uint64_t *)c->d_reads, d_largetab, d_mirror);
         HIP_TRY(hipGetLastError());
     }
@@ -2860,7 +2869,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     HIP_TRY(hipGetLastError());
 
     // SLOT_DEAD of the large bins must say "no unclaimed read" from the first super-round on (the seeds of k_init_chains are claimed)
-    if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge, (const uint32_t *)d_sz0);
+    if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), wave_grid(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge, (const uint32_t *)d_sz0);
     if (nhuge) hipLaunchKernelGGL((k_compact_huge<W>), dim3(nhuge), dim3(1024), 0, c->stream, a, (const unsigned long long *)d_large, (const uint32_t *)d_huge, nhuge);
     // ---- rounds
     uint32_t *x_send = nullptr, *x_recv = nullptr; uint32_t x_nper = 0; size_t x_bytes = 0; unsigned long long *x_dig = nullptr;
@@ -2991,7 +3000,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             else if (reseed_mg) hipLaunchKernelGGL(k_reseed_mg, dim3(RESEED_G), dim3(RESEED_NT), 0, c->stream, a, a.reseed_g);
             else if (K <= 4096) hipLaunchKernelGGL((k_reseed<256>), dim3(1), dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((k_reseed<1024>), dim3(1), dim3(1024), 0, c->stream, a);
-            if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), dim3(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge, (const uint32_t *)d_sz0);
+            if (nlarge) hipLaunchKernelGGL((k_compact_bins<W>), wave_grid(nlarge), dim3(64), 0, c->stream, a, (const unsigned long long *)d_large, nlarge, (const uint32_t *)d_sz0);
     if (nhuge) hipLaunchKernelGGL((k_compact_huge<W>), dim3(nhuge), dim3(1024), 0, c->stream, a, (const unsigned long long *)d_large, (const uint32_t *)d_huge, nhuge);
             launches++;
         }
@@ -3154,7 +3163,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
 template <int W> static int orient_w(harc_amd_ctx *c, const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, uint64_t *out)
 {
     if (!m) return HARC_AMD_OK;
-    hipLaunchKernelGGL((k_orient<W>), dim3((m + 255) / 256), dim3(256), 0, c->stream, reads, order, rc, m, c->P.readlen, out);
+    { const uint32_t per_block = 4u * (64u / W); hipLaunchKernelGGL((k_orient<W>), dim3((m + per_block - 1) / per_block), dim3(256), 0, c->stream, reads, order, rc, m, c->P.readlen, out); }
     HIP_TRY(hipGetLastError());
     return HARC_AMD_OK;
 }

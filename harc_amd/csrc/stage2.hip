@@ -80,7 +80,7 @@ __device__ __forceinline__ long long ub_le(const uint64_t *a, long long n, uint6
 // singleton r: 2-bit read -> std::bitset<3L> words (encoder.cpp:815-821). One thread per (read, word).
 __global__ void k_cand3_from2(const uint64_t *reads2, const uint32_t *gather, uint32_t n, int L, int W, int W3, uint64_t *out)
 {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gid = harc_gid();
     if (gid >= (size_t)n * W3) return;
     const uint32_t i = (uint32_t)(gid / W3); const int w = (int)(gid % W3);
     const uint64_t *r = reads2 + (size_t)(gather ? gather[i] : i) * W;
@@ -112,7 +112,7 @@ __global__ void k_key3(const uint64_t *cand3, uint32_t T, int W3, int off, int n
 }
 __global__ void k_count_big_bins(const HashSlot *slots, uint64_t cap, uint32_t maxsearch, unsigned long long *out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = harc_gid();
     if (i >= cap) return;
     if ((slots[i].count & SLOT_CNT_MASK) > maxsearch) atomicAdd(out, 1ULL);
 }
@@ -381,7 +381,7 @@ __global__ void k_words_differ(const uint32_t *a, const uint32_t *b, uint64_t nw
 // candidates in the reads' 2-bit code + N mask (3-bit code A0 N1 G2 C4 T6: code = c3 >> 1, N = c3 & 1); one thread per (read, word)
 __global__ void k_cand2_from3(const uint64_t *cand3, uint32_t T, int L, int W, int W3, uint64_t *cand2, uint64_t *candN)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     if (gid >= (uint64_t)T * W) return;
     const uint32_t i = (uint32_t)(gid / W); const int w = (int)(gid % W);
     const uint64_t *r = cand3 + (size_t)i * W3;
@@ -640,11 +640,11 @@ __global__ void k_ev_gather(const uint4 *ev, const uint32_t *perm, uint32_t nev,
 // one wave per event: the L columns of its window (forward, or reverse-complemented) as W3 words of the candidates' 3-bit code.  One lane per base
 // fetches its code from the packed consensus (A0 G1 C2 T3 there, twice that in the 3-bit code; complement = 3 - code) into LDS, then lanes
 // 0..W3-1 put one word together each
-__global__ __launch_bounds__(256) void k_ev_windows(S2Args s, const uint4 *ev, uint32_t nev, uint64_t *win)
+__global__ __launch_bounds__(256) void k_ev_windows(S2Args s, const uint4 *ev, uint32_t nev, uint64_t *win, uint32_t kbase)
 {
     __shared__ uint8_t sc3[4][256];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t e = blockIdx.x * 4 + wv;
+    const uint32_t e = kbase + blockIdx.x * 4 + wv;
     if (e >= nev) return;
     const uint4 v = ev[e];
     const unsigned long long tp = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void k_ev_windows(S2Args s, const uint4 *ev, u
 }
 __global__ void k_ev_gather_win(const uint64_t *win, const uint32_t *perm, uint32_t nev, int W3, uint64_t *out)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t t = harc_gid();
     if (t >= (uint64_t)nev * W3) return;
     const uint32_t i = (uint32_t)(t / W3); const int w = (int)(t % W3);
     out[t] = win[(size_t)perm[i] * W3 + w];
@@ -783,11 +783,11 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
     return ch;
 }
 __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
-                                                     uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, uint32_t rlo, uint32_t rhi, const uint32_t *order2)
+                                                     uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, uint32_t rlo, uint32_t rhi, const uint32_t *order2, uint32_t kbase)
 {
     __shared__ unsigned long long swin[4][HARC_MAXW3 + 32];            // the window words of a wave's event + 256 bytes for the codes they are made of
     const int wv = threadIdx.x >> 6;
-    const uint32_t k = blockIdx.x * 4 + wv;
+    const uint32_t k = kbase + blockIdx.x * 4 + wv;
     if (k >= nev) return;                                         // nev: the events of the ranges this pass covers (order2) or all of them
     const uint32_t ei = order2 ? order2[k] : k;                   // estart / lastpass are indexed by the event's position in (bin, tuple) order
     uint32_t e = ei;
@@ -803,11 +803,11 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uin
 #define EV_CHASE_QUIET 16
 #define EV_CHASE_MAX 64
 __global__ __launch_bounds__(256) void k_realign_chase(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
-                                                       uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, const uint32_t *seglen, uint32_t rhi)
+                                                       uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, const uint32_t *seglen, uint32_t rhi, uint32_t kbase)
 {
     __shared__ unsigned long long swin[4][HARC_MAXW3 + 32];            // the window words of a wave's event + 256 bytes for the codes they are made of
     const int wv = threadIdx.x >> 6;
-    const uint32_t i0 = blockIdx.x * 4 + wv;
+    const uint32_t i0 = kbase + blockIdx.x * 4 + wv;
     if (i0 >= nev || rank[i0] != 0) return;                       // one wave per bin: the first of its events in (bin, tuple) order
     const uint4 ev0 = s.events[i0];
     const int l = (int)(ev0.x & 1u);
@@ -1060,7 +1060,7 @@ __global__ void k_left_orders(S2Args s, uint32_t t0, uint32_t nt, const uint32_t
 __global__ void k_left_emit(S2Args s, uint32_t t0, uint32_t nt, const uint32_t *rs, const uint32_t *rn, uint8_t *sing_bases, char *ntext)
 {
     const int G = (s.L + 15) / 16;
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     if (gid >= (uint64_t)nt * G) return;
     const uint32_t i = t0 + (uint32_t)(gid / G); const int g = (int)(gid % G);
     if (s.best[i] != TUPLE_NONE) return;
@@ -1091,9 +1091,9 @@ __global__ void k_left_list(const uint32_t *fs, const uint32_t *fn, const uint32
     if (fs[t]) list[rs[t]] = t;
     else if (fn[t]) list[US + rn[t]] = t;
 }
-__global__ __launch_bounds__(256) void k_left_emit_w(S2Args s, uint32_t t0, const uint32_t *list, uint32_t nl, uint32_t US, uint8_t *sing_bases, char *ntext)
+__global__ __launch_bounds__(256) void k_left_emit_w(S2Args s, uint32_t t0, const uint32_t *list, uint32_t nl, uint32_t US, uint8_t *sing_bases, char *ntext, uint32_t kbase)
 {
-    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);      // entry of the list: singletons [0, US), reads with N behind them
+    const uint32_t q = kbase + blockIdx.x * 4u + (threadIdx.x >> 6);      // entry of the list: singletons [0, US), reads with N behind them
     const int lane = threadIdx.x & 63;
     if (q >= nl) return;
     const uint32_t i = t0 + list[q];
@@ -1138,7 +1138,7 @@ __global__ void k_bases_to_ascii(const uint8_t *bases, uint64_t n, uint8_t *out)
 // pack_order.cpp:36-65: every 32 values -> numbits u32 words, LSB-first bit stream. One thread per output word.
 __global__ void k_pack_order(const uint32_t *order, uint32_t ngroups, int numbits, uint32_t *out)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     if (gid >= (uint64_t)ngroups * numbits) return;
     const uint32_t g = (uint32_t)(gid / numbits); const int w = (int)(gid % numbits);
     const int k0 = (32 * w) / numbits, k1 = (32 * w + 31) / numbits;
@@ -1170,7 +1170,13 @@ __global__ void k_stream_digest(const uint8_t *base, uint64_t nbytes, uint64_t s
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-#define G256(n) dim3((unsigned)((((uint64_t)(n)) + 255) / 256)), dim3(256), 0, c->stream
+// One WAVE per item, four items per workgroup of 256 threads, in launches of at most 2^23 workgroups: a grid is dispatched with its size in WORK-ITEMS as a
+// 32-bit number (devutil.h), and 2^26 items x 64 lanes is 2^32.  (Round 5: configs[3] with human-like repeats makes 402 M probes into bins above maxsearch; the launch
+// over all of them was cut short without an error, the window passes ended early and differently from run to run -- lossless, but neither deterministic
+// nor the sequential result.  From 67 M probes on; nothing smaller had ever been run.)  `launch` sees nb_ (workgroups) and kb_ (first item).
+#define WAVE_PER_ITEM(n, launch) do { const uint64_t nwg_ = ((uint64_t)(n) + 3) / 4; for (uint64_t b_ = 0; b_ < nwg_; b_ += (1u << 23)) { \
+        const unsigned nb_ = (unsigned)(nwg_ - b_ < (1u << 23) ? nwg_ - b_ : (1u << 23)); const uint32_t kb_ = (uint32_t)(b_ * 4); launch; } } while (0)
+#define G256(n) harc_grid256((uint64_t)(n)), dim3(256), 0, c->stream
 static int digest_range(harc_amd_ctx *c, const void *base, uint64_t nbytes, uint64_t salt, unsigned long long *d_out)
 {
     if (!nbytes) return HARC_AMD_OK;
@@ -1430,13 +1436,27 @@ int stage2_run(harc_amd_ctx *c)
         }
     }
     HIP_TRY(hipGetLastError());
+    // trace: the claims folded into one word after the proposals and after the window passes (two runs on the same input must print the same words)
+    unsigned long long *d_bdig = nullptr;
+    auto best_digest = [&](const char *what) -> int {
+        if (!getenv("HARC_AMD_TRACE") || !T) return HARC_AMD_OK;
+        if (!d_bdig) RC_TRY(dalloc(c, &d_bdig, 2));
+        unsigned long long hv = 0;
+        HIP_TRY(hipMemsetAsync(d_bdig, 0, 8, c->stream));
+        RC_TRY(digest_range(c, best, (uint64_t)T * 8, 0xBE57ull, d_bdig));
+        HIP_TRY(hipMemcpyAsync(&hv, d_bdig, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[stage II] digest of the claims %s: %016llx (%u probes into large bins)\n", what, hv, nev);
+        return HARC_AMD_OK;
+    };
+    RC_TRY(best_digest("after the proposals"));
     lap("consensus + read_seq + proposals (this rank's columns)");
     // ---- the window words of the events (k_realign_big reads them instead of the consensus: with the columns partitioned the consensus under an
     //      event of another rank is not here)
     uint64_t *evwin = nullptr;
     if (nev) {
         RC_TRY(dalloc(c, &evwin, (size_t)nev * W3 + 1));
-        hipLaunchKernelGGL(k_ev_windows, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, (const uint4 *)a.events, nev, evwin);
+        WAVE_PER_ITEM(nev, hipLaunchKernelGGL(k_ev_windows, dim3(nb_), dim3(256), 0, c->stream, a, (const uint4 *)a.events, nev, evwin, kb_));
     }
     if (cm && T) {
         // ---- the claims of all ranks: ONE all-reduce(min) over the packed tuples; then every rank's events (with their windows) to everybody
@@ -1521,12 +1541,12 @@ int stage2_run(harc_amd_ctx *c)
             HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 4, c->stream));
             hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
             const uint32_t nact = (ranges && order2) ? range_end[ridx < 31 ? ridx : 31] : nev;      // the events of the ranges reached so far come first in order2
-            hipLaunchKernelGGL(k_realign_big, dim3((nact + 3) / 4), dim3(256), 0, c->stream, a, nact, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
-                               (const uint32_t *)perm, (const uint32_t *)rank, 0u, ranges ? rhi : 0xFFFFFFFFu, (const uint32_t *)(ranges ? order2 : nullptr));     // the ranks below rlo are validated in passing: no event is ever left unlooked-at for a pass
+            WAVE_PER_ITEM(nact, hipLaunchKernelGGL(k_realign_big, dim3(nb_), dim3(256), 0, c->stream, a, nact, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
+                               (const uint32_t *)perm, (const uint32_t *)rank, 0u, ranges ? rhi : 0xFFFFFFFFu, (const uint32_t *)(ranges ? order2 : nullptr), kb_));     // the ranks below rlo are validated in passing: no event is ever left unlooked-at for a pass
             // the chaser, after the passes over everything from the second one on (the ranges settle by themselves; the chains it is for show
             // when the ranges meet); its claims count for the pass (the same stamp)
-            if (perm && !nochase && !ranges && nall++ > 0) hipLaunchKernelGGL(k_realign_chase, dim3((nev + 3) / 4), dim3(256), 0, c->stream, a, nev, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
-                                                     (const uint32_t *)perm, (const uint32_t *)rank, (const uint32_t *)seglen, ranges ? rhi : 0xFFFFFFFFu);
+            if (perm && !nochase && !ranges && nall++ > 0) WAVE_PER_ITEM(nev, hipLaunchKernelGGL(k_realign_chase, dim3(nb_), dim3(256), 0, c->stream, a, nev, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
+                                                     (const uint32_t *)perm, (const uint32_t *)rank, (const uint32_t *)seglen, ranges ? rhi : 0xFFFFFFFFu, kb_));
             unsigned int chg = 0, nlook = 0;
             HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
             if (trace) HIP_TRY(hipMemcpyAsync(&nlook, d_changed + 2, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1545,6 +1565,7 @@ int stage2_run(harc_amd_ctx *c)
     }
     HIP_TRY(hipGetLastError());
 
+    RC_TRY(best_digest("after the window passes"));
     lap("window passes over the large bins (all probes, on every rank)");
     unsigned long long big = 0;
     HIP_TRY(hipMemcpyAsync(&big, d_big, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1573,7 +1594,7 @@ int stage2_run(harc_amd_ctx *c)
         uint32_t *llist = nullptr;
         RC_TRY(dalloc(c, &llist, (size_t)US + UN + 1));
         hipLaunchKernelGGL(k_left_list, G256(nt), (const uint32_t *)ls, (const uint32_t *)ln, (const uint32_t *)rs, (const uint32_t *)rn, nt, US, llist);
-        hipLaunchKernelGGL(k_left_emit_w, dim3((US + UN + 3) / 4), dim3(256), 0, c->stream, a, t0, (const uint32_t *)llist, US + UN, US, sing_bases, ntext);
+        WAVE_PER_ITEM(US + UN, hipLaunchKernelGGL(k_left_emit_w, dim3(nb_), dim3(256), 0, c->stream, a, t0, (const uint32_t *)llist, US + UN, US, sing_bases, ntext, kb_));
     }
     if (sing_nb) hipLaunchKernelGGL(k_pack2_bytes, G256(sing_nb), sing_bases, sing_nb, spk);
     if (sing_tl) hipLaunchKernelGGL(k_bases_to_ascii, G256(sing_tl), sing_bases + 4 * sing_nb, sing_tl, spk + sing_nb);

@@ -97,7 +97,7 @@ __global__ void k_sig_codes(const uint8_t *codes, uint32_t n, int L, unsigned lo
     sig_accumulate(h, i < n, sig);
 }
 
-#define G256(n) dim3((unsigned)((((uint64_t)(n)) + 255) / 256)), dim3(256), 0, c->stream
+#define G256(n) harc_grid256((uint64_t)(n)), dim3(256), 0, c->stream
 
 static bool get_out(harc_amd_ctx *c, int id, int shard, const uint8_t **p, size_t *n)
 {
@@ -219,7 +219,7 @@ __global__ void k_decode_text(const uint8_t *seqb, uint64_t seqlen, const uint64
 // stable split of the lines: reads without N to outA[rankA], reads with N to outN[i - rankA]
 __global__ void k_split_lines(const char *tmp, const uint32_t *isN, const uint32_t *rankN, uint32_t n, int L, char *outA, char *outN)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     const uint64_t LL = (uint64_t)L + 1;
     if (gid >= (uint64_t)n * LL) return;
     const uint32_t i = (uint32_t)(gid / LL); const uint32_t j = (uint32_t)(gid % LL);
@@ -228,7 +228,7 @@ __global__ void k_split_lines(const char *tmp, const uint32_t *isN, const uint32
 }
 __global__ void k_codes_to_lines(const uint8_t *codes, uint32_t n, int L, char *out)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     const uint64_t LL = (uint64_t)L + 1;
     if (gid >= (uint64_t)n * LL) return;
     const uint32_t i = (uint32_t)(gid / LL); const uint32_t j = (uint32_t)(gid % LL);
@@ -391,7 +391,7 @@ extern "C" int harc_amd_input_signature(harc_amd_ctx *c, uint64_t *sig3)
 // N read (merge_N.cpp:37-57).
 __global__ void k_unpack_order(const uint32_t *packed, uint32_t ngroups, int numbits, uint32_t *out)      // unpack_order.cpp:34-62
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     if (gid >= (uint64_t)ngroups * 32) return;
     const uint32_t g = (uint32_t)(gid >> 5); const int k = (int)(gid & 31);
     const uint32_t *w = packed + (size_t)g * numbits;
@@ -404,7 +404,7 @@ __global__ void k_unpack_order(const uint32_t *packed, uint32_t ngroups, int num
 // order[i] >= ndst is an inconsistent archive
 __global__ void k_permute_lines(const char *src, const uint32_t *order, uint32_t n, int L, char *dst, uint32_t lo, uint32_t hi, uint32_t ndst, unsigned int *err)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     const uint64_t LL = (uint64_t)L + 1;
     if (gid >= (uint64_t)n * LL) return;
     const uint32_t i = (uint32_t)(gid / LL);
@@ -424,7 +424,7 @@ __global__ void k_mark_N(const uint32_t *orderN, uint32_t nN, uint32_t total, ui
 // the N reads from index nlo on (merge_N.cpp:37-57, one bin of it)
 __global__ void k_merge_lines(const char *clean, const char *withN, const uint32_t *flag, const uint32_t *rankN, uint32_t p0, uint32_t n, uint32_t clo, uint32_t nlo, int L, char *out)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     const uint64_t LL = (uint64_t)L + 1;
     if (gid >= (uint64_t)n * LL) return;
     const uint32_t p = p0 + (uint32_t)(gid / LL); const uint64_t j = gid % LL;

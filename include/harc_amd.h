@@ -224,6 +224,9 @@ int harc_amd_input_signature(harc_amd_ctx *ctx, uint64_t sig[3]);           /* o
 int harc_amd_stream_digest(harc_amd_ctx *ctx, uint64_t out[4]);
 /* sha256 (hex) of the kernel sources this library was built from: ties a committed profile (profiles/k_steps_traffic.json) to a build */
 const char *harc_amd_build_id(void);
+/* Self-test of the library's launch geometry (one thread per item over n items, n beyond 2^32 included: a one-dimensional grid of 2^32 and more
+ * work-items is cut short without an error on this platform).  *visited == n and *index_sum == n (n - 1) / 2 mod 2^64 when every item was visited once. */
+int harc_amd_selftest_launch(harc_amd_ctx *ctx, uint64_t n, uint64_t *visited, uint64_t *index_sum);
 
 /* ---- file contract: drop-ins for the reference's stage programs.  basedir as argv[1] of those programs. */
 int harc_amd_reorder_files(const harc_amd_params *params, const char *basedir);

@@ -82,6 +82,10 @@ def test_parity_fuzz_bounded(it, oracle, tmp_path, monkeypatch):
     import harc_amd
     if it % 2:
         monkeypatch.setenv("HARC_AMD_SUCC", "1")
+    if it % 3 == 0:      # ... and every third with the kernels of a large run forced, the walk by several chains per wave (k_steps_grp) where it can run (L >= 100, S <= 16)
+        for k, v in {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_SEQ": "1", "HARC_AMD_S1BLOOM_MZMB": "0", "HARC_AMD_GRP": "1", "HARC_AMD_GRP_WIDE": "1",
+                     "HARC_AMD_GRP_WIDE_LIMIT": str(3 + it)}.items():
+            monkeypatch.setenv(k, v)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_parity as fz
     rs = np.random.RandomState(7000 + it)
