@@ -265,7 +265,7 @@ def synth_chunks(n, L, G, err, seed, dev, spike=None):
             pa = torch.randint(0, G - 400, (spike["polya"],), generator=g, device=dev)
             genome[(pa[:, None] + ar150[None, :]).reshape(-1)] = ord("A")
         if spike.get("ca", 0):
-            pc = torch.randint(0, G - 400, (spike["ca"],), generator=g, device=dev)
+            pc = torch.randint(0, (G - 400) // 2, (spike["ca"],), generator=g, device=dev) * 2      # even starts: two runs that overlap write the same bases (a scatter with clashing values is not reproducible)
             ca = torch.tensor(list(b"CA" * 75), dtype=torch.uint8, device=dev)
             genome[(pc[:, None] + ar150[None, :]).reshape(-1)] = ca.repeat(pc.shape[0])
         if spike.get("sat"):

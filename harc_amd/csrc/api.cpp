@@ -34,6 +34,7 @@ int harc_raw_alloc(harc_amd_ctx *c, void **p, size_t bytes)
     *p = nullptr;
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
     if (e != hipSuccess && !c->pool.empty() && pool_hand_back(c, c->pool_cur, bytes)) e = hipMalloc(p, bytes);
     if (e != hipSuccess) { (void)hipGetLastError(); harc_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return HARC_AMD_ENOMEM; }
     c->owned.push_back(*p);
@@ -82,7 +83,8 @@ int harc_dev_alloc(harc_amd_ctx *c, void **p, size_t bytes)
         if (want < ((size_t)64 << 20)) want = (size_t)64 << 20;
         void *base = nullptr;
         hipError_t e = hipMalloc(&base, want);
-        if (e != hipSuccess && want > bytes) { want = bytes; e = hipMalloc(&base, want); }
+        if (e != hipSuccess) (void)hipGetLastError();              // (a failed attempt that is recovered from below must not be what a later hipGetLastError() reports)
+        if (e != hipSuccess && want > bytes) { want = bytes; e = hipMalloc(&base, want); if (e != hipSuccess) (void)hipGetLastError(); }
         if (e != hipSuccess && !c->pool.empty() && pool_hand_back(c, cur_in, bytes)) e = hipMalloc(&base, want);
         if (e != hipSuccess) { (void)hipGetLastError(); harc_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return HARC_AMD_ENOMEM; }
         if (getenv("HARC_AMD_POISON")) (void)hipMemset(base, 0xA5, want);   // debugging aid: make reads of uninitialised pool memory show

@@ -803,12 +803,14 @@ __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uin
 #define EV_CHASE_QUIET 16
 #define EV_CHASE_MAX 64
 __global__ __launch_bounds__(256) void k_realign_chase(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
-                                                       uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, const uint32_t *seglen, uint32_t rhi, uint32_t kbase)
+                                                       uint32_t *lastpass, uint32_t pass, uint32_t T1, const uint32_t *perm, const uint32_t *rank, const uint32_t *seglen, uint32_t rhi, uint32_t kbase, const uint32_t *firsts)
 {
     __shared__ unsigned long long swin[4][HARC_MAXW3 + 32];            // the window words of a wave's event + 256 bytes for the codes they are made of
     const int wv = threadIdx.x >> 6;
-    const uint32_t i0 = kbase + blockIdx.x * 4 + wv;
-    if (i0 >= nev || rank[i0] != 0) return;                       // one wave per bin: the first of its events in (bin, tuple) order
+    const uint32_t k0 = kbase + blockIdx.x * 4 + wv;
+    if (k0 >= nev) return;                                        // nev: the bins (firsts) or the events
+    const uint32_t i0 = firsts ? firsts[k0] : k0;
+    if (rank[i0] != 0) return;                       // one wave per bin: the first of its events in (bin, tuple) order
     const uint4 ev0 = s.events[i0];
     const int l = (int)(ev0.x & 1u);
     const unsigned long long m = __hip_atomic_load((l ? binmin1 : binmin0) + (size_t)(pass & 1u) * T1 + ev0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -828,6 +830,67 @@ __global__ __launch_bounds__(256) void k_realign_chase(S2Args s, uint32_t nev, u
         quiet = ch ? 0 : quiet + 1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+}
+// Large passes in two kernels (round 5).  k_realign_big starts a WAVE per event of the ranges reached so far and lets most of them leave at once --
+// validated, or done for good: configs[3] with human-like repeats has 402 M probes into large bins, a hundred passes, and a few thousand to a few
+// million events that actually look in most of them: 13 s of waves that read two words and left.  From a million events on a pass first asks the
+// question with a THREAD per event (the same tests as the top of realign_event, in the same order: what the previous pass left is final, so asking
+// before the pass or inside it is the same) and lists the events that have to look; a wave is started for those only.
+__global__ void k_ev_validate(S2Args s, uint32_t nact, const uint32_t *order2, const uint32_t *perm, const uint32_t *rank, uint32_t rhi, uint32_t *estart, const unsigned long long *binmin0,
+                              const unsigned long long *binmin1, uint32_t *lastpass, uint32_t pass, uint32_t T1, uint32_t *list, unsigned int *nlist)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    bool look = false; uint32_t ei = 0;
+    if (k < nact) {
+        ei = order2 ? order2[k] : k;
+        const uint32_t lp = lastpass[ei];
+        bool go = lp != EV_DONE;
+        if (go && perm && rank[ei] >= rhi) go = false;
+        if (go) {
+            const uint4 ev = s.events[ei];
+            const unsigned long long tp = (unsigned long long)ev.x | ((unsigned long long)ev.y << 32);
+            const int l = (int)(tp & 1);
+            bool moved = true;
+            if (lp == pass - 1) {
+                const unsigned long long m = ((l ? binmin1 : binmin0) + ev.z)[(size_t)((pass - 1u) & 1u) * T1];
+                moved = (m >> EV_TBITS) == (unsigned long long)(~(pass - 1) & 0xFFFFFFu) && (m & ((1ULL << EV_TBITS) - 1ULL)) < tp;
+                if (!moved) lastpass[ei] = pass;
+            }
+            if (moved) { if (estart[ei] == 0) lastpass[ei] = EV_DONE; else look = true; }
+        }
+    }
+    const unsigned long long m = __ballot(look);
+    if (m) {
+        unsigned int base = 0;
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        if (lane == leader) base = atomicAdd(nlist, (unsigned int)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (look) list[base + (unsigned int)__popcll(m & ((1ULL << lane) - 1ULL))] = ei;
+    }
+}
+__global__ __launch_bounds__(256) void k_realign_list(S2Args s, const uint32_t *list, uint32_t nl, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
+                                                      uint32_t *lastpass, uint32_t pass, uint32_t T1, uint32_t kbase)
+{
+    __shared__ unsigned long long swin[4][HARC_MAXW3 + 32];
+    const int wv = threadIdx.x >> 6;
+    const uint32_t k = kbase + blockIdx.x * 4 + wv;
+    if (k >= nl) return;
+    const uint32_t ei = list[k];
+    (void)realign_event(s, ei, ei, estart, changed, binmin0, binmin1, lastpass, pass, T1, swin[wv], true);
+}
+// the first event of every bin in (bin, tuple) order: the chaser starts a wave per BIN, not one per event that finds out it is not a bin's first
+__global__ void k_ev_firsts(const uint32_t *rank, uint32_t nev, uint32_t *list, unsigned int *nlist)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool first = i < nev && rank[i] == 0;
+    const unsigned long long m = __ballot(first);
+    if (m) {
+        unsigned int base = 0;
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        if (lane == leader) base = atomicAdd(nlist, (unsigned int)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (first) list[base + (unsigned int)__popcll(m & ((1ULL << lane) - 1ULL))] = i;
     }
 }
 // the rank range an event belongs to ([0, r0), [r0, 4 r0), [4 r0, 16 r0) ...) as a sort key, and how many events every range holds: the passes
@@ -1497,7 +1560,7 @@ int stage2_run(harc_amd_ctx *c)
         a.trace = trace ? 1 : 0;
         struct timespec tw0; clock_gettime(CLOCK_MONOTONIC, &tw0);
         // events in (bin, tuple) order and their rank inside the bin (k_realign_big's header)
-        uint32_t *perm = nullptr, *rank = nullptr, *seglen = nullptr, *order2 = nullptr; unsigned int maxrank = 0;
+        uint32_t *perm = nullptr, *rank = nullptr, *seglen = nullptr, *order2 = nullptr, *firsts = nullptr, *looklist = nullptr; unsigned int maxrank = 0, *d_nlist = nullptr, nfirsts = 0;
         uint32_t rhi0 = 64, range_end[32];
         if (const char *e = getenv("HARC_AMD_S2_RANK0")) { const int v = atoi(e); rhi0 = v < 1 ? 1u : (uint32_t)v; }       // tests: narrow ranges on small inputs
         for (int k = 0; k < 32; k++) range_end[k] = nev;
@@ -1516,6 +1579,9 @@ int stage2_run(harc_amd_ctx *c)
             hipLaunchKernelGGL(k_ev_rank, G256(nev), rank, nev, d_changed + 1);
             RC_TRY(dalloc(c, &seglen, (size_t)nev + 1));
             hipLaunchKernelGGL(k_ev_seglen, G256(nev), (const uint32_t *)rank, nev, seglen);
+            RC_TRY(dalloc(c, &firsts, (size_t)nev + 1)); RC_TRY(dalloc(c, &d_nlist, 4)); HIP_TRY(hipMemsetAsync(d_nlist, 0, 16, c->stream));
+            hipLaunchKernelGGL(k_ev_firsts, G256(nev), (const uint32_t *)rank, nev, firsts, d_nlist);
+            HIP_TRY(hipMemcpyAsync(&nfirsts, d_nlist, 4, hipMemcpyDeviceToHost, c->stream));
             {
                 uint4 *evs = nullptr; uint64_t *wins = nullptr; RC_TRY(dalloc(c, &evs, (size_t)nev + 1)); RC_TRY(dalloc(c, &wins, (size_t)nev * W3 + 1));
                 hipLaunchKernelGGL(k_ev_gather, G256(nev), (const uint4 *)a.events, (const uint32_t *)perm, nev, evs);
@@ -1541,12 +1607,24 @@ int stage2_run(harc_amd_ctx *c)
             HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 4, c->stream));
             hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
             const uint32_t nact = (ranges && order2) ? range_end[ridx < 31 ? ridx : 31] : nev;      // the events of the ranges reached so far come first in order2
+            const bool two_kernels = (nact >= (1u << 20) || getenv("HARC_AMD_S2_TWOKERNELS")) && nact > 0 && !getenv("HARC_AMD_S2_ONEKERNEL");      // (tests force either form)
+            if (two_kernels) {
+                if (!looklist) RC_TRY(dalloc(c, &looklist, (size_t)nev + 1));
+                if (!d_nlist) RC_TRY(dalloc(c, &d_nlist, 4));
+                unsigned int nl = 0;
+                HIP_TRY(hipMemsetAsync(d_nlist, 0, 4, c->stream));
+                hipLaunchKernelGGL(k_ev_validate, G256(nact), a, nact, (const uint32_t *)(ranges ? order2 : nullptr), (const uint32_t *)perm, (const uint32_t *)rank, ranges ? rhi : 0xFFFFFFFFu, estart,
+                                   (const unsigned long long *)binmin[0], (const unsigned long long *)binmin[1], lastver, (uint32_t)npass + 1u, T + 1u, looklist, d_nlist);
+                HIP_TRY(hipMemcpyAsync(&nl, d_nlist, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                WAVE_PER_ITEM(nl, hipLaunchKernelGGL(k_realign_list, dim3(nb_), dim3(256), 0, c->stream, a, (const uint32_t *)looklist, nl, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u, kb_));
+            } else
             WAVE_PER_ITEM(nact, hipLaunchKernelGGL(k_realign_big, dim3(nb_), dim3(256), 0, c->stream, a, nact, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
                                (const uint32_t *)perm, (const uint32_t *)rank, 0u, ranges ? rhi : 0xFFFFFFFFu, (const uint32_t *)(ranges ? order2 : nullptr), kb_));     // the ranks below rlo are validated in passing: no event is ever left unlooked-at for a pass
             // the chaser, after the passes over everything from the second one on (the ranges settle by themselves; the chains it is for show
-            // when the ranges meet); its claims count for the pass (the same stamp)
-            if (perm && !nochase && !ranges && nall++ > 0) WAVE_PER_ITEM(nev, hipLaunchKernelGGL(k_realign_chase, dim3(nb_), dim3(256), 0, c->stream, a, nev, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
-                                                     (const uint32_t *)perm, (const uint32_t *)rank, (const uint32_t *)seglen, ranges ? rhi : 0xFFFFFFFFu, kb_));
+            // when the ranges meet); its claims count for the pass (the same stamp).  One wave per bin (firsts)
+            if (perm && !nochase && !ranges && nall++ > 0) WAVE_PER_ITEM(nfirsts, hipLaunchKernelGGL(k_realign_chase, dim3(nb_), dim3(256), 0, c->stream, a, nfirsts, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
+                                                     (const uint32_t *)perm, (const uint32_t *)rank, (const uint32_t *)seglen, ranges ? rhi : 0xFFFFFFFFu, kb_, (const uint32_t *)firsts));
             unsigned int chg = 0, nlook = 0;
             HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
             if (trace) HIP_TRY(hipMemcpyAsync(&nlook, d_changed + 2, 4, hipMemcpyDeviceToHost, c->stream));

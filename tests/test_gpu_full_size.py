@@ -160,6 +160,57 @@ def test_configs4_share_500M_x_150bp_pack_order():
         _free()
 
 
+def test_decoder_of_a_shard_beyond_2_32_text_bytes(tmp_path):
+    """`decoder.out` (decoder.cpp:90-169) on ONE shard of 43 M reads x 100 bp: its text is 4.34 G characters, a thread each -- beyond the 2^32 work-items a
+    one-dimensional grid holds on this platform (devutil.h: such a launch was cut short without an error; ./harc -d of a configs[2]-sized archive made with
+    -t 8 has shards of this size).  The decoded file must be the input multiset."""
+    import shutil
+    import tempfile
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    import harc_amd
+    n, L = 43_000_000, 100
+    assert n * (L + 1) > (1 << 32)
+    dev = torch.device("cuda", 0)
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (24 << 30) else None
+    h = harc_amd.HarcAmd(harc_amd.default_params(L))
+    with tempfile.TemporaryDirectory(dir=shm or str(tmp_path), prefix="harc_bigshard_") as td:
+        od = os.path.join(td, "output"); os.makedirs(od)
+        sig_in = [0, 0, 0]
+        with open(os.path.join(od, "input_clean.dna"), "wb") as f:
+            for r in bench.synth_chunks(n, L, 380_000_000, 0.0, 4321, dev):
+                lines = torch.full((r.shape[0], L + 1), 10, dtype=torch.uint8, device=dev)
+                lines[:, :L] = r
+                torch.cuda.synchronize()
+                c3 = h.reads_signature_device(lines.data_ptr(), lines.shape[0], L + 1)
+                sig_in[0] += c3[0]; sig_in[1] = (sig_in[1] + c3[1]) % (1 << 64); sig_in[2] ^= c3[2]
+                f.write(lines.cpu().numpy().tobytes())
+                del lines, r
+        open(os.path.join(od, "input_N.dna"), "wb").close()
+        np.array([n], dtype=np.uint32).tofile(os.path.join(od, "numreads.bin"))
+        torch.cuda.empty_cache()
+        harc_amd.compress(td, L, num_thr=1, num_chains=0)
+        harc_amd.decoder(td, 1)
+        out = os.path.join(od, "output.dna")
+        assert os.path.getsize(out) == n * (L + 1)
+        sig = [0, 0, 0]
+        CH = 4_000_000 * (L + 1)
+        with open(out, "rb") as f:
+            while True:
+                b = f.read(CH)
+                if not b:
+                    break
+                t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+                torch.cuda.synchronize()
+                c3 = h.reads_signature_device(t.data_ptr(), len(b) // (L + 1), L + 1)
+                sig[0] += c3[0]; sig[1] = (sig[1] + c3[1]) % (1 << 64); sig[2] ^= c3[2]
+                del t
+    h.close()
+    _free()
+    assert tuple(sig) == tuple(sig_in), "the decoded file of a 43 M-read shard is not the input multiset"
+
+
 @pytest.mark.parametrize("case", ol.md5_cases())
 def test_exact_mode_at_config_size(case, tmp_path):
     """north_star's "bit-exact vs CPU" at configs[0] / configs[1] size: num_chains = 1, num_thr = 1 against the md5 of every file the REFERENCE

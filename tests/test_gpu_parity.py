@@ -297,7 +297,8 @@ def test_kernel_variants_same_bytes(env, oracle, tmp_path, monkeypatch):
     assert_same(ol.read_dir(base), s2, ol.stage2_files(E), "stage II vs oracle under %r" % env)
 
 
-@pytest.mark.parametrize("K,S,E,maxev,ndup,sched", [(1, 16, 1, 0, 2500, ""), (8, 16, 3, 0, 2500, "rank0=1"), (4, 16, 2, 7, 2500, ""), (3, 16, 1, 0, 5200, ""), (3, 16, 1, 0, 5200, "flat"), (3, 16, 1, 0, 5200, "rank0=2")])
+@pytest.mark.parametrize("K,S,E,maxev,ndup,sched", [(1, 16, 1, 0, 2500, ""), (8, 16, 3, 0, 2500, "rank0=1"), (4, 16, 2, 7, 2500, ""), (3, 16, 1, 0, 5200, ""), (3, 16, 1, 0, 5200, "flat"), (3, 16, 1, 0, 5200, "rank0=2"),
+                                                     (3, 16, 1, 0, 5200, "two"), (8, 16, 3, 0, 2500, "rank0=1,two"), (3, 16, 1, 0, 5200, "flat,two")])
 def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, maxev, ndup, sched, oracle, tmp_path, monkeypatch):
     """ndup N reads sharing their first 50 bases: both stage-II dictionaries hold a bin of ndup > maxsearch.  The reference's
     window slides over the still-unclaimed ids (encoder.cpp:293,321-336); the GPU settles those probes as a fixed point over all of them
@@ -320,15 +321,19 @@ def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, maxev, ndup, 
 
 
 def _set_sched(monkeypatch, sched):
-    if sched == "flat":
-        monkeypatch.setenv("HARC_AMD_S2_FLATPASSES", "1")
-    elif sched == "nochase":
-        monkeypatch.setenv("HARC_AMD_S2_NOCHASE", "1")
-    elif sched.startswith("rank0="):
-        monkeypatch.setenv("HARC_AMD_S2_RANK0", sched[6:])
+    for part in sched.split(","):
+        if part == "flat":
+            monkeypatch.setenv("HARC_AMD_S2_FLATPASSES", "1")
+        elif part == "nochase":
+            monkeypatch.setenv("HARC_AMD_S2_NOCHASE", "1")
+        elif part.startswith("rank0="):
+            monkeypatch.setenv("HARC_AMD_S2_RANK0", part[6:])
+        elif part == "two":                                        # the passes in two kernels (a thread per event asks who has to look, a wave per event that has to), as on inputs with millions of such probes
+            monkeypatch.setenv("HARC_AMD_S2_TWOKERNELS", "1")
 
 
-@pytest.mark.parametrize("K,S,E,seed,fail,sched", [(1, 16, 1, 5, 0.6, ""), (4, 16, 2, 6, 0.5, "rank0=3"), (1, 16, 1, 7, 0.8, "flat"), (2, 8, 1, 8, 0.3, "rank0=1"), (1, 16, 1, 9, 0.5, "rank0=2"), (1, 16, 1, 9, 0.5, "nochase")])
+@pytest.mark.parametrize("K,S,E,seed,fail,sched", [(1, 16, 1, 5, 0.6, ""), (4, 16, 2, 6, 0.5, "rank0=3"), (1, 16, 1, 7, 0.8, "flat"), (2, 8, 1, 8, 0.3, "rank0=1"), (1, 16, 1, 9, 0.5, "rank0=2"), (1, 16, 1, 9, 0.5, "nochase"),
+                                                    (4, 16, 2, 6, 0.5, "rank0=3,two"), (1, 16, 1, 7, 0.8, "flat,two"), (1, 16, 1, 9, 0.5, "two")])
 def test_stage2_big_bins_partial_claims_exact(K, S, E, seed, fail, sched, oracle, tmp_path, monkeypatch):
     """bins above maxsearch whose reads only partly pass the Hamming test, probed from several places of the consensus: what a probe
     sees depends on which reads the probes before it took AND on the ones nobody takes (they fill the window).  The passes of
