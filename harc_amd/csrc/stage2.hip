@@ -710,6 +710,19 @@ __global__ void k_bestbin_refresh(const unsigned long long *best, const uint32_t
     if (i >= T) return;
     bb0[i] = best[ids0[i]]; bb1[i] = best[ids1[i]];
 }
+// ... and only where somebody reads them: the bins that have events (one workgroup per bin through the list of the bins' first events; the copy over all
+// 2 T entries was 9.3 ms per pass at configs[3] with repeats -- a second per step over its hundred passes -- for 1210 bins that hold a tenth of the entries)
+__global__ __launch_bounds__(256) void k_bestbin_refresh_bins(const unsigned long long *best, const uint32_t *ids0, const uint32_t *ids1, const uint4 *events, const uint32_t *firsts, uint32_t nfirsts,
+                                                              unsigned long long *bb0, unsigned long long *bb1)
+{
+    const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;
+    if (b >= nfirsts) return;
+    const uint4 ev = events[firsts[b]];
+    const int l = (int)(ev.x & 1u);
+    const uint32_t *const ids = (l ? ids1 : ids0) + ev.z;
+    unsigned long long *const bb = (l ? bb1 : bb0) + ev.z;
+    for (uint32_t i = threadIdx.x; i < ev.w; i += 256) bb[i] = best[ids[i]];
+}
 // one event (probe e, at position ei of the pass order), one wave.  validate: an event that looked in the previous pass and finds no earlier
 // claim on its bin since is validated without looking.  Returns whether a claim moved (wave-uniform).
 __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint32_t e, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
@@ -1605,7 +1618,9 @@ int stage2_run(harc_amd_ctx *c)
         RC_TRY(dalloc(c, &a.bestbin[0], (size_t)T + 1)); RC_TRY(dalloc(c, &a.bestbin[1], (size_t)T + 1));
         for (bool ranges = perm != nullptr;;) {
             HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 4, c->stream));
-            hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
+            if (firsts && nfirsts) hipLaunchKernelGGL(k_bestbin_refresh_bins, dim3(nfirsts < 65535u ? nfirsts : 65535u, (nfirsts + 65534u) / 65535u), dim3(256), 0, c->stream, (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1],
+                                                      (const uint4 *)a.events, (const uint32_t *)firsts, nfirsts, a.bestbin[0], a.bestbin[1]);
+            else hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
             const uint32_t nact = (ranges && order2) ? range_end[ridx < 31 ? ridx : 31] : nev;      // the events of the ranges reached so far come first in order2
             const bool two_kernels = (nact >= (1u << 20) || getenv("HARC_AMD_S2_TWOKERNELS")) && nact > 0 && !getenv("HARC_AMD_S2_ONEKERNEL");      // (tests force either form)
             if (two_kernels) {
