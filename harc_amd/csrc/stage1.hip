@@ -383,7 +383,11 @@ __global__ void k_place_keys(const uint64_t *skeys, const uint32_t *binstart, ui
 // bins: 2 x 2.6 ms per dictionary at configs[2]).  pass 1 (after pass 0 has finished, over the last 16 384 bins only): the few bins at the very
 // end whose slot falls past the table: they wrap around like a probe would.  Single-read bins (the common case) carry the read id in
 // `start`: one dependent load less on every hit.
-#define TP_SPAN 2048u             // table slots a workgroup of the filling placement stages in LDS (32 KB): 256 bins span ~1024 slots at load factor 1/4
+#ifndef TP_SPAN
+#define TP_SPAN 1280u             // table slots a workgroup of the filling placement stages in LDS: 256 bins span 1024 +- 64 slots at load factor 1/4.  (2048 slots = 32 KB held
+                                  // the kernel at 5 workgroups per CU, and a workgroup is a chain of five dependent loads before its first store: 10.75 ms per dictionary at
+                                  // configs[2] for 22 GB, 2.1 TB/s; 20 KB lets the CU's 8 workgroups in: 6.4 ms.  A longer stretch -- 4 sigma -- takes the untiled path)
+#endif
 __global__ __launch_bounds__(256) void k_table_place(const uint64_t *skeys, const uint32_t *sids, const uint32_t *binstart, uint32_t nbins, uint32_t n, const uint64_t *q,
                               HashSlot *slots, uint64_t cap, uint32_t bigthresh,
                               unsigned long long *large_list, unsigned int *large_n, uint32_t large_max, uint32_t large_tag, uint32_t *nbins_p, int pass, uint32_t first_block, int fill)

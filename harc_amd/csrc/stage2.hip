@@ -892,6 +892,135 @@ __global__ __launch_bounds__(256) void k_realign_list(S2Args s, const uint32_t *
     const uint32_t ei = list[k];
     (void)realign_event(s, ei, ei, estart, changed, binmin0, binmin1, lastpass, pass, T1, swin[wv], true);
 }
+// The looks TRANSPOSED (round 5, default): one wave per 64 consecutive events of the pass order -- events of ONE bin in tuple order, except where two
+// bins meet -- with an event per LANE.  A wave per event fetched, for every candidate of its window, the candidate's words by read id (64 lanes, 64
+// random lines, an early-out loop of dependent loads per lane): configs[3] with human-like repeats made 1.4 G looks of up to 1000 candidates, 10.4 s of
+// k_realign_list per step at 1.5 TB/s of such fetches.  The events of a bin look at the SAME candidates: here the wave fetches a chunk of 64 entries of
+// the bin once (claim, read id, words: lane j takes entry j) into LDS, and every lane then runs its own event over the chunk, entry by entry from the
+// highest id down -- the entry's words are the same address for all lanes (a broadcast read), the window words of the lane's event stay in registers, and
+// what a lane does with an entry is what realign_event does with it: skipped above the event's start, counted as visible when not claimed before the
+// event's tuple, tested while the window (maxsearch visible entries) is open.  The fetches per look fall by the number of lanes that look (the events
+// that have to look again are the ones BEHIND a claim that moved: runs of neighbours), the compare becomes the kernel's cost: ~35 vector instructions
+// per entry for 64 events.
+// The lanes of a bin are in tuple order, and that is used: when several of them accept an entry in the same step, the first one -- the smallest tuple --
+// claims it, and for the lanes behind it the entry is claimed before their tuple from that moment (not visible, not counted): within a wave the events
+// see each other's claims as the sequential run would, instead of one pass later.  (Any such value is a claim that holds: the argument above k_realign_big.)
+template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args s, uint32_t nact, const uint32_t *order2, const uint32_t *rank, uint32_t rhi, uint32_t *estart, unsigned int *changed,
+                                                                         unsigned long long *binmin0, unsigned long long *binmin1, uint32_t *lastpass, uint32_t pass, uint32_t T1, int sorted)
+{
+    __shared__ unsigned long long sw[4][64 * NW];                  // the chunk: words of entry j at [j * NW, j * NW + NW)
+    __shared__ unsigned long long sb[4][64];                       // its claims
+    __shared__ uint32_t srid[4][64];                               // its read ids
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t k = harc_gid();                                 // a thread per event of the pass order (G256: more than 2^32 threads go to a second grid row)
+    const int W3 = s.W3;
+    const unsigned long long tmask = (1ULL << EV_TBITS) - 1ULL, stamp = ((unsigned long long)(~pass & 0xFFFFFFu)) << EV_TBITS;
+    const size_t cur = (size_t)(pass & 1u) * T1, prv = (size_t)((pass - 1u) & 1u) * T1;
+    // ---- which lanes look (the tests of k_ev_validate / the top of realign_event, in the same order)
+    bool look = false; uint32_t ei = 0, st = 0, cnt = 0; int l = 0; unsigned long long tp = 0;
+    if (k < nact) {
+        ei = order2 ? order2[k] : (uint32_t)k;
+        const uint32_t lp = lastpass[ei];
+        bool go = lp != EV_DONE;
+        if (go && rank && rank[ei] >= rhi) go = false;
+        if (go) {
+            const uint4 ev = s.events[ei];
+            tp = (unsigned long long)ev.x | ((unsigned long long)ev.y << 32);
+            l = (int)(tp & 1); st = ev.z; cnt = ev.w;
+            bool moved = true;
+            if (lp == pass - 1) {
+                const unsigned long long m = __hip_atomic_load((l ? binmin1 : binmin0) + prv + st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                moved = (m >> EV_TBITS) == (unsigned long long)(~(pass - 1) & 0xFFFFFFu) && (m & tmask) < tp;
+                if (!moved) lastpass[ei] = pass;
+            }
+            if (moved) { if (estart[ei] == 0) lastpass[ei] = EV_DONE; else look = true; }
+        }
+    }
+    unsigned long long todo = __ballot(look);
+    if (!todo) return;
+    if (s.trace && lane == 0) atomicAdd(changed + 2, (unsigned int)__popcll(todo));
+    unsigned long long win[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) win[w] = s.evwin[(size_t)(look ? ei : 0u) * W3 + (w < W3 ? w : W3 - 1)];
+#pragma unroll
+    for (int w = 0; w < NW; w++) if (!look || w >= W3) win[w] = 0ULL;
+    bool anych = false;
+    while (todo) {                                                 // bin by bin (one, nearly always)
+        const int first = __ffsll((long long)todo) - 1;
+        const uint32_t g_st = (uint32_t)__shfl((int)st, first, 64); const int g_l = __shfl(l, first, 64);
+        const uint32_t g_cnt = (uint32_t)__shfl((int)cnt, first, 64);
+        const bool act = look && st == g_st && l == g_l;
+        const unsigned long long grp = __ballot(act);
+        todo &= ~grp;
+        const uint32_t *const idl = s.ids[g_l] + g_st;
+        unsigned long long *const bbl = s.bestbin[g_l] + g_st;
+        uint32_t top0 = 0;
+        if (act) { top0 = estart[ei]; if (top0 > g_cnt) top0 = g_cnt; }
+        uint32_t top = top0, seen = 0; bool leading = true, done = !act, ch = false;
+        uint32_t pos0 = top0;                                      // the chunk covers the entries [pos0 - nv, pos0), lane j fetches entry pos0 - 1 - j
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)pos0, o, 64); pos0 = x > pos0 ? x : pos0; }
+        while (pos0 > 0 && __ballot(!done)) {
+            const uint32_t nv = pos0 < 64u ? pos0 : 64u;
+            __builtin_amdgcn_wave_barrier();
+            if ((uint32_t)lane < nv) {
+                const uint32_t p = pos0 - 1u - (uint32_t)lane;
+                const uint32_t rid = idl[p];
+                sb[wv][lane] = __hip_atomic_load(&bbl[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                srid[wv][lane] = rid;
+                const uint64_t *r = s.cand3 + (size_t)rid * W3;
+                unsigned long long cw[NW];                         // all words asked for at once (a word behind the read's last: its last word again, then dropped)
+#pragma unroll
+                for (int w = 0; w < NW; w++) cw[w] = r[w < W3 ? w : W3 - 1];
+#pragma unroll
+                for (int w = 0; w < NW; w++) sw[wv][lane * NW + w] = w < W3 ? cw[w] : 0ULL;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = 0; j < nv; j++) {
+                const uint32_t p = pos0 - 1u - j;
+                const unsigned long long bj = sb[wv][j];
+                const bool in = !done && p < top0;
+                bool un = in && bj >= tp;                          // not claimed before this event's tuple (claimed BY it in an earlier pass counts as visible)
+                if (leading && in) { if (un) leading = false; else top = p; }      // the claimed reads on top stay claimed for this event
+                const bool test = un && bj > tp;
+                if (__ballot(test)) {
+                    int hd = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) hd += __popcll(win[w] ^ sw[wv][j * NW + w]);
+                    const unsigned long long pm = __ballot(test && hd <= s.thresh_s);      // every passing candidate of the window is taken (encoder.cpp:296-317)
+                    if (pm) {
+                        // (sorted: the pass order is (bin, tuple) order.  HARC_AMD_S2_FLATPASSES runs over the events as they were recorded: there every
+                        // lane that accepts the entry bids for it, as separate waves would)
+                        const int f = sorted ? __ffsll((long long)pm) - 1 : -1;   // the smallest tuple among them
+                        if (sorted ? lane == f : (test && hd <= s.thresh_s)) {
+                            const uint32_t rid = srid[wv][j];
+                            if (atomicMin(&s.best[rid], tp) > tp) {
+                                atomicMin(&bbl[p], tp);
+                                ch = true;
+                                // the read's bin in the other dictionary sees a claim at this tuple too
+                                const unsigned long long *r = &sw[wv][j * NW];
+                                const int ol = 1 - g_l, off = 3 * s.ds[ol], wi = off >> 6, sh = off & 63;
+                                uint64_t okey = r[wi] >> sh;
+                                if (sh && wi + 1 < W3) okey |= r[wi + 1] << (64 - sh);
+                                if (s.kbits[ol] < 64) okey &= ((uint64_t)1 << s.kbits[ol]) - 1;
+                                uint32_t ost = 0, ocnt = 0;
+                                if (dict_lookup_b(s.slots[ol], s.cap[ol], okey, &ost, &ocnt) && !(ocnt & SLOT_EMB)) atomicMin((ol ? binmin1 : binmin0) + cur + ost, stamp | tp);
+                            }
+                        } else if (sorted && lane > f) un = false;  // claimed at a tuple below this lane's: not visible to it any more
+                    }
+                }
+                if (un) { seen++; if (seen >= (uint32_t)s.maxsearch) done = true; }
+            }
+            pos0 -= nv;
+        }
+        if (act) {
+            estart[ei] = top; lastpass[ei] = g_cnt <= (uint32_t)s.maxsearch ? EV_DONE : pass;
+            if (ch) atomicMin((g_l ? binmin1 : binmin0) + cur + g_st, stamp | tp);
+        }
+        anych |= __ballot(ch) != 0;
+    }
+    if (anych && lane == 0) atomicOr(changed, 1u);
+}
 // the first event of every bin in (bin, tuple) order: the chaser starts a wave per BIN, not one per event that finds out it is not a bin's first
 __global__ void k_ev_firsts(const uint32_t *rank, uint32_t nev, uint32_t *list, unsigned int *nlist)
 {
@@ -1623,7 +1752,15 @@ int stage2_run(harc_amd_ctx *c)
             else hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
             const uint32_t nact = (ranges && order2) ? range_end[ridx < 31 ? ridx : 31] : nev;      // the events of the ranges reached so far come first in order2
             const bool two_kernels = (nact >= (1u << 20) || getenv("HARC_AMD_S2_TWOKERNELS")) && nact > 0 && !getenv("HARC_AMD_S2_ONEKERNEL");      // (tests force either form)
-            if (two_kernels) {
+            // default: an event per lane (k_realign_block); HARC_AMD_S2_BLOCK=0, or either of the two variables above: a wave per event (rounds 2-5; tests)
+            const bool block = nact > 0 && !getenv("HARC_AMD_S2_TWOKERNELS") && !getenv("HARC_AMD_S2_ONEKERNEL") && !(getenv("HARC_AMD_S2_BLOCK") && atoi(getenv("HARC_AMD_S2_BLOCK")) == 0);
+            if (block) {
+#define BLOCK_ARGS a, nact, (const uint32_t *)(ranges ? order2 : nullptr), (const uint32_t *)(perm ? rank : nullptr), ranges ? rhi : 0xFFFFFFFFu, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u, perm ? 1 : 0
+                if (W3 <= 5) hipLaunchKernelGGL((k_realign_block<5>), G256(nact), BLOCK_ARGS);
+                else if (W3 <= 8) hipLaunchKernelGGL((k_realign_block<8>), G256(nact), BLOCK_ARGS);
+                else hipLaunchKernelGGL((k_realign_block<HARC_MAXW3>), G256(nact), BLOCK_ARGS);
+#undef BLOCK_ARGS
+            } else if (two_kernels) {
                 if (!looklist) RC_TRY(dalloc(c, &looklist, (size_t)nev + 1));
                 if (!d_nlist) RC_TRY(dalloc(c, &d_nlist, 4));
                 unsigned int nl = 0;

@@ -298,13 +298,15 @@ def test_kernel_variants_same_bytes(env, oracle, tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize("K,S,E,maxev,ndup,sched", [(1, 16, 1, 0, 2500, ""), (8, 16, 3, 0, 2500, "rank0=1"), (4, 16, 2, 7, 2500, ""), (3, 16, 1, 0, 5200, ""), (3, 16, 1, 0, 5200, "flat"), (3, 16, 1, 0, 5200, "rank0=2"),
-                                                     (3, 16, 1, 0, 5200, "two"), (8, 16, 3, 0, 2500, "rank0=1,two"), (3, 16, 1, 0, 5200, "flat,two")])
+                                                     (3, 16, 1, 0, 5200, "two"), (8, 16, 3, 0, 2500, "rank0=1,two"), (3, 16, 1, 0, 5200, "flat,two"),
+                                                     (3, 16, 1, 0, 5200, "wave"), (8, 16, 3, 0, 2500, "rank0=1,wave"), (3, 16, 1, 0, 5200, "flat,wave"), (4, 16, 2, 7, 2500, "wave")])
 def test_stage2_bins_above_maxsearch_sliding_window_exact(K, S, E, maxev, ndup, sched, oracle, tmp_path, monkeypatch):
     """ndup N reads sharing their first 50 bases: both stage-II dictionaries hold a bin of ndup > maxsearch.  The reference's
     window slides over the still-unclaimed ids (encoder.cpp:293,321-336); the GPU settles those probes as a fixed point over all of them
     at once (k_realign_big) -- same bytes as the sequential oracle.  maxev: a deliberately tiny event buffer, so that the pass has to be
     repeated with the size it asks for; ndup = 5200: five windows deep.  sched: the passes go over rank ranges of the events inside their
-    bin (first range 64 wide; forced to 1 or 2 here so that a small input walks through many ranges) or, "flat", over all events every time."""
+    bin (first range 64 wide; forced to 1 or 2 here so that a small input walks through many ranges) or, "flat", over all events every time;
+    the looks with an event per lane (k_realign_block, the default), with a wave per event ("wave"), or that in two kernels ("two")."""
     import harc_amd
     if maxev:
         monkeypatch.setenv("HARC_AMD_MAXEVENTS", str(maxev))
@@ -328,12 +330,15 @@ def _set_sched(monkeypatch, sched):
             monkeypatch.setenv("HARC_AMD_S2_NOCHASE", "1")
         elif part.startswith("rank0="):
             monkeypatch.setenv("HARC_AMD_S2_RANK0", part[6:])
+        elif part == "wave":                                       # a wave per event (k_realign_big) instead of an event per lane (k_realign_block)
+            monkeypatch.setenv("HARC_AMD_S2_BLOCK", "0")
         elif part == "two":                                        # the passes in two kernels (a thread per event asks who has to look, a wave per event that has to), as on inputs with millions of such probes
             monkeypatch.setenv("HARC_AMD_S2_TWOKERNELS", "1")
 
 
 @pytest.mark.parametrize("K,S,E,seed,fail,sched", [(1, 16, 1, 5, 0.6, ""), (4, 16, 2, 6, 0.5, "rank0=3"), (1, 16, 1, 7, 0.8, "flat"), (2, 8, 1, 8, 0.3, "rank0=1"), (1, 16, 1, 9, 0.5, "rank0=2"), (1, 16, 1, 9, 0.5, "nochase"),
-                                                    (4, 16, 2, 6, 0.5, "rank0=3,two"), (1, 16, 1, 7, 0.8, "flat,two"), (1, 16, 1, 9, 0.5, "two")])
+                                                    (4, 16, 2, 6, 0.5, "rank0=3,two"), (1, 16, 1, 7, 0.8, "flat,two"), (1, 16, 1, 9, 0.5, "two"),
+                                                    (4, 16, 2, 6, 0.5, "rank0=3,wave"), (1, 16, 1, 7, 0.8, "flat,wave"), (1, 16, 1, 9, 0.5, "wave"), (2, 8, 1, 8, 0.3, "rank0=1,wave")])
 def test_stage2_big_bins_partial_claims_exact(K, S, E, seed, fail, sched, oracle, tmp_path, monkeypatch):
     """bins above maxsearch whose reads only partly pass the Hamming test, probed from several places of the consensus: what a probe
     sees depends on which reads the probes before it took AND on the ones nobody takes (they fill the window).  The passes of
@@ -349,6 +354,22 @@ def test_stage2_big_bins_partial_claims_exact(K, S, E, seed, fail, sched, oracle
     assert_same(ol.read_dir(base), s2, ol.stage2_files(E), "stage II, partly matching bins above maxsearch vs oracle")
     nleft = len(s2["input_N.dna"]) // 101
     assert 200 < nleft < 3000 - 200                              # some were taken, some never are
+
+
+@pytest.mark.parametrize("L,sched", [(150, ""), (150, "rank0=2"), (250, ""), (250, "wave"), (106, "rank0=1"), (107, "")])
+def test_stage2_big_bins_other_read_lengths(L, sched, oracle, tmp_path, monkeypatch):
+    """the same partly matching bins above maxsearch at other read lengths: k_realign_block is compiled for windows of up to 5 / 8 / 12 words of the
+    3-bit code (reads of up to 106 / 170 / 255 bases)"""
+    import harc_amd
+    _set_sched(monkeypatch, sched)
+    txt = gen.reads_text_bigbin_stage2_mixed(11 + L, L=L, genome_len=8000, fail_frac=0.5, nsub=max(16, L // 3))
+    (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, L, 2, 2, tmp_path / "o", 16)
+    base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.compress(base, L, num_thr=2, num_chains=2, num_steps=16)
+    assert_same(ol.read_dir(base), s2, ol.stage2_files(2), "stage II, bins above maxsearch at L = %d vs oracle" % L)
+    nleft = len(s2["input_N.dna"]) // (L + 1)
+    assert 100 < nleft < 3000 - 100                              # some were taken, some never are
 
 
 @pytest.mark.parametrize("case", CASES)
