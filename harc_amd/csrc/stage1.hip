@@ -293,11 +293,12 @@ __global__ void k_mark_heads(const uint64_t *skeys, uint32_t n, uint32_t *head)
     if (i >= n) return;
     head[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1u : 0u;
 }
-__global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint32_t n, uint32_t *binstart, uint32_t *nbins)
+// ... and, with the keys at hand, what the placement's max-scan starts from: 4 b_i - i of bin i (see below), biased by n to stay unsigned
+__global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint32_t n, uint32_t *binstart, uint32_t *nbins, const uint64_t *skeys, uint64_t cap, uint64_t *v)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (head[i]) binstart[binidx[i]] = i;
+    if (head[i]) { const uint32_t b = binidx[i]; binstart[b] = i; v[b] = bucket_slot(skeys[i], cap) + (uint64_t)n - (uint64_t)b; }
     if (i == n - 1) *nbins = binidx[i] + head[i];
 }
 #define HARC_LARGEBIN 16u    // stage-I bins with more reads than this are compacted between super-rounds (k_compact_bins)
@@ -374,11 +375,6 @@ __global__ void k_rotate_keys(uint64_t *keys, uint32_t n, unsigned rot)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) keys[i] = rotl64(keys[i], rot);
 }
-__global__ void k_place_keys(const uint64_t *skeys, const uint32_t *binstart, uint32_t nbins, uint64_t cap, uint64_t *v)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nbins) v[i] = bucket_slot(skeys[binstart[i]], cap) + (uint64_t)nbins - (uint64_t)i;     // 4 b_i - i, biased by nbins to stay unsigned
-}
 // pass 0: the bins whose slot lies inside the table, plain 16-byte stores, overflow flags included (round 2 set them in a second pass over all
 // bins: 2 x 2.6 ms per dictionary at configs[2]).  pass 1 (after pass 0 has finished, over the last 16 384 bins only): the few bins at the very
 // end whose slot falls past the table: they wrap around like a probe would.  Single-read bins (the common case) carry the read id in
@@ -396,7 +392,7 @@ __global__ __launch_bounds__(256) void k_table_place(const uint64_t *skeys, cons
     if (blockIdx.x < first_block) return;                                          // pass 1: the bins beyond the end of the table are among the last
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool have = i < nbins;
-    auto slot_of = [&](uint32_t k) -> uint64_t { return q[k] - (uint64_t)nbins + (uint64_t)k; };     // max-scan value + k
+    auto slot_of = [&](uint32_t k) -> uint64_t { return q[k] - (uint64_t)n + (uint64_t)k; };     // max-scan value (biased by n, k_bin_starts) + k
     // fill (pass 0): the table has NOT been cleared (22 GB per dictionary at configs[2]): slots grow with the bin index, so the 256 bins of a
     // workgroup own one contiguous stretch of the table -- from behind the last slot of the workgroup before to their own last slot, to the end
     // of the table for the last bins inside it.  The stretch is put together in LDS (zeros, then the bins' slots) and written out as ONE
@@ -2525,7 +2521,8 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     if (const char *e = getenv("HARC_AMD_SORT_BITS")) { const int x = atoi(e); if (x >= 1 && x <= 64) sbits = (unsigned)x; }
     uint32_t *mixed = nullptr; unsigned int *mmeta = nullptr; uint64_t *k2 = nullptr;
     RC_TRY(dalloc(c, &mixed, MIXED_MAX)); RC_TRY(dalloc(c, &mmeta, 4));
-    if (sbits < 64) RC_TRY(dalloc(c, &k2, n));
+    RC_TRY(dalloc(c, &k2, n));                                    // the sort's output on the top bits; then (k_bin_starts) what the placement's max-scan starts from
+    uint64_t *const k2v = k2;
     hipLaunchKernelGGL(k_scramble_keys, dim3(g), dim3(256), 0, c->stream, keys, n, sbits < 64 ? sbits : 0u);
     uint32_t nbins = 0;
     for (;;) {
@@ -2539,7 +2536,7 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
         } else RC_TRY(prim_sort_pairs_u64_u32(c, keys, k1, ids, d->ids, n, 64));
         hipLaunchKernelGGL(k_mark_heads, dim3(g), dim3(256), 0, c->stream, k1, n, h0);
         RC_TRY(prim_excl_scan_u32(c, h0, b0, n));
-        hipLaunchKernelGGL(k_bin_starts, dim3(g), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins);
+        hipLaunchKernelGGL(k_bin_starts, dim3(g), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins, (const uint64_t *)k1, d->cap, k2v);
         unsigned int mm[2] = { 0, 0 };
         HIP_TRY(hipMemcpyAsync(&nbins, d->d_nbins, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(mm, mmeta, 8, hipMemcpyDeviceToHost, c->stream));
@@ -2554,10 +2551,8 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     if (!fill) HIP_TRY(hipMemsetAsync(d->slots, 0, d->cap * sizeof(HashSlot), c->stream));
     d->nbins = nbins;
     {
-        uint64_t *v = keys, *q = nullptr;                          // the unsorted keys are not needed any more
-        RC_TRY(dalloc(c, &q, (size_t)nbins + 1));
+        uint64_t *v = k2v, *q = keys;                              // the unsorted keys are not needed any more
         const unsigned gb = (nbins + 255) / 256;
-        hipLaunchKernelGGL(k_place_keys, dim3(gb), dim3(256), 0, c->stream, (const uint64_t *)k1, (const uint32_t *)bs, nbins, d->cap, v);
         RC_TRY(prim_incl_max_u64(c, v, q, nbins));
         for (int pass = 0; pass < 2; pass++)
             hipLaunchKernelGGL(k_table_place, dim3(gb), dim3(256), 0, c->stream, (const uint64_t *)k1, (const uint32_t *)d->ids, (const uint32_t *)bs, nbins, n, (const uint64_t *)q,

@@ -1096,14 +1096,26 @@ __global__ void k_merge_cuts(const uint64_t *gstart, uint32_t i0, uint32_t n, co
     while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if ((tup[mid] >> 2) < g) lo = mid; else hi = mid; }
     cut[b] = lo;
 }
-__global__ void k_merge_orig(const uint64_t *gstart, uint32_t i0, uint32_t n, const uint64_t *tup, uint32_t A, FinalArrays f, uint32_t fbase, const long long *cut)
+// (round 5: the candidates between the two cuts go to LDS first, one coalesced read for the workgroup, and the searches run there -- through global
+// memory every read made ~6 dependent loads of lines its neighbours had just asked for: 1.7 ms per shard of 44 M reads at configs[2], eight shards a step)
+#define MERGE_TILE 2048
+__global__ __launch_bounds__(256) void k_merge_orig(const uint64_t *gstart, uint32_t i0, uint32_t n, const uint64_t *tup, uint32_t A, FinalArrays f, uint32_t fbase, const long long *cut)
 {
+    __shared__ uint64_t cols[MERGE_TILE];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long c0 = cut[blockIdx.x], c1 = cut[blockIdx.x + 1] + 1;      // tup[c0] < g (or c0 = -1); tup[c1] >= the next block's first g >= g (or c1 = A)
+    const long long inside = c1 - c0 - 1;                                  // the candidates a search of this block can land on
+    const bool tiled = inside <= MERGE_TILE;
+    if (tiled) {
+        for (long long j = threadIdx.x; j < inside; j += 256) cols[j] = tup[c0 + 1 + j] >> 2;
+        __syncthreads();
+    }
     if (t >= n) return;
     const uint32_t i = i0 + t;
     const uint64_t g = gstart[i];
-    long long lo = cut[blockIdx.x], hi = cut[blockIdx.x + 1] + 1;  // tup[lo] < g (or lo = -1); tup[hi] >= the next block's first g >= g (or hi = A)
-    while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if ((tup[mid] >> 2) < g) lo = mid; else hi = mid; }
+    long long lo = c0, hi = c1;
+    if (tiled) while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if (cols[mid - c0 - 1] < g) lo = mid; else hi = mid; }
+    else while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if ((tup[mid] >> 2) < g) lo = mid; else hi = mid; }
     const uint32_t at = i + (uint32_t)(lo + 1) - fbase;
     f.ref[at] = i; f.kind[at] = 0; f.g[at] = g;
 }
