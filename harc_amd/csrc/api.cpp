@@ -177,6 +177,9 @@ extern "C" int harc_amd_create(const harc_amd_params *params, harc_amd_ctx **out
     c->W3 = (3 * params->readlen + 63) / 64;
     memset(&c->C, 0, sizeof c->C);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; harc_set_error("hipStreamCreate failed"); return HARC_AMD_ENODEVICE; }
+    // (Under rocprofv3 the device -> host copies of the copy stream show up as kernels of the runtime's, __amd_rocclr_copyBuffer, and the kernels of the main
+    // stream beside them as stretched to the copy's length -- configs[3]: k_acc_flags 30 ms beside a 1.4 GB copy.  Outside the profiler the copies do not
+    // take compute units: a copy stream held to 8 / 16 / 32 units by a CU mask changed nothing, profiles/r05.)
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) {
         if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
         (void)hipStreamDestroy(c->stream); delete c; harc_set_error("hipStreamCreate failed"); return HARC_AMD_ENODEVICE;

@@ -46,6 +46,8 @@ struct S2Args {
     // so whole contigs -- and launches its tile kernels from tile `tile_base` on; on one GPU: [0, total), 0
     uint64_t col0, col1; uint32_t tile_base;
     const uint64_t *evwin;             // k_realign_big: the 3-bit window words of every event (k_ev_windows), W3 per event
+    int binmax_on;                     // (HARC_AMD_S2_RANGE=0: off -- every event behind the earliest moved claim looks again, as before round 5; tests)
+    unsigned long long *binmax[2];     // window passes: per bin, (pass stamp, the LATEST tuple a claim of the bin was moved away from in that pass) -- see EV_TBITS
 };
 
 // ---------------------------------------------------------------------------------------------- small device helpers
@@ -696,6 +698,11 @@ __global__ void k_ev_rank(uint32_t *seg, uint32_t nev, unsigned int *maxrank)
 // pass and finds no entry of that pass below its own tuple is validated again without touching the bin.  (A version counter per bin made
 // every event of a bin look again whenever ANY claim of the bin moved: once the ranges had settled, 16 more passes of 13 ms over all
 // events of the deep bins while a handful of claims moved between the two dictionaries -- c3sd with another stage-I schedule: 220 ms.)
+// (round 5) ... and only an event BETWEEN the two tuples of a moved claim: a claim that moves from tuple t_old to t_new < t_old changes "claimed before my
+// tuple" for the events with t_new < tuple <= t_old and for nobody else (behind t_old the read was claimed before and still is).  binmax[l][bin] = (pass
+// stamp, the largest t_old of the pass; all ones in the tuple field for a read that was unclaimed), kept with atomicMax on (pass << 40 | t_old).  Once
+// the claims only shift among neighbouring probes -- the last ten passes over everything at configs[3] with repeats, 20 M probes looking again in each --
+// the probes behind the place where it happens stay validated.
 #define EV_TBITS 40
 // The claims in bin order.  A look used to gather best[ids[l][..]] -- 64 random 8-byte loads per chunk, ~2 G of them per step on a repeat-rich
 // 50 M-read set; a deep bin is looked at by hundreds of thousands of events that all want the same entries.  Before every pass one thread per
@@ -741,7 +748,8 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
     const unsigned long long tmask = (1ULL << EV_TBITS) - 1ULL, stamp = ((unsigned long long)(~pass & 0xFFFFFFu)) << EV_TBITS;
     if (validate && lp == pass - 1) {                             // looked, or was validated, in the previous pass: anything earlier than this event since?
         const unsigned long long m = __hip_atomic_load(mymin + prv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool moved = (m >> EV_TBITS) == (unsigned long long)(~(pass - 1) & 0xFFFFFFu) && (m & tmask) < tp;
+        bool moved = (m >> EV_TBITS) == (unsigned long long)(~(pass - 1) & 0xFFFFFFu) && (m & tmask) < tp;
+        if (moved && s.binmax_on) { const unsigned long long x = __hip_atomic_load(s.binmax[l] + prv + st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if ((x >> EV_TBITS) == (unsigned long long)((pass - 1) & 0xFFFFFFu)) moved = tp <= (x & tmask); }
         if (!moved) { if (lane == 0) lastpass[ei] = pass; return false; }
     }
     if (estart[ei] == 0) { if (lane == 0) lastpass[ei] = EV_DONE; return false; }      // every read of the bin was claimed before this event: claims only move to earlier tuples
@@ -753,6 +761,8 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
     __builtin_amdgcn_wave_barrier();
     uint32_t top = estart[ei]; if (top > cnt) top = cnt;
     uint32_t seen = 0, pos = top; bool ch = false, leading = true;   // wave-uniform
+    unsigned long long oldmax = 0;                                 // the latest tuple a claim of this look was taken from (per lane)
+    const unsigned long long pstamp = ((unsigned long long)(pass & 0xFFFFFFu)) << EV_TBITS;
     // claims from the bin-ordered copy (k_bestbin_refresh), the next chunk's requested before this one is worked on (more in flight -- two ahead with
     // the gathered claims, eight, or four at once with the copy -- cost the many short looks more than they saved the long ones); ids only for
     // the candidates tested
@@ -776,23 +786,26 @@ __device__ __forceinline__ bool realign_event(const S2Args &s, uint32_t ei, uint
             const uint64_t *r = s.cand3 + (size_t)rid * W3;
             int hd = 0;
             for (int w = 0; w < W3; w++) { hd += __popcll(swin[w] ^ r[w]); if (hd > s.thresh_s) break; }
-            if (hd <= s.thresh_s && atomicMin(&s.best[rid], tp) > tp) {               // every passing candidate of the window is taken (encoder.cpp:296-317)
+            unsigned long long old = 0;
+            if (hd <= s.thresh_s && (old = atomicMin(&s.best[rid], tp)) > tp) {      // every passing candidate of the window is taken (encoder.cpp:296-317)
                 atomicMin(&bbl[pos - 1 - lane], tp);
                 ch = true;
+                old = old > tmask ? tmask : old; oldmax = old > oldmax ? old : oldmax;
                 // the read's bin in the other dictionary sees a claim at this tuple too
                 const int ol = 1 - l, off = 3 * s.ds[ol], wi = off >> 6, sh = off & 63;
                 uint64_t okey = r[wi] >> sh;
                 if (sh && wi + 1 < W3) okey |= r[wi + 1] << (64 - sh);
                 if (s.kbits[ol] < 64) okey &= ((uint64_t)1 << s.kbits[ol]) - 1;
                 uint32_t ost = 0, ocnt = 0;
-                if (dict_lookup_b(s.slots[ol], s.cap[ol], okey, &ost, &ocnt) && !(ocnt & SLOT_EMB)) atomicMin((ol ? binmin1 : binmin0) + cur + ost, stamp | tp);
+                if (dict_lookup_b(s.slots[ol], s.cap[ol], okey, &ost, &ocnt) && !(ocnt & SLOT_EMB)) { atomicMin((ol ? binmin1 : binmin0) + cur + ost, stamp | tp); atomicMax(s.binmax[ol] + cur + ost, pstamp | old); }
             }
         }
         seen += (uint32_t)__popcll(um);
         pos = pos1; pos1 = pos2; b = b1;
     }
     ch = __ballot(ch) != 0;
-    if (lane == 0) { estart[ei] = top; lastpass[ei] = cnt <= (uint32_t)s.maxsearch ? EV_DONE : pass; if (ch) { atomicMin(mymin + cur, stamp | tp); atomicOr(changed, 1u); } }
+    if (ch) for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = shfl_u64(oldmax, (lane + o) & 63); oldmax = x > oldmax ? x : oldmax; }
+    if (lane == 0) { estart[ei] = top; lastpass[ei] = cnt <= (uint32_t)s.maxsearch ? EV_DONE : pass; if (ch) { atomicMin(mymin + cur, stamp | tp); atomicMax(s.binmax[l] + cur + st, pstamp | oldmax); atomicOr(changed, 1u); } }
     return ch;
 }
 __global__ __launch_bounds__(256) void k_realign_big(S2Args s, uint32_t nev, uint32_t *estart, unsigned int *changed, unsigned long long *binmin0, unsigned long long *binmin1,
@@ -868,6 +881,7 @@ __global__ void k_ev_validate(S2Args s, uint32_t nact, const uint32_t *order2, c
             if (lp == pass - 1) {
                 const unsigned long long m = ((l ? binmin1 : binmin0) + ev.z)[(size_t)((pass - 1u) & 1u) * T1];
                 moved = (m >> EV_TBITS) == (unsigned long long)(~(pass - 1) & 0xFFFFFFu) && (m & ((1ULL << EV_TBITS) - 1ULL)) < tp;
+                if (moved && s.binmax_on) { const unsigned long long x = (s.binmax[l] + ev.z)[(size_t)((pass - 1u) & 1u) * T1]; if ((x >> EV_TBITS) == (unsigned long long)((pass - 1) & 0xFFFFFFu)) moved = tp <= (x & ((1ULL << EV_TBITS) - 1ULL)); }
                 if (!moved) lastpass[ei] = pass;
             }
             if (moved) { if (estart[ei] == 0) lastpass[ei] = EV_DONE; else look = true; }
@@ -906,8 +920,13 @@ __global__ __launch_bounds__(256) void k_realign_list(S2Args s, const uint32_t *
 // claims it, and for the lanes behind it the entry is claimed before their tuple from that moment (not visible, not counted): within a wave the events
 // see each other's claims as the sequential run would, instead of one pass later.  (Any such value is a claim that holds: the argument above k_realign_big.)
 template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args s, uint32_t nact, const uint32_t *order2, const uint32_t *rank, uint32_t rhi, uint32_t *estart, unsigned int *changed,
-                                                                         unsigned long long *binmin0, unsigned long long *binmin1, uint32_t *lastpass, uint32_t pass, uint32_t T1, int sorted)
+                                                                         unsigned long long *binmin0, unsigned long long *binmin1, uint32_t *lastpass, uint32_t pass, uint32_t T1, int sorted, uint32_t *ebot)
 {
+    // ebot[event] (may be null: HARC_AMD_S2_EBOT=0): the lowest entry of its bin the event has had in its open window so far.  An event that looks AGAIN
+    // tests only below it: an entry above it that is visible now (not claimed before the event's tuple) was visible at that look as well -- claims only
+    // move to earlier tuples -- and was tested then, with the result it would have now; everything else above it is claimed before the tuple and stays so.
+    // What remains of a second look is the count of the visible entries from the claims alone (the window still has to be found), and the chunks wholly
+    // above every lane's mark are not fetched at all.  (The late passes over everything are such looks: 20 M of them per pass at configs[3] with repeats.)
     __shared__ unsigned long long sw[4][64 * NW];                  // the chunk: words of entry j at [j * NW, j * NW + NW)
     __shared__ unsigned long long sb[4][64];                       // its claims
     __shared__ uint32_t srid[4][64];                               // its read ids
@@ -931,6 +950,7 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
             if (lp == pass - 1) {
                 const unsigned long long m = __hip_atomic_load((l ? binmin1 : binmin0) + prv + st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 moved = (m >> EV_TBITS) == (unsigned long long)(~(pass - 1) & 0xFFFFFFu) && (m & tmask) < tp;
+                if (moved && s.binmax_on) { const unsigned long long x = __hip_atomic_load(s.binmax[l] + prv + st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if ((x >> EV_TBITS) == (unsigned long long)((pass - 1) & 0xFFFFFFu)) moved = tp <= (x & tmask); }
                 if (!moved) lastpass[ei] = pass;
             }
             if (moved) { if (estart[ei] == 0) lastpass[ei] = EV_DONE; else look = true; }
@@ -938,7 +958,7 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
     }
     unsigned long long todo = __ballot(look);
     if (!todo) return;
-    if (s.trace && lane == 0) atomicAdd(changed + 2, (unsigned int)__popcll(todo));
+    if (s.trace && lane == 0) { atomicAdd(changed + 2, (unsigned int)__popcll(todo)); atomicAdd(changed + 3, 1u); }      // trace only: events that look, waves that hold one
     unsigned long long win[NW];
 #pragma unroll
     for (int w = 0; w < NW; w++) win[w] = s.evwin[(size_t)(look ? ei : 0u) * W3 + (w < W3 ? w : W3 - 1)];
@@ -954,18 +974,21 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
         todo &= ~grp;
         const uint32_t *const idl = s.ids[g_l] + g_st;
         unsigned long long *const bbl = s.bestbin[g_l] + g_st;
-        uint32_t top0 = 0;
-        if (act) { top0 = estart[ei]; if (top0 > g_cnt) top0 = g_cnt; }
+        uint32_t top0 = 0, ebot0 = 0xFFFFFFFFu, plow = 0xFFFFFFFFu;
+        if (act) { top0 = estart[ei]; if (top0 > g_cnt) top0 = g_cnt; if (ebot) ebot0 = ebot[ei]; }
         uint32_t top = top0, seen = 0; bool leading = true, done = !act, ch = false;
+        unsigned long long oldmax = 0;                             // the latest tuple a claim of this lane's event was taken from
+        const unsigned long long pstamp = ((unsigned long long)(pass & 0xFFFFFFu)) << EV_TBITS;
         uint32_t pos0 = top0;                                      // the chunk covers the entries [pos0 - nv, pos0), lane j fetches entry pos0 - 1 - j
         for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)pos0, o, 64); pos0 = x > pos0 ? x : pos0; }
         while (pos0 > 0 && __ballot(!done)) {
             const uint32_t nv = pos0 < 64u ? pos0 : 64u;
+            const bool needw = __ballot(!done && ebot0 > pos0 - nv) != 0;      // somebody may test an entry of this chunk
             __builtin_amdgcn_wave_barrier();
-            if ((uint32_t)lane < nv) {
+            if ((uint32_t)lane < nv) sb[wv][lane] = __hip_atomic_load(&bbl[pos0 - 1u - (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (needw && (uint32_t)lane < nv) {
                 const uint32_t p = pos0 - 1u - (uint32_t)lane;
                 const uint32_t rid = idl[p];
-                sb[wv][lane] = __hip_atomic_load(&bbl[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 srid[wv][lane] = rid;
                 const uint64_t *r = s.cand3 + (size_t)rid * W3;
                 unsigned long long cw[NW];                         // all words asked for at once (a word behind the read's last: its last word again, then dropped)
@@ -982,7 +1005,8 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
                 const bool in = !done && p < top0;
                 bool un = in && bj >= tp;                          // not claimed before this event's tuple (claimed BY it in an earlier pass counts as visible)
                 if (leading && in) { if (un) leading = false; else top = p; }      // the claimed reads on top stay claimed for this event
-                const bool test = un && bj > tp;
+                if (in) plow = p;
+                const bool test = un && bj > tp && p < ebot0;
                 if (__ballot(test)) {
                     int hd = 0;
 #pragma unroll
@@ -994,9 +1018,11 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
                         const int f = sorted ? __ffsll((long long)pm) - 1 : -1;   // the smallest tuple among them
                         if (sorted ? lane == f : (test && hd <= s.thresh_s)) {
                             const uint32_t rid = srid[wv][j];
-                            if (atomicMin(&s.best[rid], tp) > tp) {
+                            unsigned long long old = atomicMin(&s.best[rid], tp);
+                            if (old > tp) {
                                 atomicMin(&bbl[p], tp);
                                 ch = true;
+                                old = old > tmask ? tmask : old; oldmax = old > oldmax ? old : oldmax;
                                 // the read's bin in the other dictionary sees a claim at this tuple too
                                 const unsigned long long *r = &sw[wv][j * NW];
                                 const int ol = 1 - g_l, off = 3 * s.ds[ol], wi = off >> 6, sh = off & 63;
@@ -1004,7 +1030,7 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
                                 if (sh && wi + 1 < W3) okey |= r[wi + 1] << (64 - sh);
                                 if (s.kbits[ol] < 64) okey &= ((uint64_t)1 << s.kbits[ol]) - 1;
                                 uint32_t ost = 0, ocnt = 0;
-                                if (dict_lookup_b(s.slots[ol], s.cap[ol], okey, &ost, &ocnt) && !(ocnt & SLOT_EMB)) atomicMin((ol ? binmin1 : binmin0) + cur + ost, stamp | tp);
+                                if (dict_lookup_b(s.slots[ol], s.cap[ol], okey, &ost, &ocnt) && !(ocnt & SLOT_EMB)) { atomicMin((ol ? binmin1 : binmin0) + cur + ost, stamp | tp); atomicMax(s.binmax[ol] + cur + ost, pstamp | old); }
                             }
                         } else if (sorted && lane > f) un = false;  // claimed at a tuple below this lane's: not visible to it any more
                     }
@@ -1015,7 +1041,8 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
         }
         if (act) {
             estart[ei] = top; lastpass[ei] = g_cnt <= (uint32_t)s.maxsearch ? EV_DONE : pass;
-            if (ch) atomicMin((g_l ? binmin1 : binmin0) + cur + g_st, stamp | tp);
+            if (ebot && plow < ebot0) ebot[ei] = plow;
+            if (ch) { atomicMin((g_l ? binmin1 : binmin0) + cur + g_st, stamp | tp); atomicMax(s.binmax[g_l] + cur + g_st, pstamp | oldmax); }
         }
         anych |= __ballot(ch) != 0;
     }
@@ -1710,6 +1737,8 @@ int stage2_run(harc_amd_ctx *c)
         HIP_TRY(hipMemsetAsync(estart, 0xFF, ((size_t)nev + 1) * 4, c->stream));
         HIP_TRY(hipMemsetAsync(lastver, 0xFF, ((size_t)nev + 1) * 4, c->stream));
         for (int l = 0; l < 2; l++) { RC_TRY(dalloc(c, &binmin[l], 2 * ((size_t)T + 1))); HIP_TRY(hipMemsetAsync(binmin[l], 0xFF, 2 * ((size_t)T + 1) * 8, c->stream)); }
+        a.binmax_on = !(getenv("HARC_AMD_S2_RANGE") && atoi(getenv("HARC_AMD_S2_RANGE")) == 0);
+        for (int l = 0; l < 2; l++) { RC_TRY(dalloc(c, &a.binmax[l], 2 * ((size_t)T + 1))); HIP_TRY(hipMemsetAsync(a.binmax[l], 0, 2 * ((size_t)T + 1) * 8, c->stream)); }
         const bool trace = getenv("HARC_AMD_TRACE") != nullptr, nochase = getenv("HARC_AMD_S2_NOCHASE") != nullptr;
         a.trace = trace ? 1 : 0;
         struct timespec tw0; clock_gettime(CLOCK_MONOTONIC, &tw0);
@@ -1755,19 +1784,21 @@ int stage2_run(harc_amd_ctx *c)
             for (int k = 1; k < 32; k++) range_end[k] = range_end[k - 1] + hh[k];
         }
         uint64_t npass = 0; uint32_t rlo = 0, rhi = rhi0; int nall = 0, ridx = 0;
+        uint32_t *ebot = nullptr; bool ebot_tried = false;           // k_realign_block: how far down every event has tested its bin
         const uint32_t pipeline_from = getenv("HARC_AMD_S2_PIPE") ? (uint32_t)atoi(getenv("HARC_AMD_S2_PIPE")) : 1024u;
         RC_TRY(dalloc(c, &a.bestbin[0], (size_t)T + 1)); RC_TRY(dalloc(c, &a.bestbin[1], (size_t)T + 1));
         for (bool ranges = perm != nullptr;;) {
-            HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 4, c->stream));
+            HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 8, c->stream));
             if (firsts && nfirsts) hipLaunchKernelGGL(k_bestbin_refresh_bins, dim3(nfirsts < 65535u ? nfirsts : 65535u, (nfirsts + 65534u) / 65535u), dim3(256), 0, c->stream, (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1],
                                                       (const uint4 *)a.events, (const uint32_t *)firsts, nfirsts, a.bestbin[0], a.bestbin[1]);
             else hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
             const uint32_t nact = (ranges && order2) ? range_end[ridx < 31 ? ridx : 31] : nev;      // the events of the ranges reached so far come first in order2
             const bool two_kernels = (nact >= (1u << 20) || getenv("HARC_AMD_S2_TWOKERNELS")) && nact > 0 && !getenv("HARC_AMD_S2_ONEKERNEL");      // (tests force either form)
             // default: an event per lane (k_realign_block); HARC_AMD_S2_BLOCK=0, or either of the two variables above: a wave per event (rounds 2-5; tests)
+            if (!ebot && !ebot_tried && !(getenv("HARC_AMD_S2_EBOT") && atoi(getenv("HARC_AMD_S2_EBOT")) == 0)) { ebot_tried = true; RC_TRY(dalloc(c, &ebot, (size_t)nev + 1)); HIP_TRY(hipMemsetAsync(ebot, 0xFF, ((size_t)nev + 1) * 4, c->stream)); }
             const bool block = nact > 0 && !getenv("HARC_AMD_S2_TWOKERNELS") && !getenv("HARC_AMD_S2_ONEKERNEL") && !(getenv("HARC_AMD_S2_BLOCK") && atoi(getenv("HARC_AMD_S2_BLOCK")) == 0);
             if (block) {
-#define BLOCK_ARGS a, nact, (const uint32_t *)(ranges ? order2 : nullptr), (const uint32_t *)(perm ? rank : nullptr), ranges ? rhi : 0xFFFFFFFFu, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u, perm ? 1 : 0
+#define BLOCK_ARGS a, nact, (const uint32_t *)(ranges ? order2 : nullptr), (const uint32_t *)(perm ? rank : nullptr), ranges ? rhi : 0xFFFFFFFFu, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u, perm ? 1 : 0, ebot
                 if (W3 <= 5) hipLaunchKernelGGL((k_realign_block<5>), G256(nact), BLOCK_ARGS);
                 else if (W3 <= 8) hipLaunchKernelGGL((k_realign_block<8>), G256(nact), BLOCK_ARGS);
                 else hipLaunchKernelGGL((k_realign_block<HARC_MAXW3>), G256(nact), BLOCK_ARGS);
@@ -1789,11 +1820,11 @@ int stage2_run(harc_amd_ctx *c)
             // when the ranges meet); its claims count for the pass (the same stamp).  One wave per bin (firsts)
             if (perm && !nochase && !ranges && nall++ > 0) WAVE_PER_ITEM(nfirsts, hipLaunchKernelGGL(k_realign_chase, dim3(nb_), dim3(256), 0, c->stream, a, nfirsts, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
                                                      (const uint32_t *)perm, (const uint32_t *)rank, (const uint32_t *)seglen, ranges ? rhi : 0xFFFFFFFFu, kb_, (const uint32_t *)firsts));
-            unsigned int chg = 0, nlook = 0;
+            unsigned int chg = 0, nlook = 0, nwaves = 0;
             HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
-            if (trace) HIP_TRY(hipMemcpyAsync(&nlook, d_changed + 2, 4, hipMemcpyDeviceToHost, c->stream));
+            if (trace) { HIP_TRY(hipMemcpyAsync(&nlook, d_changed + 2, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipMemcpyAsync(&nwaves, d_changed + 3, 4, hipMemcpyDeviceToHost, c->stream)); }
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (trace) { struct timespec tw; clock_gettime(CLOCK_MONOTONIC, &tw); fprintf(stderr, "[stage II] window pass %llu over %u events (%u looked), ranks [%u, %u)%s: %s, %.2f ms since the first\n", (unsigned long long)npass, nev, nlook, ranges ? rlo : 0u, ranges ? rhi : maxrank + 1, ranges ? "" : " (all)", chg ? "claims moved" : "quiet", (tw.tv_sec - tw0.tv_sec) * 1e3 + (tw.tv_nsec - tw0.tv_nsec) * 1e-6); }
+            if (trace) { struct timespec tw; clock_gettime(CLOCK_MONOTONIC, &tw); fprintf(stderr, "[stage II] window pass %llu over %u events (%u looked in %u waves), ranks [%u, %u)%s: %s, %.2f ms since the first\n", (unsigned long long)npass, nev, nlook, nwaves, ranges ? rlo : 0u, ranges ? rhi : maxrank + 1, ranges ? "" : " (all)", chg ? "claims moved" : "quiet", (tw.tv_sec - tw0.tv_sec) * 1e3 + (tw.tv_nsec - tw0.tv_nsec) * 1e-6); }
             if (++npass > (uint64_t)T + 256) { harc_set_error("stage II: the window passes over the large bins did not settle"); return HARC_AMD_EINTERNAL; }
             // a range is repeated until quiet only while it is small (its passes cost next to nothing and the early events of a bin decide
             // what all later ones see); a large range moves on at once: every later pass validates its events, and those with an

@@ -126,7 +126,7 @@ def test_human_like_repeats_at_baseline_size(workload, monkeypatch):
         assert c0["n_clean"] + c0["n_N"] == n and c0["n_main"] + c0["n_singleton"] == c0["n_clean"]
         assert h.decode_signature() == sig_in, f"{workload}: the decoded streams are not the input reads"
         # ... and so do the two forms of stage II's window passes over the bins above maxsearch (an event per lane -- the default -- and a wave per event)
-        for env in ({"HARC_AMD_SEQ": "0"}, {"HARC_AMD_SEQ": "1"}, {"HARC_AMD_S2_BLOCK": "0"}):
+        for env in ({"HARC_AMD_SEQ": "0"}, {"HARC_AMD_SEQ": "1"}, {"HARC_AMD_S2_BLOCK": "0", "HARC_AMD_S2_RANGE": "0"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             dv, cv = _run(h)

@@ -330,6 +330,10 @@ def _set_sched(monkeypatch, sched):
             monkeypatch.setenv("HARC_AMD_S2_NOCHASE", "1")
         elif part.startswith("rank0="):
             monkeypatch.setenv("HARC_AMD_S2_RANK0", part[6:])
+        elif part == "noebot":                                     # an event that looks again tests its whole window again
+            monkeypatch.setenv("HARC_AMD_S2_EBOT", "0")
+        elif part == "norange":                                    # every event behind the earliest moved claim of its bin looks again (not only those between the two tuples of a moved claim)
+            monkeypatch.setenv("HARC_AMD_S2_RANGE", "0")
         elif part == "wave":                                       # a wave per event (k_realign_big) instead of an event per lane (k_realign_block)
             monkeypatch.setenv("HARC_AMD_S2_BLOCK", "0")
         elif part == "two":                                        # the passes in two kernels (a thread per event asks who has to look, a wave per event that has to), as on inputs with millions of such probes
@@ -338,7 +342,9 @@ def _set_sched(monkeypatch, sched):
 
 @pytest.mark.parametrize("K,S,E,seed,fail,sched", [(1, 16, 1, 5, 0.6, ""), (4, 16, 2, 6, 0.5, "rank0=3"), (1, 16, 1, 7, 0.8, "flat"), (2, 8, 1, 8, 0.3, "rank0=1"), (1, 16, 1, 9, 0.5, "rank0=2"), (1, 16, 1, 9, 0.5, "nochase"),
                                                     (4, 16, 2, 6, 0.5, "rank0=3,two"), (1, 16, 1, 7, 0.8, "flat,two"), (1, 16, 1, 9, 0.5, "two"),
-                                                    (4, 16, 2, 6, 0.5, "rank0=3,wave"), (1, 16, 1, 7, 0.8, "flat,wave"), (1, 16, 1, 9, 0.5, "wave"), (2, 8, 1, 8, 0.3, "rank0=1,wave")])
+                                                    (4, 16, 2, 6, 0.5, "rank0=3,wave"), (1, 16, 1, 7, 0.8, "flat,wave"), (1, 16, 1, 9, 0.5, "wave"), (2, 8, 1, 8, 0.3, "rank0=1,wave"),
+                                                    (4, 16, 2, 6, 0.5, "rank0=3,norange"), (1, 16, 1, 7, 0.8, "flat,wave,norange"), (1, 16, 1, 9, 0.5, "two,norange"), (2, 8, 1, 8, 0.3, "rank0=1,norange"),
+                                                    (4, 16, 2, 6, 0.5, "rank0=3,noebot"), (1, 16, 1, 7, 0.8, "flat,noebot"), (1, 16, 1, 9, 0.5, "noebot,norange"), (2, 8, 1, 8, 0.3, "rank0=1,noebot")])
 def test_stage2_big_bins_partial_claims_exact(K, S, E, seed, fail, sched, oracle, tmp_path, monkeypatch):
     """bins above maxsearch whose reads only partly pass the Hamming test, probed from several places of the consensus: what a probe
     sees depends on which reads the probes before it took AND on the ones nobody takes (they fill the window).  The passes of
