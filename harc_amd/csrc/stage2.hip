@@ -1044,7 +1044,7 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
             if (ebot && plow < ebot0) ebot[ei] = plow;
             if (ch) { atomicMin((g_l ? binmin1 : binmin0) + cur + g_st, stamp | tp); atomicMax(s.binmax[g_l] + cur + g_st, pstamp | oldmax); }
         }
-        anych |= __ballot(ch) != 0;
+        { const unsigned long long cm = __ballot(ch); anych |= cm != 0; if (s.trace && cm && lane == 0) atomicAdd(changed + 4, (unsigned int)__popcll(cm)); }      // trace only: events that moved a claim
     }
     if (anych && lane == 0) atomicOr(changed, 1u);
 }
@@ -1733,7 +1733,7 @@ int stage2_run(harc_amd_ctx *c)
     if (nev) {                                                        // exact sliding-window semantics as a fixed point (k_realign_big)
         unsigned int *d_changed = nullptr; uint32_t *estart = nullptr, *lastver = nullptr; unsigned long long *binmin[2] = { nullptr, nullptr };
         if (total >> (EV_TBITS - 2)) { harc_set_error("stage II: more than 2^%d consensus columns", EV_TBITS - 2); return HARC_AMD_EINVAL; }
-        RC_TRY(dalloc(c, &d_changed, 4)); RC_TRY(dalloc(c, &estart, (size_t)nev + 1)); RC_TRY(dalloc(c, &lastver, (size_t)nev + 1));
+        RC_TRY(dalloc(c, &d_changed, 8)); RC_TRY(dalloc(c, &estart, (size_t)nev + 1)); RC_TRY(dalloc(c, &lastver, (size_t)nev + 1));
         HIP_TRY(hipMemsetAsync(estart, 0xFF, ((size_t)nev + 1) * 4, c->stream));
         HIP_TRY(hipMemsetAsync(lastver, 0xFF, ((size_t)nev + 1) * 4, c->stream));
         for (int l = 0; l < 2; l++) { RC_TRY(dalloc(c, &binmin[l], 2 * ((size_t)T + 1))); HIP_TRY(hipMemsetAsync(binmin[l], 0xFF, 2 * ((size_t)T + 1) * 8, c->stream)); }
@@ -1788,7 +1788,7 @@ int stage2_run(harc_amd_ctx *c)
         const uint32_t pipeline_from = getenv("HARC_AMD_S2_PIPE") ? (uint32_t)atoi(getenv("HARC_AMD_S2_PIPE")) : 1024u;
         RC_TRY(dalloc(c, &a.bestbin[0], (size_t)T + 1)); RC_TRY(dalloc(c, &a.bestbin[1], (size_t)T + 1));
         for (bool ranges = perm != nullptr;;) {
-            HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 8, c->stream));
+            HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 12, c->stream));
             if (firsts && nfirsts) hipLaunchKernelGGL(k_bestbin_refresh_bins, dim3(nfirsts < 65535u ? nfirsts : 65535u, (nfirsts + 65534u) / 65535u), dim3(256), 0, c->stream, (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1],
                                                       (const uint4 *)a.events, (const uint32_t *)firsts, nfirsts, a.bestbin[0], a.bestbin[1]);
             else hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
@@ -1820,11 +1820,11 @@ int stage2_run(harc_amd_ctx *c)
             // when the ranges meet); its claims count for the pass (the same stamp).  One wave per bin (firsts)
             if (perm && !nochase && !ranges && nall++ > 0) WAVE_PER_ITEM(nfirsts, hipLaunchKernelGGL(k_realign_chase, dim3(nb_), dim3(256), 0, c->stream, a, nfirsts, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u,
                                                      (const uint32_t *)perm, (const uint32_t *)rank, (const uint32_t *)seglen, ranges ? rhi : 0xFFFFFFFFu, kb_, (const uint32_t *)firsts));
-            unsigned int chg = 0, nlook = 0, nwaves = 0;
+            unsigned int chg = 0, nlook = 0, nwaves = 0, nclaim = 0;
             HIP_TRY(hipMemcpyAsync(&chg, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
-            if (trace) { HIP_TRY(hipMemcpyAsync(&nlook, d_changed + 2, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipMemcpyAsync(&nwaves, d_changed + 3, 4, hipMemcpyDeviceToHost, c->stream)); }
+            if (trace) { HIP_TRY(hipMemcpyAsync(&nlook, d_changed + 2, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipMemcpyAsync(&nwaves, d_changed + 3, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipMemcpyAsync(&nclaim, d_changed + 4, 4, hipMemcpyDeviceToHost, c->stream)); }
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (trace) { struct timespec tw; clock_gettime(CLOCK_MONOTONIC, &tw); fprintf(stderr, "[stage II] window pass %llu over %u events (%u looked in %u waves), ranks [%u, %u)%s: %s, %.2f ms since the first\n", (unsigned long long)npass, nev, nlook, nwaves, ranges ? rlo : 0u, ranges ? rhi : maxrank + 1, ranges ? "" : " (all)", chg ? "claims moved" : "quiet", (tw.tv_sec - tw0.tv_sec) * 1e3 + (tw.tv_nsec - tw0.tv_nsec) * 1e-6); }
+            if (trace) { struct timespec tw; clock_gettime(CLOCK_MONOTONIC, &tw); fprintf(stderr, "[stage II] window pass %llu over %u events (%u looked in %u waves, %u of them moved a claim), ranks [%u, %u)%s: %s, %.2f ms since the first\n", (unsigned long long)npass, nev, nlook, nwaves, nclaim, ranges ? rlo : 0u, ranges ? rhi : maxrank + 1, ranges ? "" : " (all)", chg ? "claims moved" : "quiet", (tw.tv_sec - tw0.tv_sec) * 1e3 + (tw.tv_nsec - tw0.tv_nsec) * 1e-6); }
             if (++npass > (uint64_t)T + 256) { harc_set_error("stage II: the window passes over the large bins did not settle"); return HARC_AMD_EINTERNAL; }
             // a range is repeated until quiet only while it is small (its passes cost next to nothing and the early events of a bin decide
             // what all later ones see); a large range moves on at once: every later pass validates its events, and those with an
