@@ -1794,9 +1794,11 @@ int stage2_run(harc_amd_ctx *c)
             else hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
             const uint32_t nact = (ranges && order2) ? range_end[ridx < 31 ? ridx : 31] : nev;      // the events of the ranges reached so far come first in order2
             const bool two_kernels = (nact >= (1u << 20) || getenv("HARC_AMD_S2_TWOKERNELS")) && nact > 0 && !getenv("HARC_AMD_S2_ONEKERNEL");      // (tests force either form)
-            // default: an event per lane (k_realign_block); HARC_AMD_S2_BLOCK=0, or either of the two variables above: a wave per event (rounds 2-5; tests)
+            // default for large passes: an event per lane (k_realign_block); otherwise, and with HARC_AMD_S2_BLOCK=0 or either of the two variables above: a wave per event
             if (!ebot && !ebot_tried && !(getenv("HARC_AMD_S2_EBOT") && atoi(getenv("HARC_AMD_S2_EBOT")) == 0)) { ebot_tried = true; RC_TRY(dalloc(c, &ebot, (size_t)nev + 1)); HIP_TRY(hipMemsetAsync(ebot, 0xFF, ((size_t)nev + 1) * 4, c->stream)); }
-            const bool block = nact > 0 && !getenv("HARC_AMD_S2_TWOKERNELS") && !getenv("HARC_AMD_S2_ONEKERNEL") && !(getenv("HARC_AMD_S2_BLOCK") && atoi(getenv("HARC_AMD_S2_BLOCK")) == 0);
+            // (from a million events of a pass on: below that a wave per 64 events leaves the chip empty where a wave per event fills it -- a 3.3 M-read
+            // repeat-rich set spent 8.4 instead of 5.0 ms in stage II with the block form throughout; HARC_AMD_S2_BLOCK=1 / 0 force either)
+            const bool block = nact > 0 && !getenv("HARC_AMD_S2_TWOKERNELS") && !getenv("HARC_AMD_S2_ONEKERNEL") && (getenv("HARC_AMD_S2_BLOCK") ? atoi(getenv("HARC_AMD_S2_BLOCK")) != 0 : nact >= (1u << 20));
             if (block) {
 #define BLOCK_ARGS a, nact, (const uint32_t *)(ranges ? order2 : nullptr), (const uint32_t *)(perm ? rank : nullptr), ranges ? rhi : 0xFFFFFFFFu, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u, perm ? 1 : 0, ebot
                 if (W3 <= 5) hipLaunchKernelGGL((k_realign_block<5>), G256(nact), BLOCK_ARGS);
