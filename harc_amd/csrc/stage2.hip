@@ -46,6 +46,10 @@ struct S2Args {
     // so whole contigs -- and launches its tile kernels from tile `tile_base` on; on one GPU: [0, total), 0
     uint64_t col0, col1; uint32_t tile_base;
     const uint64_t *evwin;             // k_realign_big: the 3-bit window words of every event (k_ev_windows), W3 per event
+    // k_realign_block, passes of a million events and more: the bin-ordered claims COMPACTED (k_bestbin_refresh_bins) -- of every bin that has an event looking in
+    // this pass, only the entries not claimed before the EARLIEST such event (nobody who looks can see the others): cbb = their claims, cpos = their positions in
+    // the bin, ccnt[first entry of the bin] = how many.  Deep in a drained bin a window of 1000 visible entries spans tens of thousands of claimed ones.
+    unsigned long long *cbb[2]; uint32_t *cpos[2], *ccnt[2]; unsigned long long *tminbin[2]; int compact;
     int binmax_on;                     // (HARC_AMD_S2_RANGE=0: off -- every event behind the earliest moved claim looks again, as before round 5; tests)
     unsigned long long *binmax[2];     // window passes: per bin, (pass stamp, the LATEST tuple a claim of the bin was moved away from in that pass) -- see EV_TBITS
 };
@@ -720,15 +724,44 @@ __global__ void k_bestbin_refresh(const unsigned long long *best, const uint32_t
 // ... and only where somebody reads them: the bins that have events (one workgroup per bin through the list of the bins' first events; the copy over all
 // 2 T entries was 9.3 ms per pass at configs[3] with repeats -- a second per step over its hundred passes -- for 1210 bins that hold a tenth of the entries)
 __global__ __launch_bounds__(256) void k_bestbin_refresh_bins(const unsigned long long *best, const uint32_t *ids0, const uint32_t *ids1, const uint4 *events, const uint32_t *firsts, uint32_t nfirsts,
-                                                              unsigned long long *bb0, unsigned long long *bb1)
+                                                              unsigned long long *bb0, unsigned long long *bb1, S2Args s, int compact)
 {
+    __shared__ uint32_t wcnt[4];
+    __shared__ unsigned long long sh_tmin;
     const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;
     if (b >= nfirsts) return;
     const uint4 ev = events[firsts[b]];
     const int l = (int)(ev.x & 1u);
     const uint32_t *const ids = (l ? ids1 : ids0) + ev.z;
     unsigned long long *const bb = (l ? bb1 : bb0) + ev.z;
-    for (uint32_t i = threadIdx.x; i < ev.w; i += 256) bb[i] = best[ids[i]];
+    if (!compact) {
+        for (uint32_t i = threadIdx.x; i < ev.w; i += 256) bb[i] = best[ids[i]];
+        return;
+    }
+    // compact (s.compact passes): the copy as before, and beside it the entries somebody who looks in this pass can see -- not claimed before the earliest
+    // event of the bin that looks (k_ev_validate_tmin) --, in order, with their positions.  A bin nobody looks at keeps what it had (nobody reads it).
+    if (threadIdx.x == 0) { sh_tmin = s.tminbin[l][ev.z]; s.tminbin[l][ev.z] = ~0ULL; }
+    __syncthreads();
+    const unsigned long long tmin = sh_tmin;
+    const bool any = tmin != ~0ULL;
+    unsigned long long *const cb = s.cbb[l] + ev.z; uint32_t *const cp = s.cpos[l] + ev.z;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    for (uint32_t i0 = 0; i0 < ev.w; i0 += 256) {
+        const uint32_t i = i0 + threadIdx.x;
+        unsigned long long v = 0; bool keep = false;
+        if (i < ev.w) { v = best[ids[i]]; bb[i] = v; keep = any && v >= tmin; }
+        if (!any) continue;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wcnt[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = base;
+        for (int w = 0; w < wv; w++) off += wcnt[w];
+        if (keep) { const uint32_t at = off + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL)); cb[at] = v; cp[at] = i; }
+        base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    if (any && threadIdx.x == 0) s.ccnt[l][ev.z] = base;
 }
 // one event (probe e, at position ei of the pass order), one wave.  validate: an event that looked in the previous pass and finds no earlier
 // claim on its bin since is validated without looking.  Returns whether a claim moved (wave-uniform).
@@ -906,6 +939,46 @@ __global__ __launch_bounds__(256) void k_realign_list(S2Args s, const uint32_t *
     const uint32_t ei = list[k];
     (void)realign_event(s, ei, ei, estart, changed, binmin0, binmin1, lastpass, pass, T1, swin[wv], true);
 }
+// In front of a compacted pass: the validation of k_realign_block by a thread per event (the same tests; an event validated here has lastpass = pass and is
+// passed over by the kernel), and for every bin the smallest tuple among its events that LOOK (tminbin, reset by k_bestbin_refresh_bins when it has used it):
+// the events of a bin follow each other in tuple order, so that is the first looking lane of a run of lanes of one bin.
+__global__ __launch_bounds__(256) void k_ev_validate_tmin(S2Args s, uint32_t nact, const uint32_t *order2, const uint32_t *rank, uint32_t rhi, uint32_t *estart, const unsigned long long *binmin0,
+                                                          const unsigned long long *binmin1, uint32_t *lastpass, uint32_t pass, uint32_t T1)
+{
+    const uint64_t k = harc_gid();
+    const int lane = threadIdx.x & 63;
+    bool look = false; unsigned long long tp = 0, key = ~0ULL; int l = 0; uint32_t st = 0;
+    if (k < nact) {
+        const uint32_t ei = order2 ? order2[k] : (uint32_t)k;
+        const uint32_t lp = lastpass[ei];
+        bool go = lp != EV_DONE && lp != pass;
+        if (go && rank && rank[ei] >= rhi) go = false;
+        if (go) {
+            const uint4 ev = s.events[ei];
+            tp = (unsigned long long)ev.x | ((unsigned long long)ev.y << 32);
+            const unsigned long long tmask = (1ULL << EV_TBITS) - 1ULL;
+            l = (int)(tp & 1); st = ev.z; key = ((unsigned long long)st << 1) | (unsigned long long)l;
+            bool moved = true;
+            if (lp == pass - 1) {
+                const size_t prv = (size_t)((pass - 1u) & 1u) * T1;
+                const unsigned long long m = ((l ? binmin1 : binmin0) + st)[prv];
+                moved = (m >> EV_TBITS) == (unsigned long long)(~(pass - 1) & 0xFFFFFFu) && (m & tmask) < tp;
+                if (moved && s.binmax_on) { const unsigned long long x = (s.binmax[l] + st)[prv]; if ((x >> EV_TBITS) == (unsigned long long)((pass - 1) & 0xFFFFFFu)) moved = tp <= (x & tmask); }
+                if (!moved) lastpass[ei] = pass;
+            }
+            if (moved) { if (estart[ei] == 0) lastpass[ei] = EV_DONE; else look = true; }
+        }
+    }
+    const unsigned long long m = __ballot(look);
+    if (!m) return;
+    const unsigned long long pk = shfl_u64(key, (lane + 63) & 63);
+    const unsigned long long heads = __ballot(lane == 0 || key != pk);      // (a lane that does not look has key = all ones: it ends a run, which is what is wanted: fewer atomics, not exactness)
+    if (look) {
+        const int runstart = 63 - __clzll((long long)(heads & ((2ULL << lane) - 1ULL)));
+        const unsigned long long earlier = m & ((1ULL << lane) - 1ULL) & ~((1ULL << runstart) - 1ULL);
+        if (!earlier) atomicMin(s.tminbin[l] + st, tp);
+    }
+}
 // The looks TRANSPOSED (round 5, default): one wave per 64 consecutive events of the pass order -- events of ONE bin in tuple order, except where two
 // bins meet -- with an event per LANE.  A wave per event fetched, for every candidate of its window, the candidate's words by read id (64 lanes, 64
 // random lines, an early-out loop of dependent loads per lane): configs[3] with human-like repeats made 1.4 G looks of up to 1000 candidates, 10.4 s of
@@ -930,6 +1003,7 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
     __shared__ unsigned long long sw[4][64 * NW];                  // the chunk: words of entry j at [j * NW, j * NW + NW)
     __shared__ unsigned long long sb[4][64];                       // its claims
     __shared__ uint32_t srid[4][64];                               // its read ids
+    __shared__ uint32_t spos[4][64];                               // its positions in the bin (s.compact: the entries that are left are not neighbours)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t k = harc_gid();                                 // a thread per event of the pass order (G256: more than 2^32 threads go to a second grid row)
     const int W3 = s.W3;
@@ -940,7 +1014,7 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
     if (k < nact) {
         ei = order2 ? order2[k] : (uint32_t)k;
         const uint32_t lp = lastpass[ei];
-        bool go = lp != EV_DONE;
+        bool go = lp != EV_DONE && lp != pass;                     // (lp == pass: validated by k_ev_validate_tmin in front of this launch)
         if (go && rank && rank[ei] >= rhi) go = false;
         if (go) {
             const uint4 ev = s.events[ei];
@@ -981,13 +1055,29 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
         const unsigned long long pstamp = ((unsigned long long)(pass & 0xFFFFFFu)) << EV_TBITS;
         uint32_t pos0 = top0;                                      // the chunk covers the entries [pos0 - nv, pos0), lane j fetches entry pos0 - 1 - j
         for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)pos0, o, 64); pos0 = x > pos0 ? x : pos0; }
+        // s.compact: the walk is over the entries that are LEFT of the bin -- entry number x is cb[x], at position cp[x] of the bin; it starts at the first
+        // of them at or above the highest start of the lanes
+        const bool cmp = s.compact != 0;
+        unsigned long long *const cb = cmp ? s.cbb[g_l] + g_st : bbl;
+        const uint32_t *const cp = cmp ? s.cpos[g_l] + g_st : nullptr;
+        if (cmp) {
+            uint32_t lo = 0, hi = s.ccnt[g_l][g_st];
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cp[mid] < pos0) lo = mid + 1; else hi = mid; }
+            pos0 = lo;
+        }
         while (pos0 > 0 && __ballot(!done)) {
             const uint32_t nv = pos0 < 64u ? pos0 : 64u;
-            const bool needw = __ballot(!done && ebot0 > pos0 - nv) != 0;      // somebody may test an entry of this chunk
             __builtin_amdgcn_wave_barrier();
-            if ((uint32_t)lane < nv) sb[wv][lane] = __hip_atomic_load(&bbl[pos0 - 1u - (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)lane < nv) {
+                const uint32_t x = pos0 - 1u - (uint32_t)lane;
+                sb[wv][lane] = __hip_atomic_load(&cb[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                spos[wv][lane] = cmp ? cp[x] : x;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool needw = __ballot(!done && ebot0 > spos[wv][nv - 1u]) != 0;      // somebody may test an entry of this chunk
             if (needw && (uint32_t)lane < nv) {
-                const uint32_t p = pos0 - 1u - (uint32_t)lane;
+                const uint32_t p = spos[wv][lane];
                 const uint32_t rid = idl[p];
                 srid[wv][lane] = rid;
                 const uint64_t *r = s.cand3 + (size_t)rid * W3;
@@ -1000,7 +1090,7 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (uint32_t j = 0; j < nv; j++) {
-                const uint32_t p = pos0 - 1u - j;
+                const uint32_t p = spos[wv][j];
                 const unsigned long long bj = sb[wv][j];
                 const bool in = !done && p < top0;
                 bool un = in && bj >= tp;                          // not claimed before this event's tuple (claimed BY it in an earlier pass counts as visible)
@@ -1020,7 +1110,7 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
                             const uint32_t rid = srid[wv][j];
                             unsigned long long old = atomicMin(&s.best[rid], tp);
                             if (old > tp) {
-                                atomicMin(&bbl[p], tp);
+                                atomicMin(&cb[pos0 - 1u - j], tp);
                                 ch = true;
                                 old = old > tmask ? tmask : old; oldmax = old > oldmax ? old : oldmax;
                                 // the read's bin in the other dictionary sees a claim at this tuple too
@@ -1039,6 +1129,8 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
             }
             pos0 -= nv;
         }
+        // (compacted, and the walk came to the end with this lane's window open: what was left out below is claimed before its tuple like what it saw)
+        if (cmp && act && !done && pos0 == 0) { plow = 0; if (leading) top = 0; }
         if (act) {
             estart[ei] = top; lastpass[ei] = g_cnt <= (uint32_t)s.maxsearch ? EV_DONE : pass;
             if (ebot && plow < ebot0) ebot[ei] = plow;
@@ -1789,16 +1881,25 @@ int stage2_run(harc_amd_ctx *c)
         RC_TRY(dalloc(c, &a.bestbin[0], (size_t)T + 1)); RC_TRY(dalloc(c, &a.bestbin[1], (size_t)T + 1));
         for (bool ranges = perm != nullptr;;) {
             HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream)); HIP_TRY(hipMemsetAsync(d_changed + 2, 0, 12, c->stream));
-            if (firsts && nfirsts) hipLaunchKernelGGL(k_bestbin_refresh_bins, dim3(nfirsts < 65535u ? nfirsts : 65535u, (nfirsts + 65534u) / 65535u), dim3(256), 0, c->stream, (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1],
-                                                      (const uint4 *)a.events, (const uint32_t *)firsts, nfirsts, a.bestbin[0], a.bestbin[1]);
-            else hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
             const uint32_t nact = (ranges && order2) ? range_end[ridx < 31 ? ridx : 31] : nev;      // the events of the ranges reached so far come first in order2
-            const bool two_kernels = (nact >= (1u << 20) || getenv("HARC_AMD_S2_TWOKERNELS")) && nact > 0 && !getenv("HARC_AMD_S2_ONEKERNEL");      // (tests force either form)
-            // default for large passes: an event per lane (k_realign_block); otherwise, and with HARC_AMD_S2_BLOCK=0 or either of the two variables above: a wave per event
-            if (!ebot && !ebot_tried && !(getenv("HARC_AMD_S2_EBOT") && atoi(getenv("HARC_AMD_S2_EBOT")) == 0)) { ebot_tried = true; RC_TRY(dalloc(c, &ebot, (size_t)nev + 1)); HIP_TRY(hipMemsetAsync(ebot, 0xFF, ((size_t)nev + 1) * 4, c->stream)); }
             // (from a million events of a pass on: below that a wave per 64 events leaves the chip empty where a wave per event fills it -- a 3.3 M-read
             // repeat-rich set spent 8.4 instead of 5.0 ms in stage II with the block form throughout; HARC_AMD_S2_BLOCK=1 / 0 force either)
             const bool block = nact > 0 && !getenv("HARC_AMD_S2_TWOKERNELS") && !getenv("HARC_AMD_S2_ONEKERNEL") && (getenv("HARC_AMD_S2_BLOCK") ? atoi(getenv("HARC_AMD_S2_BLOCK")) != 0 : nact >= (1u << 20));
+            // the block form walks COMPACTED bins (S2Args.cbb; HARC_AMD_S2_COMPACT=0: the whole bins): who looks is asked first, per bin the earliest tuple among them
+            const bool compact = block && firsts && nfirsts && !(getenv("HARC_AMD_S2_COMPACT") && atoi(getenv("HARC_AMD_S2_COMPACT")) == 0);
+            if (compact && !a.cbb[0]) for (int l = 0; l < 2; l++) {
+                RC_TRY(dalloc(c, &a.cbb[l], (size_t)T + 1)); RC_TRY(dalloc(c, &a.cpos[l], (size_t)T + 1)); RC_TRY(dalloc(c, &a.ccnt[l], (size_t)T + 1)); RC_TRY(dalloc(c, &a.tminbin[l], (size_t)T + 1));
+                HIP_TRY(hipMemsetAsync(a.tminbin[l], 0xFF, ((size_t)T + 1) * 8, c->stream));
+            }
+            a.compact = compact ? 1 : 0;
+            if (compact) hipLaunchKernelGGL(k_ev_validate_tmin, G256(nact), a, nact, (const uint32_t *)(ranges ? order2 : nullptr), (const uint32_t *)(perm ? rank : nullptr), ranges ? rhi : 0xFFFFFFFFu, estart,
+                                            (const unsigned long long *)binmin[0], (const unsigned long long *)binmin[1], lastver, (uint32_t)npass + 1u, T + 1u);
+            if (firsts && nfirsts) hipLaunchKernelGGL(k_bestbin_refresh_bins, dim3(nfirsts < 65535u ? nfirsts : 65535u, (nfirsts + 65534u) / 65535u), dim3(256), 0, c->stream, (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1],
+                                                      (const uint4 *)a.events, (const uint32_t *)firsts, nfirsts, a.bestbin[0], a.bestbin[1], a, compact ? 1 : 0);
+            else hipLaunchKernelGGL(k_bestbin_refresh, G256(T), (const unsigned long long *)best, (const uint32_t *)a.ids[0], (const uint32_t *)a.ids[1], T, a.bestbin[0], a.bestbin[1]);
+            const bool two_kernels = (nact >= (1u << 20) || getenv("HARC_AMD_S2_TWOKERNELS")) && nact > 0 && !getenv("HARC_AMD_S2_ONEKERNEL");      // (tests force either form)
+            // default for large passes: an event per lane (k_realign_block); otherwise, and with HARC_AMD_S2_BLOCK=0 or either of the two variables above: a wave per event
+            if (!ebot && !ebot_tried && !(getenv("HARC_AMD_S2_EBOT") && atoi(getenv("HARC_AMD_S2_EBOT")) == 0)) { ebot_tried = true; RC_TRY(dalloc(c, &ebot, (size_t)nev + 1)); HIP_TRY(hipMemsetAsync(ebot, 0xFF, ((size_t)nev + 1) * 4, c->stream)); }
             if (block) {
 #define BLOCK_ARGS a, nact, (const uint32_t *)(ranges ? order2 : nullptr), (const uint32_t *)(perm ? rank : nullptr), ranges ? rhi : 0xFFFFFFFFu, estart, d_changed, binmin[0], binmin[1], lastver, (uint32_t)npass + 1u, T + 1u, perm ? 1 : 0, ebot
                 if (W3 <= 5) hipLaunchKernelGGL((k_realign_block<5>), G256(nact), BLOCK_ARGS);

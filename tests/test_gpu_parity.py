@@ -335,6 +335,8 @@ def _set_sched(monkeypatch, sched):
             monkeypatch.setenv("HARC_AMD_S2_NOCHASE", "1")
         elif part.startswith("rank0="):
             monkeypatch.setenv("HARC_AMD_S2_RANK0", part[6:])
+        elif part == "nocompact":                                  # the block form walks the whole bins, not what is left of them for the events that look
+            monkeypatch.setenv("HARC_AMD_S2_COMPACT", "0")
         elif part == "noebot":                                     # an event that looks again tests its whole window again
             monkeypatch.setenv("HARC_AMD_S2_EBOT", "0")
         elif part == "norange":                                    # every event behind the earliest moved claim of its bin looks again (not only those between the two tuples of a moved claim)
@@ -349,7 +351,8 @@ def _set_sched(monkeypatch, sched):
                                                     (4, 16, 2, 6, 0.5, "rank0=3,two"), (1, 16, 1, 7, 0.8, "flat,two"), (1, 16, 1, 9, 0.5, "two"),
                                                     (4, 16, 2, 6, 0.5, "rank0=3,wave"), (1, 16, 1, 7, 0.8, "flat,wave"), (1, 16, 1, 9, 0.5, "wave"), (2, 8, 1, 8, 0.3, "rank0=1,wave"),
                                                     (4, 16, 2, 6, 0.5, "rank0=3,norange"), (1, 16, 1, 7, 0.8, "flat,wave,norange"), (1, 16, 1, 9, 0.5, "two,norange"), (2, 8, 1, 8, 0.3, "rank0=1,norange"),
-                                                    (4, 16, 2, 6, 0.5, "rank0=3,noebot"), (1, 16, 1, 7, 0.8, "flat,noebot"), (1, 16, 1, 9, 0.5, "noebot,norange"), (2, 8, 1, 8, 0.3, "rank0=1,noebot")])
+                                                    (4, 16, 2, 6, 0.5, "rank0=3,noebot"), (1, 16, 1, 7, 0.8, "flat,noebot"), (1, 16, 1, 9, 0.5, "noebot,norange"), (2, 8, 1, 8, 0.3, "rank0=1,noebot"),
+                                                    (4, 16, 2, 6, 0.5, "rank0=3,nocompact"), (1, 16, 1, 9, 0.5, "nocompact"), (2, 8, 1, 8, 0.3, "rank0=1,nocompact,noebot")])
 def test_stage2_big_bins_partial_claims_exact(K, S, E, seed, fail, sched, oracle, tmp_path, monkeypatch):
     """bins above maxsearch whose reads only partly pass the Hamming test, probed from several places of the consensus: what a probe
     sees depends on which reads the probes before it took AND on the ones nobody takes (they fill the window).  The passes of

@@ -16,7 +16,7 @@ from tests import gen, oracle_lib as ol                            # noqa: E402
 
 FORMS = [{"HARC_AMD_S2_BLOCK": "1"}, {"HARC_AMD_S2_BLOCK": "0"}, {"HARC_AMD_S2_TWOKERNELS": "1"}, {}]
 SCHED = [{}, {"HARC_AMD_S2_RANK0": "1"}, {"HARC_AMD_S2_RANK0": "3"}, {"HARC_AMD_S2_FLATPASSES": "1"}, {"HARC_AMD_S2_NOCHASE": "1"}, {"HARC_AMD_S2_RANK0": "2", "HARC_AMD_S2_NOCHASE": "1"}]
-RULES = [{}, {}, {"HARC_AMD_S2_RANGE": "0"}, {"HARC_AMD_S2_EBOT": "0"}, {"HARC_AMD_S2_RANGE": "0", "HARC_AMD_S2_EBOT": "0"}]
+RULES = [{}, {}, {"HARC_AMD_S2_RANGE": "0"}, {"HARC_AMD_S2_EBOT": "0"}, {"HARC_AMD_S2_RANGE": "0", "HARC_AMD_S2_EBOT": "0"}, {"HARC_AMD_S2_COMPACT": "0"}, {"HARC_AMD_S2_COMPACT": "0", "HARC_AMD_S2_EBOT": "0"}]
 KEYS = sorted({k for group in (FORMS, SCHED, RULES) for e in group for k in e})
 
 
