@@ -2649,6 +2649,12 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // one chain cannot lose a bid: its output does not depend on S, and every super-round is three launches for S steps --
     // exact mode takes the longest walks there are (a launch per 64 reads instead of per 16)
     if (P.num_steps <= 0 && K == 1) nsteps = 64;
+    // ... and with tens of thousands of chains -- every BASELINE-sized input -- 32: half the super-rounds, i.e. half of the ~100 us a round costs beside its walks
+    // (arbitration at the random-access rate, new seeds, three launches), for walks that lose their later steps a little more often.  Measured (round 5, S = 16 /
+    // 32 / 64): configs[2] 613 / 626 / 604 Mreads/s with 6.50 / 6.48 / 6.44 M contigs and the same xz size; configs[3] 656 / 667; a 50 M-read repeat-rich set 222 /
+    // 234; configs[4]'s share 490 / 487.  Below 16 384 chains 16 stays (3.3 M reads: +7 % clean, -18 % with repeats; 1 M reads: slower).  The two-chains-per-wave
+    // kernel walks at most 16 steps: asking for it keeps 16.
+    if (P.num_steps <= 0 && K > 16384 && !(getenv("HARC_AMD_GRP") && atoi(getenv("HARC_AMD_GRP")) != 0)) nsteps = 32;
     if (nsteps > 64) nsteps = 64;
     // few chains -> every launch is a chain of dependent HBM round trips: fetch whole buckets; many chains -> request-rate bound: single slots
     bool quad = K <= 16384;

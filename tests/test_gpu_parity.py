@@ -84,7 +84,7 @@ def _oracle_pipeline(oracle, reads_txt, L, K, E, d, S=1):
     return inputs, s1, ol.read_dir(base), base
 
 
-@pytest.mark.parametrize("S", [1, 4, 16, 64])
+@pytest.mark.parametrize("S", [1, 4, 16, 32, 64])
 @pytest.mark.parametrize("case,K,E", [("L100_err_5k", 4, 3), ("L100_err_5k", 64, 8), ("L150_err_3k", 16, 2), ("L63_err_3k", 7, 5),
                                         ("L100_repeat_dup_4k", 32, 4), ("L100_three", 8, 8), ("L100_allN_20", 2, 2),
                                         ("L255_err_1k", 5, 3), ("L100_lowcov_4k", 128, 1), ("L40_err_3k", 300, 2), ("L101_err_3k", 9, 4)])

@@ -82,7 +82,7 @@ def main():
         txt = make_reads(rs, L)
         nreads = len(txt) // (L + 1)
         K = int(rs.choice([1, 2, 7, 33, 0, nreads // 64 + 1]))
-        S = int(rs.choice([1, 4, 16, 16, 64]))
+        S = int(rs.choice([1, 4, 16, 16, 32, 64]))
         E = int(rs.choice([1, 2, 5]))
         if os.environ.get("FUZZ_K"): K = int(os.environ["FUZZ_K"])          # e.g. FUZZ_K=1 FUZZ_S=64: exact mode only
         if os.environ.get("FUZZ_S"): S = int(os.environ["FUZZ_S"])
