@@ -90,6 +90,7 @@ struct harc_amd_ctx {
     hipStream_t copy_stream = nullptr;     // device -> host copies that run beside the kernels of `stream` (stage II: read_seq)
     hipEvent_t ev_copy = nullptr;
     uint32_t s2_events_hint = 0;           // stage II: probes into large bins the last run recorded (+ 25 %): the event buffer of the next run
+    uint64_t s1_seq_key = 0; int s1_seq_choice = -1;   // stage I: which scan of the small bins an earlier run over an input of this shape MEASURED to be faster (stage1_run_w)
     size_t dev_bytes = 0, dev_peak = 0;    // raw allocations + pool high-water mark
     std::vector<void *> owned;             // raw allocations (inputs, rocPRIM scratch), freed in destroy
     std::map<void *, size_t> sizes;

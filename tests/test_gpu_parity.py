@@ -257,6 +257,31 @@ def test_table_slots_per_read_is_not_visible_in_the_bytes(oracle, tmp_path):
     assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0]
 
 
+def test_scan_choice_of_a_context_is_measured_once_and_never_visible_in_the_bytes(monkeypatch):
+    """a dense run (more than 16 384 chains) over mostly single-read bins MEASURES which scan of the small bins is faster -- eight super-rounds with
+    each -- and the context keeps the answer for later inputs of the same shape (round 5: the eight rounds with the slower one were 3.5 ms of every
+    configs[2] step).  Both scans compute the same thing: the run that measures, the run that starts from the kept answer, a run made to measure
+    again and a run with the other scan forced produce the same streams"""
+    import harc_amd
+    arr = gen.reads_array(707, 60000, 100, 500000, err=0.002)
+    hasN = (arr == ord("N")).any(1)
+    h = harc_amd.HarcAmd(harc_amd.default_params(100, num_thr=2, num_chains=17000, num_steps=16))
+    outs = []
+    try:
+        h.set_reads_ascii(gen.lines_of(arr[~hasN]), int((~hasN).sum()), 101)
+        h.set_nreads_ascii(gen.lines_of(arr[hasN]), int(hasN.sum()), 101)
+        for rep in range(5):
+            if rep == 2:
+                monkeypatch.setenv("HARC_AMD_SEQ_REMEASURE", "1")
+            if rep >= 3:
+                monkeypatch.setenv("HARC_AMD_SEQ", str(rep - 3))
+            h.reorder(); h.encode()
+            outs.append([h.stream(sid, e) for e in range(2) for sid in ("S2_SEQ", "S2_POS", "S2_NOISE", "S2_NOISEPOS", "S2_REV")] + [h.stream("S2_SINGLETON")])
+    finally:
+        h.close()
+    assert all(o == outs[0] for o in outs[1:])
+
+
 @pytest.mark.parametrize("env", [{"HARC_AMD_QUAD": "0"}, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1"},
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_S1BLOOM_MZMB": "0"}, {"HARC_AMD_S1BLOOM_MZMB": "0"},
                                  {"HARC_AMD_S1BLOOM": "0"}, {"HARC_AMD_BLOOM4_HASHED": "1"}, {"HARC_AMD_BLOOM1": "1"}, {"HARC_AMD_CAPMULT": "2"},
