@@ -2654,7 +2654,13 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // 32 / 64): configs[2] 613 / 626 / 604 Mreads/s with 6.50 / 6.48 / 6.44 M contigs and the same xz size; configs[3] 656 / 667; a 50 M-read repeat-rich set 222 /
     // 234; configs[4]'s share 490 / 487.  Below 16 384 chains 16 stays (3.3 M reads: +7 % clean, -18 % with repeats; 1 M reads: slower).  The two-chains-per-wave
     // kernel walks at most 16 steps: asking for it keeps 16.
-    if (P.num_steps <= 0 && K > 16384 && !(getenv("HARC_AMD_GRP") && atoi(getenv("HARC_AMD_GRP")) != 0)) nsteps = 32;
+    // ... where walks rarely meet: on a repeat-rich input at 26x (configs[3] with a human-like repeat content) the longer walks took 3216 super-rounds instead of
+    // 2008 and the chain phase 7.5 s instead of 4.2 -- chains of one repeat family walk into each other, and a walk that loses a bid gives up everything behind
+    // it.  No count taken DURING the run tells such an input early enough (the share of walks that end at a lost bid is 0.4 % after 16 rounds there as on
+    // clean data, 20 % only after a thousand: profiles/r05/s_choice_trace.txt), so the choice is made from the index, below: 32 only where the bins of more
+    // than HARC_LARGEBIN reads hold less than 2 % of N entries (clean inputs: none), 16 otherwise.  A function of the input alone, like the chain count.
+    const bool steps_auto32 = P.num_steps <= 0 && K > 16384 && !(getenv("HARC_AMD_GRP") && atoi(getenv("HARC_AMD_GRP")) != 0);
+    if (steps_auto32) nsteps = 32;
     if (nsteps > 64) nsteps = 64;
     // few chains -> every launch is a chain of dependent HBM round trips: fetch whole buckets; many chains -> request-rate bound: single slots
     bool quad = K <= 16384;
@@ -2759,6 +2765,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // their reads once more, in bin order (k_large_fill); nothing on ordinary data
     uint2 *d_largetab = nullptr; uint64_t *d_mirror = nullptr;
     uint32_t *d_sz0 = nullptr, *d_huge = nullptr; unsigned int *d_nhuge = nullptr; uint32_t nhuge = 0;     // the bins k_compact_huge takes
+    uint64_t large_entries = 0;                                   // reads in bins of more than HARC_LARGEBIN reads, both dictionaries
     if (nlarge) {
         uint32_t *sz = nullptr; uint64_t *moff = nullptr;
         RC_TRY(dalloc(c, &d_largetab, nlarge)); RC_TRY(dalloc(c, &sz, (size_t)nlarge + 1)); RC_TRY(dalloc(c, &moff, (size_t)nlarge + 1));
@@ -2774,11 +2781,15 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         HIP_TRY(hipMemcpyAsync(&mtotal, moff + nlarge, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (mtotal > 0xFFFFFFFFull) { harc_set_error("stage I: more than 2^32 reads in large bins"); return HARC_AMD_EINVAL; }
+        large_entries = mtotal;
         RC_TRY(dalloc(c, &d_mirror, (size_t)mtotal * W + 1));
         hipLaunchKernelGGL((k_large_fill<W>), wave_grid(nlarge), dim3(64), 0, c->stream, (const unsigned long long *)d_large, nlarge, dict[0].slots, dict[1].slots,
                            (const uint32_t *)dict[0].ids, (const uint32_t *)dict[1].ids, (const uint64_t *)moff, (const uint64_t *)c->d_reads, d_largetab, d_mirror);
         HIP_TRY(hipGetLastError());
     }
+    if (steps_auto32 && large_entries * 50 > (uint64_t)N) nsteps = 16;      // (see steps_auto32 above)
+    if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] %u bins of more than %u reads hold %llu entries (%.2f %% of the reads): %d steps per super-round\n", nlarge, HARC_LARGEBIN,
+                                          (unsigned long long)large_entries, N ? 100.0 * (double)large_entries / (double)N : 0.0, nsteps);
     HIP_TRY(hipEventRecord(e1, c->stream));
 
     // ---- chain state
