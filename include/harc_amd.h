@@ -58,8 +58,9 @@ typedef struct harc_amd_params {
     int32_t dict_end[2];      /* `dict1_end`,`dict2_end` */
     int32_t device;           /* HIP device ordinal */
     int32_t profile;          /* 1: time every launch of the dominant kernel with HIP events on the context's stream */
-    int32_t num_steps;        /* S: speculative chain steps per launch of the chain kernel (1..64; 0 = auto: 16, 32 from 16 385 chains on,
-                                 64 for one chain).  Output is independent of S when num_chains = 1; for num_chains > 1 the pair (K,S)
+    int32_t num_steps;        /* S: speculative chain steps per launch of the chain kernel (1..64; 0 = auto: 16; 64 for one chain; 32 from
+                                 16 385 chains on where the index's bins of more than 16 reads hold less than 2 % of N entries -- a function
+                                 of the input alone).  Output is independent of S when num_chains = 1; for num_chains > 1 the pair (K,S)
                                  defines the schedule */
     int32_t reads_per_chain;  /* auto mode (num_chains = 0): one chain per this many reads, capped at 65536 chains; 0 = 2048.  Inputs that are
                                  already fragmented (one minimizer bucket of a multi-GPU shard) lose nothing with 1024 and run faster. */

@@ -282,6 +282,34 @@ def test_scan_choice_of_a_context_is_measured_once_and_never_visible_in_the_byte
     assert all(o == outs[0] for o in outs[1:])
 
 
+def _streams_of(txt, L, **params):
+    import numpy as np
+    import harc_amd
+    arr = np.frombuffer(txt, dtype=np.uint8).reshape(-1, L + 1)[:, :L]
+    hasN = (arr == ord("N")).any(1)
+    h = harc_amd.HarcAmd(harc_amd.default_params(L, num_thr=2, **params))
+    try:
+        h.set_reads_ascii(gen.lines_of(arr[~hasN]), int((~hasN).sum()), L + 1)
+        h.set_nreads_ascii(gen.lines_of(arr[hasN]), int(hasN.sum()), L + 1)
+        h.reorder(); h.encode()
+        return [h.stream(sid, e) for e in range(2) for sid in ("S2_SEQ", "S2_POS", "S2_NOISE", "S2_NOISEPOS", "S2_REV")] + [h.stream("S2_SINGLETON")]
+    finally:
+        h.close()
+
+
+def test_steps_per_super_round_chosen_from_the_index():
+    """num_steps = 0 with more than 16 384 chains: 32 steps per super-round where the bins of more than 16 reads hold less than 2 % of N entries (clean
+    data), 16 where repeat families fill such bins (longer walks of chains that meet lose more of what they walked: configs[3] with human-like repeats,
+    profiles/r05/s_choice_trace.txt).  A function of the input alone: the automatic choice gives the bytes of the explicit one"""
+    clean = gen.lines_of(gen.reads_array(707, 60000, 100, 500000, err=0.002))
+    auto, s32, s16 = (_streams_of(clean, 100, num_chains=17000, num_steps=S) for S in (0, 32, 16))
+    assert auto == s32
+    rich = gen.reads_text_lowcomplexity(99, 40000, 100, 100000, err=0.004)
+    auto_r, r32, r16 = (_streams_of(rich, 100, num_chains=17000, num_steps=S) for S in (0, 32, 16))
+    assert auto_r == r16
+    assert s32 != s16 or r32 != r16          # (the two schedules do differ on at least one of the inputs: the test can tell them apart)
+
+
 @pytest.mark.parametrize("env", [{"HARC_AMD_QUAD": "0"}, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1"},
                                  {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_S1BLOOM_MZMB": "0"}, {"HARC_AMD_S1BLOOM_MZMB": "0"},
                                  {"HARC_AMD_S1BLOOM": "0"}, {"HARC_AMD_BLOOM4_HASHED": "1"}, {"HARC_AMD_BLOOM1": "1"}, {"HARC_AMD_CAPMULT": "2"},
