@@ -39,6 +39,7 @@ struct S1Args {
     uint32_t reseed_win;             // words of the claim bitmap one pass of k_reseed_mg looks at: RESEED_G * RESEED_NT (tests, HARC_AMD_RESEED_WIN: fewer, so that small inputs take several passes; same seeds)
     unsigned int *reseed_g;          // k_reseed_mg: meeting counter, flag, per-workgroup counts (k_resolve zeroes the first two words every round)
     uint2 *cst2;                     // per chain: x seeds taken (= unmatched reads, reorder.cpp:701), y lost bids
+    uint32_t *bo;                    // back-off (null: off): per chain, bits 0-7 super-rounds it still sits out, bits 8-15 its walks cut in a row
     uint32_t *sugg;                  // [K][HARC_NSUGG] look-ahead seeds of every chain, highest id first
     int S;                           // speculative steps per super-round (1..64)
     int nsugg_per_seed;              // look-ahead seeds per reseed (HARC_NSUGG; 0 disables them: experiments only, the oracle uses the same value)
@@ -304,6 +305,8 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
 #define HARC_LARGEBIN 16u    // stage-I bins with more reads than this are compacted between super-rounds (k_compact_bins)
 #define HARC_STEP_CAP 6     // schedule: a STEP that has made this many probes into such bins without a hit is put off -- the walk ends in front of it, and the next
                              // super-round takes the step up again behind the probes already made (they found nothing against fewer claims; ChainHdr.flags >> 16)
+#define HARC_BO_FREE 1u      // schedule (repeat-rich input with more than 16 384 chains only; oracle: BO_FREE / BO_CAP): in the end phase of such an input every chain walks towards the
+#define HARC_BO_CAP 3u       // same few reads and nine walks in ten are cut (profiles/r05/phantom_bids.txt); a chain whose walks keep being cut sits out 0, 1, 3, 7, 7 ... super-rounds
 #define HARC_SCAN_BUDGET 8   // schedule: a walk ends after the step in which the probes it made into such bins (still holding unclaimed reads) reach this number
 // The table is probed bucket by bucket (64 B = 4 slots); a search that finds a full bucket WITHOUT the overflow flag can stop.
 // The reads arrive sorted by scrambled key, so the bins arrive in bucket order (bucket_slot is monotone): the slot of bin i is
@@ -1298,6 +1301,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     cst.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)cst.x); cst.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)cst.y);
     cst.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)cst.z); cst.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)cst.w);
     if (!(h.flags & CH_ACTIVE)) return;
+    if (!COOP && s.bo && (s.bo[c] & 0xFFu)) return;             // sits this super-round out (back-off; resolve_body counts the rounds down)
     if (COOP && !(h.flags & CH_COOP)) return;
     if (!COOP && s.need[c]) {
         // the chain asked for a seed last super-round and k_reseed ranked it: take seed number `rank` (reorder.cpp:650-688), or finish
@@ -1935,7 +1939,11 @@ template <int G> __device__ __forceinline__ void resolve_body(const S1Args &s, c
     const uint32_t c = (bx * 4 + (threadIdx.x >> 6)) * CPW + sub;
     ChainHdr h; h.flags = 0; h.nsteps = 0; h.n_main = 0; h.n_sing = 0; h.prev = 0; h.pad0 = 0;
     if (c < s.K) h = s.hdr[c];
-    const bool act = c < s.K && (h.flags & CH_ACTIVE);
+    // back-off: a chain that sat this super-round out is not touched by it (its header keeps the roll-back of the round in which it was cut)
+    const uint32_t bo0 = (s.bo && c < s.K) ? s.bo[c] : 0u;
+    const bool asleep = (bo0 & 0xFFu) != 0;
+    if (asleep && sl == 0) s.bo[c] = bo0 - 1u;
+    const bool act = c < s.K && (h.flags & CH_ACTIVE) && !asleep;
     const int n = act ? (int)(h.nsteps & 0xFF) : 0;
     uint2 sp = make_uint2(HARC_NONE, 0);
     bool mineb = false;
@@ -2037,6 +2045,12 @@ template <int G> __device__ __forceinline__ void resolve_body(const S1Args &s, c
         s.hdr[c] = h;
         if (nseed || cut) { uint2 q = s.cst2[c]; q.x += (uint32_t)nseed; q.y += cut ? 1u : 0u; s.cst2[c] = q; }
         s.need[c] = (!cut && (h.flags & CH_NEEDSEED)) ? 1 : 0;
+        if (s.bo) {   // a walk cut at a lost bid: the chain sits out 2^(k - HARC_BO_FREE) - 1 super-rounds, k = its cuts in a row (at most HARC_BO_FREE + HARC_BO_CAP); a walk that was kept whole clears k
+            uint32_t k = (bo0 >> 8) & 0xFFu, zs = 0u;
+            if (cut) { if (k < HARC_BO_FREE + HARC_BO_CAP) k++; zs = k > HARC_BO_FREE ? (1u << (k - HARC_BO_FREE)) - 1u : 0u; }
+            else if (n > 0) k = 0;
+            s.bo[c] = zs | (k << 8);
+        }
     }
 }
 template <int G> __global__ __launch_bounds__(256) void k_resolve(S1Args s) { resolve_body<G>(s, blockIdx.x); }
@@ -2788,6 +2802,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         HIP_TRY(hipGetLastError());
     }
     if (steps_auto32 && large_entries * 50 > (uint64_t)N) nsteps = 16;      // (see steps_auto32 above)
+    const bool backoff = K > 16384 && large_entries * 50 > (uint64_t)N;      // the same inputs: chains that keep losing bids sit rounds out (HARC_BO_FREE)
     if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] %u bins of more than %u reads hold %llu entries (%.2f %% of the reads): %d steps per super-round\n", nlarge, HARC_LARGEBIN,
                                           (unsigned long long)large_entries, N ? 100.0 * (double)large_entries / (double)N : 0.0, nsteps);
     HIP_TRY(hipEventRecord(e1, c->stream));
@@ -2796,6 +2811,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     S1Args a; memset(&a, 0, sizeof a);
     a.L = P.readlen; a.maxmatch = P.maxmatch; a.thresh = P.thresh; a.maxsearch = P.maxsearch;
     a.Lp = ((W + 1) / 2) * 64; a.S = nsteps;
+    if (backoff) { RC_TRY(dalloc(c, &a.bo, (size_t)K)); HIP_TRY(hipMemsetAsync(a.bo, 0, (size_t)K * 4, c->stream)); }
     a.nsugg_per_seed = HARC_NSUGG;
     // ONE chain (exact mode) takes its seeds from the same descending cursor whatever the look-ahead holds (nobody else claims anything between the
     // hand-out and the use, and the walk skips what it took itself): 64 look-ahead seeds instead of 8 are the same bytes and a third of the
@@ -2916,7 +2932,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
                       bloom_mmask == 0xFFFFFFFFu && (dict[0].cap >> 34) == 0 && P.maxsearch >= (int)HARC_LARGEBIN && a.firstmax == 64;
     // two chains per wave (k_steps_grp, steps_group.h): the dense SPEC conditions, at most 32 steps and look-ahead seeds per group of 32 lanes.
     // HARC_AMD_GRP=1 asks for it wherever it can run, =0 never (same bytes either way: tests)
-    const bool grp_ok = (W == 4 || W == 5) && dense && !quad && spec && nsteps <= 16 && a.nsugg_per_seed <= 16 && a.nsugg_stride <= 16 && (dict[0].cap >> 32) == 0;
+    const bool grp_ok = (W == 4 || W == 5) && dense && !quad && spec && !backoff && nsteps <= 16 && a.nsugg_per_seed <= 16 && a.nsugg_stride <= 16 && (dict[0].cap >> 32) == 0;
     bool grp = grp_ok && (getenv("HARC_AMD_GRP") ? atoi(getenv("HARC_AMD_GRP")) != 0 : false);
     if (getenv("HARC_AMD_GRP") && atoi(getenv("HARC_AMD_GRP")) == 2 && !grp) {      // tests: the kernel asked for must be the kernel that runs
         harc_set_error("HARC_AMD_GRP=2: k_steps_grp cannot run here (W %d dense %d quad %d spec %d steps %d look-ahead seeds %d)", W, (int)dense, (int)quad, (int)spec, nsteps, a.nsugg_per_seed);

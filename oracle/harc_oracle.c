@@ -42,6 +42,8 @@
 #define LARGEBIN 16u      /* HARC_LARGEBIN of harc_amd/csrc/stage1.hip */
 #define STEP_CAP 6        /* HARC_STEP_CAP: a step that has made this many probes into such bins without a hit is put off: the walk ends in front of it and the
                               next super-round takes the step up again BEHIND the probes already made (they found nothing against fewer claims) */
+#define BO_FREE 1          /* HARC_BO_FREE / HARC_BO_CAP of stage1.hip: on repeat-rich input with more than 16 384 chains a chain whose walk was cut at a lost bid */
+#define BO_CAP 3           /* sits out 2^(k - BO_FREE) - 1 super-rounds, k = its cuts in a row, at most BO_FREE + BO_CAP (0, 1, 3, 7, 7 ... rounds) */
 #define SCAN_BUDGET 8      /* HARC_SCAN_BUDGET: a walk ends after the step in which its probes into bins of more than LARGEBIN reads (not yet exhausted) reach this number */
 
 /* ------------------------------------------------------------------ parameters (harc:52-60) */
@@ -163,6 +165,7 @@ typedef struct {
     uint32_t s_rid[MAXSTEPS]; uint8_t s_j[MAXSTEPS], s_dir[MAXSTEPS], s_kind[MAXSTEPS], s_sidx[MAXSTEPS]; int nsteps, need_reseed;
     uint32_t sugg[NSUGG]; int nsugg, sugg_pos;   /* unclaimed ids right below the cursor at the chain's last reseed, highest first */
     int32_t *count0; uint8_t *cons0;  /* state at the start of the super-round (rollback point) */
+    int sleep, ncut;                  /* back-off (BO_*): super-rounds the chain still sits out; its walks cut in a row */
 } chain_t;
 
 typedef struct {
@@ -318,6 +321,13 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
         dict_build(&dict[l], keys, N);
     }
     free(keys);
+    /* the back-off applies where the library applies it: more than 16 384 chains and the bins of more than LARGEBIN reads hold more than 2 % of N entries */
+    int backoff = 0;
+    {
+        uint64_t large_entries = 0;
+        for (int l = 0; l < 2; l++) for (uint32_t b = 0; b < dict[l].nkeys; b++) { uint32_t nb = dict[l].start[b + 1] - dict[l].start[b]; if (nb > LARGEBIN) large_entries += nb; }
+        backoff = K > 16384 && large_entries * 50 > (uint64_t)N;
+    }
     /* generatemasks (reorder.cpp:706-718) */
     uint64_t *mask = calloc((size_t)p->maxmatch * W + 1, 8), *revmask = calloc((size_t)p->maxmatch * W + 1, 8);
     for (int j = 0; j < p->maxmatch; j++) {
@@ -349,7 +359,7 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
         /* (A) speculative steps against the frozen state */
         for (uint32_t c = 0; c < K; c++) {
             chain_t *x = &ch[c];
-            if (!x->active) continue;
+            if (!x->active || x->sleep) continue;                  /* a chain that sits the round out is not touched by it */
             memcpy(x->count0, x->count, sizeof(int32_t) * 4 * L); memcpy(x->cons0, x->cons, L);
             x->nsteps = 0; x->need_reseed = 0;
             int spos = x->sugg_pos, bigprobes = 0;
@@ -390,6 +400,7 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
         for (uint32_t c = 0; c < K; c++) {
             chain_t *x = &ch[c];
             if (!x->active) continue;
+            if (x->sleep) { x->sleep--; continue; }
             int v = 0;
             while (v < x->nsteps && bid[x->s_rid[v]] == (((uint32_t)v << 20) | c)) v++;
             if (v < x->nsteps) {                                  /* lost a bid: roll back and replay the kept steps */
@@ -401,6 +412,10 @@ static int stage1_run(const uint64_t *reads, uint32_t N, const params_t *p, uint
                 }
                 for (int t = v - 1; t >= 0; t--) if (x->s_kind[t]) { x->sugg_pos = x->s_sidx[t]; break; }   /* look-ahead seeds of dropped steps stay available */
             } else x->sugg_pos = x->p_j;
+            if (backoff) {
+                if (v < x->nsteps) { if (x->ncut < BO_FREE + BO_CAP) x->ncut++; x->sleep = x->ncut > BO_FREE ? (1 << (x->ncut - BO_FREE)) - 1 : 0; }
+                else if (x->nsteps > 0) x->ncut = 0;
+            }
             for (int t = 0; t < v; t++) {
                 uint32_t k = x->s_rid[t];
                 CLAIM(k); x->cur = k;

@@ -282,32 +282,46 @@ def test_scan_choice_of_a_context_is_measured_once_and_never_visible_in_the_byte
     assert all(o == outs[0] for o in outs[1:])
 
 
-def _streams_of(txt, L, **params):
-    import numpy as np
+def test_back_off_of_chains_that_keep_losing_bids_matches_the_oracle(oracle, tmp_path):
+    """more than 16 384 chains on a repeat-rich input (the bins of more than 16 reads hold more than 2 % of N entries): a chain whose walks keep being cut
+    at a lost bid sits out 0, 1, 3, 7 ... super-rounds (stage1.hip HARC_BO_*, oracle BO_*).  The same schedule on both sides: every file is the oracle's"""
     import harc_amd
-    arr = np.frombuffer(txt, dtype=np.uint8).reshape(-1, L + 1)[:, :L]
-    hasN = (arr == ord("N")).any(1)
-    h = harc_amd.HarcAmd(harc_amd.default_params(L, num_thr=2, **params))
-    try:
-        h.set_reads_ascii(gen.lines_of(arr[~hasN]), int((~hasN).sum()), L + 1)
-        h.set_nreads_ascii(gen.lines_of(arr[hasN]), int(hasN.sum()), L + 1)
-        h.reorder(); h.encode()
-        return [h.stream(sid, e) for e in range(2) for sid in ("S2_SEQ", "S2_POS", "S2_NOISE", "S2_NOISEPOS", "S2_REV")] + [h.stream("S2_SINGLETON")]
-    finally:
-        h.close()
+    txt = gen.reads_text_lowcomplexity(99, 400000, 100, 1000000, n_repeat=600, n_polya=12, err=0.004)
+    (tmp_path / "o").mkdir(); (tmp_path / "g").mkdir()
+    K, S, E = 20000, 16, 2
+    inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, K, E, tmp_path / "o", S)
+    base = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+    harc_amd.reorder(base, 100, num_chains=K, num_steps=S)
+    assert_same(ol.read_dir(base), s1, ol.STAGE1_FILES, "stage I with the back-off vs oracle")
+    harc_amd.encoder(base, 100, num_thr=E)
+    assert_same(ol.read_dir(base), s2, ol.stage2_files(E), "stage II behind it vs oracle")
 
 
-def test_steps_per_super_round_chosen_from_the_index():
+def test_steps_per_super_round_chosen_from_the_index(oracle, tmp_path):
     """num_steps = 0 with more than 16 384 chains: 32 steps per super-round where the bins of more than 16 reads hold less than 2 % of N entries (clean
     data), 16 where repeat families fill such bins (longer walks of chains that meet lose more of what they walked: configs[3] with human-like repeats,
-    profiles/r05/s_choice_trace.txt).  A function of the input alone: the automatic choice gives the bytes of the explicit one"""
+    profiles/r05/s_choice_trace.txt).  A function of the input alone: the automatic choice gives the ORACLE's bytes for that S (every file; round 5
+    compared the library with itself here), and the other S gives other bytes on at least one of the inputs.  tests/test_gpu_many_chains.py has the same
+    at 20 000 / 65 536 chains on 1-2 M reads"""
+    import harc_amd
     clean = gen.lines_of(gen.reads_array(707, 60000, 100, 500000, err=0.002))
-    auto, s32, s16 = (_streams_of(clean, 100, num_chains=17000, num_steps=S) for S in (0, 32, 16))
-    assert auto == s32
     rich = gen.reads_text_lowcomplexity(99, 40000, 100, 100000, err=0.004)
-    auto_r, r32, r16 = (_streams_of(rich, 100, num_chains=17000, num_steps=S) for S in (0, 32, 16))
-    assert auto_r == r16
-    assert s32 != s16 or r32 != r16          # (the two schedules do differ on at least one of the inputs: the test can tell them apart)
+    K, E = 17000, 2
+    differ = False
+    for name, txt, S_rule in (("clean", clean, 32), ("rich", rich, 16)):
+        want = {}
+        for S in (16, 32):
+            d = tmp_path / f"o_{name}_{S}"; d.mkdir()
+            inputs, s1, s2, _ = _oracle_pipeline(oracle, txt, 100, K, E, d, S)
+            want[S] = (s1, s2)
+        differ = differ or any(want[16][1][f] != want[32][1][f] for f in ol.stage2_files(E))
+        g = tmp_path / f"g_{name}"; g.mkdir()
+        base = ol.stage_dir(g, {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
+        harc_amd.reorder(base, 100, num_chains=K, num_steps=0)
+        assert_same(ol.read_dir(base), want[S_rule][0], ol.STAGE1_FILES, f"{name}: stage I with the library's choice of S vs the oracle at S = {S_rule}")
+        harc_amd.encoder(base, 100, num_thr=E)
+        assert_same(ol.read_dir(base), want[S_rule][1], ol.stage2_files(E), f"{name}: stage II behind it vs the oracle at S = {S_rule}")
+    assert differ          # (the two schedules do differ on at least one of the inputs: the test can tell them apart)
 
 
 @pytest.mark.parametrize("env", [{"HARC_AMD_QUAD": "0"}, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1"},
