@@ -470,6 +470,38 @@ def stage2_blobs(h, shards):
     return out
 
 
+L2_PEAK_GBS = 34500.0     # MI355X_MICROARCH.md "L2 (per XCD)": 8 x 4 MiB, ~34.5 TB/s aggregate
+
+
+def chain_kernels_roofline(steps_alg, useful, cands_seq, dense_ms, dense_launches, coop):
+    """The two kernels of the chain phase priced apart (a `frac` above 1 on the repeat workloads came from counters that covered both kernels
+    over a time that covered one).  dense = k_steps' main form: random accesses into tables, bitmaps and reads -> HBM.  coop = k_steps<COOP>: walks that reach a
+    dictionary bin of more than 16 reads; its up-to-maxsearch Hamming tests per probe (reorder.cpp:540-556) read bin-ordered MIRRORS of the reads that the
+    scans of one super-round share out of L2 (16 concurrent walks per CU over a few thousand hot bins) -> priced against L2 bandwidth, not HBM.
+    Algorithmic bytes per kernel, SURVEY.md 8(d)'s chain step: 49 B per read + 16 B per sequential dictionary lookup + 36 B per sequential candidate, each
+    from the kernel's OWN counters; the reads are shared out by the steps each kernel walked.  coop = dict(ms, launches, useful, cands_seq, steps, dense_steps)."""
+    walked = coop["steps"] + coop["dense_steps"]
+    share_c = (coop["steps"] / walked) if walked else 0.0
+    out = {}
+    d_bytes = 49.0 * steps_alg * (1.0 - share_c) + 16.0 * (useful - coop["useful"]) + 36.0 * (cands_seq - coop["cands_seq"])
+    c_bytes = 49.0 * steps_alg * share_c + 16.0 * coop["useful"] + 36.0 * coop["cands_seq"]
+    for name, kern, nbytes, ms, launches, bound, peak, why in (
+            ("dense", "k_steps (main form)", d_bytes, dense_ms, dense_launches, "hbm", 8000.0, "random accesses into tables, bitmaps and reads"),
+            ("coop", "k_steps<COOP> (walks into bins of more than 16 reads)", c_bytes, coop["ms"], coop["launches"], "l2", L2_PEAK_GBS,
+             "candidate scans stream the bin-ordered mirrors of the reads, shared by the walks of a super-round out of L2")):
+        if not launches or ms <= 0:
+            continue
+        ach = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {"kernel": kern, "bound": bound, "peak": peak, "unit": "GB/s", "achieved": round(ach, 2), "frac": round(ach / peak, 5), "ms_total": round(ms, 2),
+                     "launches": int(launches), "avg_launch_us": round(ms / launches * 1e3, 2), "alg_bytes_per_launch": round(nbytes / launches, 1), "why_this_ceiling": why}
+    if out:
+        worst = min(out, key=lambda k: out[k]["frac"])
+        longest = max(out, key=lambda k: out[k]["ms_total"])
+        out["furthest_from_its_ceiling"] = f"{worst}: {out[worst]['frac']:.3f} of {out[worst]['bound'].upper()} peak"
+        out["most_time"] = f"{longest}: {out[longest]['ms_total']:.0f} ms"
+    return out
+
+
 def run_other_config(harc_amd, name, dev_index, dev, shards, steps=2):
     """one of the other BASELINE configurations on this GPU: 1 warm-up (pool growth) + `steps` timed reorder + encode (+ pack_order) passes,
     timed like the main line (reads resident in HBM -> streams in pinned host memory), then the round trip on all reads"""
@@ -495,6 +527,8 @@ def run_other_config(harc_amd, name, dev_index, dev, shards, steps=2):
         return {"value": round(n * steps / dt / 1e6, 3), "unit": "Mreads/s", "steps": steps, "warmup": 1, "ms_per_step": round(dt / steps * 1e3, 2), "description": desc,
                 "phases_ms_last_step": {"index": round(c.index_ms, 2), "chain": round(c.chain_ms, 2), "encode": round(c.encode_ms, 2)},
                 "k_steps_avg_launch_us": round(c.propose_ms / max(1, c.propose_launches) * 1e3, 2), "rounds": int(c.rounds), "chains": int(c.chains),
+                "chain_kernels": chain_kernels_roofline(c.n_clean, c.useful_probes, c.candidates_seq, c.propose_ms, c.propose_launches,
+                                                        dict(ms=c.coop_ms, launches=c.coop_launches, useful=c.coop_useful_probes, cands_seq=c.coop_candidates_seq, steps=c.coop_steps, dense_steps=c.dense_steps)),
                 "roundtrip": {"ok": bool(tuple(dsig) == tuple(sig_in)), "reads_decoded": int(dsig[0]), "reads_in": int(sig_in[0])},
                 "device_bytes_peak": int(c.device_bytes_peak)}
     finally:
@@ -515,7 +549,7 @@ def main():
     ap.add_argument("--no-side-legs", action="store_true", help="N>1: skip rank 0's GPU side legs after the timed region (n1_equivalent, size_vs_1gpu) -- the peers wait for them in the final barrier")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket exchange even at world size 1 (exercises the N>1 path on one GPU)")
     ap.add_argument("--cpu-sample", type=int, default=0)
-    ap.add_argument("--no-other-configs", action="store_true", help="default workload on one GPU: skip the side lines for configs[3] (c4) and configs[4]'s share (c5g), 2 timed steps each after the main line's timed region")
+    ap.add_argument("--no-other-configs", action="store_true", help="default workload on one GPU: skip the side lines for configs[2] with repeats (c3r, 1 timed step), configs[3] (c4) and configs[4]'s share (c5g), 2 timed steps each, after the main line's timed region")
     ap.add_argument("--mg-mode", default="bucket", choices=["bucket", "replicate"],
                     help="N>1: bucket = minimizer-bucket shard + one all-to-all, independent shards (north_star; larger archives); replicate = design (R): "
                          "all-gather of the reads, chains partitioned over the GPUs, one all-gather of the walked steps per super-round -- every GPU "
@@ -607,7 +641,7 @@ def main():
     for _ in range(args.warmup + priming):
         with wd.phase("warm-up step", args.watchdog):
             step()
-    agg = dict(propose_ms=0.0, launches=0, steps_alg=0, useful=0, cands=0, cands_seq=0, probes=0, rounds=0)
+    agg = dict(propose_ms=0.0, launches=0, steps_alg=0, useful=0, cands=0, cands_seq=0, probes=0, rounds=0, coop_ms=0.0, coop_launches=0, coop_useful=0, coop_cseq=0, coop_steps=0, dense_steps=0)
     with wd.phase("barrier before the timed region", args.watchdog):
         barrier()
     t0 = time.perf_counter()
@@ -623,6 +657,8 @@ def main():
         agg["useful"] += c.useful_probes
         agg["rounds"] += c.rounds
         agg["steps_alg"] += c.n_clean
+        agg["coop_ms"] += c.coop_ms; agg["coop_launches"] += c.coop_launches; agg["coop_useful"] += c.coop_useful_probes
+        agg["coop_cseq"] += c.coop_candidates_seq; agg["coop_steps"] += c.coop_steps; agg["dense_steps"] += c.dense_steps
     with wd.phase("barrier after the timed region", args.watchdog):
         barrier()
     dt = time.perf_counter() - t0
@@ -657,7 +693,12 @@ def main():
     #   49 B/read (removals 40 + claim 2 + outputs 7) + 16 B per dictionary lookup of a strictly sequential scan (L-bar, counted by
     #   the kernel as `useful_probes`) + 36 B per candidate that scan would test (C-bar, `candidates_seq`).  The speculative lookups and
     #   candidates of the 64-lane batches are NOT counted; `candidates_per_read_speculative` shows them.
-    alg_bytes = 49.0 * agg["steps_alg"] + 16.0 * agg["useful"] + 36.0 * agg["cands_seq"]
+    kernels = chain_kernels_roofline(agg["steps_alg"], agg["useful"], agg["cands_seq"], agg["propose_ms"], agg["launches"],
+                                     dict(ms=agg["coop_ms"], launches=agg["coop_launches"], useful=agg["coop_useful"], cands_seq=agg["coop_cseq"], steps=agg["coop_steps"], dense_steps=agg["dense_steps"]))
+    # the top-level block is the MAIN kernel's on every workload, from its own counters over its own launches (no cooperative launch on inputs without large bins)
+    walked = agg["coop_steps"] + agg["dense_steps"]
+    share_d = (agg["dense_steps"] / walked) if walked else 1.0
+    alg_bytes = 49.0 * agg["steps_alg"] * share_d + 16.0 * (agg["useful"] - agg["coop_useful"]) + 36.0 * (agg["cands_seq"] - agg["coop_cseq"])
     launches = max(1, agg["launches"])
     avg_ms = agg["propose_ms"] / launches
     achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -670,7 +711,8 @@ def main():
                 "slots_inspected_per_read": round(agg["probes"] / max(1, agg["steps_alg"]), 2),
                 "candidates_per_read_speculative": round(agg["cands"] / max(1, agg["steps_alg"]), 3),
                 "Gslots_per_s": round(agg["probes"] / (agg["propose_ms"] * 1e-3) / 1e9, 2) if agg["propose_ms"] > 0 else None,
-                "note": "random-access regime: 16-B slots and 32-B reads fetched as >=64-B sectors; see DESIGN.md"}
+                "note": "random-access regime: 16-B slots and 32-B reads fetched as >=64-B sectors; see DESIGN.md",
+                "kernels": kernels}
     try:                                                          # HBM bytes per launch from the committed PMC passes of the same command
         tr = json.load(open(os.path.join(ROOT, "profiles", "k_steps_traffic.json"))).get(args.workload)
         if tr and world == 1:
@@ -814,12 +856,14 @@ def main():
     if rank == 0 and world == 1 and dist is None and args.workload == "c3" and not args.no_other_configs and not args.no_cpu:
         out["other_configs"] = {}
         t_other = time.perf_counter()
-        for name in ("c4", "c5g"):
-            if time.perf_counter() - t_other > 100.0:            # c4 took long on this box: the line must not
+        # (round 6: c3r first -- configs[2] on a genome with a human-like repeat content, the input shape of the real configs[1] / [3]; one warm-up + ONE timed
+        #  step of ~2.3 s, so that the repeat-bearing rate is the driver's number too and not only the builder's)
+        for name in ("c3r", "c4", "c5g"):
+            if time.perf_counter() - t_other > 150.0:            # the side lines took long on this box: the line must not
                 out["other_configs"][name] = {"skipped": "wall-time bound of the side lines reached"}
                 continue
             try:
-                out["other_configs"][name] = run_other_config(harc_amd, name, local, dev, args.shards)
+                out["other_configs"][name] = run_other_config(harc_amd, name, local, dev, args.shards, steps=1 if name == "c3r" else 2)
             except Exception as e:                                # a side line never takes the main line down
                 out["other_configs"][name] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()

@@ -25,7 +25,9 @@ class Counters(C.Structure):
                 ("conflicts", C.c_uint64), ("propose_launches", C.c_uint64), ("propose_ms", C.c_double),
                 ("index_ms", C.c_double), ("chain_ms", C.c_double), ("encode_ms", C.c_double), ("total_ms", C.c_double),
                 ("contigs", C.c_uint64), ("seq_bases", C.c_uint64), ("bins_over_maxsearch", C.c_uint64),
-                ("device_bytes_peak", C.c_uint64), ("useful_probes", C.c_uint64), ("candidates_seq", C.c_uint64)]
+                ("device_bytes_peak", C.c_uint64), ("useful_probes", C.c_uint64), ("candidates_seq", C.c_uint64),
+                ("coop_launches", C.c_uint64), ("coop_ms", C.c_double), ("coop_useful_probes", C.c_uint64), ("coop_candidates_seq", C.c_uint64),
+                ("coop_candidates", C.c_uint64), ("coop_steps", C.c_uint64), ("dense_steps", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

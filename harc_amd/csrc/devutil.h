@@ -6,8 +6,9 @@
 // A grid is dispatched with its size in WORK-ITEMS per dimension as a 32-bit number: blocks x threads of 2^32 and more is taken modulo 2^32 WITHOUT an error
 // (tools/micro/grid_limit.hip: 39 000 000 x 256 runs 5 445 568 workgroups and reports hipSuccess; an exact multiple of 2^32 is hipErrorInvalidConfiguration,
 // which the next successful call erases).  Found in round 5 at 402 M probes into stage II's large bins; the decoders had it from 42 M reads per shard on.
-// A thread per item: harc_grid256(n) folds the workgroups into rows of at most HARC_GRID_ROW (x 256 threads < 2^32) and the kernel takes its index from
-// harc_gid().  Kernels whose item count is a 32-bit number never get a second row and may keep blockIdx.x * blockDim.x + threadIdx.x.
+// A thread per item: harc_grid256(n) folds the workgroups into rows of at most HARC_GRID_ROW (x 256 threads < 2^32) and EVERY such kernel takes its index
+// from harc_gid() -- or from harc_gid32() when its item count is a 32-bit number (a count in (2^32 - 256, 2^32) already asks for 2^24 workgroups = a
+// second row): no kernel of the library computes blockIdx.x * blockDim.x + threadIdx.x by itself outside a grid-stride loop over a bounded grid.
 #define HARC_GRID_ROW 16777215u
 static inline dim3 harc_grid256(uint64_t n)
 {
@@ -16,9 +17,20 @@ static inline dim3 harc_grid256(uint64_t n)
     if (b <= HARC_GRID_ROW) return dim3((unsigned)b);
     return dim3(HARC_GRID_ROW, (unsigned)((b + HARC_GRID_ROW - 1) / HARC_GRID_ROW));
 }
+// workgroups of 256 threads that are not one thread per item (a wave per item, W lanes per read): nblocks of them, folded the same way; the kernel takes
+// its workgroup's number from harc_bid()
+static inline dim3 harc_fold256(uint64_t nblocks)
+{
+    if (nblocks == 0) nblocks = 1;
+    if (nblocks <= HARC_GRID_ROW) return dim3((unsigned)nblocks);
+    return dim3(HARC_GRID_ROW, (unsigned)((nblocks + HARC_GRID_ROW - 1) / HARC_GRID_ROW));
+}
 // a workgroup of 64 threads per item (blockIdx.y * gridDim.x + blockIdx.x in the kernel): rows of 2^25 items x 64 threads = 2^31 work-items
 static inline dim3 wave_grid(uint32_t n) { if (n <= (1u << 25)) return dim3(n ? n : 1u); return dim3(1u << 25, (n + (1u << 25) - 1) >> 25); }
+__device__ __forceinline__ uint64_t harc_bid() { return (uint64_t)blockIdx.y * gridDim.x + blockIdx.x; }
 __device__ __forceinline__ uint64_t harc_gid() { return ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; }
+// ... for an item count that is a 32-bit number: 0xFFFFFFFF -- beyond every such count's last item -- for the threads of a second row past it
+__device__ __forceinline__ uint32_t harc_gid32() { const uint64_t g = harc_gid(); return g > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)g; }
 
 // ------------------------------------------------------------------------------------------------ device helpers
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)

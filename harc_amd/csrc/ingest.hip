@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_nl_write(const char *txt, uint64_t n, c
 // record r = lines 4r .. 4r+3 ; sequence = line 4r+1 = bytes (nl[4r], nl[4r+1]).  flags: bit0 = has N, err counts bad lengths
 __global__ void k_classify(const char *txt, const uint64_t *nl, uint32_t nrec, int L, uint32_t *isN, uint32_t *isClean, unsigned int *err)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = harc_gid32();
     if (r >= nrec) return;
     const uint64_t s = nl[4ull * r] + 1, e = nl[4ull * r + 1];
     uint64_t len = e - s;
@@ -122,7 +122,7 @@ struct IngestState {
 };
 __global__ void k_q_idlen(const uint64_t *nls, uint32_t nid, uint32_t *len)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = harc_gid32();
     if (r < nid) len[r] = (uint32_t)(nls[4ll * r] - (nls[4ll * r - 1] + 1));
 }
 static int ingest_begin(harc_amd_ctx *c, IngestState &st)
@@ -237,28 +237,28 @@ extern "C" int harc_amd_set_fastq_device(harc_amd_ctx *c, const char *d_txt, uin
 // line `k` (0 = id, 3 = quality) becomes output line p.
 __global__ void k_q_idflags(const uint32_t *isN, uint32_t nid, uint32_t *idC, uint32_t *idN)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = harc_gid32();
     if (r >= nid) return;
     const uint32_t prevN = r ? isN[r - 1] : 0u;                    // preprocess.cpp:83-88 runs before :98-110 of the same record
     idC[r] = prevN ? 0u : 1u; idN[r] = prevN;
 }
 __global__ void k_q_compact(const uint32_t *flag, const uint32_t *rank, uint32_t n, uint32_t *out)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = harc_gid32();
     if (r < n && flag[r]) out[rank[r]] = r;
 }
 __global__ void k_q_gather(const uint32_t *src, uint32_t nsrc, const uint32_t *order, uint32_t n, uint32_t *out, unsigned int *err)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = harc_gid32();
     if (p >= n) return;
     const uint32_t o = order[p];
     if (o >= nsrc) { atomicAdd(err, 1u); out[p] = 0; return; }
     out[p] = src[o];
 }
-__global__ void k_q_iota(uint32_t *out, uint32_t n) { const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; if (p < n) out[p] = p; }
+__global__ void k_q_iota(uint32_t *out, uint32_t n) { const uint32_t p = harc_gid32(); if (p < n) out[p] = p; }
 __global__ void k_q_linelen(const uint64_t *nls, const uint32_t *rec, uint32_t n, int k, int want, uint32_t *len, unsigned int *err)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = harc_gid32();
     if (p >= n) return;
     const int64_t li = 4ll * rec[p] + k;
     const uint64_t l = nls[li] - (nls[li - 1] + 1);
@@ -413,15 +413,15 @@ static int emit_quality_and_ids(harc_amd_ctx *c, const char *d_txt, uint64_t nby
 // must be readlen long, reorder_quality.cpp:78-79 -- id lines go by a prefix sum of their lengths).  Quality and id bins share a pass.
 __global__ void k_q_scatter_flag(const uint32_t *idx, uint32_t n, uint32_t lim, uint32_t *flag, unsigned int *err)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     const uint32_t r = idx[i];
     if (r >= lim) { atomicAdd(err, 1u); return; }
     flag[r] = 1u;
 }
-__global__ void k_q_not(const uint32_t *isN, uint32_t n, uint32_t *isC) { const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r < n) isC[r] = isN[r] ? 0u : 1u; }
-__global__ void k_q_invert(const uint32_t *rec, uint32_t n, uint32_t *pos) { const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; if (p < n) pos[rec[p]] = p; }
-__global__ void k_q_outlen(const uint32_t *idlen, const uint32_t *rec, uint32_t n, uint32_t *len) { const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; if (p < n) len[p] = idlen[rec[p]] + 1u; }
+__global__ void k_q_not(const uint32_t *isN, uint32_t n, uint32_t *isC) { const uint32_t r = harc_gid32(); if (r < n) isC[r] = isN[r] ? 0u : 1u; }
+__global__ void k_q_invert(const uint32_t *rec, uint32_t n, uint32_t *pos) { const uint32_t p = harc_gid32(); if (p < n) pos[rec[p]] = p; }
+__global__ void k_q_outlen(const uint32_t *idlen, const uint32_t *rec, uint32_t n, uint32_t *len) { const uint32_t p = harc_gid32(); if (p < n) len[p] = idlen[rec[p]] + 1u; }
 // first p in [lo, n] with off[p] - off[lo] > budget, minus one (at least lo + 1 when lo < n): the end of the bin that starts at lo
 __global__ void k_q_bin_end(const uint64_t *off, uint32_t lo, uint32_t n, uint64_t budget, uint32_t *out)
 {

@@ -97,18 +97,46 @@ __global__ void k_selftest_grid(uint64_t n, unsigned long long *out)
     for (int o = 32; o > 0; o >>= 1) { one += __shfl_xor(one, o, 64); idx += __shfl_xor(idx, o, 64); }
     if ((threadIdx.x & 63) == 0 && one) { atomicAdd(&out[0], one); atomicAdd(&out[1], idx); }
 }
+// ... the same through harc_gid32() (kernels whose item count is a 32-bit number; n < 2^32 only) ...
+__global__ void k_selftest_grid32(uint32_t n, unsigned long long *out)
+{
+    const uint32_t i = harc_gid32();
+    unsigned long long one = i < n ? 1ULL : 0ULL, idx = i < n ? (unsigned long long)i : 0ULL;
+    for (int o = 32; o > 0; o >>= 1) { one += __shfl_xor(one, o, 64); idx += __shfl_xor(idx, o, 64); }
+    if ((threadIdx.x & 63) == 0 && one) { atomicAdd(&out[0], one); atomicAdd(&out[1], idx); }
+}
+// ... and with FOUR LANES PER ITEM in folded workgroups (harc_fold256 / harc_bid: the geometry of k_orient and k_succ -- 4 n work-items pass 2^32 at a
+// quarter of the items): lane 0 of an item's four counts it
+__global__ void k_selftest_fold(uint64_t n, unsigned long long *out)
+{
+    const uint64_t wave = harc_bid() * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint64_t i = wave * 16 + (uint64_t)(lane >> 2);
+    const bool mine = i < n && (lane & 3) == 0;
+    unsigned long long one = mine ? 1ULL : 0ULL, idx = mine ? (unsigned long long)i : 0ULL;
+    for (int o = 32; o > 0; o >>= 1) { one += __shfl_xor(one, o, 64); idx += __shfl_xor(idx, o, 64); }
+    if (lane == 0 && one) { atomicAdd(&out[0], one); atomicAdd(&out[1], idx); }
+}
 extern "C" int harc_amd_selftest_launch(harc_amd_ctx *c, uint64_t n, uint64_t *visited, uint64_t *index_sum)
 {
     if (!c || !visited || !index_sum) return HARC_AMD_EINVAL;
     HIP_TRY(hipSetDevice(c->P.device));
-    unsigned long long *d = nullptr, h[2] = { 0, 0 };
-    HIP_TRY(hipMalloc((void **)&d, 16));
-    hipError_t e = hipMemsetAsync(d, 0, 16, c->stream);
+    unsigned long long *d = nullptr, h[6] = { 0, 0, 0, 0, 0, 0 };
+    HIP_TRY(hipMalloc((void **)&d, sizeof h));
+    const bool n32 = n <= 0xFFFFFFFFull;
+    hipError_t e = hipMemsetAsync(d, 0, sizeof h, c->stream);
     if (e == hipSuccess) { hipLaunchKernelGGL(k_selftest_grid, harc_grid256(n), dim3(256), 0, c->stream, n, d); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && n32) { hipLaunchKernelGGL(k_selftest_grid32, harc_grid256(n), dim3(256), 0, c->stream, (uint32_t)n, d + 2); e = hipGetLastError(); }
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_selftest_fold, harc_fold256((n + 63) / 64), dim3(256), 0, c->stream, n, d + 4); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) { harc_set_error("harc_amd_selftest_launch: %s", hipGetErrorString(e)); return HARC_AMD_ENODEVICE; }
-    *visited = h[0]; *index_sum = h[1];
-    return HARC_AMD_OK;
+    // the three geometries must agree; the first one that does not is what the caller gets to see
+    int k = 0;
+    if (n32 && (h[2] != h[0] || h[3] != h[1])) k = 2;
+    else if (h[4] != h[0] || h[5] != h[1]) k = 4;
+    if (k) harc_set_error("harc_amd_selftest_launch: %s visited %llu items (index sum %llx), the thread-per-item grid %llu (%llx)", k == 2 ? "harc_gid32" : "harc_fold256 / harc_bid", h[k], h[k + 1], h[0], h[1]);
+    *visited = h[k]; *index_sum = h[k + 1];
+    return k ? HARC_AMD_EINTERNAL : HARC_AMD_OK;
 }

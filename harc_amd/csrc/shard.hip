@@ -14,7 +14,7 @@
 // packed code of the clean store, so that an N read goes where the clean reads around it go); no clean window: hash of the id
 __global__ void k_bucket3(const uint64_t *reads3, uint32_t n, int L, int W3, uint32_t nb, uint32_t gid0, uint32_t *out)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     const uint64_t *r = reads3 + (size_t)i * W3;
     const int K = L < 15 ? L : 15;
@@ -37,7 +37,7 @@ __global__ void k_bucket3(const uint64_t *reads3, uint32_t n, int L, int W3, uin
 // (bucket, index) keys for the stable radix pass + reads per bucket (one atomic per distinct bucket per wave)
 __global__ void k_shard_keys(const uint32_t *bucket, uint32_t n, uint64_t *keys, uint32_t *idx, unsigned long long *counts)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     const bool in = i < n;
     const uint32_t b = in ? bucket[i] : 0xFFFFFFFFu;
     if (in) { keys[i] = b; idx[i] = i; }
@@ -52,7 +52,7 @@ __global__ void k_shard_keys(const uint32_t *bucket, uint32_t n, uint64_t *keys,
 }
 __global__ void k_shard_gather(const uint64_t *words, const uint32_t *idx, uint32_t n, int nw, uint32_t gid0, uint64_t *out, uint32_t *gid_out)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t t = harc_gid();
     if (t >= (uint64_t)n * nw) return;
     const uint32_t i = (uint32_t)(t / nw); const int w = (int)(t % nw);
     const uint32_t src = idx[i];
@@ -61,7 +61,7 @@ __global__ void k_shard_gather(const uint64_t *words, const uint32_t *idx, uint3
 }
 __global__ void k_map_ids(uint32_t *v, uint64_t n, const uint32_t *map, uint32_t nmap, unsigned int *err)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = harc_gid();
     if (i >= n) return;
     const uint32_t x = v[i];
     if (x >= nmap) { atomicAdd(err, 1u); return; }
@@ -71,7 +71,7 @@ __global__ void k_map_ids(uint32_t *v, uint64_t n, const uint32_t *map, uint32_t
 int shard_map_ids(harc_amd_ctx *c, uint32_t *d_v, uint64_t n, const uint32_t *d_map, uint32_t nmap, unsigned int *d_err)
 {
     if (!n) return HARC_AMD_OK;
-    hipLaunchKernelGGL(k_map_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_v, n, d_map, nmap, d_err);
+    hipLaunchKernelGGL(k_map_ids, harc_grid256(n), dim3(256), 0, c->stream, d_v, n, d_map, nmap, d_err);
     HIP_TRY(hipGetLastError());
     return HARC_AMD_OK;
 }
@@ -86,13 +86,13 @@ int shard_partition(harc_amd_ctx *c, const uint64_t *d_words, uint32_t n, int nw
     PoolScope scope(c);                                           // temporaries go on every way out
     uint32_t *b = nullptr, *i0 = nullptr, *i1 = nullptr; uint64_t *k0 = nullptr, *k1 = nullptr;
     RC_TRY(dalloc(c, &b, n)); RC_TRY(dalloc(c, &i0, n)); RC_TRY(dalloc(c, &i1, n)); RC_TRY(dalloc(c, &k0, n)); RC_TRY(dalloc(c, &k1, n));
-    const dim3 g((n + 255) / 256), t(256);
+    const dim3 g = harc_grid256(n), t(256);
     if (three_bit) hipLaunchKernelGGL(k_bucket3, g, t, 0, c->stream, d_words, n, c->P.readlen, nw, nb, gid0, b);
     else RC_TRY(s1_bucket_reads(c, d_words, n, nb, b));
     hipLaunchKernelGGL(k_shard_keys, g, t, 0, c->stream, (const uint32_t *)b, n, k0, i0, d_counts);
     unsigned bits = 1; while ((1u << bits) < nb) bits++;
     RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i0, i1, n, bits));                 // stable: original order inside a bucket
-    hipLaunchKernelGGL(k_shard_gather, dim3((unsigned)(((uint64_t)n * nw + 255) / 256)), t, 0, c->stream, d_words, (const uint32_t *)i1, n, nw, gid0, d_out, d_gid_out);
+    hipLaunchKernelGGL(k_shard_gather, harc_grid256((uint64_t)n * nw), t, 0, c->stream, d_words, (const uint32_t *)i1, n, nw, gid0, d_out, d_gid_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return HARC_AMD_OK;

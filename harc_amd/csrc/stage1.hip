@@ -62,6 +62,8 @@ struct S1Args {
     int stepcap;                     // HARC_STEP_CAP (HARC_AMD_STEPCAP)
     int weedmin;                     // wave-uniform scan: single-read bins a batch must find before their claim bits are looked up ahead of the tests (HARC_AMD_WEEDMIN)
     int lazy;                        // 1: steps that agree with the consensus everywhere take the rows from their read and leave the counts to cons_flush (HARC_AMD_LAZY=0: every step applies its counts; same bytes)
+    uint4 *cstat_coop;               // ... the cooperative kernel's own (k_chain_counts adds both up and keeps its share apart: bench.py prices the two kernels against different ceilings)
+    uint2 *csteps;                   // per chain: steps walked by the launches of the main kernel (x) and of the cooperative kernel (y), kept or not
     uint4 *cstat;                    // per chain statistics: x slots inspected, y candidates tested, z sequential-equivalent key lookups, w sequential-equivalent candidates
     const uint2 *succ;               // runs with one chain or a few (k_succ): per (read, orientation) the first HARC_SUCC_N candidates of the step whose consensus IS that read; null = none
     unsigned long long *dbg;         // HARC_TIMING builds only: per-phase cycle sums of k_steps
@@ -86,14 +88,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { for (int o = 32; 
 #else
 #define TICK(k) do { } while (0)
 #endif
-enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_USEFUL = 5, ST_CANDS_SEQ = 6, ST_WIDE = 7 /* k_steps_grp: some chain's counts passed GRP_WIDE_WARN (sticky) */, ST_N = 10 /* the last word: entries of the singleton log */ };
+enum { ST_UNMATCHED = 0, ST_CONFLICTS = 1, ST_ACTIVE = 2, ST_PROBES = 3, ST_CANDS = 4, ST_USEFUL = 5, ST_CANDS_SEQ = 6, ST_WIDE = 7 /* k_steps_grp: some chain's counts passed GRP_WIDE_WARN (sticky) */, /* 8: ST_WIDE + 1 */
+       ST_COOP_USEFUL = 9, ST_COOP_CANDS_SEQ = 10, ST_COOP_CANDS = 11 /* the cooperative kernel's share of ST_USEFUL / ST_CANDS_SEQ / ST_CANDS */, ST_COOP_STEPS = 12, ST_DENSE_STEPS = 13 /* steps WALKED (kept or not) by the launches of either kernel */,
+       ST_N = 16 /* the last word: entries of the singleton log */ };
 #define HARC_COOPCNT 64   // counters of the walks handed to the cooperative kernel, spread over as many words (one word serialised 1300 atomics per round: +10 us)
 
 // ------------------------------------------------------------------------------------------------ packing kernels
 // ASCII -> std::bitset<2L> words (reorder.cpp:184-209). One thread per (read, word).
 __global__ void k_pack2(const char *ascii, uint32_t n, uint32_t stride, int L, int W, uint64_t *out)
 {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gid = harc_gid();
     if (gid >= (size_t)n * W) return;
     const uint32_t i = (uint32_t)(gid / W); const int w = (int)(gid % W);
     const char *s = ascii + (size_t)i * stride;
@@ -111,7 +115,7 @@ __global__ void k_pack2(const char *ascii, uint32_t n, uint32_t stride, int L, i
 // ASCII -> std::bitset<3L> words (encoder.cpp:729-749): A=0 N=1 G=2 C=4 T=6 at bits 3i.. One thread per (read, word).
 __global__ void k_pack3(const char *ascii, uint32_t n, uint32_t stride, int L, int W3, uint64_t *out)
 {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gid = harc_gid();
     if (gid >= (size_t)n * W3) return;
     const uint32_t i = (uint32_t)(gid / W3); const int w = (int)(gid % W3);
     const char *s = ascii + (size_t)i * stride;
@@ -128,7 +132,7 @@ __global__ void k_pack3(const char *ascii, uint32_t n, uint32_t stride, int L, i
 // 2-bit words -> text lines of L+1 bytes (reorder.cpp:832-846 bitsettostring). One thread per (read, word).
 __global__ void k_unpack2(const uint64_t *reads, uint32_t n, int L, int W, char *out)
 {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gid = harc_gid();
     if (gid >= (size_t)n * W) return;
     const uint32_t i = (uint32_t)(gid / W); const int w = (int)(gid % W);
     uint64_t v = reads[gid];
@@ -144,7 +148,7 @@ int s1_pack_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t str
 {
     if (!n) return HARC_AMD_OK;
     const size_t tot = (size_t)n * c->W;
-    hipLaunchKernelGGL(k_pack2, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, d_ascii, n, stride, c->P.readlen, c->W, d_out);
+    hipLaunchKernelGGL(k_pack2, harc_grid256(tot), dim3(256), 0, c->stream, d_ascii, n, stride, c->P.readlen, c->W, d_out);
     HIP_TRY(hipGetLastError());
     return HARC_AMD_OK;
 }
@@ -152,7 +156,7 @@ int s1_pack3_ascii(harc_amd_ctx *c, const char *d_ascii, uint32_t n, uint32_t st
 {
     if (!n) return HARC_AMD_OK;
     const size_t tot = (size_t)n * c->W3;
-    hipLaunchKernelGGL(k_pack3, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, d_ascii, n, stride, c->P.readlen, c->W3, d_out);
+    hipLaunchKernelGGL(k_pack3, harc_grid256(tot), dim3(256), 0, c->stream, d_ascii, n, stride, c->P.readlen, c->W3, d_out);
     HIP_TRY(hipGetLastError());
     return HARC_AMD_OK;
 }
@@ -160,7 +164,7 @@ int s1_unpack_to_ascii(harc_amd_ctx *c, const uint64_t *d_reads, uint32_t n, cha
 {
     if (!n) return HARC_AMD_OK;
     const size_t tot = (size_t)n * c->W;
-    hipLaunchKernelGGL(k_unpack2, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, d_reads, n, c->P.readlen, c->W, d_out);
+    hipLaunchKernelGGL(k_unpack2, harc_grid256(tot), dim3(256), 0, c->stream, d_reads, n, c->P.readlen, c->W, d_out);
     HIP_TRY(hipGetLastError());
     return HARC_AMD_OK;
 }
@@ -168,7 +172,7 @@ int s1_unpack_to_ascii(harc_amd_ctx *c, const uint64_t *d_reads, uint32_t n, cha
 // multi-GPU shard key: hash of the canonical minimizer (k=15) of the whole read, modulo the number of GPUs.  One thread per read.
 __global__ void k_bucket(const uint64_t *reads, uint32_t n, int L, int W, uint32_t nb, uint32_t *out)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     const uint64_t *r = reads + (size_t)i * W;
     const int K = L < 15 ? L : 15;
@@ -185,7 +189,7 @@ __global__ void k_bucket(const uint64_t *reads, uint32_t n, int L, int W, uint32
 int s1_bucket_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint32_t nb, uint32_t *d_out)
 {
     if (!n) return HARC_AMD_OK;
-    hipLaunchKernelGGL(k_bucket, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_packed, n, c->P.readlen, c->W, nb, d_out);
+    hipLaunchKernelGGL(k_bucket, harc_grid256(n), dim3(256), 0, c->stream, d_packed, n, c->P.readlen, c->W, nb, d_out);
     HIP_TRY(hipGetLastError());
     return HARC_AMD_OK;
 }
@@ -194,7 +198,7 @@ int s1_bucket_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, uint3
 // -> gather; counts[b] = reads of bucket b
 __global__ void k_bucket_keys(const uint32_t *bucket, uint32_t n, uint64_t *keys, uint32_t *idx, unsigned long long *counts)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     const bool in = i < n;
     const uint32_t b = in ? bucket[i] : 0xFFFFFFFFu;
     if (in) { keys[i] = b; idx[i] = i; }
@@ -210,7 +214,7 @@ __global__ void k_bucket_keys(const uint32_t *bucket, uint32_t n, uint64_t *keys
 }
 __global__ void k_gather_reads(const uint64_t *reads, const uint32_t *idx, uint32_t n, int W, uint64_t *out)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     if (gid >= (uint64_t)n * W) return;
     const uint32_t i = (uint32_t)(gid / W); const int w = (int)(gid % W);
     out[gid] = reads[(size_t)idx[i] * W + w];
@@ -222,11 +226,11 @@ int s1_partition_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, ui
     PoolScope scope(c);
     uint32_t *b = nullptr, *i0 = nullptr, *i1 = nullptr; uint64_t *k0 = nullptr, *k1 = nullptr;
     RC_TRY(dalloc(c, &b, n)); RC_TRY(dalloc(c, &i0, n)); RC_TRY(dalloc(c, &i1, n)); RC_TRY(dalloc(c, &k0, n)); RC_TRY(dalloc(c, &k1, n));
-    hipLaunchKernelGGL(k_bucket, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_packed, n, c->P.readlen, c->W, nb, b);
-    hipLaunchKernelGGL(k_bucket_keys, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)b, n, k0, i0, d_counts);
+    hipLaunchKernelGGL(k_bucket, harc_grid256(n), dim3(256), 0, c->stream, d_packed, n, c->P.readlen, c->W, nb, b);
+    hipLaunchKernelGGL(k_bucket_keys, harc_grid256(n), dim3(256), 0, c->stream, (const uint32_t *)b, n, k0, i0, d_counts);
     unsigned bits = 1; while ((1u << bits) < nb) bits++;
     RC_TRY(prim_sort_pairs_u64_u32(c, k0, k1, i0, i1, n, bits));                 // stable: original order inside a bucket
-    hipLaunchKernelGGL(k_gather_reads, dim3((unsigned)(((uint64_t)n * c->W + 255) / 256)), dim3(256), 0, c->stream, d_packed, (const uint32_t *)i1, n, c->W, d_out);
+    hipLaunchKernelGGL(k_gather_reads, harc_grid256((uint64_t)n * c->W), dim3(256), 0, c->stream, d_packed, (const uint32_t *)i1, n, c->W, d_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return HARC_AMD_OK;
@@ -237,7 +241,7 @@ int s1_partition_reads(harc_amd_ctx *c, const uint64_t *d_packed, uint32_t n, ui
 // both dictionaries' keys in ONE pass over the reads (the second pass was 11 GB read again at configs[2]: 2.7 ms)
 template <int W> __global__ void k_keygen2(const uint64_t *reads, uint32_t n, int off0, int nbits0, int off1, int nbits1, uint64_t *keys0, uint64_t *keys1, uint32_t *ids)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     uint64_t r[W];
 #pragma unroll
@@ -263,7 +267,7 @@ template <int W> __global__ void k_keygen2(const uint64_t *reads, uint32_t n, in
 // Hamming scan" of the north star, for the bins where it pays).  large_list was filled by k_table_insert: (slot index << 1) | dictionary.
 __global__ void k_large_sizes(const unsigned long long *list, uint32_t nlist, HashSlot *s0, HashSlot *s1, uint32_t *sz)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = harc_gid32();
     if (b >= nlist) return;
     const unsigned long long e = list[b];
     const HashSlot *slot = ((e & 1) ? s1 : s0) + (e >> 1);
@@ -290,14 +294,14 @@ template <int W> __global__ __launch_bounds__(64) void k_large_fill(const unsign
 }
 __global__ void k_mark_heads(const uint64_t *skeys, uint32_t n, uint32_t *head)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     head[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1u : 0u;
 }
 // ... and, with the keys at hand, what the placement's max-scan starts from: 4 b_i - i of bin i (see below), biased by n to stay unsigned
 __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint32_t n, uint32_t *binstart, uint32_t *nbins, const uint64_t *skeys, uint64_t cap, uint64_t *v)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     if (head[i]) { const uint32_t b = binidx[i]; binstart[b] = i; v[b] = bucket_slot(skeys[i], cap) + (uint64_t)n - (uint64_t)b; }
     if (i == n - 1) *nbins = binidx[i] + head[i];
@@ -325,7 +329,7 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, unsigned r) { r &= 63u; return r ? (x << r) | (x >> (64u - r)) : x; }
 __global__ void k_mixed_find(const uint64_t *rk, uint32_t n, unsigned sbits, uint64_t *sk, uint32_t *list, unsigned int *meta)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     const int shift = (int)(64u - sbits);
     const uint64_t b = rotl64(rk[i], 64u - sbits);                // rotate right by sbits
@@ -337,7 +341,7 @@ __global__ void k_mixed_find(const uint64_t *rk, uint32_t n, unsigned sbits, uin
 // which listed place owns its stretch (the first one inside it); the others are struck off before anything moves
 __global__ void k_mixed_own(const uint64_t *sk, int shift, uint32_t *list, unsigned int *meta)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = harc_gid32();
     const unsigned int nl = meta[0] < MIXED_MAX ? meta[0] : MIXED_MAX;
     if (t >= nl || meta[1]) return;
     const uint32_t i = list[t];
@@ -350,7 +354,7 @@ __global__ void k_mixed_own(const uint64_t *sk, int shift, uint32_t *list, unsig
 }
 __global__ void k_mixed_fix(uint64_t *sk, uint32_t *ids, uint32_t n, int shift, const uint32_t *list, unsigned int *meta)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = harc_gid32();
     const unsigned int nl = meta[0] < MIXED_MAX ? meta[0] : MIXED_MAX;
     if (t >= nl || meta[1]) return;
     const uint32_t i = list[t];
@@ -370,12 +374,12 @@ __global__ void k_mixed_fix(uint64_t *sk, uint32_t *ids, uint32_t n, int shift, 
 }
 __global__ void k_scramble_keys(uint64_t *keys, uint32_t n, unsigned rot)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i < n) keys[i] = rotl64(key_scramble(keys[i]), rot);
 }
 __global__ void k_rotate_keys(uint64_t *keys, uint32_t n, unsigned rot)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i < n) keys[i] = rotl64(keys[i], rot);
 }
 // pass 0: the bins whose slot lies inside the table, plain 16-byte stores, overflow flags included (round 2 set them in a second pass over all
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(256) void k_table_place(const uint64_t *skeys, cons
 {
     __shared__ uint4 tile[TP_SPAN];
     if (blockIdx.x < first_block) return;                                          // pass 1: the bins beyond the end of the table are among the last
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     const bool have = i < nbins;
     auto slot_of = [&](uint32_t k) -> uint64_t { return q[k] - (uint64_t)n + (uint64_t)k; };     // max-scan value (biased by n, k_bin_starts) + k
     // fill (pass 0): the table has NOT been cleared (22 GB per dictionary at configs[2]): slots grow with the bin index, so the 256 bins of a
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256) void k_table_place(const uint64_t *skeys, cons
 // stream -- every byte of the bitmap is written exactly once, so it needs no clearing either.
 __global__ void k_s1_bloom_keys(const uint64_t *keys, uint32_t n, uint32_t nlines, int nwin, uint32_t mmask, uint64_t *pk)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     uint32_t w, m;
     bloom_pos(keys[i], key_scramble(keys[i]), nlines, nwin, mmask, &w, &m);
@@ -523,14 +527,14 @@ int harc_bitmap_from_items(harc_amd_ctx *c, const uint64_t *items, uint64_t *tmp
 }
 __global__ void k_s1_bloom_diff(const uint32_t *a, const uint32_t *b, uint64_t nwords, unsigned long long *ndiff)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = harc_gid();
     const bool d = i < nwords && a[i] != b[i];
     const unsigned long long m = __ballot(d);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(ndiff, (unsigned long long)__popcll(m));
 }
 __global__ void k_s1_bloom_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, uint32_t nlines, int nwin, uint32_t mmask)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     uint32_t w, m;
     bloom_pos(keys[i], key_scramble(keys[i]), nlines, nwin, mmask, &w, &m);
@@ -545,7 +549,7 @@ __global__ void k_s1_bloom_set(const uint64_t *keys, uint32_t n, uint32_t *bloom
 //   k_reseed  (C) chains that ran out of candidates take new seeds, in chain order, from ONE descending cursor (reorder.cpp:652-668).
 __global__ void k_init_chains(S1Args s)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = harc_gid32();
     if (c >= s.K) return;
     ChainHdr h; memset(&h, 0, sizeof h);
     const uint32_t step = s.N / s.K;                             // reorder.cpp:490
@@ -1118,7 +1122,7 @@ template <int W> __global__ __launch_bounds__(256) void k_succ(S1Args s, uint2 *
     { const uint2 *const pt = reinterpret_cast<const uint2 *>(s.lds_tab + nm); for (int i = threadIdx.x; i < s.nprobe; i += 256) s_pinfo[i] = pt[i]; }
     for (int i = threadIdx.x; i < 4 * 2 * ROW; i += 256) s_rows[i] = 0u;
     __syncthreads();
-    const uint64_t g = (uint64_t)blockIdx.x * 4 + wv;
+    const uint64_t g = harc_bid() * 4 + wv;                      // (a wave per (read, orientation): 128 n work-items pass 2^32 at 33.5 M reads -- folded grid)
     if (g >= 2ull * n) return;
     const uint32_t r = (uint32_t)(g >> 1); const int o = (int)(g & 1);
     const int L = s.L;
@@ -1270,7 +1274,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             hnc += r.nc;
         }
         hnc = wave_sum_u32(hnc);
-        if (lane == 0 && hnc) { atomicAdd(&s.cstat[blockIdx.x].y, hnc); atomicAdd(&s.cstat[blockIdx.x].w, hnc); }
+        if (lane == 0 && hnc) { atomicAdd(&s.cstat_coop[blockIdx.x].y, hnc); atomicAdd(&s.cstat_coop[blockIdx.x].w, hnc); }
         return;
     }
     const long long dbg_t0 = (COOP && s.dbg) ? wall_clock64() : 0;
@@ -1830,8 +1834,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     if (COOP && lane == 0 && s.dbg) { const unsigned long long dt = (unsigned long long)(wall_clock64() - dbg_t0); atomicAdd(&s.dbg[9], 1ULL); atomicAdd(&s.dbg[10], dt); atomicMax(&s.dbg[11], dt); atomicAdd(&s.dbg[12], (unsigned long long)(nst)); }
     if (lane == 0 && s.dbg) { atomicAdd(&s.dbg[0], (unsigned long long)dbg_bins); atomicAdd(&s.dbg[1], (unsigned long long)dbg_iter); atomicAdd(&s.dbg[2], (unsigned long long)dbg_miss); atomicAdd(&s.dbg[3], (unsigned long long)dbg_surv); atomicAdd(&s.dbg[4], (unsigned long long)nst); atomicAdd(&s.dbg[5], (unsigned long long)dbg_batches); atomicMax(&s.dbg[6], (unsigned long long)dbg_iter); atomicMax(&s.dbg[7], (unsigned long long)dbg_surv); atomicMax(&s.dbg[8], (unsigned long long)dbg_bins); }
     if (lane == 0) {
-        if (COOP) { atomicAdd(&s.cstat[c].x, np); atomicAdd(&s.cstat[c].y, nc); atomicAdd(&s.cstat[c].z, nuse); atomicAdd(&s.cstat[c].w, ncu); }   // the helpers add to it too
-        else { cst.x += np; cst.y += nc; cst.z += nuse; cst.w += ncu; s.cstat[c] = cst; }
+        if (COOP) { atomicAdd(&s.cstat_coop[c].x, np); atomicAdd(&s.cstat_coop[c].y, nc); atomicAdd(&s.cstat_coop[c].z, nuse); atomicAdd(&s.cstat_coop[c].w, ncu); s.csteps[c].y += (uint32_t)nst; }   // the helpers add to it too
+        else { cst.x += np; cst.y += nc; cst.z += nuse; cst.w += ncu; s.cstat[c] = cst; s.csteps[c].x += (uint32_t)nst; }
         h.mode = 0;
         h.nsteps = (h.nsteps & 0xFFFF0000u) | (uint32_t)(T0 + nst);
         h.pad0 = ((uint32_t)lastp & 0xFFFFu) | (((uint32_t)spos & 0xFFu) << 16) | (widebits << 24);
@@ -1855,7 +1859,7 @@ __device__ __forceinline__ bool chain_owned(uint32_t c, uint32_t mod, uint32_t r
 // the seed a chain takes at the top of k_steps (reorder.cpp:650-688), on the ranks that do NOT walk it: same records, same counters
 __global__ void k_apply_seed(S1Args s)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = harc_gid32();
     if (c >= s.K || chain_owned(c, s.own_mod, s.own_rem)) return;
     ChainHdr h = s.hdr[c];
     if (!(h.flags & CH_ACTIVE) || !s.need[c]) return;
@@ -1884,7 +1888,7 @@ __global__ void k_apply_seed(S1Args s)
 __global__ void k_pack_chains(S1Args s, uint32_t *buf, uint32_t nper)
 {
     const uint32_t recw = 8u + 2u * (uint32_t)s.S;
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = harc_gid();
     if (gid >= (uint64_t)nper * recw) return;
     const uint32_t li = (uint32_t)(gid / recw), d = (uint32_t)(gid % recw);
     const uint32_t c = ((li >> 2) * s.own_mod + s.own_rem) * 4u + (li & 3u);
@@ -1896,7 +1900,7 @@ __global__ void k_unpack_chains(S1Args s, const uint32_t *buf, uint32_t nper)
 {
     const uint32_t recw = 8u + 2u * (uint32_t)s.S, p = blockIdx.y;
     if (p == s.own_rem) return;                                   // this rank's own chains are in place
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (blockIdx.y is the peer; K * (8 + 2 S) dwords < 2^24)
     if (gid >= (uint64_t)nper * recw) return;
     const uint32_t li = (uint32_t)(gid / recw), d = (uint32_t)(gid % recw);
     const uint32_t c = ((li >> 2) * s.own_mod + p) * 4u + (li & 3u);
@@ -2327,7 +2331,7 @@ __global__ __launch_bounds__(RESEED_NT) void k_reseed_mg(S1Args s, unsigned int 
 #define HARC_HUGEBIN 512u    // bins that start with more reads than this are compacted by a workgroup of 1024 threads (k_compact_huge), the others by a wave
 __global__ void k_huge_list(const uint32_t *sz, uint32_t nlarge, uint32_t *huge, unsigned int *nhuge)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = harc_gid32();
     if (b < nlarge && sz[b] > HARC_HUGEBIN) huge[atomicAdd(nhuge, 1u)] = b;
 }
 // A wave per bin walks a bin of 17 000 reads in 270 dependent passes while the chip idles: the kernel lasted as long as its largest bin
@@ -2354,7 +2358,7 @@ template <int W> __global__ __launch_bounds__(1024) void k_compact_huge(S1Args s
     // down to it (A = 0: the whole bin, as before).  A bin of 130 000 reads of a diverged repeat family was 127 dependent passes of this workgroup
     // every super-round -- the kernel lasts as long as its largest bin: 540 us per round, a seventh of the chain phase of configs[2] with repeats.
     uint32_t A = 0;
-    for (uint32_t T = 4096; T < cnt; T *= 4) {
+    for (uint32_t T = 4096; T < cnt && T <= (1u << 30); T *= 4) {      // (T *= 4 would wrap to 0 beyond 2^30 and never end)
         uint32_t u = 0;
         for (uint32_t pos = cnt - T; pos < cnt; pos += 1024) {
             if (pos + t < cnt) { const uint32_t rid = ids[pos + t]; u += ((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL) ? 0u : 1u; }
@@ -2427,12 +2431,18 @@ template <int W> __global__ __launch_bounds__(64) void k_compact_bins(S1Args s, 
 }
 
 // ------------------------------------------------------------------------------------------------ finalisation
-__global__ void k_chain_counts(const ChainHdr *hdr, const uint4 *cstat, const uint2 *cst2, uint32_t K, uint32_t *nmain, uint32_t *nsing, unsigned long long *stats)
+__global__ void k_chain_counts(const ChainHdr *hdr, const uint4 *cstat, const uint4 *cstat_coop, const uint2 *csteps, const uint2 *cst2, uint32_t K, uint32_t *nmain, uint32_t *nsing, unsigned long long *stats)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t np = 0, nc = 0, nu = 0, um = 0, cf = 0, ncs = 0;
-    if (c < K) { nmain[c] = hdr[c].n_main; nsing[c] = hdr[c].n_sing; const uint4 st = cstat[c]; np = st.x; nc = st.y; nu = st.z; ncs = st.w; const uint2 q = cst2[c]; um = q.x; cf = q.y; }
+    const uint32_t c = harc_gid32();
+    uint32_t np = 0, nc = 0, nu = 0, um = 0, cf = 0, ncs = 0, cnc = 0, cnu = 0, cncs = 0, sd = 0, sc = 0;
+    if (c < K) {
+        nmain[c] = hdr[c].n_main; nsing[c] = hdr[c].n_sing;
+        const uint4 st = cstat[c], sx = cstat_coop[c]; const uint2 q = cst2[c], w = csteps[c];
+        np = st.x + sx.x; nc = st.y + sx.y; nu = st.z + sx.z; ncs = st.w + sx.w; um = q.x; cf = q.y;
+        cnc = sx.y; cnu = sx.z; cncs = sx.w; sd = w.x; sc = w.y;
+    }
     np = wave_sum_u32(np); nc = wave_sum_u32(nc); nu = wave_sum_u32(nu); um = wave_sum_u32(um); cf = wave_sum_u32(cf); ncs = wave_sum_u32(ncs);
+    cnc = wave_sum_u32(cnc); cnu = wave_sum_u32(cnu); cncs = wave_sum_u32(cncs); sd = wave_sum_u32(sd); sc = wave_sum_u32(sc);
     if ((threadIdx.x & 63) == 0) {
         if (um) atomicAdd(&stats[ST_UNMATCHED], (unsigned long long)um);
         if (cf) atomicAdd(&stats[ST_CONFLICTS], (unsigned long long)cf);
@@ -2440,6 +2450,11 @@ __global__ void k_chain_counts(const ChainHdr *hdr, const uint4 *cstat, const ui
         if (nc) atomicAdd(&stats[ST_CANDS], (unsigned long long)nc);
         if (nu) atomicAdd(&stats[ST_USEFUL], (unsigned long long)nu);
         if (ncs) atomicAdd(&stats[ST_CANDS_SEQ], (unsigned long long)ncs);
+        if (cnc) atomicAdd(&stats[ST_COOP_CANDS], (unsigned long long)cnc);
+        if (cnu) atomicAdd(&stats[ST_COOP_USEFUL], (unsigned long long)cnu);
+        if (cncs) atomicAdd(&stats[ST_COOP_CANDS_SEQ], (unsigned long long)cncs);
+        if (sd) atomicAdd(&stats[ST_DENSE_STEPS], (unsigned long long)sd);
+        if (sc) atomicAdd(&stats[ST_COOP_STEPS], (unsigned long long)sc);
     }
 }
 // per-chain streams concatenated in chain order (reorder.cpp:778-821)
@@ -2483,9 +2498,10 @@ template <int W> __global__ void k_orient(const uint64_t *reads, const uint32_t 
 {
     constexpr int RPW = 64 / W;                                   // reads per wave
     const int lane = threadIdx.x & 63, rl = lane / W, w = lane % W;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t i = wave * RPW + (uint32_t)rl;
-    const bool on = rl < RPW && i < m;
+    const uint64_t wave = harc_gid() >> 6;                       // (64-bit: W x m work-items pass 2^32 from a billion reads of 128 bases on; the grid is folded into rows)
+    const uint64_t i64 = wave * RPW + (uint64_t)rl;
+    const uint32_t i = (uint32_t)i64;
+    const bool on = rl < RPW && i64 < m;
     uint64_t mine = 0; bool rev = false;
     if (on) {
         const uint32_t rid = order[i];
@@ -2527,7 +2543,6 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     PoolScope scope(c);                                           // temporaries go on every way out
     uint64_t *k1 = nullptr; uint32_t *h0 = nullptr, *b0 = nullptr, *bs = nullptr;
     RC_TRY(dalloc(c, &k1, n)); RC_TRY(dalloc(c, &h0, n)); RC_TRY(dalloc(c, &b0, n)); RC_TRY(dalloc(c, &bs, n));
-    const unsigned g = (n + 255) / 256;
     // top bits the sort looks at: log2(n) + 8, in whole radix digits, all 64 from 2^36 keys on (HARC_AMD_SORT_BITS forces a count: tests use 8,
     // where nearly every stretch is mixed, and 64)
     unsigned sbits = 64;
@@ -2537,27 +2552,27 @@ int harc_dict_build(harc_amd_ctx *c, DictDev *d, uint64_t *keys, uint32_t *ids, 
     RC_TRY(dalloc(c, &mixed, MIXED_MAX)); RC_TRY(dalloc(c, &mmeta, 4));
     RC_TRY(dalloc(c, &k2, n));                                    // the sort's output on the top bits; then (k_bin_starts) what the placement's max-scan starts from
     uint64_t *const k2v = k2;
-    hipLaunchKernelGGL(k_scramble_keys, dim3(g), dim3(256), 0, c->stream, keys, n, sbits < 64 ? sbits : 0u);
+    hipLaunchKernelGGL(k_scramble_keys, harc_grid256(n), dim3(256), 0, c->stream, keys, n, sbits < 64 ? sbits : 0u);
     uint32_t nbins = 0;
     for (;;) {
         HIP_TRY(hipMemsetAsync(mmeta, 0, 16, c->stream));
         HIP_TRY(hipMemsetAsync(d->d_nbins, 0, 8, c->stream));
         if (sbits < 64) {
             RC_TRY(prim_sort_pairs_u64_u32(c, keys, k2, ids, d->ids, n, sbits));       // stable: ids ascending inside a bin (reorder.cpp:372-384)
-            hipLaunchKernelGGL(k_mixed_find, dim3(g), dim3(256), 0, c->stream, (const uint64_t *)k2, n, sbits, k1, mixed, mmeta);
+            hipLaunchKernelGGL(k_mixed_find, harc_grid256(n), dim3(256), 0, c->stream, (const uint64_t *)k2, n, sbits, k1, mixed, mmeta);
             hipLaunchKernelGGL(k_mixed_own, dim3(MIXED_MAX / 256), dim3(256), 0, c->stream, (const uint64_t *)k1, (int)(64 - sbits), mixed, mmeta);
             hipLaunchKernelGGL(k_mixed_fix, dim3(MIXED_MAX / 256), dim3(256), 0, c->stream, k1, d->ids, n, (int)(64 - sbits), (const uint32_t *)mixed, mmeta);
         } else RC_TRY(prim_sort_pairs_u64_u32(c, keys, k1, ids, d->ids, n, 64));
-        hipLaunchKernelGGL(k_mark_heads, dim3(g), dim3(256), 0, c->stream, k1, n, h0);
+        hipLaunchKernelGGL(k_mark_heads, harc_grid256(n), dim3(256), 0, c->stream, k1, n, h0);
         RC_TRY(prim_excl_scan_u32(c, h0, b0, n));
-        hipLaunchKernelGGL(k_bin_starts, dim3(g), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins, (const uint64_t *)k1, d->cap, k2v);
+        hipLaunchKernelGGL(k_bin_starts, harc_grid256(n), dim3(256), 0, c->stream, h0, b0, n, bs, d->d_nbins, (const uint64_t *)k1, d->cap, k2v);
         unsigned int mm[2] = { 0, 0 };
         HIP_TRY(hipMemcpyAsync(&nbins, d->d_nbins, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(mm, mmeta, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[index] sort on the top %u bits: %u places where different keys share them%s\n", sbits, mm[0], mm[1] ? " -- too many or too long, sorting on all bits" : "");
         if (!mm[1] || sbits == 64) break;
-        hipLaunchKernelGGL(k_rotate_keys, dim3(g), dim3(256), 0, c->stream, keys, n, 64u - sbits);      // back to the scrambled keys as they are
+        hipLaunchKernelGGL(k_rotate_keys, harc_grid256(n), dim3(256), 0, c->stream, keys, n, 64u - sbits);      // back to the scrambled keys as they are
         sbits = 64;
     }
     // the placement clears the table on its way when the gaps between bins are short (fill); a table of few bins is cleared here
@@ -2615,19 +2630,35 @@ static uint32_t auto_chains(uint32_t N, int reads_per_chain)
 
 // Everything stage1_run_w owns besides pool memory: released on every way out.  The launches of the dominant kernel are timed with a
 // fixed ring of event pairs (params.profile = 1), not with two new events per launch.
-struct S1Resources {
+// HIP-event pairs around the launches of ONE kernel (params.profile): a ring of 64 pairs, a pair's previous use read before it is recorded again
+struct EventRing {
     static constexpr int RING = 64;
+    hipEvent_t ring[RING][2];
+    int ring_used = 0; uint64_t ring_next = 0; double ms = 0; uint64_t launches = 0;
+    EventRing() { for (int i = 0; i < RING; i++) ring[i][0] = ring[i][1] = nullptr; }
+    ~EventRing() { for (int i = 0; i < ring_used; i++) { (void)hipEventDestroy(ring[i][0]); (void)hipEventDestroy(ring[i][1]); } }
+    // the pair for the next launch; its previous use (RING launches ago) is read first
+    int next_pair(hipEvent_t **pair)
+    {
+        const int k = (int)(ring_next % RING);
+        if (k >= ring_used) { HIP_TRY(hipEventCreate(&ring[k][0])); HIP_TRY(hipEventCreate(&ring[k][1])); ring_used = k + 1; }
+        else RC_TRY(collect(k));
+        ring_next++; launches++;
+        *pair = ring[k];
+        return HARC_AMD_OK;
+    }
+    int collect(int k) { float x = 0; HIP_TRY(hipEventSynchronize(ring[k][1])); HIP_TRY(hipEventElapsedTime(&x, ring[k][0], ring[k][1])); ms += x; return HARC_AMD_OK; }
+    int collect_all() { const uint64_t n = ring_next < (uint64_t)RING ? ring_next : (uint64_t)RING; for (uint64_t i = 0; i < n; i++) RC_TRY(collect((int)i)); ring_next = 0; return HARC_AMD_OK; }
+};
+struct S1Resources {
     hipEvent_t e[3] = { nullptr, nullptr, nullptr };
     hipEvent_t eb[2] = { nullptr, nullptr };
-    hipEvent_t ring[RING][2];
-    int ring_used = 0; uint64_t ring_next = 0; double ms = 0;
+    EventRing dense, coop;                                        // the main kernel's launches; the cooperative kernel's (walks that reach a bin of more than HARC_LARGEBIN reads)
     unsigned long long *h_stats = nullptr;
-    S1Resources() { for (int i = 0; i < RING; i++) ring[i][0] = ring[i][1] = nullptr; }
     ~S1Resources()
     {
         for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x);
         for (hipEvent_t x : eb) if (x) (void)hipEventDestroy(x);
-        for (int i = 0; i < ring_used; i++) { (void)hipEventDestroy(ring[i][0]); (void)hipEventDestroy(ring[i][1]); }
         if (h_stats) (void)hipHostFree(h_stats);
     }
     int init()
@@ -2637,18 +2668,6 @@ struct S1Resources {
         HIP_TRY(hipHostMalloc((void **)&h_stats, (ST_N + HARC_COOPCNT + 8 + 1) * 8));      // statistics, cooperative-walk counters, replica digest, k_reseed_mg's timeout flag
         return HARC_AMD_OK;
     }
-    // the pair for the next launch; its previous use (RING launches ago) is read first
-    int next_pair(hipEvent_t **pair)
-    {
-        const int k = (int)(ring_next % RING);
-        if (k >= ring_used) { HIP_TRY(hipEventCreate(&ring[k][0])); HIP_TRY(hipEventCreate(&ring[k][1])); ring_used = k + 1; }
-        else RC_TRY(collect(k));
-        ring_next++;
-        *pair = ring[k];
-        return HARC_AMD_OK;
-    }
-    int collect(int k) { float x = 0; HIP_TRY(hipEventSynchronize(ring[k][1])); HIP_TRY(hipEventElapsedTime(&x, ring[k][0], ring[k][1])); ms += x; return HARC_AMD_OK; }
-    int collect_all() { const uint64_t n = ring_next < (uint64_t)RING ? ring_next : (uint64_t)RING; for (uint64_t i = 0; i < n; i++) RC_TRY(collect((int)i)); ring_next = 0; return HARC_AMD_OK; }
 };
 
 template <int W> static int stage1_run_w(harc_amd_ctx *c)
@@ -2733,7 +2752,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         PoolScope kscope(c);
         uint64_t *kboth[2] = { nullptr, nullptr }; uint32_t *i0 = nullptr;
         RC_TRY(dalloc(c, &kboth[0], N)); RC_TRY(dalloc(c, &kboth[1], N)); RC_TRY(dalloc(c, &i0, N));
-        hipLaunchKernelGGL((k_keygen2<W>), dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[0], 2 * (P.dict_end[0] - P.dict_start[0] + 1),
+        hipLaunchKernelGGL((k_keygen2<W>), harc_grid256(N), dim3(256), 0, c->stream, c->d_reads, N, 2 * P.dict_start[0], 2 * (P.dict_end[0] - P.dict_start[0] + 1),
                            2 * P.dict_start[1], 2 * (P.dict_end[1] - P.dict_start[1] + 1), kboth[0], kboth[1], i0);
         ilap("bitmaps allocated, keys made");
         for (int l = 0; l < 2; l++) {
@@ -2743,19 +2762,19 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
                 PoolScope bscope(c);
                 uint64_t *pa = nullptr, *pb = nullptr; RC_TRY(dalloc(c, &pa, (size_t)N + 1)); RC_TRY(dalloc(c, &pb, (size_t)N + 1));
                 const uint64_t nwords = (uint64_t)bloom_lines * 16;
-                hipLaunchKernelGGL(k_s1_bloom_keys, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, bloom_lines, bloom_nwin[l], bloom_mmask, pa);
+                hipLaunchKernelGGL(k_s1_bloom_keys, harc_grid256(N), dim3(256), 0, c->stream, (const uint64_t *)k0, N, bloom_lines, bloom_nwin[l], bloom_mmask, pa);
                 RC_TRY(harc_bitmap_from_items(c, pa, pb, N, nwords, d_bloom[l]));
                 if (getenv("HARC_AMD_S1BLOOM_VERIFY")) {            // tests: word for word what the atomics build
                     uint32_t *ref = nullptr; unsigned long long *nd = nullptr, hnd = 0;
                     RC_TRY(dalloc(c, &ref, (size_t)nwords)); RC_TRY(dalloc(c, &nd, 1));
                     HIP_TRY(hipMemsetAsync(ref, 0, (size_t)nwords * 4, c->stream)); HIP_TRY(hipMemsetAsync(nd, 0, 8, c->stream));
-                    hipLaunchKernelGGL(k_s1_bloom_set, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, ref, bloom_lines, bloom_nwin[l], bloom_mmask);
-                    hipLaunchKernelGGL(k_s1_bloom_diff, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)ref, (const uint32_t *)d_bloom[l], nwords, nd);
+                    hipLaunchKernelGGL(k_s1_bloom_set, harc_grid256(N), dim3(256), 0, c->stream, (const uint64_t *)k0, N, ref, bloom_lines, bloom_nwin[l], bloom_mmask);
+                    hipLaunchKernelGGL(k_s1_bloom_diff, harc_grid256(nwords), dim3(256), 0, c->stream, (const uint32_t *)ref, (const uint32_t *)d_bloom[l], nwords, nd);
                     HIP_TRY(hipMemcpyAsync(&hnd, nd, 8, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));
                     if (hnd) { harc_set_error("stage I bitmap built by tiles differs from the one built with atomics in %llu words", hnd); return HARC_AMD_EINTERNAL; }
                 }
-            } else if (bloom_lines) hipLaunchKernelGGL(k_s1_bloom_set, dim3((N + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)k0, N, d_bloom[l], bloom_lines, bloom_nwin[l], bloom_mmask);
+            } else if (bloom_lines) hipLaunchKernelGGL(k_s1_bloom_set, harc_grid256(N), dim3(256), 0, c->stream, (const uint64_t *)k0, N, d_bloom[l], bloom_lines, bloom_nwin[l], bloom_mmask);
             ilap("bitmap built");
             RC_TRY(harc_dict_build(c, &dict[l], k0, i0, N, (unsigned)kbits));
             ilap("table built");
@@ -2784,11 +2803,11 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         uint32_t *sz = nullptr; uint64_t *moff = nullptr;
         RC_TRY(dalloc(c, &d_largetab, nlarge)); RC_TRY(dalloc(c, &sz, (size_t)nlarge + 1)); RC_TRY(dalloc(c, &moff, (size_t)nlarge + 1));
         HIP_TRY(hipMemsetAsync(sz + nlarge, 0, 4, c->stream));
-        hipLaunchKernelGGL(k_large_sizes, dim3((nlarge + 255) / 256), dim3(256), 0, c->stream, (const unsigned long long *)d_large, nlarge, dict[0].slots, dict[1].slots, sz);
+        hipLaunchKernelGGL(k_large_sizes, harc_grid256(nlarge), dim3(256), 0, c->stream, (const unsigned long long *)d_large, nlarge, dict[0].slots, dict[1].slots, sz);
         d_sz0 = sz;
         RC_TRY(dalloc(c, &d_huge, (size_t)nlarge + 1)); RC_TRY(dalloc(c, &d_nhuge, 4));
         HIP_TRY(hipMemsetAsync(d_nhuge, 0, 16, c->stream));
-        hipLaunchKernelGGL(k_huge_list, dim3((nlarge + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)sz, nlarge, d_huge, d_nhuge);
+        hipLaunchKernelGGL(k_huge_list, harc_grid256(nlarge), dim3(256), 0, c->stream, (const uint32_t *)sz, nlarge, d_huge, d_nhuge);
         HIP_TRY(hipMemcpyAsync(&nhuge, d_nhuge, 4, hipMemcpyDeviceToHost, c->stream));
         RC_TRY(prim_excl_scan_u32_to_u64(c, sz, moff, (size_t)nlarge + 1));
         uint64_t mtotal = 0;
@@ -2843,6 +2862,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     RC_TRY(dalloc(c, &a.pg_rec, pg_max * 64)); RC_TRY(dalloc(c, &a.pg_hdr, pg_max)); RC_TRY(dalloc(c, &a.pg_cur, (size_t)K + 1)); RC_TRY(dalloc(c, &a.pg_count, 4));
     RC_TRY(dalloc(c, &a.cursor, 1)); RC_TRY(dalloc(c, &a.stats, ST_N)); RC_TRY(dalloc(c, &a.coopcnt, HARC_COOPCNT)); HIP_TRY(hipMemsetAsync(a.coopcnt, 0, HARC_COOPCNT * 8, c->stream));
     RC_TRY(dalloc(c, &a.cstat, K)); HIP_TRY(hipMemsetAsync(a.cstat, 0, (size_t)K * 16, c->stream));
+    RC_TRY(dalloc(c, &a.cstat_coop, K)); HIP_TRY(hipMemsetAsync(a.cstat_coop, 0, (size_t)K * 16, c->stream)); RC_TRY(dalloc(c, &a.csteps, K)); HIP_TRY(hipMemsetAsync(a.csteps, 0, (size_t)K * 8, c->stream));
     RC_TRY(dalloc(c, &a.dbg, 48)); HIP_TRY(hipMemsetAsync(a.dbg, 0, 48 * 8, c->stream));
     unsigned long long *const dbg_ptr = a.dbg;
     if (!getenv("HARC_AMD_TRACE")) a.dbg = nullptr;
@@ -2879,7 +2899,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         if (want && N && quad && !cm && a.lazy && P.maxsearch >= (int)HARC_LARGEBIN && P.thresh <= 127 && a.nprobe <= 4095 && P.maxmatch <= 255 && sbytes < tot / 8) {
             uint2 *sp = nullptr;
             RC_TRY(dalloc(c, &sp, (size_t)N * 2 * HARC_SUCC_N));
-            hipLaunchKernelGGL((k_succ<W>), dim3((unsigned)(((uint64_t)N * 2 + 3) / 4)), dim3(256), succ_lds_bytes(W, P.maxmatch, a.nprobe), c->stream, a, sp, N);
+            hipLaunchKernelGGL((k_succ<W>), harc_fold256(((uint64_t)N * 2 + 3) / 4), dim3(256), succ_lds_bytes(W, P.maxmatch, a.nprobe), c->stream, a, sp, N);
             HIP_TRY(hipGetLastError());
             a.succ = sp;
             if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] successor lists of %u reads x 2 orientations (%.1f MB)\n", N, (double)sbytes / 1e6);
@@ -2994,7 +3014,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         for (int r = 0; r < batch; r++) {
             hipEvent_t *pair = nullptr;
             if (cm) hipLaunchKernelGGL(k_apply_seed, dim3(nblk), dim3(256), 0, c->stream, a);          // the seeds of the chains other ranks walk
-            if (prof) { RC_TRY(R.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }
+            if (prof) { RC_TRY(R.dense.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }
             if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
             else if (grp) {
                 if constexpr (W == 4 || W == 5) {
@@ -3013,13 +3033,15 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (prof) HIP_TRY(hipEventRecord(pair[1], c->stream));
             // the steps that have to scan a large bin (none without such bins: the launch is skipped)
             if (nlarge) {
+                if (prof) { RC_TRY(R.coop.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }      // timed apart from the main kernel: its scans stream mirrors from L2, another ceiling
                 if (coop_waves == 1) hipLaunchKernelGGL((k_steps<W, true, true, false, 1>), dim3(K), dim3(64), lds_bytes_coop, c->stream, a);
                 else if (coop_waves == 2) hipLaunchKernelGGL((k_steps<W, true, true, false, 2>), dim3(K), dim3(128), lds_bytes_coop, c->stream, a);
                 else hipLaunchKernelGGL((k_steps<W, true, true>), dim3(K), dim3(256), lds_bytes_coop, c->stream, a);
+                if (prof) HIP_TRY(hipEventRecord(pair[1], c->stream));
             }
             if (cm) {   // ONE all-gather per super-round: header + walked steps of every chain, from the rank that walked it
                 const uint64_t tot = (uint64_t)x_nper * (8 + 2 * (uint64_t)nsteps);
-                hipLaunchKernelGGL(k_pack_chains, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, a, x_send, x_nper);
+                hipLaunchKernelGGL(k_pack_chains, harc_grid256(tot), dim3(256), 0, c->stream, a, x_send, x_nper);
                 const void *sp[1] = { x_send }; void *rp[1] = { x_recv };
                 const size_t *sop[1] = { x_so.data() }, *sbp[1] = { x_sb.data() }, *rop[1] = { x_ro.data() }, *rbp[1] = { x_rb.data() };
                 RC_TRY(cm->alltoallv(c, 1, sp, sop, sbp, rp, rop, rbp));
@@ -3111,7 +3133,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     uint32_t *nmain = nullptr, *nsing = nullptr, *bmain = nullptr, *bsing = nullptr;
     RC_TRY(dalloc(c, &nmain, (size_t)K + 1)); RC_TRY(dalloc(c, &nsing, (size_t)K + 1)); RC_TRY(dalloc(c, &bmain, (size_t)K + 1)); RC_TRY(dalloc(c, &bsing, (size_t)K + 1));
     HIP_TRY(hipMemsetAsync(nmain, 0, ((size_t)K + 1) * 4, c->stream)); HIP_TRY(hipMemsetAsync(nsing, 0, ((size_t)K + 1) * 4, c->stream));
-    hipLaunchKernelGGL(k_chain_counts, dim3(nblk), dim3(256), 0, c->stream, a.hdr, a.cstat, (const uint2 *)a.cst2, K, nmain, nsing, a.stats);
+    hipLaunchKernelGGL(k_chain_counts, dim3(nblk), dim3(256), 0, c->stream, a.hdr, a.cstat, (const uint4 *)a.cstat_coop, (const uint2 *)a.csteps, (const uint2 *)a.cst2, K, nmain, nsing, a.stats);
     RC_TRY(prim_excl_scan_u32(c, nmain, bmain, (size_t)K + 1));
     RC_TRY(prim_excl_scan_u32(c, nsing, bsing, (size_t)K + 1));
     uint32_t M = 0, S = 0; const unsigned long long nlog = N;
@@ -3150,8 +3172,11 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1)); c->C.index_ms = ms;
     HIP_TRY(hipEventElapsedTime(&ms, e1, e2)); c->C.chain_ms = ms;
-    RC_TRY(R.collect_all());
-    c->C.propose_ms = R.ms;
+    RC_TRY(R.dense.collect_all()); RC_TRY(R.coop.collect_all());
+    c->C.propose_ms = R.dense.ms;
+    c->C.coop_ms = R.coop.ms; c->C.coop_launches = R.coop.launches;
+    c->C.coop_useful_probes = h_stats[ST_COOP_USEFUL]; c->C.coop_candidates_seq = h_stats[ST_COOP_CANDS_SEQ]; c->C.coop_candidates = h_stats[ST_COOP_CANDS];
+    c->C.coop_steps = h_stats[ST_COOP_STEPS]; c->C.dense_steps = h_stats[ST_DENSE_STEPS];
 #ifdef HARC_TIMING
     {
         unsigned long long d[16];
@@ -3201,7 +3226,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
 template <int W> static int orient_w(harc_amd_ctx *c, const uint64_t *reads, const uint32_t *order, const uint8_t *rc, uint32_t m, uint64_t *out)
 {
     if (!m) return HARC_AMD_OK;
-    { const uint32_t per_block = 4u * (64u / W); hipLaunchKernelGGL((k_orient<W>), dim3((m + per_block - 1) / per_block), dim3(256), 0, c->stream, reads, order, rc, m, c->P.readlen, out); }
+    { const uint32_t per_block = 4u * (64u / W); hipLaunchKernelGGL((k_orient<W>), harc_fold256(((uint64_t)m + per_block - 1) / per_block), dim3(256), 0, c->stream, reads, order, rc, m, c->P.readlen, out); }
     HIP_TRY(hipGetLastError());
     return HARC_AMD_OK;
 }

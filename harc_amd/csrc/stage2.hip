@@ -101,13 +101,13 @@ __global__ void k_cand3_from2(const uint64_t *reads2, const uint32_t *gather, ui
 }
 __global__ void k_cand_order(const uint32_t *order_s, uint32_t S, uint32_t T, uint32_t *out)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= T) return;
     out[i] = i < S ? order_s[i] : i - S;                          // encoder.cpp:865-870
 }
 __global__ void k_key3(const uint64_t *cand3, uint32_t T, int W3, int off, int nbits, uint64_t *keys, uint32_t *ids)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= T) return;
     const uint64_t *r = cand3 + (size_t)i * W3;
     const int wi = off >> 6, sh = off & 63;
@@ -127,7 +127,7 @@ __global__ void k_count_big_bins(const HashSlot *slots, uint64_t cap, uint32_t m
 // contig heads: flag '0', shard starts (encoder.cpp:171-180) -- step 1
 __global__ void k_heads1(const uint8_t *flag, uint32_t M, uint32_t q, uint8_t *head, uint32_t *hidx)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= M) return;
     const uint8_t h = (flag[i] == '0' || (i % q) == 0) ? 1 : 0;
     head[i] = h; hidx[i] = h ? i : 0;
@@ -135,7 +135,7 @@ __global__ void k_heads1(const uint8_t *flag, uint32_t M, uint32_t q, uint8_t *h
 // step 2: a contig is cut once it holds 10,000,001 reads (encoder.cpp:226 `list_size>10000000`)
 __global__ void k_heads2(uint32_t M, uint8_t *head, const uint32_t *hmax, uint32_t *hidx)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= M) return;
     const uint32_t r = i - hmax[i];
     if (r > 0 && (r % 10000001u) == 0) head[i] = 1;
@@ -143,13 +143,13 @@ __global__ void k_heads2(uint32_t M, uint8_t *head, const uint32_t *hmax, uint32
 }
 __global__ void k_col_steps(const uint8_t *head, const uint8_t *pos, uint32_t M, int L, uint64_t *d)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= M) return;
     d[i] = head[i] ? (i == 0 ? 0 : (uint64_t)L) : (uint64_t)pos[i];
 }
 __global__ void k_contig_heads(const uint8_t *head, const uint32_t *cid, uint32_t M, uint32_t *chead)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= M) return;
     if (head[i]) chead[cid[i]] = i;
 }
@@ -157,7 +157,7 @@ __global__ void k_contig_heads(const uint8_t *head, const uint32_t *cid, uint32_
 // per contig: end column, and bit 63 = "no realignment" (the last contig of a shard, encoder.cpp:438-441)
 __global__ void k_contig_info(S2Args s, unsigned long long *cinfo)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = harc_gid32();
     if (k >= s.nC) return;
     const bool lastc = (k + 1 == s.nC) || (s.chead[k + 1] % s.q) == 0;
     const unsigned long long cend = (k + 1 == s.nC) ? s.total : s.gstart[s.chead[k + 1]];
@@ -176,7 +176,7 @@ __global__ void k_contig_info(S2Args s, unsigned long long *cinfo)
 // first and last read that touch tile t (a binary search per tile here, not two dependent ones at the top of every workgroup)
 __global__ void k_consensus_tiles(S2Args s, uint32_t ntiles, uint32_t *tlo, uint32_t *thi)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = harc_gid32();
     if (t >= ntiles) return;
     const uint64_t X0 = (uint64_t)(t + s.tile_base) * CTILE, X1 = X0 + CTILE < s.total ? X0 + CTILE : s.total;
     thi[t] = (uint32_t)ub_le(s.gstart, (long long)s.M, X1 - 1);             // last read starting inside or before the tile (every column is covered: >= 0)
@@ -300,7 +300,7 @@ __device__ __forceinline__ bool dict_lookup_b(const HashSlot *tab, uint64_t cap,
 }
 __global__ void k_bloom_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, int shift)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     const uint64_t b = mix64(keys[i] ^ 0x9E3779B97F4A7C15ULL) >> shift;
     atomicOr(&bloom[b >> 5], 1u << (b & 31));
@@ -341,7 +341,7 @@ __device__ __forceinline__ void bloom4_pos(uint64_t fk, uint32_t minz, int nwin,
 }
 __global__ void k_bloom4_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, int lbits, int nwin, int l, int nb)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     const uint64_t k = keys[i];
     uint64_t f = 0, r = 0;                                        // the k-mer and its reverse complement in the 2-bit code
@@ -361,7 +361,7 @@ __global__ void k_bloom4_set(const uint64_t *keys, uint32_t n, uint32_t *bloom, 
 // candidates: reads with N on a 150-bp set) is built from sorted items instead of with random atomics; keys with an N become items that set nothing
 __global__ void k_bloom4_items(const uint64_t *keys, uint32_t n, int lbits, int nwin, int l, int nb, uint32_t skip_tile, uint64_t *items)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     const uint64_t k = keys[i];
     uint64_t f = 0, r = 0; bool hasn = false;
@@ -380,7 +380,7 @@ __global__ void k_bloom4_items(const uint64_t *keys, uint32_t n, int lbits, int 
 }
 __global__ void k_words_differ(const uint32_t *a, const uint32_t *b, uint64_t nwords, unsigned long long *ndiff)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = harc_gid();
     const unsigned long long m = __ballot(i < nwords && a[i] != b[i]);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(ndiff, (unsigned long long)__popcll(m));
 }
@@ -625,14 +625,14 @@ template <int W> __global__ __launch_bounds__(256) void k_realign_propose(S2Args
 #define EV_DONE 0xFFFFFFFEu     // lastver of an event that never needs to look again (bins within maxsearch: the window never closes)
 __global__ void k_ev_key_tuple(const uint4 *ev, uint32_t nev, uint64_t *key, uint32_t *idx)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= nev) return;
     const uint4 e = ev[i];
     key[i] = (uint64_t)e.x | ((uint64_t)e.y << 32); idx[i] = i;
 }
 __global__ void k_ev_key_bin(const uint4 *ev, const uint32_t *idx, uint32_t nev, uint64_t *key)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= nev) return;
     const uint4 e = ev[idx[i]];
     key[i] = ((uint64_t)(e.x & 1u) << 32) | e.z;                  // (dictionary, first id index of the bin)
@@ -640,7 +640,7 @@ __global__ void k_ev_key_bin(const uint4 *ev, const uint32_t *idx, uint32_t nev,
 // the events once more in (bin, tuple) order: a look starts with its event, and through perm[] that was two dependent round trips
 __global__ void k_ev_gather(const uint4 *ev, const uint32_t *perm, uint32_t nev, uint4 *out)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i < nev) out[i] = ev[perm[i]];
 }
 // one wave per event: the L columns of its window (forward, or reverse-complemented) as W3 words of the candidates' 3-bit code.  One lane per base
@@ -682,13 +682,13 @@ __global__ void k_ev_gather_win(const uint64_t *win, const uint32_t *perm, uint3
 }
 __global__ void k_ev_heads(const uint64_t *key, uint32_t nev, uint32_t *head)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= nev) return;
     head[i] = (i > 0 && key[i] != key[i - 1]) ? i : 0u;          // max-scan -> first position of the bin's events
 }
 __global__ void k_ev_rank(uint32_t *seg, uint32_t nev, unsigned int *maxrank)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     uint32_t r = 0;
     if (i < nev) { r = i - seg[i]; seg[i] = r; }
     for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(r, o, 64); r = x > r ? x : r; }
@@ -717,7 +717,7 @@ __global__ void k_ev_rank(uint32_t *seg, uint32_t nev, unsigned int *maxrank)
 // marked for another look); the pass that ends it changes nothing, so it saw the truth.
 __global__ void k_bestbin_refresh(const unsigned long long *best, const uint32_t *ids0, const uint32_t *ids1, uint32_t T, unsigned long long *bb0, unsigned long long *bb1)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= T) return;
     bb0[i] = best[ids0[i]]; bb1[i] = best[ids1[i]];
 }
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256) void k_realign_chase(S2Args s, uint32_t nev, u
 __global__ void k_ev_validate(S2Args s, uint32_t nact, const uint32_t *order2, const uint32_t *perm, const uint32_t *rank, uint32_t rhi, uint32_t *estart, const unsigned long long *binmin0,
                               const unsigned long long *binmin1, uint32_t *lastpass, uint32_t pass, uint32_t T1, uint32_t *list, unsigned int *nlist)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = harc_gid32();
     bool look = false; uint32_t ei = 0;
     if (k < nact) {
         ei = order2 ? order2[k] : k;
@@ -1143,7 +1143,7 @@ template <int NW> __global__ __launch_bounds__(256) void k_realign_block(S2Args 
 // the first event of every bin in (bin, tuple) order: the chaser starts a wave per BIN, not one per event that finds out it is not a bin's first
 __global__ void k_ev_firsts(const uint32_t *rank, uint32_t nev, uint32_t *list, unsigned int *nlist)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     const bool first = i < nev && rank[i] == 0;
     const unsigned long long m = __ballot(first);
     if (m) {
@@ -1159,7 +1159,7 @@ __global__ void k_ev_firsts(const uint32_t *rank, uint32_t nev, uint32_t *list, 
 // that leave at once cost 0.5 ms per pass, and the first ranges take dozens of passes)
 __global__ void k_ev_range_keys(const uint32_t *rank, uint32_t nev, uint32_t r0, uint64_t *key, uint32_t *pos, unsigned int *hist)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     const bool in = i < nev;
     uint32_t k = 0xFFFFFFFFu;
     if (in) {
@@ -1179,14 +1179,14 @@ __global__ void k_ev_range_keys(const uint32_t *rank, uint32_t nev, uint32_t r0,
 }
 __global__ void k_ev_seglen(const uint32_t *rank, uint32_t nev, uint32_t *seglen)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= nev) return;
     if (i + 1 == nev || rank[i + 1] == 0) seglen[i - rank[i]] = rank[i] + 1;      // written at the bin's first position
 }
 
 __global__ void k_acc_flags(const unsigned long long *best, uint32_t T, uint32_t *flag)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= T) return;
     flag[i] = best[i] != TUPLE_NONE ? 1u : 0u;
 }
@@ -1194,7 +1194,7 @@ __global__ void k_acc_flags(const unsigned long long *best, uint32_t T, uint32_t
 // the order in which one bin scan inserts them, encoder.cpp:293-317)
 __global__ void k_acc_compact(const unsigned long long *best, const uint32_t *rank, uint32_t T, uint32_t A, uint64_t *tup, uint32_t *rid)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= T) return;
     if (best[i] != TUPLE_NONE) { const uint32_t at = A - 1 - rank[i]; tup[at] = best[i]; rid[at] = i; }
 }
@@ -1207,7 +1207,7 @@ struct FinalArrays { uint32_t *ref; uint8_t *kind; uint64_t *g; };   // kind 0 o
 // its neighbours ask for too, instead of 28 dependent ones through 180 M tuples: encode 327 -> 317 ms there, 88 -> 84 ms at configs[2])
 __global__ void k_merge_cuts(const uint64_t *gstart, uint32_t i0, uint32_t n, const uint64_t *tup, uint32_t A, long long *cut)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, nb = (n + 255u) / 256u;
+    const uint32_t b = harc_gid32(), nb = (n + 255u) / 256u;
     if (b > nb) return;
     const uint32_t t = b < nb ? b * 256u : n - 1u;
     const uint64_t g = gstart[i0 + t];
@@ -1221,8 +1221,8 @@ __global__ void k_merge_cuts(const uint64_t *gstart, uint32_t i0, uint32_t n, co
 __global__ __launch_bounds__(256) void k_merge_orig(const uint64_t *gstart, uint32_t i0, uint32_t n, const uint64_t *tup, uint32_t A, FinalArrays f, uint32_t fbase, const long long *cut)
 {
     __shared__ uint64_t cols[MERGE_TILE];
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const long long c0 = cut[blockIdx.x], c1 = cut[blockIdx.x + 1] + 1;      // tup[c0] < g (or c0 = -1); tup[c1] >= the next block's first g >= g (or c1 = A)
+    const uint32_t t = harc_gid32();
+    const long long c0 = cut[harc_bid()], c1 = cut[harc_bid() + 1] + 1;      // tup[c0] < g (or c0 = -1); tup[c1] >= the next block's first g >= g (or c1 = A)
     const long long inside = c1 - c0 - 1;                                  // the candidates a search of this block can land on
     const bool tiled = inside <= MERGE_TILE;
     if (tiled) {
@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(256) void k_merge_orig(const uint64_t *gstart, uint
 }
 __global__ void k_merge_acc(const uint64_t *gstart, uint32_t M, const uint64_t *tup, const uint32_t *rid, uint32_t a0, uint32_t na, FinalArrays f, uint32_t fbase)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = harc_gid32();
     if (t >= na) return;
     const uint32_t k = a0 + t;
     const uint64_t x = tup[k] >> 2;
@@ -1251,7 +1251,7 @@ __global__ void k_merge_acc(const uint64_t *gstart, uint32_t M, const uint64_t *
 // final index of the first read of every encoder shard (F where a shard is empty), and the first accepted candidate at or behind its first column
 __global__ void k_shard_bounds(const uint64_t *gstart, uint32_t M, uint32_t q, uint32_t E, const uint64_t *tup, uint32_t A, uint64_t total, uint32_t *sh_f, uint32_t *sh_a, uint64_t *sh_col)
 {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t e = harc_gid32();
     if (e > E) return;
     const uint64_t st = (uint64_t)e * q;
     if (e == E || st >= M) { sh_f[e] = M + A; sh_a[e] = A; sh_col[e] = total; return; }
@@ -1266,7 +1266,7 @@ __global__ void k_shard_bounds(const uint64_t *gstart, uint32_t M, uint32_t q, u
 // ((x | x>>1) & 0x55..) with x = read ^ consensus; an N of a candidate read is a mismatch wherever it stands.
 __global__ void k_pack_cons2(const uint8_t *cons, uint64_t total, uint64_t w0, uint64_t nwords, uint64_t *cons2)
 {
-    const uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // the words [w0, w0 + nwords)
+    const uint64_t w = w0 + harc_gid();      // the words [w0, w0 + nwords)
     if (w >= w0 + nwords) return;
     uint64_t v = 0;
     const uint64_t c0 = w * 32;
@@ -1325,8 +1325,9 @@ template <int W, bool EMIT> __global__ void k_noise(S2Args s, FinalArrays f, con
                                                     const uint64_t *nmoff, const uint32_t *nonNrank,
                                                     uint8_t *noise, uint8_t *noisepos, uint8_t *posb, uint8_t *rcb, uint32_t *order_out, uint32_t *orderN_out)
 {
-    const uint32_t i = fb + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= F) return;
+    const uint64_t i64 = (uint64_t)fb + harc_gid();
+    if (i64 >= F) return;
+    const uint32_t i = (uint32_t)i64;
     const uint32_t ref = f.ref[i]; const int kind = f.kind[i]; const uint64_t g = f.g[i];
     uint64_t rd[W], nk[W], cw[W], mm[W];
     final_words<W>(s, ref, kind, rd, nk);
@@ -1367,7 +1368,7 @@ template <bool EMIT> static void launch_noise(harc_amd_ctx *c, const S2Args &a, 
                                               const uint64_t *nmoff, const uint32_t *nonNrank, uint8_t *noise, uint8_t *noisepos, uint8_t *posb, uint8_t *rcb,
                                               uint32_t *order_out, uint32_t *orderN_out)
 {
-#define NOISE_CASE(WW) case WW: hipLaunchKernelGGL((k_noise<WW, EMIT>), dim3((F - fb + 255) / 256), dim3(256), 0, c->stream, a, f, cons2, fb, F, nm, nonN, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out); break;
+#define NOISE_CASE(WW) case WW: hipLaunchKernelGGL((k_noise<WW, EMIT>), harc_grid256(F - fb), dim3(256), 0, c->stream, a, f, cons2, fb, F, nm, nonN, nmoff, nonNrank, noise, noisepos, posb, rcb, order_out, orderN_out); break;
     switch (a.W) { NOISE_CASE(1) NOISE_CASE(2) NOISE_CASE(3) NOISE_CASE(4) NOISE_CASE(5) NOISE_CASE(6) NOISE_CASE(7) NOISE_CASE(8) }
 #undef NOISE_CASE
 }
@@ -1376,7 +1377,7 @@ template <bool EMIT> static void launch_noise(harc_amd_ctx *c, const S2Args &a, 
 // (candidates [t0, t0 + n): this rank's share of the leftovers; fs / fn / rs / rn are indexed from t0)
 __global__ void k_left_flags(const unsigned long long *best, uint32_t t0, uint32_t n, uint32_t S, uint32_t *fs, uint32_t *fn)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = harc_gid32();
     if (t >= n) return;
     const uint32_t i = t0 + t;
     const bool un = best[i] == TUPLE_NONE;
@@ -1387,7 +1388,7 @@ __global__ void k_left_flags(const unsigned long long *best, uint32_t t0, uint32
 // their order entries (behind the aligned ones: the bases are known long before -- k_noise's sizes pass decides where the aligned entries end)
 __global__ void k_left_orders(S2Args s, uint32_t t0, uint32_t nt, const uint32_t *rs, const uint32_t *rn, uint32_t *order_out, uint32_t order_base, uint32_t *orderN_out, uint32_t orderN_base)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = harc_gid32();
     if (t >= nt) return;
     const uint32_t i = t0 + t;
     if (s.best[i] != TUPLE_NONE) return;
@@ -1422,7 +1423,7 @@ __global__ void k_left_emit(S2Args s, uint32_t t0, uint32_t nt, const uint32_t *
 // concurrent writer, cause not found.  This form has no loop and no branch on the field's position.)
 __global__ void k_left_list(const uint32_t *fs, const uint32_t *fn, const uint32_t *rs, const uint32_t *rn, uint32_t nt, uint32_t US, uint32_t *list)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = harc_gid32();
     if (t >= nt) return;
     if (fs[t]) list[rs[t]] = t;
     else if (fn[t]) list[US + rn[t]] = t;
@@ -1450,14 +1451,14 @@ __global__ __launch_bounds__(256) void k_left_emit_w(S2Args s, uint32_t t0, cons
 // packbits (encoder.cpp:527-548, :560-578)
 __global__ void k_pack2_bytes(const uint8_t *bases, uint64_t nbytes_out, uint8_t *out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = harc_gid();
     if (i >= nbytes_out) return;
     const uint8_t *b = bases + 4 * i;
     out[i] = (uint8_t)((b[0] & 3) | ((b[1] & 3) << 2) | ((b[2] & 3) << 4) | ((b[3] & 3) << 6));
 }
 __global__ void k_pack1_bytes(const uint8_t *rc, uint64_t nbytes_out, uint8_t *out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = harc_gid();
     if (i >= nbytes_out) return;
     const uint8_t *b = rc + 8 * i;
     uint8_t v = 0;
@@ -1466,7 +1467,7 @@ __global__ void k_pack1_bytes(const uint8_t *rc, uint64_t nbytes_out, uint8_t *o
 }
 __global__ void k_bases_to_ascii(const uint8_t *bases, uint64_t n, uint8_t *out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = harc_gid();
     if (i >= n) return;
     out[i] = (uint8_t)"ACGT"[bases[i] & 3];
 }
@@ -1701,7 +1702,7 @@ int stage2_run(harc_amd_ctx *c)
                     hipLaunchKernelGGL(k_key3, G256(T), cand3, T, W3, 3 * a.ds[l], a.kbits[l], k0, i0k);
                     hipLaunchKernelGGL(k_bloom4_set, G256(T), (const uint64_t *)k0, T, ref, a.bloom_lbits, a.bloom_nwin, l, a.kbits[l] / 3);
                 }
-                hipLaunchKernelGGL(k_words_differ, dim3((unsigned)((b4words + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)ref, (const uint32_t *)bloom[0], b4words, nd);
+                hipLaunchKernelGGL(k_words_differ, harc_grid256(b4words), dim3(256), 0, c->stream, (const uint32_t *)ref, (const uint32_t *)bloom[0], b4words, nd);
                 HIP_TRY(hipMemcpyAsync(&hnd, nd, 8, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 if (hnd) { harc_set_error("stage II bitmap built by tiles differs from the one built with atomics in %llu words", hnd); return HARC_AMD_EINTERNAL; }

@@ -25,7 +25,7 @@ __device__ __forceinline__ void sig_accumulate(uint64_t h, bool valid, unsigned 
 
 __global__ void k_sig_ascii(const char *ascii, uint32_t n, uint32_t stride, int L, unsigned long long *sig)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     uint64_t h = READ_HASH_INIT;
     if (i < n) {
         const char *s = ascii + (size_t)i * stride;
@@ -37,23 +37,23 @@ __global__ void k_sig_ascii(const char *ascii, uint32_t n, uint32_t stride, int 
 // 2-bit packed stream (A0 C1 G2 T3, 4 per byte, encoder.cpp:540-541) + ASCII tail -> one code per byte
 __global__ void k_unpack_seq(const uint8_t *packed, uint64_t nb, const uint8_t *tail, uint64_t ntail, uint8_t *out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = harc_gid();
     if (i < 4 * nb) out[i] = (packed[i >> 2] >> (2 * (i & 3))) & 3;
     else if (i < 4 * nb + ntail) { const uint8_t ch = tail[i - 4 * nb]; out[i] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3; }
 }
 __global__ void k_pos_to_u64(const uint8_t *pos, uint32_t n, uint64_t *out)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i < n) out[i] = pos[i];
 }
 __global__ void k_nl_flags(const uint8_t *noise, uint64_t n, uint32_t *flag)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = harc_gid();
     if (i < n) flag[i] = noise[i] == '\n' ? 1u : 0u;
 }
 __global__ void k_nl_positions(const uint8_t *noise, const uint32_t *rank, uint64_t n, uint64_t *nlpos)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = harc_gid();
     if (i < n && noise[i] == '\n') nlpos[rank[i]] = i;
 }
 // one thread per read of a shard: decode, hash
@@ -61,7 +61,7 @@ __global__ void k_decode_sig(const uint8_t *seqb, uint64_t seqlen, const uint64_
                              const uint64_t *nlpos, const uint8_t *revb, uint64_t nrevb, const uint8_t *revtail, uint32_t n, int L,
                              unsigned long long *sig, unsigned int *err)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     uint64_t h = READ_HASH_INIT;
     bool ok = i < n;
     if (ok) {
@@ -91,7 +91,7 @@ __global__ void k_decode_sig(const uint8_t *seqb, uint64_t seqlen, const uint64_
 // unaligned singletons: 2-bit packed, L bases each, back to back (encoder.cpp:484-491)
 __global__ void k_sig_codes(const uint8_t *codes, uint32_t n, int L, unsigned long long *sig)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     uint64_t h = READ_HASH_INIT;
     if (i < n) { for (int j = 0; j < L; j++) h = read_hash_step(h, codes[(size_t)i * L + j]); h = mix64(h); }
     sig_accumulate(h, i < n, sig);
@@ -194,7 +194,7 @@ __global__ void k_decode_text(const uint8_t *seqb, uint64_t seqlen, const uint64
                               const uint64_t *nlpos, const uint8_t *revb, uint64_t nrevb, const uint8_t *revtail, uint32_t n, int L,
                               char *tmp, uint32_t *isN, unsigned int *err)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     if (i >= n) return;
     const uint64_t start = possum[i] - (uint64_t)L;
     char *o = tmp + (size_t)i * (L + 1);
@@ -343,7 +343,7 @@ extern "C" int harc_amd_decoder_files(const harc_amd_params *params, const char 
 // when the inputs never existed as ASCII on this GPU (the shard received through the all-to-all)
 __global__ void k_sig_packed2(const uint64_t *reads, uint32_t n, int L, int W, unsigned long long *sig)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     uint64_t h = READ_HASH_INIT;
     if (i < n) {
         const uint64_t *r = reads + (size_t)i * W;
@@ -354,7 +354,7 @@ __global__ void k_sig_packed2(const uint64_t *reads, uint32_t n, int L, int W, u
 }
 __global__ void k_sig_packed3(const uint64_t *reads, uint32_t n, int L, int W3, unsigned long long *sig)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = harc_gid32();
     uint64_t h = READ_HASH_INIT;
     if (i < n) {
         const uint64_t *r = reads + (size_t)i * W3;
@@ -415,7 +415,7 @@ __global__ void k_permute_lines(const char *src, const uint32_t *order, uint32_t
 }
 __global__ void k_mark_N(const uint32_t *orderN, uint32_t nN, uint32_t total, uint32_t *flag, unsigned int *err)
 {
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t m = harc_gid32();
     if (m >= nN) return;
     if (orderN[m] >= total) { atomicAdd(err, 1u); return; }
     flag[orderN[m]] = 1u;

@@ -96,6 +96,12 @@ typedef struct harc_amd_counters {
                                          priority index of the winning probe + 1, or all probes of the step on a miss */
     uint64_t candidates_seq;          /* candidates that sequential scan would have fetched and Hamming-tested: those of the probes up to and
                                          including the winning one (`candidates` also counts the speculative ones behind it) */
+    /* the two kernels of the chain phase apart (round 6): the main kernel's launches are propose_launches / propose_ms; walks that reach a dictionary
+       bin of more than 16 reads (repeat families: up to maxsearch Hamming tests per probe, reorder.cpp:540-556) go through the cooperative kernel,
+       whose scans stream bin-ordered mirrors of the reads out of L2 -- another ceiling than the main kernel's random accesses */
+    uint64_t coop_launches; double coop_ms;
+    uint64_t coop_useful_probes, coop_candidates_seq, coop_candidates;   /* its share of useful_probes / candidates_seq / candidates */
+    uint64_t coop_steps, dense_steps; /* chain steps WALKED by the launches of either kernel (kept or rolled back) */
 } harc_amd_counters;
 
 /* stream ids for harc_amd_get_stream; names are the reference's file names */
@@ -226,7 +232,7 @@ int harc_amd_input_signature(harc_amd_ctx *ctx, uint64_t sig[3]);           /* o
 int harc_amd_stream_digest(harc_amd_ctx *ctx, uint64_t out[4]);
 /* sha256 (hex) of the kernel sources this library was built from: ties a committed profile (profiles/k_steps_traffic.json) to a build */
 const char *harc_amd_build_id(void);
-/* Self-test of the library's launch geometry (one thread per item over n items, n beyond 2^32 included: a one-dimensional grid of 2^32 and more
+/* Self-test of the library's launch geometry (one thread per item over n items through harc_gid / harc_gid32, and four lanes per item in folded workgroups, n beyond 2^32 included: a one-dimensional grid of 2^32 and more
  * work-items is cut short without an error on this platform).  *visited == n and *index_sum == n (n - 1) / 2 mod 2^64 when every item was visited once. */
 int harc_amd_selftest_launch(harc_amd_ctx *ctx, uint64_t n, uint64_t *visited, uint64_t *index_sum);
 
