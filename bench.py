@@ -502,6 +502,88 @@ def chain_kernels_roofline(steps_alg, useful, cands_seq, dense_ms, dense_launche
     return out
 
 
+def end_to_end_leg(harc_amd, dev_index, dev, shards, n=100_000_000, L=100, cover=26.0, err=0.005):
+    """FASTQ FILE -> raw stream FILES (SURVEY.md 8(d) "end-to-end, reported separately"; preprocess.cpp:81-121 + harc:50-69), outside the timed region:
+    a synthetic FASTQ of n reads (ids @T.<i>, quality all 'H' as gen_fastq_noRC.cpp writes them) in /dev/shm -> harc_amd_compress_fastq_files_ex -> the stage-II
+    files under <dir>/output, wall clock around the ONE library call with the library's own breakdown; then the decode side (harc:188: decoder.out's
+    replacement) files -> output.dna, and the multiset signature of the decoded file against the reads written.  No stage III (bsc / 7z): the path ends where
+    the reference's stage programs end."""
+    import numpy as np
+    import shutil
+    root = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    rec_bytes = 2 * L + 17
+    free = shutil.disk_usage(root).free
+    n = int(min(n, free * 0.30 / rec_bytes))                      # input + outputs + output.dna must fit what /dev/shm has left
+    d = tempfile.mkdtemp(dir=root, prefix="harc_e2e_")
+    hs = harc_amd.HarcAmd(harc_amd.default_params(L, device=dev_index))          # only for the signature kernel
+    try:
+        fq = os.path.join(d, "x.fastq")
+        G = max(4 * L, int(n * L / cover))
+        t0 = time.perf_counter()
+        sig = [0, 0, 0]
+        at = 0
+        pw = torch.tensor([10 ** (8 - k) for k in range(9)], dtype=torch.int64, device=dev)
+        with open(fq, "wb") as f:
+            for r in synth_chunks(n, L, G, err, 4321, dev, None):
+                m = r.shape[0]
+                torch.cuda.synchronize()
+                c3 = hs.reads_signature_device(r.data_ptr(), m, L)
+                sig[0] += c3[0]; sig[1] = (sig[1] + c3[1]) % (1 << 64); sig[2] ^= c3[2]
+                rec = torch.empty((m, rec_bytes), dtype=torch.uint8, device=dev)
+                rec[:, 0] = ord("@"); rec[:, 1] = ord("T"); rec[:, 2] = ord(".")
+                idx = torch.arange(at, at + m, device=dev, dtype=torch.int64)
+                rec[:, 3:12] = ((idx[:, None] // pw[None, :]) % 10 + 48).to(torch.uint8)
+                rec[:, 12] = 10; rec[:, 13:13 + L] = r; rec[:, 13 + L] = 10; rec[:, 14 + L] = ord("+"); rec[:, 15 + L] = 10
+                rec[:, 16 + L:16 + 2 * L] = ord("H"); rec[:, 16 + 2 * L] = 10
+                f.write(memoryview(rec.cpu().numpy()).cast("B"))
+                at += m
+                del rec, idx, r
+        torch.cuda.empty_cache()
+        t_gen = time.perf_counter() - t0
+        fsz = os.path.getsize(fq)
+        os.makedirs(os.path.join(d, "output"))
+        t0 = time.perf_counter()
+        harc_amd.compress_fastq(fq, d, L, num_thr=shards, num_chains=0, device=dev_index)
+        t_c = time.perf_counter() - t0
+        lap = harc_amd.last_fastq_timing()
+        os.remove(fq)
+        out_bytes = sum(os.path.getsize(os.path.join(d, "output", x)) for x in os.listdir(os.path.join(d, "output")))
+        t0 = time.perf_counter()
+        harc_amd.decoder(d, shards, device=dev_index)
+        t_d = time.perf_counter() - t0
+        # the decoded file's reads against the reads written: multiset signature, the file through the GPU 256 MB at a time
+        dn = os.path.join(d, "output", "output.dna")
+        dsig = [0, 0, 0]
+        rows = (256 << 20) // (L + 1)
+        with open(dn, "rb") as f:
+            while True:
+                b = f.read(rows * (L + 1))
+                if not b:
+                    break
+                t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev).view(-1, L + 1)
+                torch.cuda.synchronize()
+                c3 = hs.reads_signature_device(t.data_ptr(), t.shape[0], L + 1)
+                dsig[0] += c3[0]; dsig[1] = (dsig[1] + c3[1]) % (1 << 64); dsig[2] ^= c3[2]
+                del t
+        other = max(0.0, lap["total"] - lap["context_and_pool"] - lap["ingest"] - lap["reorder"] - lap["encode"] - lap["stream_files"])
+        return {"value": round(n / t_c / 1e6, 2), "unit": "Mreads/s, FASTQ file -> raw stage-II stream files (one call of harc_amd_compress_fastq_files_ex, wall clock)",
+                "reads": n, "readlen": L, "fastq_bytes": fsz, "stream_file_bytes": out_bytes, "wall_s": round(t_c, 3),
+                "breakdown_s": {"context_and_device_pool": round(lap["context_and_pool"], 3),
+                                "ingest_file_to_packed_reads": round(lap["ingest"], 3),
+                                "ingest_of_which_waiting_for_the_file_readers": round(lap["ingest_waiting_for_file_readers"], 3),
+                                "ingest_of_which_device_passes": round(lap["ingest_device_passes"], 3),
+                                "reorder": round(lap["reorder"], 3), "encode_with_d2h": round(lap["encode"], 3), "stream_files_written": round(lap["stream_files"], 3),
+                                "small_files_and_rest": round(other, 3), "outside_the_library_call_to_its_own_clock": round(t_c - lap["total"], 3)},
+                "file_read_GBps": round(fsz / max(1e-9, lap["ingest"]) / 1e9, 2),
+                "decode": {"value": round(n / t_d / 1e6, 2), "unit": "Mreads/s, stream files -> output.dna (harc_amd_decoder_files)", "wall_s": round(t_d, 3)},
+                "roundtrip": {"ok": bool(tuple(dsig) == tuple(sig)), "reads_decoded": int(dsig[0]), "reads_in": int(sig[0])},
+                "input": f"{n} x {L} bp at {cover:g}x on an i.i.d. genome, {err:g} substitutions (a quarter N), ids @T.<i>, quality all H; in {root}",
+                "fastq_generation_s": round(t_gen, 1)}
+    finally:
+        hs.close()
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def run_other_config(harc_amd, name, dev_index, dev, shards, steps=2):
     """one of the other BASELINE configurations on this GPU: 1 warm-up (pool growth) + `steps` timed reorder + encode (+ pack_order) passes,
     timed like the main line (reads resident in HBM -> streams in pinned host memory), then the round trip on all reads"""
@@ -550,6 +632,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket exchange even at world size 1 (exercises the N>1 path on one GPU)")
     ap.add_argument("--cpu-sample", type=int, default=0)
     ap.add_argument("--no-other-configs", action="store_true", help="default workload on one GPU: skip the side lines for configs[2] with repeats (c3r, 1 timed step), configs[3] (c4) and configs[4]'s share (c5g), 2 timed steps each, after the main line's timed region")
+    ap.add_argument("--end-to-end", type=int, default=0, help="run the end-to-end leg (FASTQ file in /dev/shm -> stream files -> output.dna) on this many reads whatever the workload (default: 100 M reads with the default workload)")
     ap.add_argument("--mg-mode", default="bucket", choices=["bucket", "replicate"],
                     help="N>1: bucket = minimizer-bucket shard + one all-to-all, independent shards (north_star; larger archives); replicate = design (R): "
                          "all-gather of the reads, chains partitioned over the GPUs, one all-gather of the walked steps per super-round -- every GPU "
@@ -868,6 +951,14 @@ def main():
                 out["other_configs"][name] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
         out["other_configs"]["wall_s"] = round(time.perf_counter() - t_other, 1)
+    # ---- end to end, FASTQ file -> stream files (and back), on the same line, outside the timed region
+    if rank == 0 and world == 1 and dist is None and ((args.workload == "c3" and not args.no_cpu and not args.no_other_configs) or args.end_to_end):
+        t_e = time.perf_counter()
+        try:
+            out["end_to_end"] = end_to_end_leg(harc_amd, local, dev, args.shards, n=args.end_to_end or 100_000_000)
+        except Exception as e:
+            out["end_to_end"] = {"error": repr(e)[:300]}
+        out["end_to_end"]["leg_wall_s"] = round(time.perf_counter() - t_e, 1)
     if dist is not None:
         with wd.phase("final barrier (rank 0 runs the side legs meanwhile)", max(args.watchdog, 1800.0)):
             dist.barrier()

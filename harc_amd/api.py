@@ -81,6 +81,7 @@ def lib():
     l.harc_amd_preprocess_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     l.harc_amd_decoder_files.argtypes = [PP, C.c_char_p, C.c_int32]
     l.harc_amd_compress_fastq_files_ex.argtypes = [PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
+    l.harc_amd_last_fastq_timing.argtypes = [C.POINTER(C.c_double), C.c_int32]
     l.harc_amd_decoder_preserve_files.argtypes = [PP, C.c_char_p, C.c_int32]
     l.harc_amd_compress_fastq_files.argtypes = [PP, C.c_char_p, C.c_char_p]
     l.harc_amd_set_fastq_device.argtypes = [ctx, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -153,6 +154,14 @@ def compress_fastq(fastq, basedir, readlen, num_thr=1, num_chains=1, preserve_or
     (preprocess.cpp:61-118, reorder_quality.cpp)"""
     p = default_params(readlen, num_thr=num_thr, num_chains=num_chains, **kw)
     _check(lib().harc_amd_compress_fastq_files_ex(C.byref(p), os.fsencode(fastq), os.fsencode(basedir), int(preserve_order), int(preserve_quality)))
+
+
+def last_fastq_timing():
+    """seconds of the last compress_fastq of this process, by phase (include/harc_amd.h: harc_amd_last_fastq_timing)"""
+    t = (C.c_double * 8)()
+    _check(lib().harc_amd_last_fastq_timing(t, 8))
+    names = ("context_and_pool", "ingest", "ingest_waiting_for_file_readers", "ingest_device_passes", "reorder", "encode", "stream_files", "total")
+    return {k: float(v) for k, v in zip(names, t)}
 
 
 COMM_ID_BYTES = 128

@@ -198,6 +198,7 @@ extern "C" void harc_amd_destroy(harc_amd_ctx *c)
     for (void *p : c->owned) (void)hipFree(p);
     for (auto &k : c->pool) (void)hipFree(k.base);
     for (auto &k : c->harena) (void)hipHostFree(k.base);
+    if (c->feed_ring) (void)hipHostFree(c->feed_ring);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);

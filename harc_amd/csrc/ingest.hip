@@ -7,6 +7,13 @@
 #include <string>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 // line index in two levels: newlines per 4096-byte tile -> scan of the tile counts -> positions written tile by tile
 #define NL_TILE 4096
@@ -569,31 +576,175 @@ static int emit_quality_and_ids_streamed(harc_amd_ctx *c, FILE *f, const char *n
 }
 
 // ------------------------------------------------------------------------------------------------ file drivers
-// bytes [lo, hi) of the file -> device memory, through two pinned buffers; *d_txt is a raw allocation of the context
+// Where the wall time of the last harc_amd_compress_fastq_files_ex of this process went (seconds; harc_amd_last_fastq_timing): [0] context + device pool,
+// [1] ingest = file -> HBM -> packed stores, reads / uploads / kernels overlapped, [2] of it the calling thread waiting for the reader threads (file-read bound),
+// [3] of it the device's line index / classify / pack kernels and their syncs, [4] reorder, [5] encode (the D2H of the streams inside), [6] stream files written,
+// [7] total
+static double g_fastq_timing[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+static inline double mono_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+extern "C" int harc_amd_last_fastq_timing(double *out, int32_t n)
+{
+    if (!out || n < 1) return HARC_AMD_EINVAL;
+    for (int i = 0; i < n; i++) out[i] = i < 8 ? g_fastq_timing[i] : 0.0;
+    return HARC_AMD_OK;
+}
+// File -> HBM at the rate of the host's memory system instead of one core's (round 6; round 3's ./harc -c spent most of its 6 s on 100 M reads in a
+// single-threaded fread into one pinned buffer): reader threads pread() slices of the file into a ring of pinned slices kept by the context, the calling
+// thread uploads every filled slice (hipMemcpyAsync on the context's stream) and hands the slice back when its copy has finished.  The slices of ALL the
+// pieces of a range are read ahead in file order as far as the ring goes: while the device indexes and packs piece i the readers already hold the first
+// slices of piece i + 1.  A slice is taken from the ring BEFORE its chunk number, under one lock: the chunks that hold slices are always the lowest
+// unfinished ones, so a piece being waited for can never starve behind read-ahead that cannot be uploaded yet.
+struct FileFeeder {
+    struct Chunk { uint64_t off; uint32_t len; uint32_t piece; uint64_t at; };     // file offset, bytes, piece, byte offset inside the piece
+    harc_amd_ctx *c; int fd = -1; const char *name;
+    bool use_mmap = true;                                         // the readers copy out of a mapping of their slice instead of calling pread (HARC_AMD_FEED_MMAP=0: pread)
+    std::vector<Chunk> chunks; std::vector<size_t> piece_left;                     // chunks of each piece not uploaded yet
+    size_t SL = 0; int NS = 0;
+    std::vector<hipEvent_t> ev;
+    std::mutex mu; std::condition_variable cv_free, cv_filled;
+    std::deque<int> free_slices; std::deque<std::pair<int, size_t>> filled, held;  // (slice, chunk)
+    std::deque<int> inflight;                                                      // slices whose upload is on the stream, oldest first
+    size_t next_chunk = 0; bool stop = false; int err = 0;
+    double t_ring = 0, t_pread = 0, t_wait_free = 0, t_wait_filled = 0, t_wait_copy = 0, t_enqueue = 0;      // HARC_AMD_TRACE: summed over the readers / of the calling thread
+    std::vector<std::thread> th;
+    FileFeeder(harc_amd_ctx *c_, const char *name_) : c(c_), name(name_) {}
+    ~FileFeeder()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_free.notify_all();
+        for (auto &t : th) t.join();
+        (void)hipStreamSynchronize(c->stream);                    // before the ring is used again
+        if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[file feeder] %zu slices of %zu MB through %d pinned slices by %zu readers (pinned ring allocated in %.3f s): readers in pread %.2f s, waiting for a free slice %.2f s (summed); uploader enqueueing %.2f s, waiting for a filled slice %.2f s, for a copy %.2f s\n",
+                                              chunks.size(), SL >> 20, NS, th.size(), t_ring, t_pread, t_wait_free, t_enqueue, t_wait_filled, t_wait_copy);
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+        if (fd >= 0) close(fd);
+    }
+    // pieces: [lo, hi) byte ranges of the file, in file order
+    int start(const std::vector<std::pair<uint64_t, uint64_t>> &pieces)
+    {
+        fd = open(name, O_RDONLY);
+        if (fd < 0) { harc_set_error("cannot open %s", name); return HARC_AMD_EIO; }
+        // 16 slices of 64 MB, 16 readers (tools/micro/feed_rate.cpp, profiles/r06/feed_rate.txt: a file that has been read before reaches HBM at 54 GB/s this way, the
+        // PCIe rate is 57; 16-MB slices 42; the FIRST read of a freshly written tmpfs file runs at 24 GB/s whatever is done here -- the kernel's own first touch)
+        SL = (size_t)64 << 20; NS = 16;
+        int nthr = 16;
+        // a read() of page-cache pages that nobody has read yet marks every one of them accessed (LRU lists, under a lock the readers share): the first read of
+        // a freshly written 21.7-GB file ran at 14-24 GB/s with 16 readers, the second at 54.  Copies out of a shared mapping do not go that way -- but ONE
+        // mapping of the whole file took 0.8 s to take down again (the same marking, at unmap, by one thread): every reader maps its own slice, tells the kernel
+        // that it reads it once from front to back (no recency kept for such a mapping), copies and unmaps.  HARC_AMD_FEED_MMAP=0: pread.
+        use_mmap = !(getenv("HARC_AMD_FEED_MMAP") && atoi(getenv("HARC_AMD_FEED_MMAP")) == 0);
+        const double t_ring0 = mono_now();
+        if (c->feed_ring_bytes < SL * (size_t)NS) {
+            if (c->feed_ring) { (void)hipHostFree(c->feed_ring); c->feed_ring = nullptr; c->feed_ring_bytes = 0; }
+            if (hipHostMalloc((void **)&c->feed_ring, SL * (size_t)NS) != hipSuccess) { harc_set_error("hipHostMalloc of the ingest ring (%zu bytes) failed", SL * (size_t)NS); return HARC_AMD_ENOMEM; }
+            c->feed_ring_bytes = SL * (size_t)NS;
+        }
+        t_ring = mono_now() - t_ring0;
+        ev.assign(NS, nullptr);
+        for (int k = 0; k < NS; k++) { if (hipEventCreate(&ev[k]) != hipSuccess) { harc_set_error("hipEventCreate failed"); return HARC_AMD_ENODEVICE; } free_slices.push_back(k); }
+        piece_left.assign(pieces.size(), 0);
+        for (size_t p = 0; p < pieces.size(); p++)
+            for (uint64_t a = pieces[p].first; a < pieces[p].second; a += SL) {
+                const uint64_t b = pieces[p].second - a < SL ? pieces[p].second : a + SL;
+                chunks.push_back(Chunk{ a, (uint32_t)(b - a), (uint32_t)p, a - pieces[p].first });
+                piece_left[p]++;
+            }
+        if ((size_t)nthr > chunks.size()) nthr = (int)chunks.size();
+        for (int t = 0; t < nthr; t++) th.emplace_back([this] { reader(); });
+        return HARC_AMD_OK;
+    }
+    void reader()
+    {
+        for (;;) {
+            int sl; size_t k;
+            const double tw0 = mono_now();
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_free.wait(lk, [&] { return stop || next_chunk >= chunks.size() || !free_slices.empty(); });
+                if (stop || next_chunk >= chunks.size()) return;
+                sl = free_slices.front(); free_slices.pop_front(); k = next_chunk++;
+            }
+            const Chunk &ch = chunks[k];
+            const double tr0 = mono_now();
+            char *dst = c->feed_ring + (size_t)sl * SL; size_t got = 0; int e = 0;
+            if (use_mmap) {
+                const uint64_t a0 = ch.off & ~(uint64_t)4095; const size_t mlen = (size_t)(ch.off + ch.len - a0);
+                void *m = mmap(nullptr, mlen, PROT_READ, MAP_SHARED, fd, (off_t)a0);
+                if (m != MAP_FAILED) {
+                    (void)madvise(m, mlen, MADV_SEQUENTIAL);
+                    memcpy(dst, (const char *)m + (ch.off - a0), ch.len); got = ch.len;
+                    munmap(m, mlen);
+                }
+            }
+            while (got < ch.len) {
+                const ssize_t r = pread(fd, dst + got, ch.len - got, (off_t)(ch.off + got));
+                if (r <= 0) { e = 1; break; }
+                got += (size_t)r;
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (e) { err = 1; stop = true; }
+                filled.emplace_back(sl, k);
+                t_wait_free += tr0 - tw0; t_pread += mono_now() - tr0;
+            }
+            cv_filled.notify_one();
+            if (e) { cv_free.notify_all(); return; }
+        }
+    }
+    void give_back(int sl) { { std::lock_guard<std::mutex> lk(mu); free_slices.push_back(sl); } cv_free.notify_one(); }
+    // every chunk of piece p on the stream towards d_txt; chunks of piece p + 1 that are ready meanwhile go to d_next (may be null: they wait)
+    int upload_piece(size_t p, char *d_txt, char *d_next)
+    {
+        auto put = [&](int sl, size_t k) -> int {
+            const Chunk &ch = chunks[k];
+            char *base = ch.piece == p ? d_txt : d_next;
+            const double te0 = mono_now();
+            if (hipMemcpyAsync(base + ch.at, c->feed_ring + (size_t)sl * SL, ch.len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { harc_set_error("upload of %s failed", name); return HARC_AMD_ENODEVICE; }
+            (void)hipEventRecord(ev[sl], c->stream);
+            inflight.push_back(sl); piece_left[ch.piece]--;
+            t_enqueue += mono_now() - te0;
+            return HARC_AMD_OK;
+        };
+        // what was read ahead for this piece while the last one was uploaded
+        for (size_t i = 0; i < held.size();) {
+            const Chunk &ch = chunks[held[i].second];
+            if (ch.piece == p || (ch.piece == p + 1 && d_next)) { RC_TRY(put(held[i].first, held[i].second)); held.erase(held.begin() + (long)i); } else i++;
+        }
+        while (piece_left[p] > 0) {
+            while (!inflight.empty() && hipEventQuery(ev[inflight.front()]) == hipSuccess) { give_back(inflight.front()); inflight.pop_front(); }
+            std::pair<int, size_t> it(-1, 0);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (filled.empty() && !err) {
+                    if (!inflight.empty()) { lk.unlock(); const double t0 = mono_now(); (void)hipEventSynchronize(ev[inflight.front()]); t_wait_copy += mono_now() - t0; give_back(inflight.front()); inflight.pop_front(); continue; }
+                    const double t0 = mono_now();
+                    cv_filled.wait(lk, [&] { return !filled.empty() || err; });
+                    t_wait_filled += mono_now() - t0;
+                }
+                if (err) { harc_set_error("short read on %s", name); return HARC_AMD_EIO; }
+                it = filled.front(); filled.pop_front();
+            }
+            const Chunk &ch = chunks[it.second];
+            if (ch.piece == p || (ch.piece == p + 1 && d_next)) RC_TRY(put(it.first, it.second));
+            else held.push_back(it);
+        }
+        return HARC_AMD_OK;
+    }
+};
+// bytes [lo, hi) of the file -> device memory; *d_txt is a raw allocation of the context
 static int load_file_range(harc_amd_ctx *c, FILE *f, const char *name, uint64_t lo, uint64_t hi, char **d_txt)
 {
+    (void)f;
     *d_txt = nullptr;
     const uint64_t n = hi - lo;
     RC_TRY(harc_raw_alloc(c, (void **)d_txt, (size_t)n + 16));
-    const size_t CH = (size_t)64 << 20;
-    struct Pinned {
-        char *hb[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr };
-        ~Pinned() { for (int k = 0; k < 2; k++) { if (ev[k]) (void)hipEventDestroy(ev[k]); if (hb[k]) (void)hipHostFree(hb[k]); } }
-    } pb;
     int rc = HARC_AMD_OK;
-    for (int k = 0; k < 2 && rc == HARC_AMD_OK; k++)
-        if (hipHostMalloc((void **)&pb.hb[k], CH) != hipSuccess || hipEventCreate(&pb.ev[k]) != hipSuccess) { harc_set_error("hipHostMalloc / hipEventCreate failed"); rc = HARC_AMD_ENOMEM; }
-    if (rc == HARC_AMD_OK && fseeko(f, (off_t)lo, SEEK_SET) != 0) { harc_set_error("cannot seek in %s", name); rc = HARC_AMD_EIO; }
-    size_t off = 0; int k = 0; bool used[2] = { false, false };
-    while (rc == HARC_AMD_OK && off < (size_t)n) {
-        if (used[k]) (void)hipEventSynchronize(pb.ev[k]);
-        const size_t want = (size_t)n - off < CH ? (size_t)n - off : CH;
-        if (fread(pb.hb[k], 1, want, f) != want) { harc_set_error("short read on %s", name); rc = HARC_AMD_EIO; break; }
-        if (hipMemcpyAsync(*d_txt + off, pb.hb[k], want, hipMemcpyHostToDevice, c->stream) != hipSuccess) { harc_set_error("upload of %s failed", name); rc = HARC_AMD_ENODEVICE; break; }
-        (void)hipEventRecord(pb.ev[k], c->stream); used[k] = true;
-        off += want; k ^= 1;
+    if (n) {
+        FileFeeder fd(c, name);
+        rc = fd.start({ { lo, hi } });
+        if (rc == HARC_AMD_OK) rc = fd.upload_piece(0, *d_txt, nullptr);
     }
-    (void)hipStreamSynchronize(c->stream);                        // before the pinned buffers go
+    if (rc == HARC_AMD_OK && hipStreamSynchronize(c->stream) != hipSuccess) { harc_set_error("upload of %s failed", name); rc = HARC_AMD_ENODEVICE; }
     if (rc != HARC_AMD_OK) { harc_raw_free(c, *d_txt); *d_txt = nullptr; }
     return rc;
 }
@@ -668,31 +819,64 @@ static int ingest_file_range(harc_amd_ctx *c, FILE *f, const char *name, uint64_
 {
     uint64_t piece = (uint64_t)1 << 30;
     if (const char *e = getenv("HARC_AMD_INGEST_CHUNK")) { piece = strtoull(e, nullptr, 10); if (piece < 16) piece = 16; }    // tests: pieces of a few records
+    const bool tlog = getenv("HARC_AMD_TRACE") != nullptr;
+    double tl = mono_now();
+    auto lap = [&](const char *what) { if (tlog) { const double t = mono_now(); fprintf(stderr, "[ingest] %s: %.3f s\n", what, t - tl); tl = t; } };
     RC_TRY(ingest_begin(c, st));
-    const uint64_t start = lo;
-    while (lo < end) {
+    lap("previous inputs dropped");
+    // the pieces first (a piece ends where a record starts: a 64-KB look at the file per boundary), so that the readers can run ahead over all of them
+    std::vector<std::pair<uint64_t, uint64_t>> pieces;
+    uint64_t maxlen = 0;
+    for (uint64_t a = lo; a < end;) {
         uint64_t hi = end;
-        if (end - lo > piece) { RC_TRY(record_start_at_or_after(f, lo + piece, fsz, &hi)); if (hi > end) hi = end; if (hi <= lo) hi = end; }
-        char *d_txt = nullptr;
-        RC_TRY(load_file_range(c, f, name, lo, hi, &d_txt));
-        struct Free { harc_amd_ctx *c; char *p; ~Free() { harc_raw_free(c, p); } } fr{ c, d_txt };
+        if (end - a > piece) { RC_TRY(record_start_at_or_after(f, a + piece, fsz, &hi)); if (hi > end) hi = end; if (hi <= a) hi = end; }
+        pieces.emplace_back(a, hi); if (hi - a > maxlen) maxlen = hi - a;
+        a = hi;
+    }
+    if (pieces.empty()) return ingest_finish(c, st);
+    lap("piece boundaries");
+    // two device buffers: piece i + 1 is uploaded (behind piece i's kernels on the stream) while the host still waits for piece i's counts
+    struct Bufs { harc_amd_ctx *c; char *p[2] = { nullptr, nullptr }; ~Bufs() { for (char *x : p) if (x) harc_raw_free(c, x); } } db{ c };
+    RC_TRY(harc_raw_alloc(c, (void **)&db.p[0], (size_t)maxlen + 16));
+    if (pieces.size() > 1) RC_TRY(harc_raw_alloc(c, (void **)&db.p[1], (size_t)maxlen + 16));
+    lap("two device buffers");
+    {
+    FileFeeder feed(c, name);
+    RC_TRY(feed.start(pieces));
+    lap("feeder started (file mapped, ring pinned, readers running)");
+    const uint64_t start = lo;
+    for (size_t p = 0; p < pieces.size(); p++) {
+        const uint64_t a = pieces[p].first, hi = pieces[p].second;
+        char *d_txt = db.p[p & 1];
+        const double tu = mono_now();
+        RC_TRY(feed.upload_piece(p, d_txt, p + 1 < pieces.size() ? db.p[(p + 1) & 1] : nullptr));
+        const double ta = mono_now(); g_fastq_timing[2] += ta - tu;
         // the first piece tells how many reads the whole range will hold, give or take: the stores are sized once
         uint64_t expC = 0, expN = 0;
-        if (lo > start) { const double scale = 1.03 * (double)(end - start) / (double)(lo - start); expC = (uint64_t)(scale * (double)st.nC); expN = (uint64_t)(scale * (double)st.nN); }
-        RC_TRY(ingest_append(c, st, d_txt, hi - lo, hi == fsz, expC, expN));
-        if (fq) RC_TRY(emit_q_fileorder(c, d_txt, hi - lo, fq, fi));
-        lo = hi;
+        if (a > start) { const double scale = 1.03 * (double)(end - start) / (double)(a - start); expC = (uint64_t)(scale * (double)st.nC); expN = (uint64_t)(scale * (double)st.nN); }
+        RC_TRY(ingest_append(c, st, d_txt, hi - a, hi == fsz, expC, expN));
+        g_fastq_timing[3] += mono_now() - ta;
+        if (fq) RC_TRY(emit_q_fileorder(c, d_txt, hi - a, fq, fi));
     }
-    return ingest_finish(c, st);
+    lap("pieces uploaded, indexed, classified, packed");
+    }
+    lap("feeder gone (readers joined, file unmapped)");
+    const int rc = ingest_finish(c, st);
+    lap("ingest_finish");
+    return rc;
 }
 
 // FASTQ file -> every stage-II file under <basedir>/output (+ read_order_N.bin, numreads.bin): harc:50-69 without input_clean.dna
 extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, const char *fastq, const char *basedir, int32_t preserve_order, int32_t preserve_quality)
 {
     if (!params || !fastq || !basedir) return HARC_AMD_EINVAL;
+    for (double &x : g_fastq_timing) x = 0;
+    const double t_begin = mono_now();
     harc_amd_ctx *c = nullptr;
     RC_TRY(harc_amd_create(params, &c));
     struct Guard { harc_amd_ctx *c; ~Guard() { harc_amd_destroy(c); } } guard{ c };
+    g_fastq_timing[0] = mono_now() - t_begin;
+    const double t_ingest = mono_now();
     FILE *f = fopen(fastq, "rb");
     if (!f) { harc_set_error("cannot open %s", fastq); return HARC_AMD_EIO; }
     struct FClose { FILE *f; ~FClose() { fclose(f); } } fcl{ f };
@@ -724,6 +908,7 @@ extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, c
         st.want_idlen = stream_q;
         RC_TRY(ingest_file_range(c, f, fastq, 0, fsz, fsz, st, fq, fi));
     }
+    g_fastq_timing[1] = mono_now() - t_ingest;
     printf("Read length: %d\nTotal number of reads: %llu\nTotal number of reads without N: %llu\nPreprocessing Done!\n", params->readlen,
            (unsigned long long)st.nfull, (unsigned long long)c->N);                                       // preprocess.cpp:133-136
     const bool tlog = getenv("HARC_AMD_TRACE") != nullptr;
@@ -732,10 +917,13 @@ extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, c
     auto lap = [&](const char *what) { if (tlog) { const double t = now(); fprintf(stderr, "[compress_fastq] %s: %.3f s\n", what, t - tl0); tl0 = t; } };
     RC_TRY(spit_stream_to(c, HARC_AMD_IN_ORDER_N, 0, od + "read_order_N.bin"));
     { const uint32_t n32 = c->N; RC_TRY(spit_file(od + "numreads.bin", &n32, 4)); }
+    double t_ph = mono_now();
     RC_TRY(harc_amd_reorder(c));
     lap("reorder");
+    g_fastq_timing[4] = mono_now() - t_ph; t_ph = mono_now();
     RC_TRY(harc_amd_encode(c));
     lap("encode");
+    g_fastq_timing[5] = mono_now() - t_ph; t_ph = mono_now();
     harc_amd_counters C; harc_amd_get_counters(c, &C);
     printf("Reordering done, %llu were unmatched\n", (unsigned long long)C.unmatched);
     printf("Encoding done:\n%llu singleton reads were aligned\n%llu reads with N were aligned\n", (unsigned long long)C.aligned_singletons, (unsigned long long)C.aligned_N);
@@ -745,6 +933,7 @@ extern "C" int harc_amd_compress_fastq_files_ex(const harc_amd_params *params, c
         { HARC_AMD_S2_ORDER, "read_order.bin" }, { HARC_AMD_S2_ORDER_N_PE, "read_order_N_pe.bin" }, { HARC_AMD_S2_INPUT_N, "input_N.dna" },
         { HARC_AMD_S2_META, "read_meta.txt" }, { HARC_AMD_S2_SINGLETON, "read_singleton.txt" }, { HARC_AMD_S2_SINGLETON_TAIL, "read_singleton.txt.tail" } };
     for (auto &fd : whole) RC_TRY(spit_stream_to(c, fd.id, 0, od + fd.name));
+    g_fastq_timing[6] = mono_now() - t_ph; g_fastq_timing[7] = mono_now() - t_begin;
     if (preserve_quality && !preserve_order) {
         printf("Reordering quality values and ids\n");                                                      // harc:122
         lap("whole-job files");

@@ -138,6 +138,9 @@ struct harc_amd_ctx {
     harc_amd_counters C;
     uint64_t digest[4] = { 0, 0, 0, 0 }; bool have_digest = false;   // harc_amd_stream_digest: the stage-II streams of the last encode, folded on the device (params.stream_digest)
 
+    // pinned ring of the file feeder (ingest.hip: FASTQ file -> HBM by several reader threads), kept for the next file
+    char *feed_ring = nullptr; size_t feed_ring_bytes = 0;
+
     // scratch for rocPRIM
     void *d_tmp = nullptr; size_t tmp_bytes = 0;
 };

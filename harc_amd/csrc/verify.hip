@@ -8,6 +8,14 @@
 #include "devutil.h"
 #include <string>
 #include <stdlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 __device__ __forceinline__ uint64_t read_hash_step(uint64_t h, int code) { return (h ^ (uint64_t)code) * 1099511628211ULL; }   // FNV-1a over codes A0 C1 G2 T3 N4
 #define READ_HASH_INIT 1469598103934665603ULL
@@ -247,6 +255,98 @@ static bool slurp_file(const std::string &path, std::vector<uint8_t> &out)
     return ok;
 }
 
+// HBM -> file at the rate of the host's memory system (round 6: decoder.out's replacement spent 4.4 of its 4.7 s on 100 M reads in D2H copies into pageable
+// vectors and one thread's fwrite): the output file is sized and mapped first (its length is known from the stream files' sizes), the calling thread sends
+// pieces of device memory through a ring of pinned slices (hipMemcpyAsync on the context's stream), writer threads copy every slice that has arrived into the
+// mapping.  write() calls to ONE tmpfs file serialise on its inode (tools/micro/feed_rate.cpp: 6 GB/s with 1 or 16 threads); page faults of a shared mapping do not.
+struct FileDrain {
+    struct Job { int sl; size_t len; uint64_t off; };
+    harc_amd_ctx *c; int fd = -1; char *map = nullptr; size_t fsize = 0;
+    size_t SL = 0; int NS = 0;
+    std::vector<hipEvent_t> ev;
+    std::mutex mu; std::condition_variable cv_free, cv_job, cv_idle;
+    std::deque<int> free_slices; std::deque<Job> jobs; int busy = 0; bool stop = false;
+    std::vector<std::thread> th;
+    explicit FileDrain(harc_amd_ctx *c_) : c(c_) {}
+    ~FileDrain() { (void)finish(); }
+    int start(const std::string &path, size_t bytes)
+    {
+        fd = open(path.c_str(), O_CREAT | O_RDWR | O_TRUNC, 0644);
+        if (fd < 0) { harc_set_error("cannot create %s", path.c_str()); return HARC_AMD_EIO; }
+        fsize = bytes;
+        if (bytes) {
+            if (ftruncate(fd, (off_t)bytes) != 0) { harc_set_error("cannot size %s to %zu bytes", path.c_str(), bytes); return HARC_AMD_EIO; }
+            map = (char *)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (map == MAP_FAILED) { map = nullptr; harc_set_error("cannot map %s", path.c_str()); return HARC_AMD_EIO; }
+        }
+        SL = (size_t)64 << 20; NS = 16;
+        int nthr = 16;
+        if (const char *e = getenv("HARC_AMD_FEED_THREADS")) { const int x = atoi(e); if (x >= 1 && x <= 64) nthr = x; }
+        if (const char *e = getenv("HARC_AMD_FEED_SLICE")) { const long long x = atoll(e); if (x >= 16 && x <= ((long long)1 << 30)) SL = (size_t)x; }      // tests: slices of a few reads
+        if (c->feed_ring_bytes < SL * (size_t)NS) {
+            if (c->feed_ring) { (void)hipHostFree(c->feed_ring); c->feed_ring = nullptr; c->feed_ring_bytes = 0; }
+            if (hipHostMalloc((void **)&c->feed_ring, SL * (size_t)NS) != hipSuccess) { harc_set_error("hipHostMalloc of the output ring (%zu bytes) failed", SL * (size_t)NS); return HARC_AMD_ENOMEM; }
+            c->feed_ring_bytes = SL * (size_t)NS;
+        }
+        ev.assign(NS, nullptr);
+        for (int k = 0; k < NS; k++) { if (hipEventCreate(&ev[k]) != hipSuccess) { harc_set_error("hipEventCreate failed"); return HARC_AMD_ENODEVICE; } free_slices.push_back(k); }
+        const int dev = c->P.device;
+        for (int t = 0; t < nthr; t++) th.emplace_back([this, dev] {
+            (void)hipSetDevice(dev);
+            for (;;) {
+                Job j;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_job.wait(lk, [&] { return stop || !jobs.empty(); });
+                    if (jobs.empty()) return;
+                    j = jobs.front(); jobs.pop_front(); busy++;
+                }
+                (void)hipEventSynchronize(ev[j.sl]);              // the slice has arrived
+                memcpy(map + j.off, c->feed_ring + (size_t)j.sl * SL, j.len);
+                { std::lock_guard<std::mutex> lk(mu); busy--; free_slices.push_back(j.sl); }
+                cv_free.notify_one(); cv_idle.notify_all();
+            }
+        });
+        return HARC_AMD_OK;
+    }
+    // n bytes of device memory -> bytes [off, off + n) of the file.  The copies are on the context's stream: what is enqueued behind them may reuse d_src
+    int put(const void *d_src, size_t n, uint64_t off)
+    {
+        if (off + n > fsize) { harc_set_error("output file: %zu bytes at %llu do not fit its %zu bytes", n, (unsigned long long)off, fsize); return HARC_AMD_EINTERNAL; }
+        for (size_t a = 0; a < n; a += SL) {
+            const size_t len = n - a < SL ? n - a : SL;
+            int sl;
+            { std::unique_lock<std::mutex> lk(mu); cv_free.wait(lk, [&] { return !free_slices.empty(); }); sl = free_slices.front(); free_slices.pop_front(); }
+            if (hipMemcpyAsync(c->feed_ring + (size_t)sl * SL, (const char *)d_src + a, len, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipEventRecord(ev[sl], c->stream) != hipSuccess) {
+                harc_set_error("device -> host copy of the output failed"); return HARC_AMD_ENODEVICE; }
+            { std::lock_guard<std::mutex> lk(mu); jobs.push_back(Job{ sl, len, off + a }); }
+            cv_job.notify_one();
+        }
+        return HARC_AMD_OK;
+    }
+    int put_host(const void *h, size_t n, uint64_t off)
+    {
+        if (off + n > fsize) { harc_set_error("output file: %zu bytes at %llu do not fit its %zu bytes", n, (unsigned long long)off, fsize); return HARC_AMD_EINTERNAL; }
+        if (n) memcpy(map + off, h, n);
+        return HARC_AMD_OK;
+    }
+    int finish()
+    {
+        if (!th.empty()) {
+            { std::unique_lock<std::mutex> lk(mu); cv_idle.wait(lk, [&] { return jobs.empty() && busy == 0; }); stop = true; }
+            cv_job.notify_all();
+            for (auto &t : th) t.join();
+            th.clear();
+        }
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+        ev.clear();
+        if (map) { munmap(map, fsize); map = nullptr; }
+        if (fd >= 0) { close(fd); fd = -1; }
+        return HARC_AMD_OK;
+    }
+};
+static size_t file_size_or_zero(const std::string &path) { struct stat st; return stat(path.c_str(), &st) == 0 ? (size_t)st.st_size : 0; }
+
 // decoder.out <basedir> <num_thr> <num_thr_e>  (src/decoder.cpp:44-172, harc:188): writes output/output.dna
 extern "C" int harc_amd_decoder_files(const harc_amd_params *params, const char *basedir, int32_t num_thr_e)
 {
@@ -262,18 +362,31 @@ extern "C" int harc_amd_decoder_files(const harc_amd_params *params, const char 
     harc_amd_ctx *c = nullptr;
     RC_TRY(harc_amd_create(&P, &c));
     struct Guard { harc_amd_ctx *c; ~Guard() { harc_amd_destroy(c); } } guard{ c };
-    FILE *fo = fopen((od + "output.dna").c_str(), "wb");
-    if (!fo) { harc_set_error("cannot create %soutput.dna", od.c_str()); return HARC_AMD_EIO; }
-    struct FG { FILE *f; ~FG() { if (f) fclose(f); } } fg{ fo };
-    std::vector<std::vector<uint8_t>> nparts((size_t)num_thr_e);
+    // output.dna holds one line per read: its length is known before a byte is decoded -- a read per byte of read_pos.txt.<e> (decoder.cpp:96), the singletons
+    // (4 bases per byte + tail, :148-158), input_N.dna as it is (:166-168)
+    const size_t LLo = (size_t)L + 1;
+    size_t total_out = file_size_or_zero(od + "input_N.dna");
+    for (int e = 0; e < num_thr_e; e++) total_out += file_size_or_zero(od + "read_pos.txt." + std::to_string(e)) * LLo;
+    total_out += ((4 * file_size_or_zero(od + "read_singleton.txt") + file_size_or_zero(od + "read_singleton.txt.tail")) / (size_t)L) * LLo;
+    // the N reads of every shard come behind the singletons (decoder.cpp:159-165): they wait in device memory of their own (declared in front of the
+    // drain: it goes after the drain has written what it still holds)
+    struct NParts { harc_amd_ctx *c; std::vector<std::pair<char *, size_t>> v; ~NParts() { for (auto &x : v) if (x.first) harc_raw_free(c, x.first); } } nparts{ c, {} };
+    auto wall = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    const double td0 = wall(); double t_slurp = 0, t_put = 0;
+    FileDrain drain(c);
+    RC_TRY(drain.start(od + "output.dna", total_out));
+    const double td1 = wall();
+    uint64_t out_at = 0;
     unsigned int *d_err = nullptr; RC_TRY(dalloc(c, &d_err, 4));
     HIP_TRY(hipMemsetAsync(d_err, 0, 16, c->stream));
     for (int e = 0; e < num_thr_e; e++) {
         const std::string sfx = "." + std::to_string(e);
         std::vector<uint8_t> seq, seqt, pos, noise, npz, rev, revt;
+        const double ts0 = wall();
         if (!slurp_file(od + "read_seq.txt" + sfx, seq) || !slurp_file(od + "read_seq.txt" + sfx + ".tail", seqt) || !slurp_file(od + "read_pos.txt" + sfx, pos) ||
             !slurp_file(od + "read_noise.txt" + sfx, noise) || !slurp_file(od + "read_noisepos.txt" + sfx, npz) ||
             !slurp_file(od + "read_rev.txt" + sfx, rev) || !slurp_file(od + "read_rev.txt" + sfx + ".tail", revt)) { harc_set_error("shard %d: stream files missing", e); return HARC_AMD_EIO; }
+        t_slurp += wall() - ts0;
         if (pos.empty()) continue;
         if (pos.size() > 0xFFFFFFFFull || 8 * rev.size() + revt.size() != pos.size()) { harc_set_error("shard %d: rev stream does not match pos stream", e); return HARC_AMD_EIO; }
         const harc_mark_t mk = harc_pool_mark(c);
@@ -301,13 +414,15 @@ extern "C" int harc_amd_decoder_files(const harc_amd_params *params, const char 
         uint32_t nN = 0;
         HIP_TRY(hipMemcpyAsync(&nN, rkN + n, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        std::vector<uint8_t> hA((size_t)(n - nN) * LL);
-        nparts[(size_t)e].resize((size_t)nN * LL);
-        if (!hA.empty()) HIP_TRY(hipMemcpyAsync(hA.data(), outA, hA.size(), hipMemcpyDeviceToHost, c->stream));
-        if (nN) HIP_TRY(hipMemcpyAsync(nparts[(size_t)e].data(), outN, nparts[(size_t)e].size(), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (!hA.empty() && fwrite(hA.data(), 1, hA.size(), fo) != hA.size()) { harc_set_error("short write on output.dna"); return HARC_AMD_EIO; }
-        harc_pool_release(c, mk);
+        const size_t bytesA = (size_t)(n - nN) * LL, bytesN = (size_t)nN * LL;
+        if (bytesN) {
+            char *keep = nullptr;
+            RC_TRY(harc_raw_alloc(c, (void **)&keep, bytesN + 16));
+            nparts.v.emplace_back(keep, bytesN);
+            HIP_TRY(hipMemcpyAsync(keep, outN, bytesN, hipMemcpyDeviceToDevice, c->stream));
+        }
+        { const double tp0 = wall(); if (bytesA) { RC_TRY(drain.put(outA, bytesA, out_at)); out_at += bytesA; } t_put += wall() - tp0; }
+        harc_pool_release(c, mk);                                  // (the copies out of outA / outN are on the stream in front of whatever takes their place)
     }
     {   // singletons (decoder.cpp:148-158), then the N reads of every shard (:159-165), then input_N.dna (:166-168)
         std::vector<uint8_t> sg, sgt, nt;
@@ -322,18 +437,19 @@ extern "C" int harc_amd_decoder_files(const harc_amd_params *params, const char 
             RC_TRY(dalloc(c, &lines, (size_t)ns * (L + 1) + 16));
             hipLaunchKernelGGL(k_unpack_seq, G256(nb), d_sg, (uint64_t)sg.size(), d_sgt, (uint64_t)sgt.size(), codes);
             hipLaunchKernelGGL(k_codes_to_lines, G256((uint64_t)ns * (L + 1)), codes, ns, L, lines);
-            std::vector<uint8_t> hs((size_t)ns * (L + 1));
-            HIP_TRY(hipMemcpyAsync(hs.data(), lines, hs.size(), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (fwrite(hs.data(), 1, hs.size(), fo) != hs.size()) { harc_set_error("short write on output.dna"); return HARC_AMD_EIO; }
+            RC_TRY(drain.put(lines, (size_t)ns * (L + 1), out_at)); out_at += (size_t)ns * (L + 1);
             harc_pool_release(c, mk);
         }
-        for (auto &p : nparts) if (!p.empty() && fwrite(p.data(), 1, p.size(), fo) != p.size()) { harc_set_error("short write on output.dna"); return HARC_AMD_EIO; }
-        if (!nt.empty() && fwrite(nt.data(), 1, nt.size(), fo) != nt.size()) { harc_set_error("short write on output.dna"); return HARC_AMD_EIO; }
+        for (auto &p : nparts.v) { RC_TRY(drain.put(p.first, p.second, out_at)); out_at += p.second; }
+        RC_TRY(drain.put_host(nt.data(), nt.size(), out_at)); out_at += nt.size();
     }
+    if (out_at != total_out) { harc_set_error("decoder: %llu bytes decoded, the stream files announce %zu", (unsigned long long)out_at, total_out); return HARC_AMD_EIO; }
     unsigned int err = 0;
     HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const double tf0 = wall();
+    RC_TRY(drain.finish());
+    if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[decoder] %.3f s: output mapped and ring ready %.3f, stream files read %.3f, waiting for ring slices %.3f, last slices written %.3f\n", wall() - td0, td1 - td0, t_slurp, t_put, wall() - tf0);
     if (err) { harc_set_error("decoder: %u reads with inconsistent pos/noise streams", err); return HARC_AMD_EIO; }
     printf("Decoding done\n");                                                 // decoder.cpp:170
     return HARC_AMD_OK;

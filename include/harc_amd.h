@@ -236,6 +236,12 @@ const char *harc_amd_build_id(void);
  * work-items is cut short without an error on this platform).  *visited == n and *index_sum == n (n - 1) / 2 mod 2^64 when every item was visited once. */
 int harc_amd_selftest_launch(harc_amd_ctx *ctx, uint64_t n, uint64_t *visited, uint64_t *index_sum);
 
+/* Where the wall time of this process's last harc_amd_compress_fastq_files_ex went, in seconds (the end-to-end leg of bench.py; preprocess.cpp:81-121 + harc:50-69):
+ * out[0] context + device pool, [1] ingest (file -> HBM -> packed stores; reads, uploads and kernels overlapped), [2] of it the calling thread waiting for
+ * the file reader threads, [3] of it the device's line index / classify / pack passes, [4] reorder, [5] encode (the D2H of the streams inside),
+ * [6] stream files written, [7] total up to there (the -q files of a run without -p come after it).  n = how many of them the caller wants. */
+int harc_amd_last_fastq_timing(double *out, int32_t n);
+
 /* ---- file contract: drop-ins for the reference's stage programs.  basedir as argv[1] of those programs. */
 int harc_amd_reorder_files(const harc_amd_params *params, const char *basedir);
 int harc_amd_encoder_files(const harc_amd_params *params, const char *basedir);

@@ -463,9 +463,14 @@ def test_decoder_matches_reference_decoder(case, tmp_path):
     assert ol.read_dir(base)["output.dna"] == g["decoded.txt"]
 
 
+@pytest.mark.parametrize("slice_bytes,threads", [(0, 0), (300, 7), (65536, 1)])
 @pytest.mark.parametrize("case,K,S,E", [("L100_err_5k", 16, 8, 4), ("L150_err_3k", 8, 16, 3), ("L100_bigbin2_5k", 4, 16, 8), ("L100_allN_20", 2, 4, 2)])
-def test_decoder_matches_oracle_decoder_E_shards(case, K, S, E, oracle, tmp_path):
+def test_decoder_matches_oracle_decoder_E_shards(case, K, S, E, slice_bytes, threads, oracle, tmp_path, monkeypatch):
+    """(slice_bytes: output.dna leaves through verify.hip's FileDrain -- pinned slices, writer threads, a mapping of the file sized from the stream files --
+    with slices of three reads and seven writers, and with one writer)"""
     import harc_amd
+    if slice_bytes:
+        monkeypatch.setenv("HARC_AMD_FEED_SLICE", str(slice_bytes)); monkeypatch.setenv("HARC_AMD_FEED_THREADS", str(threads))
     g = ol.load_golden(case)
     L = _L(g)
     base = ol.stage_dir(tmp_path, {k: g["stage1/" + k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
@@ -960,8 +965,11 @@ def test_preserve_order_decoder_in_small_bins(case, E, bins, tmp_path, monkeypat
         assert (b / "output" / "output.dna").read_bytes() == g["reads.txt"]
 
 
-@pytest.mark.parametrize("case,piece", [("L100_err_5k", 3000), ("L150_err_3k", 700), ("L100_repfam_5k", 100000), ("L100_three", 16)])
-def test_fastq_ingest_in_pieces_is_the_same(case, piece, tmp_path, monkeypatch):
+@pytest.mark.parametrize("case,piece,slice_bytes,threads", [("L100_err_5k", 3000, 0, 0), ("L150_err_3k", 700, 0, 0), ("L100_repfam_5k", 100000, 0, 0), ("L100_three", 16, 0, 0),
+                                                            # the file feeder (ingest.hip FileFeeder: reader threads -> ring of pinned slices -> uploads): pieces of many
+                                                            # slices, more pieces than the ring has slices (hundreds of one-slice pieces read ahead), one reader, many readers
+                                                            ("L100_repfam_5k", 100000, 4096, 3), ("L100_err_5k", 3000, 256, 8), ("L100_err_5k", 3000, 1 << 20, 1), ("L150_err_3k", 100000000, 777, 5)])
+def test_fastq_ingest_in_pieces_is_the_same(case, piece, slice_bytes, threads, tmp_path, monkeypatch):
     """a FASTQ larger than HBM is ingested a piece of whole records at a time (HARC_AMD_INGEST_CHUNK forces pieces of a few records here;
     quality lines that begin with '@' sit at the cuts): same files as the one-piece ingest, -q -p files in file order, truncated last
     record handled as the reference's getline loop does (preprocess.cpp:90-111)"""
@@ -983,6 +991,8 @@ def test_fastq_ingest_in_pieces_is_the_same(case, piece, tmp_path, monkeypatch):
         os.makedirs(base / "output")
         if env:
             monkeypatch.setenv("HARC_AMD_INGEST_CHUNK", env)
+            if slice_bytes:
+                monkeypatch.setenv("HARC_AMD_FEED_SLICE", str(slice_bytes)); monkeypatch.setenv("HARC_AMD_FEED_THREADS", str(threads))
         harc_amd.compress_fastq(str(fq), str(base), L, num_thr=2, num_chains=4, num_steps=16, preserve_order=True, preserve_quality=True)
         outs.append(ol.read_dir(str(base)))
     assert outs[0].keys() == outs[1].keys()
