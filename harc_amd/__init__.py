@@ -6,9 +6,9 @@ programs (``reorder.out`` / ``encoder.out`` / ``pack_order.out`` <basedir>, harc
 There is no CPU fallback: importing works anywhere, every compute call needs a gfx950 device.
 """
 from .api import (HarcAmd, HarcAmdError, Params, Counters, default_params, lib, lib_path, reorder, encoder, compress,
-                  pack_order, preprocess, decoder, compress_fastq, STREAMS, comm_get_id, compress_fastq_shard, merge_shards, build_id, last_fastq_timing)
+                  pack_order, preprocess, decoder, compress_fastq, STREAMS, comm_get_id, compress_fastq_shard, merge_shards, build_id, last_fastq_timing, build_has)
 from ._build import build
 
 __all__ = ["HarcAmd", "HarcAmdError", "Params", "Counters", "default_params", "lib", "lib_path", "reorder", "encoder",
            "compress", "pack_order", "preprocess", "decoder", "compress_fastq", "build", "STREAMS", "comm_get_id", "compress_fastq_shard",
-           "merge_shards", "build_id", "last_fastq_timing"]
+           "merge_shards", "build_id", "last_fastq_timing", "build_has"]

@@ -81,6 +81,7 @@ def lib():
     l.harc_amd_preprocess_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
     l.harc_amd_decoder_files.argtypes = [PP, C.c_char_p, C.c_int32]
     l.harc_amd_compress_fastq_files_ex.argtypes = [PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
+    l.harc_amd_build_has.argtypes = [C.c_char_p]
     l.harc_amd_last_fastq_timing.argtypes = [C.POINTER(C.c_double), C.c_int32]
     l.harc_amd_decoder_preserve_files.argtypes = [PP, C.c_char_p, C.c_int32]
     l.harc_amd_compress_fastq_files.argtypes = [PP, C.c_char_p, C.c_char_p]
@@ -154,6 +155,11 @@ def compress_fastq(fastq, basedir, readlen, num_thr=1, num_chains=1, preserve_or
     (preprocess.cpp:61-118, reorder_quality.cpp)"""
     p = default_params(readlen, num_thr=num_thr, num_chains=num_chains, **kw)
     _check(lib().harc_amd_compress_fastq_files_ex(C.byref(p), os.fsencode(fastq), os.fsencode(basedir), int(preserve_order), int(preserve_quality)))
+
+
+def build_has(feature):
+    """True when the loaded library was built with the optional part `feature` ("grp", "test_transport", "experiments")"""
+    return bool(lib().harc_amd_build_has(feature.encode()))
 
 
 def last_fastq_timing():

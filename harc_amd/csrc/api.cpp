@@ -485,6 +485,20 @@ extern "C" int harc_amd_stream_digest(harc_amd_ctx *c, uint64_t out[4])
 #include "build_id.h"
 extern "C" const char *harc_amd_build_id(void) { return HARC_AMD_BUILD_ID; }
 
+extern "C" int harc_amd_build_has(const char *feature)
+{
+    if (!feature) return 0;
+#ifdef HARC_AMD_WITH_GRP
+    if (!strcmp(feature, "grp")) return 1;
+#endif
+#ifdef HARC_AMD_TEST_TRANSPORT
+    if (!strcmp(feature, "test_transport")) return 1;
+#endif
+#ifdef HARC_AMD_EXPERIMENTS
+    if (!strcmp(feature, "experiments")) return 1;
+#endif
+    return 0;
+}
 extern "C" int harc_amd_get_counters(harc_amd_ctx *c, harc_amd_counters *out)
 {
     if (!c || !out) return HARC_AMD_EINVAL;

@@ -944,7 +944,11 @@ struct WgCmd {
     uint8_t mj[64], mdir[64];        // shift and direction of every probe
     uint32_t own[64];                // reads the chain took earlier in this super-round
 };
-struct WgResult { int besthit, fj, fdir; uint32_t iters, tests, nc; };
+struct WgResult { int besthit, fj, fdir; uint32_t iters, tests, nc;
+#ifdef HARC_SKETCH_STATS
+    uint32_t rej1, rej2, acc;         // experiment (make variant VFLAGS=-DHARC_SKETCH_STATS): tests a 16- / 32-base sketch of the candidate would have rejected; tests that passed
+#endif
+};
 static_assert(sizeof(WgCmd) <= HARC_WGCMD_BYTES, "HARC_WGCMD_BYTES too small");
 // every wave of the workgroup: scan the bin of the command; same order, same maxsearch window as a lane-serial scan (reorder.cpp:540-552).
 // No claim bit is asked for: k_compact_bins runs after the last change of the claim bitmap of a super-round (k_resolve, k_reseed), so every
@@ -957,6 +961,9 @@ template <int W, int NWV> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd
 {
     constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW, CH = HARC_SCAN_CH;
     WgResult r; r.besthit = 64; r.fj = 0; r.fdir = 0; r.iters = 0; r.tests = 0; r.nc = 0;
+#ifdef HARC_SKETCH_STATS
+    r.rej1 = r.rej2 = r.acc = 0;
+#endif
     const uint32_t *oids = ids[cmd->l];
     const uint32_t ids0 = cmd->ids0, m0 = cmd->m0;
     const int t = cmd->t; const bool fast = cmd->fast != 0;
@@ -1008,6 +1015,15 @@ template <int W, int NWV> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd
             for (int c = 0; c < CH; c++) {
                 ok[c] = false;
                 if (cand[c]) { r.nc++; ok[c] = ham_window<W>(rowF, obit, omrow, mrd[c]) <= thresh; }
+#ifdef HARC_SKETCH_STATS
+                if (cand[c]) {   // the Hamming distance over any part of the overlap is a lower bound of the distance over all of it: would 16 / 32 bases of the candidate
+                                 // that every probe of this direction overlaps (forward: the first ones; reverse: bases 16 (NW - 4) ... of a read of >= 16 (NW - 2) + 50 bases) have settled it?
+                    const int i0 = obit >> 5, sh = obit & 31, k0 = g_dir ? NW - 4 : 0;
+                    const int p1 = __popc((__builtin_amdgcn_alignbit(rowF[i0 + k0 + 1], rowF[i0 + k0], sh) ^ mrd[c][k0]) & omrow[k0]);
+                    const int p2 = p1 + __popc((__builtin_amdgcn_alignbit(rowF[i0 + k0 + 2], rowF[i0 + k0 + 1], sh) ^ mrd[c][k0 + 1]) & omrow[k0 + 1]);
+                    r.rej1 += p1 > thresh; r.rej2 += p2 > thresh; r.acc += ok[c];
+                }
+#endif
                 anyok |= ok[c];
             }
             if (anyok && !ownknown) {
@@ -1272,6 +1288,9 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
             if (cmd->op == 0) break;
             const WgResult r = wg_scan<W, NWV>(cmd, role, lane, idp, s.mirror, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh);
             hnc += r.nc;
+#ifdef HARC_SKETCH_STATS
+            if (s.dbg) { const uint32_t a1 = wave_sum_u32(r.rej1), a2 = wave_sum_u32(r.rej2), a3 = wave_sum_u32(r.acc), a0 = wave_sum_u32(r.nc); if (lane == 0) { atomicAdd(&s.dbg[44], (unsigned long long)a0); atomicAdd(&s.dbg[45], (unsigned long long)a1); atomicAdd(&s.dbg[46], (unsigned long long)a2); atomicAdd(&s.dbg[47], (unsigned long long)a3); } }
+#endif
         }
         hnc = wave_sum_u32(hnc);
         if (lane == 0 && hnc) { atomicAdd(&s.cstat_coop[blockIdx.x].y, hnc); atomicAdd(&s.cstat_coop[blockIdx.x].w, hnc); }
@@ -1717,6 +1736,9 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                     const uint32_t *const idp[2] = { s.ids[0], s.ids[1] };
                     const WgResult wr = wg_scan<W, NWV>(cmd, 0, lane, idp, s.mirror, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh);
                     dbg_iter += wr.iters; dbg_surv += wr.tests; nc += wr.nc; ncu += wr.nc;
+#ifdef HARC_SKETCH_STATS
+                    if (s.dbg) { const uint32_t a1 = wave_sum_u32(wr.rej1), a2 = wave_sum_u32(wr.rej2), a3 = wave_sum_u32(wr.acc), a0 = wave_sum_u32(wr.nc); if (lane == 0) { atomicAdd(&s.dbg[44], (unsigned long long)a0); atomicAdd(&s.dbg[45], (unsigned long long)a1); atomicAdd(&s.dbg[46], (unsigned long long)a2); atomicAdd(&s.dbg[47], (unsigned long long)a3); } }
+#endif
                     const int besthit = wr.besthit;
                     if (besthit < 64) { found = cmd->found; fj = wr.fj; fdir = wr.fdir; fhd = -1; }     // the helpers' scan does not report the distance
                     if (besthit < 64) { winlane = besthit; bigm &= (1ULL << besthit) - 1ULL; }
@@ -1848,7 +1870,12 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     }
 }
 
-#include "steps_group.h"       // k_steps_grp: the dense SPEC kernel with two chains per wave (round 5)
+// k_steps_grp (steps_group.h): the dense SPEC kernel with two to four chains per wave, round 5's structural attempt -- byte-identical, 1001 us per launch
+// against k_steps' 992 and 18 % slower at 1 % errors.  Not part of the default build since round 6 (`make GRP=1` compiles it in, HARC_AMD_GRP=1 / 2 then
+// selects it, and the tests that ask for it run; harc_amd_build_has("grp") tells).
+#ifdef HARC_AMD_WITH_GRP
+#include "steps_group.h"
+#endif
 
 // ---- design (R): replicate the reads and the index, partition the chains (harc_amd_replicate_exchange).  Everything a super-round
 // changes outside the walking wave's own state is either recomputed identically on every rank (k_resolve, k_reseed, the compaction of the
@@ -2692,7 +2719,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // it.  No count taken DURING the run tells such an input early enough (the share of walks that end at a lost bid is 0.4 % after 16 rounds there as on
     // clean data, 20 % only after a thousand: profiles/r05/s_choice_trace.txt), so the choice is made from the index, below: 32 only where the bins of more
     // than HARC_LARGEBIN reads hold less than 2 % of N entries (clean inputs: none), 16 otherwise.  A function of the input alone, like the chain count.
-    const bool steps_auto32 = P.num_steps <= 0 && K > 16384 && !(getenv("HARC_AMD_GRP") && atoi(getenv("HARC_AMD_GRP")) != 0);
+    const bool steps_auto32 = P.num_steps <= 0 && K > 16384;     // (a function of the input alone: no environment variable changes S -- k_steps_grp walks at most 16 steps and leaves S = 32 to k_steps)
     if (steps_auto32) nsteps = 32;
     if (nsteps > 64) nsteps = 64;
     // few chains -> every launch is a chain of dependent HBM round trips: fetch whole buckets; many chains -> request-rate bound: single slots
@@ -2952,6 +2979,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
                       bloom_mmask == 0xFFFFFFFFu && (dict[0].cap >> 34) == 0 && P.maxsearch >= (int)HARC_LARGEBIN && a.firstmax == 64;
     // two chains per wave (k_steps_grp, steps_group.h): the dense SPEC conditions, at most 32 steps and look-ahead seeds per group of 32 lanes.
     // HARC_AMD_GRP=1 asks for it wherever it can run, =0 never (same bytes either way: tests)
+#ifdef HARC_AMD_WITH_GRP
     const bool grp_ok = (W == 4 || W == 5) && dense && !quad && spec && !backoff && nsteps <= 16 && a.nsugg_per_seed <= 16 && a.nsugg_stride <= 16 && (dict[0].cap >> 32) == 0;
     bool grp = grp_ok && (getenv("HARC_AMD_GRP") ? atoi(getenv("HARC_AMD_GRP")) != 0 : false);
     if (getenv("HARC_AMD_GRP") && atoi(getenv("HARC_AMD_GRP")) == 2 && !grp) {      // tests: the kernel asked for must be the kernel that runs
@@ -2984,8 +3012,14 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] k_steps_grp: %d lanes per chain, %d probes per lane and batch, %d workgroups per compute unit x %d\n", grp_g, grp_u, per_cu, ncu);
         }
     }
+#else
+    const bool grp = false;
+    if (getenv("HARC_AMD_GRP") && atoi(getenv("HARC_AMD_GRP")) == 2) { harc_set_error("HARC_AMD_GRP=2: k_steps_grp is not compiled into this library (make GRP=1)"); return HARC_AMD_EINVAL; }
+#endif
     if (grp && !getenv("HARC_AMD_WEEDMIN")) a.weedmin = 99;     // with several chains per wave the look at the claim bitmap ahead of the tests is one more trip for everybody: 1090 -> 1066 us per wave
+#ifdef HARC_AMD_WITH_GRP
     bool grp_wide_seen = getenv("HARC_AMD_GRP_WIDE") && atoi(getenv("HARC_AMD_GRP_WIDE")) != 0; uint64_t grp_rounds = 0;
+#endif
     int seq_probe = (!getenv("HARC_AMD_SEQ") && HARC_SEQ_SCAN && dense && !quad && seq && !grp) ? 0 : 2;      // 0 / 1: the batch being timed, 2: decided
     float seq_ms[2] = { 0, 0 };
     // ... once per context and input shape: a later run over as many reads of the same length with the same schedule starts with the scan the earlier one
@@ -3016,6 +3050,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
             if (cm) hipLaunchKernelGGL(k_apply_seed, dim3(nblk), dim3(256), 0, c->stream, a);          // the seeds of the chains other ranks walk
             if (prof) { RC_TRY(R.dense.next_pair(&pair)); HIP_TRY(hipEventRecord(pair[0], c->stream)); }
             if (quad) hipLaunchKernelGGL((k_steps<W, true, false>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
+#ifdef HARC_AMD_WITH_GRP
             else if (grp) {
                 if constexpr (W == 4 || W == 5) {
                     // a persistent grid: as many workgroups as the chip holds at once (its groups take further chains by ticket), fewer when there are fewer chains
@@ -3026,6 +3061,7 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
                     grp_rounds++;
                 }
             }
+#endif
             else if (dense && seq && spec) hipLaunchKernelGGL((k_steps<W, false, false, true, 4, true, true>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
             else if (dense && seq) hipLaunchKernelGGL((k_steps<W, false, false, true, 4, true>), dim3((K + 3) / 4), dim3(256), lds_bytes_seq, c->stream, a);
             else if (dense) hipLaunchKernelGGL((k_steps<W, false, false, true>), dim3((K + 3) / 4), dim3(256), lds_bytes, c->stream, a);
@@ -3080,10 +3116,12 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipGetLastError());
+#ifdef HARC_AMD_WITH_GRP
         if (grp) {
             if (h_stats[ST_WIDE]) grp_wide_seen = true;
             if (h_stats[ST_WIDE + 1]) { harc_set_error("stage I: %llu chains with wide counts were left unwalked by k_steps_grp (super-round %llu)", h_stats[ST_WIDE + 1], (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
         }
+#endif
         if (*h_reseed_timeout) { harc_set_error("stage I: the workgroups of k_reseed_mg did not meet (super-round %llu); HARC_AMD_RESEED_MG=0 uses the single workgroup", (unsigned long long)rounds); return HARC_AMD_EINTERNAL; }
         // what this rank would run next, from its own clock and counters: which scan of the small bins (measured over the first two batches) and how
         // many waves per cooperative workgroup.  Every variant computes the same bytes; design (R) still runs rank 0's choice on all ranks (below), so
@@ -3201,6 +3239,10 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     if (a.dbg) {
         unsigned long long d[48];
         HIP_TRY(hipMemcpy(d, dbg_ptr, sizeof d, hipMemcpyDeviceToHost));
+#ifdef HARC_SKETCH_STATS
+        fprintf(stderr, "[sketch] Hamming tests of the cooperative scans: %llu; passed %llu (%.3f %%); a 16-base sketch would have rejected %llu (%.1f %%), a 32-base sketch %llu (%.1f %%)\n", d[44], d[47], 100.0 * (double)d[47] / (double)(d[44] ? d[44] : 1),
+                d[45], 100.0 * (double)d[45] / (double)(d[44] ? d[44] : 1), d[46], 100.0 * (double)d[46] / (double)(d[44] ? d[44] : 1));
+#endif
         const double stp = (double)(d[4] ? d[4] : 1);
         fprintf(stderr, "[k_steps] steps walked %llu (of them kept %u): per step batches %.2f, cooperative bin scans %.2f, their 64-entry chunks %.2f, chunk x probe tests %.2f; steps without a hit %.3f\n", d[4], N, d[5] / stp, d[0] / stp, d[1] / stp, d[3] / stp, d[2] / stp);
         fprintf(stderr, "[k_steps] worst walk of the run: %llu chunks, %llu chunk x probe tests, %llu bin scans\n", d[6], d[7], d[8]);

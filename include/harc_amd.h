@@ -232,6 +232,9 @@ int harc_amd_input_signature(harc_amd_ctx *ctx, uint64_t sig[3]);           /* o
 int harc_amd_stream_digest(harc_amd_ctx *ctx, uint64_t out[4]);
 /* sha256 (hex) of the kernel sources this library was built from: ties a committed profile (profiles/k_steps_traffic.json) to a build */
 const char *harc_amd_build_id(void);
+/* 1 when this library was built with the named optional part: "grp" (make GRP=1: k_steps_grp, the walk with several chains per wave), "test_transport"
+ * (the file-mailbox transport of the one-GPU multi-rank tests), "experiments" (schedule constants from the environment); 0 otherwise */
+int harc_amd_build_has(const char *feature);
 /* Self-test of the library's launch geometry (one thread per item over n items through harc_gid / harc_gid32, and four lanes per item in folded workgroups, n beyond 2^32 included: a one-dimensional grid of 2^32 and more
  * work-items is cut short without an error on this platform).  *visited == n and *index_sum == n (n - 1) / 2 mod 2^64 when every item was visited once. */
 int harc_amd_selftest_launch(harc_amd_ctx *ctx, uint64_t n, uint64_t *visited, uint64_t *index_sum);

@@ -44,6 +44,8 @@ def _synth_text(n, L, G, err, seed):
     ("configs0", 1_000_000, 100, 35_000_000, 0.0, 8, True, {"HARC_AMD_QUAD": "0", "HARC_AMD_DENSE": "1", "HARC_AMD_RESEED_MG": "1", "HARC_AMD_S1BLOOM_TILED": "1", "HARC_AMD_S1BLOOM_VERIFY": "1"})])
 def test_config_size_matches_oracle(name, n, L, G, err, E, expect_lowcov, env, oracle, tmp_path, monkeypatch):
     import harc_amd
+    if "HARC_AMD_GRP" in env and not harc_amd.build_has("grp"):
+        pytest.skip("k_steps_grp is not in this build (make -C harc_amd/csrc GRP=1)")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     txt = _synth_text(n, L, G, err, 20260 + n % 97)

@@ -37,6 +37,8 @@ def assert_same(got, want, files, what):
 def test_stage1_K1_matches_reference(case, env, tmp_path, monkeypatch):
     """exact mode: by default through the successor lists (k_succ) and with k_resolve + k_reseed in one launch; without the lists; with two launches"""
     import harc_amd
+    if "HARC_AMD_GRP" in env and not harc_amd.build_has("grp"):
+        pytest.skip("k_steps_grp is not in this build (make -C harc_amd/csrc GRP=1)")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     g = ol.load_golden(case)
@@ -351,6 +353,8 @@ def test_kernel_variants_same_bytes(env, oracle, tmp_path, monkeypatch):
     minimizer, with / without the bitmaps, the table cleared by a memset or by the placement itself, the index sorted on its top 8 / 13 bits with the mixed stretches fixed up, on 1 bit (stretches too long: falls back to all 64) and on all bits, the stage-I bitmap built tile by tile from sorted keys instead of with atomics (and compared with it word for word), the column counts applied step by step instead of a run of agreeing steps at once (HARC_AMD_LAZY=0), stage-II bitmap kinds, a fuller table, 1 / 2 / 4 waves per cooperative workgroup) are execution details: forced on a small repeat-rich
     input, every stage-I and stage-II file is the oracle's"""
     import harc_amd
+    if "HARC_AMD_GRP" in env and not harc_amd.build_has("grp"):
+        pytest.skip("k_steps_grp is not in this build (make -C harc_amd/csrc GRP=1)")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     txt = gen.reads_text_lowcomplexity(99, 20000, 100, 50000, err=0.004)
