@@ -736,7 +736,11 @@ template <int W> struct StepsLds {
 #ifndef HARC_SCAN_CH
 #define HARC_SCAN_CH 1                // chunks of 256 bin entries the cooperative scan fetches per round trip (see wg_scan)
 #endif
-#define HARC_WGCMD_BYTES 1280          // >= sizeof(WgCmd), checked where the struct is defined
+#define HARC_WGCMD_BYTES 3584          // >= sizeof(WgCmd), checked where the struct is defined
+#define HARC_SK_E 4                    // wg_scan_sk: bin entries per lane and round trip (their 8-byte sketches fill the registers ONE whole read took)
+#ifndef HARC_SCAN_SKETCH
+#define HARC_SCAN_SKETCH 1             // the cooperative kernel scans large bins by sketch (wg_scan_sk); 0 (make variant): whole reads, 64 entries per wave and trip (wg_scan)
+#endif
 // the reads a chain has taken in the running super-round (they are not in the frozen claim bitmap yet), as a hash table in LDS: 128 slots per wave for
 // at most 64 of them.  The wave-uniform scan weeds them out of its candidates by all lanes at once; walking the wave's register copy with
 // v_readlane (one per read taken so far, every batch) was ~40 of the ~460 vector instructions of a step
@@ -770,7 +774,7 @@ static inline size_t steps_lds_bytes_coop(int W, int maxmatch, int nprobe)
 static inline size_t steps_lds_bytes(int W, int maxmatch, int nprobe, bool seq = false)
 {
     const int NW = 2 * W, ROW = 3 * NW + 1, MROW = (NW + 3) & ~3;
-    return (size_t)4 * (64 * ((W + 1) / 2)) * 16 + ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)4 * 32 + (size_t)(seq ? 4 * HARC_OWN_SLOTS : 0) + (size_t)2 * nprobe + 8) * 4 + HARC_WGCMD_BYTES + 16;
+    return (size_t)4 * (64 * ((W + 1) / 2)) * 16 + ((size_t)2 * maxmatch * MROW + (size_t)4 * 2 * ROW + (size_t)4 * MROW + (size_t)4 * 8 * NW + (size_t)4 * 32 + (size_t)(seq ? 4 * HARC_OWN_SLOTS : 0) + (size_t)2 * nprobe + 8) * 4 + 32;      // (no command block: only the cooperative kernel scans by workgroup)
 }
 // Hamming distance between a candidate read (registers) and the consensus shifted by the lane's own amount: `row` = ref or rref window
 // row in LDS, bitoff = 32 NW +- 2j, mrow = mask row of (direction, shift) (reorder.cpp:543,608 with mask[j] / revmask[j] of :706-718)
@@ -943,6 +947,11 @@ struct WgCmd {
     unsigned long long um[2][HARC_SCAN_CH][4];     // which entries of each wave count for the maxsearch window
     uint8_t mj[64], mdir[64];        // shift and direction of every probe
     uint32_t own[64];                // reads the chain took earlier in this super-round
+    // wg_scan_sk (the scan by sketch): which entries of every (quarter, wave) count for the maxsearch window; every wave's earliest hit; every wave's queue of
+    // the entries whose sketch did not settle them
+    unsigned long long um4[2][HARC_SK_E][4];
+    uint32_t best[2][4];
+    uint16_t queue[4][64 * HARC_SK_E];
 };
 struct WgResult { int besthit, fj, fdir; uint32_t iters, tests, nc;
 #ifdef HARC_SKETCH_STATS
@@ -1080,6 +1089,163 @@ template <int W, int NWV> __device__ __forceinline__ WgResult wg_scan(WgCmd *cmd
         }
         if (!fast) seen += total;
         pos -= pos - lo > 64u * NWV * CH ? 64u * NWV * CH : pos - lo;
+    }
+    __syncthreads();                                               // the winner's words are in place; the command block is free for the next scan
+    return r;
+}
+
+// ---- the same scan BY SKETCH (round 6).  On repeat-rich input nearly every Hamming test of these scans fails: configs[2] with human-like repeats makes
+//      1.56e11 of them per step and 0.22 % pass (profiles/r06/sketch_rejection_c3r.txt) -- up to maxsearch of them per probe into a bin of a diverged
+//      repeat family is what reorder.cpp:540-556 asks for -- and a walk waits a trip to L2 per 64 NWV entries: sixteen dependent trips through a bin of a
+//      thousand with one wave per walk (the shape the kernel takes at 33 000 walks per super-round).  The Hamming distance over ANY part of the overlap is a
+//      lower bound of the distance over all of it: a lane fetches, of HARC_SK_E = 4 entries at once, only the two dwords of the read that every probe of the
+//      direction overlaps (forward: bases 0..31; reverse: the 32 bases from dword NW - 4 on) -- as many registers as ONE whole read -- and 83 % of the
+//      entries are settled there, exactly.  The survivors are queued in LDS in priority order and take the whole test, a lane each, in a second trip:
+//      two dependent trips per 256 NWV entries instead of four, a quarter of the barriers.  Same order, same maxsearch window, same winner as wg_scan:
+//      the bytes are the oracle's either way (make variant VFLAGS=-DHARC_SCAN_SKETCH=0 builds the other one; both are held to the oracle by the suite).
+template <int W, int NWV> __device__ __forceinline__ WgResult wg_scan_sk(WgCmd *cmd, int role, int lane, const uint32_t *const *ids, const uint64_t *mirror,
+                                                               const uint32_t *rowF, const uint32_t *s_mask, uint32_t *rdl, int maxsearch, int maxmatch, int thresh)
+{
+    constexpr int NW = StepsLds<W>::NW, ROW = StepsLds<W>::ROW, MROW = StepsLds<W>::MROW, E = HARC_SK_E;
+    constexpr int K0R = NW >= 4 ? NW - 4 : 0;                     // reverse probes keep the bits from 2j on, j < maxmatch <= L / 2: these two dwords lie behind every j
+    WgResult r; r.besthit = 64; r.fj = 0; r.fdir = 0; r.iters = 0; r.tests = 0; r.nc = 0;
+#ifdef HARC_SKETCH_STATS
+    r.rej1 = r.rej2 = r.acc = 0;
+#endif
+    const uint32_t *oids = ids[cmd->l];
+    const uint32_t ids0 = cmd->ids0, m0 = cmd->m0;
+    const int t = cmd->t; const bool fast = cmd->fast != 0;
+    unsigned long long grp = cmd->grp;
+    // the chain's own reads of this super-round (they are not in the frozen claim bitmap): asked for an entry only when its id lies between the smallest and the largest of them
+    uint32_t omin = 0xFFFFFFFFu, omax = 0u;
+    for (int k = 0; k < t; k++) { const uint32_t x = cmd->own[k]; omin = x < omin ? x : omin; omax = x > omax ? x : omax; }
+    auto is_own = [&](uint32_t rid) -> bool { bool o = false; if (rid >= omin && rid <= omax) for (int k = 0; k < t; k++) o |= (cmd->own[k] == rid); return o; };
+    uint16_t *const queue = cmd->queue[role];
+    int seen = 0, par = 0;
+    const uint32_t rot = cmd->rot;                                // (the two segments of wg_scan: schedule rule of round 3)
+    uint32_t pos = cmd->cnt - rot, lo = 0; bool second = rot == 0;
+    for (;;) {
+        if (pos == lo) { if (second) break; second = true; pos = cmd->cnt; lo = cmd->cnt - rot; }
+        if (!(seen < maxsearch && grp)) break;
+        r.iters++;
+        // entry off = (e NWV + role) 64 + lane from the top of what is left of the segment: priority = (e, role, lane) = ascending off
+        unsigned long long um[E];                                  // per quarter: the lanes whose entry counts for the window (valid, not the chain's own)
+        uint2 sk[E];
+        const unsigned long long gfirst = grp & (0ULL - grp);
+        const int dir0 = cmd->mdir[__ffsll((long long)gfirst) - 1];      // the probes into one bin share key and dictionary; their direction differs only for a palindromic window
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t off = 64u * (uint32_t)(e * NWV + role) + (uint32_t)lane;
+            const bool valid = off < pos - lo;
+            bool un = valid; sk[e] = make_uint2(0u, 0u);
+            if (valid) {
+                const uint32_t at = pos - 1 - off;
+                const uint32_t *row = reinterpret_cast<const uint32_t *>(mirror + (size_t)(m0 + at) * W);
+                sk[e] = *reinterpret_cast<const uint2 *>(row + (dir0 ? K0R : 0));
+                if (!fast && t > 0) un = !is_own(oids[ids0 + at]);    // above maxsearch the chain's own reads do not count for the window either: asked of every entry
+            }
+            um[e] = __ballot(un);
+        }
+        // the maxsearch window (reorder.cpp:540): entries that count, in priority order, up to maxsearch of them.  While the bin fits the window it never closes.
+        unsigned long long cm[E];                                  // candidates: count and lie inside the window
+        int total = 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) cm[e] = um[e];
+        if (!fast) {
+            if (NWV > 1) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int e = 0; e < E; e++) cmd->um4[par][e][role] = um[e];
+                }
+                __syncthreads();
+            }
+            int before[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                before[e] = total;
+                for (int w = 0; w < NWV; w++) { const int x = NWV > 1 ? __popcll(cmd->um4[par][e][w]) : __popcll(um[e]); if (w < role) before[e] += x; total += x; }
+            }
+            if (NWV > 1) par ^= 1;
+            if (seen + total > maxsearch) {                        // the window closes inside this stretch: exact ranks
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int rank = seen + before[e] + __popcll(um[e] & ((1ULL << lane) - 1ULL));
+                    cm[e] = __ballot(((um[e] >> lane) & 1ULL) && rank < maxsearch);
+                }
+            }
+        }
+        unsigned long long gm = grp; r.tests += (uint32_t)__popcll(grp);
+        while (gm) {                                               // the probes of this bin, highest priority first
+            const int g = __ffsll((long long)gm) - 1;
+            gm &= gm - 1;
+            const int g_j = cmd->mj[g], g_dir = cmd->mdir[g];
+            const uint32_t *const omrow = s_mask + (size_t)(g_dir * maxmatch + g_j) * MROW;
+            const int obit = g_dir * ROW * 32 + 32 * NW + (g_dir ? -2 * g_j : 2 * g_j);
+            // (1) the sketch: two dwords of the candidate against the same two of the shifted consensus, under the probe's mask
+            unsigned long long sm[E]; int nsurv = 0;
+            {
+                const int i0 = obit >> 5, sh = obit & 31, k0 = g_dir ? K0R : 0;
+                const bool same = g_dir == dir0;                   // (else this probe's dwords were not fetched: nothing is settled by sketch)
+                const uint32_t cA = __builtin_amdgcn_alignbit(rowF[i0 + k0 + 1], rowF[i0 + k0], sh), cB = __builtin_amdgcn_alignbit(rowF[i0 + k0 + 2], rowF[i0 + k0 + 1], sh);
+                const uint32_t mA = omrow[k0], mB = omrow[k0 + 1];
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const bool c = (cm[e] >> lane) & 1ULL;
+                    const int lb = __popc((cA ^ sk[e].x) & mA) + __popc((cB ^ sk[e].y) & mB);
+                    if (c) r.nc++;
+                    sm[e] = __ballot(c && (!same || lb <= thresh));
+                    // the survivors of this wave, in priority order, into its queue
+                    if ((sm[e] >> lane) & 1ULL) queue[nsurv + __popcll(sm[e] & ((1ULL << lane) - 1ULL))] = (uint16_t)(64u * (uint32_t)(e * NWV + role) + (uint32_t)lane);
+                    nsurv += __popcll(sm[e]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // (2) the survivors take the whole test, a lane each; the earliest one that passes (and is not the chain's own) is this wave's hit
+            uint32_t mybest = 0xFFFFFFFFu, myrid = HARC_NONE; uint32_t full[NW];
+            for (int b = 0; b < nsurv; b += 64) {
+                const int i = b + lane;
+                bool ok = false; uint32_t o = 0, rid = 0;
+                if (i < nsurv) {
+                    o = queue[i];
+                    const uint32_t at = pos - 1 - o;
+                    load_read32<W>(mirror, m0 + at, full);
+                    ok = ham_window<W>(rowF, obit, omrow, full) <= thresh;
+                    if (ok) { rid = oids[ids0 + at]; if (fast && t > 0) ok = !is_own(rid); }      // (below maxsearch the own reads are only asked for what passes)
+#ifdef HARC_SKETCH_STATS
+                    r.acc += ok;
+#endif
+                }
+                const unsigned long long pm = __ballot(ok);
+                if (pm) {
+                    const int wl = __ffsll((long long)pm) - 1;
+                    mybest = (uint32_t)__builtin_amdgcn_readlane((int)o, wl);
+                    if (lane == wl) myrid = rid; else myrid = HARC_NONE;      // the lane that holds the winner's words keeps them in `full`
+                    break;
+                }
+            }
+            // (3) the earliest hit of the workgroup
+            uint32_t wbest = mybest; int wrole = role;
+            if (NWV > 1) {
+                if (lane == 0) cmd->best[par][role] = mybest;
+                __syncthreads();
+                wbest = 0xFFFFFFFFu; wrole = 0;
+                for (int w = 0; w < NWV; w++) { const uint32_t x = cmd->best[par][w]; if (x < wbest) { wbest = x; wrole = w; } }
+                par ^= 1;
+            }
+            if (wbest != 0xFFFFFFFFu) {
+                if (role == wrole && myrid != HARC_NONE) {
+#pragma unroll
+                    for (int k = 0; k < NW; k++) rdl[k] = full[k];
+                    cmd->found = myrid;
+                }
+                r.fj = g_j; r.fdir = g_dir; r.besthit = g;
+                grp &= (1ULL << g) - 1ULL;                         // this probe is settled, the ones behind it are beaten; the ones before it go on
+                break;
+            }
+        }
+        if (!fast) seen += total;
+        pos -= pos - lo > 64u * NWV * E ? 64u * NWV * E : pos - lo;
     }
     __syncthreads();                                               // the winner's words are in place; the command block is free for the next scan
     return r;
@@ -1286,7 +1452,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         for (;;) {
             __syncthreads();
             if (cmd->op == 0) break;
-            const WgResult r = wg_scan<W, NWV>(cmd, role, lane, idp, s.mirror, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh);
+            const WgResult r = HARC_SCAN_SKETCH ? wg_scan_sk<W, NWV>(cmd, role, lane, idp, s.mirror, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh)
+                                                : wg_scan<W, NWV>(cmd, role, lane, idp, s.mirror, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh);
             hnc += r.nc;
 #ifdef HARC_SKETCH_STATS
             if (s.dbg) { const uint32_t a1 = wave_sum_u32(r.rej1), a2 = wave_sum_u32(r.rej2), a3 = wave_sum_u32(r.acc), a0 = wave_sum_u32(r.nc); if (lane == 0) { atomicAdd(&s.dbg[44], (unsigned long long)a0); atomicAdd(&s.dbg[45], (unsigned long long)a1); atomicAdd(&s.dbg[46], (unsigned long long)a2); atomicAdd(&s.dbg[47], (unsigned long long)a3); } }
@@ -1734,7 +1901,8 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                     }
                     __syncthreads();                                           // the helpers start
                     const uint32_t *const idp[2] = { s.ids[0], s.ids[1] };
-                    const WgResult wr = wg_scan<W, NWV>(cmd, 0, lane, idp, s.mirror, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh);
+                    const WgResult wr = HARC_SCAN_SKETCH ? wg_scan_sk<W, NWV>(cmd, 0, lane, idp, s.mirror, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh)
+                                                         : wg_scan<W, NWV>(cmd, 0, lane, idp, s.mirror, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh);
                     dbg_iter += wr.iters; dbg_surv += wr.tests; nc += wr.nc; ncu += wr.nc;
 #ifdef HARC_SKETCH_STATS
                     if (s.dbg) { const uint32_t a1 = wave_sum_u32(wr.rej1), a2 = wave_sum_u32(wr.rej2), a3 = wave_sum_u32(wr.acc), a0 = wave_sum_u32(wr.nc); if (lane == 0) { atomicAdd(&s.dbg[44], (unsigned long long)a0); atomicAdd(&s.dbg[45], (unsigned long long)a1); atomicAdd(&s.dbg[46], (unsigned long long)a2); atomicAdd(&s.dbg[47], (unsigned long long)a3); } }
