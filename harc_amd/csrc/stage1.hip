@@ -2565,19 +2565,27 @@ template <int W> __global__ __launch_bounds__(1024) void k_compact_huge(S1Args s
     uint32_t out = A;
     for (uint32_t pos = A; pos < cnt; pos += 1024) {
         const bool valid = pos + t < cnt;
-        uint32_t rid = 0; bool un = false; uint64_t rw[W];
-        if (valid) {
-            rid = ids[pos + t]; un = !((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL);
-#pragma unroll
-            for (int w = 0; w < W; w++) rw[w] = mir[(size_t)(pos + t) * W + w];
-        }
-        __builtin_amdgcn_s_waitcnt(0);                            // every entry of the pass has arrived ...
-        uint32_t total; const uint32_t off = block_excl_scan_u32<1024>(un ? 1u : 0u, sm, &total);     // ... before anybody passes the barriers in here
-        if (un) {
+        uint32_t rid = 0; bool un = false;
+        if (valid) { rid = ids[pos + t]; un = !((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL); }
+        uint32_t total; const uint32_t off = block_excl_scan_u32<1024>(un ? 1u : 0u, sm, &total);
+        // (round 6, as k_compact_bins: words fetched and entries written only where something moves -- uniform for the workgroup: the pass starts behind
+        // `out`, or drops an entry)
+        const uint32_t nvalid = cnt - pos < 1024u ? cnt - pos : 1024u;
+        if (out != pos || total != nvalid) {
             const uint32_t at = out + off;                        // out <= pos: never ahead of the entries of this pass
-            ids[at] = rid;
+            const bool moves = un && at != pos + (uint32_t)t;
+            uint64_t rw[W];
+            if (moves) {
 #pragma unroll
-            for (int w = 0; w < W; w++) mir[(size_t)at * W + w] = rw[w];
+                for (int w = 0; w < W; w++) rw[w] = mir[(size_t)(pos + t) * W + w];
+            }
+            __builtin_amdgcn_s_waitcnt(0);                        // every entry that moves has arrived ...
+            __syncthreads();                                      // ... in every wave, before the first one of the pass is overwritten
+            if (moves) {
+                ids[at] = rid;
+#pragma unroll
+                for (int w = 0; w < W; w++) mir[(size_t)at * W + w] = rw[w];
+            }
         }
         out += total;
     }
@@ -2601,21 +2609,27 @@ template <int W> __global__ __launch_bounds__(64) void k_compact_bins(S1Args s, 
     const uint2 lt = s.largetab[b];                               // the slot's `start` is b (k_large_fill)
     uint32_t *ids = const_cast<uint32_t *>(s.ids[l]) + lt.x;
     uint64_t *mir = s.mirror + (size_t)lt.y * W;
+    // (round 6: the words of an entry are fetched -- and id and words written -- only where the entry MOVES.  Most bins lose nothing in a super-round: every
+    // round read 36 bytes and wrote 36 per entry of every live large bin, 108 us per round at configs[2] with repeats, 1312 rounds a step)
     uint32_t out = 0;
     for (uint32_t pos = 0; pos < cnt; pos += 64) {
         const bool valid = pos + lane < cnt;
-        uint32_t rid = 0; bool un = false; uint64_t rw[W];
-        if (valid) {
-            rid = ids[pos + lane]; un = !((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL);
-#pragma unroll
-            for (int w = 0; w < W; w++) rw[w] = mir[(size_t)(pos + lane) * W + w];
-        }
+        uint32_t rid = 0; bool un = false;
+        if (valid) { rid = ids[pos + lane]; un = !((s.claimed[rid >> 6] >> (rid & 63)) & 1ULL); }
         const unsigned long long um = __ballot(un);
         const uint32_t at = out + (uint32_t)__popcll(um & ((1ULL << lane) - 1ULL));     // out <= pos: never ahead of the entries of this pass
-        if (un) {
-            ids[at] = rid;
+        const bool moves = un && at != pos + (uint32_t)lane;
+        if (__ballot(moves)) {
+            uint64_t rw[W];
+            if (moves) {
 #pragma unroll
-            for (int w = 0; w < W; w++) mir[(size_t)at * W + w] = rw[w];
+                for (int w = 0; w < W; w++) rw[w] = mir[(size_t)(pos + lane) * W + w];
+            }
+            if (moves) {                                           // (every lane's words are in its registers before the first store of the wave is issued)
+                ids[at] = rid;
+#pragma unroll
+                for (int w = 0; w < W; w++) mir[(size_t)at * W + w] = rw[w];
+            }
         }
         out += (uint32_t)__popcll(um);
     }
