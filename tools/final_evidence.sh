@@ -4,7 +4,7 @@
 #   PMC passes of the default command FIRST, so that the bench lines that follow can say `traffic_stale: false` for their own library; the default line
 #   twice (as the driver runs it, and with 20 timed steps); kernel tables of configs[2] / [3] / [4]'s share; the repeat workloads; the small ones; the GPU suite.
 #   tools/final_evidence.sh <tag> a|b      (two calls: a gpurun call lasts at most 20 minutes; a = counters, default lines, kernel tables; b = the other workloads, the suite)
-R=${1:-r05f}; PART=${2:-a}
+R=${1:-r06f}; PART=${2:-a}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$ROOT"; mkdir -p gpurun_out/$R
 if [ "$PART" = a ]; then
