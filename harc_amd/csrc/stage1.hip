@@ -307,11 +307,11 @@ __global__ void k_bin_starts(const uint32_t *head, const uint32_t *binidx, uint3
     if (i == n - 1) *nbins = binidx[i] + head[i];
 }
 #define HARC_LARGEBIN 16u    // stage-I bins with more reads than this are compacted between super-rounds (k_compact_bins)
-#define HARC_STEP_CAP 6     // schedule: a STEP that has made this many probes into such bins without a hit is put off -- the walk ends in front of it, and the next
+#define HARC_STEP_CAP 12    // schedule: a STEP that has made this many probes into such bins without a hit is put off -- the walk ends in front of it, and the next
                              // super-round takes the step up again behind the probes already made (they found nothing against fewer claims; ChainHdr.flags >> 16)
 #define HARC_BO_FREE 1u      // schedule (repeat-rich input with more than 16 384 chains only; oracle: BO_FREE / BO_CAP): in the end phase of such an input every chain walks towards the
 #define HARC_BO_CAP 3u       // same few reads and nine walks in ten are cut (profiles/r05/phantom_bids.txt); a chain whose walks keep being cut sits out 0, 1, 3, 7, 7 ... super-rounds
-#define HARC_SCAN_BUDGET 8   // schedule: a walk ends after the step in which the probes it made into such bins (still holding unclaimed reads) reach this number
+#define HARC_SCAN_BUDGET 12  // schedule: a walk ends after the step in which the probes it made into such bins (still holding unclaimed reads) reach this number
 // The table is probed bucket by bucket (64 B = 4 slots); a search that finds a full bucket WITHOUT the overflow flag can stop.
 // The reads arrive sorted by scrambled key, so the bins arrive in bucket order (bucket_slot is monotone): the slot of bin i is
 // max(4 * bucket_i, slot_{i-1} + 1) -- the linear-probing invariant -- i.e. an inclusive max-scan of (4 * bucket_i - i), plus i.
@@ -739,7 +739,8 @@ template <int W> struct StepsLds {
 #define HARC_WGCMD_BYTES 3584          // >= sizeof(WgCmd), checked where the struct is defined
 #define HARC_SK_E 4                    // wg_scan_sk: bin entries per lane and round trip (their 8-byte sketches fill the registers ONE whole read took)
 #ifndef HARC_SCAN_SKETCH
-#define HARC_SCAN_SKETCH 1             // the cooperative kernel scans large bins by sketch (wg_scan_sk); 0 (make variant): whole reads, 64 entries per wave and trip (wg_scan)
+#define HARC_SCAN_SKETCH 1             // the cooperative kernel in its ONE-wave form (many walks per super-round) scans large bins by sketch (wg_scan_sk); with 2 / 4 waves per walk, and with 0
+                                       // (make variant) always: whole reads, 64 entries per wave and trip (wg_scan) -- measured: c2d 68.0 against 59.7 Mreads/s, c2r 50.6 / 47.4 with four waves
 #endif
 // the reads a chain has taken in the running super-round (they are not in the frozen claim bitmap yet), as a hash table in LDS: 128 slots per wave for
 // at most 64 of them.  The wave-uniform scan weeds them out of its candidates by all lanes at once; walking the wave's register copy with
@@ -1452,7 +1453,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
         for (;;) {
             __syncthreads();
             if (cmd->op == 0) break;
-            const WgResult r = HARC_SCAN_SKETCH ? wg_scan_sk<W, NWV>(cmd, role, lane, idp, s.mirror, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh)
+            const WgResult r = (HARC_SCAN_SKETCH && NWV == 1) ? wg_scan_sk<W, NWV>(cmd, role, lane, idp, s.mirror, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh)
                                                 : wg_scan<W, NWV>(cmd, role, lane, idp, s.mirror, s_rows, s_mask, s_rdl, s.maxsearch, s.maxmatch, s.thresh);
             hnc += r.nc;
 #ifdef HARC_SKETCH_STATS
@@ -1901,7 +1902,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
                     }
                     __syncthreads();                                           // the helpers start
                     const uint32_t *const idp[2] = { s.ids[0], s.ids[1] };
-                    const WgResult wr = HARC_SCAN_SKETCH ? wg_scan_sk<W, NWV>(cmd, 0, lane, idp, s.mirror, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh)
+                    const WgResult wr = (HARC_SCAN_SKETCH && NWV == 1) ? wg_scan_sk<W, NWV>(cmd, 0, lane, idp, s.mirror, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh)
                                                          : wg_scan<W, NWV>(cmd, 0, lane, idp, s.mirror, rowF, s_mask, rdl, s.maxsearch, s.maxmatch, s.thresh);
                     dbg_iter += wr.iters; dbg_surv += wr.tests; nc += wr.nc; ncu += wr.nc;
 #ifdef HARC_SKETCH_STATS

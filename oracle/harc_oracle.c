@@ -40,11 +40,11 @@
 #define NSUGG 8           /* look-ahead seeds handed to a chain at every reseed */
 #define LOOK_CHUNKS 16     /* the look-ahead inspects at most this many chunks of 1024 64-bit bitmap words below the cursor (the GPU's k_reseed) */
 #define LARGEBIN 16u      /* HARC_LARGEBIN of harc_amd/csrc/stage1.hip */
-#define STEP_CAP 6        /* HARC_STEP_CAP: a step that has made this many probes into such bins without a hit is put off: the walk ends in front of it and the
+#define STEP_CAP 12       /* HARC_STEP_CAP: a step that has made this many probes into such bins without a hit is put off: the walk ends in front of it and the
                               next super-round takes the step up again BEHIND the probes already made (they found nothing against fewer claims) */
 #define BO_FREE 1          /* HARC_BO_FREE / HARC_BO_CAP of stage1.hip: on repeat-rich input with more than 16 384 chains a chain whose walk was cut at a lost bid */
 #define BO_CAP 3           /* sits out 2^(k - BO_FREE) - 1 super-rounds, k = its cuts in a row, at most BO_FREE + BO_CAP (0, 1, 3, 7, 7 ... rounds) */
-#define SCAN_BUDGET 8      /* HARC_SCAN_BUDGET: a walk ends after the step in which its probes into bins of more than LARGEBIN reads (not yet exhausted) reach this number */
+#define SCAN_BUDGET 12     /* HARC_SCAN_BUDGET: a walk ends after the step in which its probes into bins of more than LARGEBIN reads (not yet exhausted) reach this number */
 
 /* ------------------------------------------------------------------ parameters (harc:52-60) */
 typedef struct {
