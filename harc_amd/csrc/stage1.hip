@@ -2023,6 +2023,7 @@ template <int W, bool QUAD, bool COOP, bool DENSE = false, int NWV = 4, bool SEQ
     }
 #endif
     if (COOP && lane == 0 && s.dbg) { const unsigned long long dt = (unsigned long long)(wall_clock64() - dbg_t0); atomicAdd(&s.dbg[9], 1ULL); atomicAdd(&s.dbg[10], dt); atomicMax(&s.dbg[11], dt); atomicAdd(&s.dbg[12], (unsigned long long)(nst)); }
+    if (!COOP && lane == 0 && s.dbg) { atomicAdd(&s.dbg[13], 1ULL); if (defer) atomicAdd(&s.dbg[15], 1ULL); if (defer && nst == 0) atomicAdd(&s.dbg[14], 1ULL); }      // trace: walks of the main kernel; those that end in front of a large bin; of them, without a step
     if (lane == 0 && s.dbg) { atomicAdd(&s.dbg[0], (unsigned long long)dbg_bins); atomicAdd(&s.dbg[1], (unsigned long long)dbg_iter); atomicAdd(&s.dbg[2], (unsigned long long)dbg_miss); atomicAdd(&s.dbg[3], (unsigned long long)dbg_surv); atomicAdd(&s.dbg[4], (unsigned long long)nst); atomicAdd(&s.dbg[5], (unsigned long long)dbg_batches); atomicMax(&s.dbg[6], (unsigned long long)dbg_iter); atomicMax(&s.dbg[7], (unsigned long long)dbg_surv); atomicMax(&s.dbg[8], (unsigned long long)dbg_bins); }
     if (lane == 0) {
         if (COOP) { atomicAdd(&s.cstat_coop[c].x, np); atomicAdd(&s.cstat_coop[c].y, nc); atomicAdd(&s.cstat_coop[c].z, nuse); atomicAdd(&s.cstat_coop[c].w, ncu); s.csteps[c].y += (uint32_t)nst; }   // the helpers add to it too
@@ -3429,6 +3430,8 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
         const double stp = (double)(d[4] ? d[4] : 1);
         fprintf(stderr, "[k_steps] steps walked %llu (of them kept %u): per step batches %.2f, cooperative bin scans %.2f, their 64-entry chunks %.2f, chunk x probe tests %.2f; steps without a hit %.3f\n", d[4], N, d[5] / stp, d[0] / stp, d[1] / stp, d[3] / stp, d[2] / stp);
         fprintf(stderr, "[k_steps] worst walk of the run: %llu chunks, %llu chunk x probe tests, %llu bin scans\n", d[6], d[7], d[8]);
+        fprintf(stderr, "[k_steps] walks of the main kernel: %llu (%.0f per super-round); %llu of them end in front of a large bin (%.1f %%), %llu of those without a step walked (%.1f %% of all walks)\n",
+                d[13], (double)d[13] / (double)(rounds ? rounds : 1), d[15], 100.0 * (double)d[15] / (double)(d[13] ? d[13] : 1), d[14], 100.0 * (double)d[14] / (double)(d[13] ? d[13] : 1));
         if (d[9]) fprintf(stderr, "[k_steps] cooperative walks: %llu (%.1f per super-round), %.2f steps each, mean %.1f us, longest %.1f us (100 MHz wall clock)\n",
                           d[9], (double)d[9] / (double)(rounds ? rounds : 1), (double)d[12] / (double)d[9], (double)d[10] / (double)d[9] / 100.0, (double)d[11] / 100.0);
         if (d[9] && d[16]) {                                         // -DHARC_COOP_TRACE builds

@@ -267,13 +267,17 @@ struct FileDrain {
     std::mutex mu; std::condition_variable cv_free, cv_job, cv_idle;
     std::deque<int> free_slices; std::deque<Job> jobs; int busy = 0; bool stop = false;
     std::vector<std::thread> th;
+    // the file's blocks are ALLOCATED ahead of the writers by a thread of its own (posix_fallocate, 64 MB at a time): a store into a mapping of a sparse file on a full
+    // file system is a SIGBUS, not an error code -- this way "no space left" is an error of the call, as it was with fwrite
+    std::thread alloc_th; std::condition_variable cv_alloc; uint64_t alloc_upto = 0; int alloc_err = 0;
+    std::string fname;
     explicit FileDrain(harc_amd_ctx *c_) : c(c_) {}
     ~FileDrain() { (void)finish(); }
     int start(const std::string &path, size_t bytes)
     {
         fd = open(path.c_str(), O_CREAT | O_RDWR | O_TRUNC, 0644);
         if (fd < 0) { harc_set_error("cannot create %s", path.c_str()); return HARC_AMD_EIO; }
-        fsize = bytes;
+        fsize = bytes; fname = path;
         if (bytes) {
             if (ftruncate(fd, (off_t)bytes) != 0) { harc_set_error("cannot size %s to %zu bytes", path.c_str(), bytes); return HARC_AMD_EIO; }
             map = (char *)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
@@ -290,6 +294,20 @@ struct FileDrain {
         }
         ev.assign(NS, nullptr);
         for (int k = 0; k < NS; k++) { if (hipEventCreate(&ev[k]) != hipSuccess) { harc_set_error("hipEventCreate failed"); return HARC_AMD_ENODEVICE; } free_slices.push_back(k); }
+        alloc_th = std::thread([this] {
+            const uint64_t STEP = (uint64_t)64 << 20;
+            for (uint64_t a = 0; a < (uint64_t)fsize; a += STEP) {
+                const uint64_t len = (uint64_t)fsize - a < STEP ? (uint64_t)fsize - a : STEP;
+                const int e = posix_fallocate(fd, (off_t)a, (off_t)len);
+                std::lock_guard<std::mutex> lk(mu);
+                if (e == EOPNOTSUPP || e == EINVAL) { alloc_upto = (uint64_t)fsize; break; }      // a file system without preallocation: as before this round
+                if (e) { alloc_err = e; break; }
+                alloc_upto = a + len;
+                cv_alloc.notify_all();
+                if (stop) break;
+            }
+            cv_alloc.notify_all();
+        });
         const int dev = c->P.device;
         for (int t = 0; t < nthr; t++) th.emplace_back([this, dev] {
             (void)hipSetDevice(dev);
@@ -302,7 +320,9 @@ struct FileDrain {
                     j = jobs.front(); jobs.pop_front(); busy++;
                 }
                 (void)hipEventSynchronize(ev[j.sl]);              // the slice has arrived
-                memcpy(map + j.off, c->feed_ring + (size_t)j.sl * SL, j.len);
+                bool space;
+                { std::unique_lock<std::mutex> lk(mu); cv_alloc.wait(lk, [&] { return alloc_err != 0 || alloc_upto >= j.off + j.len; }); space = alloc_err == 0; }
+                if (space) memcpy(map + j.off, c->feed_ring + (size_t)j.sl * SL, j.len);
                 { std::lock_guard<std::mutex> lk(mu); busy--; free_slices.push_back(j.sl); }
                 cv_free.notify_one(); cv_idle.notify_all();
             }
@@ -327,7 +347,10 @@ struct FileDrain {
     int put_host(const void *h, size_t n, uint64_t off)
     {
         if (off + n > fsize) { harc_set_error("output file: %zu bytes at %llu do not fit its %zu bytes", n, (unsigned long long)off, fsize); return HARC_AMD_EINTERNAL; }
-        if (n) memcpy(map + off, h, n);
+        if (n) {
+            { std::unique_lock<std::mutex> lk(mu); cv_alloc.wait(lk, [&] { return alloc_err != 0 || alloc_upto >= off + n; }); if (alloc_err) return HARC_AMD_OK; }      // (finish() reports it)
+            memcpy(map + off, h, n);
+        }
         return HARC_AMD_OK;
     }
     int finish()
@@ -338,10 +361,12 @@ struct FileDrain {
             for (auto &t : th) t.join();
             th.clear();
         }
+        if (alloc_th.joinable()) alloc_th.join();
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
         ev.clear();
         if (map) { munmap(map, fsize); map = nullptr; }
         if (fd >= 0) { close(fd); fd = -1; }
+        if (alloc_err) { harc_set_error("cannot allocate %zu bytes for %s: %s", fsize, fname.c_str(), strerror(alloc_err)); const int e = alloc_err; alloc_err = 0; (void)e; return HARC_AMD_EIO; }
         return HARC_AMD_OK;
     }
 };
