@@ -940,13 +940,14 @@ def main():
         out["other_configs"] = {}
         t_other = time.perf_counter()
         # (round 6: c3r first -- configs[2] on a genome with a human-like repeat content, the input shape of the real configs[1] / [3]; one warm-up + ONE timed
-        #  step of ~2.3 s, so that the repeat-bearing rate is the driver's number too and not only the builder's)
-        for name in ("c3r", "c4", "c5g"):
+        #  step of ~1.9 s, so that the repeat-bearing rate is the driver's number too and not only the builder's; behind them the two small configurations, configs[1]'s
+        #  and configs[0]'s stand-ins, ten steps of 16 / 8 ms each)
+        for name in ("c3r", "c4", "c5g", "c2", "c1"):
             if time.perf_counter() - t_other > 150.0:            # the side lines took long on this box: the line must not
                 out["other_configs"][name] = {"skipped": "wall-time bound of the side lines reached"}
                 continue
             try:
-                out["other_configs"][name] = run_other_config(harc_amd, name, local, dev, args.shards, steps=1 if name == "c3r" else 2)
+                out["other_configs"][name] = run_other_config(harc_amd, name, local, dev, args.shards, steps=1 if name == "c3r" else 10 if name in ("c1", "c2") else 2)
             except Exception as e:                                # a side line never takes the main line down
                 out["other_configs"][name] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()

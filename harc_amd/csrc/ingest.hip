@@ -631,7 +631,8 @@ struct FileFeeder {
         // a read() of page-cache pages that nobody has read yet marks every one of them accessed (LRU lists, under a lock the readers share): the first read of
         // a freshly written 21.7-GB file ran at 14-24 GB/s with 16 readers, the second at 54.  Copies out of a shared mapping do not go that way -- but ONE
         // mapping of the whole file took 0.8 s to take down again (the same marking, at unmap, by one thread): every reader maps its own slice, tells the kernel
-        // that it reads it once from front to back (no recency kept for such a mapping), copies and unmaps.  HARC_AMD_FEED_MMAP=0: pread.
+        // that it reads it once from front to back (no recency kept for such a mapping), copies and unmaps.  HARC_AMD_FEED_MMAP=0: pread -- the way to read a file
+        // that somebody may TRUNCATE meanwhile: a copy out of a mapping beyond the new end of the file is a SIGBUS, not a short read.
         use_mmap = !(getenv("HARC_AMD_FEED_MMAP") && atoi(getenv("HARC_AMD_FEED_MMAP")) == 0);
         const double t_ring0 = mono_now();
         if (c->feed_ring_bytes < SL * (size_t)NS) {

@@ -2993,10 +2993,12 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     }
     // Low coverage: almost every read has its k-mer to itself (distinct k-mers / reads = (1 - e^-x) / x with x reads per genome position:
     // 0.986 at 2.9x, 0.95 at 11x, 0.77 at 52x).  There chains cost next to nothing in compressed size (configs[0] stand-in: 1.003 of the
-    // reference's -t 8 with twice the chains) and a small input leaves the chip idle: up to 4096 chains of at least 512 reads.  At 52x the
-    // same would cost 21 % (measured), so the rule asks the index.
+    // reference's -t 8 with twice the chains) and a small input leaves the chip idle: up to 4096 chains of at least 256 reads (round 6; 512 before: configs[0]'s
+    // stand-in 96 -> 119 Mreads/s with 3906 instead of 1953 chains -- 56 -> 32 super-rounds of a kernel whose launch lasts as long as one wave's 16 steps --
+    // for 1.0050 instead of 1.0026 of the reference's -t 8 in xz bytes).  At 52x the same costs 6 % (configs[1]'s stand-in with 4096 chains: 274 instead of
+    // 202 Mreads/s, 1.030 instead of 0.968 of the reference's size: not taken), so the rule asks the index.
     if (N && P.num_chains <= 0 && P.reads_per_chain <= 0 && (double)dict[0].nbins > 0.98 * (double)N) {
-        const uint32_t k2 = N / 512 < 4096 ? N / 512 : 4096;
+        const uint32_t k2 = N / 256 < 4096 ? N / 256 : 4096;
         if (k2 > K) { K = k2; c->C.chains = K; if (!getenv("HARC_AMD_QUAD")) quad = K <= 16384; }
     }
     // bins large enough to be worth compacting between super-rounds were listed by k_table_insert (none on ordinary data)

@@ -165,7 +165,7 @@ def reads_text_hugebin_stage1(seed, n_core=9000, n_norm=6000, L=100, genome_len=
 def auto_chains(n_clean, reads_per_chain=2048, clean=None):
     """auto_chains() of harc_amd/csrc/stage1.hip: K when harc_amd_params.num_chains = 0.  clean: the clean reads ([n, L] uint8 array or
     the lines of input_clean.dna) for the low-coverage rule of stage1_run_w -- more than 98 % distinct first-dictionary k-mers: up to
-    4096 chains of at least 512 reads"""
+    4096 chains of at least 256 reads"""
     k = n_clean // reads_per_chain
     k = max(k, min(2048, n_clean // 1024))
     k = max(1, min(k, 65536))
@@ -178,5 +178,5 @@ def auto_chains(n_clean, reads_per_chain=2048, clean=None):
         de = L // 2 - 1
         nbins = np.unique(np.ascontiguousarray(clean[:, ds:de + 1]), axis=0).shape[0]
         if nbins > 0.98 * n_clean:
-            k = max(k, min(4096, n_clean // 512))
+            k = max(k, min(4096, n_clean // 256))
     return k
