@@ -2903,8 +2903,9 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
     // it.  No count taken DURING the run tells such an input early enough (the share of walks that end at a lost bid is 0.4 % after 16 rounds there as on
     // clean data, 20 % only after a thousand: profiles/r05/s_choice_trace.txt), so the choice is made from the index, below: 32 only where the bins of more
     // than HARC_LARGEBIN reads hold less than 2 % of N entries (clean inputs: none), 16 otherwise.  A function of the input alone, like the chain count.
-    const bool steps_auto32 = P.num_steps <= 0 && K > 16384;     // (a function of the input alone: no environment variable changes S -- k_steps_grp walks at most 16 steps and leaves S = 32 to k_steps)
-    if (steps_auto32) nsteps = 32;
+    // Round 6: also from 2048 chains on where the input is NOT a low-coverage one (the index again: at most 98 % of the reads alone in their first-dictionary bin) -- configs[1]'s
+    // stand-in (3.3 M reads at 52x, 2048 chains) 203-206 -> 216-220 Mreads/s with fewer contigs; configs[0]'s (2.9x, where a walk needs a new seed every few reads) would lose 7 %.
+    // Decided below, once the index is there.  (A function of the input alone: no environment variable changes S -- k_steps_grp walks at most 16 steps and leaves S = 32 to k_steps.)
     if (nsteps > 64) nsteps = 64;
     // few chains -> every launch is a chain of dependent HBM round trips: fetch whole buckets; many chains -> request-rate bound: single slots
     bool quad = K <= 16384;
@@ -3033,7 +3034,10 @@ template <int W> static int stage1_run_w(harc_amd_ctx *c)
                            (const uint32_t *)dict[0].ids, (const uint32_t *)dict[1].ids, (const uint64_t *)moff, (const uint64_t *)c->d_reads, d_largetab, d_mirror);
         HIP_TRY(hipGetLastError());
     }
-    if (steps_auto32 && large_entries * 50 > (uint64_t)N) nsteps = 16;      // (see steps_auto32 above)
+    if (P.num_steps <= 0 && K > 1) {                              // (see above)
+        const bool lowcov = N && (double)dict[0].nbins > 0.98 * (double)N;
+        nsteps = ((K > 16384 || (K >= 2048 && !lowcov)) && large_entries * 50 <= (uint64_t)N) ? 32 : 16;
+    }
     const bool backoff = K > 16384 && large_entries * 50 > (uint64_t)N;      // the same inputs: chains that keep losing bids sit rounds out (HARC_BO_FREE)
     if (getenv("HARC_AMD_TRACE")) fprintf(stderr, "[stage I] %u bins of more than %u reads hold %llu entries (%.2f %% of the reads): %d steps per super-round\n", nlarge, HARC_LARGEBIN,
                                           (unsigned long long)large_entries, N ? 100.0 * (double)large_entries / (double)N : 0.0, nsteps);

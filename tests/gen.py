@@ -180,3 +180,34 @@ def auto_chains(n_clean, reads_per_chain=2048, clean=None):
         if nbins > 0.98 * n_clean:
             k = max(k, min(4096, n_clean // 256))
     return k
+
+
+def _clean_array(clean):
+    if isinstance(clean, (bytes, bytearray)):
+        rows = [l for l in bytes(clean).split(b"\n") if l and b"N" not in l]
+        return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), -1)
+    return clean
+
+
+def auto_steps(clean, K):
+    """steps per super-round when harc_amd_params.num_steps = 0 (stage1_run_w): 64 for one chain; 32 with more than 16 384 chains, or from 2048 chains on an input
+    that is not a low-coverage one (at most 98 % distinct first-dictionary k-mers) -- in both cases only where the bins of more than 16 reads of the two
+    dictionaries hold at most 2 % of N entries; 16 otherwise.  clean: the clean reads ([n, L] uint8 array or the lines of input_clean.dna)"""
+    if K == 1:
+        return 64
+    a = _clean_array(clean)
+    n, L = a.shape
+    if n == 0:
+        return 16
+    w = 32 if L >= 100 else L * 32 // 100
+    d1 = (L // 2 - w, L // 2 - 1)                                  # harc:57-60
+    d2 = (L // 2, L // 2 + w - 1)
+    large = 0
+    nb1 = 0
+    for k, (ds, de) in enumerate((d1, d2)):
+        _, cnt = np.unique(np.ascontiguousarray(a[:, ds:de + 1]), axis=0, return_counts=True)
+        if k == 0:
+            nb1 = cnt.shape[0]
+        large += int(cnt[cnt > 16].sum())
+    lowcov = nb1 > 0.98 * n
+    return 32 if (K > 16384 or (K >= 2048 and not lowcov)) and large * 50 <= n else 16

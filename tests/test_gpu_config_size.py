@@ -57,12 +57,14 @@ def test_config_size_matches_oracle(name, n, L, G, err, E, expect_lowcov, env, o
     K_plain = gen.auto_chains(nclean)
     K = gen.auto_chains(nclean, clean=inputs["input_clean.dna"])
     assert (K > K_plain) == expect_lowcov, (K, K_plain)               # configs[0]: the low-coverage rule must be what decides K
-    assert oracle.harc_oracle_reorder(bo.encode(), L, K, 16, None, None) == 0
+    S = gen.auto_steps(inputs["input_clean.dna"], K)                  # ... and of S: 32 at configs[1] (2048 chains, not a low-coverage input, no large bins), 16 at configs[0]
+    assert S == (16 if expect_lowcov else 32), S
+    assert oracle.harc_oracle_reorder(bo.encode(), L, K, S, None, None) == 0
     s1 = ol.read_dir(bo)
     assert oracle.harc_oracle_encoder(bo.encode(), L, E, None, None) == 0
     s2 = ol.read_dir(bo)
     bg = ol.stage_dir(tmp_path / "g", {k: inputs[k] for k in ["input_clean.dna", "numreads.bin", "input_N.dna"]})
-    harc_amd.reorder(bg, L, num_chains=0)                              # the library's own choice of K
+    harc_amd.reorder(bg, L, num_chains=0)                              # the library's own choice of K and S
     g1 = ol.read_dir(bg)
     bad = [f for f in ol.STAGE1_FILES if g1.get(f) != s1[f]]
     assert not bad, f"{name}: stage I differs from the oracle (K = {K}): {bad}"
