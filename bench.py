@@ -624,7 +624,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("HARC_BENCH_WORKLOAD", "c3"))
     ap.add_argument("--chains", type=int, default=0)
-    ap.add_argument("--super-steps", type=int, default=0, help="steps per super-round (num_steps; 0 = the library's choice: 16; 64 for one chain; 32 from 16 385 chains on where the index holds next to no large bins)")
+    ap.add_argument("--super-steps", type=int, default=0, help="steps per super-round (num_steps; 0 = the library's choice: 16; 64 for one chain; 32 from 16 385 chains on, and from 2048 chains on inputs that are not low-coverage ones, where the index holds next to no large bins)")
     ap.add_argument("--shards", type=int, default=8, help="num_thr of the reference = encoder shards per GPU (harc:195 default 8)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (reference baseline, size comparison) and the exact-mode sample")
     ap.add_argument("--no-prime", action="store_true", help="with --warmup 0: do NOT make the untimed pass that allocates the context's device pool and pinned buffers (the first timed step then pays for them: cold-start numbers)")
