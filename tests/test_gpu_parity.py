@@ -594,6 +594,46 @@ def test_fastq_ingest_on_gpu_matches_reference(case, tmp_path):
     assert_same(got, {f: g["stage2/" + f] for f in fs}, fs, f"{case}: FASTQ -> streams vs reference")
 
 
+def test_fastq_file_through_the_feeder_and_the_drain_at_their_real_slice_sizes(oracle, tmp_path):
+    """2.5 M reads (a 540-MB FASTQ: nine 64-MB slices of the ingest's pinned ring, sixteen reader threads, default settings): the stream files of
+    harc_amd_compress_fastq_files_ex are those of the same library fed with the ORACLE's preprocess files (preprocess.cpp:81-121 restated on the CPU), byte for byte,
+    and the decoder's output.dna (through the drain: 250 MB, four slices, sixteen writers into a preallocated mapping) holds exactly the reads written"""
+    import numpy as np
+    import harc_amd
+    n, L, E = 2_500_000, 100, 4
+    arr = gen.reads_array_big(77, n, L, 10_000_000, err=0.004)
+    rec = np.empty((n, 2 * L + 17), dtype=np.uint8)
+    rec[:, 0:3] = np.frombuffer(b"@T.", dtype=np.uint8)
+    idx = np.arange(n)
+    for k in range(9):
+        rec[:, 3 + k] = (idx // 10 ** (8 - k)) % 10 + 48
+    rec[:, 12] = 10; rec[:, 13:13 + L] = arr; rec[:, 13 + L] = 10; rec[:, 14 + L] = ord("+"); rec[:, 15 + L] = 10
+    rec[:, 16 + L:16 + 2 * L] = ord("H"); rec[:, 16 + 2 * L] = 10
+    root = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    import shutil, tempfile
+    d = tempfile.mkdtemp(dir=root, prefix="harc_test_e2e_")
+    try:
+        fq = os.path.join(d, "x.fastq")
+        rec.tofile(fq)
+        del rec
+        a = os.path.join(d, "a"); b = os.path.join(d, "b")
+        os.makedirs(os.path.join(a, "output")); os.makedirs(os.path.join(b, "output"))
+        harc_amd.compress_fastq(fq, a, L, num_thr=E, num_chains=0)
+        lines = gen.lines_of(arr)
+        assert oracle.harc_oracle_preprocess(lines, len(lines), L, b.encode()) == 0
+        harc_amd.compress(b, L, num_thr=E, num_chains=0)
+        ga, gb = ol.read_dir(a), ol.read_dir(b)
+        fs = ol.stage2_files(E) + ["numreads.bin", "read_order_N.bin"]
+        assert_same(ga, gb, fs, "FASTQ file -> streams vs the oracle's preprocess files -> streams")
+        harc_amd.decoder(a, E)
+        out = np.fromfile(os.path.join(a, "output", "output.dna"), dtype=np.uint8).reshape(-1, L + 1)
+        assert out.shape[0] == n and bool((out[:, L] == 10).all())
+        v = np.dtype((np.void, L))
+        assert np.array_equal(np.sort(np.ascontiguousarray(out[:, :L]).view(v).ravel()), np.sort(np.ascontiguousarray(arr).view(v).ravel()))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def test_fastq_ingest_edge_cases(tmp_path):
     import harc_amd
     base = ol.stage_dir(tmp_path, {})
