@@ -30,7 +30,13 @@ static inline dim3 wave_grid(uint32_t n) { if (n <= (1u << 25)) return dim3(n ? 
 __device__ __forceinline__ uint64_t harc_bid() { return (uint64_t)blockIdx.y * gridDim.x + blockIdx.x; }
 __device__ __forceinline__ uint64_t harc_gid() { return ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; }
 // ... for an item count that is a 32-bit number: 0xFFFFFFFF -- beyond every such count's last item -- for the threads of a second row past it
-__device__ __forceinline__ uint32_t harc_gid32() { const uint64_t g = harc_gid(); return g > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)g; }
+__device__ __forceinline__ uint32_t harc_gid32()
+{
+    // one row -- every launch of fewer than 2^32 - 256 items --: at most HARC_GRID_ROW x 256 + 255 < 2^32, a wave-uniform branch.  (Without it the 64-bit index and its
+    // saturation cost the streaming kernels of the index build 2.7 ms per configs[2] step: k_bin_starts 916 -> 1061 us, k_s1_bloom_keys 1205 -> 1571 us.)
+    if (gridDim.y == 1) return blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t g = harc_gid(); return g > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)g;
+}
 
 // ------------------------------------------------------------------------------------------------ device helpers
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
