@@ -59,10 +59,12 @@ typedef struct harc_amd_params {
     int32_t device;           /* HIP device ordinal */
     int32_t profile;          /* 1: time every launch of the dominant kernel with HIP events on the context's stream */
     int32_t num_steps;        /* S: speculative chain steps per launch of the chain kernel (1..64; 0 = auto: 16; 64 for one chain; 32 from
-                                 16 385 chains on where the index's bins of more than 16 reads hold less than 2 % of N entries -- a function
-                                 of the input alone).  Output is independent of S when num_chains = 1; for num_chains > 1 the pair (K,S)
-                                 defines the schedule */
-    int32_t reads_per_chain;  /* auto mode (num_chains = 0): one chain per this many reads, capped at 65536 chains; 0 = 2048.  Inputs that are
+                                 16 385 chains on -- and from 2048 chains on where the input is not a low-coverage one (at most 98 % of the reads
+                                 alone in their first-dictionary bin) -- where the index's bins of more than 16 reads hold at most 2 % of N
+                                 entries: a function of the input alone).  Output is independent of S when num_chains = 1; for num_chains > 1
+                                 the pair (K,S) defines the schedule */
+    int32_t reads_per_chain;  /* auto mode (num_chains = 0): one chain per this many reads, capped at 65536 chains; 0 = 2048 (inputs below 4 M reads:
+                                 up to 2048 chains of at least 1024 reads; low-coverage ones up to 4096 of at least 256).  Inputs that are
                                  already fragmented (one minimizer bucket of a multi-GPU shard) lose nothing with 1024 and run faster. */
     int32_t decode_memory_gb; /* -m of `./harc -d -p` (harc:225, MAX_BIN_SIZE of decoder_preserve.cpp:249-253): the original order is restored in bins of
                                  decode_memory_gb * 2e8 / 7 reads (0 = the driver's default 7; <= 3 counts as 3), and never more than fits in HBM */
