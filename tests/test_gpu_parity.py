@@ -229,11 +229,11 @@ def test_huge_bin_compacted_from_its_top_matches_oracle(K, S, oracle, tmp_path):
     assert_same(ol.read_dir(base), s2, ol.stage2_files(2), "huge-bin stage II vs oracle")
 
 
-@pytest.mark.parametrize("n", [1, 255, 1 << 20, (1 << 32) - 256, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, 39_000_000 * 256, 10_100_000_000, (1 << 34) + 12345])
+@pytest.mark.parametrize("n", [1, 255, 1 << 20, (1 << 32) - 256, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, 39_000_000 * 256, (1 << 33) + 12345])
 def test_launches_of_more_than_2_32_work_items_visit_every_item(n):
     """a grid is dispatched with its size in work-items as a 32-bit number per dimension: 2^32 and more is taken modulo 2^32 WITHOUT an error
     (tools/micro/grid_limit.hip).  The library's thread-per-item launches fold their workgroups into rows (devutil.h harc_grid256 / harc_gid): every item
-    is visited exactly once whatever n -- found when 402 M probes into stage II's large bins (x 64 lanes) were cut short and the window passes ended early"""
+    is visited exactly once whatever n, through all three geometries of the library (harc_gid, harc_gid32, folded workgroups of four lanes per item) -- found when 402 M probes into stage II's large bins (x 64 lanes) were cut short and the window passes ended early"""
     import harc_amd
     h = harc_amd.HarcAmd(harc_amd.default_params(100))
     try:
